@@ -1,0 +1,158 @@
+/* zkmi.h -- C ABI of libzkmi.so: the MI355X (gfx950) BN254 proving hot path.
+ *
+ * This is the drop-in boundary for the ONE path this repository replaces inside
+ * lambdaclass/noir_backend_using_gnark: the gnark-crypto calls that gnark's provers make
+ *     (*G1Jac).MultiExp / (*G2Jac).MultiExp      ecc/bn254/multiexp.go          (Pippenger MSM)
+ *     (*fft.Domain).FFT / FFTInverse / BitReverse ecc/bn254/fr/fft/fft.go        (radix-2 NTT over Fr)
+ *     computeH + the 5 MSMs of groth16.Prove      gnark internal/backend/bn254/groth16/prove.go
+ *     kzg.Commit (= one G1 MSM)                   ecc/bn254/fr/kzg/kzg.go
+ * The reference pins those modules at /root/reference/gnark_backend_ffi/go.mod:5 (gnark-crypto v0.9.1) and
+ * go.mod:23 (gnark v0.8.0) and reaches them ONLY through
+ *     groth16.Prove   /root/reference/gnark_backend_ffi/main.go:131
+ *     plonk.Prove     /root/reference/gnark_backend_ffi/backend/plonk/plonk.go:67
+ *     plonk.Setup     /root/reference/gnark_backend_ffi/backend/plonk/plonk.go:21
+ *     kzg.NewSRS      /root/reference/gnark_backend_ffi/backend/common.go:137
+ * (there is no direct MultiExp / fft call site in the reference: SURVEY.md §0 fact 2).  INTEGRATION.md shows the
+ * cgo stubs that bind each entry point below at those gnark-crypto call sites; the outer Rust->Go FFI
+ * (PlonkProveWithPK & co, /root/reference/gnark_backend_ffi/main.go:24-78) is untouched by construction.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is valid for the duration of the call only (cgo rule: C must not retain Go
+ *    pointers) unless the function name ends in _dev, in which case the pointer is a HIP device pointer owned by
+ *    the caller.
+ *  - field elements are gnark-crypto's memory image: uint64_t[4], little-endian limbs, Montgomery form
+ *    (x * 2^256 mod p).  G1Affine = {X, Y}; G2Affine = {X.A0, X.A1, Y.A0, Y.A1}; the point at infinity is (0,0).
+ *  - results that are points are AFFINE (canonical); the Go shim calls FromAffine to satisfy *G1Jac.
+ *  - return value: 0 = ok, negative = zk_status error; zk_last_error() gives a thread-local message.
+ *  - thread-safe and re-entrant: gnark issues its MSMs from several goroutines; each call picks a stream slot.
+ *  - there is NO CPU fallback: without a usable HIP device every compute entry point returns ZK_ERR_NO_DEVICE.
+ */
+#ifndef ZKMI_H
+#define ZKMI_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } zk_fr;                 /* fr.Element  (go.mod:5 ecc/bn254/fr)  */
+typedef struct { uint64_t l[4]; } zk_fp;                 /* fp.Element  (go.mod:5 ecc/bn254/fp)  */
+typedef struct { zk_fp x, y; } zk_g1_affine;             /* bn254.G1Affine */
+typedef struct { zk_fp x0, x1, y0, y1; } zk_g2_affine;   /* bn254.G2Affine {X E2{A0,A1}, Y E2{A0,A1}} */
+
+typedef enum {
+    ZK_OK = 0,
+    ZK_ERR_LEN = -1,        /* MultiExp: "len(points) != len(scalars)" */
+    ZK_ERR_NB_TASKS = -2,   /* MultiExp: "invalid config: config.NbTasks > 1024" */
+    ZK_ERR_NO_DEVICE = -3,  /* no usable gfx950 device / HIP runtime -- never falls back to the CPU */
+    ZK_ERR_HIP = -4,        /* a HIP call failed; see zk_last_error() */
+    ZK_ERR_ARG = -5,        /* bad argument (null pointer, size not a power of two, log_n > 28, ...) */
+    ZK_ERR_HANDLE = -6      /* unknown or freed handle */
+} zk_status;
+
+/* mirrors ecc.MultiExpConfig{NbTasks, ScalarsMont} of gnark-crypto v0.9.1, plus device-side knobs */
+typedef struct {
+    int nb_tasks;      /* accepted for compatibility; > 1024 is rejected like upstream; otherwise ignored      */
+    int scalars_mont;  /* 1: scalars are Montgomery fr.Element images (gnark's default container); 0: canonical */
+    int window_bits;   /* 0 = auto (cost model for the GPU), else c in [4, 20]                                   */
+    int reserved;
+} zk_msm_cfg;
+
+enum { ZK_DIT = 0, ZK_DIF = 1 }; /* fft.Decimation (same iota order as gnark-crypto) */
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------------ */
+int zk_device_count(void);             /* number of visible HIP devices (0 if none / runtime missing)             */
+int zk_init(int device);               /* optional: bind the calling process to `device` (default: 0, lazily)     */
+const char *zk_last_error(void);
+const char *zk_version(void);
+
+/* ---- MSM: (*G1Jac).MultiExp / (*G2Jac).MultiExp ------------------------------------------------------------------
+ * out = sum_i scalars[i] * points[i].  n_points != n_scalars -> ZK_ERR_LEN (upstream error).  Host pointers. */
+int zk_bn254_g1_msm(const zk_g1_affine *points, size_t n_points, const zk_fr *scalars, size_t n_scalars,
+                    const zk_msm_cfg *cfg, zk_g1_affine *out);
+int zk_bn254_g2_msm(const zk_g2_affine *points, size_t n_points, const zk_fr *scalars, size_t n_scalars,
+                    const zk_msm_cfg *cfg, zk_g2_affine *out);
+/* Same, inputs already resident in HBM (device pointers); `stream` is a hipStream_t or NULL for the library's own. */
+int zk_bn254_g1_msm_dev(const void *d_points, const void *d_scalars, size_t n, const zk_msm_cfg *cfg,
+                        zk_g1_affine *out_host, void *stream);
+int zk_bn254_g2_msm_dev(const void *d_points, const void *d_scalars, size_t n, const zk_msm_cfg *cfg,
+                        zk_g2_affine *out_host, void *stream);
+/* Partial result for range-sharded multi-GPU MSM: the un-normalised sum as XYZZ (4 coordinates, same limb image);
+ * partials from several ranks are combined with zk_bn254_g1_sum_xyzz / zk_bn254_g2_sum_xyzz on any rank. */
+int zk_bn254_g1_msm_partial_dev(const void *d_points, const void *d_scalars, size_t n, const zk_msm_cfg *cfg,
+                                uint64_t out_xyzz[16], void *stream);
+int zk_bn254_g2_msm_partial_dev(const void *d_points, const void *d_scalars, size_t n, const zk_msm_cfg *cfg,
+                                uint64_t out_xyzz[32], void *stream);
+int zk_bn254_g1_sum_xyzz(const uint64_t *partials, size_t n_partials, zk_g1_affine *out);
+int zk_bn254_g2_sum_xyzz(const uint64_t *partials, size_t n_partials, zk_g2_affine *out);
+
+/* Resident bases (Groth16 pk.G1.{A,B,K,Z}, pk.G2.B, kzg SRS.G1): upload once, reuse for every proof. */
+int zk_bn254_bases_register(const void *points, size_t n, int is_g2, uint64_t *handle);
+int zk_bn254_bases_free(uint64_t handle);
+int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr *scalars, size_t n, const zk_msm_cfg *cfg, void *out);
+
+/* ---- NTT: (*fft.Domain).FFT / FFTInverse / fft.BitReverse ------------------------------------------------------
+ * In place on a[0 .. 2^log_n).  decimation: ZK_DIF natural in -> bit-reversed out; ZK_DIT bit-reversed in ->
+ * natural out.  coset != 0 evaluates on / interpolates from the coset g*H, g = 5 (FrMultiplicativeGen).
+ * FFTInverse also scales by 1/N exactly like upstream. */
+int zk_bn254_ntt(zk_fr *a, uint32_t log_n, int inverse, int decimation, int coset);
+int zk_bn254_ntt_dev(void *d_a, uint32_t log_n, int inverse, int decimation, int coset, void *stream);
+int zk_bn254_bit_reverse(zk_fr *a, uint32_t log_n);
+int zk_bn254_bit_reverse_dev(void *d_a, uint32_t log_n, void *stream);
+
+/* ---- Groth16: computeH and Prove (gnark v0.8.0 internal/backend/bn254/groth16/prove.go) -------------------------
+ * computeH: a, b, c hold n <= 2^log_N evaluations each; h_out receives 2^log_N coefficients in the order gnark's
+ * computeH leaves them (bit-reversed; the caller uses h[:N-1]). */
+int zk_bn254_groth16_compute_h(const zk_fr *a, const zk_fr *b, const zk_fr *c, size_t n, uint32_t log_N, zk_fr *h_out);
+int zk_bn254_groth16_compute_h_dev(const void *d_a, const void *d_b, const void *d_c, size_t n, uint32_t log_N,
+                                   void *d_h_out, void *stream);
+
+/* ProvingKey image (host pointers; copied to the device by zk_bn254_groth16_pk_load).  Same field names as gnark's
+ * groth16.ProvingKey{G1{Alpha,Beta,Delta,A,B,K,Z}, G2{Beta,Delta,B}}; A/B/G2.B have n_wires entries (points at
+ * infinity allowed -- they contribute nothing, which is what gnark's InfinityA/InfinityB filtering achieves);
+ * K has n_wires - n_public; Z has 2^log_domain entries in gnark's (bit-reversed) order, N-1 are used. */
+typedef struct {
+    uint32_t log_domain;
+    size_t n_wires, n_public;
+    const zk_g1_affine *g1_alpha, *g1_beta, *g1_delta;
+    const zk_g1_affine *g1_a, *g1_b, *g1_k, *g1_z;
+    const zk_g2_affine *g2_beta, *g2_delta;
+    const zk_g2_affine *g2_b;
+    int bases_on_device; /* 1: g1_a, g1_b, g1_k, g1_z, g2_b are DEVICE pointers that stay owned by the caller */
+} zk_groth16_pk;
+int zk_bn254_groth16_pk_load(const zk_groth16_pk *pk, uint64_t *handle);
+int zk_bn254_groth16_pk_free(uint64_t handle);
+/* Prove with the prover randomness (r, s) as INPUTS (upstream draws them from crypto/rand; pinning them is what
+ * makes "bit-exact proof bytes" well defined).  a, b, c: n_constraints evaluations (solver output); w: n_wires wire
+ * values; all Montgomery fr.Element.  proof_out = Ar | Bs | Krs in gnark's compressed encoding (32+64+32 bytes),
+ * i.e. Proof.WriteTo.  `on_device` != 0: a, b, c, w are device pointers. */
+int zk_bn254_groth16_prove(uint64_t pk_handle, const void *a, const void *b, const void *c, size_t n_constraints,
+                           const void *w, const zk_fr *r, const zk_fr *s, int on_device, uint8_t proof_out[128]);
+
+/* ---- synthetic data on the device (bench / tests; deterministic SplitMix64 streams) -------------- */
+int zk_bn254_fr_random_dev(void *d_out, size_t n, uint64_t seed, int mont, int witness_like, void *stream);
+int zk_bn254_g1_generate_dev(void *d_out, size_t n, uint64_t seed, void *stream); /* P_i = k_i * G1 */
+int zk_bn254_g2_generate_dev(void *d_out, size_t n, uint64_t seed, void *stream); /* P_i = k_i * G2 */
+int zk_bn254_fr_mul_dev(void *d_out, const void *d_a, const void *d_b, size_t n, void *stream); /* out = a*b (Montgomery) */
+
+/* ---- device memory plumbing for hosts without a HIP binding (ctypes tests, the cgo shim) ------------------------ */
+int zk_dev_alloc(void **d_ptr, size_t bytes);
+int zk_dev_free(void *d_ptr);
+int zk_dev_h2d(void *d_dst, const void *h_src, size_t bytes);
+int zk_dev_d2h(void *h_dst, const void *d_src, size_t bytes);
+int zk_dev_sync(void);
+
+/* ---- per-kernel timing (hipEvent pairs on the stream the kernels run on; feeds bench.py's roofline object) ------- */
+int zk_profile_enable(int on);                 /* 1: record an event pair around every kernel launch */
+int zk_profile_reset(void);
+int zk_profile_count(void);                    /* number of distinct kernel names seen */
+int zk_profile_get(int idx, char *name_out, size_t name_cap, uint64_t *launches, double *total_ms);
+
+/* ---- host-only self test (runs WITHOUT a GPU): the shared 32-bit-limb field / XYZZ code vs the 64-bit host code;
+ * returns the number of mismatches (0 = ok). */
+int zk_selftest_host(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMI_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of libzkmi.so (include/zkmi.h).  The product path fails loudly here: a missing library raises at
+load time, and every compute entry point returns ZK_ERR_NO_DEVICE (raised as ZkmiError) when no GPU is usable."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+
+ZK_OK, ZK_ERR_LEN, ZK_ERR_NB_TASKS, ZK_ERR_NO_DEVICE, ZK_ERR_HIP, ZK_ERR_ARG, ZK_ERR_HANDLE = 0, -1, -2, -3, -4, -5, -6
+
+
+class ZkmiError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libzkmi error %d: %s" % (code, msg))
+        self.code = code
+
+
+class MsmCfg(C.Structure):
+    _fields_ = [("nb_tasks", C.c_int), ("scalars_mont", C.c_int), ("window_bits", C.c_int), ("reserved", C.c_int)]
+
+
+class Groth16PK(C.Structure):
+    _fields_ = [("log_domain", C.c_uint32), ("n_wires", C.c_size_t), ("n_public", C.c_size_t),
+                ("g1_alpha", C.c_void_p), ("g1_beta", C.c_void_p), ("g1_delta", C.c_void_p),
+                ("g1_a", C.c_void_p), ("g1_b", C.c_void_p), ("g1_k", C.c_void_p), ("g1_z", C.c_void_p),
+                ("g2_beta", C.c_void_p), ("g2_delta", C.c_void_p), ("g2_b", C.c_void_p), ("bases_on_device", C.c_int)]
+
+
+# every symbol include/zkmi.h declares (tests check that the library exports exactly these)
+SYMBOLS = [
+    "zk_device_count", "zk_init", "zk_last_error", "zk_version",
+    "zk_bn254_g1_msm", "zk_bn254_g2_msm", "zk_bn254_g1_msm_dev", "zk_bn254_g2_msm_dev",
+    "zk_bn254_g1_msm_partial_dev", "zk_bn254_g2_msm_partial_dev", "zk_bn254_g1_sum_xyzz", "zk_bn254_g2_sum_xyzz",
+    "zk_bn254_bases_register", "zk_bn254_bases_free", "zk_bn254_msm_bases",
+    "zk_bn254_ntt", "zk_bn254_ntt_dev", "zk_bn254_bit_reverse", "zk_bn254_bit_reverse_dev",
+    "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev",
+    "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_prove",
+    "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev",
+    "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
+    "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_selftest_host",
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libzkmi.so is missing at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C noir_backend_using_gnark_amd/csrc).  There is no CPU fallback for the product path." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.zk_last_error.restype = C.c_char_p
+        _lib.zk_version.restype = C.c_char_p
+        for name in SYMBOLS:
+            fn = getattr(_lib, name)
+            if name not in ("zk_last_error", "zk_version"):
+                fn.restype = C.c_int
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != ZK_OK:
+        raise ZkmiError(rc, (lib().zk_last_error() or b"").decode())
+
+
+def device_count() -> int:
+    return int(lib().zk_device_count())
+
+
+def require_device() -> None:
+    if device_count() <= 0:
+        raise ZkmiError(ZK_ERR_NO_DEVICE, "no HIP device visible; the MI355X path has no CPU fallback")
+
+
+def vp(x) -> C.c_void_p:
+    """numpy array / int device pointer / None -> c_void_p"""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.ctypes.data)
+
+
+class DeviceBuffer:
+    """A hipMalloc'd buffer owned through the C ABI (no torch needed).  `.ptr` is the raw device address."""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        check(lib().zk_dev_alloc(C.byref(p), C.c_size_t(nbytes)))
+        self.ptr = int(p.value)
+        self.nbytes = nbytes
+
+    @classmethod
+    def from_numpy(cls, a):
+        import numpy as np
+        a = np.ascontiguousarray(a)
+        b = cls(max(a.nbytes, 16))
+        if a.nbytes:
+            check(lib().zk_dev_h2d(C.c_void_p(b.ptr), vp(a), C.c_size_t(a.nbytes)))
+        return b
+
+    def to_numpy(self, dtype, shape):
+        import numpy as np
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        if out.nbytes:
+            check(lib().zk_dev_d2h(vp(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().zk_dev_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def profile(enable: bool) -> None:
+    check(lib().zk_profile_enable(C.c_int(1 if enable else 0)))
+
+
+def profile_reset() -> None:
+    check(lib().zk_profile_reset())
+
+
+def profile_read() -> dict:
+    """kernel name -> (launches, total_ms), measured with hipEvent pairs on the stream the kernels ran on."""
+    out = {}
+    n = lib().zk_profile_count()
+    for i in range(n):
+        name = C.create_string_buffer(128)
+        launches = C.c_uint64()
+        ms = C.c_double()
+        check(lib().zk_profile_get(C.c_int(i), name, C.c_size_t(128), C.byref(launches), C.byref(ms)))
+        out[name.value.decode()] = (int(launches.value), float(ms.value))
+    return out

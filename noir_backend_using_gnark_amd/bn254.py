@@ -1,0 +1,173 @@
+"""Host-side mirror of the gnark-crypto v0.9.1 interface for the hot path (names and argument meaning follow upstream;
+pinned at /root/reference/gnark_backend_ffi/go.mod:5 and reached through groth16.Prove main.go:131 / plonk.Prove
+backend/plonk/plonk.go:67):
+
+    ecc.MultiExpConfig{NbTasks, ScalarsMont}      -> MultiExpConfig
+    (*G1Jac).MultiExp(points, scalars, config)    -> g1_multi_exp(points, scalars, config)   (affine result)
+    (*G2Jac).MultiExp                             -> g2_multi_exp
+    fft.NewDomain(m); (*Domain).FFT / FFTInverse  -> Domain(m).fft / .fft_inverse (in place, returns the array)
+    fft.BitReverse                                -> bit_reverse
+    fft.DIT / fft.DIF                             -> DIT / DIF
+
+Containers are numpy uint64 arrays holding gnark's memory images: fr.Vector (n, 4); []G1Affine (n, 8);
+[]G2Affine (n, 16) -- or `_lib.DeviceBuffer` / raw device pointers for data already resident in HBM.
+Everything here dispatches to libzkmi.so; nothing is computed on the host."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import MsmCfg, check, lib, vp
+
+DIT, DIF = 0, 1
+
+
+@dataclass
+class MultiExpConfig:
+    nb_tasks: int = 0          # upstream NbTasks; > 1024 is an error like upstream, otherwise ignored on the GPU
+    scalars_mont: bool = True  # scalars are Montgomery fr.Element images (gnark's container)
+    window_bits: int = 0       # 0 = auto
+
+    def _c(self) -> MsmCfg:
+        return MsmCfg(self.nb_tasks, 1 if self.scalars_mont else 0, self.window_bits, 0)
+
+
+def _as_u64(a, width) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.size % width:
+        raise ValueError("array size %d is not a multiple of %d limbs" % (a.size, width))
+    return a.reshape(-1, width)
+
+
+def _multi_exp(fn, width, points, scalars, config):
+    config = config or MultiExpConfig()
+    points, scalars = _as_u64(points, width), _as_u64(scalars, 4)
+    if points.shape[0] != scalars.shape[0]:
+        # upstream: errors.New("len(points) != len(scalars)") -- raised by the library, not here, so that the C ABI is what is tested
+        pass
+    out = np.zeros(width, dtype=np.uint64)
+    cfg = config._c()
+    rc = fn(vp(points), C.c_size_t(points.shape[0]), vp(scalars), C.c_size_t(scalars.shape[0]), C.byref(cfg), vp(out))
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_NB_TASKS):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    return out
+
+
+def g1_multi_exp(points, scalars, config: MultiExpConfig | None = None) -> np.ndarray:
+    """sum_i scalars[i] * points[i] on G1; returns the G1Affine image (8 limbs)."""
+    return _multi_exp(lib().zk_bn254_g1_msm, 8, points, scalars, config)
+
+
+def g2_multi_exp(points, scalars, config: MultiExpConfig | None = None) -> np.ndarray:
+    """sum_i scalars[i] * points[i] on G2; returns the G2Affine image (16 limbs)."""
+    return _multi_exp(lib().zk_bn254_g2_msm, 16, points, scalars, config)
+
+
+def g1_multi_exp_dev(d_points: int, d_scalars: int, n: int, config: MultiExpConfig | None = None, stream: int = 0, partial=False):
+    """Device-pointer variant (inputs resident in HBM).  partial=True returns the un-normalised XYZZ sum (16 limbs)."""
+    cfg = (config or MultiExpConfig())._c()
+    out = np.zeros(16 if partial else 8, dtype=np.uint64)
+    fn = lib().zk_bn254_g1_msm_partial_dev if partial else lib().zk_bn254_g1_msm_dev
+    check(fn(C.c_void_p(d_points), C.c_void_p(d_scalars), C.c_size_t(n), C.byref(cfg), vp(out), C.c_void_p(stream)))
+    return out
+
+
+def g2_multi_exp_dev(d_points: int, d_scalars: int, n: int, config: MultiExpConfig | None = None, stream: int = 0, partial=False):
+    cfg = (config or MultiExpConfig())._c()
+    out = np.zeros(32 if partial else 16, dtype=np.uint64)
+    fn = lib().zk_bn254_g2_msm_partial_dev if partial else lib().zk_bn254_g2_msm_dev
+    check(fn(C.c_void_p(d_points), C.c_void_p(d_scalars), C.c_size_t(n), C.byref(cfg), vp(out), C.c_void_p(stream)))
+    return out
+
+
+def g1_sum_partials(partials) -> np.ndarray:
+    """Combine XYZZ partial sums (k, 16) from range-sharded MSMs into one affine point (host, O(k))."""
+    p = _as_u64(partials, 16)
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib().zk_bn254_g1_sum_xyzz(vp(p), C.c_size_t(p.shape[0]), vp(out)))
+    return out
+
+
+def g2_sum_partials(partials) -> np.ndarray:
+    p = _as_u64(partials, 32)
+    out = np.zeros(16, dtype=np.uint64)
+    check(lib().zk_bn254_g2_sum_xyzz(vp(p), C.c_size_t(p.shape[0]), vp(out)))
+    return out
+
+
+class ResidentBases:
+    """pk / SRS bases kept in HBM across calls (zk_bn254_bases_register)."""
+
+    def __init__(self, points, is_g2: bool = False):
+        width = 16 if is_g2 else 8
+        points = _as_u64(points, width)
+        self.n, self.is_g2, self.handle = points.shape[0], is_g2, C.c_uint64(0)
+        check(lib().zk_bn254_bases_register(vp(points), C.c_size_t(self.n), C.c_int(int(is_g2)), C.byref(self.handle)))
+
+    def multi_exp(self, scalars, config: MultiExpConfig | None = None, offset: int = 0) -> np.ndarray:
+        scalars = _as_u64(scalars, 4)
+        out = np.zeros(16 if self.is_g2 else 8, dtype=np.uint64)
+        cfg = (config or MultiExpConfig())._c()
+        rc = lib().zk_bn254_msm_bases(self.handle, C.c_size_t(offset), vp(scalars), C.c_size_t(scalars.shape[0]), C.byref(cfg), vp(out))
+        if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_NB_TASKS):
+            raise ValueError((lib().zk_last_error() or b"").decode())
+        check(rc)
+        return out
+
+    def free(self):
+        if self.handle.value:
+            lib().zk_bn254_bases_free(self.handle)
+            self.handle = C.c_uint64(0)
+
+
+class Domain:
+    """fft.NewDomain(m): Cardinality = next power of two >= m.  The generator / coset / twiddle tables live on the device
+    (built lazily per size by the library)."""
+
+    def __init__(self, m: int):
+        n = 1
+        while n < m:
+            n <<= 1
+        self.cardinality = n
+        self.log_n = n.bit_length() - 1
+        if self.log_n > 28:
+            raise ValueError("domain size 2^%d exceeds the Fr two-adicity 2^28" % self.log_n)
+
+    def _run(self, a, inverse, decimation, coset):
+        if decimation not in (DIT, DIF):
+            raise ValueError("decimation must be DIT or DIF")
+        if isinstance(a, (int, _lib.DeviceBuffer)):
+            ptr = a if isinstance(a, int) else a.ptr
+            check(lib().zk_bn254_ntt_dev(C.c_void_p(ptr), C.c_uint32(self.log_n), C.c_int(int(inverse)), C.c_int(decimation),
+                                         C.c_int(int(bool(coset))), C.c_void_p(0)))
+            return a
+        if not (isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]):
+            raise TypeError("in-place transform needs a C-contiguous uint64 numpy array (or a device buffer)")
+        if a.size != 4 * self.cardinality:
+            raise ValueError("len(a) = %d != domain cardinality %d" % (a.size // 4, self.cardinality))
+        check(lib().zk_bn254_ntt(vp(a), C.c_uint32(self.log_n), C.c_int(int(inverse)), C.c_int(decimation), C.c_int(int(bool(coset)))))
+        return a
+
+    def fft(self, a, decimation: int, coset: bool = False):
+        """(*Domain).FFT(a, decimation, coset...) -- in place."""
+        return self._run(a, False, decimation, coset)
+
+    def fft_inverse(self, a, decimation: int, coset: bool = False):
+        """(*Domain).FFTInverse(a, decimation, coset...) -- in place, includes the 1/N scaling."""
+        return self._run(a, True, decimation, coset)
+
+
+def bit_reverse(a):
+    """fft.BitReverse(a) -- in place."""
+    if not (isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]):
+        raise TypeError("needs a C-contiguous uint64 numpy array")
+    n = a.size // 4
+    log_n = n.bit_length() - 1
+    if n == 0 or (1 << log_n) != n:
+        raise ValueError("BitReverse needs a power-of-two length")
+    check(lib().zk_bn254_bit_reverse(vp(a), C.c_uint32(log_n)))
+    return a

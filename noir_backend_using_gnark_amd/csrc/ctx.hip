@@ -1,0 +1,242 @@
+// libzkmi runtime: device init, stream slots, arenas, profiling, device-memory plumbing entry points.
+#include "ctx.hpp"
+
+#include <string.h>
+
+#include <thread>
+
+namespace zkmi {
+
+thread_local std::string g_err;
+
+int set_err(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+Ctx& ctx() {
+    static Ctx c;
+    return c;
+}
+
+static int init_locked(int device) {
+    Ctx& c = ctx();
+    if (c.ready) return ZK_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_err(ZK_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount: %s); libzkmi has no CPU fallback",
+                       e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return set_err(ZK_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    ZK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ZK_HIP(hipGetDeviceProperties(&prop, device));
+    c.device = device;
+    c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int i = 0; i < Ctx::NSLOTS; i++) ZK_HIP(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
+    c.ready = true;
+    return ZK_OK;
+}
+
+int ensure_init() {
+    Ctx& c = ctx();
+    if (c.ready) {
+        // other host threads (goroutine-backed OS threads) must also target the device
+        hipError_t e = hipSetDevice(c.device);
+        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+        return ZK_OK;
+    }
+    std::lock_guard<std::mutex> lk(c.mu);
+    return init_locked(0);
+}
+
+int acquire_slot(Slot** out) {
+    ZK_TRY(ensure_init());
+    Ctx& c = ctx();
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            for (int i = 0; i < Ctx::NSLOTS; i++)
+                if (!c.slots[i].busy) {
+                    c.slots[i].busy = true;
+                    c.slots[i].reset();
+                    *out = &c.slots[i];
+                    return ZK_OK;
+                }
+        }
+        std::this_thread::yield();
+    }
+}
+
+void release_slot(Slot* s) {
+    std::lock_guard<std::mutex> lk(ctx().mu);
+    s->busy = false;
+}
+
+int Slot::reserve(size_t bytes) {
+    bytes = align_up(bytes + 4096, 1 << 20);
+    if (bytes <= arena_cap) return ZK_OK;
+    if (arena) {
+        ZK_HIP(hipStreamSynchronize(stream));
+        ZK_HIP(hipFree(arena));
+        arena = nullptr;
+        arena_cap = 0;
+    }
+    hipError_t e = hipMalloc((void**)&arena, bytes);
+    if (e != hipSuccess) return set_err(ZK_ERR_HIP, "hipMalloc(%zu bytes of workspace): %s", bytes, hipGetErrorString(e));
+    arena_cap = bytes;
+    arena_off = 0;
+    return ZK_OK;
+}
+
+void* Slot::alloc(size_t bytes) {
+    size_t off = align_up(arena_off, 256);
+    if (off + bytes > arena_cap) return nullptr;
+    arena_off = off + bytes;
+    return arena + off;
+}
+
+int Slot::pinned_reserve(size_t bytes) {
+    if (bytes <= pinned_cap) return ZK_OK;
+    if (pinned) ZK_HIP(hipHostFree(pinned));
+    pinned = nullptr;
+    pinned_cap = 0;
+    ZK_HIP(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+    pinned_cap = bytes;
+    return ZK_OK;
+}
+
+void prof_begin(Slot* s, hipStream_t st, const char* name) {
+    Slot::Pending p;
+    p.name = name;
+    for (hipEvent_t* e : {&p.e0, &p.e1}) {
+        if (!s->free_events.empty()) {
+            *e = s->free_events.back();
+            s->free_events.pop_back();
+        } else {
+            hipEventCreate(e);
+        }
+    }
+    hipEventRecord(p.e0, st);
+    s->pending.push_back(p);
+}
+void prof_end(Slot* s, hipStream_t st) { hipEventRecord(s->pending.back().e1, st); }
+
+int slot_sync(Slot* s, hipStream_t st) {
+    ZK_HIP(hipStreamSynchronize(st));
+    if (!s->pending.empty()) {
+        Ctx& c = ctx();
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (auto& p : s->pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+                auto it = c.prof.find(p.name);
+                if (it == c.prof.end()) {
+                    c.prof_names.push_back(p.name);
+                    it = c.prof.emplace(p.name, ProfEntry{}).first;
+                }
+                it->second.launches++;
+                it->second.total_ms += ms;
+            }
+            s->free_events.push_back(p.e0);
+            s->free_events.push_back(p.e1);
+        }
+        s->pending.clear();
+    }
+    return ZK_OK;
+}
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int zk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int zk_init(int device) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.ready) return c.device == device ? ZK_OK : set_err(ZK_ERR_ARG, "already bound to device %d", c.device);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return set_err(ZK_ERR_NO_DEVICE, "no HIP device visible; libzkmi has no CPU fallback");
+    if (device < 0 || device >= n) return set_err(ZK_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    // inline the body of init_locked with the requested device
+    ZK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ZK_HIP(hipGetDeviceProperties(&prop, device));
+    c.device = device;
+    c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int i = 0; i < Ctx::NSLOTS; i++) ZK_HIP(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
+    c.ready = true;
+    return ZK_OK;
+}
+
+const char* zk_last_error(void) { return g_err.c_str(); }
+const char* zk_version(void) { return "libzkmi 0.1 (gfx950; BN254 G1/G2 MSM + Fr NTT + Groth16 prove)"; }
+
+int zk_dev_alloc(void** d_ptr, size_t bytes) {
+    if (!d_ptr) return set_err(ZK_ERR_ARG, "null out pointer");
+    ZK_TRY(ensure_init());
+    ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return ZK_OK;
+}
+int zk_dev_free(void* d_ptr) {
+    ZK_TRY(ensure_init());
+    ZK_HIP(hipFree(d_ptr));
+    return ZK_OK;
+}
+int zk_dev_h2d(void* d_dst, const void* h_src, size_t bytes) {
+    ZK_TRY(ensure_init());
+    ZK_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+int zk_dev_d2h(void* h_dst, const void* d_src, size_t bytes) {
+    ZK_TRY(ensure_init());
+    ZK_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+int zk_dev_sync(void) {
+    ZK_TRY(ensure_init());
+    ZK_HIP(hipDeviceSynchronize());
+    return ZK_OK;
+}
+
+int zk_profile_enable(int on) {
+    ctx().profiling = on != 0;
+    return ZK_OK;
+}
+int zk_profile_reset(void) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.prof.clear();
+    c.prof_names.clear();
+    return ZK_OK;
+}
+int zk_profile_count(void) { return (int)ctx().prof_names.size(); }
+int zk_profile_get(int idx, char* name_out, size_t name_cap, uint64_t* launches, double* total_ms) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (idx < 0 || idx >= (int)c.prof_names.size()) return set_err(ZK_ERR_ARG, "profile index out of range");
+    const std::string& n = c.prof_names[idx];
+    if (name_out && name_cap) {
+        strncpy(name_out, n.c_str(), name_cap - 1);
+        name_out[name_cap - 1] = 0;
+    }
+    const ProfEntry& e = c.prof[n];
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.total_ms;
+    return ZK_OK;
+}
+
+}  // extern "C"

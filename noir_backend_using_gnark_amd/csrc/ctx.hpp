@@ -1,0 +1,94 @@
+// Runtime context of libzkmi: device binding, stream slots with bump-allocated HBM workspaces, per-kernel hipEvent
+// timing, thread-local error text.  One process drives one GPU (multi-GPU = one process per GPU, see parallel.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/zkmi.h"
+
+namespace zkmi {
+
+extern thread_local std::string g_err;
+int set_err(int code, const char* fmt, ...);
+
+#define ZK_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return zkmi::set_err(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define ZK_TRY(expr)              \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != ZK_OK) return _rc; \
+    } while (0)
+
+struct ProfEntry {
+    uint64_t launches = 0;
+    double total_ms = 0;
+};
+
+// A stream slot: one HIP stream + one growing HBM arena + pinned host staging + pending profile events.
+struct Slot {
+    hipStream_t stream = nullptr;
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    bool busy = false;
+    struct Pending {
+        const char* name;
+        hipEvent_t e0, e1;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+
+    int reserve(size_t bytes);              // make sure the arena holds `bytes` (call before any alloc of a request)
+    void* alloc(size_t bytes);              // bump allocate (256-B aligned); nullptr if reserve() was too small
+    void reset() { arena_off = 0; }
+    int pinned_reserve(size_t bytes);
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = 0;
+    int num_cus = 256;
+    std::mutex mu;
+    static constexpr int NSLOTS = 8;
+    Slot slots[NSLOTS];
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<std::string> prof_names;
+};
+
+Ctx& ctx();
+int ensure_init();                  // lazy device init; ZK_ERR_NO_DEVICE if there is no GPU
+int acquire_slot(Slot** out);       // blocks (spins) until a slot is free
+void release_slot(Slot* s);
+int slot_sync(Slot* s, hipStream_t st);  // synchronize + fold pending profile events
+
+struct SlotGuard {
+    Slot* s = nullptr;
+    ~SlotGuard() { if (s) release_slot(s); }
+};
+
+// launch wrapper: optional event pair around the kernel, on the stream it is launched on
+void prof_begin(Slot* s, hipStream_t st, const char* name);
+void prof_end(Slot* s, hipStream_t st);
+
+#define ZK_LAUNCH(slot, st, name, kernel, grid, block, shmem, ...)                  \
+    do {                                                                            \
+        if (zkmi::ctx().profiling) zkmi::prof_begin(slot, st, name);                \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);            \
+        if (zkmi::ctx().profiling) zkmi::prof_end(slot, st);                        \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace zkmi

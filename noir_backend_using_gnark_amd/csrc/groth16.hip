@@ -1,0 +1,211 @@
+// Groth16 prove on gfx950: gnark v0.8.0 `groth16.Prove` (internal/backend/bn254/groth16/prove.go; pinned at
+// /root/reference/gnark_backend_ffi/go.mod:23; the reference's only live call is /root/reference/gnark_backend_ffi/main.go:131,
+// and its intended FFI shape is the commented-out ProveWithPK at backend/groth16/r1cs.go:107-143) from the solver's
+// output onwards:
+//      h   = computeH(a, b, c)                                  7 NTTs of size N            (ntt.hip)
+//      Ar  = MSM(pk.G1.A, w) + alpha + r*delta
+//      Bs1 = MSM(pk.G1.B, w) + beta  + s*delta
+//      Bs  = MSM(pk.G2.B, w) + beta2 + s*delta2
+//      Krs = MSM(pk.G1.K, w[nPub:]) + MSM(pk.G1.Z, h[:N-1]) + s*Ar + r*Bs1 - rs*delta
+//      proof bytes = Ar | Bs | Krs compressed (Proof.WriteTo)
+// The prover randomness (r, s) is an INPUT here (upstream: crypto/rand), which is what makes proof bytes reproducible.
+// The five MSMs and the NTTs run on the device; the O(1) tail (5 scalar multiplications, a few additions, 3 inversions,
+// compression) runs on the host like upstream.
+#include <string.h>
+
+#include "ctx.hpp"
+#include "curve.hpp"
+#include "host_ff.hpp"
+#include "msm.hpp"
+#include "ntt.hpp"
+
+namespace zkmi {
+
+struct Groth16PK {
+    uint32_t log_domain = 0;
+    size_t n_wires = 0, n_public = 0;
+    Affine<HFp> alpha, beta, delta;
+    Affine<HFp2> beta2, delta2;
+    void *d_a = nullptr, *d_b = nullptr, *d_k = nullptr, *d_z = nullptr, *d_b2 = nullptr;
+    bool owns = true;
+};
+static std::mutex g_pk_mu;
+static std::map<uint64_t, Groth16PK> g_pks;
+static uint64_t g_next_pk = 1;
+
+static void to_canonical_u32(const HFr& mont, uint32_t out[8]) {
+    HFr c = mont.from_mont();
+    memcpy(out, c.l, 32);
+}
+
+// gnark-crypto G1Affine.Bytes(): 32 B big-endian X; top bits of byte 0: 10 = y smallest, 11 = y largest, 01 = infinity
+static void fp_to_be(const HFp& mont, uint8_t out[32]) {
+    HFp c = mont.from_mont();
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 8; b++) out[31 - (8 * i + b)] = (uint8_t)(c.l[i] >> (8 * b));
+}
+static bool fp_lex_largest(const HFp& mont) {  // canonical value > (q-1)/2
+    HFp c = mont.from_mont();
+    uint64_t h[4];
+    for (int i = 0; i < 4; i++) h[i] = (HFpParams::MOD[i] >> 1) | (i < 3 ? HFpParams::MOD[i + 1] << 63 : 0);
+    for (int i = 3; i >= 0; i--)
+        if (c.l[i] != h[i]) return c.l[i] > h[i];
+    return false;
+}
+static void g1_compress(const Affine<HFp>& p, uint8_t out[32]) {
+    if (p.is_inf()) {
+        memset(out, 0, 32);
+        out[0] = 0x40;
+        return;
+    }
+    fp_to_be(p.x, out);
+    out[0] |= fp_lex_largest(p.y) ? 0xC0 : 0x80;
+}
+static void g2_compress(const Affine<HFp2>& p, uint8_t out[64]) {
+    if (p.is_inf()) {
+        memset(out, 0, 64);
+        out[0] = 0x40;
+        return;
+    }
+    fp_to_be(p.x.a1, out);
+    fp_to_be(p.x.a0, out + 32);
+    bool largest = p.y.a1.is_zero() ? fp_lex_largest(p.y.a0) : fp_lex_largest(p.y.a1);
+    out[0] |= largest ? 0xC0 : 0x80;
+}
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
+    if (!pk || !handle) return set_err(ZK_ERR_ARG, "null pointer");
+    if (pk->log_domain > 28 || pk->n_public > pk->n_wires) return set_err(ZK_ERR_ARG, "bad proving-key geometry");
+    if (!pk->g1_alpha || !pk->g1_beta || !pk->g1_delta || !pk->g2_beta || !pk->g2_delta) return set_err(ZK_ERR_ARG, "null pk element");
+    ZK_TRY(ensure_init());
+    Groth16PK P;
+    P.log_domain = pk->log_domain;
+    P.n_wires = pk->n_wires;
+    P.n_public = pk->n_public;
+    memcpy(&P.alpha, pk->g1_alpha, 64);
+    memcpy(&P.beta, pk->g1_beta, 64);
+    memcpy(&P.delta, pk->g1_delta, 64);
+    memcpy(&P.beta2, pk->g2_beta, 128);
+    memcpy(&P.delta2, pk->g2_delta, 128);
+    size_t N = (size_t)1 << pk->log_domain, nk = pk->n_wires - pk->n_public;
+    if (pk->bases_on_device) {
+        P.owns = false;
+        P.d_a = (void*)pk->g1_a; P.d_b = (void*)pk->g1_b; P.d_k = (void*)pk->g1_k; P.d_z = (void*)pk->g1_z; P.d_b2 = (void*)pk->g2_b;
+    } else {
+        struct { void** d; const void* h; size_t bytes; } up[5] = {{&P.d_a, pk->g1_a, pk->n_wires * 64}, {&P.d_b, pk->g1_b, pk->n_wires * 64},
+                                                                   {&P.d_k, pk->g1_k, nk * 64},          {&P.d_z, pk->g1_z, N * 64},
+                                                                   {&P.d_b2, pk->g2_b, pk->n_wires * 128}};
+        for (auto& u : up) {
+            if (u.bytes && !u.h) return set_err(ZK_ERR_ARG, "null pk base array");
+            ZK_HIP(hipMalloc(u.d, u.bytes ? u.bytes : 16));
+            if (u.bytes) ZK_HIP(hipMemcpy(*u.d, u.h, u.bytes, hipMemcpyHostToDevice));
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    *handle = g_next_pk++;
+    g_pks[*handle] = P;
+    return ZK_OK;
+}
+
+int zk_bn254_groth16_pk_free(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
+    if (it->second.owns)
+        for (void* d : {it->second.d_a, it->second.d_b, it->second.d_k, it->second.d_z, it->second.d_b2}) (void)hipFree(d);
+    g_pks.erase(it);
+    return ZK_OK;
+}
+
+int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, const void* c, size_t n_constraints, const void* w, const zk_fr* r_,
+                           const zk_fr* s_, int on_device, uint8_t proof_out[128]) {
+    if (!a || !b || !c || !w || !r_ || !s_ || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
+    Groth16PK P;
+    {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        auto it = g_pks.find(pk_handle);
+        if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)pk_handle);
+        P = it->second;
+    }
+    const size_t N = (size_t)1 << P.log_domain, nw = P.n_wires, nk = P.n_wires - P.n_public;
+    if (n_constraints > N) return set_err(ZK_ERR_ARG, "n_constraints = %zu exceeds the domain size %zu", n_constraints, N);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    zk_msm_cfg cfg = {0, 1, 0, 0};  // scalars are Montgomery fr.Element images
+    size_t msm_need = 0;
+    {
+        const size_t g1_sizes[3] = {nw, nk, N - 1};
+        for (size_t sz : g1_sizes) {
+            size_t need = 0;
+            ZK_TRY(msm_g1_need(sz, &cfg, st, &need));
+            if (need > msm_need) msm_need = need;
+        }
+        size_t need = 0;
+        ZK_TRY(msm_g2_need(nw, &cfg, st, &need));
+        if (need > msm_need) msm_need = need;
+    }
+    ZK_TRY(g.s->reserve(3 * N * 32 + nw * 32 + 4096 + msm_need));
+    Fr* d_abc[3];
+    const void* src[3] = {a, b, c};
+    hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int i = 0; i < 3; i++) {
+        d_abc[i] = (Fr*)g.s->alloc(N * 32);
+        if (n_constraints) ZK_HIP(hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st));
+        if (n_constraints < N) ZK_HIP(hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st));
+    }
+    Fr* d_w = (Fr*)g.s->alloc(nw * 32 + 16);
+    if (nw) ZK_HIP(hipMemcpyAsync(d_w, w, nw * 32, kind, st));
+    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
+    ZK_TRY(compute_h_inplace(g.s, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain));
+    const size_t mark = g.s->arena_off;
+    XYZZ<HFp> m_a, m_b, m_k, m_z;
+    XYZZ<HFp2> m_b2;
+    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_a, d_w, nw, &cfg, &m_a));
+    g.s->arena_off = mark;
+    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_b, d_w, nw, &cfg, &m_b));
+    g.s->arena_off = mark;
+    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_k, d_w + P.n_public, nk, &cfg, &m_k));
+    g.s->arena_off = mark;
+    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_z, d_abc[0], N - 1, &cfg, &m_z));
+    g.s->arena_off = mark;
+    ZK_TRY(msm_g2_xyzz(g.s, st, P.d_b2, d_w, nw, &cfg, &m_b2));
+    g.s->arena_off = mark;
+
+    // ---- host tail
+    HFr r, s;
+    memcpy(&r, r_, 32);
+    memcpy(&s, s_, 32);
+    HFr rs = r * s;
+    uint32_t rk[8], sk[8], rsk[8];
+    to_canonical_u32(r, rk);
+    to_canonical_u32(s, sk);
+    to_canonical_u32(rs, rsk);
+    XYZZ<HFp> ar = m_a;
+    ar.madd(P.alpha);
+    ar.add(scalar_mul(P.delta, rk));
+    XYZZ<HFp> bs1 = m_b;
+    bs1.madd(P.beta);
+    bs1.add(scalar_mul(P.delta, sk));
+    XYZZ<HFp2> bs = m_b2;
+    bs.madd(P.beta2);
+    bs.add(scalar_mul(P.delta2, sk));
+    Affine<HFp> ar_aff = ar.to_affine(), bs1_aff = bs1.to_affine();
+    XYZZ<HFp> krs = m_k;
+    krs.add(m_z);
+    krs.add(scalar_mul(ar_aff, sk));
+    krs.add(scalar_mul(bs1_aff, rk));
+    krs.add(scalar_mul(P.delta, rsk).neg());
+    g1_compress(ar_aff, proof_out);
+    g2_compress(bs.to_affine(), proof_out + 32);
+    g1_compress(krs.to_affine(), proof_out + 96);
+    return ZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,598 @@
+// Pippenger multi-scalar multiplication over BN254 G1 / G2 on gfx950.
+//
+// Replaces gnark-crypto v0.9.1 `(*G1Jac).MultiExp` / `(*G2Jac).MultiExp` (ecc/bn254/multiexp.go; pinned at
+// /root/reference/gnark_backend_ffi/go.mod:5), the dominant cost of groth16.Prove
+// (/root/reference/gnark_backend_ffi/main.go:131) and of every kzg.Commit inside plonk.Prove / plonk.Setup
+// (/root/reference/gnark_backend_ffi/backend/plonk/plonk.go:67,21).  Same contract: out = sum_i s_i * P_i, errors for
+// len(points) != len(scalars) and NbTasks > 1024; the AFFINE result is canonical, so it is bit-identical to upstream's
+// whatever window size either side picks.
+//
+// Device pipeline (all on one stream, no host round trip until the window sums come back):
+//   1. k_msm_digits      scalars (Montgomery or canonical) -> signed c-bit digits (gnark's partitionScalars recoding);
+//                        one (bucket key, point index|sign) pair per non-zero digit, zero digits get a sentinel key
+//   2. radix sort        rocprim radix_sort_pairs on the ~log2(W * 2^(c-1)) key bits  (a library sort; the hot kernel is 3)
+//   3. k_bucket_bounds   bucket -> [start, end) in the sorted array
+//   4. k_task_plan       buckets are cut into tasks of <= L points so that one giant bucket (scalars 0/1 dominate real
+//                        witnesses) cannot serialise the GPU; exclusive scan -> task offsets
+//   5. k_accumulate      one thread per task: XYZZ accumulator += affine points (madd-2008-s); gathers of 64-B / 128-B
+//                        points by sorted index; buckets with several tasks are folded by k_fold_multi (one WG each)
+//   6. k_reduce_l1 / k_reduce_wave   sum_k k * B_k per window: thread-serial running sums over 8 buckets, then
+//                        wave-cooperative suffix scans (64 lanes, DPP/bpermute shuffles of whole points)
+//   7. host              Horner over the <= 32 window sums + one inversion (HField, host_ff.hpp), like gnark's final step.
+// Roofline: algorithmic bytes = 96 B (G1) / 160 B (G2) per scalar-mul.  The kernel is VALU-bound on CDNA4: each mixed
+// addition is 10 Fp products of ~136 quarter-rate v_mad_u64_u32 each -- see DESIGN.md for both fractions.
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ctx.hpp"
+#include "curve.hpp"
+#include "host_ff.hpp"
+#include "msm.hpp"
+
+namespace zkmi {
+
+// ---------------------------------------------------------------------------------------- wide global loads/stores
+template <class T>
+__device__ __forceinline__ T gload(const T* p) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte multiples only");
+    T r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = q[i];
+    return r;
+}
+template <class T>
+__device__ __forceinline__ void gstore(T* p, const T& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const uint4* d = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = d[i];
+}
+template <class T>
+__device__ __forceinline__ T shfl_down_t(const T& v, unsigned d) {
+    T r;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* o = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) o[i] = __shfl_down(s[i], d, 64);
+    return r;
+}
+template <class T>
+__device__ __forceinline__ T shfl_xor_t(const T& v, unsigned d) {
+    T r;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* o = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) o[i] = __shfl_xor(s[i], d, 64);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------- 1. digits
+// gnark-crypto partitionScalars: digit = bits [w*c, (w+1)*c) + carry; if digit > 2^(c-1): digit -= 2^c, carry = 1.
+__global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c, unsigned W, uint32_t* keys, uint32_t* vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s;
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(scalars + i);
+        uint4 a = q[0], b = q[1];
+        s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w;
+        s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
+    }
+    if (mont) s = s.from_mont();
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t sentinel = W * B;
+    uint32_t carry = 0;
+    for (unsigned w = 0; w < W; w++) {
+        unsigned bit = w * c, limb = bit >> 5, off = bit & 31;
+        uint64_t v = 0;
+        if (limb < 8) {
+            v = s.l[limb];
+            if (limb + 1 < 8) v |= (uint64_t)s.l[limb + 1] << 32;
+            v >>= off;
+        }
+        uint32_t d = ((uint32_t)v & ((1u << c) - 1)) + carry;
+        carry = 0;
+        uint32_t neg = 0, mag = d;
+        if (d > B) {  // d - 2^c is negative: magnitude 2^c - d
+            mag = (1u << c) - d;
+            neg = 1;
+            carry = 1;
+        }
+        size_t o = (size_t)w * n + i;
+        keys[o] = mag ? (w * B + (mag - 1)) : sentinel;
+        vals[o] = (i << 1) | neg;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- 3. bucket boundaries
+// start[b] = first sorted position whose key >= b, for b in [0, nb]; (nb = W*B; key nb is the zero-digit sentinel)
+__global__ void k_bucket_bounds(const uint32_t* keys, uint32_t total, uint32_t nb, uint32_t* start) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    uint32_t k = keys[j];
+    uint32_t lo = (j == 0) ? 0 : keys[j - 1] + 1;
+    for (uint32_t b = lo; b <= k && b <= nb; b++) start[b] = j;
+    if (j == total - 1)
+        for (uint32_t b = k + 1; b <= nb; b++) start[b] = total;
+}
+
+// ---------------------------------------------------------------------------------------- 4. task plan
+__global__ void k_task_plan(const uint32_t* start, uint32_t nb, uint32_t L, uint32_t* ntasks, uint32_t* multi_list, uint32_t* num_multi) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    if (b == nb) { ntasks[b] = 0; return; }
+    uint32_t cnt = start[b + 1] - start[b];
+    uint32_t t = (cnt + L - 1) / L;
+    ntasks[b] = t;
+    if (t > 1) multi_list[atomicAdd(num_multi, 1u)] = b;
+}
+
+// ---------------------------------------------------------------------------------------- 5. accumulate
+template <class F>
+__global__ __launch_bounds__(256) void k_accumulate(const Affine<F>* __restrict__ pts, const uint32_t* __restrict__ vals,
+                                                    const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off,
+                                                    uint32_t nb, uint32_t L, XYZZ<F>* __restrict__ partial) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t total_tasks = task_off[nb];
+    if (t >= total_tasks) return;
+    // bucket = last b with task_off[b] <= t  (empty buckets have task_off[b] == task_off[b+1] and are skipped)
+    uint32_t lo = 0, hi = nb;  // invariant: task_off[lo] <= t < task_off[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (task_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    uint32_t b = lo;
+    uint32_t begin = start[b] + (t - task_off[b]) * L;
+    uint32_t end = min(begin + L, start[b + 1]);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t j = begin; j < end; j++) {
+        uint32_t v = vals[j];
+        Affine<F> p = gload(pts + (v >> 1));
+        if (v & 1) p.y = p.y.neg();
+        acc.madd(p.x, p.y);
+    }
+    gstore(partial + t, acc);
+}
+
+// buckets cut into several tasks: one workgroup folds the bucket's partials into the first one
+template <class F>
+__global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list,
+                                                    const uint32_t* num_multi) {
+    extern __shared__ uint4 lds_raw[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
+    uint32_t nm = *num_multi;
+    for (uint32_t m = blockIdx.x; m < nm; m += gridDim.x) {
+        uint32_t b = multi_list[m];
+        uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+            XYZZ<F> p = gload(partial + t);
+            acc.add(p);
+        }
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (unsigned s = blockDim.x >> 1; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+                XYZZ<F> x = sh[threadIdx.x], y = sh[threadIdx.x + s];
+                x.add(y);
+                sh[threadIdx.x] = x;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) gstore(partial + t0, sh[0]);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------- 6. bucket reduce
+// Invariant carried through the levels, per window:  value = sum_j A[j] + 2^sh * sum_j j * S[j]   (j = 0..N-1).
+// Level 1 (thread-serial, m buckets per thread): buckets X_k (weight k+1) -> A'[q] = sum_l (l+1) X_{qm+l},
+// S'[q] = sum_l X_{qm+l}; then value = sum A' + m * sum q S'.
+template <class F>
+__global__ __launch_bounds__(256) void k_reduce_l1(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t B,
+                                                   uint32_t W, uint32_t m, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
+    uint32_t N1 = B / m;
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= W * N1) return;
+    uint32_t w = g / N1, q = g % N1;
+    uint32_t b0 = w * B + q * m;
+    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+    for (int l = (int)m - 1; l >= 0; l--) {
+        uint32_t b = b0 + l;
+        uint32_t t0 = task_off[b];
+        if (task_off[b + 1] > t0) {
+            XYZZ<F> x = gload(partial + t0);
+            run.add(x);
+        }
+        acc.add(run);
+    }
+    gstore(A_out + g, acc);
+    gstore(S_out + g, run);
+}
+
+// Wave-cooperative level: 64 consecutive entries per wave (lane = l).
+//   S' = sum_l S_l ;  A' = sum_l A_l + 2^sh * sum_l l * S_l ;   next shift = sh + 6
+// suffix scan of S (6 shuffle steps), per-lane doublings, one butterfly reduction.
+template <class F>
+__global__ __launch_bounds__(64) void k_reduce_wave(const XYZZ<F>* __restrict__ A_in, const XYZZ<F>* __restrict__ S_in, uint32_t N, uint32_t W,
+                                                    uint32_t sh, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
+    uint32_t Nout = (N + 63) / 64;
+    uint32_t chunk = blockIdx.x;  // W * Nout chunks
+    uint32_t w = chunk / Nout, q = chunk % Nout;
+    uint32_t lane = threadIdx.x;
+    uint32_t j = q * 64 + lane;
+    XYZZ<F> s = XYZZ<F>::inf(), a = XYZZ<F>::inf();
+    if (j < N) {
+        s = gload(S_in + (size_t)w * N + j);
+        a = gload(A_in + (size_t)w * N + j);
+    }
+    // inclusive suffix sums: s_l = sum_{u >= l} S_u
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        XYZZ<F> t = shfl_down_t(s, d);
+        if (lane + d < 64) s.add(t);
+    }
+    XYZZ<F> y = s;  // lane 0 holds the plain sum S'
+    if (lane == 0) y = XYZZ<F>::inf();
+    for (uint32_t i = 0; i < sh; i++) y.dbl();  // 2^sh * suffix_l, in parallel on the lanes
+    y.add(a);
+    for (unsigned d = 32; d > 0; d >>= 1) {
+        XYZZ<F> t = shfl_xor_t(y, d);
+        y.add(t);
+    }
+    if (lane == 0) {
+        gstore(S_out + chunk, s);
+        gstore(A_out + chunk, y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- host side
+template <class HF> struct HostOf;
+template <> struct HostOf<Fp> { typedef HFp type; };
+template <> struct HostOf<Fp2> { typedef HFp2 type; };
+
+unsigned msm_pick_window(size_t n) {
+    // GPU cost model in Fp products: accumulate n*W mixed adds (10 each) + bucket reduce W*2^(c-1) * ~2 full adds (14 each)
+    // + fixed per-bucket overhead of the plan/scan kernels.
+    unsigned best = 8;
+    double bc = 1e300;
+    for (unsigned c = 6; c <= 22; c++) {
+        unsigned W = (255 + c - 1) / c;
+        double cost = (double)n * W * 10.0 + (double)W * (double)((size_t)1 << (c - 1)) * 34.0;
+        if (cost < bc) { bc = cost; best = c; }
+    }
+    return best;
+}
+
+struct MsmPlan {
+    unsigned c, W, key_bits;
+    uint32_t B, nb, L, m1, N1;
+    size_t total, max_tasks, sort_tmp_bytes, scan_tmp_bytes, lvl_elems, need;
+};
+
+// Sizes every buffer of one MSM call; `need` is what the caller must reserve in the slot's arena BEFORE it carves
+// anything else out of it (the arena cannot grow while allocations are live).
+template <class F>
+static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P) {
+    typedef XYZZ<F> Pt;
+    memset(P, 0, sizeof *P);
+    if (n == 0) return ZK_OK;
+    if (n > ((size_t)1 << 27)) return set_err(ZK_ERR_ARG, "n = %zu exceeds the per-call limit 2^27 (shard the MSM)", n);
+    unsigned c = (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : msm_pick_window(n);
+    if (c < 2 || c > 22) return set_err(ZK_ERR_ARG, "window_bits = %u outside [2, 22]", c);
+    P->c = c;
+    P->W = (255 + c - 1) / c;
+    P->B = 1u << (c - 1);
+    P->nb = P->W * P->B;
+    P->total = n * P->W;
+    if (P->total >= ((size_t)1 << 32)) return set_err(ZK_ERR_ARG, "n * windows = %zu overflows 32-bit positions", P->total);
+    // tasks of at most L points: 2x the mean bucket load of a uniform input, at least 32
+    size_t mean = n / P->B + 1;
+    P->L = (uint32_t)(mean * 2 < 32 ? 32 : mean * 2);
+    P->max_tasks = (size_t)P->nb + P->total / P->L + 1;
+    P->m1 = P->B >= 8 ? 8 : P->B;  // level-1 serial chunk
+    P->N1 = P->B / P->m1;
+    P->key_bits = 1;
+    while (((uint64_t)1 << P->key_bits) <= P->nb) P->key_bits++;
+    {
+        rocprim::double_buffer<uint32_t> kb(nullptr, nullptr), vb(nullptr, nullptr);
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, P->sort_tmp_bytes, kb, vb, P->total, 0, P->key_bits, st);
+        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs sizing: %s", hipGetErrorString(e));
+        e = rocprim::exclusive_scan(nullptr, P->scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P->nb + 1,
+                                    rocprim::plus<uint32_t>(), st);
+        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan sizing: %s", hipGetErrorString(e));
+    }
+    P->lvl_elems = (size_t)P->W * P->N1;  // level-1 outputs; later levels are 64x smaller
+    P->need = 4 * align_up(P->total * 4, 256) + align_up(P->sort_tmp_bytes + 16, 256) + align_up(P->scan_tmp_bytes + 16, 256) +
+              3 * align_up(((size_t)P->nb + 2) * 4, 256) + align_up((size_t)P->nb * 4, 256) + 256 +
+              align_up(P->max_tasks * sizeof(Pt), 256) + 4 * align_up((P->lvl_elems + 64) * sizeof(Pt), 256) + 65536;
+    return ZK_OK;
+}
+
+template <class F>
+static int msm_run(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>* d_pts, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg,
+                   XYZZ<typename HostOf<F>::type>* total_out) {
+    typedef typename HostOf<F>::type HF;
+    typedef XYZZ<F> Pt;
+    *total_out = XYZZ<HF>::inf();
+    if (n == 0) return ZK_OK;
+    const unsigned c = P.c, W = P.W, key_bits = P.key_bits;
+    const uint32_t B = P.B, nb = P.nb, L = P.L, m1 = P.m1, N1 = P.N1;
+    const size_t total = P.total, max_tasks = P.max_tasks, lvl_elems = P.lvl_elems;
+    size_t sort_tmp_bytes = P.sort_tmp_bytes, scan_tmp_bytes = P.scan_tmp_bytes;
+    uint32_t* keys0 = (uint32_t*)s->alloc(total * 4);
+    uint32_t* keys1 = (uint32_t*)s->alloc(total * 4);
+    uint32_t* vals0 = (uint32_t*)s->alloc(total * 4);
+    uint32_t* vals1 = (uint32_t*)s->alloc(total * 4);
+    void* sort_tmp = s->alloc(sort_tmp_bytes + 16);
+    void* scan_tmp = s->alloc(scan_tmp_bytes + 16);
+    uint32_t* start = (uint32_t*)s->alloc(((size_t)nb + 2) * 4);
+    uint32_t* ntasks = (uint32_t*)s->alloc(((size_t)nb + 2) * 4);
+    uint32_t* task_off = (uint32_t*)s->alloc(((size_t)nb + 2) * 4);
+    uint32_t* multi_list = (uint32_t*)s->alloc((size_t)nb * 4);
+    uint32_t* num_multi = (uint32_t*)s->alloc(256);
+    Pt* partial = (Pt*)s->alloc(max_tasks * sizeof(Pt));
+    Pt* lvlA[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
+    Pt* lvlS[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
+    if (!keys0 || !keys1 || !vals0 || !vals1 || !sort_tmp || !scan_tmp || !start || !ntasks || !task_off || !multi_list || !num_multi ||
+        !partial || !lvlA[0] || !lvlA[1] || !lvlS[0] || !lvlS[1])
+        return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need);
+
+    // ---- 1. digits
+    ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
+              (cfg && cfg->scalars_mont) ? 1 : 0, c, W, keys0, vals0);
+    // ---- 2. sort (bucket key -> point index|sign)
+    rocprim::double_buffer<uint32_t> kb(keys0, keys1), vb(vals0, vals1);
+    {
+        if (ctx().profiling) prof_begin(s, st, "msm_radix_sort(rocprim)");
+        hipError_t e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, kb, vb, total, 0, key_bits, st);
+        if (ctx().profiling) prof_end(s, st);
+        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
+    }
+    const uint32_t* keys = kb.current();
+    const uint32_t* vals = vb.current();
+    // ---- 3. bucket bounds
+    ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, keys, (uint32_t)total, nb, start);
+    // ---- 4. plan
+    ZK_HIP(hipMemsetAsync(num_multi, 0, 4, st));
+    ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, L, ntasks, multi_list, num_multi);
+    {
+        if (ctx().profiling) prof_begin(s, st, "msm_task_scan(rocprim)");
+        hipError_t e = rocprim::exclusive_scan(scan_tmp, scan_tmp_bytes, ntasks, task_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
+        if (ctx().profiling) prof_end(s, st);
+        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
+    }
+    // ---- 5. accumulate
+    const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
+    ZK_LAUNCH(s, st, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, d_pts, vals, (const uint32_t*)start,
+              (const uint32_t*)task_off, nb, L, partial);
+    ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(512), dim3(256), 256 * sizeof(Pt), partial, (const uint32_t*)task_off,
+              (const uint32_t*)multi_list, (const uint32_t*)num_multi);
+    // ---- 6. bucket reduce
+    ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial,
+              (const uint32_t*)task_off, B, W, m1, lvlA[0], lvlS[0]);
+    uint32_t N = N1, sh = 0;
+    for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;  // value = sum A + 2^sh * sum j S_j
+    int cur = 0;
+    while (N > 1) {
+        uint32_t Nout = (N + 63) / 64;
+        ZK_LAUNCH(s, st, "msm_reduce_wave", (k_reduce_wave<F>), dim3(W * Nout), dim3(64), 0, (const Pt*)lvlA[cur], (const Pt*)lvlS[cur], N, W, sh,
+                  lvlA[cur ^ 1], lvlS[cur ^ 1]);
+        cur ^= 1;
+        N = Nout;
+        sh += 6;
+    }
+    // ---- 7. window sums -> host, Horner
+    ZK_TRY(s->pinned_reserve((size_t)W * sizeof(Pt)));
+    ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[cur], (size_t)W * sizeof(Pt), hipMemcpyDeviceToHost, st));
+    ZK_TRY(slot_sync(s, st));
+    const XYZZ<HF>* ws = reinterpret_cast<const XYZZ<HF>*>(s->pinned);
+    XYZZ<HF> tot = XYZZ<HF>::inf();
+    for (int w = (int)W - 1; w >= 0; w--) {
+        for (unsigned k = 0; k < c; k++) tot.dbl();
+        tot.add(ws[w]);
+    }
+    *total_out = tot;
+    return ZK_OK;
+}
+
+int msm_g1_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need) {
+    MsmPlan P;
+    ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));
+    *need = P.need;
+    return ZK_OK;
+}
+int msm_g2_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need) {
+    MsmPlan P;
+    ZK_TRY(msm_plan<Fp2>(n, cfg, st, &P));
+    *need = P.need;
+    return ZK_OK;
+}
+// The slot's arena must already hold msm_g?_need() free bytes.
+int msm_g1_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp>* out) {
+    MsmPlan P;
+    ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));
+    return msm_run<Fp>(s, st, P, (const Affine<Fp>*)d_pts, (const Fr*)d_scalars, n, cfg, out);
+}
+int msm_g2_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp2>* out) {
+    MsmPlan P;
+    ZK_TRY(msm_plan<Fp2>(n, cfg, st, &P));
+    return msm_run<Fp2>(s, st, P, (const Affine<Fp2>*)d_pts, (const Fr*)d_scalars, n, cfg, out);
+}
+
+static int check_cfg(const zk_msm_cfg* cfg) {
+    if (cfg && cfg->nb_tasks > 1024) return set_err(ZK_ERR_NB_TASKS, "invalid config: config.NbTasks > 1024");
+    return ZK_OK;
+}
+
+// bases registry -----------------------------------------------------------------------------------------------------
+struct Bases {
+    void* d = nullptr;
+    size_t n = 0;
+    int is_g2 = 0;
+};
+static std::mutex g_bases_mu;
+static std::map<uint64_t, Bases> g_bases;
+static uint64_t g_next_handle = 1;
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+template <class HF, class OUT>
+static void write_affine(const XYZZ<HF>& t, OUT* out) {
+    Affine<HF> a = t.to_affine();
+    memcpy(out, &a, sizeof(a));
+}
+
+template <int G2>
+static int msm_host_impl(const void* points, size_t n_points, const zk_fr* scalars, size_t n_scalars, const zk_msm_cfg* cfg, void* out) {
+    const size_t psz = G2 ? 128 : 64;
+    if (n_points != n_scalars) return set_err(ZK_ERR_LEN, "len(points) != len(scalars)");
+    ZK_TRY(check_cfg(cfg));
+    if (!out || (n_points && (!points || !scalars))) return set_err(ZK_ERR_ARG, "null pointer");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    size_t n = n_points, need = 0;
+    ZK_TRY(G2 ? msm_g2_need(n, cfg, st, &need) : msm_g1_need(n, cfg, st, &need));
+    ZK_TRY(g.s->reserve(n * (psz + 32) + 1024 + need));
+    void* d_p = g.s->alloc(n * psz + 16);
+    void* d_s = g.s->alloc(n * 32 + 16);
+    if (n) {
+        ZK_HIP(hipMemcpyAsync(d_p, points, n * psz, hipMemcpyHostToDevice, st));
+        ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, st));
+    }
+    if (G2) {
+        XYZZ<HFp2> t;
+        ZK_TRY(msm_g2_xyzz(g.s, st, d_p, d_s, n, cfg, &t));
+        write_affine(t, (zk_g2_affine*)out);
+    } else {
+        XYZZ<HFp> t;
+        ZK_TRY(msm_g1_xyzz(g.s, st, d_p, d_s, n, cfg, &t));
+        write_affine(t, (zk_g1_affine*)out);
+    }
+    return ZK_OK;
+}
+
+template <int G2>
+static int msm_dev_impl(const void* d_points, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, void* out, void* stream, int partial) {
+    ZK_TRY(check_cfg(cfg));
+    if (!out || (n && (!d_points || !d_scalars))) return set_err(ZK_ERR_ARG, "null pointer");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    size_t need = 0;
+    ZK_TRY(G2 ? msm_g2_need(n, cfg, st, &need) : msm_g1_need(n, cfg, st, &need));
+    ZK_TRY(g.s->reserve(need));
+    if (G2) {
+        XYZZ<HFp2> t;
+        ZK_TRY(msm_g2_xyzz(g.s, st, d_points, d_scalars, n, cfg, &t));
+        if (partial) memcpy(out, &t, sizeof(t)); else write_affine(t, (zk_g2_affine*)out);
+    } else {
+        XYZZ<HFp> t;
+        ZK_TRY(msm_g1_xyzz(g.s, st, d_points, d_scalars, n, cfg, &t));
+        if (partial) memcpy(out, &t, sizeof(t)); else write_affine(t, (zk_g1_affine*)out);
+    }
+    return ZK_OK;
+}
+
+extern "C" {
+
+int zk_bn254_g1_msm(const zk_g1_affine* points, size_t n_points, const zk_fr* scalars, size_t n_scalars, const zk_msm_cfg* cfg, zk_g1_affine* out) {
+    return msm_host_impl<0>(points, n_points, scalars, n_scalars, cfg, out);
+}
+int zk_bn254_g2_msm(const zk_g2_affine* points, size_t n_points, const zk_fr* scalars, size_t n_scalars, const zk_msm_cfg* cfg, zk_g2_affine* out) {
+    return msm_host_impl<1>(points, n_points, scalars, n_scalars, cfg, out);
+}
+int zk_bn254_g1_msm_dev(const void* d_points, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, zk_g1_affine* out_host, void* stream) {
+    return msm_dev_impl<0>(d_points, d_scalars, n, cfg, out_host, stream, 0);
+}
+int zk_bn254_g2_msm_dev(const void* d_points, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, zk_g2_affine* out_host, void* stream) {
+    return msm_dev_impl<1>(d_points, d_scalars, n, cfg, out_host, stream, 0);
+}
+int zk_bn254_g1_msm_partial_dev(const void* d_points, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, uint64_t out_xyzz[16], void* stream) {
+    return msm_dev_impl<0>(d_points, d_scalars, n, cfg, out_xyzz, stream, 1);
+}
+int zk_bn254_g2_msm_partial_dev(const void* d_points, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, uint64_t out_xyzz[32], void* stream) {
+    return msm_dev_impl<1>(d_points, d_scalars, n, cfg, out_xyzz, stream, 1);
+}
+int zk_bn254_g1_sum_xyzz(const uint64_t* partials, size_t n_partials, zk_g1_affine* out) {
+    if (!out || (n_partials && !partials)) return set_err(ZK_ERR_ARG, "null pointer");
+    XYZZ<HFp> t = XYZZ<HFp>::inf();
+    for (size_t i = 0; i < n_partials; i++) {
+        XYZZ<HFp> p;
+        memcpy(&p, partials + 16 * i, sizeof(p));
+        t.add(p);
+    }
+    write_affine(t, out);
+    return ZK_OK;
+}
+int zk_bn254_g2_sum_xyzz(const uint64_t* partials, size_t n_partials, zk_g2_affine* out) {
+    if (!out || (n_partials && !partials)) return set_err(ZK_ERR_ARG, "null pointer");
+    XYZZ<HFp2> t = XYZZ<HFp2>::inf();
+    for (size_t i = 0; i < n_partials; i++) {
+        XYZZ<HFp2> p;
+        memcpy(&p, partials + 32 * i, sizeof(p));
+        t.add(p);
+    }
+    write_affine(t, out);
+    return ZK_OK;
+}
+
+int zk_bn254_bases_register(const void* points, size_t n, int is_g2, uint64_t* handle) {
+    if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
+    ZK_TRY(ensure_init());
+    Bases b;
+    b.n = n;
+    b.is_g2 = is_g2 ? 1 : 0;
+    size_t bytes = n * (is_g2 ? 128 : 64);
+    ZK_HIP(hipMalloc(&b.d, bytes ? bytes : 16));
+    if (bytes) ZK_HIP(hipMemcpy(b.d, points, bytes, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    *handle = g_next_handle++;
+    g_bases[*handle] = b;
+    return ZK_OK;
+}
+int zk_bn254_bases_free(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
+    (void)hipFree(it->second.d);
+    g_bases.erase(it);
+    return ZK_OK;
+}
+int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr* scalars, size_t n, const zk_msm_cfg* cfg, void* out) {
+    Bases b;
+    {
+        std::lock_guard<std::mutex> lk(g_bases_mu);
+        auto it = g_bases.find(handle);
+        if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
+        b = it->second;
+    }
+    if (offset + n > b.n) return set_err(ZK_ERR_LEN, "len(points) != len(scalars): offset %zu + n %zu exceeds the %zu registered bases", offset, n, b.n);
+    ZK_TRY(check_cfg(cfg));
+    if (!out || (n && !scalars)) return set_err(ZK_ERR_ARG, "null pointer");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    size_t need = 0;
+    ZK_TRY(b.is_g2 ? msm_g2_need(n, cfg, st, &need) : msm_g1_need(n, cfg, st, &need));
+    ZK_TRY(g.s->reserve(n * 32 + 1024 + need));
+    void* d_s = g.s->alloc(n * 32 + 16);
+    if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, st));
+    if (b.is_g2) {
+        XYZZ<HFp2> t;
+        ZK_TRY(msm_g2_xyzz(g.s, st, (const char*)b.d + offset * 128, d_s, n, cfg, &t));
+        write_affine(t, (zk_g2_affine*)out);
+    } else {
+        XYZZ<HFp> t;
+        ZK_TRY(msm_g1_xyzz(g.s, st, (const char*)b.d + offset * 64, d_s, n, cfg, &t));
+        write_affine(t, (zk_g1_affine*)out);
+    }
+    return ZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,460 @@
+// Radix-2 NTT over BN254 Fr on gfx950, with the exact in-place semantics of gnark-crypto v0.9.1
+// `(*fft.Domain).FFT / FFTInverse` and `fft.BitReverse` (ecc/bn254/fr/fft; pinned at
+// /root/reference/gnark_backend_ffi/go.mod:5; reached through groth16.Prove main.go:131 and plonk.Prove
+// backend/plonk/plonk.go:67), plus gnark v0.8.0's `computeH` fused on the device.
+//
+// Structure: the log2(N) butterfly stages are grouped in passes; a pass keeps a tile of 2^k * L elements in LDS and
+// runs k stages on it (one workgroup per tile), so HBM is touched once per pass instead of once per stage.
+//   * tile  = every value of the k transformed index bits  x  L consecutive values of the lower bits  (so global
+//     loads/stores are L*32-byte contiguous runs; the pass over the lowest bits has L = 1 and is fully contiguous)
+//   * LDS layout = two uint4 arrays (low / high 16 bytes of each element): a wave reading consecutive elements
+//     issues conflict-free ds_read_b128 / ds_write_b128
+//   * the in-place DIF (natural -> bit-reversed) and DIT (bit-reversed -> natural) orders fall out of doing the
+//     butterflies in place -- there is no transpose and no separate permutation pass
+//   * coset / 1/N scalings are folded into the first stage's loads (pre table) or the last stage's stores (post)
+// Roofline: 64 B per element per transform algorithmic (read + write once).  On CDNA4 the transform is VALU-bound
+// (a 254-bit Montgomery product is ~136 quarter-rate v_mad_u64_u32), not HBM-bound -- see DESIGN.md.
+#include <vector>
+
+#include "ctx.hpp"
+#include "ff.hpp"
+#include "host_ff.hpp"
+#include "ntt.hpp"
+
+namespace zkmi {
+
+static constexpr unsigned TILE_LOG = 11;        // 2048 elements = 64 KiB of LDS per workgroup
+static constexpr unsigned K_STRIDED = 8;        // strided passes: k <= 8 with L = 8 (256-byte runs)
+static constexpr unsigned NTT_THREADS = 256;
+
+struct PowBasis {
+    Fr pw[28];  // base^(2^b)
+};
+
+__device__ __forceinline__ unsigned bitrev_u32(unsigned i, unsigned logn) { return logn ? (__brev(i) >> (32 - logn)) : 0; }
+
+// out[i] = scale * base^(i) or base^(bitrev(i))
+__global__ void k_pow_table(Fr* out, size_t n, unsigned logn, PowBasis basis, Fr scale, int reversed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned e = reversed ? bitrev_u32((unsigned)i, logn) : (unsigned)i;
+    Fr acc = scale;
+    for (unsigned b = 0; b < 28; b++)
+        if ((e >> b) & 1) acc = acc * basis.pw[b];
+    out[i] = acc;
+}
+
+struct PassArgs {
+    Fr* data;
+    const Fr* tw;        // w^i, i < N/2  (forward or inverse table)
+    const Fr* pre;       // multiply element i by pre[i] on entry of the pass's first stage (or null)
+    const Fr* post;      // multiply element i by post[i] on exit of the pass's last stage (or null)
+    Fr post_const;       // if has_post_const: multiply by this constant on exit
+    unsigned logn, bit_lo, k, logL;
+    int dif, has_post_const;
+};
+
+__device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, unsigned t) {
+    uint4 a = lo[t], b = hi[t];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_store(uint4* lo, uint4* hi, unsigned t, const Fr& v) {
+    lo[t] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    hi[t] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ Fr gload_fr(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs A) {
+    extern __shared__ uint4 lds[];
+    const unsigned E = 1u << (A.k + A.logL);
+    uint4* lo = lds;
+    uint4* hi = lds + E;
+    const unsigned L = 1u << A.logL;
+    const unsigned lo_blks = (1u << A.bit_lo) >> A.logL;  // >= 1
+    const size_t tile = blockIdx.x;
+    const size_t hi_idx = tile / lo_blks;
+    const unsigned lo_blk = (unsigned)(tile % lo_blks);
+    const size_t base = (hi_idx << (A.bit_lo + A.k)) + ((size_t)lo_blk << A.logL);
+    uint4* g = reinterpret_cast<uint4*>(A.data);
+
+    // ---- load tile: consecutive threads fetch consecutive 16-byte halves
+    for (unsigned h = threadIdx.x; h < 2 * E; h += NTT_THREADS) {
+        unsigned e = h >> 1, half = h & 1;
+        unsigned mid = e >> A.logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        uint4 v = g[gi * 2 + half];
+        (half ? hi : lo)[e] = v;
+    }
+    __syncthreads();
+
+    for (unsigned s = 0; s < A.k; s++) {
+        const unsigned q = A.dif ? (A.k - 1 - s) : s;  // tile bit handled by this stage
+        const unsigned b = A.bit_lo + q;               // global index bit
+        const bool first = (s == 0), last = (s + 1 == A.k);
+        for (unsigned u = threadIdx.x; u < (E >> 1); u += NTT_THREADS) {
+            unsigned l = u & (L - 1), r = u >> A.logL;
+            unsigned mid0 = ((r >> q) << (q + 1)) | (r & ((1u << q) - 1));
+            unsigned t0 = (mid0 << A.logL) + l, t1 = t0 + (L << q);
+            Fr x = lds_load(lo, hi, t0), y = lds_load(lo, hi, t1);
+            size_t g0 = base + ((size_t)mid0 << A.bit_lo) + l, g1 = g0 + ((size_t)1 << b);
+            if (first && A.pre) {
+                x = x * gload_fr(A.pre + g0);
+                y = y * gload_fr(A.pre + g1);
+            }
+            if (A.dif) {
+                Fr sum = x + y, dif = x - y;
+                if (b != 0) {
+                    size_t j = g0 & (((size_t)1 << b) - 1);
+                    dif = dif * gload_fr(A.tw + (j << (A.logn - 1 - b)));
+                }
+                x = sum;
+                y = dif;
+            } else {
+                if (b != 0) {
+                    size_t j = g0 & (((size_t)1 << b) - 1);
+                    y = y * gload_fr(A.tw + (j << (A.logn - 1 - b)));
+                }
+                Fr sum = x + y, dif = x - y;
+                x = sum;
+                y = dif;
+            }
+            if (last) {
+                if (A.post) {
+                    x = x * gload_fr(A.post + g0);
+                    y = y * gload_fr(A.post + g1);
+                } else if (A.has_post_const) {
+                    x = x * A.post_const;
+                    y = y * A.post_const;
+                }
+            }
+            lds_store(lo, hi, t0, x);
+            lds_store(lo, hi, t1, y);
+        }
+        __syncthreads();
+    }
+
+    for (unsigned h = threadIdx.x; h < 2 * E; h += NTT_THREADS) {
+        unsigned e = h >> 1, half = h & 1;
+        unsigned mid = e >> A.logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        g[gi * 2 + half] = (half ? hi : lo)[e];
+    }
+}
+
+// a[i] *= t[i]  (used when a transform has no stage to fold a scaling into: N == 1)
+__global__ void k_scale_table(Fr* a, const Fr* t, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = a[i] * gload_fr(t + i);
+}
+
+__global__ void k_bit_reverse(Fr* a, unsigned logn) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)1 << logn;
+    if (i >= n) return;
+    size_t j = bitrev_u32((unsigned)i, logn);
+    if (i < j) {
+        Fr x = gload_fr(a + i), y = gload_fr(a + j);
+        a[i] = y;
+        a[j] = x;
+    }
+}
+
+// h = (a*b - c) * den    (gnark computeH pointwise step)
+__global__ void k_h_pointwise(Fr* a, const Fr* b, const Fr* c, Fr den, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr x = gload_fr(a + i) * gload_fr(b + i) - gload_fr(c + i);
+    a[i] = x * den;
+}
+
+__global__ void k_fr_mul(Fr* out, const Fr* a, const Fr* b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gload_fr(a + i) * gload_fr(b + i);
+}
+
+// ---------------------------------------------------------------------------------------------- domain tables
+static const uint64_t ROOT_2_28_MONT[4] = {0x636e735580d13d9cULL, 0xa22bf3742445ffd6ULL, 0x56452ac01eb203d8ULL, 0x1860ef942963f9e7ULL};
+
+static std::mutex g_dom_mu;
+static std::map<unsigned, Domain*> g_domains;
+
+static Fr to_dev(const HFr& h) {
+    Fr r;
+    memcpy(&r, &h, 32);
+    return r;
+}
+
+static int make_pow_table(Slot* s, hipStream_t st, Fr** out, size_t n, unsigned logn, HFr base, HFr scale, int reversed) {
+    ZK_HIP(hipMalloc((void**)out, (n ? n : 1) * sizeof(Fr)));
+    PowBasis pb;
+    HFr p = base;
+    for (int b = 0; b < 28; b++) {
+        pb.pw[b] = to_dev(p);
+        p = p.sqr();
+    }
+    unsigned grid = (unsigned)((n + 255) / 256);
+    ZK_LAUNCH(s, st, "pow_table", k_pow_table, dim3(grid ? grid : 1), dim3(256), 0, *out, n, logn, pb, to_dev(scale), reversed);
+    return ZK_OK;
+}
+
+int get_domain(Slot* s, hipStream_t st, unsigned logn, unsigned need, Domain** out) {
+    if (logn > 28) return set_err(ZK_ERR_ARG, "log_n = %u exceeds Fr two-adicity 28", logn);
+    std::lock_guard<std::mutex> lk(g_dom_mu);
+    Domain*& d = g_domains[logn];
+    if (!d) {
+        d = new Domain();
+        d->logn = logn;
+        HFr w;
+        memcpy(&w, ROOT_2_28_MONT, 32);
+        for (unsigned i = logn; i < 28; i++) w = w.sqr();
+        d->gen = w;
+        d->gen_inv = w.inv();
+        HFr n = HFr{{(uint64_t)1 << logn, 0, 0, 0}}.to_mont();
+        d->card_inv = n.inv();
+        d->coset = HFr{{5, 0, 0, 0}}.to_mont();
+        d->coset_inv = d->coset.inv();
+    }
+    size_t N = (size_t)1 << logn, H = N > 1 ? N / 2 : 1;
+    bool made = false;
+    if ((need & DOM_TW) && !d->tw) { ZK_TRY(make_pow_table(s, st, &d->tw, H, logn, d->gen, HFr::one(), 0)); made = true; }
+    if ((need & DOM_TW_INV) && !d->tw_inv) { ZK_TRY(make_pow_table(s, st, &d->tw_inv, H, logn, d->gen_inv, HFr::one(), 0)); made = true; }
+    if ((need & DOM_COSET) && !d->coset_tab) { ZK_TRY(make_pow_table(s, st, &d->coset_tab, N, logn, d->coset, HFr::one(), 0)); made = true; }
+    if ((need & DOM_COSET_REV) && !d->coset_rev) { ZK_TRY(make_pow_table(s, st, &d->coset_rev, N, logn, d->coset, HFr::one(), 1)); made = true; }
+    if ((need & DOM_COSET_INV_N) && !d->coset_inv_n) { ZK_TRY(make_pow_table(s, st, &d->coset_inv_n, N, logn, d->coset_inv, d->card_inv, 0)); made = true; }
+    if ((need & DOM_COSET_INV_N_REV) && !d->coset_inv_n_rev) { ZK_TRY(make_pow_table(s, st, &d->coset_inv_n_rev, N, logn, d->coset_inv, d->card_inv, 1)); made = true; }
+    if ((need & DOM_COSET_REV_N) && !d->coset_rev_n) { ZK_TRY(make_pow_table(s, st, &d->coset_rev_n, N, logn, d->coset, d->card_inv, 1)); made = true; }
+    if (made) ZK_HIP(hipStreamSynchronize(st));  // tables are shared by every stream from here on
+    *out = d;
+    return ZK_OK;
+}
+
+// Runs the log2(N) stages of one transform as a sequence of tile passes.
+static int run_passes(Slot* s, hipStream_t st, Fr* data, unsigned logn, const Fr* tw, int dif, const Fr* pre, const Fr* post,
+                      const Fr* post_const) {
+    if (logn == 0) {
+        if (pre) ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3(1), dim3(64), 0, data, pre, (size_t)1);
+        if (post) ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3(1), dim3(64), 0, data, post, (size_t)1);
+        return ZK_OK;  // 1/N = 1
+    }
+    // split the index bits: the lowest kc bits form the contiguous pass (L = 1); the rest go to strided passes
+    unsigned kc = logn < TILE_LOG ? logn : TILE_LOG;
+    unsigned rest = logn - kc;
+    unsigned np = (rest + K_STRIDED - 1) / K_STRIDED;
+    struct P { unsigned bit_lo, k, logL; };
+    std::vector<P> passes;  // in increasing bit order
+    passes.push_back({0, kc, 0});
+    unsigned bit = kc;
+    for (unsigned i = 0; i < np; i++) {
+        unsigned k = (rest - (bit - kc) + (np - i) - 1) / (np - i);
+        unsigned logL = TILE_LOG - k;
+        if (logL > bit) logL = bit;
+        if (logL > 4) logL = 4;
+        passes.push_back({bit, k, logL});
+        bit += k;
+    }
+    size_t npass = passes.size();
+    for (size_t idx = 0; idx < npass; idx++) {
+        // DIF walks the bits from the top, DIT from the bottom
+        const P& p = dif ? passes[npass - 1 - idx] : passes[idx];
+        PassArgs A;
+        A.data = data; A.tw = tw; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
+        A.pre = (idx == 0) ? pre : nullptr;
+        A.post = (idx + 1 == npass) ? post : nullptr;
+        A.has_post_const = (idx + 1 == npass && post_const && !post) ? 1 : 0;
+        if (A.has_post_const) A.post_const = *post_const; else A.post_const = Fr::zero();
+        unsigned E = 1u << (p.k + p.logL);
+        size_t tiles = ((size_t)1 << logn) / E;
+        size_t shmem = (size_t)E * 32;
+        const char* name = p.logL ? "ntt_pass_strided" : "ntt_pass_contig";
+        ZK_LAUNCH(s, st, name, k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), shmem, A);
+    }
+    return ZK_OK;
+}
+
+static bool g_lds_attr_set = false;
+static int ensure_lds_attr() {
+    if (!g_lds_attr_set) {
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 32));
+        g_lds_attr_set = true;
+    }
+    return ZK_OK;
+}
+
+// (*Domain).FFT / FFTInverse on device memory
+int ntt_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn, int inverse, int decimation, int coset) {
+    ZK_TRY(ensure_lds_attr());
+    unsigned need = inverse ? DOM_TW_INV : DOM_TW;
+    if (coset) {
+        if (!inverse) need |= (decimation == ZK_DIT) ? DOM_COSET_REV : DOM_COSET;
+        else need |= (decimation == ZK_DIT) ? DOM_COSET_INV_N : DOM_COSET_INV_N_REV;
+    }
+    Domain* d;
+    ZK_TRY(get_domain(s, st, logn, need, &d));
+    int dif = (decimation == ZK_DIF);
+    if (!inverse) {
+        // FFT: coset scaling first -- DIF by CosetTable[i], DIT (bit-reversed memory order) by CosetTableReversed[i]
+        const Fr* pre = coset ? (dif ? d->coset_tab : d->coset_rev) : nullptr;
+        return run_passes(s, st, d_a, logn, d->tw, dif, pre, nullptr, nullptr);
+    }
+    // FFTInverse: TwiddlesInv, then * CardinalityInv (and CosetTableInv[i] for DIT / CosetTableInvReversed[i] for DIF)
+    const Fr* post = coset ? (dif ? d->coset_inv_n_rev : d->coset_inv_n) : nullptr;
+    Fr cinv = to_dev(d->card_inv);
+    return run_passes(s, st, d_a, logn, d->tw_inv, dif, nullptr, post, &cinv);
+}
+
+int bit_reverse_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn) {
+    size_t n = (size_t)1 << logn;
+    ZK_LAUNCH(s, st, "bit_reverse", k_bit_reverse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_a, logn);
+    return ZK_OK;
+}
+
+// gnark v0.8.0 computeH on device buffers a (in/out, N), b, c (scratch, N); result left in a, bit-reversed order.
+//   3 x FFTInverse(DIF) ; 3 x FFT(DIT, coset) ; a = (a*b - c) / (g^N - 1) ; FFTInverse(a, DIF, coset)
+// The 1/N of the first inverse and the coset pre-scale g^bitrev(i) of the following forward transform are one
+// table (coset_rev_n) applied while the inverse transform stores its last stage.
+int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned logN) {
+    ZK_TRY(ensure_lds_attr());
+    Domain* d;
+    ZK_TRY(get_domain(s, st, logN, DOM_TW | DOM_TW_INV | DOM_COSET_REV_N | DOM_COSET_INV_N_REV, &d));
+    size_t N = (size_t)1 << logN;
+    for (Fr* v : {a, b, c}) {
+        ZK_TRY(run_passes(s, st, v, logN, d->tw_inv, 1, nullptr, d->coset_rev_n, nullptr));
+        ZK_TRY(run_passes(s, st, v, logN, d->tw, 0, nullptr, nullptr, nullptr));
+    }
+    // den = 1 / (g^N - 1)
+    HFr gN = d->coset;
+    for (unsigned i = 0; i < logN; i++) gN = gN.sqr();
+    HFr den = (gN - HFr::one()).inv();
+    ZK_LAUNCH(s, st, "h_pointwise", k_h_pointwise, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)b, (const Fr*)c, to_dev(den), N);
+    ZK_TRY(run_passes(s, st, a, logN, d->tw_inv, 1, nullptr, d->coset_inv_n_rev, nullptr));
+    return ZK_OK;
+}
+
+int fr_mul_dev(Slot* s, hipStream_t st, Fr* out, const Fr* a, const Fr* b, size_t n) {
+    ZK_LAUNCH(s, st, "fr_mul", k_fr_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, out, a, b, n);
+    return ZK_OK;
+}
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int zk_bn254_ntt_dev(void* d_a, uint32_t log_n, int inverse, int decimation, int coset, void* stream) {
+    if (!d_a) return set_err(ZK_ERR_ARG, "null data pointer");
+    if (log_n > 28) return set_err(ZK_ERR_ARG, "log_n = %u exceeds Fr two-adicity 28", log_n);
+    if (decimation != ZK_DIT && decimation != ZK_DIF) return set_err(ZK_ERR_ARG, "decimation must be ZK_DIT or ZK_DIF");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    ZK_TRY(ntt_dev(g.s, st, (Fr*)d_a, log_n, inverse, decimation, coset));
+    // no workspace is used: safe to return without synchronising a caller-provided stream
+    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    return ZK_OK;
+}
+
+int zk_bn254_ntt(zk_fr* a, uint32_t log_n, int inverse, int decimation, int coset) {
+    if (!a) return set_err(ZK_ERR_ARG, "null data pointer");
+    if (log_n > 28) return set_err(ZK_ERR_ARG, "log_n = %u exceeds Fr two-adicity 28", log_n);
+    if (decimation != ZK_DIT && decimation != ZK_DIF) return set_err(ZK_ERR_ARG, "decimation must be ZK_DIT or ZK_DIF");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    size_t bytes = ((size_t)1 << log_n) * 32;
+    ZK_TRY(g.s->reserve(bytes));
+    Fr* d = (Fr*)g.s->alloc(bytes);
+    hipStream_t st = g.s->stream;
+    ZK_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, st));
+    ZK_TRY(ntt_dev(g.s, st, d, log_n, inverse, decimation, coset));
+    ZK_HIP(hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, st));
+    return slot_sync(g.s, st);
+}
+
+int zk_bn254_bit_reverse_dev(void* d_a, uint32_t log_n, void* stream) {
+    if (!d_a || log_n > 28) return set_err(ZK_ERR_ARG, "bad argument");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    ZK_TRY(bit_reverse_dev(g.s, st, (Fr*)d_a, log_n));
+    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    return ZK_OK;
+}
+
+int zk_bn254_bit_reverse(zk_fr* a, uint32_t log_n) {
+    if (!a || log_n > 28) return set_err(ZK_ERR_ARG, "bad argument");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    size_t bytes = ((size_t)1 << log_n) * 32;
+    ZK_TRY(g.s->reserve(bytes));
+    Fr* d = (Fr*)g.s->alloc(bytes);
+    hipStream_t st = g.s->stream;
+    ZK_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, st));
+    ZK_TRY(bit_reverse_dev(g.s, st, d, log_n));
+    ZK_HIP(hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, st));
+    return slot_sync(g.s, st);
+}
+
+int zk_bn254_groth16_compute_h_dev(const void* d_a, const void* d_b, const void* d_c, size_t n, uint32_t log_N, void* d_h_out, void* stream) {
+    if (!d_a || !d_b || !d_c || !d_h_out) return set_err(ZK_ERR_ARG, "null pointer");
+    if (log_N > 28) return set_err(ZK_ERR_ARG, "log_N exceeds 28");
+    size_t N = (size_t)1 << log_N;
+    if (n > N) return set_err(ZK_ERR_ARG, "n = %zu exceeds the domain size %zu", n, N);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    ZK_TRY(g.s->reserve(2 * N * 32 + 512));
+    Fr* a = (Fr*)d_h_out;
+    Fr* b = (Fr*)g.s->alloc(N * 32);
+    Fr* c = (Fr*)g.s->alloc(N * 32);
+    const void* src[3] = {d_a, d_b, d_c};
+    Fr* dst[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) {
+        if (src[i] != dst[i]) ZK_HIP(hipMemcpyAsync(dst[i], src[i], n * 32, hipMemcpyDeviceToDevice, st));
+        if (n < N) ZK_HIP(hipMemsetAsync(dst[i] + n, 0, (N - n) * 32, st));
+    }
+    ZK_TRY(compute_h_inplace(g.s, st, a, b, c, log_N));
+    return slot_sync(g.s, st);  // scratch lives in the slot's arena
+}
+
+int zk_bn254_groth16_compute_h(const zk_fr* a, const zk_fr* b, const zk_fr* c, size_t n, uint32_t log_N, zk_fr* h_out) {
+    if (!a || !b || !c || !h_out) return set_err(ZK_ERR_ARG, "null pointer");
+    if (log_N > 28) return set_err(ZK_ERR_ARG, "log_N exceeds 28");
+    size_t N = (size_t)1 << log_N;
+    if (n > N) return set_err(ZK_ERR_ARG, "n = %zu exceeds the domain size %zu", n, N);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    ZK_TRY(g.s->reserve(3 * N * 32 + 1024));
+    Fr* d[3];
+    const zk_fr* src[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) {
+        d[i] = (Fr*)g.s->alloc(N * 32);
+        ZK_HIP(hipMemcpyAsync(d[i], src[i], n * 32, hipMemcpyHostToDevice, st));
+        if (n < N) ZK_HIP(hipMemsetAsync(d[i] + n, 0, (N - n) * 32, st));
+    }
+    ZK_TRY(compute_h_inplace(g.s, st, d[0], d[1], d[2], log_N));
+    ZK_HIP(hipMemcpyAsync(h_out, d[0], N * 32, hipMemcpyDeviceToHost, st));
+    return slot_sync(g.s, st);
+}
+
+int zk_bn254_fr_mul_dev(void* d_out, const void* d_a, const void* d_b, size_t n, void* stream) {
+    if (!d_out || !d_a || !d_b) return set_err(ZK_ERR_ARG, "null pointer");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    ZK_TRY(fr_mul_dev(g.s, st, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n));
+    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    return ZK_OK;
+}
+
+}  // extern "C"

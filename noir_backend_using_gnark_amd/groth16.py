@@ -1,0 +1,81 @@
+"""Host-side mirror of gnark v0.8.0 groth16 prove for the hot path (pinned at /root/reference/gnark_backend_ffi/go.mod:23;
+the reference's live call is groth16.Prove at /root/reference/gnark_backend_ffi/main.go:131; the FFI it intended is the
+commented-out ProveWithPK at backend/groth16/r1cs.go:107-143).  `prove` takes what gnark's prover has after
+`r1cs.Solve`: the evaluation vectors a, b, c and the wire values w -- plus the randomness (r, s) as explicit inputs."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Groth16PK, check, lib, vp
+
+
+class ProvingKey:
+    """groth16.ProvingKey{G1{Alpha,Beta,Delta,A,B,K,Z}, G2{Beta,Delta,B}} resident in HBM.
+
+    Arrays are gnark memory images (numpy uint64) or, with bases_on_device=True, raw device pointers for the five
+    base arrays (used by the benchmark, whose bases are generated on the device)."""
+
+    def __init__(self, log_domain: int, n_wires: int, n_public: int, g1_alpha, g1_beta, g1_delta, g1_a, g1_b, g1_k, g1_z,
+                 g2_beta, g2_delta, g2_b, bases_on_device: bool = False):
+        self.log_domain, self.n_wires, self.n_public = log_domain, n_wires, n_public
+        self._keep = []
+
+        def host(a):
+            a = np.ascontiguousarray(a, dtype=np.uint64)
+            self._keep.append(a)
+            return a.ctypes.data
+
+        def base(a):
+            if bases_on_device:
+                return int(a.ptr if isinstance(a, _lib.DeviceBuffer) else a)
+            return host(a) if np.asarray(a).size else 0
+
+        pk = Groth16PK(log_domain, n_wires, n_public, host(g1_alpha), host(g1_beta), host(g1_delta), base(g1_a), base(g1_b),
+                       base(g1_k), base(g1_z), host(g2_beta), host(g2_delta), base(g2_b), 1 if bases_on_device else 0)
+        if bases_on_device:
+            self._keep += [g1_a, g1_b, g1_k, g1_z, g2_b]  # keep DeviceBuffers alive
+        self.handle = C.c_uint64(0)
+        check(lib().zk_bn254_groth16_pk_load(C.byref(pk), C.byref(self.handle)))
+
+    def free(self):
+        if self.handle.value:
+            lib().zk_bn254_groth16_pk_free(self.handle)
+            self.handle = C.c_uint64(0)
+
+
+def _ptr(x):
+    if isinstance(x, _lib.DeviceBuffer):
+        return C.c_void_p(x.ptr)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return vp(np.ascontiguousarray(x, dtype=np.uint64))
+
+
+def prove(pk: ProvingKey, a, b, c, w, r, s, n_constraints: int | None = None, on_device: bool = False) -> bytes:
+    """groth16.Prove from the solver output: returns Proof.WriteTo bytes (Ar | Bs | Krs compressed, 128 B)."""
+    if not on_device:
+        a, b, c, w = (np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4) for v in (a, b, c, w))
+        if not (a.shape == b.shape == c.shape):
+            raise ValueError("a, b, c must have the same length")
+        if w.shape[0] != pk.n_wires:
+            raise ValueError("len(w) = %d != n_wires %d" % (w.shape[0], pk.n_wires))
+        n_constraints = a.shape[0]
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+    s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+    proof = (C.c_uint8 * 128)()
+    check(lib().zk_bn254_groth16_prove(pk.handle, _ptr(a), _ptr(b), _ptr(c), C.c_size_t(n_constraints), _ptr(w), vp(r), vp(s),
+                                       C.c_int(int(on_device)), proof))
+    return bytes(proof)
+
+
+def compute_h(a, b, c, log_domain: int) -> np.ndarray:
+    """gnark's computeH(a, b, c, domain): (N, 4) coefficients of h in the (bit-reversed) order upstream leaves them."""
+    a, b, c = (np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4) for v in (a, b, c))
+    if not (a.shape == b.shape == c.shape):
+        raise ValueError("a, b, c must have the same length")
+    h = np.zeros((1 << log_domain, 4), dtype=np.uint64)
+    check(lib().zk_bn254_groth16_compute_h(vp(a), vp(b), vp(c), C.c_size_t(a.shape[0]), C.c_uint32(log_domain), vp(h)))
+    return h

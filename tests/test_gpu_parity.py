@@ -1,0 +1,280 @@
+"""GPU parity suite (-m gpu): the HIP path, called through the C ABI (libzkmi.so via ctypes), against the CPU oracle on the
+same seeded inputs, against the committed golden vectors, and -- at BASELINE sizes -- through size-independent properties.
+Bit-exact everywhere: this path is integer arithmetic only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import noir_backend_using_gnark_amd as zk
+from noir_backend_using_gnark_amd import _lib
+from noir_backend_using_gnark_amd import bn254 as zb
+from oracle import bn254_ref as ref
+from oracle import oracle as orc
+from tests.helpers import (from_mont_limbs, g1_points_from_scalars, g2_points_from_scalars, golden_pk, h2i, mont_limbs, sha_image)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    _lib.require_device()  # fail loudly: no silent fallback
+
+
+# ------------------------------------------------------------------------------------------------ field / generators
+def test_fr_mul_on_device_matches_oracle():
+    n = 4096
+    a, b = orc.rand_fr(101, n), orc.rand_fr(102, n)
+    edge = mont_limbs([0, 1, ref.R - 1, ref.R - 2, 2, (ref.R - 1) // 2, ref.MONT_R % ref.R, 3])
+    a[:8] = edge
+    b[:8] = edge[::-1]
+    da, db, do = _lib.DeviceBuffer.from_numpy(a), _lib.DeviceBuffer.from_numpy(b), _lib.DeviceBuffer(n * 32)
+    _lib.check(_lib.lib().zk_bn254_fr_mul_dev(C.c_void_p(do.ptr), C.c_void_p(da.ptr), C.c_void_p(db.ptr), C.c_size_t(n), None))
+    got = do.to_numpy(np.uint64, (n, 4))
+    exp = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(n)])
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("mont", [0, 1])
+@pytest.mark.parametrize("witness", [0, 1])
+def test_fr_random_matches_oracle(mont, witness):
+    n = 3000
+    d = _lib.DeviceBuffer(n * 32)
+    _lib.check(_lib.lib().zk_bn254_fr_random_dev(C.c_void_p(d.ptr), C.c_size_t(n), C.c_uint64(0xC0FFEE), C.c_int(mont), C.c_int(witness), None))
+    assert (d.to_numpy(np.uint64, (n, 4)) == orc.rand_fr(0xC0FFEE, n, mont=bool(mont), witness_like=bool(witness))).all()
+
+
+def test_generate_points_match_oracle():
+    n = 96
+    d1, d2 = _lib.DeviceBuffer(n * 64), _lib.DeviceBuffer(n * 128)
+    _lib.check(_lib.lib().zk_bn254_g1_generate_dev(C.c_void_p(d1.ptr), C.c_size_t(n), C.c_uint64(77), None))
+    _lib.check(_lib.lib().zk_bn254_g2_generate_dev(C.c_void_p(d2.ptr), C.c_size_t(n), C.c_uint64(77), None))
+    p1, p2 = d1.to_numpy(np.uint64, (n, 8)), d2.to_numpy(np.uint64, (n, 16))
+    assert (p1 == orc.g1_gen_points(77, n)).all()
+    assert (p2 == orc.g2_gen_points(77, n)).all()
+    assert all(orc.g1_on_curve(p) for p in p1[:8]) and all(orc.g2_on_curve(p) for p in p2[:8])
+
+
+# ------------------------------------------------------------------------------------------------ NTT
+def test_ntt_golden_modes(golden):
+    for e in golden["ntt"]:
+        if e["kind"] == "survey_ntt4":
+            x = mont_limbs([h2i(v) for v in e["input"]])
+            zk.Domain(4).fft(x, zk.DIF)
+            assert from_mont_limbs(x) == [h2i(v) for v in e["dif"]]
+            zk.bit_reverse(x)
+            assert from_mont_limbs(x) == [h2i(v) for v in e["natural"]]
+            continue
+        n = 1 << e["log_n"]
+        x = mont_limbs(ref.rand_felts(e["seed"], n))
+        d = zk.Domain(n)
+        (d.fft_inverse if e["inverse"] else d.fft)(x, e["decimation"], bool(e["coset"]))
+        assert sha_image(x) == e["sha256"], e
+        if "output" in e:
+            assert from_mont_limbs(x) == [h2i(v) for v in e["output"]]
+
+
+@pytest.mark.parametrize("log_n", [11, 12, 14, 16, 19, 20])
+def test_ntt_vs_oracle_all_modes(log_n):
+    n = 1 << log_n
+    x = orc.rand_fr(500 + log_n, n)
+    modes = [(i, d, c) for i in (0, 1) for d in (zk.DIT, zk.DIF) for c in (0, 1)]
+    if log_n >= 19:
+        modes = [(0, zk.DIF, 0), (1, zk.DIF, 0), (0, zk.DIT, 1), (1, zk.DIF, 1)]  # the four combinations computeH uses
+    dom = zk.Domain(n)
+    for inverse, dec, coset in modes:
+        y = x.copy()
+        (dom.fft_inverse if inverse else dom.fft)(y, dec, bool(coset))
+        exp = orc.fr_ntt(x, bool(inverse), dec, bool(coset))
+        assert (y == exp).all(), (log_n, inverse, dec, coset)
+
+
+def test_ntt_roundtrip_full_size_on_device():
+    """2^22: FFTInverse(DIT) . FFT(DIF) == identity, data resident in HBM (size-independent property)."""
+    log_n = 22
+    n = 1 << log_n
+    d = _lib.DeviceBuffer(n * 32)
+    _lib.check(_lib.lib().zk_bn254_fr_random_dev(C.c_void_p(d.ptr), C.c_size_t(n), C.c_uint64(9), C.c_int(1), C.c_int(0), None))
+    x0 = d.to_numpy(np.uint64, (n, 4))
+    dom = zk.Domain(n)
+    for coset in (False, True):
+        dom.fft(d, zk.DIF, coset)
+        mid = d.to_numpy(np.uint64, (n, 4))
+        assert not (mid == x0).all()
+        dom.fft_inverse(d, zk.DIT, coset)
+        assert (d.to_numpy(np.uint64, (n, 4)) == x0).all()
+    # spot check against the oracle on the same input (transform of size 2^22 takes the oracle a few seconds)
+    dom.fft(d, zk.DIF)
+    assert sha_image(d.to_numpy(np.uint64, (n, 4))) == sha_image(orc.fr_ntt(x0, False, orc.DIF))
+
+
+def test_bit_reverse():
+    for log_n in (0, 1, 5, 13):
+        x = orc.rand_fr(3, 1 << log_n)
+        y = x.copy()
+        zk.bit_reverse(y)
+        assert (y == orc.fr_bit_reverse(x)).all()
+
+
+def test_ntt_argument_errors():
+    with pytest.raises(ValueError):
+        zk.Domain(8).fft(np.zeros((4, 4), np.uint64), zk.DIF)
+    with pytest.raises(ValueError):
+        zk.Domain(8).fft(np.zeros((8, 4), np.uint64), 7)
+    with pytest.raises(ValueError):
+        zk.Domain(1 << 29)
+
+
+# ------------------------------------------------------------------------------------------------ MSM
+@pytest.mark.parametrize("c", [0, 4, 9, 16])
+def test_msm_golden(golden, c):
+    for e in golden["msm"]:
+        pts1 = g1_points_from_scalars([h2i(x) for x in e["point_scalars"]])
+        pts2 = g2_points_from_scalars([h2i(x) for x in e["point_scalars"]])
+        sc = [h2i(x) for x in e["scalars"]]
+        cfg = zk.MultiExpConfig(window_bits=c)
+        assert zk.g1_multi_exp(pts1, mont_limbs(sc), cfg).tobytes().hex() == e["g1"], (e["kind"], c)
+        assert zk.g2_multi_exp(pts2, mont_limbs(sc), cfg).tobytes().hex() == e["g2"], (e["kind"], c)
+        cfg2 = zk.MultiExpConfig(window_bits=c, scalars_mont=False)
+        assert zk.g1_multi_exp(pts1, orc.ints_to_limbs(sc), cfg2).tobytes().hex() == e["g1"]
+
+
+def test_msm_errors_and_empty():
+    p, s = np.zeros((3, 8), np.uint64), np.zeros((2, 4), np.uint64)
+    with pytest.raises(ValueError, match=r"len\(points\) != len\(scalars\)"):
+        zk.g1_multi_exp(p, s)
+    with pytest.raises(ValueError, match="NbTasks"):
+        zk.g1_multi_exp(p, np.zeros((3, 4), np.uint64), zk.MultiExpConfig(nb_tasks=2000))
+    assert (zk.g1_multi_exp(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)) == 0).all()
+    assert (zk.g2_multi_exp(np.zeros((0, 16), np.uint64), np.zeros((0, 4), np.uint64)) == 0).all()
+    # all-zero scalars, all-infinity points
+    pts = orc.g1_gen_points(1, 10)
+    assert (zk.g1_multi_exp(pts, np.zeros((10, 4), np.uint64)) == 0).all()
+    assert (zk.g1_multi_exp(np.zeros((10, 8), np.uint64), orc.rand_fr(2, 10)) == 0).all()
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (63, 3), (1000, 4), (4097, 5), (1 << 16, 6)])
+def test_g1_msm_vs_oracle_uniform(n, seed):
+    pts, sc = orc.g1_gen_points(seed, n), orc.rand_fr(seed + 100, n)
+    assert (zk.g1_multi_exp(pts, sc) == orc.g1_msm(pts, sc)).all()
+
+
+@pytest.mark.parametrize("n,c", [(20000, 0), (20000, 16), (3000, 5)])
+def test_g1_msm_witness_like_heavy_buckets(n, c):
+    """50% of the scalars in {0,1}: one bucket holds a quarter of all points (exercises task splitting + fold)."""
+    pts, sc = orc.g1_gen_points(11, n), orc.rand_fr(12, n, witness_like=True)
+    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=c)) == orc.g1_msm(pts, sc)).all()
+
+
+def test_g1_msm_collisions_and_cancellation():
+    """Repeated points (P+P -> doubling inside a bucket), P + (-P) -> infinity inside a bucket, all scalars equal."""
+    n = 512
+    base = orc.g1_gen_points(21, 4)
+    pts = np.tile(base, (n // 4, 1))
+    sc = np.tile(orc.rand_fr(22, 1), (n, 1))
+    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=8)) == orc.g1_msm(pts, sc)).all()
+    # scalars s and r - s on the same point cancel
+    s_int = ref.rand_felts(23, n // 2)
+    sc2 = mont_limbs(s_int + [(ref.R - v) % ref.R for v in s_int])
+    pts2 = np.concatenate([orc.g1_gen_points(24, n // 2)] * 2)
+    assert (zk.g1_multi_exp(pts2, sc2) == 0).all()
+    assert (orc.g1_msm(pts2, sc2) == 0).all()
+
+
+@pytest.mark.parametrize("n,witness", [(1, False), (500, False), (5000, True), (1 << 14, False)])
+def test_g2_msm_vs_oracle(n, witness):
+    pts, sc = orc.g2_gen_points(31, n), orc.rand_fr(32, n, witness_like=witness)
+    assert (zk.g2_multi_exp(pts, sc) == orc.g2_msm(pts, sc)).all()
+
+
+def test_msm_resident_bases_and_device_pointers():
+    n = 5000
+    pts, sc = orc.g1_gen_points(41, n), orc.rand_fr(42, n)
+    exp = orc.g1_msm(pts, sc)
+    rb = zb.ResidentBases(pts)
+    assert (rb.multi_exp(sc) == exp).all()
+    assert (rb.multi_exp(sc[100:600], offset=100) == orc.g1_msm(pts[100:600], sc[100:600])).all()
+    with pytest.raises(ValueError):
+        rb.multi_exp(sc, offset=1)
+    rb.free()
+    dp, ds = _lib.DeviceBuffer.from_numpy(pts), _lib.DeviceBuffer.from_numpy(sc)
+    assert (zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n) == exp).all()
+    # range-sharded partials (what two ranks would compute) combine to the same point
+    h = n // 2
+    parts = np.stack([zb.g1_multi_exp_dev(dp.ptr, ds.ptr, h, partial=True),
+                      zb.g1_multi_exp_dev(dp.ptr + h * 64, ds.ptr + h * 32, n - h, partial=True)])
+    assert (zb.g1_sum_partials(parts) == exp).all()
+    p2 = orc.g2_gen_points(43, 300)
+    d2, s2 = _lib.DeviceBuffer.from_numpy(p2), _lib.DeviceBuffer.from_numpy(sc[:300])
+    parts2 = np.stack([zb.g2_multi_exp_dev(d2.ptr, s2.ptr, 100, partial=True), zb.g2_multi_exp_dev(d2.ptr + 100 * 128, s2.ptr + 100 * 32, 200, partial=True)])
+    assert (zb.g2_sum_partials(parts2) == orc.g2_msm(p2, sc[:300])).all()
+
+
+def test_g1_msm_full_size_properties():
+    """2^20 points generated on the device: (1) result equals the multi-threaded oracle's; (2) homogeneity
+    MSM(P, k*s) == k * MSM(P, s) with the scalars scaled on the device."""
+    n = 1 << 20
+    L = _lib.lib()
+    dp, ds, dk, dks = (_lib.DeviceBuffer(n * 64), _lib.DeviceBuffer(n * 32), _lib.DeviceBuffer(n * 32), _lib.DeviceBuffer(n * 32))
+    _lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(dp.ptr), C.c_size_t(n), C.c_uint64(0xB1), None))
+    _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0xC), C.c_int(1), C.c_int(0), None))
+    k = orc.rand_fr(0xD, 1)
+    dk_host = np.tile(k, (n, 1))
+    _lib.check(L.zk_dev_h2d(C.c_void_p(dk.ptr), dk_host.ctypes.data_as(C.c_void_p), C.c_size_t(n * 32)))
+    _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(dks.ptr), C.c_void_p(ds.ptr), C.c_void_p(dk.ptr), C.c_size_t(n), None))
+    r1 = zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n)
+    r2 = zb.g1_multi_exp_dev(dp.ptr, dks.ptr, n)
+    assert orc.g1_on_curve(r1)
+    assert (orc.g1_mul(r1, k[0]) == r2).all()
+    pts, sc = dp.to_numpy(np.uint64, (n, 8)), ds.to_numpy(np.uint64, (n, 4))
+    assert (orc.g1_msm(pts, sc) == r1).all()
+    # witness-like scalars at full size
+    _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0xC), C.c_int(1), C.c_int(1), None))
+    assert (zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n) == orc.g1_msm(pts, ds.to_numpy(np.uint64, (n, 4)))).all()
+
+
+# ------------------------------------------------------------------------------------------------ Groth16
+def test_compute_h_golden_and_oracle(golden):
+    for e in golden["compute_h"]:
+        a, b, c = (mont_limbs(ref.rand_felts(s, e["n"])) for s in e["seeds"])
+        assert sha_image(zk.compute_h(a, b, c, e["log_n"])) == e["sha256"]
+    for log_n, n in ((12, 4000), (16, 1 << 16)):
+        a, b, c = orc.rand_fr(1, n), orc.rand_fr(2, n), orc.rand_fr(3, n)
+        assert (zk.compute_h(a, b, c, log_n) == orc.groth16_compute_h(a, b, c, log_n)).all()
+
+
+def test_groth16_golden_proofs(golden):
+    """Byte-identical 128-B proofs on the committed instances (each verified by the independent pairing check when
+    the fixture was generated), incl. the reference's own toy circuit X*Y=Z (main.go:80-107)."""
+    for e in golden["groth16"]:
+        pkd = golden_pk(e)
+        pk = zk.ProvingKey(pkd["log_domain"], pkd["n_wires"], pkd["n_public"], pkd["g1_alpha"], pkd["g1_beta"], pkd["g1_delta"], pkd["g1_a"],
+                           pkd["g1_b"], pkd["g1_k"], pkd["g1_z"], pkd["g2_beta"], pkd["g2_delta"], pkd["g2_b"])
+        a, b, c, w = (mont_limbs([h2i(v) for v in e[k]]) for k in ("a", "b", "c", "w"))
+        r, s = mont_limbs([h2i(e["r"])])[0], mont_limbs([h2i(e["s"])])[0]
+        assert zk.prove(pk, a, b, c, w, r, s).hex() == e["proof"], e["name"]
+        pk.free()
+
+
+@pytest.mark.parametrize("log_n,witness", [(10, False), (14, True)])
+def test_groth16_prove_vs_oracle_random_pk(log_n, witness):
+    """Synthetic proving key (random valid bases, like bench.py's workload): GPU proof bytes == oracle proof bytes."""
+    N = 1 << log_n
+    n_wires, n_public = N - 3, 5
+    pkd = dict(log_domain=log_n, n_wires=n_wires, n_public=n_public,
+               g1_alpha=orc.g1_gen_points(1, 1)[0], g1_beta=orc.g1_gen_points(2, 1)[0], g1_delta=orc.g1_gen_points(3, 1)[0],
+               g1_a=orc.g1_gen_points(4, n_wires), g1_b=orc.g1_gen_points(5, n_wires), g1_k=orc.g1_gen_points(6, n_wires - n_public),
+               g1_z=orc.g1_gen_points(7, N), g2_beta=orc.g2_gen_points(8, 1)[0], g2_delta=orc.g2_gen_points(9, 1)[0],
+               g2_b=orc.g2_gen_points(10, n_wires))
+    pkd["g1_a"][7] = 0  # points at infinity in A / B (gnark's InfinityA / InfinityB case)
+    pkd["g1_b"][11] = 0
+    pkd["g2_b"][11] = 0
+    n_cons = N - 10
+    a, b = orc.rand_fr(20, n_cons), orc.rand_fr(21, n_cons)
+    c = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(n_cons)])
+    w = orc.rand_fr(22, n_wires, witness_like=witness)
+    r, s = orc.rand_fr(23, 1)[0], orc.rand_fr(24, 1)[0]
+    exp, _ = orc.groth16_prove(pkd, a, b, c, w, r, s)
+    pk = zk.ProvingKey(**pkd)
+    assert zk.prove(pk, a, b, c, w, r, s) == exp
+    pk.free()
