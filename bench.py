@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- Groth16 prove (BN254) on synthetic R1CS data, BASELINE.json config 2 at N=1 GPU:
+"Synthetic R1CS 2^20 constraints, BN254 Groth16 prove on 1xMI355X (G1 MSM + Fr NTT)".
+
+One step = one proof from the solver output onwards (computeH = 7 NTTs, 4 G1 MSMs, 1 G2 MSM, host tail), inputs already
+resident in HBM.  --gpus N > 1 (one process per GPU, torchrun): the same proof over N * 2^log_n constraints with every
+MSM range-sharded over the ranks (weak scaling in the MSMs; computeH is replicated -- there is no distributed NTT yet);
+the only collective is an all-gather of the 768-byte partial-sum record per proof (RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric / value / unit follow BASELINE.json; `roofline`
+describes the dominant kernel (hipEvent pairs recorded inside libzkmi on the stream the kernels run on, live over the
+timed region); `cpu_baseline` is the CPU oracle (a restatement of gnark's algorithm, NOT the gnark binary: no Go toolchain
+here) timed on this box's host cores on the SAME proof -- whose bytes are compared with the GPU's (parity at full size).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+GOLDEN = 0x9E3779B97F4A7C15
+MASK = (1 << 64) - 1
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def seed_at(seed: int, per: int, offset: int) -> int:
+    """SplitMix64 stream `seed` advanced so that element 0 of the new stream is element `offset` of the old one
+    (per = outputs consumed per element: 4 uniform, 5 witness-like)."""
+    return (seed + per * offset * GOLDEN) & MASK
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20, help="log2(constraints) per GPU")
+    ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import noir_backend_using_gnark_amd as zk
+    from noir_backend_using_gnark_amd import _lib, parallel as par
+    from noir_backend_using_gnark_amd import bn254 as zb
+
+    rank, world, local = par.init_distributed()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    L = _lib.lib()
+    _lib.check(L.zk_init(C.c_int(local)))
+    torch.cuda.set_device(local)
+    _lib.require_device()
+
+    log_n = args.log_n
+    log_ng = log_n + (world.bit_length() - 1)
+    if (1 << (log_ng - log_n)) != world:
+        raise SystemExit("--gpus must be a power of two")
+    N_loc, N_g = 1 << log_n, 1 << log_ng
+    n_public = 8
+    witness = 1 if args.scalars == "witness" else 0
+    lo, hi = par.shard_range(N_g, rank, world)  # this rank's slice of every wire-indexed / coefficient-indexed array
+    assert hi - lo == N_loc
+
+    def dev(nbytes):
+        return _lib.DeviceBuffer(nbytes)
+
+    def gen_g1(seed, n, off):
+        b = dev(n * 64)
+        _lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 4, off)), None))
+        return b
+
+    def gen_g2(seed, n, off):
+        b = dev(n * 128)
+        _lib.check(L.zk_bn254_g2_generate_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 4, off)), None))
+        return b
+
+    def gen_fr(seed, n, off, wit=0):
+        b = dev(n * 32)
+        _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 5 if wit else 4, off)), C.c_int(1), C.c_int(wit), None))
+        return b
+
+    # ---- synthetic proving key: valid curve points P_i = k_i * G, slices [lo, hi) of the global arrays
+    t_setup = time.time()
+    g1_a, g1_b, g1_k, g1_z = (gen_g1(s, N_loc, lo) for s in (0xA1, 0xB1, 0xC1, 0xD1))
+    g2_b = gen_g2(0xB2, N_loc, lo)
+    small = {k: gen_g1(s, 1, 0).to_numpy(np.uint64, (8,)) for k, s in (("alpha", 1), ("beta", 2), ("delta", 3))}
+    small2 = {k: gen_g2(s, 1, 0).to_numpy(np.uint64, (16,)) for k, s in (("beta", 8), ("delta", 9))}
+    # solver output: a, b uniform; c = a*b on the evaluation domain (h is a true quotient); w uniform or witness-like.
+    # computeH is replicated: every rank holds the full a, b, c.
+    d_a, d_b = gen_fr(0xA, N_g, 0), gen_fr(0xB, N_g, 0)
+    d_c = dev(N_g * 32)
+    _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(d_c.ptr), C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_size_t(N_g), None))
+    d_w = gen_fr(0xC, N_loc, lo, witness)
+    rs = gen_fr(0x23, 2, 0).to_numpy(np.uint64, (2, 4))  # pinned prover randomness (r, s)
+    r, s = rs[0].copy(), rs[1].copy()
+    # K is indexed by wire like the other arrays; gnark's pk.G1.K starts at the first private wire
+    pk = zk.ProvingKey(log_ng, N_g, n_public, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + n_public * 64, g1_z,
+                       small2["beta"], small2["delta"], g2_b, bases_on_device=True)
+    d_h = dev(N_g * 32) if world > 1 else None
+    _lib.check(L.zk_dev_sync())
+    t_setup = time.time() - t_setup
+
+    def step():
+        if world == 1:
+            return zk.prove(pk, d_a, d_b, d_c, d_w, r, s, n_constraints=N_g, on_device=True)
+        # range-sharded proof: full computeH on every rank, MSMs on this rank's slices, all-gather, host tail
+        _lib.check(L.zk_bn254_groth16_compute_h_dev(C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_void_p(d_c.ptr), C.c_size_t(N_g),
+                                                    C.c_uint32(log_ng), C.c_void_p(d_h.ptr), None))
+        k_skip = n_public if rank == 0 else 0          # K pairs with w[n_public:]
+        nz = N_loc - (1 if rank == world - 1 else 0)   # Z uses h[:N-1]
+        rec = par.groth16_msm5_local(g1_a.ptr, g1_b.ptr, g2_b.ptr, d_w.ptr, N_loc,
+                                     g1_k.ptr + k_skip * 64, d_w.ptr + k_skip * 32, N_loc - k_skip,
+                                     g1_z.ptr, d_h.ptr + lo * 32, nz)
+        return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)
+
+    def barrier():
+        if world > 1:
+            par.dist().barrier()
+        torch.cuda.synchronize()
+        _lib.check(L.zk_dev_sync())
+
+    proof = None
+    for _ in range(args.warmup):
+        proof = step()
+    _lib.profile(True)
+    _lib.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.profile(False)
+    prof = _lib.profile_read()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        par.dist().all_reduce(t, op=par.dist().ReduceOp.MAX)
+        elapsed = float(t.item())
+        allp = par.all_gather_limbs(np.frombuffer(proof, dtype=np.uint64))
+        assert (allp == allp[0]).all(), "ranks disagree on the proof bytes"
+
+    # G1 scalar-muls per proof: A (n), B1 (n), K (n - n_public), Z (N - 1); G2: B2 (n)
+    g1_units = N_g + N_g + (N_g - n_public) + (N_g - 1)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = g1_units * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (by total time over the timed region)
+    name, (launches, tot_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+    per_launch_ms = tot_ms / launches
+    if name == "msm_accumulate_g1":
+        units_per_launch, bytes_per_unit = g1_units / 4.0 / world, 96.0
+    elif name == "msm_accumulate_g2":
+        units_per_launch, bytes_per_unit = N_loc, 160.0
+    else:  # an NTT pass: 64 B per element per pass
+        units_per_launch, bytes_per_unit = N_g, 64.0
+    achieved = units_per_launch * bytes_per_unit / (per_launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_ms": round(per_launch_ms, 4), "launches": launches,
+                "note": "VALU-bound kernel (254-bit modular multiplies on 32-bit integer ALUs); see DESIGN.md for the ALU-issue fraction",
+                "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+
+    out = {
+        "metric": "Groth16 prove ms + BN254 G1 MSM scalar-muls/sec at 2^%d constraints" % log_ng,
+        "value": round(value, 1), "unit": "G1 scalar-muls/s (whole prove: 4 G1 MSMs + G2 MSM + 7 NTTs per step)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "prove_ms": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_ng, "constraints": N_g, "wires": N_g, "n_public": n_public,
+                   "scalars": args.scalars, "per_gpu_constraints": N_loc,
+                   "parallelism": "single GPU" if world == 1 else "MSMs range-sharded x%d (all-gather of partial sums), computeH replicated" % world},
+        "roofline": roofline, "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16], "setup_s": round(t_setup, 2),
+    }
+
+    # ---- CPU baseline: the oracle proves the SAME instance on this box's host cores (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc  # the CPU oracle is used ONLY in this leg, as the timed baseline and the checker
+        cores = orc.max_threads()
+        pkd = dict(log_domain=log_n, n_wires=N_g, n_public=n_public, g1_alpha=small["alpha"], g1_beta=small["beta"], g1_delta=small["delta"],
+                   g1_a=g1_a.to_numpy(np.uint64, (N_g, 8)), g1_b=g1_b.to_numpy(np.uint64, (N_g, 8)),
+                   g1_k=g1_k.to_numpy(np.uint64, (N_g, 8))[n_public:], g1_z=g1_z.to_numpy(np.uint64, (N_g, 8)),
+                   g2_beta=small2["beta"], g2_delta=small2["delta"], g2_b=g2_b.to_numpy(np.uint64, (N_g, 16)))
+        ha, hb, hc, hw = (d.to_numpy(np.uint64, (N_g, 4)) for d in (d_a, d_b, d_c, d_w))
+        t0 = time.perf_counter()
+        cpu_proof, _ = orc.groth16_prove(pkd, ha, hb, hc, hw, r, s, nthreads=cores)
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(g1_units / cpu_s, 1), "unit": out["unit"], "cores": cores, "kind": "port",
+                               "sample": "1 full proof of the same instance (2^%d constraints, same seeds) by oracle/bn254_oracle.c "
+                                         "(OpenMP, window-parallel Pippenger + radix-2 FFT; a restatement, not the gnark binary)" % log_n,
+                               "prove_ms": round(cpu_s * 1e3, 1), "proof_bytes_match_gpu": bool(cpu_proof == proof)}
+        if cpu_proof != proof:
+            out["parity_error"] = "GPU proof bytes differ from the CPU oracle's"
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        par.dist().barrier()
+        par.dist().destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,17 @@ int zk_bn254_groth16_pk_free(uint64_t handle);
 int zk_bn254_groth16_prove(uint64_t pk_handle, const void *a, const void *b, const void *c, size_t n_constraints,
                            const void *w, const zk_fr *r, const zk_fr *s, int on_device, uint8_t proof_out[128]);
 
+/* The two halves of zk_bn254_groth16_prove, exposed so that one proof can be range-sharded over several GPUs
+ * (one process per GPU): every rank runs the five MSMs on ITS slice of the bases / wire values / h, the un-normalised
+ * XYZZ sums (4 x G1 = 64 limbs, then G2 = 32 limbs; order A, B1, K, Z, B2) are all-gathered, and any rank finishes.
+ *   msm5_dev : d_a, d_b (G1), d_b2 (G2) against d_w[0..nw); d_k against d_wk[0..nk); d_z against d_h[0..nz).
+ *   finalize : sums n_partials x 96-limb records, adds alpha/beta/delta terms with (r, s), writes the 128-byte proof. */
+int zk_bn254_groth16_msm5_dev(const void *d_a, const void *d_b, const void *d_b2, const void *d_w, size_t nw,
+                              const void *d_k, const void *d_wk, size_t nk, const void *d_z, const void *d_h, size_t nz,
+                              uint64_t out_xyzz[96], void *stream);
+int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t *partials, size_t n_partials, const zk_fr *r,
+                              const zk_fr *s, uint8_t proof_out[128]);
+
 /* ---- synthetic data on the device (bench / tests; deterministic SplitMix64 streams) -------------- */
 int zk_bn254_fr_random_dev(void *d_out, size_t n, uint64_t seed, int mont, int witness_like, void *stream);
 int zk_bn254_g1_generate_dev(void *d_out, size_t n, uint64_t seed, void *stream); /* P_i = k_i * G1 */

@@ -123,62 +123,70 @@ int zk_bn254_groth16_pk_free(uint64_t handle) {
     return ZK_OK;
 }
 
-int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, const void* c, size_t n_constraints, const void* w, const zk_fr* r_,
-                           const zk_fr* s_, int on_device, uint8_t proof_out[128]) {
-    if (!a || !b || !c || !w || !r_ || !s_ || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
-    Groth16PK P;
-    {
-        std::lock_guard<std::mutex> lk(g_pk_mu);
-        auto it = g_pks.find(pk_handle);
-        if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)pk_handle);
-        P = it->second;
-    }
-    const size_t N = (size_t)1 << P.log_domain, nw = P.n_wires, nk = P.n_wires - P.n_public;
-    if (n_constraints > N) return set_err(ZK_ERR_ARG, "n_constraints = %zu exceeds the domain size %zu", n_constraints, N);
-    SlotGuard g;
-    ZK_TRY(acquire_slot(&g.s));
-    hipStream_t st = g.s->stream;
+// The five MSMs of one proof (or of one rank's shard of it) on device-resident inputs; un-normalised XYZZ sums out:
+// out[0..16) = MSM(G1.A, w), [16..32) = MSM(G1.B, w), [32..48) = MSM(G1.K, wk), [48..64) = MSM(G1.Z, h), [64..96) = MSM(G2.B, w).
+static int msm5(Slot* sl, hipStream_t st, const void* d_a, const void* d_b, const void* d_b2, const void* d_w, size_t nw, const void* d_k,
+                const void* d_wk, size_t nk, const void* d_z, const void* d_h, size_t nz, uint64_t out[96]) {
     zk_msm_cfg cfg = {0, 1, 0, 0};  // scalars are Montgomery fr.Element images
-    size_t msm_need = 0;
-    {
-        const size_t g1_sizes[3] = {nw, nk, N - 1};
-        for (size_t sz : g1_sizes) {
-            size_t need = 0;
-            ZK_TRY(msm_g1_need(sz, &cfg, st, &need));
-            if (need > msm_need) msm_need = need;
-        }
-        size_t need = 0;
-        ZK_TRY(msm_g2_need(nw, &cfg, st, &need));
-        if (need > msm_need) msm_need = need;
-    }
-    ZK_TRY(g.s->reserve(3 * N * 32 + nw * 32 + 4096 + msm_need));
-    Fr* d_abc[3];
-    const void* src[3] = {a, b, c};
-    hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    for (int i = 0; i < 3; i++) {
-        d_abc[i] = (Fr*)g.s->alloc(N * 32);
-        if (n_constraints) ZK_HIP(hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st));
-        if (n_constraints < N) ZK_HIP(hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st));
-    }
-    Fr* d_w = (Fr*)g.s->alloc(nw * 32 + 16);
-    if (nw) ZK_HIP(hipMemcpyAsync(d_w, w, nw * 32, kind, st));
-    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
-    ZK_TRY(compute_h_inplace(g.s, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain));
-    const size_t mark = g.s->arena_off;
+    const size_t mark = sl->arena_off;
     XYZZ<HFp> m_a, m_b, m_k, m_z;
     XYZZ<HFp2> m_b2;
-    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_a, d_w, nw, &cfg, &m_a));
-    g.s->arena_off = mark;
-    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_b, d_w, nw, &cfg, &m_b));
-    g.s->arena_off = mark;
-    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_k, d_w + P.n_public, nk, &cfg, &m_k));
-    g.s->arena_off = mark;
-    ZK_TRY(msm_g1_xyzz(g.s, st, P.d_z, d_abc[0], N - 1, &cfg, &m_z));
-    g.s->arena_off = mark;
-    ZK_TRY(msm_g2_xyzz(g.s, st, P.d_b2, d_w, nw, &cfg, &m_b2));
-    g.s->arena_off = mark;
+    ZK_TRY(msm_g1_xyzz(sl, st, d_a, d_w, nw, &cfg, &m_a));
+    sl->arena_off = mark;
+    ZK_TRY(msm_g1_xyzz(sl, st, d_b, d_w, nw, &cfg, &m_b));
+    sl->arena_off = mark;
+    ZK_TRY(msm_g1_xyzz(sl, st, d_k, d_wk, nk, &cfg, &m_k));
+    sl->arena_off = mark;
+    ZK_TRY(msm_g1_xyzz(sl, st, d_z, d_h, nz, &cfg, &m_z));
+    sl->arena_off = mark;
+    ZK_TRY(msm_g2_xyzz(sl, st, d_b2, d_w, nw, &cfg, &m_b2));
+    sl->arena_off = mark;
+    memcpy(out, &m_a, 128);
+    memcpy(out + 16, &m_b, 128);
+    memcpy(out + 32, &m_k, 128);
+    memcpy(out + 48, &m_z, 128);
+    memcpy(out + 64, &m_b2, 256);
+    return ZK_OK;
+}
 
-    // ---- host tail
+static int msm5_need(hipStream_t st, size_t nw, size_t nk, size_t nz, size_t* out) {
+    zk_msm_cfg cfg = {0, 1, 0, 0};
+    size_t msm_need = 0;
+    const size_t g1_sizes[3] = {nw, nk, nz};
+    for (size_t sz : g1_sizes) {
+        size_t need = 0;
+        ZK_TRY(msm_g1_need(sz, &cfg, st, &need));
+        if (need > msm_need) msm_need = need;
+    }
+    size_t need = 0;
+    ZK_TRY(msm_g2_need(nw, &cfg, st, &need));
+    if (need > msm_need) msm_need = need;
+    *out = msm_need;
+    return ZK_OK;
+}
+
+static int lookup_pk(uint64_t h, Groth16PK* P) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(h);
+    if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)h);
+    *P = it->second;
+    return ZK_OK;
+}
+
+// host tail of groth16.Prove from the (summed) MSM results
+static void finalize(const Groth16PK& P, const uint64_t* parts, size_t n_parts, const zk_fr* r_, const zk_fr* s_, uint8_t proof_out[128]) {
+    XYZZ<HFp> m_a = XYZZ<HFp>::inf(), m_b = m_a, m_k = m_a, m_z = m_a;
+    XYZZ<HFp2> m_b2 = XYZZ<HFp2>::inf();
+    for (size_t i = 0; i < n_parts; i++) {
+        const uint64_t* p = parts + 96 * i;
+        XYZZ<HFp> t;
+        XYZZ<HFp2> t2;
+        memcpy(&t, p, 128); m_a.add(t);
+        memcpy(&t, p + 16, 128); m_b.add(t);
+        memcpy(&t, p + 32, 128); m_k.add(t);
+        memcpy(&t, p + 48, 128); m_z.add(t);
+        memcpy(&t2, p + 64, 256); m_b2.add(t2);
+    }
     HFr r, s;
     memcpy(&r, r_, 32);
     memcpy(&s, s_, 32);
@@ -205,6 +213,57 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     g1_compress(ar_aff, proof_out);
     g2_compress(bs.to_affine(), proof_out + 32);
     g1_compress(krs.to_affine(), proof_out + 96);
+}
+
+int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2, const void* d_w, size_t nw, const void* d_k, const void* d_wk,
+                              size_t nk, const void* d_z, const void* d_h, size_t nz, uint64_t out_xyzz[96], void* stream) {
+    if (!out_xyzz) return set_err(ZK_ERR_ARG, "null pointer");
+    if ((nw && (!d_a || !d_b || !d_b2 || !d_w)) || (nk && (!d_k || !d_wk)) || (nz && (!d_z || !d_h))) return set_err(ZK_ERR_ARG, "null pointer");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    size_t need = 0;
+    ZK_TRY(msm5_need(st, nw, nk, nz, &need));
+    ZK_TRY(g.s->reserve(need + 4096));
+    return msm5(g.s, st, d_a, d_b, d_b2, d_w, nw, d_k, d_wk, nk, d_z, d_h, nz, out_xyzz);
+}
+
+int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size_t n_partials, const zk_fr* r, const zk_fr* s, uint8_t proof_out[128]) {
+    if (!partials || !n_partials || !r || !s || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
+    Groth16PK P;
+    ZK_TRY(lookup_pk(pk_handle, &P));
+    finalize(P, partials, n_partials, r, s, proof_out);
+    return ZK_OK;
+}
+
+int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, const void* c, size_t n_constraints, const void* w, const zk_fr* r_,
+                           const zk_fr* s_, int on_device, uint8_t proof_out[128]) {
+    if (!a || !b || !c || !w || !r_ || !s_ || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
+    Groth16PK P;
+    ZK_TRY(lookup_pk(pk_handle, &P));
+    const size_t N = (size_t)1 << P.log_domain, nw = P.n_wires, nk = P.n_wires - P.n_public;
+    if (n_constraints > N) return set_err(ZK_ERR_ARG, "n_constraints = %zu exceeds the domain size %zu", n_constraints, N);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    size_t msm_need = 0;
+    ZK_TRY(msm5_need(st, nw, nk, N - 1, &msm_need));
+    ZK_TRY(g.s->reserve(3 * N * 32 + nw * 32 + 4096 + msm_need));
+    Fr* d_abc[3];
+    const void* src[3] = {a, b, c};
+    hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int i = 0; i < 3; i++) {
+        d_abc[i] = (Fr*)g.s->alloc(N * 32);
+        if (n_constraints) ZK_HIP(hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st));
+        if (n_constraints < N) ZK_HIP(hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st));
+    }
+    Fr* d_w = (Fr*)g.s->alloc(nw * 32 + 16);
+    if (nw) ZK_HIP(hipMemcpyAsync(d_w, w, nw * 32, kind, st));
+    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
+    ZK_TRY(compute_h_inplace(g.s, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain));
+    uint64_t parts[96];
+    ZK_TRY(msm5(g.s, st, P.d_a, P.d_b, P.d_b2, d_w, nw, P.d_k, d_w + P.n_public, nk, P.d_z, d_abc[0], N - 1, parts));
+    finalize(P, parts, 1, r_, s_, proof_out);
     return ZK_OK;
 }
 

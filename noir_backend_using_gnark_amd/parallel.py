@@ -1,0 +1,90 @@
+"""One process per GPU: range-sharding of the MSMs of a proof across the GPUs of a node.
+
+The path shards by POINT RANGE (SURVEY.md §8e "point-range-sharded"): rank g owns bases / scalars [g*n/G, (g+1)*n/G),
+runs the local Pippenger MSMs, and the only exchange is an all-gather of the un-normalised partial sums (96 limbs =
+768 B per rank per proof) -- RCCL over xGMI on GPUs (`torch.distributed` backend "nccl"), gloo in the CPU tests.
+Field / group addition is not an RCCL reduction op, so the "reduce" is all-gather + a local combine on every rank
+(zk_bn254_g1_sum_xyzz / zk_bn254_groth16_finalize, host side, O(G))."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, vp
+
+
+def dist():
+    import torch.distributed as d
+    return d
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's environment; initialises the process group when world > 1."""
+    import torch
+    import torch.distributed as d
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not d.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        d.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous balanced range [lo, hi) of n units owned by `rank`."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def all_gather_limbs(local: np.ndarray) -> np.ndarray:
+    """All-gather a small uint64 record from every rank -> (world, len).  Device tensors under nccl (RCCL), host under gloo."""
+    import torch
+    d = dist()
+    local = np.ascontiguousarray(local, dtype=np.uint64).reshape(-1)
+    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+        return local.reshape(1, -1)
+    world = d.get_world_size()
+    t = torch.from_numpy(local.view(np.int64).copy())
+    if d.get_backend() == "nccl":
+        t = t.cuda()
+    out = torch.empty((world, t.numel()), dtype=torch.int64, device=t.device)
+    d.all_gather_into_tensor(out, t) if hasattr(d, "all_gather_into_tensor") and d.get_backend() == "nccl" else d.all_gather(list(out.unbind(0)), t)
+    return out.cpu().numpy().view(np.uint64)
+
+
+def sharded_g1_multi_exp(d_points_local: int, d_scalars_local: int, n_local: int, config=None) -> np.ndarray:
+    """Every rank passes ITS slice (device pointers); returns the affine sum over all ranks, identical on every rank."""
+    from . import bn254
+    part = bn254.g1_multi_exp_dev(d_points_local, d_scalars_local, n_local, config, partial=True)
+    return bn254.g1_sum_partials(all_gather_limbs(part))
+
+
+def sharded_g2_multi_exp(d_points_local: int, d_scalars_local: int, n_local: int, config=None) -> np.ndarray:
+    from . import bn254
+    part = bn254.g2_multi_exp_dev(d_points_local, d_scalars_local, n_local, config, partial=True)
+    return bn254.g2_sum_partials(all_gather_limbs(part))
+
+
+def groth16_msm5_local(d_a, d_b, d_b2, d_w, nw, d_k, d_wk, nk, d_z, d_h, nz) -> np.ndarray:
+    """The five MSMs of this rank's slice of one proof -> 96-limb record of XYZZ partial sums."""
+    out = np.zeros(96, dtype=np.uint64)
+    check(lib().zk_bn254_groth16_msm5_dev(C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_b2), C.c_void_p(d_w), C.c_size_t(nw),
+                                          C.c_void_p(d_k), C.c_void_p(d_wk), C.c_size_t(nk), C.c_void_p(d_z), C.c_void_p(d_h), C.c_size_t(nz),
+                                          vp(out), None))
+    return out
+
+
+def groth16_finalize(pk, partials: np.ndarray, r, s) -> bytes:
+    """Host tail of groth16.Prove from the gathered (world, 96) partial records; same bytes on every rank."""
+    partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, 96)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+    s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+    proof = (C.c_uint8 * 128)()
+    check(lib().zk_bn254_groth16_finalize(pk.handle, vp(partials), C.c_size_t(partials.shape[0]), vp(r), vp(s), proof))
+    return bytes(proof)
