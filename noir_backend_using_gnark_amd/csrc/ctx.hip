@@ -73,6 +73,30 @@ int acquire_slot(Slot** out) {
     }
 }
 
+int acquire_slots(int k, Slot** out) {
+    ZK_TRY(ensure_init());
+    Ctx& c = ctx();
+    if (k > Ctx::NSLOTS) return set_err(ZK_ERR_ARG, "asked for %d stream slots, only %d exist", k, Ctx::NSLOTS);
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            int nfree = 0;
+            for (int i = 0; i < Ctx::NSLOTS; i++) nfree += !c.slots[i].busy;
+            if (nfree >= k) {
+                int got = 0;
+                for (int i = 0; i < Ctx::NSLOTS && got < k; i++)
+                    if (!c.slots[i].busy) {
+                        c.slots[i].busy = true;
+                        c.slots[i].reset();
+                        out[got++] = &c.slots[i];
+                    }
+                return ZK_OK;
+            }
+        }
+        std::this_thread::yield();
+    }
+}
+
 void release_slot(Slot* s) {
     std::lock_guard<std::mutex> lk(ctx().mu);
     s->busy = false;

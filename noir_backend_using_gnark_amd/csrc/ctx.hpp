@@ -70,12 +70,18 @@ struct Ctx {
 Ctx& ctx();
 int ensure_init();                  // lazy device init; ZK_ERR_NO_DEVICE if there is no GPU
 int acquire_slot(Slot** out);       // blocks (spins) until a slot is free
+int acquire_slots(int k, Slot** out); // k slots at once (all or nothing: no partial holds, hence no deadlock)
 void release_slot(Slot* s);
 int slot_sync(Slot* s, hipStream_t st);  // synchronize + fold pending profile events
 
 struct SlotGuard {
     Slot* s = nullptr;
     ~SlotGuard() { if (s) release_slot(s); }
+};
+template <int K>
+struct SlotsGuard {
+    Slot* s[K] = {};
+    ~SlotsGuard() { for (int i = 0; i < K; i++) if (s[i]) release_slot(s[i]); }
 };
 
 // launch wrapper: optional event pair around the kernel, on the stream it is launched on

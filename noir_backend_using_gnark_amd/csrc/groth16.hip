@@ -125,22 +125,61 @@ int zk_bn254_groth16_pk_free(uint64_t handle) {
 
 // The five MSMs of one proof (or of one rank's shard of it) on device-resident inputs; un-normalised XYZZ sums out:
 // out[0..16) = MSM(G1.A, w), [16..32) = MSM(G1.B, w), [32..48) = MSM(G1.K, wk), [48..64) = MSM(G1.Z, h), [64..96) = MSM(G2.B, w).
-static int msm5(Slot* sl, hipStream_t st, const void* d_a, const void* d_b, const void* d_b2, const void* d_w, size_t nw, const void* d_k,
-                const void* d_wk, size_t nk, const void* d_z, const void* d_h, size_t nz, uint64_t out[96]) {
-    zk_msm_cfg cfg = {0, 1, 0, 0};  // scalars are Montgomery fr.Element images
-    const size_t mark = sl->arena_off;
+// Each MSM runs on its own stream slot so that the latency-bound tail kernels of one (bucket reduction: a few waves)
+// overlap with the throughput-bound accumulate kernels of the others.  `ev_w` / `ev_h` (optional) gate the streams on
+// the producers of w and h.
+struct Msm5Inputs {
+    const void *d_a, *d_b, *d_b2, *d_w;
+    size_t nw;
+    const void *d_k, *d_wk;
+    size_t nk;
+    const void *d_z, *d_h;
+    size_t nz;
+};
+static const zk_msm_cfg kMontCfg = {0, 1, 0, 0};  // scalars are Montgomery fr.Element images
+
+// K pairs with w[j:] for some j (gnark: j = number of public wires): then A, B1, K and G2.B all share the scalar-side
+// work (digits, sort, bucket bounds, task plan) of ONE preparation of w; K's bases are addressed as K[i - j].
+static bool k_shares_w(const Msm5Inputs& in, size_t* j) {
+    if (!in.nk || !in.nw) return false;
+    ptrdiff_t d = (const char*)in.d_wk - (const char*)in.d_w;
+    if (d < 0 || d % 32) return false;
+    *j = (size_t)d / 32;
+    return *j + in.nk == in.nw;
+}
+
+struct Msm5State {
+    MsmJob jobs[5];
+    MsmPrep prep_w;
+};
+
+// slot 0 runs Z (it usually follows computeH on the same stream); slot 1 prepares w and runs A; slots 2, 3, 4 run B1, K, B2
+static int msm5_launch(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, bool z_now = true) {
+    for (int i = 1; i < 5; i++)
+        if (ev_w) ZK_HIP(hipStreamWaitEvent(sl[i]->stream, ev_w, 0));
+    size_t j = 0;
+    const bool share_k = k_shares_w(in, &j);
+    ZK_TRY(msm_prepare_scalars(sl[1], sl[1]->stream, in.d_w, in.nw, &kMontCfg, &S->prep_w));
+    ZK_TRY(msm_g1_accumulate(sl[1], sl[1]->stream, S->prep_w, in.d_a, 0, &S->jobs[1]));
+    ZK_TRY(msm_g2_accumulate(sl[4], sl[4]->stream, S->prep_w, in.d_b2, 0, &S->jobs[4]));
+    ZK_TRY(msm_g1_accumulate(sl[2], sl[2]->stream, S->prep_w, in.d_b, 0, &S->jobs[2]));
+    if (share_k)
+        ZK_TRY(msm_g1_accumulate(sl[3], sl[3]->stream, S->prep_w, (const char*)in.d_k - j * 64, (uint32_t)j, &S->jobs[3]));
+    else
+        ZK_TRY(msm_g1_launch(sl[3], sl[3]->stream, in.d_k, in.d_wk, in.nk, &kMontCfg, &S->jobs[3]));
+    if (z_now) ZK_TRY(msm_g1_launch(sl[0], st0, in.d_z, in.d_h, in.nz, &kMontCfg, &S->jobs[0]));
+    return ZK_OK;
+}
+static int msm5_finish(Msm5State* S, uint64_t out[96]) {
     XYZZ<HFp> m_a, m_b, m_k, m_z;
     XYZZ<HFp2> m_b2;
-    ZK_TRY(msm_g1_xyzz(sl, st, d_a, d_w, nw, &cfg, &m_a));
-    sl->arena_off = mark;
-    ZK_TRY(msm_g1_xyzz(sl, st, d_b, d_w, nw, &cfg, &m_b));
-    sl->arena_off = mark;
-    ZK_TRY(msm_g1_xyzz(sl, st, d_k, d_wk, nk, &cfg, &m_k));
-    sl->arena_off = mark;
-    ZK_TRY(msm_g1_xyzz(sl, st, d_z, d_h, nz, &cfg, &m_z));
-    sl->arena_off = mark;
-    ZK_TRY(msm_g2_xyzz(sl, st, d_b2, d_w, nw, &cfg, &m_b2));
-    sl->arena_off = mark;
+    int rc = msm_g1_finish(S->jobs[1], &m_a);
+    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[2], &m_b);
+    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[3], &m_k);
+    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[0], &m_z);
+    if (rc == ZK_OK) rc = msm_g2_finish(S->jobs[4], &m_b2);
+    msm_prep_release(&S->prep_w);
+    ZK_TRY(rc);
     memcpy(out, &m_a, 128);
     memcpy(out + 16, &m_b, 128);
     memcpy(out + 32, &m_k, 128);
@@ -148,20 +187,18 @@ static int msm5(Slot* sl, hipStream_t st, const void* d_a, const void* d_b, cons
     memcpy(out + 64, &m_b2, 256);
     return ZK_OK;
 }
-
-static int msm5_need(hipStream_t st, size_t nw, size_t nk, size_t nz, size_t* out) {
-    zk_msm_cfg cfg = {0, 1, 0, 0};
-    size_t msm_need = 0;
-    const size_t g1_sizes[3] = {nw, nk, nz};
-    for (size_t sz : g1_sizes) {
-        size_t need = 0;
-        ZK_TRY(msm_g1_need(sz, &cfg, st, &need));
-        if (need > msm_need) msm_need = need;
-    }
-    size_t need = 0;
-    ZK_TRY(msm_g2_need(nw, &cfg, st, &need));
-    if (need > msm_need) msm_need = need;
-    *out = msm_need;
+// arena reservations: slot 0 also carries `extra0` bytes of the caller's own buffers
+static int msm5_reserve(Slot* sl[5], const Msm5Inputs& in, size_t extra0) {
+    size_t need[5] = {0, 0, 0, 0, 0}, prep = 0, acc1 = 0, acc2 = 0, j = 0;
+    ZK_TRY(msm_g1_need(in.nz, &kMontCfg, sl[0]->stream, &need[0]));
+    ZK_TRY(msm_prep_need(in.nw, &kMontCfg, sl[1]->stream, &prep, &acc1, &acc2));
+    need[1] = prep + acc1;
+    need[2] = acc1;
+    need[4] = acc2;
+    if (k_shares_w(in, &j)) need[3] = acc1;
+    else ZK_TRY(msm_g1_need(in.nk, &kMontCfg, sl[3]->stream, &need[3]));
+    need[0] += extra0;
+    for (int i = 0; i < 5; i++) ZK_TRY(sl[i]->reserve(need[i] + 4096));
     return ZK_OK;
 }
 
@@ -219,13 +256,22 @@ int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2
                               size_t nk, const void* d_z, const void* d_h, size_t nz, uint64_t out_xyzz[96], void* stream) {
     if (!out_xyzz) return set_err(ZK_ERR_ARG, "null pointer");
     if ((nw && (!d_a || !d_b || !d_b2 || !d_w)) || (nk && (!d_k || !d_wk)) || (nz && (!d_z || !d_h))) return set_err(ZK_ERR_ARG, "null pointer");
-    SlotGuard g;
-    ZK_TRY(acquire_slot(&g.s));
-    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
-    size_t need = 0;
-    ZK_TRY(msm5_need(st, nw, nk, nz, &need));
-    ZK_TRY(g.s->reserve(need + 4096));
-    return msm5(g.s, st, d_a, d_b, d_b2, d_w, nw, d_k, d_wk, nk, d_z, d_h, nz, out_xyzz);
+    SlotsGuard<5> g;
+    ZK_TRY(acquire_slots(5, g.s));
+    Msm5Inputs in = {d_a, d_b, d_b2, d_w, nw, d_k, d_wk, nk, d_z, d_h, nz};
+    ZK_TRY(msm5_reserve(g.s, in, 0));
+    hipEvent_t ev = nullptr;
+    if (stream) {  // inputs are produced on the caller's stream: gate all five streams on it
+        ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(ev, (hipStream_t)stream));
+        ZK_HIP(hipStreamWaitEvent(g.s[0]->stream, ev, 0));
+    }
+    Msm5State S;
+    int rc = msm5_launch(g.s, g.s[0]->stream, in, ev, &S);
+    if (rc == ZK_OK) rc = msm5_finish(&S, out_xyzz);
+    else msm_prep_release(&S.prep_w);
+    if (ev) (void)hipEventDestroy(ev);
+    return rc;
 }
 
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size_t n_partials, const zk_fr* r, const zk_fr* s, uint8_t proof_out[128]) {
@@ -243,26 +289,42 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     ZK_TRY(lookup_pk(pk_handle, &P));
     const size_t N = (size_t)1 << P.log_domain, nw = P.n_wires, nk = P.n_wires - P.n_public;
     if (n_constraints > N) return set_err(ZK_ERR_ARG, "n_constraints = %zu exceeds the domain size %zu", n_constraints, N);
-    SlotGuard g;
-    ZK_TRY(acquire_slot(&g.s));
-    hipStream_t st = g.s->stream;
-    size_t msm_need = 0;
-    ZK_TRY(msm5_need(st, nw, nk, N - 1, &msm_need));
-    ZK_TRY(g.s->reserve(3 * N * 32 + nw * 32 + 4096 + msm_need));
-    Fr* d_abc[3];
-    const void* src[3] = {a, b, c};
+    SlotsGuard<5> g;
+    ZK_TRY(acquire_slots(5, g.s));
+    Slot* s0 = g.s[0];
+    hipStream_t st = s0->stream;
+    Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, nullptr, nw, P.d_k, nullptr, nk, P.d_z, nullptr, N - 1};
+    in.d_wk = (const char*)in.d_w + P.n_public * 32;  // placeholder geometry for the reservation; real pointers below
+    ZK_TRY(msm5_reserve(g.s, in, 3 * N * 32 + nw * 32 + 4096));
     hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    for (int i = 0; i < 3; i++) {
-        d_abc[i] = (Fr*)g.s->alloc(N * 32);
-        if (n_constraints) ZK_HIP(hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st));
-        if (n_constraints < N) ZK_HIP(hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st));
-    }
-    Fr* d_w = (Fr*)g.s->alloc(nw * 32 + 16);
+    // wire values first: the A / B1 / K / B2 MSMs only need w and start while computeH is still running on stream 0
+    Fr* d_w = (Fr*)s0->alloc(nw * 32 + 16);
     if (nw) ZK_HIP(hipMemcpyAsync(d_w, w, nw * 32, kind, st));
-    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
-    ZK_TRY(compute_h_inplace(g.s, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain));
+    hipEvent_t ev_w = nullptr;
+    ZK_HIP(hipEventCreateWithFlags(&ev_w, hipEventDisableTiming));
+    ZK_HIP(hipEventRecord(ev_w, st));
+    in.d_w = d_w;
+    in.d_wk = d_w + P.n_public;
+    Msm5State S;
+    int rc = msm5_launch(g.s, st, in, ev_w, &S, /*z_now=*/false);
+    Fr* d_abc[3] = {nullptr, nullptr, nullptr};
+    const void* src[3] = {a, b, c};
+    for (int i = 0; i < 3 && rc == ZK_OK; i++) {
+        d_abc[i] = (Fr*)s0->alloc(N * 32);
+        if (n_constraints && hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+        if (n_constraints < N && hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemsetAsync failed");
+    }
+    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match); then Z on the same stream
+    if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain);
+    if (rc == ZK_OK) rc = msm_g1_launch(s0, st, P.d_z, d_abc[0], N - 1, &kMontCfg, &S.jobs[0]);
     uint64_t parts[96];
-    ZK_TRY(msm5(g.s, st, P.d_a, P.d_b, P.d_b2, d_w, nw, P.d_k, d_w + P.n_public, nk, P.d_z, d_abc[0], N - 1, parts));
+    if (rc == ZK_OK) rc = msm5_finish(&S, parts);
+    else {
+        for (int i = 0; i < 5; i++) (void)hipStreamSynchronize(g.s[i]->stream);
+        msm_prep_release(&S.prep_w);
+    }
+    (void)hipEventDestroy(ev_w);
+    if (rc != ZK_OK) return rc;
     finalize(P, parts, 1, r_, s_, proof_out);
     return ZK_OK;
 }

@@ -108,15 +108,18 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
 }
 
 // ---------------------------------------------------------------------------------------- 3. bucket boundaries
-// start[b] = first sorted position whose key >= b, for b in [0, nb]; (nb = W*B; key nb is the zero-digit sentinel)
-__global__ void k_bucket_bounds(const uint32_t* keys, uint32_t total, uint32_t nb, uint32_t* start) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
-    uint32_t k = keys[j];
-    uint32_t lo = (j == 0) ? 0 : keys[j - 1] + 1;
-    for (uint32_t b = lo; b <= k && b <= nb; b++) start[b] = j;
-    if (j == total - 1)
-        for (uint32_t b = k + 1; b <= nb; b++) start[b] = total;
+// start[b] = first sorted position whose key >= b (lower bound), for b in [0, nb]; key nb is the zero-digit sentinel.
+// One lane per bucket, ~log2(total) dependent L2 hits each: no serial gap-filling loops whatever the key distribution
+// (the top window leaves ~20k empty buckets in a row for uniform scalars).
+__global__ void k_bucket_bounds(const uint32_t* __restrict__ keys, uint32_t total, uint32_t nb, uint32_t* __restrict__ start) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    uint32_t lo = 0, hi = total;  // answer in [lo, hi]
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    start[b] = lo;
 }
 
 // ---------------------------------------------------------------------------------------- 4. task plan
@@ -130,14 +133,20 @@ __global__ void k_task_plan(const uint32_t* start, uint32_t nb, uint32_t L, uint
     if (t > 1) multi_list[atomicAdd(num_multi, 1u)] = b;
 }
 
-// ---------------------------------------------------------------------------------------- 5. accumulate
-template <class F>
-__global__ __launch_bounds__(256) void k_accumulate(const Affine<F>* __restrict__ pts, const uint32_t* __restrict__ vals,
-                                                    const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off,
-                                                    uint32_t nb, uint32_t L, XYZZ<F>* __restrict__ partial) {
+// One record per task (thread t < total tasks): where its points start in the sorted array, and a sort key that orders
+// tasks by DECREASING length so that the 64 lanes of a wave run tasks of (nearly) equal length -- bucket loads are
+// Poisson-distributed, and a wave otherwise waits for its longest lane.
+__global__ void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t L, uint32_t max_tasks,
+                            uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ task_id) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= max_tasks) return;
+    task_id[t] = t;
     uint32_t total_tasks = task_off[nb];
-    if (t >= total_tasks) return;
+    if (t >= total_tasks) {
+        len_key[t] = 0xffffffffu;  // padding sorts to the end
+        task_begin[t] = 0;
+        return;
+    }
     // bucket = last b with task_off[b] <= t  (empty buckets have task_off[b] == task_off[b+1] and are skipped)
     uint32_t lo = 0, hi = nb;  // invariant: task_off[lo] <= t < task_off[hi]
     while (hi - lo > 1) {
@@ -147,9 +156,26 @@ __global__ __launch_bounds__(256) void k_accumulate(const Affine<F>* __restrict_
     uint32_t b = lo;
     uint32_t begin = start[b] + (t - task_off[b]) * L;
     uint32_t end = min(begin + L, start[b + 1]);
+    task_begin[t] = begin;
+    len_key[t] = L - (end - begin);  // 0 = longest
+}
+
+// ---------------------------------------------------------------------------------------- 5. accumulate
+template <class F>
+__global__ __launch_bounds__(256) void k_accumulate(const Affine<F>* __restrict__ pts, const uint32_t* __restrict__ vals,
+                                                    const uint32_t* __restrict__ task_begin, const uint32_t* __restrict__ len_key_sorted,
+                                                    const uint32_t* __restrict__ task_sorted, uint32_t L, uint32_t max_tasks,
+                                                    uint32_t skip_below, XYZZ<F>* __restrict__ partial) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_tasks) return;
+    uint32_t key = len_key_sorted[i];
+    if (key == 0xffffffffu) return;
+    uint32_t t = task_sorted[i];
+    uint32_t begin = task_begin[t], end = begin + (L - key);
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t j = begin; j < end; j++) {
         uint32_t v = vals[j];
+        if ((v >> 1) < skip_below) continue;  // scalars shared with an MSM whose first bases do not exist (pk.G1.K vs w)
         Affine<F> p = gload(pts + (v >> 1));
         if (v & 1) p.y = p.y.neg();
         acc.madd(p.x, p.y);
@@ -157,33 +183,25 @@ __global__ __launch_bounds__(256) void k_accumulate(const Affine<F>* __restrict_
     gstore(partial + t, acc);
 }
 
-// buckets cut into several tasks: one workgroup folds the bucket's partials into the first one
+// buckets cut into several tasks: one WAVE folds the bucket's partials into the first one
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list,
                                                     const uint32_t* num_multi) {
-    extern __shared__ uint4 lds_raw[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
-    uint32_t nm = *num_multi;
-    for (uint32_t m = blockIdx.x; m < nm; m += gridDim.x) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nm = *num_multi;
+    for (uint32_t m = blockIdx.x * 4 + wave; m < nm; m += gridDim.x * 4) {
         uint32_t b = multi_list[m];
         uint32_t t0 = task_off[b], t1 = task_off[b + 1];
         XYZZ<F> acc = XYZZ<F>::inf();
-        for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        for (uint32_t t = t0 + lane; t < t1; t += 64) {
             XYZZ<F> p = gload(partial + t);
             acc.add(p);
         }
-        sh[threadIdx.x] = acc;
-        __syncthreads();
-        for (unsigned s = blockDim.x >> 1; s > 0; s >>= 1) {
-            if (threadIdx.x < s) {
-                XYZZ<F> x = sh[threadIdx.x], y = sh[threadIdx.x + s];
-                x.add(y);
-                sh[threadIdx.x] = x;
-            }
-            __syncthreads();
+        for (unsigned d = 32; d > 0; d >>= 1) {
+            XYZZ<F> o = shfl_down_t(acc, d);
+            if (lane < d) acc.add(o);
         }
-        if (threadIdx.x == 0) gstore(partial + t0, sh[0]);
-        __syncthreads();
+        if (lane == 0) gstore(partial + t0, acc);
     }
 }
 
@@ -266,12 +284,6 @@ unsigned msm_pick_window(size_t n) {
     return best;
 }
 
-struct MsmPlan {
-    unsigned c, W, key_bits;
-    uint32_t B, nb, L, m1, N1;
-    size_t total, max_tasks, sort_tmp_bytes, scan_tmp_bytes, lvl_elems, need;
-};
-
 // Sizes every buffer of one MSM call; `need` is what the caller must reserve in the slot's arena BEFORE it carves
 // anything else out of it (the arena cannot grow while allocations are live).
 template <class F>
@@ -288,8 +300,19 @@ static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P)
     P->nb = P->W * P->B;
     P->total = n * P->W;
     if (P->total >= ((size_t)1 << 32)) return set_err(ZK_ERR_ARG, "n * windows = %zu overflows 32-bit positions", P->total);
-    // tasks of at most L points: 2x the mean bucket load of a uniform input, at least 32
+    // tasks of at most L points: 2x the mean bucket load of a uniform input in the DENSEST window, at least 32.  The top
+    // window only sees digits up to (r-1) >> (c*(W-1)), so its buckets are denser than 2^(c-1) suggests.
     size_t mean = n / P->B + 1;
+    {
+        // r - 1 = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000000; its top 64 bits:
+        const uint64_t r_top64 = 0x30644e72e131a029ULL;
+        unsigned shift = c * (P->W - 1);                        // bits below the top window
+        uint64_t top_max = shift >= 192 ? (r_top64 >> (shift - 192)) : ~0ULL;
+        if (top_max < P->B && top_max > 0) {
+            size_t mt = n / (size_t)top_max + 1;
+            if (mt > mean) mean = mt;
+        }
+    }
     P->L = (uint32_t)(mean * 2 < 32 ? 32 : mean * 2);
     P->max_tasks = (size_t)P->nb + P->total / P->L + 1;
     P->m1 = P->B >= 8 ? 8 : P->B;  // level-1 serial chunk
@@ -305,23 +328,31 @@ static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P)
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan sizing: %s", hipGetErrorString(e));
     }
     P->lvl_elems = (size_t)P->W * P->N1;  // level-1 outputs; later levels are 64x smaller
-    P->need = 4 * align_up(P->total * 4, 256) + align_up(P->sort_tmp_bytes + 16, 256) + align_up(P->scan_tmp_bytes + 16, 256) +
-              3 * align_up(((size_t)P->nb + 2) * 4, 256) + align_up((size_t)P->nb * 4, 256) + 256 +
-              align_up(P->max_tasks * sizeof(Pt), 256) + 4 * align_up((P->lvl_elems + 64) * sizeof(Pt), 256) + 65536;
+    {
+        rocprim::double_buffer<uint32_t> kb(nullptr, nullptr), vb(nullptr, nullptr);
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, P->tsort_tmp_bytes, kb, vb, P->max_tasks, 0, 32, st);
+        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs sizing: %s", hipGetErrorString(e));
+    }
+    P->need_prep = 5 * align_up(P->max_tasks * 4, 256) + align_up(P->tsort_tmp_bytes + 16, 256) + 4 * align_up(P->total * 4, 256) +
+                   align_up(P->sort_tmp_bytes + 16, 256) + align_up(P->scan_tmp_bytes + 16, 256) + 3 * align_up(((size_t)P->nb + 2) * 4, 256) +
+                   align_up((size_t)P->nb * 4, 256) + 256 + 32768;
+    P->need_acc = align_up(P->max_tasks * sizeof(Pt), 256) + 4 * align_up((P->lvl_elems + 64) * sizeof(Pt), 256) + 32768;
+    P->need = P->need_prep + P->need_acc;
     return ZK_OK;
 }
 
-template <class F>
-static int msm_run(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>* d_pts, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg,
-                   XYZZ<typename HostOf<F>::type>* total_out) {
-    typedef typename HostOf<F>::type HF;
-    typedef XYZZ<F> Pt;
-    *total_out = XYZZ<HF>::inf();
+// Scalar-side half of an MSM on stream `st`: digits, sort, bucket bounds, task plan.  The result only depends on the
+// scalars, so several MSMs over the same scalar vector (Groth16: A, B1, K and G2.B all pair with the wire values) share it.
+static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
+    out->P = P;
+    out->n = n;
+    out->empty = (n == 0);
+    out->ready = nullptr;
     if (n == 0) return ZK_OK;
     const unsigned c = P.c, W = P.W, key_bits = P.key_bits;
-    const uint32_t B = P.B, nb = P.nb, L = P.L, m1 = P.m1, N1 = P.N1;
-    const size_t total = P.total, max_tasks = P.max_tasks, lvl_elems = P.lvl_elems;
-    size_t sort_tmp_bytes = P.sort_tmp_bytes, scan_tmp_bytes = P.scan_tmp_bytes;
+    const uint32_t nb = P.nb, L = P.L;
+    const size_t total = P.total, max_tasks = P.max_tasks;
+    size_t sort_tmp_bytes = P.sort_tmp_bytes, scan_tmp_bytes = P.scan_tmp_bytes, tsort_tmp_bytes = P.tsort_tmp_bytes;
     uint32_t* keys0 = (uint32_t*)s->alloc(total * 4);
     uint32_t* keys1 = (uint32_t*)s->alloc(total * 4);
     uint32_t* vals0 = (uint32_t*)s->alloc(total * 4);
@@ -333,12 +364,15 @@ static int msm_run(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>* d
     uint32_t* task_off = (uint32_t*)s->alloc(((size_t)nb + 2) * 4);
     uint32_t* multi_list = (uint32_t*)s->alloc((size_t)nb * 4);
     uint32_t* num_multi = (uint32_t*)s->alloc(256);
-    Pt* partial = (Pt*)s->alloc(max_tasks * sizeof(Pt));
-    Pt* lvlA[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
-    Pt* lvlS[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
+    uint32_t* task_begin = (uint32_t*)s->alloc(max_tasks * 4);
+    uint32_t* lkey0 = (uint32_t*)s->alloc(max_tasks * 4);
+    uint32_t* lkey1 = (uint32_t*)s->alloc(max_tasks * 4);
+    uint32_t* tid0 = (uint32_t*)s->alloc(max_tasks * 4);
+    uint32_t* tid1 = (uint32_t*)s->alloc(max_tasks * 4);
+    void* tsort_tmp = s->alloc(tsort_tmp_bytes + 16);
     if (!keys0 || !keys1 || !vals0 || !vals1 || !sort_tmp || !scan_tmp || !start || !ntasks || !task_off || !multi_list || !num_multi ||
-        !partial || !lvlA[0] || !lvlA[1] || !lvlS[0] || !lvlS[1])
-        return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need);
+        !task_begin || !lkey0 || !lkey1 || !tid0 || !tid1 || !tsort_tmp)
+        return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_prep);
 
     // ---- 1. digits
     ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
@@ -352,9 +386,8 @@ static int msm_run(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>* d
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
     }
     const uint32_t* keys = kb.current();
-    const uint32_t* vals = vb.current();
     // ---- 3. bucket bounds
-    ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, keys, (uint32_t)total, nb, start);
+    ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, keys, (uint32_t)total, nb, start);
     // ---- 4. plan
     ZK_HIP(hipMemsetAsync(num_multi, 0, 4, st));
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, L, ntasks, multi_list, num_multi);
@@ -364,15 +397,61 @@ static int msm_run(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>* d
         if (ctx().profiling) prof_end(s, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
     }
+    // ---- 4b. per-task records, sorted by decreasing length (keys are L - len: at most ~log2(L) significant bits)
+    ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, (const uint32_t*)start,
+              (const uint32_t*)task_off, nb, L, (uint32_t)max_tasks, task_begin, lkey0, tid0);
+    rocprim::double_buffer<uint32_t> lkb(lkey0, lkey1), tib(tid0, tid1);
+    {
+        unsigned lbits = 1;
+        while (((uint64_t)1 << lbits) <= L) lbits++;
+        if (ctx().profiling) prof_begin(s, st, "msm_task_sort(rocprim)");
+        // padding keys are 0xffffffff: sorting only the low lbits+1 bits keeps them last (bit lbits is set only for padding)
+        hipError_t e = rocprim::radix_sort_pairs(tsort_tmp, tsort_tmp_bytes, lkb, tib, max_tasks, 0, lbits + 1, st);
+        if (ctx().profiling) prof_end(s, st);
+        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs (tasks): %s", hipGetErrorString(e));
+    }
+    out->vals = vb.current();
+    out->start = start;
+    out->task_off = task_off;
+    out->task_begin = task_begin;
+    out->lkeys = lkb.current();
+    out->tids = tib.current();
+    out->multi_list = multi_list;
+    out->num_multi = num_multi;
+    ZK_HIP(hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
+    ZK_HIP(hipEventRecord(out->ready, st));
+    return ZK_OK;
+}
+
+// Base-side half: bucket accumulation, bucket reduction, window sums to pinned memory -- on stream `st`, which waits for
+// the preparation when it ran elsewhere.  `d_pts` is indexed by the scalar index; indices < skip_below are skipped.
+template <class F>
+static int msm_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const Affine<F>* d_pts, uint32_t skip_below, MsmJob* job) {
+    typedef XYZZ<F> Pt;
+    const MsmPlan& P = R.P;
+    job->s = s;
+    job->st = st;
+    job->c = P.c;
+    job->W = P.W;
+    job->empty = R.empty;
+    if (R.empty) return ZK_OK;
+    const unsigned W = P.W;
+    const uint32_t B = P.B, L = P.L, m1 = P.m1, N1 = P.N1;
+    const size_t max_tasks = P.max_tasks, lvl_elems = P.lvl_elems;
+    Pt* partial = (Pt*)s->alloc(max_tasks * sizeof(Pt));
+    Pt* lvlA[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
+    Pt* lvlS[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
+    if (!partial || !lvlA[0] || !lvlA[1] || !lvlS[0] || !lvlS[1])
+        return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
+    if (R.ready) ZK_HIP(hipStreamWaitEvent(st, R.ready, 0));
     // ---- 5. accumulate
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
-    ZK_LAUNCH(s, st, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, d_pts, vals, (const uint32_t*)start,
-              (const uint32_t*)task_off, nb, L, partial);
-    ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(512), dim3(256), 256 * sizeof(Pt), partial, (const uint32_t*)task_off,
-              (const uint32_t*)multi_list, (const uint32_t*)num_multi);
+    ZK_LAUNCH(s, st, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, d_pts, R.vals, R.task_begin, R.lkeys, R.tids,
+              L, (uint32_t)max_tasks, skip_below, partial);
+    ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial, R.task_off, R.multi_list, R.num_multi);
     // ---- 6. bucket reduce
-    ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial,
-              (const uint32_t*)task_off, B, W, m1, lvlA[0], lvlS[0]);
+    ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial, R.task_off, B,
+              W, m1, lvlA[0], lvlS[0]);
     uint32_t N = N1, sh = 0;
     for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;  // value = sum A + 2^sh * sum j S_j
     int cur = 0;
@@ -384,14 +463,32 @@ static int msm_run(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>* d
         N = Nout;
         sh += 6;
     }
-    // ---- 7. window sums -> host, Horner
+    // ---- 7. window sums -> pinned host memory (Horner happens in msm_finish)
     ZK_TRY(s->pinned_reserve((size_t)W * sizeof(Pt)));
     ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[cur], (size_t)W * sizeof(Pt), hipMemcpyDeviceToHost, st));
-    ZK_TRY(slot_sync(s, st));
-    const XYZZ<HF>* ws = reinterpret_cast<const XYZZ<HF>*>(s->pinned);
+    return ZK_OK;
+}
+
+// Whole MSM on one stream.
+template <class F>
+static int msm_launch(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>* d_pts, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg,
+                      MsmJob* job) {
+    MsmPrep R;
+    ZK_TRY(msm_prepare(s, st, P, d_scalars, n, cfg, &R));
+    int rc = msm_accumulate<F>(s, st, R, d_pts, 0, job);
+    if (R.ready) (void)hipEventDestroy(R.ready);  // same stream: ordering is implicit; the wait above was a no-op
+    return rc;
+}
+
+template <class HF>
+static int msm_finish(const MsmJob& job, XYZZ<HF>* total_out) {
+    *total_out = XYZZ<HF>::inf();
+    if (job.empty) return ZK_OK;
+    ZK_TRY(slot_sync(job.s, job.st));
+    const XYZZ<HF>* ws = reinterpret_cast<const XYZZ<HF>*>(job.s->pinned);
     XYZZ<HF> tot = XYZZ<HF>::inf();
-    for (int w = (int)W - 1; w >= 0; w--) {
-        for (unsigned k = 0; k < c; k++) tot.dbl();
+    for (int w = (int)job.W - 1; w >= 0; w--) {
+        for (unsigned k = 0; k < job.c; k++) tot.dbl();
         tot.add(ws[w]);
     }
     *total_out = tot;
@@ -411,15 +508,51 @@ int msm_g2_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need) {
     return ZK_OK;
 }
 // The slot's arena must already hold msm_g?_need() free bytes.
-int msm_g1_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp>* out) {
+int msm_g1_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job) {
     MsmPlan P;
     ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));
-    return msm_run<Fp>(s, st, P, (const Affine<Fp>*)d_pts, (const Fr*)d_scalars, n, cfg, out);
+    return msm_launch<Fp>(s, st, P, (const Affine<Fp>*)d_pts, (const Fr*)d_scalars, n, cfg, job);
 }
-int msm_g2_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp2>* out) {
+int msm_g2_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job) {
     MsmPlan P;
     ZK_TRY(msm_plan<Fp2>(n, cfg, st, &P));
-    return msm_run<Fp2>(s, st, P, (const Affine<Fp2>*)d_pts, (const Fr*)d_scalars, n, cfg, out);
+    return msm_launch<Fp2>(s, st, P, (const Affine<Fp2>*)d_pts, (const Fr*)d_scalars, n, cfg, job);
+}
+int msm_prep_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2) {
+    MsmPlan P1, P2;
+    ZK_TRY(msm_plan<Fp>(n, cfg, st, &P1));
+    ZK_TRY(msm_plan<Fp2>(n, cfg, st, &P2));
+    if (need_prep) *need_prep = P1.need_prep;
+    if (need_acc_g1) *need_acc_g1 = P1.need_acc;
+    if (need_acc_g2) *need_acc_g2 = P2.need_acc;
+    return ZK_OK;
+}
+int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
+    MsmPlan P;
+    ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));  // the scalar-side plan does not depend on the group
+    return msm_prepare(s, st, P, (const Fr*)d_scalars, n, cfg, out);
+}
+void msm_prep_release(MsmPrep* R) {
+    if (R->ready) (void)hipEventDestroy(R->ready);
+    R->ready = nullptr;
+}
+int msm_g1_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job) {
+    return msm_accumulate<Fp>(s, st, R, (const Affine<Fp>*)d_pts, skip_below, job);
+}
+int msm_g2_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job) {
+    return msm_accumulate<Fp2>(s, st, R, (const Affine<Fp2>*)d_pts, skip_below, job);
+}
+int msm_g1_finish(const MsmJob& job, XYZZ<HFp>* out) { return msm_finish<HFp>(job, out); }
+int msm_g2_finish(const MsmJob& job, XYZZ<HFp2>* out) { return msm_finish<HFp2>(job, out); }
+int msm_g1_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp>* out) {
+    MsmJob job;
+    ZK_TRY(msm_g1_launch(s, st, d_pts, d_scalars, n, cfg, &job));
+    return msm_g1_finish(job, out);
+}
+int msm_g2_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp2>* out) {
+    MsmJob job;
+    ZK_TRY(msm_g2_launch(s, st, d_pts, d_scalars, n, cfg, &job));
+    return msm_g2_finish(job, out);
 }
 
 static int check_cfg(const zk_msm_cfg* cfg) {

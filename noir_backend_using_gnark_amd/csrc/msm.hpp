@@ -10,6 +10,41 @@ unsigned msm_pick_window(size_t n);
 // Bytes of arena an MSM of n points needs; reserve them (plus anything else the call carves out) up front.
 int msm_g1_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need);
 int msm_g2_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need);
+struct MsmPlan {
+    unsigned c, W, key_bits;
+    uint32_t B, nb, L, m1, N1;
+    size_t total, max_tasks, sort_tmp_bytes, scan_tmp_bytes, tsort_tmp_bytes, lvl_elems, need, need_prep, need_acc;
+};
+// Result of the scalar-side half of an MSM (digits, sort, bucket bounds, task plan); device arrays live in the
+// preparing slot's arena and stay valid until that slot's arena is reset.
+struct MsmPrep {
+    MsmPlan P;
+    size_t n = 0;
+    bool empty = true;
+    const uint32_t *vals = nullptr, *start = nullptr, *task_off = nullptr, *task_begin = nullptr, *lkeys = nullptr, *tids = nullptr,
+                   *multi_list = nullptr, *num_multi = nullptr;
+    hipEvent_t ready = nullptr;  // recorded on the preparing stream
+};
+
+// Asynchronous form: *_launch enqueues the device pipeline on `st` (window sums land in the slot's pinned buffer),
+// *_finish synchronises that stream and does the host Horner.  One job per slot at a time.
+struct MsmJob {
+    Slot* s = nullptr;
+    hipStream_t st = nullptr;
+    unsigned c = 0, W = 0;
+    bool empty = true;
+};
+int msm_g1_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job);
+int msm_g2_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job);
+// Split form for MSMs that share one scalar vector: prepare once, accumulate per base array (bases indexed by scalar
+// index; indices below `skip_below` are ignored).
+int msm_prep_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2);
+int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out);
+void msm_prep_release(MsmPrep* R);
+int msm_g1_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);
+int msm_g2_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);
+int msm_g1_finish(const MsmJob& job, XYZZ<HFp>* out);
+int msm_g2_finish(const MsmJob& job, XYZZ<HFp2>* out);
 // Device-pointer MSMs returning the un-normalised total (host XYZZ); they synchronise `st` before returning.
 int msm_g1_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp>* out);
 int msm_g2_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp2>* out);
