@@ -38,7 +38,14 @@ static int init_locked(int device) {
     ZK_HIP(hipGetDeviceProperties(&prop, device));
     c.device = device;
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    for (int i = 0; i < Ctx::NSLOTS; i++) ZK_HIP(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;  // numerically lower = higher priority
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        for (int i = 0; i < Ctx::NSLOTS; i++) {
+            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
+            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi, hipStreamNonBlocking, hi));
+        }
+    }
     c.ready = true;
     return ZK_OK;
 }
@@ -201,7 +208,14 @@ int zk_init(int device) {
     ZK_HIP(hipGetDeviceProperties(&prop, device));
     c.device = device;
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    for (int i = 0; i < Ctx::NSLOTS; i++) ZK_HIP(hipStreamCreateWithFlags(&c.slots[i].stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;  // numerically lower = higher priority
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        for (int i = 0; i < Ctx::NSLOTS; i++) {
+            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
+            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi, hipStreamNonBlocking, hi));
+        }
+    }
     c.ready = true;
     return ZK_OK;
 }

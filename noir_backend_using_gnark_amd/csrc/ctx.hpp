@@ -36,7 +36,8 @@ struct ProfEntry {
 
 // A stream slot: one HIP stream + one growing HBM arena + pinned host staging + pending profile events.
 struct Slot {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // normal priority
+    hipStream_t stream_hi = nullptr;  // high priority (critical-path chains of a proof)
     char* arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
     void* pinned = nullptr;

@@ -150,35 +150,76 @@ static bool k_shares_w(const Msm5Inputs& in, size_t* j) {
 
 struct Msm5State {
     MsmJob jobs[5];
-    MsmPrep prep_w;
+    MsmPrep prep_w, prep_h;
 };
 
-// slot 0 runs Z (it usually follows computeH on the same stream); slot 1 prepares w and runs A; slots 2, 3, 4 run B1, K, B2
-static int msm5_launch(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, bool z_now = true) {
-    for (int i = 1; i < 5; i++)
-        if (ev_w) ZK_HIP(hipStreamWaitEvent(sl[i]->stream, ev_w, 0));
+// Stream plan (priorities matter: the MSM that finishes LAST exposes its latency-bound bucket-reduction tail, so the
+// long chains go first and the three plain G1 MSMs fill the machine behind them):
+//   slot 0, high priority : (computeH ->) prepare(h) -> Z accumulate -> reduce          [st0, passed in]
+//   slot 4, high priority : prepare(w) -> G2.B accumulate -> reduce                     (the largest single MSM)
+//   slots 1, 2, 3, normal : A, B1, K accumulate -> reduce, all waiting on prepare(w)
+// `gate` (optional): the four w-based accumulations wait for it.  groth16_prove passes "computeH done": every kernel here
+// is ALU-bound, so running the NTTs concurrently with four accumulate kernels buys nothing and (measured) delays the
+// Z chain, which then runs alone at the end with its tail exposed.
+static int msm5_launch(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, bool z_now = true,
+                       hipEvent_t gate = nullptr, bool prepare_only = false, bool accumulate_only = false) {
+    hipStream_t st4 = sl[4]->stream_hi;
     size_t j = 0;
     const bool share_k = k_shares_w(in, &j);
-    ZK_TRY(msm_prepare_scalars(sl[1], sl[1]->stream, in.d_w, in.nw, &kMontCfg, &S->prep_w));
+    if (!accumulate_only) {
+        if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
+        ZK_TRY(msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w));
+    }
+    if (prepare_only) return ZK_OK;
+    // The accumulate kernels are chained G2.B -> (Z) -> A -> B1 -> K through events: each one gets the whole machine,
+    // and the latency-bound reduction tail of one MSM runs underneath the next MSM's accumulate.  (Measured: letting the
+    // four kernels share the GPU starves the big G2 kernel, which then finishes last, alone, with its tail exposed.)
+    if (gate) ZK_HIP(hipStreamWaitEvent(st4, gate, 0));
+    // Z's scalar-side preparation (sort of h) goes before the first accumulate kernel: once an accumulate kernel owns the
+    // machine, the bandwidth-bound sort kernels of another stream are starved (measured: 0.5 ms -> 5 ms).
+    if (z_now) {
+        ZK_TRY(msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h));
+        if (S->prep_h.ready) ZK_HIP(hipStreamWaitEvent(st4, S->prep_h.ready, 0));
+    }
+    S->jobs[4].want_done = true;
+    ZK_TRY(msm_g2_accumulate(sl[4], st4, S->prep_w, in.d_b2, 0, &S->jobs[4]));
+    hipEvent_t prev = S->jobs[4].acc_done;
+    if (z_now) {
+        S->jobs[0].gate_acc = prev;
+        S->jobs[0].want_done = true;
+        ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.d_z, 0, &S->jobs[0]));
+        if (S->jobs[0].acc_done) prev = S->jobs[0].acc_done;
+    }
+    S->jobs[1].gate_acc = prev;
+    S->jobs[1].want_done = true;
     ZK_TRY(msm_g1_accumulate(sl[1], sl[1]->stream, S->prep_w, in.d_a, 0, &S->jobs[1]));
-    ZK_TRY(msm_g2_accumulate(sl[4], sl[4]->stream, S->prep_w, in.d_b2, 0, &S->jobs[4]));
+    if (S->jobs[1].acc_done) prev = S->jobs[1].acc_done;
+    S->jobs[2].gate_acc = prev;
+    S->jobs[2].want_done = true;
     ZK_TRY(msm_g1_accumulate(sl[2], sl[2]->stream, S->prep_w, in.d_b, 0, &S->jobs[2]));
-    if (share_k)
+    if (S->jobs[2].acc_done) prev = S->jobs[2].acc_done;
+    S->jobs[3].gate_acc = prev;
+    if (share_k) {
         ZK_TRY(msm_g1_accumulate(sl[3], sl[3]->stream, S->prep_w, (const char*)in.d_k - j * 64, (uint32_t)j, &S->jobs[3]));
-    else
+    } else {
+        if (ev_w) ZK_HIP(hipStreamWaitEvent(sl[3]->stream, ev_w, 0));
         ZK_TRY(msm_g1_launch(sl[3], sl[3]->stream, in.d_k, in.d_wk, in.nk, &kMontCfg, &S->jobs[3]));
-    if (z_now) ZK_TRY(msm_g1_launch(sl[0], st0, in.d_z, in.d_h, in.nz, &kMontCfg, &S->jobs[0]));
+    }
     return ZK_OK;
 }
 static int msm5_finish(Msm5State* S, uint64_t out[96]) {
     XYZZ<HFp> m_a, m_b, m_k, m_z;
     XYZZ<HFp2> m_b2;
-    int rc = msm_g1_finish(S->jobs[1], &m_a);
+    // in expected completion order, so that each host Horner overlaps the GPU work still in flight
+    int rc = msm_g2_finish(S->jobs[4], &m_b2);
+    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[0], &m_z);
+    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[1], &m_a);
     if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[2], &m_b);
     if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[3], &m_k);
-    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[0], &m_z);
-    if (rc == ZK_OK) rc = msm_g2_finish(S->jobs[4], &m_b2);
     msm_prep_release(&S->prep_w);
+    msm_prep_release(&S->prep_h);
+    for (int i = 0; i < 5; i++)
+        if (S->jobs[i].acc_done) { (void)hipEventDestroy(S->jobs[i].acc_done); S->jobs[i].acc_done = nullptr; }
     ZK_TRY(rc);
     memcpy(out, &m_a, 128);
     memcpy(out + 16, &m_b, 128);
@@ -192,9 +233,9 @@ static int msm5_reserve(Slot* sl[5], const Msm5Inputs& in, size_t extra0) {
     size_t need[5] = {0, 0, 0, 0, 0}, prep = 0, acc1 = 0, acc2 = 0, j = 0;
     ZK_TRY(msm_g1_need(in.nz, &kMontCfg, sl[0]->stream, &need[0]));
     ZK_TRY(msm_prep_need(in.nw, &kMontCfg, sl[1]->stream, &prep, &acc1, &acc2));
-    need[1] = prep + acc1;
+    need[1] = acc1;
     need[2] = acc1;
-    need[4] = acc2;
+    need[4] = prep + acc2;
     if (k_shares_w(in, &j)) need[3] = acc1;
     else ZK_TRY(msm_g1_need(in.nk, &kMontCfg, sl[3]->stream, &need[3]));
     need[0] += extra0;
@@ -210,8 +251,29 @@ static int lookup_pk(uint64_t h, Groth16PK* P) {
     return ZK_OK;
 }
 
-// host tail of groth16.Prove from the (summed) MSM results
-static void finalize(const Groth16PK& P, const uint64_t* parts, size_t n_parts, const zk_fr* r_, const zk_fr* s_, uint8_t proof_out[128]) {
+// host tail of groth16.Prove.  The four scalar multiplications that do not depend on the MSM results
+// (r*delta, s*delta, s*delta2, rs*delta) are computed while the GPU is still busy (tail_pre); what is left afterwards
+// is s*(A+alpha) and r*(B+beta):   Krs = K + Z + s*Ar + r*Bs1 - rs*delta = K + Z + s*(A+alpha) + r*(B+beta) + rs*delta.
+struct TailPre {
+    uint32_t rk[8], sk[8];
+    XYZZ<HFp> r_delta, s_delta, rs_delta;
+    XYZZ<HFp2> s_delta2;
+};
+static void tail_pre(const Groth16PK& P, const zk_fr* r_, const zk_fr* s_, TailPre* T) {
+    HFr r, s;
+    memcpy(&r, r_, 32);
+    memcpy(&s, s_, 32);
+    HFr rs = r * s;
+    uint32_t rsk[8];
+    to_canonical_u32(r, T->rk);
+    to_canonical_u32(s, T->sk);
+    to_canonical_u32(rs, rsk);
+    T->r_delta = scalar_mul(P.delta, T->rk);
+    T->s_delta = scalar_mul(P.delta, T->sk);
+    T->rs_delta = scalar_mul(P.delta, rsk);
+    T->s_delta2 = scalar_mul(P.delta2, T->sk);
+}
+static void tail_post(const Groth16PK& P, const TailPre& T, const uint64_t* parts, size_t n_parts, uint8_t proof_out[128]) {
     XYZZ<HFp> m_a = XYZZ<HFp>::inf(), m_b = m_a, m_k = m_a, m_z = m_a;
     XYZZ<HFp2> m_b2 = XYZZ<HFp2>::inf();
     for (size_t i = 0; i < n_parts; i++) {
@@ -224,32 +286,27 @@ static void finalize(const Groth16PK& P, const uint64_t* parts, size_t n_parts, 
         memcpy(&t, p + 48, 128); m_z.add(t);
         memcpy(&t2, p + 64, 256); m_b2.add(t2);
     }
-    HFr r, s;
-    memcpy(&r, r_, 32);
-    memcpy(&s, s_, 32);
-    HFr rs = r * s;
-    uint32_t rk[8], sk[8], rsk[8];
-    to_canonical_u32(r, rk);
-    to_canonical_u32(s, sk);
-    to_canonical_u32(rs, rsk);
-    XYZZ<HFp> ar = m_a;
-    ar.madd(P.alpha);
-    ar.add(scalar_mul(P.delta, rk));
-    XYZZ<HFp> bs1 = m_b;
-    bs1.madd(P.beta);
-    bs1.add(scalar_mul(P.delta, sk));
+    XYZZ<HFp> a_alpha = m_a, b_beta = m_b;
+    a_alpha.madd(P.alpha);
+    b_beta.madd(P.beta);
+    XYZZ<HFp> ar = a_alpha;
+    ar.add(T.r_delta);
     XYZZ<HFp2> bs = m_b2;
     bs.madd(P.beta2);
-    bs.add(scalar_mul(P.delta2, sk));
-    Affine<HFp> ar_aff = ar.to_affine(), bs1_aff = bs1.to_affine();
+    bs.add(T.s_delta2);
     XYZZ<HFp> krs = m_k;
     krs.add(m_z);
-    krs.add(scalar_mul(ar_aff, sk));
-    krs.add(scalar_mul(bs1_aff, rk));
-    krs.add(scalar_mul(P.delta, rsk).neg());
-    g1_compress(ar_aff, proof_out);
+    krs.add(scalar_mul(a_alpha.to_affine(), T.sk));
+    krs.add(scalar_mul(b_beta.to_affine(), T.rk));
+    krs.add(T.rs_delta);
+    g1_compress(ar.to_affine(), proof_out);
     g2_compress(bs.to_affine(), proof_out + 32);
     g1_compress(krs.to_affine(), proof_out + 96);
+}
+static void finalize(const Groth16PK& P, const uint64_t* parts, size_t n_parts, const zk_fr* r_, const zk_fr* s_, uint8_t proof_out[128]) {
+    TailPre T;
+    tail_pre(P, r_, s_, &T);
+    tail_post(P, T, parts, n_parts, proof_out);
 }
 
 int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2, const void* d_w, size_t nw, const void* d_k, const void* d_wk,
@@ -264,12 +321,12 @@ int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2
     if (stream) {  // inputs are produced on the caller's stream: gate all five streams on it
         ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         ZK_HIP(hipEventRecord(ev, (hipStream_t)stream));
-        ZK_HIP(hipStreamWaitEvent(g.s[0]->stream, ev, 0));
+        ZK_HIP(hipStreamWaitEvent(g.s[0]->stream_hi, ev, 0));
     }
     Msm5State S;
-    int rc = msm5_launch(g.s, g.s[0]->stream, in, ev, &S);
+    int rc = msm5_launch(g.s, g.s[0]->stream_hi, in, ev, &S);
     if (rc == ZK_OK) rc = msm5_finish(&S, out_xyzz);
-    else msm_prep_release(&S.prep_w);
+    else { msm_prep_release(&S.prep_w); msm_prep_release(&S.prep_h); }
     if (ev) (void)hipEventDestroy(ev);
     return rc;
 }
@@ -292,7 +349,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     SlotsGuard<5> g;
     ZK_TRY(acquire_slots(5, g.s));
     Slot* s0 = g.s[0];
-    hipStream_t st = s0->stream;
+    hipStream_t st = s0->stream_hi;
     Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, nullptr, nw, P.d_k, nullptr, nk, P.d_z, nullptr, N - 1};
     in.d_wk = (const char*)in.d_w + P.n_public * 32;  // placeholder geometry for the reservation; real pointers below
     ZK_TRY(msm5_reserve(g.s, in, 3 * N * 32 + nw * 32 + 4096));
@@ -306,7 +363,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     in.d_w = d_w;
     in.d_wk = d_w + P.n_public;
     Msm5State S;
-    int rc = msm5_launch(g.s, st, in, ev_w, &S, /*z_now=*/false);
+    int rc = ZK_OK;
     Fr* d_abc[3] = {nullptr, nullptr, nullptr};
     const void* src[3] = {a, b, c};
     for (int i = 0; i < 3 && rc == ZK_OK; i++) {
@@ -314,18 +371,28 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
         if (n_constraints && hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
         if (n_constraints < N && hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemsetAsync failed");
     }
-    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match); then Z on the same stream
+    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match).  Enqueued FIRST:
+    // the host needs ~10 us per launch, and the scalar-side preparation of w (~40 launches) overlaps it on another stream.
     if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain);
-    if (rc == ZK_OK) rc = msm_g1_launch(s0, st, P.d_z, d_abc[0], N - 1, &kMontCfg, &S.jobs[0]);
+    if (rc == ZK_OK) rc = msm5_launch(g.s, st, in, ev_w, &S, /*z_now=*/false, nullptr, /*prepare_only=*/true);
+    hipEvent_t ev_h = nullptr;
+    if (rc == ZK_OK && hipEventCreateWithFlags(&ev_h, hipEventDisableTiming) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventCreate failed");
+    if (rc == ZK_OK && hipEventRecord(ev_h, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventRecord failed");
+    in.d_h = d_abc[0];
+    if (rc == ZK_OK) rc = msm5_launch(g.s, st, in, ev_w, &S, /*z_now=*/true, ev_h, false, /*accumulate_only=*/true);
+    if (ev_h) (void)hipEventDestroy(ev_h);
     uint64_t parts[96];
+    TailPre T;
+    if (rc == ZK_OK) tail_pre(P, r_, s_, &T);  // host work hidden under the GPU's
     if (rc == ZK_OK) rc = msm5_finish(&S, parts);
     else {
-        for (int i = 0; i < 5; i++) (void)hipStreamSynchronize(g.s[i]->stream);
+        for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(g.s[i]->stream); (void)hipStreamSynchronize(g.s[i]->stream_hi); }
         msm_prep_release(&S.prep_w);
+        msm_prep_release(&S.prep_h);
     }
     (void)hipEventDestroy(ev_w);
     if (rc != ZK_OK) return rc;
-    finalize(P, parts, 1, r_, s_, proof_out);
+    tail_post(P, T, parts, 1, proof_out);
     return ZK_OK;
 }
 

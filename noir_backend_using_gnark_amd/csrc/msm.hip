@@ -427,6 +427,7 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
 // the preparation when it ran elsewhere.  `d_pts` is indexed by the scalar index; indices < skip_below are skipped.
 template <class F>
 static int msm_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const Affine<F>* d_pts, uint32_t skip_below, MsmJob* job) {
+    // job->gate_acc (in, optional): the accumulate kernel waits for it; job->want_done (in): record job->acc_done after it.
     typedef XYZZ<F> Pt;
     const MsmPlan& P = R.P;
     job->s = s;
@@ -444,11 +445,16 @@ static int msm_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const Affin
     if (!partial || !lvlA[0] || !lvlA[1] || !lvlS[0] || !lvlS[1])
         return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
     if (R.ready) ZK_HIP(hipStreamWaitEvent(st, R.ready, 0));
+    if (job->gate_acc) ZK_HIP(hipStreamWaitEvent(st, job->gate_acc, 0));
     // ---- 5. accumulate
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
     ZK_LAUNCH(s, st, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, d_pts, R.vals, R.task_begin, R.lkeys, R.tids,
               L, (uint32_t)max_tasks, skip_below, partial);
     ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial, R.task_off, R.multi_list, R.num_multi);
+    if (job->want_done) {
+        ZK_HIP(hipEventCreateWithFlags(&job->acc_done, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(job->acc_done, st));
+    }
     // ---- 6. bucket reduce
     ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial, R.task_off, B,
               W, m1, lvlA[0], lvlS[0]);

@@ -33,6 +33,11 @@ struct MsmJob {
     hipStream_t st = nullptr;
     unsigned c = 0, W = 0;
     bool empty = true;
+    // scheduling hooks (set by the caller BEFORE launch): the throughput-bound accumulate kernel waits for `gate_acc`;
+    // with `want_done` an event `acc_done` is recorded right after it (the caller destroys it).
+    hipEvent_t gate_acc = nullptr;
+    bool want_done = false;
+    hipEvent_t acc_done = nullptr;
 };
 int msm_g1_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job);
 int msm_g2_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job);
