@@ -1,0 +1,358 @@
+// Unsaturated Fp arithmetic for the MSM accumulate kernels on gfx950: 9 limbs of 29 bits in 32-bit registers,
+// Montgomery radix R' = 2^261, lazily reduced values.
+//
+// Same mathematical object as ff.hpp's Field<FpParams> (gnark-crypto `fp.Element`, /root/reference/gnark_backend_ffi/go.mod:5),
+// different in-register representation.  Memory keeps gnark's image (8 x u32, Montgomery 2^256, canonical):
+//     load : canonical V = x*2^256 mod p  ->  X = V << 5   (= x*2^261 mod p up to a multiple of p; X < 32 p)
+//     store: Montgomery-multiply by 2^256, ripple-normalise, subtract 2p / p  ->  canonical V again
+// Why: measured on MI355X (tools/ubench*.hip) a v_mad_u64_u32 costs the same issue time (~4.6 cycles/wave) as the carry
+// instruction that must follow it in the saturated schedule.  With 29-bit limbs a 64-bit column accumulator takes all 18
+// products of a column with no carry handling: 206 instructions per product instead of ~305; additions are 9 plain
+// v_add_u32; subtractions add a multiple of p whose limbs dominate the subtrahend's ("bias") and re-normalise in one
+// parallel pass.  Values are NOT canonical in flight: tools/u29_model.py propagates worst-case bounds through the exact
+// operation sequence of xyzz_madd29() to its fixed point (x < 13.5 p, y < 6 p, zz, zzz < 2 p, every limb < 2^32, every
+// column sum < 2^64) and cross-checks the limb algorithms against big integers.
+#pragma once
+#include "curve.hpp"
+#include "ff29_mul_gfx950.inc"
+
+namespace zkmi {
+
+struct U29 {
+    uint32_t l[9];
+};
+
+struct Fp29 {
+    static constexpr uint32_t MASK = 0x1fffffffu;
+    static constexpr uint32_t P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t NINV = 0x04866389u;  // -p^-1 mod 2^29
+    // 2^261 mod p: "one" of the radix-2^261 Montgomery domain (normalised limbs)
+    static constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    // k*p with every limb >= 2^30 (the top limb takes the rest): a + BIAS_k - b has no negative limb for a weakly normalised b < k*p
+    static constexpr uint32_t BIAS4[9] = {0x41f3f51cu, 0x441182d9u, 0x51ca8d3au, 0x4b548b41u, 0x561765deu, 0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u};
+    static constexpr uint32_t BIAS8[9] = {0x43e7ea38u, 0x482305b4u, 0x43951a76u, 0x56a91685u, 0x4c2ecbbeu, 0x56da0603u, 0x45370a06u, 0x52e1319eu, 0x01832271u};
+    static constexpr uint32_t BIAS12[9] = {0x45dbdf54u, 0x4c34888fu, 0x555fa7b2u, 0x41fda1c8u, 0x4246319fu, 0x42470906u, 0x47d28f0bu, 0x4c51ca6eu, 0x0244b3abu};
+    static constexpr uint32_t BIAS16[9] = {0x47cfd470u, 0x50460b6au, 0x472a34eeu, 0x4d522d0cu, 0x585d977fu, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
+    static constexpr uint32_t BIAS24[9] = {0x4bb7bea8u, 0x58691120u, 0x4abf4f66u, 0x43fb4393u, 0x448c6340u, 0x448e120eu, 0x4fa51e18u, 0x58a394deu, 0x04896758u};
+    template <int K>
+    static constexpr uint32_t bias(int i) {
+        static_assert(K == 4 || K == 8 || K == 12 || K == 16 || K == 24, "no bias table for this multiple of p");
+        return K == 4 ? BIAS4[i] : K == 8 ? BIAS8[i] : K == 12 ? BIAS12[i] : K == 16 ? BIAS16[i] : BIAS24[i];
+    }
+};
+
+__device__ __forceinline__ U29 u29_one() {
+    U29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = Fp29::ONE[i];
+    return r;
+}
+
+// a * b / 2^261 mod p (lazily reduced: < a*b/2^261 + p), limbs 0..7 < 2^29
+__device__ __forceinline__ U29 u29_mul(const U29& a, const U29& b) {
+    U29 r;
+    asm(ZKMI_MONT_MUL29_ASM
+        : [r0] "=&v"(r.l[0]), [r1] "=&v"(r.l[1]), [r2] "=&v"(r.l[2]), [r3] "=&v"(r.l[3]), [r4] "=&v"(r.l[4]), [r5] "=&v"(r.l[5]),
+          [r6] "=&v"(r.l[6]), [r7] "=&v"(r.l[7]), [r8] "=&v"(r.l[8])
+        : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]), [a5] "v"(a.l[5]), [a6] "v"(a.l[6]),
+          [a7] "v"(a.l[7]), [a8] "v"(a.l[8]), [b0] "v"(b.l[0]), [b1] "v"(b.l[1]), [b2] "v"(b.l[2]), [b3] "v"(b.l[3]), [b4] "v"(b.l[4]),
+          [b5] "v"(b.l[5]), [b6] "v"(b.l[6]), [b7] "v"(b.l[7]), [b8] "v"(b.l[8]), [p0] "s"(Fp29::P[0]), [p1] "s"(Fp29::P[1]),
+          [p2] "s"(Fp29::P[2]), [p3] "s"(Fp29::P[3]), [p4] "s"(Fp29::P[4]), [p5] "s"(Fp29::P[5]), [p6] "s"(Fp29::P[6]), [p7] "s"(Fp29::P[7]),
+          [p8] "s"(Fp29::P[8]), [ninv] "s"(Fp29::NINV)
+        : "v0", "v1", "vcc");
+    return r;
+}
+
+// Out-of-line copy for the G2 kernels: an Fp2 mixed addition is 32 products; inlined, its loop body is ~8k instructions
+// (~64 KiB) and thrashes the instruction cache shared by a CU pair.  One shared 206-instruction body keeps the loop small.
+__device__ __attribute__((noinline)) U29 u29_mul_call(U29 a, U29 b) { return u29_mul(a, b); }
+
+__device__ __forceinline__ U29 u29_add(const U29& a, const U29& b) {
+    U29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+
+// a - b + K*p  (b must be weakly normalised and < K*p)
+template <int K>
+__device__ __forceinline__ U29 u29_sub(const U29& a, const U29& b) {
+    U29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.l[i] = a.l[i] - b.l[i] + Fp29::bias<K>(i);
+    }
+    return r;
+}
+
+// one parallel carry pass: limbs 0..7 back below 2^29 + 8
+__device__ __forceinline__ U29 u29_wnorm(const U29& a) {
+    U29 r;
+    r.l[0] = a.l[0] & Fp29::MASK;
+#pragma unroll
+    for (int i = 1; i < 8; i++) r.l[i] = (a.l[i] & Fp29::MASK) + (a.l[i - 1] >> 29);
+    r.l[8] = a.l[8] + (a.l[7] >> 29);
+    return r;
+}
+
+// exact carry propagation (serial): limbs 0..7 < 2^29
+__device__ __forceinline__ U29 u29_ripple(const U29& a) {
+    U29 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t t = a.l[i] + c;
+        r.l[i] = t & Fp29::MASK;
+        c = t >> 29;
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
+
+// canonical Montgomery-2^256 image (8 x u32, < p) -> V << 5 in 29-bit limbs
+__device__ __forceinline__ U29 u29_load(const Fp& v) {
+    U29 r;
+    const uint32_t* w = v.l;
+    r.l[0] = (w[0] << 5) & Fp29::MASK;
+    r.l[1] = __funnelshift_r(w[0], w[1], 24) & Fp29::MASK;
+    r.l[2] = __funnelshift_r(w[1], w[2], 21) & Fp29::MASK;
+    r.l[3] = __funnelshift_r(w[2], w[3], 18) & Fp29::MASK;
+    r.l[4] = __funnelshift_r(w[3], w[4], 15) & Fp29::MASK;
+    r.l[5] = __funnelshift_r(w[4], w[5], 12) & Fp29::MASK;
+    r.l[6] = __funnelshift_r(w[5], w[6], 9) & Fp29::MASK;
+    r.l[7] = __funnelshift_r(w[6], w[7], 6) & Fp29::MASK;
+    r.l[8] = w[7] >> 3;
+    return r;
+}
+
+// any lazily reduced value (< 2^260) -> canonical Montgomery-2^256 image
+__device__ __forceinline__ Fp u29_store(const U29& x) {
+    U29 c;
+#pragma unroll
+    for (int i = 0; i < 8; i++) c.l[i] = 0;
+    c.l[8] = 1u << 24;  // 2^256
+    U29 t = u29_ripple(u29_mul(x, c));  // = x * 2^256 / 2^261 ; < x/32 + p < 10 p for every x this file produces
+    uint32_t w[8];
+    w[0] = t.l[0] | (t.l[1] << 29);
+    w[1] = (t.l[1] >> 3) | (t.l[2] << 26);
+    w[2] = (t.l[2] >> 6) | (t.l[3] << 23);
+    w[3] = (t.l[3] >> 9) | (t.l[4] << 20);
+    w[4] = (t.l[4] >> 12) | (t.l[5] << 17);
+    w[5] = (t.l[5] >> 15) | (t.l[6] << 14);
+    w[6] = (t.l[6] >> 18) | (t.l[7] << 11);
+    w[7] = (t.l[7] >> 21) | (t.l[8] << 8);
+    // every value this file stores is < 13.5 p, so t < 1.5 p; handle t < 4 p anyway: conditional subtractions of 2p, then p
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = w[i];
+#pragma unroll
+    for (int k = 1; k >= 0; k--) {
+        uint32_t s[8];
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t pk = (k == 0) ? FpParams::MOD[i] : ((FpParams::MOD[i] << 1) | (i ? (FpParams::MOD[i - 1] >> 31) : 0u));
+            uint64_t d = (uint64_t)r.l[i] - pk - bw;
+            s[i] = (uint32_t)d;
+            bw = d >> 63;
+        }
+        if (!bw) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) r.l[i] = s[i];
+        }
+    }
+    return r;
+}
+
+// x is the direct output of u29_mul with a product bound < p*2^261 (so x < 2p): x == 0 mod p ?
+__device__ __forceinline__ bool u29_mulout_is_zero(const U29& x) {
+    U29 t = u29_ripple(x);
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        z |= t.l[i];
+        e |= t.l[i] ^ Fp29::P[i];
+    }
+    return z == 0 || e == 0;
+}
+
+// XYZZ accumulator in the unsaturated representation (G1)
+struct Acc29 {
+    U29 x, y, zz, zzz;
+    bool inf;
+};
+
+__device__ __forceinline__ void acc29_from_xyzz(Acc29& A, const XYZZ<Fp>& c) {
+    A.inf = c.is_inf();
+    const U29 one = u29_one();
+    A.x = u29_mul(u29_load(c.x), one);  // contracting multiplication: value < 1.2 p
+    A.y = u29_mul(u29_load(c.y), one);
+    A.zz = u29_mul(u29_load(c.zz), one);
+    A.zzz = u29_mul(u29_load(c.zzz), one);
+}
+__device__ __forceinline__ XYZZ<Fp> acc29_to_xyzz(const Acc29& A) {
+    if (A.inf) return XYZZ<Fp>::inf();
+    return XYZZ<Fp>{u29_store(A.x), u29_store(A.y), u29_store(A.zz), u29_store(A.zzz)};
+}
+
+// A += (px, py), an affine point in gnark's memory image (sign already applied).  madd-2008-s; the operation order and
+// bias multiples are exactly those of tools/u29_model.py::madd_fp.
+__device__ __forceinline__ void xyzz_madd29(Acc29& A, const Fp& px, const Fp& py) {
+    if (px.is_zero() && py.is_zero()) return;
+    const U29 x2 = u29_load(px), y2 = u29_load(py);
+    if (A.inf) {
+        const U29 one = u29_one();
+        A.x = u29_mul(x2, one);
+        A.y = u29_mul(y2, one);
+        A.zz = one;
+        A.zzz = one;
+        A.inf = false;
+        return;
+    }
+    const U29 U2 = u29_mul(x2, A.zz);
+    const U29 S2 = u29_mul(y2, A.zzz);
+    const U29 P = u29_wnorm(u29_sub<16>(U2, A.x));
+    const U29 R = u29_wnorm(u29_sub<8>(S2, A.y));
+    const U29 PP = u29_mul(P, P);
+    const U29 ZZ3 = u29_mul(A.zz, PP);
+    if (u29_mulout_is_zero(ZZ3)) {
+        // P == 0 mod p: same x.  Doubling or P + (-P): rare, take the canonical saturated path (inline: an out-of-line
+        // call here costs the G1 kernel 25 VGPRs and a wave of occupancy).
+        XYZZ<Fp> c = acc29_to_xyzz(A);
+        c.madd(px, py);
+        acc29_from_xyzz(A, c);
+        return;
+    }
+    const U29 PPP = u29_mul(P, PP);
+    const U29 Q = u29_mul(A.x, PP);
+    U29 t = u29_mul(R, R);
+    t = u29_wnorm(u29_sub<4>(t, PPP));
+    t = u29_sub<4>(t, Q);
+    t = u29_sub<4>(t, Q);
+    const U29 X3 = u29_wnorm(t);
+    const U29 d = u29_wnorm(u29_sub<16>(Q, X3));
+    const U29 Y3 = u29_wnorm(u29_sub<4>(u29_mul(R, d), u29_mul(A.y, PPP)));
+    A.zzz = u29_mul(A.zzz, PPP);
+    A.zz = ZZ3;
+    A.x = X3;
+    A.y = Y3;
+}
+
+// ------------------------------------------------------------------------------------------------------------ G2 (Fp2)
+// Components are lazily reduced U29 values.  Operation order, bias multiples and the two contractions are exactly those of
+// tools/u29_model.py::madd_fp2, whose bound propagation closes at x, y < 2 p, zz, zzz < 10.6 p.
+struct U29x2 {
+    U29 c0, c1;
+};
+
+__device__ __forceinline__ U29x2 f2_mul29(const U29x2& a, const U29x2& b) {
+    const U29 v0 = u29_mul_call(a.c0, b.c0), v1 = u29_mul_call(a.c1, b.c1);
+    const U29 s = u29_mul_call(u29_add(a.c0, a.c1), u29_add(b.c0, b.c1));
+    U29x2 r;
+    r.c0 = u29_wnorm(u29_sub<4>(v0, v1));
+    r.c1 = u29_wnorm(u29_sub<4>(u29_sub<4>(s, v0), v1));
+    return r;
+}
+// (a0+a1)(a0-a1), 2 a0 a1 ; *m_out = a0*a1 (a direct product output: cheap zero filter for the caller)
+template <int KD>
+__device__ __forceinline__ U29x2 f2_sqr29(const U29x2& a, U29* m_out) {
+    const U29 d = u29_wnorm(u29_sub<KD>(a.c0, a.c1));
+    const U29 m = u29_mul_call(a.c0, a.c1);
+    U29x2 r;
+    r.c0 = u29_mul_call(u29_add(a.c0, a.c1), d);
+    r.c1 = u29_add(m, m);
+    if (m_out) *m_out = m;
+    return r;
+}
+template <int K>
+__device__ __forceinline__ U29x2 f2_sub29(const U29x2& a, const U29x2& b) {
+    return U29x2{u29_wnorm(u29_sub<K>(a.c0, b.c0)), u29_wnorm(u29_sub<K>(a.c1, b.c1))};
+}
+__device__ __forceinline__ U29x2 f2_contract29(const U29x2& a) {
+    const U29 one = u29_one();
+    return U29x2{u29_mul_call(a.c0, one), u29_mul_call(a.c1, one)};
+}
+__device__ __forceinline__ U29x2 f2_load29(const Fp2& v) { return U29x2{u29_load(v.a0), u29_load(v.a1)}; }
+__device__ __forceinline__ Fp2 f2_store29(const U29x2& v) { return Fp2{u29_store(v.c0), u29_store(v.c1)}; }
+
+// m < 3p is a direct product output: m == 0 mod p ?
+__device__ __forceinline__ bool u29_mulout3_is_zero(const U29& x) {
+    U29 t = u29_ripple(x);
+    uint32_t z = 0, e1 = 0, e2 = 0;
+    // 2p in normalised limbs
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        uint32_t p2 = 2 * Fp29::P[i] + c;
+        c = (i < 8) ? (p2 >> 29) : 0;
+        if (i < 8) p2 &= Fp29::MASK;
+        z |= t.l[i];
+        e1 |= t.l[i] ^ Fp29::P[i];
+        e2 |= t.l[i] ^ p2;
+    }
+    return z == 0 || e1 == 0 || e2 == 0;
+}
+
+struct Acc29G2 {
+    U29x2 x, y, zz, zzz;
+    bool inf;
+};
+__device__ __forceinline__ void acc29g2_from_xyzz(Acc29G2& A, const XYZZ<Fp2>& c) {
+    A.inf = c.is_inf();
+    A.x = f2_contract29(f2_load29(c.x));
+    A.y = f2_contract29(f2_load29(c.y));
+    A.zz = f2_contract29(f2_load29(c.zz));
+    A.zzz = f2_contract29(f2_load29(c.zzz));
+}
+__device__ __forceinline__ XYZZ<Fp2> acc29g2_to_xyzz(const Acc29G2& A) {
+    if (A.inf) return XYZZ<Fp2>::inf();
+    return XYZZ<Fp2>{f2_store29(A.x), f2_store29(A.y), f2_store29(A.zz), f2_store29(A.zzz)};
+}
+
+__device__ __attribute__((noinline)) void xyzz_madd29_slow(Acc29G2& A, const Fp2& px, const Fp2& py) {
+    XYZZ<Fp2> c = acc29g2_to_xyzz(A);
+    c.madd(px, py);
+    acc29g2_from_xyzz(A, c);
+}
+
+__device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2& py) {
+    if (px.is_zero() && py.is_zero()) return;
+    const U29x2 x2 = f2_load29(px), y2 = f2_load29(py);
+    if (A.inf) {
+        A.x = f2_contract29(x2);
+        A.y = f2_contract29(y2);
+        U29 z;
+#pragma unroll
+        for (int i = 0; i < 9; i++) z.l[i] = 0;
+        A.zz = U29x2{u29_one(), z};
+        A.zzz = A.zz;
+        A.inf = false;
+        return;
+    }
+    const U29x2 U2 = f2_mul29(x2, A.zz);
+    const U29x2 S2 = f2_mul29(y2, A.zzz);
+    const U29x2 P = f2_sub29<4>(U2, A.x);
+    const U29x2 R = f2_sub29<4>(S2, A.y);
+    U29 m;
+    const U29x2 PP = f2_sqr29<24>(P, &m);
+    if (u29_mulout3_is_zero(m)) {
+        // P0*P1 == 0 mod p is NECESSARY for P == 0 (same x: doubling or P + (-P)); take the canonical saturated path,
+        // which is correct for every input, whenever the filter fires.
+        xyzz_madd29_slow(A, px, py);
+        return;
+    }
+    const U29x2 PPP = f2_mul29(P, PP);
+    const U29x2 Q = f2_mul29(A.x, PP);
+    const U29x2 RR = f2_sqr29<24>(R, nullptr);
+    U29x2 t = f2_sub29<12>(RR, PPP);
+    t = f2_sub29<12>(t, Q);
+    const U29x2 X3 = f2_contract29(f2_sub29<12>(t, Q));
+    const U29x2 d = f2_sub29<4>(Q, X3);
+    const U29x2 Y3 = f2_contract29(f2_sub29<12>(f2_mul29(R, d), f2_mul29(A.y, PPP)));
+    A.zz = f2_mul29(A.zz, PP);
+    A.zzz = f2_mul29(A.zzz, PPP);
+    A.x = X3;
+    A.y = Y3;
+}
+
+}  // namespace zkmi

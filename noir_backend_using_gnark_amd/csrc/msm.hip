@@ -27,6 +27,7 @@
 
 #include "ctx.hpp"
 #include "curve.hpp"
+#include "ff29.hpp"
 #include "host_ff.hpp"
 #include "msm.hpp"
 
@@ -172,15 +173,31 @@ __global__ __launch_bounds__(256) void k_accumulate(const Affine<F>* __restrict_
     if (key == 0xffffffffu) return;
     uint32_t t = task_sorted[i];
     uint32_t begin = task_begin[t], end = begin + (L - key);
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t j = begin; j < end; j++) {
-        uint32_t v = vals[j];
-        if ((v >> 1) < skip_below) continue;  // scalars shared with an MSM whose first bases do not exist (pk.G1.K vs w)
-        Affine<F> p = gload(pts + (v >> 1));
-        if (v & 1) p.y = p.y.neg();
-        acc.madd(p.x, p.y);
+    if constexpr (sizeof(F) == sizeof(Fp)) {
+        // G1: unsaturated 9 x 29-bit accumulator (ff29.hpp); converted back to gnark's image once per task
+        Acc29 acc;
+        acc.inf = true;
+        for (uint32_t j = begin; j < end; j++) {
+            uint32_t v = vals[j];
+            if ((v >> 1) < skip_below) continue;  // scalars shared with an MSM whose first bases do not exist (pk.G1.K vs w)
+            Affine<F> p = gload(pts + (v >> 1));
+            if (v & 1) p.y = p.y.neg();
+            xyzz_madd29(acc, p.x, p.y);
+        }
+        gstore(partial + t, acc29_to_xyzz(acc));
+    } else {
+        // G2: the same representation per Fp2 component
+        Acc29G2 acc;
+        acc.inf = true;
+        for (uint32_t j = begin; j < end; j++) {
+            uint32_t v = vals[j];
+            if ((v >> 1) < skip_below) continue;
+            Affine<F> p = gload(pts + (v >> 1));
+            if (v & 1) p.y = p.y.neg();
+            xyzz_madd29(acc, p.x, p.y);
+        }
+        gstore(partial + t, acc29g2_to_xyzz(acc));
     }
-    gstore(partial + t, acc);
 }
 
 // buckets cut into several tasks: one WAVE folds the bucket's partials into the first one

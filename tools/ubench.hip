@@ -5,6 +5,7 @@
 #include <vector>
 #include "ff.hpp"
 #include "curve.hpp"
+#include "ff29.hpp"
 using namespace zkmi;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -120,6 +121,22 @@ __global__ __launch_bounds__(256) void k_madd(G1XYZZ* out, const G1Affine* in, i
     out[i] = acc;
 }
 
+__global__ __launch_bounds__(256) void k_madd29(G1XYZZ* out, const G1Affine* in, int iters) {
+    size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Acc29 acc;
+    acc.inf = true;
+    G1Affine p = in[i + 1];
+    xyzz_madd29(acc, in[i].x, in[i].y);
+    for (int it = 0; it < iters; it++) { xyzz_madd29(acc, p.x, p.y); p.x.l[0] ^= acc.x.l[0] & 0xff; }
+    out[i] = acc29_to_xyzz(acc);
+}
+__global__ void k_mul29(Fp* out, const Fp* in, int iters) {
+    size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    U29 a = u29_load(in[i]), b = u29_load(in[i + 1]);
+    for (int it = 0; it < iters; it++) { a = u29_mul(a, b); b = u29_mul(b, a); }
+    out[i] = u29_store(u29_mul(a, b));
+}
+
 template <class K, class... A>
 static double timeit(int blocks, int threads, K k, A... args) {
     hipEvent_t e0, e1;
@@ -179,6 +196,15 @@ int main() {
         printf("modmul  waves/SIMD=%d  %8.3f ms  %8.2f Gmul/s   %7.1f cyc/modmul/wave/SIMD\n", wps, ms, muls / ms * 1e-6, ms * 1e-3 * 2.4e9 / (it2 * 2.0 * wps));
         ms = timeit(blocks, 256, k_modadd, (Fp*)out, (const Fp*)in, it2);
         printf("modadd+sub waves/SIMD=%d  %8.3f ms  %8.2f Gop/s   %7.1f cyc/op/wave/SIMD\n", wps, ms, muls / ms * 1e-6, ms * 1e-3 * 2.4e9 / (it2 * 2.0 * wps));
+    }
+    for (int wps : {1, 2, 4}) {
+        int blocks = cus * wps, it2 = 500;
+        double ms = timeit(blocks, 256, k_mul29, (Fp*)out, (const Fp*)in, it2);
+        double muls = (double)blocks * 256 * it2 * 2;
+        printf("mul29   waves/SIMD=%d  %8.3f ms  %8.2f Gmul/s   %7.1f cyc/modmul/wave/SIMD\n", wps, ms, muls / ms * 1e-6, ms * 1e-3 * 2.4e9 / (it2 * 2.0 * wps));
+        it2 = 200;
+        ms = timeit(blocks, 256, k_madd29, (G1XYZZ*)out, (const G1Affine*)in, it2);
+        printf("g1 madd29 waves/SIMD=%d  %8.3f ms  %8.2f Gadd/s   %7.1f cyc/madd/wave/SIMD\n", wps, ms, (double)blocks * 256 * it2 / ms * 1e-6, ms * 1e-3 * 2.4e9 / (it2 * 1.0 * wps));
     }
     for (int wps : {1, 2, 4}) {
         int blocks = cus * wps, it2 = 200;
