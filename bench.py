@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2(constraints) per GPU")
     ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tables", action="store_true", help="disable the precomputed window tables of the resident proving key")
     args = ap.parse_args()
 
     import torch
@@ -102,7 +103,7 @@ def main():
     r, s = rs[0].copy(), rs[1].copy()
     # K is indexed by wire like the other arrays; gnark's pk.G1.K starts at the first private wire
     pk = zk.ProvingKey(log_ng, N_g, n_public, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + n_public * 64, g1_z,
-                       small2["beta"], small2["delta"], g2_b, bases_on_device=True)
+                       small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables)
     d_h = dev(N_g * 32) if world > 1 else None
     _lib.check(L.zk_dev_sync())
     t_setup = time.time() - t_setup

@@ -119,6 +119,8 @@ typedef struct {
     const zk_g2_affine *g2_beta, *g2_delta;
     const zk_g2_affine *g2_b;
     int bases_on_device; /* 1: g1_a, g1_b, g1_k, g1_z, g2_b are DEVICE pointers that stay owned by the caller */
+    int flags;           /* bit 0: do NOT build the precomputed window tables 2^(c*w)*P_i (they cost ~13x the bases in HBM and
+                            are what makes the resident-key MSMs ~20% cheaper; skipped automatically when HBM is short) */
 } zk_groth16_pk;
 int zk_bn254_groth16_pk_load(const zk_groth16_pk *pk, uint64_t *handle);
 int zk_bn254_groth16_pk_free(uint64_t handle);

@@ -25,7 +25,7 @@ class Groth16PK(C.Structure):
     _fields_ = [("log_domain", C.c_uint32), ("n_wires", C.c_size_t), ("n_public", C.c_size_t),
                 ("g1_alpha", C.c_void_p), ("g1_beta", C.c_void_p), ("g1_delta", C.c_void_p),
                 ("g1_a", C.c_void_p), ("g1_b", C.c_void_p), ("g1_k", C.c_void_p), ("g1_z", C.c_void_p),
-                ("g2_beta", C.c_void_p), ("g2_delta", C.c_void_p), ("g2_b", C.c_void_p), ("bases_on_device", C.c_int)]
+                ("g2_beta", C.c_void_p), ("g2_delta", C.c_void_p), ("g2_b", C.c_void_p), ("bases_on_device", C.c_int), ("flags", C.c_int)]
 
 
 # every symbol include/zkmi.h declares (tests check that the library exports exactly these)

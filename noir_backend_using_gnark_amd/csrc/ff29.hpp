@@ -63,10 +63,6 @@ __device__ __forceinline__ U29 u29_mul(const U29& a, const U29& b) {
     return r;
 }
 
-// Out-of-line copy for the G2 kernels: an Fp2 mixed addition is 32 products; inlined, its loop body is ~8k instructions
-// (~64 KiB) and thrashes the instruction cache shared by a CU pair.  One shared 206-instruction body keeps the loop small.
-__device__ __attribute__((noinline)) U29 u29_mul_call(U29 a, U29 b) { return u29_mul(a, b); }
-
 __device__ __forceinline__ U29 u29_add(const U29& a, const U29& b) {
     U29 r;
 #pragma unroll
@@ -246,8 +242,8 @@ struct U29x2 {
 };
 
 __device__ __forceinline__ U29x2 f2_mul29(const U29x2& a, const U29x2& b) {
-    const U29 v0 = u29_mul_call(a.c0, b.c0), v1 = u29_mul_call(a.c1, b.c1);
-    const U29 s = u29_mul_call(u29_add(a.c0, a.c1), u29_add(b.c0, b.c1));
+    const U29 v0 = u29_mul(a.c0, b.c0), v1 = u29_mul(a.c1, b.c1);
+    const U29 s = u29_mul(u29_add(a.c0, a.c1), u29_add(b.c0, b.c1));
     U29x2 r;
     r.c0 = u29_wnorm(u29_sub<4>(v0, v1));
     r.c1 = u29_wnorm(u29_sub<4>(u29_sub<4>(s, v0), v1));
@@ -257,9 +253,9 @@ __device__ __forceinline__ U29x2 f2_mul29(const U29x2& a, const U29x2& b) {
 template <int KD>
 __device__ __forceinline__ U29x2 f2_sqr29(const U29x2& a, U29* m_out) {
     const U29 d = u29_wnorm(u29_sub<KD>(a.c0, a.c1));
-    const U29 m = u29_mul_call(a.c0, a.c1);
+    const U29 m = u29_mul(a.c0, a.c1);
     U29x2 r;
-    r.c0 = u29_mul_call(u29_add(a.c0, a.c1), d);
+    r.c0 = u29_mul(u29_add(a.c0, a.c1), d);
     r.c1 = u29_add(m, m);
     if (m_out) *m_out = m;
     return r;
@@ -270,7 +266,7 @@ __device__ __forceinline__ U29x2 f2_sub29(const U29x2& a, const U29x2& b) {
 }
 __device__ __forceinline__ U29x2 f2_contract29(const U29x2& a) {
     const U29 one = u29_one();
-    return U29x2{u29_mul_call(a.c0, one), u29_mul_call(a.c1, one)};
+    return U29x2{u29_mul(a.c0, one), u29_mul(a.c1, one)};
 }
 __device__ __forceinline__ U29x2 f2_load29(const Fp2& v) { return U29x2{u29_load(v.a0), u29_load(v.a1)}; }
 __device__ __forceinline__ Fp2 f2_store29(const U29x2& v) { return Fp2{u29_store(v.c0), u29_store(v.c1)}; }
@@ -309,12 +305,6 @@ __device__ __forceinline__ XYZZ<Fp2> acc29g2_to_xyzz(const Acc29G2& A) {
     return XYZZ<Fp2>{f2_store29(A.x), f2_store29(A.y), f2_store29(A.zz), f2_store29(A.zzz)};
 }
 
-__device__ __attribute__((noinline)) void xyzz_madd29_slow(Acc29G2& A, const Fp2& px, const Fp2& py) {
-    XYZZ<Fp2> c = acc29g2_to_xyzz(A);
-    c.madd(px, py);
-    acc29g2_from_xyzz(A, c);
-}
-
 __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2& py) {
     if (px.is_zero() && py.is_zero()) return;
     const U29x2 x2 = f2_load29(px), y2 = f2_load29(py);
@@ -338,7 +328,9 @@ __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2
     if (u29_mulout3_is_zero(m)) {
         // P0*P1 == 0 mod p is NECESSARY for P == 0 (same x: doubling or P + (-P)); take the canonical saturated path,
         // which is correct for every input, whenever the filter fires.
-        xyzz_madd29_slow(A, px, py);
+        XYZZ<Fp2> c = acc29g2_to_xyzz(A);
+        c.madd(px, py);
+        acc29g2_from_xyzz(A, c);
         return;
     }
     const U29x2 PPP = f2_mul29(P, PP);

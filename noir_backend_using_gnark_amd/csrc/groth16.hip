@@ -11,6 +11,7 @@
 // The prover randomness (r, s) is an INPUT here (upstream: crypto/rand), which is what makes proof bytes reproducible.
 // The five MSMs and the NTTs run on the device; the O(1) tail (5 scalar multiplications, a few additions, 3 inversions,
 // compression) runs on the host like upstream.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.hpp"
@@ -28,6 +29,12 @@ struct Groth16PK {
     Affine<HFp2> beta2, delta2;
     void *d_a = nullptr, *d_b = nullptr, *d_k = nullptr, *d_z = nullptr, *d_b2 = nullptr;
     bool owns = true;
+    // precomputed window tables T[w][i] = 2^(c*w) * P_i for the five base arrays (resident; built once at load time):
+    // every window of an MSM then shares one bucket set -- ceil(255/c) * n mixed additions with c ~ 20 instead of 16 windows
+    // of c = 16, one bucket reduction instead of 16, no Horner.  The K table uses wire indexing (first n_public rows = infinity).
+    bool tables = false;
+    MsmTable tab_w, tab_h;
+    void *t_a = nullptr, *t_b = nullptr, *t_k = nullptr, *t_z = nullptr, *t_b2 = nullptr;
 };
 static std::mutex g_pk_mu;
 static std::map<uint64_t, Groth16PK> g_pks;
@@ -107,6 +114,33 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
             if (u.bytes) ZK_HIP(hipMemcpy(*u.d, u.h, u.bytes, hipMemcpyHostToDevice));
         }
     }
+    // ---- precomputed window tables (unless disabled or HBM is short)
+    if (!(pk->flags & 1) && pk->n_wires > 0 && N > 1) {
+        P.tab_w.c = msm_pick_window_table(pk->n_wires);
+        P.tab_w.stride = pk->n_wires;
+        P.tab_h.c = msm_pick_window_table(N - 1);
+        P.tab_h.stride = N;
+        const size_t Ww = (255 + P.tab_w.c - 1) / P.tab_w.c, Wh = (255 + P.tab_h.c - 1) / P.tab_h.c;
+        const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
+        size_t free_b = 0, total_b = 0;
+        ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (bytes < free_b / 2) {
+            SlotGuard g;
+            ZK_TRY(acquire_slot(&g.s));
+            hipStream_t st = g.s->stream;
+            struct { void** t; const void* src; size_t n, stride, off, esz; unsigned c; size_t Wd; int g2; } jobs[5] = {
+                {&P.t_a, P.d_a, pk->n_wires, pk->n_wires, 0, 64, P.tab_w.c, Ww, 0},  {&P.t_b, P.d_b, pk->n_wires, pk->n_wires, 0, 64, P.tab_w.c, Ww, 0},
+                {&P.t_k, P.d_k, nk, pk->n_wires, pk->n_public, 64, P.tab_w.c, Ww, 0}, {&P.t_z, P.d_z, N - 1, N, 0, 64, P.tab_h.c, Wh, 0},
+                {&P.t_b2, P.d_b2, pk->n_wires, pk->n_wires, 0, 128, P.tab_w.c, Ww, 1}};
+            for (auto& j : jobs) {
+                ZK_HIP(hipMalloc(j.t, j.Wd * j.stride * j.esz));
+                ZK_TRY(j.g2 ? msm_build_table_g2(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t)
+                            : msm_build_table_g1(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t));
+            }
+            ZK_TRY(slot_sync(g.s, st));
+            P.tables = true;
+        }
+    }
     std::lock_guard<std::mutex> lk(g_pk_mu);
     *handle = g_next_pk++;
     g_pks[*handle] = P;
@@ -119,6 +153,8 @@ int zk_bn254_groth16_pk_free(uint64_t handle) {
     if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
     if (it->second.owns)
         for (void* d : {it->second.d_a, it->second.d_b, it->second.d_k, it->second.d_z, it->second.d_b2}) (void)hipFree(d);
+    if (it->second.tables)
+        for (void* d : {it->second.t_a, it->second.t_b, it->second.t_k, it->second.t_z, it->second.t_b2}) (void)hipFree(d);
     g_pks.erase(it);
     return ZK_OK;
 }
@@ -135,6 +171,9 @@ struct Msm5Inputs {
     size_t nk;
     const void *d_z, *d_h;
     size_t nz;
+    // optional precomputed tables (then d_a, d_b, d_b2, d_k, d_z are ignored)
+    const MsmTable *tab_w = nullptr, *tab_h = nullptr;
+    const void *t_a = nullptr, *t_b = nullptr, *t_b2 = nullptr, *t_k = nullptr, *t_z = nullptr;
 };
 static const zk_msm_cfg kMontCfg = {0, 1, 0, 0};  // scalars are Montgomery fr.Element images
 
@@ -168,42 +207,56 @@ static int msm5_launch(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, hipEv
     const bool share_k = k_shares_w(in, &j);
     if (!accumulate_only) {
         if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
-        ZK_TRY(msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w));
+        if (in.tab_w) ZK_TRY(msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w));
+        else ZK_TRY(msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w));
     }
     if (prepare_only) return ZK_OK;
     // The accumulate kernels are chained G2.B -> (Z) -> A -> B1 -> K through events: each one gets the whole machine,
     // and the latency-bound reduction tail of one MSM runs underneath the next MSM's accumulate.  (Measured: letting the
     // four kernels share the GPU starves the big G2 kernel, which then finishes last, alone, with its tail exposed.)
-    if (gate) ZK_HIP(hipStreamWaitEvent(st4, gate, 0));
-    // Z's scalar-side preparation (sort of h) goes before the first accumulate kernel: once an accumulate kernel owns the
-    // machine, the bandwidth-bound sort kernels of another stream are starved (measured: 0.5 ms -> 5 ms).
+    // Two orders (ZKMI_SCHED=0 selects the first):
+    //   h-first: computeH and both preparations run alone, then the chain G2.B -> Z -> A -> B1 -> K;
+    //   w-first (default): the chain G2.B -> A -> B1 -> K starts as soon as w is prepared; computeH and the preparation of h run
+    //            underneath it on the high-priority stream (slowed down, but they have ~8 ms to finish), Z goes last.
+    static const bool w_first = !(getenv("ZKMI_SCHED") && atoi(getenv("ZKMI_SCHED")) == 0);
+    if (gate && !w_first) ZK_HIP(hipStreamWaitEvent(st4, gate, 0));
     if (z_now) {
-        ZK_TRY(msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h));
-        if (S->prep_h.ready) ZK_HIP(hipStreamWaitEvent(st4, S->prep_h.ready, 0));
+        if (in.tab_h) ZK_TRY(msm_prepare_scalars_table(sl[0], st0, in.d_h, in.nz, &kMontCfg, *in.tab_h, &S->prep_h));
+        else ZK_TRY(msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h));
+        // h-first: once an accumulate kernel owns the machine, the sort kernels of another stream are starved, so wait for them
+        if (S->prep_h.ready && !w_first) ZK_HIP(hipStreamWaitEvent(st4, S->prep_h.ready, 0));
     }
     S->jobs[4].want_done = true;
-    ZK_TRY(msm_g2_accumulate(sl[4], st4, S->prep_w, in.d_b2, 0, &S->jobs[4]));
+    ZK_TRY(msm_g2_accumulate(sl[4], st4, S->prep_w, in.tab_w ? in.t_b2 : in.d_b2, 0, &S->jobs[4]));
     hipEvent_t prev = S->jobs[4].acc_done;
-    if (z_now) {
+    if (z_now && !w_first) {
         S->jobs[0].gate_acc = prev;
         S->jobs[0].want_done = true;
-        ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.d_z, 0, &S->jobs[0]));
+        ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
         if (S->jobs[0].acc_done) prev = S->jobs[0].acc_done;
     }
     S->jobs[1].gate_acc = prev;
     S->jobs[1].want_done = true;
-    ZK_TRY(msm_g1_accumulate(sl[1], sl[1]->stream, S->prep_w, in.d_a, 0, &S->jobs[1]));
+    ZK_TRY(msm_g1_accumulate(sl[1], sl[1]->stream, S->prep_w, in.tab_w ? in.t_a : in.d_a, 0, &S->jobs[1]));
     if (S->jobs[1].acc_done) prev = S->jobs[1].acc_done;
     S->jobs[2].gate_acc = prev;
     S->jobs[2].want_done = true;
-    ZK_TRY(msm_g1_accumulate(sl[2], sl[2]->stream, S->prep_w, in.d_b, 0, &S->jobs[2]));
+    ZK_TRY(msm_g1_accumulate(sl[2], sl[2]->stream, S->prep_w, in.tab_w ? in.t_b : in.d_b, 0, &S->jobs[2]));
     if (S->jobs[2].acc_done) prev = S->jobs[2].acc_done;
     S->jobs[3].gate_acc = prev;
-    if (share_k) {
+    S->jobs[3].want_done = w_first;
+    if (in.tab_w) {
+        ZK_TRY(msm_g1_accumulate(sl[3], sl[3]->stream, S->prep_w, in.t_k, 0, &S->jobs[3]));  // K table is wire-indexed
+    } else if (share_k) {
         ZK_TRY(msm_g1_accumulate(sl[3], sl[3]->stream, S->prep_w, (const char*)in.d_k - j * 64, (uint32_t)j, &S->jobs[3]));
     } else {
         if (ev_w) ZK_HIP(hipStreamWaitEvent(sl[3]->stream, ev_w, 0));
         ZK_TRY(msm_g1_launch(sl[3], sl[3]->stream, in.d_k, in.d_wk, in.nk, &kMontCfg, &S->jobs[3]));
+    }
+    if (z_now && w_first) {
+        if (S->jobs[3].acc_done) prev = S->jobs[3].acc_done;
+        S->jobs[0].gate_acc = prev;
+        ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
     }
     return ZK_OK;
 }
@@ -231,12 +284,19 @@ static int msm5_finish(Msm5State* S, uint64_t out[96]) {
 // arena reservations: slot 0 also carries `extra0` bytes of the caller's own buffers
 static int msm5_reserve(Slot* sl[5], const Msm5Inputs& in, size_t extra0) {
     size_t need[5] = {0, 0, 0, 0, 0}, prep = 0, acc1 = 0, acc2 = 0, j = 0;
-    ZK_TRY(msm_g1_need(in.nz, &kMontCfg, sl[0]->stream, &need[0]));
-    ZK_TRY(msm_prep_need(in.nw, &kMontCfg, sl[1]->stream, &prep, &acc1, &acc2));
+    if (in.tab_h) {
+        size_t ph = 0, ah = 0;
+        ZK_TRY(msm_prep_need_table(in.nz, *in.tab_h, sl[0]->stream, &ph, &ah, nullptr));
+        need[0] = ph + ah;
+    } else {
+        ZK_TRY(msm_g1_need(in.nz, &kMontCfg, sl[0]->stream, &need[0]));
+    }
+    if (in.tab_w) ZK_TRY(msm_prep_need_table(in.nw, *in.tab_w, sl[1]->stream, &prep, &acc1, &acc2));
+    else ZK_TRY(msm_prep_need(in.nw, &kMontCfg, sl[1]->stream, &prep, &acc1, &acc2));
     need[1] = acc1;
     need[2] = acc1;
     need[4] = prep + acc2;
-    if (k_shares_w(in, &j)) need[3] = acc1;
+    if (in.tab_w || k_shares_w(in, &j)) need[3] = acc1;
     else ZK_TRY(msm_g1_need(in.nk, &kMontCfg, sl[3]->stream, &need[3]));
     need[0] += extra0;
     for (int i = 0; i < 5; i++) ZK_TRY(sl[i]->reserve(need[i] + 4096));
@@ -352,6 +412,10 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     hipStream_t st = s0->stream_hi;
     Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, nullptr, nw, P.d_k, nullptr, nk, P.d_z, nullptr, N - 1};
     in.d_wk = (const char*)in.d_w + P.n_public * 32;  // placeholder geometry for the reservation; real pointers below
+    if (P.tables) {
+        in.tab_w = &P.tab_w; in.tab_h = &P.tab_h;
+        in.t_a = P.t_a; in.t_b = P.t_b; in.t_b2 = P.t_b2; in.t_k = P.t_k; in.t_z = P.t_z;
+    }
     ZK_TRY(msm5_reserve(g.s, in, 3 * N * 32 + nw * 32 + 4096));
     hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     // wire values first: the A / B1 / K / B2 MSMs only need w and start while computeH is still running on stream 0

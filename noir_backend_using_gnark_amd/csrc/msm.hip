@@ -72,7 +72,10 @@ __device__ __forceinline__ T shfl_xor_t(const T& v, unsigned d) {
 
 // ---------------------------------------------------------------------------------------- 1. digits
 // gnark-crypto partitionScalars: digit = bits [w*c, (w+1)*c) + carry; if digit > 2^(c-1): digit -= 2^c, carry = 1.
-__global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c, unsigned W, uint32_t* keys, uint32_t* vals) {
+// Table mode (table_stride != 0; resident bases with precomputed 2^(c*w) * P_i): every window shares ONE bucket set, so the
+// key is the digit magnitude alone and the value indexes the table entry (w, i).
+__global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c, unsigned W, uint32_t* keys, uint32_t* vals,
+                             uint32_t table_stride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s;
@@ -84,7 +87,7 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
     }
     if (mont) s = s.from_mont();
     const uint32_t B = 1u << (c - 1);
-    const uint32_t sentinel = W * B;
+    const uint32_t sentinel = table_stride ? B : W * B;
     uint32_t carry = 0;
     for (unsigned w = 0; w < W; w++) {
         unsigned bit = w * c, limb = bit >> 5, off = bit & 31;
@@ -103,8 +106,13 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
             carry = 1;
         }
         size_t o = (size_t)w * n + i;
-        keys[o] = mag ? (w * B + (mag - 1)) : sentinel;
-        vals[o] = (i << 1) | neg;
+        if (table_stride) {
+            keys[o] = mag ? (mag - 1) : sentinel;
+            vals[o] = ((w * table_stride + i) << 1) | neg;
+        } else {
+            keys[o] = mag ? (w * B + (mag - 1)) : sentinel;
+            vals[o] = (i << 1) | neg;
+        }
     }
 }
 
@@ -303,24 +311,46 @@ unsigned msm_pick_window(size_t n) {
 
 // Sizes every buffer of one MSM call; `need` is what the caller must reserve in the slot's arena BEFORE it carves
 // anything else out of it (the arena cannot grow while allocations are live).
+// window size for resident bases with precomputed tables: all windows share one bucket set, so only 2^(c-1) buckets are reduced
+unsigned msm_pick_window_table(size_t n) {
+    unsigned best = 8;
+    double bc = 1e300;
+    for (unsigned c = 8; c <= 22; c++) {
+        unsigned W = (255 + c - 1) / c;
+        double cost = (double)n * W * 10.0 + (double)((size_t)1 << (c - 1)) * 34.0;
+        if (cost < bc) { bc = cost; best = c; }
+    }
+    return best;
+}
+
 template <class F>
-static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P) {
+static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab = nullptr) {
     typedef XYZZ<F> Pt;
     memset(P, 0, sizeof *P);
     if (n == 0) return ZK_OK;
     if (n > ((size_t)1 << 27)) return set_err(ZK_ERR_ARG, "n = %zu exceeds the per-call limit 2^27 (shard the MSM)", n);
-    unsigned c = (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : msm_pick_window(n);
+    unsigned c = tab ? tab->c : ((cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : msm_pick_window(n));
     if (c < 2 || c > 22) return set_err(ZK_ERR_ARG, "window_bits = %u outside [2, 22]", c);
     P->c = c;
-    P->W = (255 + c - 1) / c;
+    P->Wd = (255 + c - 1) / c;
+    P->W = tab ? 1 : P->Wd;
+    P->table_stride = tab ? (uint32_t)tab->stride : 0;
     P->B = 1u << (c - 1);
     P->nb = P->W * P->B;
-    P->total = n * P->W;
-    if (P->total >= ((size_t)1 << 32)) return set_err(ZK_ERR_ARG, "n * windows = %zu overflows 32-bit positions", P->total);
+    P->total = n * P->Wd;
+    if (P->total >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "n * windows = %zu overflows 31-bit positions", P->total);
+    if (tab && (size_t)tab->stride * P->Wd >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "table too large for 31-bit indices");
     // tasks of at most L points: 2x the mean bucket load of a uniform input in the DENSEST window, at least 32.  The top
     // window only sees digits up to (r-1) >> (c*(W-1)), so its buckets are denser than 2^(c-1) suggests.
-    size_t mean = n / P->B + 1;
-    {
+    size_t mean = P->total / P->nb + 1;
+    if (tab) {
+        // all windows feed one bucket set, and the top window only reaches digits below (r-1) >> (c*(Wd-1)): those low buckets
+        // carry an extra n / top_max points each
+        const uint64_t r_top64 = 0x30644e72e131a029ULL;
+        unsigned shift = c * (P->Wd - 1);
+        uint64_t top_max = shift >= 192 ? (r_top64 >> (shift - 192)) : ~0ULL;
+        if (top_max < P->B && top_max > 0) mean += n / (size_t)top_max + 1;
+    } else {
         // r - 1 = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000000; its top 64 bits:
         const uint64_t r_top64 = 0x30644e72e131a029ULL;
         unsigned shift = c * (P->W - 1);                        // bits below the top window
@@ -393,7 +423,7 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
 
     // ---- 1. digits
     ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
-              (cfg && cfg->scalars_mont) ? 1 : 0, c, W, keys0, vals0);
+              (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride);
     // ---- 2. sort (bucket key -> point index|sign)
     rocprim::double_buffer<uint32_t> kb(keys0, keys1), vb(vals0, vals1);
     {
@@ -550,6 +580,54 @@ int msm_prep_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need_
     if (need_acc_g2) *need_acc_g2 = P2.need_acc;
     return ZK_OK;
 }
+int msm_prep_need_table(size_t n, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2) {
+    MsmPlan P1, P2;
+    ZK_TRY(msm_plan<Fp>(n, nullptr, st, &P1, &tab));
+    ZK_TRY(msm_plan<Fp2>(n, nullptr, st, &P2, &tab));
+    if (need_prep) *need_prep = P1.need_prep;
+    if (need_acc_g1) *need_acc_g1 = P1.need_acc;
+    if (need_acc_g2) *need_acc_g2 = P2.need_acc;
+    return ZK_OK;
+}
+int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out) {
+    MsmPlan P;
+    ZK_TRY(msm_plan<Fp>(n, cfg, st, &P, &tab));
+    return msm_prepare(s, st, P, (const Fr*)d_scalars, n, cfg, out);
+}
+
+// T[w * stride + i] = 2^(c*w) * P_i as affine points, w < Wd; rows are `stride` entries apart, entries [n, stride) of a row
+// are left untouched (the caller zeroes the buffer: (0,0) = infinity).  One-time cost per resident base array.
+template <class F>
+__global__ __launch_bounds__(256) void k_build_table(const Affine<F>* __restrict__ pts, uint32_t n, uint32_t stride, uint32_t offset, unsigned c,
+                                                     unsigned Wd, Affine<F>* __restrict__ table) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = gload(pts + i);
+    gstore(table + offset + i, p);
+    XYZZ<F> acc = XYZZ<F>::from_affine(p);
+    for (unsigned w = 1; w < Wd; w++) {
+        for (unsigned k = 0; k < c; k++) acc.dbl();
+        Affine<F> a = acc.to_affine();
+        gstore(table + (size_t)w * stride + offset + i, a);
+        acc = XYZZ<F>::from_affine(a);  // keeps zz = zzz = 1: cheaper doublings, bounded growth
+    }
+}
+template <class F>
+static int build_table(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table) {
+    unsigned Wd = (255 + c - 1) / c;
+    ZK_HIP(hipMemsetAsync(d_table, 0, (size_t)Wd * stride * sizeof(Affine<F>), st));
+    if (n)
+        ZK_LAUNCH(s, st, sizeof(F) == 32 ? "msm_build_table_g1" : "msm_build_table_g2", (k_build_table<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                  (const Affine<F>*)d_pts, (uint32_t)n, (uint32_t)stride, (uint32_t)offset, c, Wd, (Affine<F>*)d_table);
+    return ZK_OK;
+}
+int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table) {
+    return build_table<Fp>(s, st, d_pts, n, stride, offset, c, d_table);
+}
+int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table) {
+    return build_table<Fp2>(s, st, d_pts, n, stride, offset, c, d_table);
+}
+
 int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
     MsmPlan P;
     ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));  // the scalar-side plan does not depend on the group

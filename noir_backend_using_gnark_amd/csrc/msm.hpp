@@ -10,8 +10,18 @@ unsigned msm_pick_window(size_t n);
 // Bytes of arena an MSM of n points needs; reserve them (plus anything else the call carves out) up front.
 int msm_g1_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need);
 int msm_g2_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need);
+// Precomputed-table mode for resident bases: T[w * stride + i] = 2^(c*w) * P_i; all windows then share one bucket set.
+struct MsmTable {
+    unsigned c = 0;
+    size_t stride = 0;
+};
+unsigned msm_pick_window_table(size_t n);
+int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table);
+int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table);
+
 struct MsmPlan {
-    unsigned c, W, key_bits;
+    unsigned c, W, Wd, key_bits;   // W bucket sets (windows that are reduced separately); Wd digit windows (== W unless table mode)
+    uint32_t table_stride;
     uint32_t B, nb, L, m1, N1;
     size_t total, max_tasks, sort_tmp_bytes, scan_tmp_bytes, tsort_tmp_bytes, lvl_elems, need, need_prep, need_acc;
 };
@@ -45,6 +55,8 @@ int msm_g2_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scal
 // index; indices below `skip_below` are ignored).
 int msm_prep_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2);
 int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out);
+int msm_prep_need_table(size_t n, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2);
+int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out);
 void msm_prep_release(MsmPrep* R);
 int msm_g1_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);
 int msm_g2_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);

@@ -19,7 +19,7 @@ class ProvingKey:
     base arrays (used by the benchmark, whose bases are generated on the device)."""
 
     def __init__(self, log_domain: int, n_wires: int, n_public: int, g1_alpha, g1_beta, g1_delta, g1_a, g1_b, g1_k, g1_z,
-                 g2_beta, g2_delta, g2_b, bases_on_device: bool = False):
+                 g2_beta, g2_delta, g2_b, bases_on_device: bool = False, precompute_tables: bool = True):
         self.log_domain, self.n_wires, self.n_public = log_domain, n_wires, n_public
         self._keep = []
 
@@ -34,7 +34,8 @@ class ProvingKey:
             return host(a) if np.asarray(a).size else 0
 
         pk = Groth16PK(log_domain, n_wires, n_public, host(g1_alpha), host(g1_beta), host(g1_delta), base(g1_a), base(g1_b),
-                       base(g1_k), base(g1_z), host(g2_beta), host(g2_delta), base(g2_b), 1 if bases_on_device else 0)
+                       base(g1_k), base(g1_z), host(g2_beta), host(g2_delta), base(g2_b), 1 if bases_on_device else 0,
+                       0 if precompute_tables else 1)
         if bases_on_device:
             self._keep += [g1_a, g1_b, g1_k, g1_z, g2_b]  # keep DeviceBuffers alive
         self.handle = C.c_uint64(0)

@@ -256,8 +256,8 @@ def test_groth16_golden_proofs(golden):
         pk.free()
 
 
-@pytest.mark.parametrize("log_n,witness", [(10, False), (14, True)])
-def test_groth16_prove_vs_oracle_random_pk(log_n, witness):
+@pytest.mark.parametrize("log_n,witness,tables", [(10, False, True), (10, False, False), (14, True, True), (14, True, False)])
+def test_groth16_prove_vs_oracle_random_pk(log_n, witness, tables):
     """Synthetic proving key (random valid bases, like bench.py's workload): GPU proof bytes == oracle proof bytes."""
     N = 1 << log_n
     n_wires, n_public = N - 3, 5
@@ -275,6 +275,7 @@ def test_groth16_prove_vs_oracle_random_pk(log_n, witness):
     w = orc.rand_fr(22, n_wires, witness_like=witness)
     r, s = orc.rand_fr(23, 1)[0], orc.rand_fr(24, 1)[0]
     exp, _ = orc.groth16_prove(pkd, a, b, c, w, r, s)
-    pk = zk.ProvingKey(**pkd)
+    pk = zk.ProvingKey(**pkd, precompute_tables=tables)  # resident-key window tables on / off: same bytes either way
     assert zk.prove(pk, a, b, c, w, r, s) == exp
+    assert zk.prove(pk, a, b, c, w, r, s) == exp  # the key is reusable
     pk.free()
