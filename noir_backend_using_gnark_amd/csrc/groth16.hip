@@ -124,7 +124,9 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
         size_t free_b = 0, total_b = 0;
         ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (bytes < free_b / 2) {
+        // measured: up to ~20 GB of tables (2^22 constraints) the gathers keep up with the ALUs; at 2^24 (77 GB) random 64-byte
+        // gathers over the tables are TLB / HBM-latency bound and the plain 16-window method is faster
+        if (bytes < free_b / 2 && bytes <= ((size_t)32 << 30)) {
             SlotGuard g;
             ZK_TRY(acquire_slot(&g.s));
             hipStream_t st = g.s->stream;
