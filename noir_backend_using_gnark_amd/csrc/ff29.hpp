@@ -34,10 +34,11 @@ struct Fp29 {
     static constexpr uint32_t BIAS12[9] = {0x45dbdf54u, 0x4c34888fu, 0x555fa7b2u, 0x41fda1c8u, 0x4246319fu, 0x42470906u, 0x47d28f0bu, 0x4c51ca6eu, 0x0244b3abu};
     static constexpr uint32_t BIAS16[9] = {0x47cfd470u, 0x50460b6au, 0x472a34eeu, 0x4d522d0cu, 0x585d977fu, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
     static constexpr uint32_t BIAS24[9] = {0x4bb7bea8u, 0x58691120u, 0x4abf4f66u, 0x43fb4393u, 0x448c6340u, 0x448e120eu, 0x4fa51e18u, 0x58a394deu, 0x04896758u};
+    static constexpr uint32_t BIAS40[9] = {0x53879318u, 0x48af1c8cu, 0x51e98457u, 0x514d70a1u, 0x5ce9fac1u, 0x52421e18u, 0x5a133229u, 0x5e65f81eu, 0x078fac3fu};
     template <int K>
     static constexpr uint32_t bias(int i) {
-        static_assert(K == 4 || K == 8 || K == 12 || K == 16 || K == 24, "no bias table for this multiple of p");
-        return K == 4 ? BIAS4[i] : K == 8 ? BIAS8[i] : K == 12 ? BIAS12[i] : K == 16 ? BIAS16[i] : BIAS24[i];
+        static_assert(K == 4 || K == 8 || K == 12 || K == 16 || K == 24 || K == 40, "no bias table for this multiple of p");
+        return K == 4 ? BIAS4[i] : K == 8 ? BIAS8[i] : K == 12 ? BIAS12[i] : K == 16 ? BIAS16[i] : K == 24 ? BIAS24[i] : BIAS40[i];
     }
 };
 
@@ -61,6 +62,57 @@ __device__ __forceinline__ U29 u29_mul(const U29& a, const U29& b) {
           [p8] "s"(Fp29::P[8]), [ninv] "s"(Fp29::NINV)
         : "v0", "v1", "vcc");
     return r;
+}
+
+__device__ __forceinline__ U29 u29_wnorm_fwd(const U29& a) {
+    U29 r;
+    r.l[0] = a.l[0] & 0x1fffffffu;
+#pragma unroll
+    for (int i = 1; i < 8; i++) r.l[i] = (a.l[i] & 0x1fffffffu) + (a.l[i - 1] >> 29);
+    r.l[8] = a.l[8] + (a.l[7] >> 29);
+    return r;
+}
+
+// (a0*b0 + a1*b1 [+ a2*b2 [+ a3*b3]]) / 2^261 mod p with ONE Montgomery reduction: the column accumulators take all products.
+#define ZK29_IN(t, A, B)                                                                                                              \
+    [a##t##_0] "v"(A.l[0]), [a##t##_1] "v"(A.l[1]), [a##t##_2] "v"(A.l[2]), [a##t##_3] "v"(A.l[3]), [a##t##_4] "v"(A.l[4]),          \
+        [a##t##_5] "v"(A.l[5]), [a##t##_6] "v"(A.l[6]), [a##t##_7] "v"(A.l[7]), [a##t##_8] "v"(A.l[8]), [b##t##_0] "v"(B.l[0]),      \
+        [b##t##_1] "v"(B.l[1]), [b##t##_2] "v"(B.l[2]), [b##t##_3] "v"(B.l[3]), [b##t##_4] "v"(B.l[4]), [b##t##_5] "v"(B.l[5]),      \
+        [b##t##_6] "v"(B.l[6]), [b##t##_7] "v"(B.l[7]), [b##t##_8] "v"(B.l[8])
+#define ZK29_OUT(r)                                                                                                                   \
+    [r0] "=&v"(r.l[0]), [r1] "=&v"(r.l[1]), [r2] "=&v"(r.l[2]), [r3] "=&v"(r.l[3]), [r4] "=&v"(r.l[4]), [r5] "=&v"(r.l[5]),          \
+        [r6] "=&v"(r.l[6]), [r7] "=&v"(r.l[7]), [r8] "=&v"(r.l[8])
+#define ZK29_SG                                                                                                                       \
+    [p0] "s"(Fp29::P[0]), [p1] "s"(Fp29::P[1]), [p2] "s"(Fp29::P[2]), [p3] "s"(Fp29::P[3]), [p4] "s"(Fp29::P[4]), [p5] "s"(Fp29::P[5]), \
+        [p6] "s"(Fp29::P[6]), [p7] "s"(Fp29::P[7]), [p8] "s"(Fp29::P[8]), [ninv] "s"(Fp29::NINV)
+
+__device__ __forceinline__ U29 u29_mul2(const U29& a0, const U29& b0, const U29& a1, const U29& b1) {
+    U29 r;
+    asm(ZKMI_MONT_MUL29_N2_ASM : ZK29_OUT(r) : ZK29_IN(0, a0, b0), ZK29_IN(1, a1, b1), ZK29_SG : "v0", "v1", "vcc");
+    return r;
+}
+__device__ __forceinline__ U29 u29_mul3(const U29& a0, const U29& b0, const U29& a1, const U29& b1, const U29& a2, const U29& b2) {
+    U29 r;
+    asm(ZKMI_MONT_MUL29_N3_ASM : ZK29_OUT(r) : ZK29_IN(0, a0, b0), ZK29_IN(1, a1, b1), ZK29_IN(2, a2, b2), ZK29_SG : "v0", "v1", "vcc");
+    return r;
+}
+__device__ __forceinline__ U29 u29_mul4(const U29& a0, const U29& b0, const U29& a1, const U29& b1, const U29& a2, const U29& b2, const U29& a3,
+                                        const U29& b3) {
+    U29 r;
+    asm(ZKMI_MONT_MUL29_N4_ASM
+        : ZK29_OUT(r)
+        : ZK29_IN(0, a0, b0), ZK29_IN(1, a1, b1), ZK29_IN(2, a2, b2), ZK29_IN(3, a3, b3), ZK29_SG
+        : "v0", "v1", "vcc");
+    return r;
+}
+
+// K*p - a, weakly normalised  (a weakly normalised, < K*p)
+template <int K>
+__device__ __forceinline__ U29 u29_neg(const U29& a) {
+    U29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = Fp29::bias<K>(i) - a.l[i];
+    return u29_wnorm_fwd(r);
 }
 
 __device__ __forceinline__ U29 u29_add(const U29& a, const U29& b) {
@@ -305,6 +357,13 @@ __device__ __forceinline__ XYZZ<Fp2> acc29g2_to_xyzz(const Acc29G2& A) {
     return XYZZ<Fp2>{f2_store29(A.x), f2_store29(A.y), f2_store29(A.zz), f2_store29(A.zzz)};
 }
 
+// Fp2 product with one reduction per component: c0 = a0 b0 + (-a1) b1, c1 = a0 b1 + a1 b0  (na1 = K*p - a1)
+__device__ __forceinline__ U29x2 f2_mulF29(const U29x2& a, const U29x2& b, const U29& na1) {
+    return U29x2{u29_mul2(a.c0, b.c0, na1, b.c1), u29_mul2(a.c0, b.c1, a.c1, b.c0)};
+}
+
+// A += (px, py): fused multi-product schedule of tools/u29_model.py::madd_fp2_fused -- every stored coordinate is a direct
+// product output (< 2 p), no contraction multiplications:  X3 = R^2 - (P + 2 X1) PP,  Y3 = R (Q - X3) - Y1 PPP.
 __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2& py) {
     if (px.is_zero() && py.is_zero()) return;
     const U29x2 x2 = f2_load29(px), y2 = f2_load29(py);
@@ -319,30 +378,36 @@ __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2
         A.inf = false;
         return;
     }
-    const U29x2 U2 = f2_mul29(x2, A.zz);
-    const U29x2 S2 = f2_mul29(y2, A.zzz);
+    const U29x2 U2 = f2_mulF29(x2, A.zz, u29_neg<40>(x2.c1));
+    const U29x2 S2 = f2_mulF29(y2, A.zzz, u29_neg<40>(y2.c1));
     const U29x2 P = f2_sub29<4>(U2, A.x);
     const U29x2 R = f2_sub29<4>(S2, A.y);
-    U29 m;
-    const U29x2 PP = f2_sqr29<24>(P, &m);
-    if (u29_mulout3_is_zero(m)) {
-        // P0*P1 == 0 mod p is NECESSARY for P == 0 (same x: doubling or P + (-P)); take the canonical saturated path,
-        // which is correct for every input, whenever the filter fires.
+    const U29 nP1 = u29_neg<8>(P.c1), nR1 = u29_neg<8>(R.c1);
+    U29x2 PP;
+    PP.c0 = u29_mul2(P.c0, P.c0, nP1, P.c1);
+    PP.c1 = u29_mul(u29_add(P.c0, P.c0), P.c1);
+    if (u29_mulout3_is_zero(PP.c1)) {
+        // 2 P0 P1 == 0 mod p is NECESSARY for P == 0 (same x: doubling or P + (-P)); the canonical saturated path is correct
+        // for every input, so it is taken whenever the filter fires.
         XYZZ<Fp2> c = acc29g2_to_xyzz(A);
         c.madd(px, py);
         acc29g2_from_xyzz(A, c);
         return;
     }
-    const U29x2 PPP = f2_mul29(P, PP);
-    const U29x2 Q = f2_mul29(A.x, PP);
-    const U29x2 RR = f2_sqr29<24>(R, nullptr);
-    U29x2 t = f2_sub29<12>(RR, PPP);
-    t = f2_sub29<12>(t, Q);
-    const U29x2 X3 = f2_contract29(f2_sub29<12>(t, Q));
+    const U29x2 PPP = f2_mulF29(P, PP, nP1);
+    const U29x2 Q = f2_mulF29(A.x, PP, u29_neg<8>(A.x.c1));
+    const U29 W0 = u29_wnorm(u29_add(P.c0, u29_add(A.x.c0, A.x.c0))), W1 = u29_wnorm(u29_add(P.c1, u29_add(A.x.c1, A.x.c1)));
+    const U29 nW0 = u29_neg<12>(W0), nW1 = u29_neg<12>(W1);
+    U29x2 X3;
+    X3.c0 = u29_mul4(R.c0, R.c0, nR1, R.c1, nW0, PP.c0, W1, PP.c1);
+    X3.c1 = u29_mul3(u29_add(R.c0, R.c0), R.c1, nW0, PP.c1, nW1, PP.c0);
     const U29x2 d = f2_sub29<4>(Q, X3);
-    const U29x2 Y3 = f2_contract29(f2_sub29<12>(f2_mul29(R, d), f2_mul29(A.y, PPP)));
-    A.zz = f2_mul29(A.zz, PP);
-    A.zzz = f2_mul29(A.zzz, PPP);
+    const U29 nY0 = u29_neg<8>(A.y.c0), nY1 = u29_neg<8>(A.y.c1);
+    U29x2 Y3;
+    Y3.c0 = u29_mul4(R.c0, d.c0, nR1, d.c1, nY0, PPP.c0, A.y.c1, PPP.c1);
+    Y3.c1 = u29_mul4(R.c0, d.c1, R.c1, d.c0, nY0, PPP.c1, nY1, PPP.c0);
+    A.zz = f2_mulF29(A.zz, PP, u29_neg<8>(A.zz.c1));
+    A.zzz = f2_mulF29(A.zzz, PPP, u29_neg<8>(A.zzz.c1));
     A.x = X3;
     A.y = Y3;
 }

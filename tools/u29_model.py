@@ -67,6 +67,36 @@ def mul_exact(a, b):
     return r
 
 
+def mulN_exact(pairs):
+    """(sum_t a_t * b_t) / 2^261 mod p, one reduction for all products (column accumulators shared)."""
+    acc = 0
+    m = [0] * NL
+    r = [0] * NL
+    for k in range(NL):
+        for a, b in pairs:
+            for i in range(k + 1):
+                acc += a[i] * b[k - i]
+        for j in range(k):
+            acc += m[j] * PL[k - j]
+        assert acc < 1 << 64, "column overflow"
+        m[k] = ((acc & 0xffffffff) * NINV) & MASK
+        acc += m[k] * PL[0]
+        assert acc < 1 << 64 and acc & MASK == 0
+        acc >>= W
+    for k in range(NL, 2 * NL - 1):
+        for a, b in pairs:
+            for i in range(k - NL + 1, NL):
+                acc += a[i] * b[k - i]
+        for j in range(k - NL + 1, NL):
+            acc += m[j] * PL[k - j]
+        assert acc < 1 << 64, "column overflow"
+        r[k - NL] = acc & MASK
+        acc >>= W
+    assert acc < 1 << 32
+    r[NL - 1] = acc
+    return r
+
+
 def add_exact(a, b):
     r = [x + y for x, y in zip(a, b)]
     assert all(v < 1 << 32 for v in r)
@@ -106,6 +136,18 @@ def b_mul(a, b):
         s += NL * MASK * MASK + (1 << 36)
         assert s < 1 << 64, "possible column overflow: limbs %s x %s" % ([x.bit_length() for x in a.lmax], [x.bit_length() for x in b.lmax])
     vmax = (a.vmax * b.vmax >> RBITS) + Q + 1
+    assert vmax < 1 << (RBITS - 1)
+    return B(vmax, [MASK] * (NL - 1) + [vmax >> (W * (NL - 1))])
+
+
+def b_mulN(pairs):
+    for k in range(2 * NL - 1):
+        s = 0
+        for a, b in pairs:
+            s += sum(a.lmax[i] * b.lmax[k - i] for i in range(NL) if 0 <= k - i < NL)
+        s += NL * MASK * MASK + (1 << 36)
+        assert s < 1 << 64, "possible column overflow in mulN"
+    vmax = (sum(a.vmax * b.vmax for a, b in pairs) >> RBITS) + Q + 1
     assert vmax < 1 << (RBITS - 1)
     return B(vmax, [MASK] * (NL - 1) + [vmax >> (W * (NL - 1))])
 
@@ -157,8 +199,15 @@ class ExactOps:
     def __init__(self):
         pass
     mul = staticmethod(mul_exact)
+    mulN = staticmethod(mulN_exact)
     add = staticmethod(add_exact)
     wnorm = staticmethod(wnorm_exact)
+
+    @staticmethod
+    def neg(a, k):
+        if isinstance(k, str):
+            k = SITE_K[k]
+        return wnorm_exact(sub_exact(bias_limbs(k), a, [0] * NL))
 
     @staticmethod
     def sub(a, b, k):
@@ -169,7 +218,17 @@ class ExactOps:
 
 class BoundOps:
     mul = staticmethod(b_mul)
+    mulN = staticmethod(b_mulN)
     add = staticmethod(b_add)
+
+    @staticmethod
+    def neg(a, k):
+        if isinstance(k, str):
+            k = pick_k(a, k)
+        bias = bias_limbs(k)
+        assert a.vmax <= k * Q and all(al <= z for al, z in zip(a.lmax, bias))
+        return b_wnorm(B(k * Q + 1, bias))
+
     sub = staticmethod(b_sub)
     wnorm = staticmethod(b_wnorm)
 
@@ -246,6 +305,43 @@ def madd_fp2(O, X1, Y1, ZZ1, ZZZ1, X2, Y2, one=None):
     return X3, Y3, ZZ3, ZZZ3
 
 
+def f2_mulF(O, a, b, na1=None, site="g2f.n"):
+    """Fp2 product with ONE Montgomery reduction per component: c0 = a0 b0 + (-a1) b1, c1 = a0 b1 + a1 b0."""
+    if na1 is None:
+        na1 = O.neg(a[1], site)
+    return (O.mulN([(a[0], b[0]), (na1, b[1])]), O.mulN([(a[0], b[1]), (a[1], b[0])]))
+
+
+def madd_fp2_fused(O, X1, Y1, ZZ1, ZZZ1, X2, Y2):
+    """G2 madd with fused multi-product reductions: every stored coordinate is a direct product output (< ~3 p), so no
+    contraction multiplications are needed.  X3 = R^2 - (P + 2 X1) PP,  Y3 = R (Q - X3) - Y1 PPP."""
+    U2 = f2_mulF(O, X2, ZZ1, site="g2f.nfresh")
+    S2 = f2_mulF(O, Y2, ZZZ1, site="g2f.nfresh")
+    P = f2_sub(O, U2, X1, "g2f.P")
+    R = f2_sub(O, S2, Y1, "g2f.P")
+    nP1 = O.neg(P[1], "g2f.n")
+    nR1 = O.neg(R[1], "g2f.n")
+    # PP = P^2 = (P0 P0 + nP1 P1, 2 P0 P1)
+    PP = (O.mulN([(P[0], P[0]), (nP1, P[1])]), O.mul(O.add(P[0], P[0]), P[1]))
+    PPP = f2_mulF(O, P, PP, nP1)
+    nX1 = O.neg(X1[1], "g2f.n")
+    Qv = f2_mulF(O, X1, PP, nX1)
+    # W = P + 2 X1 ; X3 = R^2 - W PP
+    Wv = (O.wnorm(O.add(P[0], O.add(X1[0], X1[0]))), O.wnorm(O.add(P[1], O.add(X1[1], X1[1]))))
+    nW0, nW1 = O.neg(Wv[0], "g2f.nW"), O.neg(Wv[1], "g2f.nW")
+    X3 = (O.mulN([(R[0], R[0]), (nR1, R[1]), (nW0, PP[0]), (Wv[1], PP[1])]),
+          O.mulN([(O.add(R[0], R[0]), R[1]), (nW0, PP[1]), (nW1, PP[0])]))
+    d = f2_sub(O, Qv, X3, "g2f.P")
+    nY0, nY1 = O.neg(Y1[0], "g2f.n"), O.neg(Y1[1], "g2f.n")
+    Y3 = (O.mulN([(R[0], d[0]), (nR1, d[1]), (nY0, PPP[0]), (Y1[1], PPP[1])]),
+          O.mulN([(R[0], d[1]), (R[1], d[0]), (nY0, PPP[1]), (nY1, PPP[0])]))
+    nZ1 = O.neg(ZZ1[1], "g2f.n")
+    ZZ3 = f2_mulF(O, ZZ1, PP, nZ1)
+    nZZ1 = O.neg(ZZZ1[1], "g2f.n")
+    ZZZ3 = f2_mulF(O, ZZZ1, PPP, nZZ1)
+    return X3, Y3, ZZ3, ZZZ3
+
+
 def fixed_point(madd, is_f2):
     fresh = B.fresh()
     one = B(2 * Q, [MASK] * (NL - 1) + [(2 * Q) >> (W * (NL - 1))])
@@ -312,7 +408,8 @@ def exact_check(n=300):
     print("  exact G1 simulation of %d chained madds: ok" % n)
 
 
-def exact_check_g2(n=60):
+def exact_check_g2(n=60, madd=None):
+    madd = madd or madd_fp2
     random.seed(11)
     nonres = Q - 1  # u^2 = -1
 
@@ -336,7 +433,7 @@ def exact_check_g2(n=60):
     acc = P0
     for _ in range(n):
         P2 = rp()
-        X, Y, ZZ, ZZZ = madd_fp2(ExactOps, X, Y, ZZ, ZZZ, (to_u29(P2[0][0]), to_u29(P2[0][1])), (to_u29(P2[1][0]), to_u29(P2[1][1])))
+        X, Y, ZZ, ZZZ = madd(ExactOps, X, Y, ZZ, ZZZ, (to_u29(P2[0][0]), to_u29(P2[0][1])), (to_u29(P2[1][0]), to_u29(P2[1][1])))
         acc = chord(acc, P2)
         g = lambda v: (from_u29(v[0]), from_u29(v[1]))
         x = f2m(g(X), f2inv(g(ZZ)))
@@ -352,11 +449,14 @@ def main():
     fixed_point(madd_fp, False)
     print("G2 (Fp2) madd bound propagation:")
     fixed_point(madd_fp2, True)
+    print("G2 (Fp2) FUSED madd bound propagation:")
+    fixed_point(madd_fp2_fused, True)
     print("bias multiple per subtraction site:", SITE_K)
     for k in sorted(set(SITE_K.values())):
         print("bias %3d p:" % k, ", ".join("0x%08xu" % v for v in bias_limbs(k)))
     exact_check()
     exact_check_g2()
+    exact_check_g2(60, madd_fp2_fused)
     # mul unit test
     random.seed(1)
     for _ in range(2000):
