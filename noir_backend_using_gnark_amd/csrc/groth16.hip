@@ -192,51 +192,32 @@ static bool k_shares_w(const Msm5Inputs& in, size_t* j) {
 struct Msm5State {
     MsmJob jobs[5];
     MsmPrep prep_w, prep_h;
+    hipStream_t chain = nullptr;  // stream on which the accumulate kernels are serialised
 };
 
-// Stream plan (priorities matter: the MSM that finishes LAST exposes its latency-bound bucket-reduction tail, so the
-// long chains go first and the three plain G1 MSMs fill the machine behind them):
-//   slot 0, high priority : (computeH ->) prepare(h) -> Z accumulate -> reduce          [st0, passed in]
-//   slot 4, high priority : prepare(w) -> G2.B accumulate -> reduce                     (the largest single MSM)
-//   slots 1, 2, 3, normal : A, B1, K accumulate -> reduce, all waiting on prepare(w)
-// `gate` (optional): the four w-based accumulations wait for it.  groth16_prove passes "computeH done": every kernel here
-// is ALU-bound, so running the NTTs concurrently with four accumulate kernels buys nothing and (measured) delays the
-// Z chain, which then runs alone at the end with its tail exposed.
-static int msm5_launch(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, bool z_now = true,
-                       hipEvent_t gate = nullptr, bool prepare_only = false, bool accumulate_only = false) {
+// Stream plan.  Every kernel of a proof is ALU-bound except the sorts, so nothing is gained by letting accumulate kernels
+// share the machine (measured: the big G2 kernel is starved and finishes last, alone, with its tail exposed).  Instead the
+// accumulate kernels are CHAINED through events -- G2.B -> A -> B1 -> K -> Z, each owning the GPU in turn -- and the
+// latency-bound bucket-reduction tail of one MSM runs underneath the next MSM's accumulate:
+//   slot 4 (high priority): prepare(w) -> G2.B accumulate -> reduce
+//   slots 1, 2, 3          : A, B1, K accumulate -> reduce (all read prepare(w))
+//   slot 0 (high priority): [computeH ->] prepare(h) -> Z accumulate -> reduce          (st0)
+// The HOST enqueue order matters too (~10 us per launch, ~40 launches per preparation): the w-side work is enqueued first so
+// that the GPU is busy while the host is still enqueuing computeH and prepare(h).
+static int msm5_launch_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc = nullptr) {
     hipStream_t st4 = sl[4]->stream_hi;
     size_t j = 0;
     const bool share_k = k_shares_w(in, &j);
-    if (!accumulate_only) {
-        if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
-        if (in.tab_w) ZK_TRY(msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w));
-        else ZK_TRY(msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w));
-    }
-    if (prepare_only) return ZK_OK;
-    // The accumulate kernels are chained G2.B -> (Z) -> A -> B1 -> K through events: each one gets the whole machine,
-    // and the latency-bound reduction tail of one MSM runs underneath the next MSM's accumulate.  (Measured: letting the
-    // four kernels share the GPU starves the big G2 kernel, which then finishes last, alone, with its tail exposed.)
-    // Two orders (ZKMI_SCHED=0 selects the first):
-    //   h-first: computeH and both preparations run alone, then the chain G2.B -> Z -> A -> B1 -> K;
-    //   w-first (default): the chain G2.B -> A -> B1 -> K starts as soon as w is prepared; computeH and the preparation of h run
-    //            underneath it on the high-priority stream (slowed down, but they have ~8 ms to finish), Z goes last.
-    static const bool w_first = !(getenv("ZKMI_SCHED") && atoi(getenv("ZKMI_SCHED")) == 0);
-    if (gate && !w_first) ZK_HIP(hipStreamWaitEvent(st4, gate, 0));
-    if (z_now) {
-        if (in.tab_h) ZK_TRY(msm_prepare_scalars_table(sl[0], st0, in.d_h, in.nz, &kMontCfg, *in.tab_h, &S->prep_h));
-        else ZK_TRY(msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h));
-        // h-first: once an accumulate kernel owns the machine, the sort kernels of another stream are starved, so wait for them
-        if (S->prep_h.ready && !w_first) ZK_HIP(hipStreamWaitEvent(st4, S->prep_h.ready, 0));
-    }
+    if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
+    if (in.tab_w) ZK_TRY(msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w));
+    else ZK_TRY(msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w));
+    // accumulate kernels chained through events, each on its MSM's own stream (measured alternatives: one shared "chain" stream
+    // for all accumulate kernels removes the ~0.15 ms event gaps but delays prepare(h) -- rocPRIM's onesweep sort spins on
+    // look-back tiles that cannot get a wave slot under an accumulate kernel -- and ends up slower)
+    S->jobs[4].gate_acc = gate_first_acc;
     S->jobs[4].want_done = true;
     ZK_TRY(msm_g2_accumulate(sl[4], st4, S->prep_w, in.tab_w ? in.t_b2 : in.d_b2, 0, &S->jobs[4]));
     hipEvent_t prev = S->jobs[4].acc_done;
-    if (z_now && !w_first) {
-        S->jobs[0].gate_acc = prev;
-        S->jobs[0].want_done = true;
-        ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
-        if (S->jobs[0].acc_done) prev = S->jobs[0].acc_done;
-    }
     S->jobs[1].gate_acc = prev;
     S->jobs[1].want_done = true;
     ZK_TRY(msm_g1_accumulate(sl[1], sl[1]->stream, S->prep_w, in.tab_w ? in.t_a : in.d_a, 0, &S->jobs[1]));
@@ -246,7 +227,7 @@ static int msm5_launch(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, hipEv
     ZK_TRY(msm_g1_accumulate(sl[2], sl[2]->stream, S->prep_w, in.tab_w ? in.t_b : in.d_b, 0, &S->jobs[2]));
     if (S->jobs[2].acc_done) prev = S->jobs[2].acc_done;
     S->jobs[3].gate_acc = prev;
-    S->jobs[3].want_done = w_first;
+    S->jobs[3].want_done = true;
     if (in.tab_w) {
         ZK_TRY(msm_g1_accumulate(sl[3], sl[3]->stream, S->prep_w, in.t_k, 0, &S->jobs[3]));  // K table is wire-indexed
     } else if (share_k) {
@@ -255,11 +236,21 @@ static int msm5_launch(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, hipEv
         if (ev_w) ZK_HIP(hipStreamWaitEvent(sl[3]->stream, ev_w, 0));
         ZK_TRY(msm_g1_launch(sl[3], sl[3]->stream, in.d_k, in.d_wk, in.nk, &kMontCfg, &S->jobs[3]));
     }
-    if (z_now && w_first) {
-        if (S->jobs[3].acc_done) prev = S->jobs[3].acc_done;
+    return ZK_OK;
+}
+// Z side, on st0 (after whatever produced h on that stream); its accumulate goes last in the chain
+static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm5State* S) {
+    if (in.tab_h) ZK_TRY(msm_prepare_scalars_table(sl[0], st0, in.d_h, in.nz, &kMontCfg, *in.tab_h, &S->prep_h));
+    else ZK_TRY(msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h));
+    // Z's accumulate goes last on the chain stream (which then waits for prepare(h) through the event inside msm_accumulate)
+    S->jobs[0].chain = S->chain;
+    if (!S->chain) {
+        hipEvent_t prev = nullptr;
+        for (int i : {4, 1, 2, 3})
+            if (S->jobs[i].acc_done) prev = S->jobs[i].acc_done;
         S->jobs[0].gate_acc = prev;
-        ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
     }
+    ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
     return ZK_OK;
 }
 static int msm5_finish(Msm5State* S, uint64_t out[96]) {
@@ -386,7 +377,8 @@ int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2
         ZK_HIP(hipStreamWaitEvent(g.s[0]->stream_hi, ev, 0));
     }
     Msm5State S;
-    int rc = msm5_launch(g.s, g.s[0]->stream_hi, in, ev, &S);
+    int rc = msm5_launch_w(g.s, in, ev, &S);
+    if (rc == ZK_OK) rc = msm5_launch_h(g.s, g.s[0]->stream_hi, in, &S);
     if (rc == ZK_OK) rc = msm5_finish(&S, out_xyzz);
     else { msm_prep_release(&S.prep_w); msm_prep_release(&S.prep_h); }
     if (ev) (void)hipEventDestroy(ev);
@@ -420,15 +412,11 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     }
     ZK_TRY(msm5_reserve(g.s, in, 3 * N * 32 + nw * 32 + 4096));
     hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    // wire values first: the A / B1 / K / B2 MSMs only need w and start while computeH is still running on stream 0
-    Fr* d_w = (Fr*)s0->alloc(nw * 32 + 16);
-    if (nw) ZK_HIP(hipMemcpyAsync(d_w, w, nw * 32, kind, st));
-    hipEvent_t ev_w = nullptr;
-    ZK_HIP(hipEventCreateWithFlags(&ev_w, hipEventDisableTiming));
-    ZK_HIP(hipEventRecord(ev_w, st));
-    in.d_w = d_w;
-    in.d_wk = d_w + P.n_public;
-    Msm5State S;
+    // Order on the GPU:  [computeH  ||  upload + prepare(w)]  ->  G2.B acc -> A acc -> B1 acc -> K acc -> Z acc  (reduce tails and
+    // prepare(h) run underneath the accumulate kernels).  computeH goes FIRST and alone with the bandwidth-bound sort of w:
+    // measured, an NTT launched underneath an accumulate kernel is starved (1.3 ms -> 8 ms) because the long-running accumulate
+    // workgroups never free enough wave slots, and the Z chain then finishes late.
+    hipStream_t st4 = g.s[4]->stream_hi;
     int rc = ZK_OK;
     Fr* d_abc[3] = {nullptr, nullptr, nullptr};
     const void* src[3] = {a, b, c};
@@ -437,15 +425,19 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
         if (n_constraints && hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
         if (n_constraints < N && hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemsetAsync failed");
     }
-    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match).  Enqueued FIRST:
-    // the host needs ~10 us per launch, and the scalar-side preparation of w (~40 launches) overlaps it on another stream.
+    // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
     if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain);
-    if (rc == ZK_OK) rc = msm5_launch(g.s, st, in, ev_w, &S, /*z_now=*/false, nullptr, /*prepare_only=*/true);
     hipEvent_t ev_h = nullptr;
     if (rc == ZK_OK && hipEventCreateWithFlags(&ev_h, hipEventDisableTiming) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventCreate failed");
     if (rc == ZK_OK && hipEventRecord(ev_h, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventRecord failed");
+    Fr* d_w = (Fr*)s0->alloc(nw * 32 + 16);
+    if (rc == ZK_OK && nw && hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+    in.d_w = d_w;
+    in.d_wk = d_w + P.n_public;
     in.d_h = d_abc[0];
-    if (rc == ZK_OK) rc = msm5_launch(g.s, st, in, ev_w, &S, /*z_now=*/true, ev_h, false, /*accumulate_only=*/true);
+    Msm5State S;
+    if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, ev_h);
+    if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
     if (ev_h) (void)hipEventDestroy(ev_h);
     uint64_t parts[96];
     TailPre T;
@@ -456,7 +448,6 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
         msm_prep_release(&S.prep_w);
         msm_prep_release(&S.prep_h);
     }
-    (void)hipEventDestroy(ev_w);
     if (rc != ZK_OK) return rc;
     tail_post(P, T, parts, 1, proof_out);
     return ZK_OK;

@@ -23,6 +23,8 @@
 // addition is 10 Fp products of ~136 quarter-rate v_mad_u64_u32 each -- see DESIGN.md for both fractions.
 #include <string.h>
 
+#include <tuple>
+
 #include <rocprim/rocprim.hpp>
 
 #include "ctx.hpp"
@@ -324,7 +326,33 @@ unsigned msm_pick_window_table(size_t n) {
 }
 
 template <class F>
+static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab);
+
+// plans are pure functions of (n, window choice, table geometry, group): memoised, because the rocPRIM workspace-size
+// queries inside cost ~0.1 ms of host time per proof otherwise
+template <class F>
 static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab = nullptr) {
+    struct Key {
+        size_t n, stride;
+        unsigned c_cfg, c_tab, g2;
+        bool operator<(const Key& o) const { return std::tie(n, stride, c_cfg, c_tab, g2) < std::tie(o.n, o.stride, o.c_cfg, o.c_tab, o.g2); }
+    };
+    static std::mutex mu;
+    static std::map<Key, MsmPlan> memo;
+    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32)};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(k);
+        if (it != memo.end()) { *P = it->second; return ZK_OK; }
+    }
+    ZK_TRY(msm_plan_uncached<F>(n, cfg, st, P, tab));
+    std::lock_guard<std::mutex> lk(mu);
+    memo[k] = *P;
+    return ZK_OK;
+}
+
+template <class F>
+static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab) {
     typedef XYZZ<F> Pt;
     memset(P, 0, sizeof *P);
     if (n == 0) return ZK_OK;
@@ -491,17 +519,22 @@ static int msm_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const Affin
     Pt* lvlS[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
     if (!partial || !lvlA[0] || !lvlA[1] || !lvlS[0] || !lvlS[1])
         return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
-    if (R.ready) ZK_HIP(hipStreamWaitEvent(st, R.ready, 0));
-    if (job->gate_acc) ZK_HIP(hipStreamWaitEvent(st, job->gate_acc, 0));
+    // The throughput-bound accumulate kernel runs on `job->chain` when given (the caller serialises the accumulate kernels of
+    // several MSMs back to back on one stream, no event round trips between them); everything after it -- the latency-bound
+    // reduction tail -- runs on this job's own stream `st`, gated on an event.
+    hipStream_t sa = job->chain ? job->chain : st;
+    if (R.ready) ZK_HIP(hipStreamWaitEvent(sa, R.ready, 0));
+    if (job->gate_acc) ZK_HIP(hipStreamWaitEvent(sa, job->gate_acc, 0));
     // ---- 5. accumulate
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
-    ZK_LAUNCH(s, st, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, d_pts, R.vals, R.task_begin, R.lkeys, R.tids,
+    ZK_LAUNCH(s, sa, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, d_pts, R.vals, R.task_begin, R.lkeys, R.tids,
               L, (uint32_t)max_tasks, skip_below, partial);
-    ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial, R.task_off, R.multi_list, R.num_multi);
-    if (job->want_done) {
+    if (job->chain || job->want_done) {
         ZK_HIP(hipEventCreateWithFlags(&job->acc_done, hipEventDisableTiming));
-        ZK_HIP(hipEventRecord(job->acc_done, st));
+        ZK_HIP(hipEventRecord(job->acc_done, sa));
+        if (job->chain) ZK_HIP(hipStreamWaitEvent(st, job->acc_done, 0));
     }
+    ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial, R.task_off, R.multi_list, R.num_multi);
     // ---- 6. bucket reduce
     ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial, R.task_off, B,
               W, m1, lvlA[0], lvlS[0]);

@@ -48,6 +48,7 @@ struct MsmJob {
     hipEvent_t gate_acc = nullptr;
     bool want_done = false;
     hipEvent_t acc_done = nullptr;
+    hipStream_t chain = nullptr;  // run the accumulate kernel on this stream (reduction tail stays on the job's stream)
 };
 int msm_g1_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job);
 int msm_g2_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmJob* job);
