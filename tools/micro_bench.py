@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5 on one GPU: standalone G1 MSM and Fr NTT of 2^log_n (default 26), inputs resident in HBM.
+Reports scalar-muls/s, elements/s and the HBM-roofline fraction of the algorithmic bytes (96 B / scalar-mul, 64 B / element)."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import noir_backend_using_gnark_amd as zk  # noqa: E402
+from noir_backend_using_gnark_amd import _lib  # noqa: E402
+from noir_backend_using_gnark_amd import bn254 as zb  # noqa: E402
+
+L = _lib.lib()
+log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 26
+n = 1 << log_n
+pts, sc = _lib.DeviceBuffer(n * 64), _lib.DeviceBuffer(n * 32)
+t0 = time.perf_counter()
+_lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(pts.ptr), C.c_size_t(n), C.c_uint64(0xB1), None))
+t_gen = time.perf_counter() - t0
+out = {"log_n": log_n, "generate_points_s": round(t_gen, 2)}
+for name, wit in (("uniform", 0), ("witness_like", 1)):
+    _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(sc.ptr), C.c_size_t(n), C.c_uint64(0xC), C.c_int(1), C.c_int(wit), None))
+    r0 = zb.g1_multi_exp_dev(pts.ptr, sc.ptr, n)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = zb.g1_multi_exp_dev(pts.ptr, sc.ptr, n)
+    dt = (time.perf_counter() - t0) / reps
+    assert (r == r0).all()
+    out["g1_msm_" + name] = {"ms": round(dt * 1e3, 2), "scalar_muls_per_s": round(n / dt, 1), "hbm_frac": round(96 * n / dt / 8e12, 5)}
+dom = zk.Domain(n)
+dom.fft(sc, zk.DIF)
+t0 = time.perf_counter()
+for _ in range(5):
+    dom.fft(sc, zk.DIF)
+_lib.check(L.zk_dev_sync())
+dt = (time.perf_counter() - t0) / 5
+out["ntt"] = {"ms": round(dt * 1e3, 3), "elements_per_s": round(n / dt, 1), "hbm_frac": round(64 * n / dt / 8e12, 5)}
+print(json.dumps(out))
