@@ -389,6 +389,9 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
         }
     }
     P->L = (uint32_t)(mean * 2 < 32 ? 32 : mean * 2);
+    // one wave folds the partials of a split bucket: bound their number (a bucket can hold up to n points -- real witnesses are
+    // mostly 0/1) by growing the task size with n
+    if (P->L < (n >> 16)) P->L = (uint32_t)(n >> 16);
     P->max_tasks = (size_t)P->nb + P->total / P->L + 1;
     P->m1 = P->B >= 8 ? 8 : P->B;  // level-1 serial chunk
     P->N1 = P->B / P->m1;
