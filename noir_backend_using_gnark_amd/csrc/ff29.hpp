@@ -286,6 +286,80 @@ __device__ __forceinline__ void xyzz_madd29(Acc29& A, const Fp& px, const Fp& py
     A.y = Y3;
 }
 
+// m < 3p is a direct product output: m == 0 mod p ?
+__device__ __forceinline__ bool u29_mulout3_is_zero(const U29& x) {
+    U29 t = u29_ripple(x);
+    uint32_t z = 0, e1 = 0, e2 = 0;
+    // 2p in normalised limbs
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        uint32_t p2 = 2 * Fp29::P[i] + c;
+        c = (i < 8) ? (p2 >> 29) : 0;
+        if (i < 8) p2 &= Fp29::MASK;
+        z |= t.l[i];
+        e1 |= t.l[i] ^ Fp29::P[i];
+        e2 |= t.l[i] ^ p2;
+    }
+    return z == 0 || e1 == 0 || e2 == 0;
+}
+
+// ---- XYZZ + XYZZ and doubling for the bucket-reduction tail (G1).  Class invariant proven by tools/u29_model.py
+// (check_add_dbl_class): with every input coordinate < 32 p and weakly normalised, every output coordinate is again < 32 p.
+__device__ __forceinline__ void acc29_load(Acc29& A, const XYZZ<Fp>& c) {  // canonical image -> lazily reduced, no multiplication
+    A.inf = c.is_inf();
+    A.x = u29_load(c.x);
+    A.y = u29_load(c.y);
+    A.zz = u29_load(c.zz);
+    A.zzz = u29_load(c.zzz);
+}
+__device__ __forceinline__ void acc29_dbl(Acc29& A) {  // dbl-2008-s-1
+    if (A.inf) return;
+    const U29 U = u29_add(A.y, A.y);
+    const U29 V = u29_mul(U, U);
+    const U29 Wv = u29_mul(U, V);
+    const U29 S = u29_mul(A.x, V);
+    const U29 X2 = u29_mul(A.x, A.x);
+    const U29 M = u29_wnorm(u29_add(u29_add(X2, X2), X2));
+    U29 t = u29_mul(M, M);
+    t = u29_sub<8>(t, S);
+    const U29 X3 = u29_wnorm(u29_sub<8>(t, S));
+    const U29 d = u29_wnorm(u29_sub<24>(S, X3));
+    const U29 Y3 = u29_wnorm(u29_sub<4>(u29_mul(M, d), u29_mul(Wv, A.y)));
+    A.zz = u29_mul(V, A.zz);
+    A.zzz = u29_mul(Wv, A.zzz);
+    A.x = X3;
+    A.y = Y3;
+}
+__device__ __forceinline__ void acc29_add(Acc29& A, const Acc29& Bq) {  // add-2008-s
+    if (Bq.inf) return;
+    if (A.inf) { A = Bq; return; }
+    const U29 U1 = u29_mul(A.x, Bq.zz), U2 = u29_mul(Bq.x, A.zz);
+    const U29 S1 = u29_mul(A.y, Bq.zzz), S2 = u29_mul(Bq.y, A.zzz);
+    const U29 P = u29_wnorm(u29_sub<8>(U2, U1));
+    const U29 R = u29_wnorm(u29_sub<8>(S2, S1));
+    const U29 PP = u29_mul(P, P);
+    if (u29_mulout3_is_zero(PP)) {
+        // same x: doubling or P + (-P).  R = S2 - S1 decides; R*R is a product output (< 3 p), so the same test applies.
+        if (u29_mulout3_is_zero(u29_mul(R, R))) acc29_dbl(A);
+        else A.inf = true;
+        return;
+    }
+    const U29 PPP = u29_mul(P, PP);
+    const U29 Q = u29_mul(U1, PP);
+    U29 t = u29_mul(R, R);
+    t = u29_wnorm(u29_sub<4>(t, PPP));
+    t = u29_sub<4>(t, Q);
+    t = u29_sub<4>(t, Q);
+    const U29 X3 = u29_wnorm(t);
+    const U29 d = u29_wnorm(u29_sub<16>(Q, X3));
+    const U29 Y3 = u29_wnorm(u29_sub<4>(u29_mul(R, d), u29_mul(S1, PPP)));
+    A.zz = u29_mul(u29_mul(A.zz, Bq.zz), PP);
+    A.zzz = u29_mul(u29_mul(A.zzz, Bq.zzz), PPP);
+    A.x = X3;
+    A.y = Y3;
+}
+
 // ------------------------------------------------------------------------------------------------------------ G2 (Fp2)
 // Components are lazily reduced U29 values.  Operation order, bias multiples and the two contractions are exactly those of
 // tools/u29_model.py::madd_fp2, whose bound propagation closes at x, y < 2 p, zz, zzz < 10.6 p.
@@ -322,24 +396,6 @@ __device__ __forceinline__ U29x2 f2_contract29(const U29x2& a) {
 }
 __device__ __forceinline__ U29x2 f2_load29(const Fp2& v) { return U29x2{u29_load(v.a0), u29_load(v.a1)}; }
 __device__ __forceinline__ Fp2 f2_store29(const U29x2& v) { return Fp2{u29_store(v.c0), u29_store(v.c1)}; }
-
-// m < 3p is a direct product output: m == 0 mod p ?
-__device__ __forceinline__ bool u29_mulout3_is_zero(const U29& x) {
-    U29 t = u29_ripple(x);
-    uint32_t z = 0, e1 = 0, e2 = 0;
-    // 2p in normalised limbs
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        uint32_t p2 = 2 * Fp29::P[i] + c;
-        c = (i < 8) ? (p2 >> 29) : 0;
-        if (i < 8) p2 &= Fp29::MASK;
-        z |= t.l[i];
-        e1 |= t.l[i] ^ Fp29::P[i];
-        e2 |= t.l[i] ^ p2;
-    }
-    return z == 0 || e1 == 0 || e2 == 0;
-}
 
 struct Acc29G2 {
     U29x2 x, y, zz, zzz;

@@ -255,6 +255,99 @@ def madd_fp(O, X1, Y1, ZZ1, ZZZ1, X2, Y2):
     return X3, Y3, ZZ3, ZZZ3
 
 
+def add_fp(O, A, Bp):
+    """XYZZ + XYZZ (add-2008-s) on lazily reduced coordinates; both inputs anywhere in the class "every coordinate < 32 p"."""
+    X1, Y1, ZZ1, ZZZ1 = A
+    X2, Y2, ZZ2, ZZZ2 = Bp
+    U1 = O.mul(X1, ZZ2)
+    U2 = O.mul(X2, ZZ1)
+    S1 = O.mul(Y1, ZZZ2)
+    S2 = O.mul(Y2, ZZZ1)
+    P = O.wnorm(O.sub(U2, U1, "g1a.8"))
+    R = O.wnorm(O.sub(S2, S1, "g1a.8"))
+    PP = O.mul(P, P)
+    PPP = O.mul(P, PP)
+    Qv = O.mul(U1, PP)
+    t = O.mul(R, R)
+    t = O.wnorm(O.sub(t, PPP, "g1a.4"))
+    t = O.sub(t, Qv, "g1a.4")
+    t = O.sub(t, Qv, "g1a.4")
+    X3 = O.wnorm(t)
+    d = O.wnorm(O.sub(Qv, X3, "g1a.16"))
+    Y3 = O.wnorm(O.sub(O.mul(R, d), O.mul(S1, PPP), "g1a.4"))
+    ZZ3 = O.mul(O.mul(ZZ1, ZZ2), PP)
+    ZZZ3 = O.mul(O.mul(ZZZ1, ZZZ2), PPP)
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def dbl_fp(O, A):
+    """2 * XYZZ (dbl-2008-s-1)"""
+    X1, Y1, ZZ1, ZZZ1 = A
+    U = O.add(Y1, Y1)
+    V = O.mul(U, U)
+    Wv = O.mul(U, V)
+    S = O.mul(X1, V)
+    X2 = O.mul(X1, X1)
+    M = O.wnorm(O.add(O.add(X2, X2), X2))
+    t = O.mul(M, M)
+    t = O.sub(t, S, "g1d.8")
+    X3 = O.wnorm(O.sub(t, S, "g1d.8"))
+    d = O.wnorm(O.sub(S, X3, "g1d.24"))
+    Y3 = O.wnorm(O.sub(O.mul(M, d), O.mul(Wv, Y1), "g1d.4"))
+    ZZ3 = O.mul(V, ZZ1)
+    ZZZ3 = O.mul(Wv, ZZZ1)
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def check_add_dbl_class():
+    """the class "all four coordinates < 32 p, weakly normalised" is closed under load, madd, add and dbl"""
+    cls = B(32 * Q, [MASK + 8] * (NL - 1) + [((32 * Q) >> (W * (NL - 1))) + 4])
+    A = (cls, cls, cls, cls)
+    for name, out in (("add", add_fp(BoundOps, A, A)), ("dbl", dbl_fp(BoundOps, A))):
+        for c in out:
+            assert c.vmax <= 32 * Q, (name, c.kp())
+            assert all(l <= MASK + 8 for l in c.lmax[:-1]), name
+        print("  %s: outputs (units of p): %s" % (name, ", ".join("%.1f" % c.kp() for c in out)))
+
+
+def exact_check_add_dbl(n=40):
+    random.seed(3)
+    def on_curve_point():
+        while True:
+            x = rand_fe()
+            rhs = (x * x * x + 3) % Q
+            y = pow(rhs, (Q + 1) // 4, Q)
+            if y * y % Q == rhs:
+                return x, y
+    def aff_add(P1, P2):
+        if P1 == P2:
+            lam = 3 * P1[0] * P1[0] * pow(2 * P1[1], -1, Q) % Q
+        else:
+            lam = (P2[1] - P1[1]) * pow(P2[0] - P1[0], -1, Q) % Q
+        x3 = (lam * lam - P1[0] - P2[0]) % Q
+        return x3, (lam * (P1[0] - x3) - P1[1]) % Q
+    def lift(Pt):
+        z = rand_fe()
+        zz, zzz = z * z % Q, z * z * z % Q
+        return tuple(to_u29(v) for v in (Pt[0] * zz % Q, Pt[1] * zzz % Q, zz, zzz))
+    def aff(A):
+        x, y, zz, zzz = (from_u29(v) for v in A)
+        return x * pow(zz, -1, Q) % Q, y * pow(zzz, -1, Q) % Q
+    P1, acc = on_curve_point(), None
+    A = lift(P1)
+    accp = P1
+    for i in range(n):
+        if i % 3 == 2:
+            A = dbl_fp(ExactOps, A)
+            accp = aff_add(accp, accp)
+        else:
+            P2 = on_curve_point()
+            A = add_fp(ExactOps, A, lift(P2))
+            accp = aff_add(accp, P2)
+        assert aff(A) == accp
+    print("  exact G1 add/dbl chain of %d operations: ok" % n)
+
+
 # Fp2 helpers: values are pairs
 def f2_mul(O, a, b):
     v0 = O.mul(a[0], b[0])
@@ -451,12 +544,15 @@ def main():
     fixed_point(madd_fp2, True)
     print("G2 (Fp2) FUSED madd bound propagation:")
     fixed_point(madd_fp2_fused, True)
+    print("G1 add / dbl class check:")
+    check_add_dbl_class()
     print("bias multiple per subtraction site:", SITE_K)
     for k in sorted(set(SITE_K.values())):
         print("bias %3d p:" % k, ", ".join("0x%08xu" % v for v in bias_limbs(k)))
     exact_check()
     exact_check_g2()
     exact_check_g2(60, madd_fp2_fused)
+    exact_check_add_dbl()
     # mul unit test
     random.seed(1)
     for _ in range(2000):
