@@ -214,6 +214,23 @@ static int msm5_launch_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm
     // accumulate kernels chained through events, each on its MSM's own stream (measured alternatives: one shared "chain" stream
     // for all accumulate kernels removes the ~0.15 ms event gaps but delays prepare(h) -- rocPRIM's onesweep sort spins on
     // look-back tiles that cannot get a wave slot under an accumulate kernel -- and ends up slower)
+    // ZKMI_CHAIN=1 (experiment switch): all accumulate kernels back to back on ONE stream, tails on the jobs' own streams
+    static const bool one_chain = getenv("ZKMI_CHAIN") && atoi(getenv("ZKMI_CHAIN")) == 1;
+    if (one_chain && (in.tab_w || share_k)) {
+        hipStream_t chain = sl[4]->stream;
+        S->jobs[4].gate_acc = gate_first_acc;
+        S->jobs[4].chain = chain;
+        ZK_TRY(msm_g2_accumulate(sl[4], st4, S->prep_w, in.tab_w ? in.t_b2 : in.d_b2, 0, &S->jobs[4]));
+        S->jobs[1].chain = chain;
+        ZK_TRY(msm_g1_accumulate(sl[1], sl[1]->stream, S->prep_w, in.tab_w ? in.t_a : in.d_a, 0, &S->jobs[1]));
+        S->jobs[2].chain = chain;
+        ZK_TRY(msm_g1_accumulate(sl[2], sl[2]->stream, S->prep_w, in.tab_w ? in.t_b : in.d_b, 0, &S->jobs[2]));
+        S->jobs[3].chain = chain;
+        S->jobs[3].want_done = true;
+        if (in.tab_w) ZK_TRY(msm_g1_accumulate(sl[3], sl[3]->stream, S->prep_w, in.t_k, 0, &S->jobs[3]));
+        else ZK_TRY(msm_g1_accumulate(sl[3], sl[3]->stream, S->prep_w, (const char*)in.d_k - j * 64, (uint32_t)j, &S->jobs[3]));
+        return ZK_OK;
+    }
     S->jobs[4].gate_acc = gate_first_acc;
     S->jobs[4].want_done = true;
     ZK_TRY(msm_g2_accumulate(sl[4], st4, S->prep_w, in.tab_w ? in.t_b2 : in.d_b2, 0, &S->jobs[4]));

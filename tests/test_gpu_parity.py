@@ -279,3 +279,67 @@ def test_groth16_prove_vs_oracle_random_pk(log_n, witness, tables):
     assert zk.prove(pk, a, b, c, w, r, s) == exp
     assert zk.prove(pk, a, b, c, w, r, s) == exp  # the key is reusable
     pk.free()
+
+
+def test_sharded_prove_path_matches_single_call():
+    """The multi-GPU decomposition (zk_bn254_groth16_msm5_dev on slices + all-gather + zk_bn254_groth16_finalize), executed here
+    as TWO slices on one GPU, yields the same 128 bytes as the single-call prover and the oracle."""
+    from noir_backend_using_gnark_amd import parallel as par
+    log_n = 11
+    N = 1 << log_n
+    nw, npub = N, 4
+    pkd = dict(log_domain=log_n, n_wires=nw, n_public=npub,
+               g1_alpha=orc.g1_gen_points(1, 1)[0], g1_beta=orc.g1_gen_points(2, 1)[0], g1_delta=orc.g1_gen_points(3, 1)[0],
+               g1_a=orc.g1_gen_points(4, nw), g1_b=orc.g1_gen_points(5, nw), g1_k=orc.g1_gen_points(6, nw - npub),
+               g1_z=orc.g1_gen_points(7, N), g2_beta=orc.g2_gen_points(8, 1)[0], g2_delta=orc.g2_gen_points(9, 1)[0],
+               g2_b=orc.g2_gen_points(10, nw))
+    a, b = orc.rand_fr(20, N), orc.rand_fr(21, N)
+    c = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(N)])
+    w = orc.rand_fr(22, nw, witness_like=True)
+    r, s = orc.rand_fr(23, 1)[0], orc.rand_fr(24, 1)[0]
+    exp, _ = orc.groth16_prove(pkd, a, b, c, w, r, s)
+    pk = zk.ProvingKey(**pkd)
+    assert zk.prove(pk, a, b, c, w, r, s) == exp
+    # device-resident copies of everything, K indexed by wire like bench.py does
+    D = _lib.DeviceBuffer.from_numpy
+    d_a, d_b, d_z, d_b2, d_w = D(pkd["g1_a"]), D(pkd["g1_b"]), D(pkd["g1_z"]), D(pkd["g2_b"]), D(w)
+    k_wire = np.zeros((nw, 8), np.uint64)
+    k_wire[npub:] = pkd["g1_k"]
+    d_k = D(k_wire)
+    d_h = _lib.DeviceBuffer(N * 32)
+    da, db, dc = D(a), D(b), D(c)
+    _lib.check(_lib.lib().zk_bn254_groth16_compute_h_dev(C.c_void_p(da.ptr), C.c_void_p(db.ptr), C.c_void_p(dc.ptr), C.c_size_t(N),
+                                                         C.c_uint32(log_n), C.c_void_p(d_h.ptr), None))
+    recs = []
+    for rank, world in ((0, 2), (1, 2)):
+        lo, hi = par.shard_range(nw, rank, world)
+        k_skip = npub if rank == 0 else 0
+        nz = (hi - lo) - (1 if rank == world - 1 else 0)
+        recs.append(par.groth16_msm5_local(d_a.ptr + lo * 64, d_b.ptr + lo * 64, d_b2.ptr + lo * 128, d_w.ptr + lo * 32, hi - lo,
+                                           d_k.ptr + (lo + k_skip) * 64, d_w.ptr + (lo + k_skip) * 32, hi - lo - k_skip,
+                                           d_z.ptr + lo * 64, d_h.ptr + lo * 32, nz))
+    assert par.groth16_finalize(pk, np.stack(recs), r, s) == exp
+    pk.free()
+
+
+def test_device_pointer_transforms_and_compute_h_dev():
+    """*_dev entry points (data resident in HBM): NTT, BitReverse, computeH against the oracle."""
+    log_n = 13
+    n = 1 << log_n
+    x = orc.rand_fr(77, n)
+    d = _lib.DeviceBuffer.from_numpy(x)
+    L = _lib.lib()
+    _lib.check(L.zk_bn254_ntt_dev(C.c_void_p(d.ptr), C.c_uint32(log_n), C.c_int(1), C.c_int(zk.DIF), C.c_int(1), None))
+    assert (d.to_numpy(np.uint64, (n, 4)) == orc.fr_ntt(x, True, orc.DIF, True)).all()
+    _lib.check(L.zk_bn254_bit_reverse_dev(C.c_void_p(d.ptr), C.c_uint32(log_n), None))
+    assert (d.to_numpy(np.uint64, (n, 4)) == orc.fr_bit_reverse(orc.fr_ntt(x, True, orc.DIF, True))).all()
+    a, b, c = orc.rand_fr(1, n - 5), orc.rand_fr(2, n - 5), orc.rand_fr(3, n - 5)
+    da, db, dc, dh = (_lib.DeviceBuffer.from_numpy(v) for v in (a, b, c)), None, None, None
+    da, db, dc = da
+    dh = _lib.DeviceBuffer(n * 32)
+    _lib.check(L.zk_bn254_groth16_compute_h_dev(C.c_void_p(da.ptr), C.c_void_p(db.ptr), C.c_void_p(dc.ptr), C.c_size_t(n - 5), C.c_uint32(log_n),
+                                                C.c_void_p(dh.ptr), None))
+    assert (dh.to_numpy(np.uint64, (n, 4)) == orc.groth16_compute_h(a, b, c, log_n)).all()
+    assert (da.to_numpy(np.uint64, (n - 5, 4)) == a).all()  # inputs untouched
+    with pytest.raises(_lib.ZkmiError):
+        _lib.check(L.zk_bn254_ntt_dev(C.c_void_p(d.ptr), C.c_uint32(29), C.c_int(0), C.c_int(zk.DIF), C.c_int(0), None))
