@@ -74,6 +74,64 @@ __device__ __forceinline__ Fr gload_fr(const Fr* p) {
     return r;
 }
 
+// G consecutive stages of the pass on one butterfly group per lane-iteration.  Stage index s counts from the start of the pass;
+// DIF walks the tile bits downwards (q = k-1-s), DIT upwards (q = s).  ql = lowest tile bit of the group.
+template <int G, bool DIF>
+__device__ __forceinline__ void ntt_group(const PassArgs& A, uint4* lo, uint4* hi, size_t base, unsigned E, unsigned s0, bool first, bool last) {
+    constexpr unsigned NE = 1u << G;
+    const unsigned L = 1u << A.logL;
+    const unsigned ql = DIF ? (A.k - s0 - G) : s0;
+    for (unsigned u = threadIdx.x; u < (E >> G); u += NTT_THREADS) {
+        const unsigned l = u & (L - 1), r = u >> A.logL;
+        const unsigned mid0 = ((r >> ql) << (ql + G)) | (r & ((1u << ql) - 1));
+        Fr x[NE];
+#pragma unroll
+        for (unsigned e = 0; e < NE; e++) {
+            const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
+            x[e] = lds_load(lo, hi, t);
+            if (first && A.pre) x[e] = x[e] * gload_fr(A.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l);
+        }
+#pragma unroll
+        for (int sl = 0; sl < G; sl++) {
+            const unsigned bitl = DIF ? (unsigned)(G - 1 - sl) : (unsigned)sl;  // bit inside the group (compile-time after unrolling)
+            const unsigned b = A.bit_lo + ql + bitl;                               // global index bit
+#pragma unroll
+            for (unsigned e0 = 0; e0 < NE; e0++) {
+                if (e0 & (1u << bitl)) continue;
+                const unsigned e1 = e0 | (1u << bitl);
+                const size_t g0 = base + ((size_t)(mid0 | (e0 << ql)) << A.bit_lo) + l;
+                if (DIF) {
+                    Fr sum = x[e0] + x[e1], dif = x[e0] - x[e1];
+                    if (b != 0) {
+                        size_t j = g0 & (((size_t)1 << b) - 1);
+                        dif = dif * gload_fr(A.tw + (j << (A.logn - 1 - b)));
+                    }
+                    x[e0] = sum;
+                    x[e1] = dif;
+                } else {
+                    Fr y = x[e1];
+                    if (b != 0) {
+                        size_t j = g0 & (((size_t)1 << b) - 1);
+                        y = y * gload_fr(A.tw + (j << (A.logn - 1 - b)));
+                    }
+                    Fr sum = x[e0] + y, dif = x[e0] - y;
+                    x[e0] = sum;
+                    x[e1] = dif;
+                }
+            }
+        }
+#pragma unroll
+        for (unsigned e = 0; e < NE; e++) {
+            const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
+            if (last) {
+                if (A.post) x[e] = x[e] * gload_fr(A.post + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l);
+                else if (A.has_post_const) x[e] = x[e] * A.post_const;
+            }
+            lds_store(lo, hi, t, x[e]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs A) {
     extern __shared__ uint4 lds[];
     const unsigned E = 1u << (A.k + A.logL);
@@ -97,49 +155,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs A) {
     }
     __syncthreads();
 
-    for (unsigned s = 0; s < A.k; s++) {
-        const unsigned q = A.dif ? (A.k - 1 - s) : s;  // tile bit handled by this stage
-        const unsigned b = A.bit_lo + q;               // global index bit
-        const bool first = (s == 0), last = (s + 1 == A.k);
-        for (unsigned u = threadIdx.x; u < (E >> 1); u += NTT_THREADS) {
-            unsigned l = u & (L - 1), r = u >> A.logL;
-            unsigned mid0 = ((r >> q) << (q + 1)) | (r & ((1u << q) - 1));
-            unsigned t0 = (mid0 << A.logL) + l, t1 = t0 + (L << q);
-            Fr x = lds_load(lo, hi, t0), y = lds_load(lo, hi, t1);
-            size_t g0 = base + ((size_t)mid0 << A.bit_lo) + l, g1 = g0 + ((size_t)1 << b);
-            if (first && A.pre) {
-                x = x * gload_fr(A.pre + g0);
-                y = y * gload_fr(A.pre + g1);
-            }
-            if (A.dif) {
-                Fr sum = x + y, dif = x - y;
-                if (b != 0) {
-                    size_t j = g0 & (((size_t)1 << b) - 1);
-                    dif = dif * gload_fr(A.tw + (j << (A.logn - 1 - b)));
-                }
-                x = sum;
-                y = dif;
-            } else {
-                if (b != 0) {
-                    size_t j = g0 & (((size_t)1 << b) - 1);
-                    y = y * gload_fr(A.tw + (j << (A.logn - 1 - b)));
-                }
-                Fr sum = x + y, dif = x - y;
-                x = sum;
-                y = dif;
-            }
-            if (last) {
-                if (A.post) {
-                    x = x * gload_fr(A.post + g0);
-                    y = y * gload_fr(A.post + g1);
-                } else if (A.has_post_const) {
-                    x = x * A.post_const;
-                    y = y * A.post_const;
-                }
-            }
-            lds_store(lo, hi, t0, x);
-            lds_store(lo, hi, t1, y);
+    // Stages are taken up to three at a time: a lane pulls the 2^G elements of one radix-2^G butterfly group out of LDS, runs
+    // G stages on them in registers and puts them back -- one LDS round trip and one barrier per G stages instead of per stage.
+    for (unsigned s0 = 0; s0 < A.k;) {
+        const unsigned G = (A.k - s0 >= 3) ? 3 : (A.k - s0);
+        const bool first = (s0 == 0), last = (s0 + G == A.k);
+        if (A.dif) {
+            if (G == 3) ntt_group<3, true>(A, lo, hi, base, E, s0, first, last);
+            else if (G == 2) ntt_group<2, true>(A, lo, hi, base, E, s0, first, last);
+            else ntt_group<1, true>(A, lo, hi, base, E, s0, first, last);
+        } else {
+            if (G == 3) ntt_group<3, false>(A, lo, hi, base, E, s0, first, last);
+            else if (G == 2) ntt_group<2, false>(A, lo, hi, base, E, s0, first, last);
+            else ntt_group<1, false>(A, lo, hi, base, E, s0, first, last);
         }
+        s0 += G;
         __syncthreads();
     }
 
@@ -257,8 +287,7 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, unsigned logn, const Fr
     for (unsigned i = 0; i < np; i++) {
         unsigned k = (rest - (bit - kc) + (np - i) - 1) / (np - i);
         unsigned logL = TILE_LOG - k;
-        if (logL > bit) logL = bit;
-        if (logL > 4) logL = 4;
+        if (logL > bit) logL = bit;  // rows of L consecutive low-order neighbours; the tile always holds up to 2^TILE_LOG elements
         passes.push_back({bit, k, logL});
         bit += k;
     }

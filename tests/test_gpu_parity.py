@@ -343,3 +343,30 @@ def test_device_pointer_transforms_and_compute_h_dev():
     assert (da.to_numpy(np.uint64, (n - 5, 4)) == a).all()  # inputs untouched
     with pytest.raises(_lib.ZkmiError):
         _lib.check(L.zk_bn254_ntt_dev(C.c_void_p(d.ptr), C.c_uint32(29), C.c_int(0), C.c_int(zk.DIF), C.c_int(0), None))
+
+
+@pytest.mark.parametrize("c", [0, 8, 16])
+def test_msm_equal_and_opposite_bucket_sums(c):
+    """Adjacent buckets holding the SAME point (running sum doubles) and OPPOSITE points (running sum returns to infinity):
+    drives the same-x branches of the XYZZ + XYZZ addition in the bucket-reduction tail (29-bit form on G1)."""
+    P = orc.g1_gen_points(71, 1)[0]
+    negP = P.copy()
+    y = from_mont_limbs(P[4:8], ref.Q)[0]
+    negP[4:8] = mont_limbs([(ref.Q - y) % ref.Q], ref.Q)[0]
+    rest_p, rest_s = orc.g1_gen_points(72, 300), ref.rand_felts(73, 300)
+    for d in (5, 77, 200):
+        for second, pt2 in ((d + 1, P), (d + 1, negP), (d, negP)):
+            pts = np.concatenate([np.stack([P, pt2]), rest_p])
+            sc = mont_limbs([d, second] + rest_s)
+            cfg = zk.MultiExpConfig(window_bits=c)
+            assert (zk.g1_multi_exp(pts, sc, cfg) == orc.g1_msm(pts, sc)).all(), (c, d, second)
+    # G2: same construction
+    Pg = orc.g2_gen_points(74, 1)[0]
+    negPg = Pg.copy()
+    ys = from_mont_limbs(Pg[8:16], ref.Q)
+    negPg[8:16] = mont_limbs([(ref.Q - v) % ref.Q for v in ys], ref.Q).reshape(-1)
+    rp, rs = orc.g2_gen_points(75, 100), ref.rand_felts(76, 100)
+    for second, pt2 in ((8, Pg), (8, negPg), (7, negPg)):
+        pts = np.concatenate([np.stack([Pg, pt2]), rp])
+        sc = mont_limbs([7, second] + rs)
+        assert (zk.g2_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=c)) == orc.g2_msm(pts, sc)).all(), (c, second)
