@@ -147,28 +147,91 @@ __global__ void k_task_plan(const uint32_t* start, uint32_t nb, uint32_t L, uint
 // One record per task (thread t < total tasks): where its points start in the sorted array, and a sort key that orders
 // tasks by DECREASING length so that the 64 lanes of a wave run tasks of (nearly) equal length -- bucket loads are
 // Poisson-distributed, and a wave otherwise waits for its longest lane.
-__global__ void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t L, uint32_t max_tasks,
-                            uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ task_id) {
+//
+// The ordering is a counting sort on the length key (k_task_fill histograms, k_task_bins scans, k_task_scatter places): three
+// small launches instead of a library sort's ~20 merge passes.  Keys above TS_BINS are quantised (bshift) -- the order only
+// balances lanes, results never depend on it (every task writes its own partial sum).
+constexpr uint32_t TS_BINS = 2048;
+
+__global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t L,
+                                                   uint32_t max_tasks, uint32_t bshift, uint32_t nbins, uint32_t* __restrict__ task_begin,
+                                                   uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[TS_BINS];
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
+    __syncthreads();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= max_tasks) return;
-    task_id[t] = t;
     uint32_t total_tasks = task_off[nb];
-    if (t >= total_tasks) {
-        len_key[t] = 0xffffffffu;  // padding sorts to the end
-        task_begin[t] = 0;
-        return;
+    if (t < max_tasks) {
+        if (t >= total_tasks) {
+            len_key[t] = 0xffffffffu;  // padding: stays behind the real tasks
+            task_begin[t] = 0;
+        } else {
+            // bucket = last b with task_off[b] <= t  (empty buckets have task_off[b] == task_off[b+1] and are skipped)
+            uint32_t lo = 0, hi = nb;  // invariant: task_off[lo] <= t < task_off[hi]
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (task_off[mid] <= t) lo = mid; else hi = mid;
+            }
+            uint32_t b = lo;
+            uint32_t begin = start[b] + (t - task_off[b]) * L;
+            uint32_t end = min(begin + L, start[b + 1]);
+            task_begin[t] = begin;
+            uint32_t key = L - (end - begin);  // 0 = longest
+            len_key[t] = key;
+            atomicAdd(&h[key >> bshift], 1u);
+        }
     }
-    // bucket = last b with task_off[b] <= t  (empty buckets have task_off[b] == task_off[b+1] and are skipped)
-    uint32_t lo = 0, hi = nb;  // invariant: task_off[lo] <= t < task_off[hi]
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (task_off[mid] <= t) lo = mid; else hi = mid;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x)
+        if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+
+// exclusive scan of the <= TS_BINS bin counts, in place (one workgroup)
+__global__ __launch_bounds__(256) void k_task_bins(uint32_t* __restrict__ hist, uint32_t nbins) {
+    __shared__ uint32_t part[256];
+    constexpr uint32_t PER = TS_BINS / 256;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        uint32_t b = threadIdx.x * PER + k;
+        v[k] = b < nbins ? hist[b] : 0;
+        sum += v[k];
     }
-    uint32_t b = lo;
-    uint32_t begin = start[b] + (t - task_off[b]) * L;
-    uint32_t end = min(begin + L, start[b + 1]);
-    task_begin[t] = begin;
-    len_key[t] = L - (end - begin);  // 0 = longest
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        uint32_t b = threadIdx.x * PER + k;
+        if (b < nbins) hist[b] = run;
+        run += v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_task_scatter(const uint32_t* __restrict__ len_key, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ len_key_sorted,
+                                                      uint32_t* __restrict__ task_sorted) {
+    __shared__ uint32_t h[TS_BINS], base[TS_BINS];
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t key = t < max_tasks ? len_key[t] : 0xffffffffu, rank = 0;
+    bool real = key != 0xffffffffu;
+    if (real) rank = atomicAdd(&h[key >> bshift], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x)
+        if (h[b]) base[b] = atomicAdd(&cursor[b], h[b]);
+    __syncthreads();
+    if (t >= max_tasks) return;
+    uint32_t pos = real ? base[key >> bshift] + rank : t;  // real tasks fill [0, total_tasks); padding keeps its own slot behind them
+    len_key_sorted[pos] = key;
+    task_sorted[pos] = t;
 }
 
 // ---------------------------------------------------------------------------------------- 5. accumulate
@@ -442,11 +505,7 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan sizing: %s", hipGetErrorString(e));
     }
     P->lvl_elems = (size_t)P->W * P->N1;  // level-1 outputs; later levels are 64x smaller
-    {
-        rocprim::double_buffer<uint32_t> kb(nullptr, nullptr), vb(nullptr, nullptr);
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, P->tsort_tmp_bytes, kb, vb, P->max_tasks, 0, 32, st);
-        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs sizing: %s", hipGetErrorString(e));
-    }
+    P->tsort_tmp_bytes = TS_BINS * 4;  // bin counters of the task counting sort
     P->need_prep = 5 * align_up(P->max_tasks * 4, 256) + align_up(P->tsort_tmp_bytes + 16, 256) + 4 * align_up(P->total * 4, 256) +
                    align_up(P->sort_tmp_bytes + 16, 256) + align_up(P->scan_tmp_bytes + 16, 256) + 3 * align_up(((size_t)P->nb + 2) * 4, 256) +
                    align_up((size_t)P->nb * 4, 256) + 256 + 32768;
@@ -466,7 +525,7 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     const unsigned c = P.c, W = P.W, key_bits = P.key_bits;
     const uint32_t nb = P.nb, L = P.L;
     const size_t total = P.total, max_tasks = P.max_tasks;
-    size_t sort_tmp_bytes = P.sort_tmp_bytes, scan_tmp_bytes = P.scan_tmp_bytes, tsort_tmp_bytes = P.tsort_tmp_bytes;
+    size_t sort_tmp_bytes = P.sort_tmp_bytes, scan_tmp_bytes = P.scan_tmp_bytes;
     uint32_t* keys0 = (uint32_t*)s->alloc(total * 4);
     uint32_t* keys1 = (uint32_t*)s->alloc(total * 4);
     uint32_t* vals0 = (uint32_t*)s->alloc(total * 4);
@@ -477,16 +536,16 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     uint32_t* ntasks = (uint32_t*)s->alloc(((size_t)nb + 2) * 4);
     uint32_t* task_off = (uint32_t*)s->alloc(((size_t)nb + 2) * 4);
     uint32_t* multi_list = (uint32_t*)s->alloc((size_t)nb * 4);
-    uint32_t* num_multi = (uint32_t*)s->alloc(256);
     uint32_t* task_begin = (uint32_t*)s->alloc(max_tasks * 4);
     uint32_t* lkey0 = (uint32_t*)s->alloc(max_tasks * 4);
     uint32_t* lkey1 = (uint32_t*)s->alloc(max_tasks * 4);
-    uint32_t* tid0 = (uint32_t*)s->alloc(max_tasks * 4);
     uint32_t* tid1 = (uint32_t*)s->alloc(max_tasks * 4);
-    void* tsort_tmp = s->alloc(tsort_tmp_bytes + 16);
-    if (!keys0 || !keys1 || !vals0 || !vals1 || !sort_tmp || !scan_tmp || !start || !ntasks || !task_off || !multi_list || !num_multi ||
-        !task_begin || !lkey0 || !lkey1 || !tid0 || !tid1 || !tsort_tmp)
+    uint32_t* bins = (uint32_t*)s->alloc(256 + TS_BINS * 4);  // [0] = num_multi, [64..] = bin counters: one memset clears both
+    if (!keys0 || !keys1 || !vals0 || !vals1 || !sort_tmp || !scan_tmp || !start || !ntasks || !task_off || !multi_list || !task_begin ||
+        !lkey0 || !lkey1 || !tid1 || !bins)
         return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_prep);
+    uint32_t* num_multi = bins;
+    uint32_t* hist = bins + 64;
 
     // ---- 1. digits
     ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
@@ -503,7 +562,7 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     // ---- 3. bucket bounds
     ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, keys, (uint32_t)total, nb, start);
     // ---- 4. plan
-    ZK_HIP(hipMemsetAsync(num_multi, 0, 4, st));
+    ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, L, ntasks, multi_list, num_multi);
     {
         if (ctx().profiling) prof_begin(s, st, "msm_task_scan(rocprim)");
@@ -511,25 +570,22 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
         if (ctx().profiling) prof_end(s, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
     }
-    // ---- 4b. per-task records, sorted by decreasing length (keys are L - len: at most ~log2(L) significant bits)
-    ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill, dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, (const uint32_t*)start,
-              (const uint32_t*)task_off, nb, L, (uint32_t)max_tasks, task_begin, lkey0, tid0);
-    rocprim::double_buffer<uint32_t> lkb(lkey0, lkey1), tib(tid0, tid1);
-    {
-        unsigned lbits = 1;
-        while (((uint64_t)1 << lbits) <= L) lbits++;
-        if (ctx().profiling) prof_begin(s, st, "msm_task_sort(rocprim)");
-        // padding keys are 0xffffffff: sorting only the low lbits+1 bits keeps them last (bit lbits is set only for padding)
-        hipError_t e = rocprim::radix_sort_pairs(tsort_tmp, tsort_tmp_bytes, lkb, tib, max_tasks, 0, lbits + 1, st);
-        if (ctx().profiling) prof_end(s, st);
-        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs (tasks): %s", hipGetErrorString(e));
-    }
+    // ---- 4b. per-task records, ordered by decreasing length (counting sort on L - len)
+    uint32_t bshift = 0;
+    while ((L >> bshift) >= TS_BINS) bshift++;
+    const uint32_t nbins = (L >> bshift) + 1;
+    const unsigned tgrid = (unsigned)((max_tasks + 255) / 256);
+    ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill, dim3(tgrid), dim3(256), 0, (const uint32_t*)start, (const uint32_t*)task_off, nb, L,
+              (uint32_t)max_tasks, bshift, nbins, task_begin, lkey0, hist);
+    ZK_LAUNCH(s, st, "msm_task_bins", k_task_bins, dim3(1), dim3(256), 0, hist, nbins);
+    ZK_LAUNCH(s, st, "msm_task_scatter", k_task_scatter, dim3(tgrid), dim3(256), 0, (const uint32_t*)lkey0, (uint32_t)max_tasks, bshift, nbins, hist,
+              lkey1, tid1);
     out->vals = vb.current();
     out->start = start;
     out->task_off = task_off;
     out->task_begin = task_begin;
-    out->lkeys = lkb.current();
-    out->tids = tib.current();
+    out->lkeys = lkey1;
+    out->tids = tid1;
     out->multi_list = multi_list;
     out->num_multi = num_multi;
     ZK_HIP(hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
