@@ -106,6 +106,17 @@ int zk_bn254_bit_reverse_dev(void *d_a, uint32_t log_n, void *stream);
 int zk_bn254_groth16_compute_h(const zk_fr *a, const zk_fr *b, const zk_fr *c, size_t n, uint32_t log_N, zk_fr *h_out);
 int zk_bn254_groth16_compute_h_dev(const void *d_a, const void *d_b, const void *d_c, size_t n, uint32_t log_N,
                                    void *d_h_out, void *stream);
+/* computeH sharded over G = 2^log_g GPUs (one process per GPU; SURVEY.md 8e: the transposes are all-to-all over xGMI,
+ * issued by the host between the phases -- the library never communicates).  Rank rho owns the block
+ * [rho*M, (rho+1)*M), M = 2^log_D / G, of a, b, c (natural order) and receives the same block of h (gnark's
+ * bit-reversed order).  "Transposed" = after an all-to-all of the block viewed as G chunks of M/G elements.
+ *   phase 0: a, b, c transposed      -> cross stages of FFTInverse(DIF)                         -> transpose back
+ *   phase 1: a, b, c blocks          -> block part of FFTInverse(DIF), *1/D*g^bitrev(i), block part of FFT(DIT, coset) -> transpose
+ *   phase 2: a, b, c transposed      -> cross stages of FFT(DIT); a = (a*b - c)/(g^D - 1); cross stages of FFTInverse(DIF) -> transpose a back
+ *   phase 3: a block                 -> block part of FFTInverse(DIF, coset): a is this rank's block of h.
+ * log_g = 0 degenerates to zk_bn254_groth16_compute_h_dev (no exchange).  In place; asynchronous on `stream` if given. */
+int zk_bn254_groth16_h_shard_dev(int phase, void *d_a, void *d_b, void *d_c, uint32_t log_D, uint32_t log_g,
+                                 uint32_t rank, void *stream);
 
 /* ProvingKey image (host pointers; copied to the device by zk_bn254_groth16_pk_load).  Same field names as gnark's
  * groth16.ProvingKey{G1{Alpha,Beta,Delta,A,B,K,Z}, G2{Beta,Delta,B}}; A/B/G2.B have n_wires entries (points at
@@ -120,7 +131,8 @@ typedef struct {
     const zk_g2_affine *g2_b;
     int bases_on_device; /* 1: g1_a, g1_b, g1_k, g1_z, g2_b are DEVICE pointers that stay owned by the caller */
     int flags;           /* bit 0: do NOT build the precomputed window tables 2^(c*w)*P_i (they cost ~13x the bases in HBM and
-                            are what makes the resident-key MSMs ~20% cheaper; skipped automatically when HBM is short) */
+                            are what makes the resident-key MSMs ~20% cheaper; skipped automatically when HBM is short)
+                            bit 1: all 2^log_domain entries of Z are used (a non-final slice of a range-sharded key) */
 } zk_groth16_pk;
 int zk_bn254_groth16_pk_load(const zk_groth16_pk *pk, uint64_t *handle);
 int zk_bn254_groth16_pk_free(uint64_t handle);
@@ -139,6 +151,10 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void *a, const void *b, con
 int zk_bn254_groth16_msm5_dev(const void *d_a, const void *d_b, const void *d_b2, const void *d_w, size_t nw,
                               const void *d_k, const void *d_wk, size_t nk, const void *d_z, const void *d_h, size_t nz,
                               uint64_t out_xyzz[96], void *stream);
+/* msm5 against a loaded key whose base arrays are THIS rank's slices (n_wires / n_public / log_domain describe the
+ * slice; flags bit 1 on every rank but the last): uses the key's resident window tables.  d_w: n_wires wire values of
+ * the slice, d_h: this rank's block of h. */
+int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void *d_w, const void *d_h, uint64_t out_xyzz[96], void *stream);
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t *partials, size_t n_partials, const zk_fr *r,
                               const zk_fr *s, uint8_t proof_out[128]);
 

@@ -35,9 +35,9 @@ SYMBOLS = [
     "zk_bn254_g1_msm_partial_dev", "zk_bn254_g2_msm_partial_dev", "zk_bn254_g1_sum_xyzz", "zk_bn254_g2_sum_xyzz",
     "zk_bn254_bases_register", "zk_bn254_bases_free", "zk_bn254_msm_bases",
     "zk_bn254_ntt", "zk_bn254_ntt_dev", "zk_bn254_bit_reverse", "zk_bn254_bit_reverse_dev",
-    "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev",
+    "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev",
     "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_prove",
-    "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_finalize",
+    "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_finalize",
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_selftest_host",

@@ -24,7 +24,7 @@ namespace zkmi {
 
 struct Groth16PK {
     uint32_t log_domain = 0;
-    size_t n_wires = 0, n_public = 0;
+    size_t n_wires = 0, n_public = 0, nz = 0;  // nz: entries of Z used (N - 1; N for a non-final shard of a range-sharded key)
     Affine<HFp> alpha, beta, delta;
     Affine<HFp2> beta2, delta2;
     void *d_a = nullptr, *d_b = nullptr, *d_k = nullptr, *d_z = nullptr, *d_b2 = nullptr;
@@ -101,6 +101,7 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     memcpy(&P.beta2, pk->g2_beta, 128);
     memcpy(&P.delta2, pk->g2_delta, 128);
     size_t N = (size_t)1 << pk->log_domain, nk = pk->n_wires - pk->n_public;
+    P.nz = (pk->flags & 2) ? N : N - 1;
     if (pk->bases_on_device) {
         P.owns = false;
         P.d_a = (void*)pk->g1_a; P.d_b = (void*)pk->g1_b; P.d_k = (void*)pk->g1_k; P.d_z = (void*)pk->g1_z; P.d_b2 = (void*)pk->g2_b;
@@ -118,7 +119,7 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     if (!(pk->flags & 1) && pk->n_wires > 0 && N > 1) {
         P.tab_w.c = msm_pick_window_table(pk->n_wires);
         P.tab_w.stride = pk->n_wires;
-        P.tab_h.c = msm_pick_window_table(N - 1);
+        P.tab_h.c = msm_pick_window_table(P.nz);
         P.tab_h.stride = N;
         const size_t Ww = (255 + P.tab_w.c - 1) / P.tab_w.c, Wh = (255 + P.tab_h.c - 1) / P.tab_h.c;
         const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
@@ -132,7 +133,7 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
             hipStream_t st = g.s->stream;
             struct { void** t; const void* src; size_t n, stride, off, esz; unsigned c; size_t Wd; int g2; } jobs[5] = {
                 {&P.t_a, P.d_a, pk->n_wires, pk->n_wires, 0, 64, P.tab_w.c, Ww, 0},  {&P.t_b, P.d_b, pk->n_wires, pk->n_wires, 0, 64, P.tab_w.c, Ww, 0},
-                {&P.t_k, P.d_k, nk, pk->n_wires, pk->n_public, 64, P.tab_w.c, Ww, 0}, {&P.t_z, P.d_z, N - 1, N, 0, 64, P.tab_h.c, Wh, 0},
+                {&P.t_k, P.d_k, nk, pk->n_wires, pk->n_public, 64, P.tab_w.c, Ww, 0}, {&P.t_z, P.d_z, P.nz, N, 0, 64, P.tab_h.c, Wh, 0},
                 {&P.t_b2, P.d_b2, pk->n_wires, pk->n_wires, 0, 128, P.tab_w.c, Ww, 1}};
             for (auto& j : jobs) {
                 ZK_HIP(hipMalloc(j.t, j.Wd * j.stride * j.esz));
@@ -402,6 +403,35 @@ int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2
     return rc;
 }
 
+int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void* d_w, const void* d_h, uint64_t out_xyzz[96], void* stream) {
+    if (!out_xyzz) return set_err(ZK_ERR_ARG, "null pointer");
+    Groth16PK P;
+    ZK_TRY(lookup_pk(pk_handle, &P));
+    const size_t nw = P.n_wires, nk = P.n_wires - P.n_public;
+    if ((nw && !d_w) || (P.nz && !d_h)) return set_err(ZK_ERR_ARG, "null pointer");
+    SlotsGuard<5> g;
+    ZK_TRY(acquire_slots(5, g.s));
+    Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, d_w, nw, P.d_k, (const char*)d_w + P.n_public * 32, nk, P.d_z, d_h, P.nz};
+    if (P.tables) {
+        in.tab_w = &P.tab_w; in.tab_h = &P.tab_h;
+        in.t_a = P.t_a; in.t_b = P.t_b; in.t_b2 = P.t_b2; in.t_k = P.t_k; in.t_z = P.t_z;
+    }
+    ZK_TRY(msm5_reserve(g.s, in, 0));
+    hipEvent_t ev = nullptr;
+    if (stream) {  // w and h are produced on the caller's stream: gate all five streams on it
+        ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(ev, (hipStream_t)stream));
+        ZK_HIP(hipStreamWaitEvent(g.s[0]->stream_hi, ev, 0));
+    }
+    Msm5State S;
+    int rc = msm5_launch_w(g.s, in, ev, &S);
+    if (rc == ZK_OK) rc = msm5_launch_h(g.s, g.s[0]->stream_hi, in, &S);
+    if (rc == ZK_OK) rc = msm5_finish(&S, out_xyzz);
+    else { msm_prep_release(&S.prep_w); msm_prep_release(&S.prep_h); }
+    if (ev) (void)hipEventDestroy(ev);
+    return rc;
+}
+
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size_t n_partials, const zk_fr* r, const zk_fr* s, uint8_t proof_out[128]) {
     if (!partials || !n_partials || !r || !s || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
     Groth16PK P;
@@ -421,7 +451,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     ZK_TRY(acquire_slots(5, g.s));
     Slot* s0 = g.s[0];
     hipStream_t st = s0->stream_hi;
-    Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, nullptr, nw, P.d_k, nullptr, nk, P.d_z, nullptr, N - 1};
+    Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, nullptr, nw, P.d_k, nullptr, nk, P.d_z, nullptr, P.nz};
     in.d_wk = (const char*)in.d_w + P.n_public * 32;  // placeholder geometry for the reservation; real pointers below
     if (P.tables) {
         in.tab_w = &P.tab_w; in.tab_h = &P.tab_h;

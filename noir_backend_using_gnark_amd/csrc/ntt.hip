@@ -34,10 +34,10 @@ struct PowBasis {
 __device__ __forceinline__ unsigned bitrev_u32(unsigned i, unsigned logn) { return logn ? (__brev(i) >> (32 - logn)) : 0; }
 
 // out[i] = scale * base^(i) or base^(bitrev(i))
-__global__ void k_pow_table(Fr* out, size_t n, unsigned logn, PowBasis basis, Fr scale, int reversed) {
+__global__ void k_pow_table(Fr* out, size_t n, unsigned logn, PowBasis basis, Fr scale, int reversed, size_t offset) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned e = reversed ? bitrev_u32((unsigned)i, logn) : (unsigned)i;
+    unsigned e = reversed ? bitrev_u32((unsigned)(i + offset), logn) : (unsigned)(i + offset);
     Fr acc = scale;
     for (unsigned b = 0; b < 28; b++)
         if ((e >> b) & 1) acc = acc * basis.pw[b];
@@ -224,7 +224,7 @@ static Fr to_dev(const HFr& h) {
     return r;
 }
 
-static int make_pow_table(Slot* s, hipStream_t st, Fr** out, size_t n, unsigned logn, HFr base, HFr scale, int reversed) {
+static int make_pow_table(Slot* s, hipStream_t st, Fr** out, size_t n, unsigned logn, HFr base, HFr scale, int reversed, size_t offset = 0) {
     ZK_HIP(hipMalloc((void**)out, (n ? n : 1) * sizeof(Fr)));
     PowBasis pb;
     HFr p = base;
@@ -233,7 +233,7 @@ static int make_pow_table(Slot* s, hipStream_t st, Fr** out, size_t n, unsigned 
         p = p.sqr();
     }
     unsigned grid = (unsigned)((n + 255) / 256);
-    ZK_LAUNCH(s, st, "pow_table", k_pow_table, dim3(grid ? grid : 1), dim3(256), 0, *out, n, logn, pb, to_dev(scale), reversed);
+    ZK_LAUNCH(s, st, "pow_table", k_pow_table, dim3(grid ? grid : 1), dim3(256), 0, *out, n, logn, pb, to_dev(scale), reversed, offset);
     return ZK_OK;
 }
 
@@ -374,6 +374,118 @@ int fr_mul_dev(Slot* s, hipStream_t st, Fr* out, const Fr* a, const Fr* b, size_
     return ZK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------ computeH sharded over G = 2^g GPUs
+// Rank rho owns the block [rho*M, (rho+1)*M) of every length-D array (M = D/G).  A radix-2 transform over D splits into
+//   * g CROSS stages on the top g index bits (the first g stages of a DIF transform, the last g of a DIT transform), and
+//   * a plain size-M transform of the block (omega_M = omega_D^G), which is the single-GPU code above.
+// For the cross stages the ranks transpose (all-to-all, done by the host over RCCL): rank rho then holds T[s][j], s < G,
+// j < C = M/G, = element s*M + rho*C + j, and one lane runs the g butterflies of column j in registers (G <= 8: the
+// radix-8 of SURVEY.md 8e).  Twiddles come from the size-D table: DIF stage t pairs s, s + (G >> (t+1)) with
+// w^(((s mod h)*M + rho*C + j) << t); DIT cross stage u pairs s, s + 2^u with w^(((s mod 2^u)*M + rho*C + j) * (G >> (u+1))).
+template <int LOGG, bool DIF>
+__global__ __launch_bounds__(256) void k_ntt_cross(Fr* __restrict__ T, const Fr* __restrict__ tw, unsigned logM, unsigned rank) {
+    constexpr unsigned G = 1u << LOGG;
+    const size_t C = ((size_t)1 << logM) >> LOGG;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C) return;
+    const size_t low = (size_t)rank * C + j;
+    Fr x[G];
+#pragma unroll
+    for (unsigned s = 0; s < G; s++) x[s] = gload_fr(T + s * C + j);
+#pragma unroll
+    for (int st = 0; st < LOGG; st++) {
+        const unsigned h = DIF ? (G >> (st + 1)) : (1u << st);  // pair distance in s
+        const unsigned mul_shift = DIF ? st : (LOGG - 1 - st);  // exponent multiplier 2^t (DIF) / G/(2h) (DIT)
+#pragma unroll
+        for (unsigned s = 0; s < G; s++) {
+            if (s & h) continue;
+            const size_t e = (((size_t)(s & (h - 1)) << logM) + low) << mul_shift;
+            Fr w = gload_fr(tw + e);
+            if (DIF) {
+                Fr u = x[s] + x[s + h];
+                x[s + h] = (x[s] - x[s + h]) * w;
+                x[s] = u;
+            } else {
+                Fr v = x[s + h] * w;
+                x[s + h] = x[s] - v;
+                x[s] = x[s] + v;
+            }
+        }
+    }
+#pragma unroll
+    for (unsigned s = 0; s < G; s++) T[s * C + j] = x[s];
+}
+
+template <bool DIF>
+static int launch_cross(Slot* s, hipStream_t st, Fr* T, const Fr* tw, unsigned logM, unsigned logg, unsigned rank) {
+    const size_t C = ((size_t)1 << logM) >> logg;
+    dim3 grid((unsigned)((C + 255) / 256)), block(256);
+    switch (logg) {
+        case 0: return ZK_OK;
+        case 1: ZK_LAUNCH(s, st, "ntt_cross", (k_ntt_cross<1, DIF>), grid, block, 0, T, tw, logM, rank); return ZK_OK;
+        case 2: ZK_LAUNCH(s, st, "ntt_cross", (k_ntt_cross<2, DIF>), grid, block, 0, T, tw, logM, rank); return ZK_OK;
+        case 3: ZK_LAUNCH(s, st, "ntt_cross", (k_ntt_cross<3, DIF>), grid, block, 0, T, tw, logM, rank); return ZK_OK;
+        default: return set_err(ZK_ERR_ARG, "computeH shards over at most 8 ranks (log_g = %u)", logg);
+    }
+}
+
+struct ShardTables {
+    Fr *coset_rev_n = nullptr, *coset_inv_n_rev = nullptr;  // this rank's M-entry slices of the size-D tables
+};
+static std::mutex g_shard_mu;
+static std::map<uint64_t, ShardTables> g_shard_tables;
+
+static int get_shard_tables(Slot* s, hipStream_t st, Domain* dD, unsigned logD, unsigned logg, unsigned rank, ShardTables* out) {
+    std::lock_guard<std::mutex> lk(g_shard_mu);
+    const uint64_t key = ((uint64_t)logD << 32) | ((uint64_t)logg << 16) | rank;
+    ShardTables& t = g_shard_tables[key];
+    if (!t.coset_rev_n) {
+        const size_t M = ((size_t)1 << logD) >> logg;
+        ZK_TRY(make_pow_table(s, st, &t.coset_rev_n, M, logD, dD->coset, dD->card_inv, 1, (size_t)rank * M));
+        ZK_TRY(make_pow_table(s, st, &t.coset_inv_n_rev, M, logD, dD->coset_inv, dD->card_inv, 1, (size_t)rank * M));
+        ZK_HIP(hipStreamSynchronize(st));
+    }
+    *out = t;
+    return ZK_OK;
+}
+
+// One compute phase of the sharded computeH (the host exchanges between phases; see include/zkmi.h).
+int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* c, unsigned logD, unsigned logg, unsigned rank) {
+    if (logg > 3 || logD < 2 * logg || logD > 28) return set_err(ZK_ERR_ARG, "bad shard geometry (log_D = %u, log_g = %u)", logD, logg);
+    if (rank >= (1u << logg)) return set_err(ZK_ERR_ARG, "rank %u out of range", rank);
+    ZK_TRY(ensure_lds_attr());
+    const unsigned logM = logD - logg;
+    const size_t M = (size_t)1 << logM;
+    Domain *dD, *dM;
+    ZK_TRY(get_domain(s, st, logD, logg ? (DOM_TW | DOM_TW_INV) : 0u, &dD));
+    ZK_TRY(get_domain(s, st, logM, DOM_TW | DOM_TW_INV, &dM));
+    ShardTables tb;
+    ZK_TRY(get_shard_tables(s, st, dD, logD, logg, rank, &tb));
+    switch (phase) {
+        case 0:  // transposed a, b, c: cross stages of FFTInverse(DIF)
+            for (Fr* v : {a, b, c}) ZK_TRY(launch_cross<true>(s, st, v, dD->tw_inv, logM, logg, rank));
+            return ZK_OK;
+        case 1:  // blocks: rest of FFTInverse(DIF), * 1/D * g^bitrev(i), block part of FFT(DIT, coset)
+            for (Fr* v : {a, b, c}) {
+                ZK_TRY(run_passes(s, st, v, logM, dM->tw_inv, 1, nullptr, tb.coset_rev_n, nullptr));
+                ZK_TRY(run_passes(s, st, v, logM, dM->tw, 0, nullptr, nullptr, nullptr));
+            }
+            return ZK_OK;
+        case 2: {  // transposed: cross stages of FFT(DIT); pointwise; cross stages of the final FFTInverse(DIF, coset)
+            for (Fr* v : {a, b, c}) ZK_TRY(launch_cross<false>(s, st, v, dD->tw, logM, logg, rank));
+            HFr gN = dD->coset;
+            for (unsigned i = 0; i < logD; i++) gN = gN.sqr();
+            HFr den = (gN - HFr::one()).inv();
+            ZK_LAUNCH(s, st, "h_pointwise", k_h_pointwise, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, a, (const Fr*)b, (const Fr*)c, to_dev(den), M);
+            return launch_cross<true>(s, st, a, dD->tw_inv, logM, logg, rank);
+        }
+        case 3:  // block of a: rest of FFTInverse(DIF, coset) -> this rank's block of h (gnark's bit-reversed order)
+            return run_passes(s, st, a, logM, dM->tw_inv, 1, nullptr, tb.coset_inv_n_rev, nullptr);
+        default: return set_err(ZK_ERR_ARG, "phase must be 0..3");
+    }
+}
+
 }  // namespace zkmi
 
 using namespace zkmi;
@@ -474,6 +586,16 @@ int zk_bn254_groth16_compute_h(const zk_fr* a, const zk_fr* b, const zk_fr* c, s
     ZK_TRY(compute_h_inplace(g.s, st, d[0], d[1], d[2], log_N));
     ZK_HIP(hipMemcpyAsync(h_out, d[0], N * 32, hipMemcpyDeviceToHost, st));
     return slot_sync(g.s, st);
+}
+
+int zk_bn254_groth16_h_shard_dev(int phase, void* d_a, void* d_b, void* d_c, uint32_t log_D, uint32_t log_g, uint32_t rank, void* stream) {
+    if (!d_a || (phase != 3 && (!d_b || !d_c))) return set_err(ZK_ERR_ARG, "null pointer");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    ZK_TRY(compute_h_shard_phase(g.s, st, phase, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, log_D, log_g, rank));
+    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));  // in place, no workspace: a caller-provided stream stays asynchronous
+    return ZK_OK;
 }
 
 int zk_bn254_fr_mul_dev(void* d_out, const void* d_a, const void* d_b, size_t n, void* stream) {

@@ -16,10 +16,13 @@ class ProvingKey:
     """groth16.ProvingKey{G1{Alpha,Beta,Delta,A,B,K,Z}, G2{Beta,Delta,B}} resident in HBM.
 
     Arrays are gnark memory images (numpy uint64) or, with bases_on_device=True, raw device pointers for the five
-    base arrays (used by the benchmark, whose bases are generated on the device)."""
+    base arrays (used by the benchmark, whose bases are generated on the device).
+
+    A rank of a range-sharded proof loads ITS slice as a key of its own (n_wires / n_public / log_domain describe the
+    slice; shard_full_z=True on every rank but the last, whose Z slice ends with the unused N-th entry)."""
 
     def __init__(self, log_domain: int, n_wires: int, n_public: int, g1_alpha, g1_beta, g1_delta, g1_a, g1_b, g1_k, g1_z,
-                 g2_beta, g2_delta, g2_b, bases_on_device: bool = False, precompute_tables: bool = True):
+                 g2_beta, g2_delta, g2_b, bases_on_device: bool = False, precompute_tables: bool = True, shard_full_z: bool = False):
         self.log_domain, self.n_wires, self.n_public = log_domain, n_wires, n_public
         self._keep = []
 
@@ -35,7 +38,7 @@ class ProvingKey:
 
         pk = Groth16PK(log_domain, n_wires, n_public, host(g1_alpha), host(g1_beta), host(g1_delta), base(g1_a), base(g1_b),
                        base(g1_k), base(g1_z), host(g2_beta), host(g2_delta), base(g2_b), 1 if bases_on_device else 0,
-                       0 if precompute_tables else 1)
+                       (0 if precompute_tables else 1) | (2 if shard_full_z else 0))
         if bases_on_device:
             self._keep += [g1_a, g1_b, g1_k, g1_z, g2_b]  # keep DeviceBuffers alive
         self.handle = C.c_uint64(0)

@@ -1,10 +1,14 @@
-"""One process per GPU: range-sharding of the MSMs of a proof across the GPUs of a node.
+"""One process per GPU: range-sharding of a proof across the GPUs of a node.
 
 The path shards by POINT RANGE (SURVEY.md §8e "point-range-sharded"): rank g owns bases / scalars [g*n/G, (g+1)*n/G),
 runs the local Pippenger MSMs, and the only exchange is an all-gather of the un-normalised partial sums (96 limbs =
 768 B per rank per proof) -- RCCL over xGMI on GPUs (`torch.distributed` backend "nccl"), gloo in the CPU tests.
 Field / group addition is not an RCCL reduction op, so the "reduce" is all-gather + a local combine on every rank
-(zk_bn254_g1_sum_xyzz / zk_bn254_groth16_finalize, host side, O(G))."""
+(zk_bn254_g1_sum_xyzz / zk_bn254_groth16_finalize, host side, O(G)).
+
+computeH shards too (SURVEY.md §8e, 4-step NTT): every rank owns one block of a, b, c and of h; the top log2(G) butterfly
+stages of each transform run on all-to-all-transposed data (`block_exchange`, RCCL all_to_all_single over xGMI), the rest
+is a block-local transform -- 10 array exchanges of 32*M*(G-1)/G bytes per rank and proof, no other traffic."""
 from __future__ import annotations
 
 import ctypes as C
@@ -88,3 +92,58 @@ def groth16_finalize(pk, partials: np.ndarray, r, s) -> bytes:
     proof = (C.c_uint8 * 128)()
     check(lib().zk_bn254_groth16_finalize(pk.handle, vp(partials), C.c_size_t(partials.shape[0]), vp(r), vp(s), proof))
     return bytes(proof)
+
+
+def block_exchange(x):
+    """The transpose of the sharded NTT: `x` (a torch tensor, this rank's array) is cut into `world` equal chunks, chunk r
+    goes to rank r and chunk s of the result is what rank s sent.  Applying it twice restores the block.
+    RCCL all_to_all_single under nccl; gloo (no all-to-all) gathers and selects -- CPU tests only."""
+    import torch
+    d = dist()
+    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+        return x
+    world, rank = d.get_world_size(), d.get_rank()
+    y = torch.empty_like(x)
+    if d.get_backend() == "nccl":
+        d.all_to_all_single(y, x)
+        return y
+    rows = [torch.empty_like(x) for _ in range(world)]
+    d.all_gather(rows, x)
+    chunk = x.numel() // world
+    for s_ in range(world):
+        y.view(-1)[s_ * chunk:(s_ + 1) * chunk] = rows[s_].view(-1)[rank * chunk:(rank + 1) * chunk]
+    return y
+
+
+def _h_shard_phase_hip(phase, a, b, c, log_d, log_g, rank):
+    """zk_bn254_groth16_h_shard_dev on torch CUDA tensors, asynchronous on torch's current stream."""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib().zk_bn254_groth16_h_shard_dev(C.c_int(phase), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr() if b is not None else 0),
+                                             C.c_void_p(c.data_ptr() if c is not None else 0), C.c_uint32(log_d), C.c_uint32(log_g),
+                                             C.c_uint32(rank), C.c_void_p(st)))
+
+
+def compute_h_sharded(a, b, c, log_d: int, rank: int, world: int, phase=_h_shard_phase_hip, exchange=block_exchange):
+    """gnark computeH with a, b, c, h sharded by blocks over `world` = 2^g ranks.  a, b, c: this rank's blocks (M = 2^log_d / world
+    elements of 4 x int64 each; destroyed).  Returns the array holding this rank's block of h (gnark's bit-reversed order).
+    `phase` / `exchange` are injectable so that the CPU tests can run the same schedule on the oracle's arithmetic over gloo."""
+    log_g = world.bit_length() - 1
+    if (1 << log_g) != world:
+        raise ValueError("world size must be a power of two")
+    a, b, c = exchange(a), exchange(b), exchange(c)
+    phase(0, a, b, c, log_d, log_g, rank)
+    a, b, c = exchange(a), exchange(b), exchange(c)
+    phase(1, a, b, c, log_d, log_g, rank)
+    a, b, c = exchange(a), exchange(b), exchange(c)
+    phase(2, a, b, c, log_d, log_g, rank)
+    a = exchange(a)
+    phase(3, a, None, None, log_d, log_g, rank)
+    return a
+
+
+def groth16_msm5_pk(pk, d_w: int, d_h: int, stream: int = 0) -> np.ndarray:
+    """The five MSMs of this rank's slice against its resident key slice `pk` (window tables included) -> 96-limb record."""
+    out = np.zeros(96, dtype=np.uint64)
+    check(lib().zk_bn254_groth16_msm5_pk(pk.handle, C.c_void_p(d_w), C.c_void_p(d_h), vp(out), C.c_void_p(stream)))
+    return out

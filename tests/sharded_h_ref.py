@@ -1,0 +1,128 @@
+"""Test infrastructure: big-integer restatement of the four compute phases of the block-sharded computeH
+(include/zkmi.h, zk_bn254_groth16_h_shard_dev) and a lock-step driver that plays all G ranks in one process.
+
+The decomposition: a radix-2 transform over D = G*M points = g = log2(G) "cross" stages on the top index bits (first
+stages of DIF, last stages of DIT) + a size-M transform of every block.  Cross stages run on transposed data
+T[s][j] = element s*M + rank*C + j (C = M/G).  Values are plain integers mod r here (no Montgomery form)."""
+from oracle import bn254_ref as ref
+
+R = ref.R
+
+
+def dif_inplace(a, w):
+    """natural in -> bit-reversed out; w = primitive len(a)-th root (gnark FFT(DIF) data movement)."""
+    n = len(a)
+    span, step = n // 2, 1
+    while span >= 1:
+        for start in range(0, n, 2 * span):
+            for i in range(span):
+                x, y = a[start + i], a[start + i + span]
+                a[start + i] = (x + y) % R
+                a[start + i + span] = (x - y) * pow(w, i * step, R) % R
+        span //= 2
+        step *= 2
+
+
+def dit_inplace(a, w):
+    """bit-reversed in -> natural out."""
+    n = len(a)
+    h = 1
+    while h < n:
+        for start in range(0, n, 2 * h):
+            for i in range(h):
+                x, y = a[start + i], a[start + i + h] * pow(w, i * (n // (2 * h)), R) % R
+                a[start + i] = (x + y) % R
+                a[start + i + h] = (x - y) % R
+        h *= 2
+
+
+def cross_dif(T, w_d, log_g, log_m, rank):
+    G, M = 1 << log_g, 1 << log_m
+    C = M // G
+    for j in range(C):
+        low = rank * C + j
+        for t in range(log_g):
+            h = G >> (t + 1)
+            for s in range(G):
+                if s & h:
+                    continue
+                e = ((s & (h - 1)) * M + low) << t
+                x, y = T[s * C + j], T[(s + h) * C + j]
+                T[s * C + j] = (x + y) % R
+                T[(s + h) * C + j] = (x - y) * pow(w_d, e, R) % R
+
+
+def cross_dit(T, w_d, log_g, log_m, rank):
+    G, M = 1 << log_g, 1 << log_m
+    C = M // G
+    for j in range(C):
+        low = rank * C + j
+        for u in range(log_g):
+            h = 1 << u
+            for s in range(G):
+                if s & h:
+                    continue
+                e = ((s & (h - 1)) * M + low) * (G >> (u + 1))
+                x, y = T[s * C + j], T[(s + h) * C + j] * pow(w_d, e, R) % R
+                T[s * C + j] = (x + y) % R
+                T[(s + h) * C + j] = (x - y) % R
+
+
+def phase_int(phase, a, b, c, log_d, log_g, rank):
+    """In place on python lists of integers mod r (this rank's arrays)."""
+    dom = ref.Domain(1 << log_d)
+    log_m = log_d - log_g
+    M, G = 1 << log_m, 1 << log_g
+    w_m, w_m_inv = pow(dom.gen, G, R), pow(dom.gen_inv, G, R)
+    if phase == 0:
+        for v in (a, b, c):
+            cross_dif(v, dom.gen_inv, log_g, log_m, rank)
+    elif phase == 1:
+        for v in (a, b, c):
+            dif_inplace(v, w_m_inv)
+            for j in range(M):
+                v[j] = v[j] * dom.card_inv % R * pow(dom.coset, ref.bitrev(rank * M + j, log_d), R) % R
+            dit_inplace(v, w_m)
+    elif phase == 2:
+        for v in (a, b, c):
+            cross_dit(v, dom.gen, log_g, log_m, rank)
+        den = ref.inv((pow(dom.coset, dom.n, R) - 1) % R, R)
+        for j in range(M):
+            a[j] = (a[j] * b[j] - c[j]) * den % R
+        cross_dif(a, dom.gen_inv, log_g, log_m, rank)
+    elif phase == 3:
+        dif_inplace(a, w_m_inv)
+        for j in range(M):
+            a[j] = a[j] * dom.card_inv % R * pow(dom.coset_inv, ref.bitrev(rank * M + j, log_d), R) % R
+    else:
+        raise ValueError(phase)
+
+
+def exchange_all(blocks):
+    """All-to-all among virtual ranks: blocks[r] is rank r's array (list or numpy rows); returns the transposed arrays."""
+    G = len(blocks)
+    C = len(blocks[0]) // G
+    out = []
+    for r in range(G):
+        rows = [blocks[s][r * C:(r + 1) * C] for s in range(G)]
+        if hasattr(rows[0], "shape"):
+            import numpy as np
+            out.append(np.concatenate(rows))
+        else:
+            out.append([x for row in rows for x in row])
+    return out
+
+
+def run_virtual(phase, A, B, Cc, log_d):
+    """Lock-step schedule of parallel.compute_h_sharded over G = len(A) virtual ranks.  phase(p, a, b, c, log_d, log_g, rank)
+    works in place on whatever array type the blocks are.  Returns the list of h blocks."""
+    G = len(A)
+    log_g = G.bit_length() - 1
+    for p in range(3):
+        A, B, Cc = exchange_all(A), exchange_all(B), exchange_all(Cc)
+        for r in range(G):
+            phase(p, A[r], B[r], Cc[r], log_d, log_g, r)
+    A = exchange_all(A)
+    for r in range(G):
+        phase(3, A[r], None, None, log_d, log_g, r)
+    return A

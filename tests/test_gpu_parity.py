@@ -370,3 +370,79 @@ def test_msm_equal_and_opposite_bucket_sums(c):
         pts = np.concatenate([np.stack([Pg, pt2]), rp])
         sc = mont_limbs([7, second] + rs)
         assert (zk.g2_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=c)) == orc.g2_msm(pts, sc)).all(), (c, second)
+
+
+def _h_phase_gpu(phase, a, b, c, log_d, log_g, rank):
+    """One compute phase of the sharded computeH through the C ABI, in place on numpy blocks (M, 4) of Montgomery limbs."""
+    D = _lib.DeviceBuffer.from_numpy
+    da, db, dc = D(a), (D(b) if b is not None else None), (D(c) if c is not None else None)
+    _lib.check(_lib.lib().zk_bn254_groth16_h_shard_dev(C.c_int(phase), C.c_void_p(da.ptr), C.c_void_p(db.ptr if db else 0),
+                                                       C.c_void_p(dc.ptr if dc else 0), C.c_uint32(log_d), C.c_uint32(log_g),
+                                                       C.c_uint32(rank), None))
+    for dst, src in ((a, da), (b, db), (c, dc)):
+        if dst is not None:
+            dst[...] = src.to_numpy(np.uint64, dst.shape)
+
+
+@pytest.mark.parametrize("log_d,G", [(6, 8), (9, 2), (12, 1), (13, 4), (15, 8), (18, 8), (20, 2)])
+def test_sharded_compute_h_matches_single_gpu_and_oracle(log_d, G):
+    """Block-sharded computeH (4 phases + transposes, played for all G ranks in lock-step on one GPU) == computeH on one GPU,
+    bit for bit; small sizes also against the oracle."""
+    from tests import sharded_h_ref as sh
+    n = 1 << log_d
+    M = n // G
+    a, b, c = orc.rand_fr(51, n), orc.rand_fr(52, n), orc.rand_fr(53, n)
+    want = zk.compute_h(a, b, c, log_d)
+    if log_d <= 15:
+        assert (want == orc.groth16_compute_h(a, b, c, log_d)).all()
+    blk = lambda v: [v[r * M:(r + 1) * M].copy() for r in range(G)]
+    H = sh.run_virtual(_h_phase_gpu, blk(a), blk(b), blk(c), log_d)
+    got = np.concatenate(H)
+    assert sha_image(got) == sha_image(want)
+
+
+def test_sharded_compute_h_argument_errors():
+    d = _lib.DeviceBuffer(64 * 32)
+    call = lambda ph, ld, lg, rk: _lib.lib().zk_bn254_groth16_h_shard_dev(C.c_int(ph), C.c_void_p(d.ptr), C.c_void_p(d.ptr), C.c_void_p(d.ptr),
+                                                                          C.c_uint32(ld), C.c_uint32(lg), C.c_uint32(rk), None)
+    assert call(0, 6, 4, 0) != 0      # more than 8 ranks
+    assert call(0, 6, 2, 4) != 0      # rank out of range
+    assert call(7, 6, 1, 0) != 0      # unknown phase
+    assert call(0, 3, 2, 0) != 0      # blocks smaller than the number of ranks
+
+
+@pytest.mark.parametrize("G,tables", [(2, True), (4, True), (4, False)])
+def test_sharded_proof_with_rank_local_keys(G, tables):
+    """The whole multi-GPU prover, all ranks played on one GPU: every rank loads ITS slice of the key (window tables over the
+    slice), runs the sharded computeH and zk_bn254_groth16_msm5_pk; the gathered records finalize to the oracle's 128 bytes."""
+    from noir_backend_using_gnark_amd import parallel as par
+    from tests import sharded_h_ref as sh
+    log_n = 11
+    N = 1 << log_n
+    nw, npub = N, 4
+    M = N // G
+    small = dict(g1_alpha=orc.g1_gen_points(1, 1)[0], g1_beta=orc.g1_gen_points(2, 1)[0], g1_delta=orc.g1_gen_points(3, 1)[0],
+                 g2_beta=orc.g2_gen_points(8, 1)[0], g2_delta=orc.g2_gen_points(9, 1)[0])
+    pkd = dict(log_domain=log_n, n_wires=nw, n_public=npub, g1_a=orc.g1_gen_points(4, nw), g1_b=orc.g1_gen_points(5, nw),
+               g1_k=orc.g1_gen_points(6, nw - npub), g1_z=orc.g1_gen_points(7, N), g2_b=orc.g2_gen_points(10, nw), **small)
+    a, b = orc.rand_fr(20, N), orc.rand_fr(21, N)
+    c = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(N)])
+    w = orc.rand_fr(22, nw, witness_like=True)
+    r, s = orc.rand_fr(23, 1)[0], orc.rand_fr(24, 1)[0]
+    exp, _ = orc.groth16_prove(pkd, a, b, c, w, r, s)
+    blk = lambda v: [v[q * M:(q + 1) * M].copy() for q in range(G)]
+    H = sh.run_virtual(_h_phase_gpu, blk(a), blk(b), blk(c), log_n)
+    recs, keys = [], []
+    for rank in range(G):
+        lo, hi = rank * M, (rank + 1) * M
+        np_loc = npub if rank == 0 else 0
+        pk = zk.ProvingKey(log_n - (G.bit_length() - 1), M, np_loc, g1_a=pkd["g1_a"][lo:hi], g1_b=pkd["g1_b"][lo:hi],
+                           g1_k=pkd["g1_k"][lo + np_loc - npub:hi - npub], g1_z=pkd["g1_z"][lo:hi], g2_b=pkd["g2_b"][lo:hi],
+                           precompute_tables=tables, shard_full_z=(rank != G - 1), **small)
+        keys.append(pk)
+        d_w, d_h = _lib.DeviceBuffer.from_numpy(w[lo:hi]), _lib.DeviceBuffer.from_numpy(H[rank])
+        recs.append(par.groth16_msm5_pk(pk, d_w.ptr, d_h.ptr))
+    assert par.groth16_finalize(keys[0], np.stack(recs), r, s) == exp
+    assert par.groth16_finalize(keys[-1], np.stack(recs), r, s) == exp
+    for pk in keys:
+        pk.free()

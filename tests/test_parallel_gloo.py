@@ -11,6 +11,13 @@ from noir_backend_using_gnark_amd import parallel as par
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %r)
@@ -32,7 +39,7 @@ total = zb.g1_sum_partials(gathered)
 assert (total == orc.g1_msm(pts, sc)).all()
 assert (gathered[rank] == rec).all()
 par.dist().barrier()
-print("rank", rank, "ok")
+sys.stdout.write("rank %%d ok\n" %% rank); sys.stdout.flush()
 ''' % ROOT
 
 
@@ -55,7 +62,7 @@ def test_two_rank_sharded_msm_gloo(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(script)]
+           "--master-port", str(free_port()), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
