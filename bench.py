@@ -3,9 +3,10 @@
 "Synthetic R1CS 2^20 constraints, BN254 Groth16 prove on 1xMI355X (G1 MSM + Fr NTT)".
 
 One step = one proof from the solver output onwards (computeH = 7 NTTs, 4 G1 MSMs, 1 G2 MSM, host tail), inputs already
-resident in HBM.  --gpus N > 1 (one process per GPU, torchrun): the same proof over N * 2^log_n constraints with every
-MSM range-sharded over the ranks (weak scaling in the MSMs; computeH is replicated -- there is no distributed NTT yet);
-the only collective is an all-gather of the 768-byte partial-sum record per proof (RCCL).
+resident in HBM.  --gpus N > 1 (one process per GPU, torchrun): ONE proof over N * 2^log_n constraints, range-sharded: every
+rank owns one block of a, b, c, w, h and of the proving key (with its window tables); computeH is block-sharded (the top
+log2 N butterfly stages of each transform run on all-to-all-transposed data: 10 RCCL all_to_all_single per proof), the
+five MSMs run on the rank's slice, and an all-gather of the 768-byte partial-sum record lets every rank finish the proof.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric / value / unit follow BASELINE.json; `roofline`
 describes the dominant kernel (hipEvent pairs recorded inside libzkmi on the stream the kernels run on, live over the
@@ -44,7 +45,7 @@ def main():
     ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tables", action="store_true", help="disable the precomputed window tables of the resident proving key")
-    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU decomposition (msm5 + all-gather + finalize) even at N=1")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU decomposition (sharded computeH phases + msm5_pk + all-gather + finalize) even at N=1")
     args = ap.parse_args()
 
     import torch
@@ -56,6 +57,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     L = _lib.lib()
+    local = local % max(1, torch.cuda.device_count())  # ranks share a GPU only in the gloo dry run on a one-GPU box
     _lib.check(L.zk_init(C.c_int(local)))
     torch.cuda.set_device(local)
     _lib.require_device()
@@ -95,32 +97,40 @@ def main():
     small = {k: gen_g1(s, 1, 0).to_numpy(np.uint64, (8,)) for k, s in (("alpha", 1), ("beta", 2), ("delta", 3))}
     small2 = {k: gen_g2(s, 1, 0).to_numpy(np.uint64, (16,)) for k, s in (("beta", 8), ("delta", 9))}
     # solver output: a, b uniform; c = a*b on the evaluation domain (h is a true quotient); w uniform or witness-like.
-    # computeH is replicated: every rank holds the full a, b, c.
-    d_a, d_b = gen_fr(0xA, N_g, 0), gen_fr(0xB, N_g, 0)
-    d_c = dev(N_g * 32)
-    _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(d_c.ptr), C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_size_t(N_g), None))
+    sharded = world > 1 or args.force_sharded
+    np_loc = n_public if rank == 0 else 0  # public wires live in rank 0's slice; gnark's pk.G1.K starts at the first private wire
     d_w = gen_fr(0xC, N_loc, lo, witness)
     rs = gen_fr(0x23, 2, 0).to_numpy(np.uint64, (2, 4))  # pinned prover randomness (r, s)
     r, s = rs[0].copy(), rs[1].copy()
-    # K is indexed by wire like the other arrays; gnark's pk.G1.K starts at the first private wire
-    pk = zk.ProvingKey(log_ng, N_g, n_public, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + n_public * 64, g1_z,
-                       small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables)
-    d_h = dev(N_g * 32) if (world > 1 or args.force_sharded) else None
+    if not sharded:
+        d_a, d_b = gen_fr(0xA, N_g, 0), gen_fr(0xB, N_g, 0)
+        d_c = dev(N_g * 32)
+        _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(d_c.ptr), C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_size_t(N_g), None))
+        pk = zk.ProvingKey(log_ng, N_g, n_public, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + n_public * 64, g1_z,
+                           small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables)
+    else:
+        # this rank's blocks of a, b, c live in torch tensors (RCCL moves them); the key is the rank's slice, loaded as a key of its own
+        t_abc = [torch.empty((N_loc, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+        for t, sd in zip(t_abc[:2], (0xA, 0xB)):
+            _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(t.data_ptr()), C.c_size_t(N_loc), C.c_uint64(seed_at(sd, 4, lo)), C.c_int(1), C.c_int(0), None))
+        _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(t_abc[2].data_ptr()), C.c_void_p(t_abc[0].data_ptr()), C.c_void_p(t_abc[1].data_ptr()),
+                                         C.c_size_t(N_loc), None))
+        pk = zk.ProvingKey(log_n, N_loc, np_loc, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + np_loc * 64, g1_z,
+                           small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables,
+                           shard_full_z=(rank != world - 1))
+        side = torch.cuda.Stream(priority=-1)  # high priority like the single-GPU prover's computeH stream; libzkmi enqueues on this stream between the collectives (a null stream would force it to synchronise)
     _lib.check(L.zk_dev_sync())
+    torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     def step():
-        if world == 1 and not args.force_sharded:
+        if not sharded:
             return zk.prove(pk, d_a, d_b, d_c, d_w, r, s, n_constraints=N_g, on_device=True)
-        # range-sharded proof: full computeH on every rank, MSMs on this rank's slices, all-gather, host tail
-        _lib.check(L.zk_bn254_groth16_compute_h_dev(C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_void_p(d_c.ptr), C.c_size_t(N_g),
-                                                    C.c_uint32(log_ng), C.c_void_p(d_h.ptr), None))
-        k_skip = n_public if rank == 0 else 0          # K pairs with w[n_public:]
-        nz = N_loc - (1 if rank == world - 1 else 0)   # Z uses h[:N-1]
-        rec = par.groth16_msm5_local(g1_a.ptr, g1_b.ptr, g2_b.ptr, d_w.ptr, N_loc,
-                                     g1_k.ptr + k_skip * 64, d_w.ptr + k_skip * 32, N_loc - k_skip,
-                                     g1_z.ptr, d_h.ptr + lo * 32, nz)
-        return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)
+        with torch.cuda.stream(side):
+            a, b, c = (t.clone() for t in t_abc)  # the prover consumes its inputs, like the single-GPU call's internal copies
+            h = par.compute_h_sharded(a, b, c, log_ng, rank, world)
+            rec = par.groth16_msm5_pk(pk, d_w.ptr, h.data_ptr(), side.cuda_stream)
+            return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)
 
     def barrier():
         if world > 1:
@@ -142,7 +152,7 @@ def main():
     _lib.profile(False)
     prof = _lib.profile_read()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if par.dist().get_backend() == "nccl" else "cpu")
         par.dist().all_reduce(t, op=par.dist().ReduceOp.MAX)
         elapsed = float(t.item())
         allp = par.all_gather_limbs(np.frombuffer(proof, dtype=np.uint64))
@@ -177,7 +187,7 @@ def main():
     # mixed-addition routine alone (tools/ubench.hip: k_madd29 16.0 G/s, G1; a G2 mixed addition costs ~2.1 G1 ones)
     valu = None
     if name.startswith("msm_accumulate"):
-        cfg_c = 20 if (not args.no_tables and world == 1 and not args.force_sharded and log_ng <= 22) else 16
+        cfg_c = 20 if (not args.no_tables and log_n <= 22) else 16
         digits = (255 + cfg_c - 1) // cfg_c
         madds = units_per_launch * digits
         peak = 16.0e9 if name.endswith("g1") else 16.0e9 / 2.1
@@ -197,12 +207,13 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_ng, "constraints": N_g, "wires": N_g, "n_public": n_public,
                    "scalars": args.scalars, "per_gpu_constraints": N_loc,
-                   "parallelism": "single GPU" if world == 1 else "MSMs range-sharded x%d (all-gather of partial sums), computeH replicated" % world},
+                   "parallelism": "single GPU" if not sharded else
+                   "one proof range-sharded x%d: block-sharded computeH (all-to-all transposes) + MSMs on rank-local key slices (all-gather of partial sums)" % world},
         "roofline": roofline, "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16], "setup_s": round(t_setup, 2),
     }
 
     # ---- CPU baseline: the oracle proves the SAME instance on this box's host cores (rank 0, N=1 only)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         from oracle import oracle as orc  # the CPU oracle is used ONLY in this leg, as the timed baseline and the checker
         cores = orc.max_threads()
         pkd = dict(log_domain=log_n, n_wires=N_g, n_public=n_public, g1_alpha=small["alpha"], g1_beta=small["beta"], g1_delta=small["delta"],

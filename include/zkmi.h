@@ -153,7 +153,8 @@ int zk_bn254_groth16_msm5_dev(const void *d_a, const void *d_b, const void *d_b2
                               uint64_t out_xyzz[96], void *stream);
 /* msm5 against a loaded key whose base arrays are THIS rank's slices (n_wires / n_public / log_domain describe the
  * slice; flags bit 1 on every rank but the last): uses the key's resident window tables.  d_w: n_wires wire values of
- * the slice, d_h: this rank's block of h. */
+ * the slice, complete before the call (their preparation starts at once); d_h: this rank's block of h, awaited on
+ * `stream` (the stream computeH was enqueued on) if given. */
 int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void *d_w, const void *d_h, uint64_t out_xyzz[96], void *stream);
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t *partials, size_t n_partials, const zk_fr *r,
                               const zk_fr *s, uint8_t proof_out[128]);

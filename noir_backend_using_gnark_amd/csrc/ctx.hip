@@ -157,29 +157,57 @@ void prof_begin(Slot* s, hipStream_t st, const char* name) {
     s->pending.push_back(p);
 }
 void prof_end(Slot* s, hipStream_t st) { hipEventRecord(s->pending.back().e1, st); }
+void prof_host(const char* name, double ms) {
+    Ctx& c = ctx();
+    if (!c.profiling) return;
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.prof.find(name);
+    if (it == c.prof.end()) {
+        c.prof_names.push_back(name);
+        it = c.prof.emplace(name, ProfEntry{}).first;
+    }
+    it->second.launches++;
+    it->second.total_ms += ms;
+}
+
+// Folds the event pairs whose kernels have completed into the profile; pairs still in flight (an asynchronous call on a
+// caller's stream returned without synchronising) stay attached to the slot until a later fold.
+static void fold_pending(Slot* s) {
+    if (s->pending.empty()) return;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    std::vector<Slot::Pending> keep;
+    for (auto& p : s->pending) {
+        if (hipEventQuery(p.e1) != hipSuccess) {
+            keep.push_back(p);
+            continue;
+        }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            auto it = c.prof.find(p.name);
+            if (it == c.prof.end()) {
+                c.prof_names.push_back(p.name);
+                it = c.prof.emplace(p.name, ProfEntry{}).first;
+            }
+            it->second.launches++;
+            it->second.total_ms += ms;
+        }
+        s->free_events.push_back(p.e0);
+        s->free_events.push_back(p.e1);
+    }
+    s->pending.swap(keep);
+}
 
 int slot_sync(Slot* s, hipStream_t st) {
     ZK_HIP(hipStreamSynchronize(st));
-    if (!s->pending.empty()) {
-        Ctx& c = ctx();
-        std::lock_guard<std::mutex> lk(c.mu);
-        for (auto& p : s->pending) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
-                auto it = c.prof.find(p.name);
-                if (it == c.prof.end()) {
-                    c.prof_names.push_back(p.name);
-                    it = c.prof.emplace(p.name, ProfEntry{}).first;
-                }
-                it->second.launches++;
-                it->second.total_ms += ms;
-            }
-            s->free_events.push_back(p.e0);
-            s->free_events.push_back(p.e1);
-        }
-        s->pending.clear();
-    }
+    fold_pending(s);
     return ZK_OK;
+}
+
+void fold_all_slots() {
+    (void)hipDeviceSynchronize();
+    Ctx& c = ctx();
+    for (int i = 0; i < Ctx::NSLOTS; i++) fold_pending(&c.slots[i]);
 }
 
 }  // namespace zkmi
@@ -261,7 +289,10 @@ int zk_profile_reset(void) {
     c.prof_names.clear();
     return ZK_OK;
 }
-int zk_profile_count(void) { return (int)ctx().prof_names.size(); }
+int zk_profile_count(void) {
+    if (ctx().ready) fold_all_slots();  // asynchronous calls may have left event pairs in flight
+    return (int)ctx().prof_names.size();
+}
 int zk_profile_get(int idx, char* name_out, size_t name_cap, uint64_t* launches, double* total_ms) {
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);

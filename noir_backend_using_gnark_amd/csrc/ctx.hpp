@@ -88,6 +88,7 @@ struct SlotsGuard {
 // launch wrapper: optional event pair around the kernel, on the stream it is launched on
 void prof_begin(Slot* s, hipStream_t st, const char* name);
 void prof_end(Slot* s, hipStream_t st);
+void prof_host(const char* name, double ms);  // host-side section of the path (wall clock), reported beside the kernels
 
 #define ZK_LAUNCH(slot, st, name, kernel, grid, block, shmem, ...)                  \
     do {                                                                            \

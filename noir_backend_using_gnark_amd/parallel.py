@@ -33,7 +33,9 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not d.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ZKMI_DIST_BACKEND=gloo: several ranks may then share one GPU (tensors are staged through the host) -- used to
+            # exercise the whole multi-process path on a one-GPU box; RCCL refuses two ranks on one device
+            backend = os.environ.get("ZKMI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -57,8 +59,12 @@ def all_gather_limbs(local: np.ndarray) -> np.ndarray:
     t = torch.from_numpy(local.view(np.int64).copy())
     if d.get_backend() == "nccl":
         t = t.cuda()
-    out = torch.empty((world, t.numel()), dtype=torch.int64, device=t.device)
-    d.all_gather_into_tensor(out, t) if hasattr(d, "all_gather_into_tensor") and d.get_backend() == "nccl" else d.all_gather(list(out.unbind(0)), t)
+        out = torch.empty((world, t.numel()), dtype=torch.int64, device=t.device)
+        d.all_gather_into_tensor(out, t)
+    else:
+        rows = [torch.empty_like(t) for _ in range(world)]
+        d.all_gather(rows, t)
+        out = torch.stack(rows)
     return out.cpu().numpy().view(np.uint64)
 
 
@@ -107,11 +113,12 @@ def block_exchange(x):
     if d.get_backend() == "nccl":
         d.all_to_all_single(y, x)
         return y
-    rows = [torch.empty_like(x) for _ in range(world)]
-    d.all_gather(rows, x)
+    xh = x.cpu() if x.is_cuda else x  # gloo collectives take host tensors
+    rows = [torch.empty_like(xh) for _ in range(world)]
+    d.all_gather(rows, xh)
     chunk = x.numel() // world
-    for s_ in range(world):
-        y.view(-1)[s_ * chunk:(s_ + 1) * chunk] = rows[s_].view(-1)[rank * chunk:(rank + 1) * chunk]
+    yh = torch.cat([rows[s_].reshape(-1)[rank * chunk:(rank + 1) * chunk] for s_ in range(world)]).reshape(x.shape)
+    y.copy_(yh)
     return y
 
 
@@ -119,6 +126,8 @@ def _h_shard_phase_hip(phase, a, b, c, log_d, log_g, rank):
     """zk_bn254_groth16_h_shard_dev on torch CUDA tensors, asynchronous on torch's current stream."""
     import torch
     st = torch.cuda.current_stream().cuda_stream
+    if not st:  # the null stream: libzkmi then runs on a stream of its own and synchronises, so torch's work must be complete first
+        torch.cuda.current_stream().synchronize()
     check(lib().zk_bn254_groth16_h_shard_dev(C.c_int(phase), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr() if b is not None else 0),
                                              C.c_void_p(c.data_ptr() if c is not None else 0), C.c_uint32(log_d), C.c_uint32(log_g),
                                              C.c_uint32(rank), C.c_void_p(st)))
