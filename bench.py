@@ -118,7 +118,6 @@ def main():
         pk = zk.ProvingKey(log_n, N_loc, np_loc, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + np_loc * 64, g1_z,
                            small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables,
                            shard_full_z=(rank != world - 1))
-        side = torch.cuda.Stream(priority=-1)  # high priority like the single-GPU prover's computeH stream; libzkmi enqueues on this stream between the collectives (a null stream would force it to synchronise)
     _lib.check(L.zk_dev_sync())
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -126,10 +125,12 @@ def main():
     def step():
         if not sharded:
             return zk.prove(pk, d_a, d_b, d_c, d_w, r, s, n_constraints=N_g, on_device=True)
+        sess = par.groth16_msm5_pk_begin(pk, d_w.ptr)  # digits / sort / task plan of w run under computeH and its exchanges
+        side = torch.cuda.ExternalStream(par.groth16_session_stream(sess))  # the library's computeH stream, shared with torch / RCCL
         with torch.cuda.stream(side):
             a, b, c = (t.clone() for t in t_abc)  # the prover consumes its inputs, like the single-GPU call's internal copies
             h = par.compute_h_sharded(a, b, c, log_ng, rank, world)
-            rec = par.groth16_msm5_pk(pk, d_w.ptr, h.data_ptr(), side.cuda_stream)
+            rec = par.groth16_msm5_pk_end(sess, h.data_ptr(), side.cuda_stream)
             return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)
 
     def barrier():

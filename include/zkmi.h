@@ -156,6 +156,14 @@ int zk_bn254_groth16_msm5_dev(const void *d_a, const void *d_b, const void *d_b2
  * the slice, complete before the call (their preparation starts at once); d_h: this rank's block of h, awaited on
  * `stream` (the stream computeH was enqueued on) if given. */
 int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void *d_w, const void *d_h, uint64_t out_xyzz[96], void *stream);
+/* The same in two calls: _begin starts the scalar-side preparation of the wire values at once (it does not need h), so it
+ * runs while the host drives the sharded computeH and its exchanges; _end (always call it: it releases the session)
+ * enqueues the rest behind `stream` and waits for the record. */
+int zk_bn254_groth16_msm5_pk_begin(uint64_t pk_handle, const void *d_w, uint64_t *session);
+int zk_bn254_groth16_msm5_pk_end(uint64_t session, const void *d_h, uint64_t out_xyzz[96], void *stream);
+/* The session's high-priority stream (valid until _end): run the sharded computeH and its exchanges on it -- that is the
+ * stream zk_bn254_groth16_prove runs computeH on, and it never shares a hardware queue with the preparation of w. */
+int zk_bn254_groth16_msm5_session_stream(uint64_t session, void **stream_out);
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t *partials, size_t n_partials, const zk_fr *r,
                               const zk_fr *s, uint8_t proof_out[128]);
 

@@ -37,7 +37,7 @@ SYMBOLS = [
     "zk_bn254_ntt", "zk_bn254_ntt_dev", "zk_bn254_bit_reverse", "zk_bn254_bit_reverse_dev",
     "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev",
     "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_prove",
-    "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_finalize",
+    "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_selftest_host",

@@ -243,13 +243,22 @@ struct Msm5State {
 //   slot 0 (high priority): [computeH ->] prepare(h) -> Z accumulate -> reduce          (st0)
 // The HOST enqueue order matters too (~10 us per launch, ~40 launches per preparation): the w-side work is enqueued first so
 // that the GPU is busy while the host is still enqueuing computeH and prepare(h).
+// scalar side of the four MSMs over the wire values (digits, sort, task plan) on slot 4's stream
+static int msm5_prepare_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S) {
+    hipStream_t st4 = sl[4]->stream_hi;
+    if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
+    if (in.tab_w) return msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w);
+    return msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w);
+}
+static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc);
 static int msm5_launch_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc = nullptr) {
+    ZK_TRY(msm5_prepare_w(sl, in, ev_w, S));
+    return msm5_accumulate_w(sl, in, ev_w, S, gate_first_acc);
+}
+static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc) {
     hipStream_t st4 = sl[4]->stream_hi;
     size_t j = 0;
     const bool share_k = k_shares_w(in, &j);
-    if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
-    if (in.tab_w) ZK_TRY(msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w));
-    else ZK_TRY(msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w));
     // accumulate kernels chained through events, each on its MSM's own stream (measured alternatives: one shared "chain" stream
     // for all accumulate kernels removes the ~0.15 ms event gaps but delays prepare(h) -- rocPRIM's onesweep sort spins on
     // look-back tiles that cannot get a wave slot under an accumulate kernel -- and ends up slower)
@@ -446,33 +455,84 @@ int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2
     return rc;
 }
 
-int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void* d_w, const void* d_h, uint64_t out_xyzz[96], void* stream) {
-    if (!out_xyzz) return set_err(ZK_ERR_ARG, "null pointer");
-    Groth16PK P;
-    ZK_TRY(lookup_pk(pk_handle, &P));
-    const size_t nw = P.n_wires, nk = P.n_wires - P.n_public;
-    if ((nw && !d_w) || (P.nz && !d_h)) return set_err(ZK_ERR_ARG, "null pointer");
+// A rank's five MSMs in two calls, so that the preparation of the wire scalars (which does not need h) is already running while
+// the host is still driving computeH and its exchanges.
+struct Msm5Session {
     SlotsGuard<5> g;
-    ZK_TRY(acquire_slots(5, g.s));
-    Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, d_w, nw, P.d_k, (const char*)d_w + P.n_public * 32, nk, P.d_z, d_h, P.nz};
-    if (P.tables) {
-        in.tab_w = &P.tab_w; in.tab_h = &P.tab_h;
-        in.t_a = P.t_a; in.t_b = P.t_b; in.t_b2 = P.t_b2; in.t_k = P.t_k; in.t_z = P.t_z;
-    }
-    ZK_TRY(msm5_reserve(g.s, in, 0));
-    hipEvent_t ev = nullptr;
-    if (stream) {  // h is being produced on the caller's stream (computeH); w is complete already: its preparation starts at once
-        ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        ZK_HIP(hipEventRecord(ev, (hipStream_t)stream));
-        ZK_HIP(hipStreamWaitEvent(g.s[0]->stream_hi, ev, 0));
-    }
+    Groth16PK P;
+    Msm5Inputs in;
     Msm5State S;
-    int rc = msm5_launch_w(g.s, in, nullptr, &S, ev);  // like prove(): the accumulate chain starts when computeH has left the machine
-    if (rc == ZK_OK) rc = msm5_launch_h(g.s, g.s[0]->stream_hi, in, &S);
-    if (rc == ZK_OK) rc = msm5_finish(&S, out_xyzz);
-    else { msm_prep_release(&S.prep_w); msm_prep_release(&S.prep_h); }
+};
+static std::mutex g_sess_mu;
+static std::map<uint64_t, Msm5Session*> g_sessions;
+static uint64_t g_next_session = 1;
+
+int zk_bn254_groth16_msm5_pk_begin(uint64_t pk_handle, const void* d_w, uint64_t* session) {
+    if (!session) return set_err(ZK_ERR_ARG, "null pointer");
+    std::unique_ptr<Msm5Session> ss(new Msm5Session());
+    ZK_TRY(lookup_pk(pk_handle, &ss->P));
+    const Groth16PK& P = ss->P;
+    const size_t nw = P.n_wires, nk = P.n_wires - P.n_public;
+    if (nw && !d_w) return set_err(ZK_ERR_ARG, "null pointer");
+    ZK_TRY(acquire_slots(5, ss->g.s));
+    ss->in = Msm5Inputs{P.d_a, P.d_b, P.d_b2, d_w, nw, P.d_k, (const char*)d_w + P.n_public * 32, nk, P.d_z, nullptr, P.nz};
+    if (P.tables) {
+        ss->in.tab_w = &ss->P.tab_w; ss->in.tab_h = &ss->P.tab_h;
+        ss->in.t_a = P.t_a; ss->in.t_b = P.t_b; ss->in.t_b2 = P.t_b2; ss->in.t_k = P.t_k; ss->in.t_z = P.t_z;
+    }
+    ZK_TRY(msm5_reserve(ss->g.s, ss->in, 0));
+    ZK_TRY(msm5_prepare_w(ss->g.s, ss->in, nullptr, &ss->S));
+    std::lock_guard<std::mutex> lk(g_sess_mu);
+    *session = g_next_session++;
+    g_sessions[*session] = ss.release();
+    return ZK_OK;
+}
+
+int zk_bn254_groth16_msm5_session_stream(uint64_t session, void** stream_out) {
+    if (!stream_out) return set_err(ZK_ERR_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(g_sess_mu);
+    auto it = g_sessions.find(session);
+    if (it == g_sessions.end()) return set_err(ZK_ERR_HANDLE, "unknown msm5 session %llu", (unsigned long long)session);
+    *stream_out = (void*)it->second->g.s[0]->stream_hi;  // the stream prove() runs computeH on: prepare(h) and Z follow on it in order
+    return ZK_OK;
+}
+
+int zk_bn254_groth16_msm5_pk_end(uint64_t session, const void* d_h, uint64_t out_xyzz[96], void* stream) {
+    std::unique_ptr<Msm5Session> ss;
+    {
+        std::lock_guard<std::mutex> lk(g_sess_mu);
+        auto it = g_sessions.find(session);
+        if (it == g_sessions.end()) return set_err(ZK_ERR_HANDLE, "unknown msm5 session %llu", (unsigned long long)session);
+        ss.reset(it->second);
+        g_sessions.erase(it);
+    }
+    Slot** sl = ss->g.s;
+    int rc = ZK_OK;
+    if (!out_xyzz || (ss->P.nz && !d_h)) rc = set_err(ZK_ERR_ARG, "null pointer");
+    ss->in.d_h = d_h;
+    hipEvent_t ev = nullptr;
+    if (rc == ZK_OK && stream) {  // h is being produced on the caller's stream (computeH)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, (hipStream_t)stream) != hipSuccess ||
+            hipStreamWaitEvent(sl[0]->stream_hi, ev, 0) != hipSuccess)
+            rc = set_err(ZK_ERR_HIP, "event setup failed");
+    }
+    // like prove(): the accumulate chain starts when computeH has left the machine
+    if (rc == ZK_OK) rc = msm5_accumulate_w(sl, ss->in, nullptr, &ss->S, ev);
+    if (rc == ZK_OK) rc = msm5_launch_h(sl, sl[0]->stream_hi, ss->in, &ss->S);
+    if (rc == ZK_OK) rc = msm5_finish(&ss->S, out_xyzz);
+    else {
+        for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(sl[i]->stream); (void)hipStreamSynchronize(sl[i]->stream_hi); }
+        msm_prep_release(&ss->S.prep_w);
+        msm_prep_release(&ss->S.prep_h);
+    }
     if (ev) (void)hipEventDestroy(ev);
     return rc;
+}
+
+int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void* d_w, const void* d_h, uint64_t out_xyzz[96], void* stream) {
+    uint64_t session = 0;
+    ZK_TRY(zk_bn254_groth16_msm5_pk_begin(pk_handle, d_w, &session));
+    return zk_bn254_groth16_msm5_pk_end(session, d_h, out_xyzz, stream);
 }
 
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size_t n_partials, const zk_fr* r, const zk_fr* s, uint8_t proof_out[128]) {

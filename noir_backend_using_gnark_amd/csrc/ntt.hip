@@ -592,25 +592,13 @@ int zk_bn254_groth16_h_shard_dev(int phase, void* d_a, void* d_b, void* d_c, uin
     if (!d_a || (phase != 3 && (!d_b || !d_c))) return set_err(ZK_ERR_ARG, "null pointer");
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
-    // The kernels run on the library's own high-priority stream, ordered after / before the caller's stream by events: a foreign
-    // stream may share a hardware queue with the stream that prepares the wire scalars of the same proof (measured: torch's
-    // stream did, which serialised the two and cost ~0.5 ms per proof).
-    hipStream_t st = g.s->stream_hi;
-    hipEvent_t ev = nullptr;
-    if (stream) {
-        ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        ZK_HIP(hipEventRecord(ev, (hipStream_t)stream));
-        ZK_HIP(hipStreamWaitEvent(st, ev, 0));
-    }
-    int rc = compute_h_shard_phase(g.s, st, phase, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, log_D, log_g, rank);
-    if (stream) {  // in place, no workspace: the caller's stream simply continues after the phase, the host does not wait
-        if (rc == ZK_OK && (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess))
-            rc = set_err(ZK_ERR_HIP, "event bridge to the caller's stream failed");
-        (void)hipEventDestroy(ev);
-        return rc;
-    }
-    if (rc != ZK_OK) return rc;
-    return slot_sync(g.s, st);
+    // Give it the stream of the proof's msm5 session (zk_bn254_groth16_msm5_session_stream): a foreign stream may share a
+    // hardware queue with the stream that prepares the wire scalars of the same proof (measured with a torch-created stream:
+    // the two serialised, ~0.5 ms per proof).
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    ZK_TRY(compute_h_shard_phase(g.s, st, phase, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, log_D, log_g, rank));
+    if (!stream) ZK_TRY(slot_sync(g.s, st));  // in place, no workspace: a caller-provided stream stays asynchronous (profiled or not)
+    return ZK_OK;
 }
 
 int zk_bn254_fr_mul_dev(void* d_out, const void* d_a, const void* d_b, size_t n, void* stream) {

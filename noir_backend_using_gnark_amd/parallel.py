@@ -156,3 +156,23 @@ def groth16_msm5_pk(pk, d_w: int, d_h: int, stream: int = 0) -> np.ndarray:
     out = np.zeros(96, dtype=np.uint64)
     check(lib().zk_bn254_groth16_msm5_pk(pk.handle, C.c_void_p(d_w), C.c_void_p(d_h), vp(out), C.c_void_p(stream)))
     return out
+
+
+def groth16_msm5_pk_begin(pk, d_w: int) -> int:
+    """Starts the preparation of the wire scalars at once (call before compute_h_sharded); returns a session for groth16_msm5_pk_end."""
+    sess = C.c_uint64(0)
+    check(lib().zk_bn254_groth16_msm5_pk_begin(pk.handle, C.c_void_p(d_w), C.byref(sess)))
+    return sess.value
+
+
+def groth16_msm5_pk_end(session: int, d_h: int, stream: int = 0) -> np.ndarray:
+    out = np.zeros(96, dtype=np.uint64)
+    check(lib().zk_bn254_groth16_msm5_pk_end(C.c_uint64(session), C.c_void_p(d_h), vp(out), C.c_void_p(stream)))
+    return out
+
+
+def groth16_session_stream(session: int) -> int:
+    """HIP stream handle of the session (wrap it with torch.cuda.ExternalStream and run compute_h_sharded under it)."""
+    st = C.c_void_p(0)
+    check(lib().zk_bn254_groth16_msm5_session_stream(C.c_uint64(session), C.byref(st)))
+    return int(st.value or 0)

@@ -409,6 +409,8 @@ def test_sharded_compute_h_argument_errors():
     assert call(0, 6, 2, 4) != 0      # rank out of range
     assert call(7, 6, 1, 0) != 0      # unknown phase
     assert call(0, 3, 2, 0) != 0      # blocks smaller than the number of ranks
+    out = np.zeros(96, np.uint64)
+    assert _lib.lib().zk_bn254_groth16_msm5_pk_end(C.c_uint64(12345), C.c_void_p(d.ptr), _lib.vp(out), None) != 0  # unknown session
 
 
 @pytest.mark.parametrize("G,tables", [(2, True), (4, True), (4, False)])
@@ -441,7 +443,11 @@ def test_sharded_proof_with_rank_local_keys(G, tables):
                            precompute_tables=tables, shard_full_z=(rank != G - 1), **small)
         keys.append(pk)
         d_w, d_h = _lib.DeviceBuffer.from_numpy(w[lo:hi]), _lib.DeviceBuffer.from_numpy(H[rank])
-        recs.append(par.groth16_msm5_pk(pk, d_w.ptr, d_h.ptr))
+        if rank % 2 == 0:
+            recs.append(par.groth16_msm5_pk(pk, d_w.ptr, d_h.ptr))
+        else:  # the two-call form: preparation of w first, the rest once h exists
+            sess = par.groth16_msm5_pk_begin(pk, d_w.ptr)
+            recs.append(par.groth16_msm5_pk_end(sess, d_h.ptr))
     assert par.groth16_finalize(keys[0], np.stack(recs), r, s) == exp
     assert par.groth16_finalize(keys[-1], np.stack(recs), r, s) == exp
     for pk in keys:
