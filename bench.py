@@ -175,7 +175,7 @@ def main():
     elif name == "msm_accumulate_g2":
         units_per_launch, bytes_per_unit = N_loc, 160.0
     else:  # an NTT pass: 64 B per element per pass
-        units_per_launch, bytes_per_unit = N_g, 64.0
+        units_per_launch, bytes_per_unit = (N_loc if sharded else N_g), 64.0
     achieved = units_per_launch * bytes_per_unit / (per_launch_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
