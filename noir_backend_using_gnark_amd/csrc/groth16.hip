@@ -158,6 +158,8 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         P.tab_w.c = msm_pick_window_table(pk->n_wires);
         P.tab_w.stride = pk->n_wires;
         P.tab_h.c = msm_pick_window_table(P.nz);
+        if (getenv("ZKMI_TABLE_C_W")) P.tab_w.c = (unsigned)atoi(getenv("ZKMI_TABLE_C_W"));  // experiment switches
+        if (getenv("ZKMI_TABLE_C_H")) P.tab_h.c = (unsigned)atoi(getenv("ZKMI_TABLE_C_H"));
         P.tab_h.stride = N;
         const size_t Ww = (255 + P.tab_w.c - 1) / P.tab_w.c, Wh = (255 + P.tab_h.c - 1) / P.tab_h.c;
         const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;

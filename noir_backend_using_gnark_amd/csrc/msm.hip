@@ -467,24 +467,19 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     P->total = n * P->Wd;
     if (P->total >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "n * windows = %zu overflows 31-bit positions", P->total);
     if (tab && (size_t)tab->stride * P->Wd >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "table too large for 31-bit indices");
-    // tasks of at most L points: 2x the mean bucket load of a uniform input in the DENSEST window, at least 32.  The top
-    // window only sees digits up to (r-1) >> (c*(W-1)), so its buckets are denser than 2^(c-1) suggests.
+    // tasks of at most L points: 2x the mean bucket load of a uniform input, at least 32.  The top window only sees digits up to
+    // (r-1) >> (c*(W-1)), so its buckets (window-per-bucket-set mode) / the lowest buckets (table mode: one bucket set) are denser
+    // than that: they are simply cut into several tasks and folded by k_fold_multi.  Only when the dense population is mild (<= 4x)
+    // is L raised to keep it whole -- one task per bucket is cheaper than a fold.
     size_t mean = P->total / P->nb + 1;
-    if (tab) {
-        // all windows feed one bucket set, and the top window only reaches digits below (r-1) >> (c*(Wd-1)): those low buckets
-        // carry an extra n / top_max points each
-        const uint64_t r_top64 = 0x30644e72e131a029ULL;
-        unsigned shift = c * (P->Wd - 1);
-        uint64_t top_max = shift >= 192 ? (r_top64 >> (shift - 192)) : ~0ULL;
-        if (top_max < P->B && top_max > 0) mean += n / (size_t)top_max + 1;
-    } else {
+    {
         // r - 1 = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000000; its top 64 bits:
         const uint64_t r_top64 = 0x30644e72e131a029ULL;
-        unsigned shift = c * (P->W - 1);                        // bits below the top window
+        unsigned shift = c * (P->Wd - 1);  // bits below the top window
         uint64_t top_max = shift >= 192 ? (r_top64 >> (shift - 192)) : ~0ULL;
         if (top_max < P->B && top_max > 0) {
-            size_t mt = n / (size_t)top_max + 1;
-            if (mt > mean) mean = mt;
+            size_t dense = n / (size_t)top_max + 1 + (tab ? mean : 0);  // table mode: the top window's points come on top of the others
+            if (dense > mean && dense <= 4 * mean + 8) mean = dense;
         }
     }
     P->L = (uint32_t)(mean * 2 < 32 ? 32 : mean * 2);
