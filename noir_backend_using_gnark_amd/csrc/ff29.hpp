@@ -468,4 +468,131 @@ __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2
     A.y = Y3;
 }
 
+// ------------------------------------------------------------------------------------------------------------ Fr (NTT)
+// The same 9 x 29-bit representation over the scalar field, for the NTT butterflies (ntt.hip).  Data stay congruent to gnark's
+// Montgomery-2^256 image (unpacked WITHOUT a shift); twiddles are kept as w * 2^261 mod r in a second table, so that
+// mont29(X, W') = X * W' / 2^261 is the exact field product in the 2^256 domain and a pass ends with a partial reduction and a
+// repacking instead of a multiplication.  tools/u29_ntt_model.py proves the bounds of the stage-group schedules of ntt.hip (no
+// 64-bit column / 32-bit limb overflow, every bias dominates its subtrahend) and checks whole transforms against the oracle.
+struct Fr29 {
+    static constexpr uint32_t MASK = 0x1fffffffu;
+    static constexpr uint32_t P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t NINV = 0x0fffffffu;  // -r^-1 mod 2^29
+    static constexpr uint32_t RC[9] = {0x0fffffffu, 0x00f05360u, 0x11a3dbafu, 0x182f6f0cu, 0x0a7a2d7cu, 0x1d24bf3fu, 0x1f591ebeu, 0x11a3d9cbu, 0x1fcf9bb1u};  // 2^261 - r
+    static constexpr uint32_t QM = 0xa948e6d7u;    // floor(2^53 / ((r >> 232) + 1))
+    static constexpr uint32_t BIAS4[9] = {0x40000004u, 0x5c3eb27cu, 0x59709141u, 0x5f4243cbu, 0x56174a0au, 0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u};
+    static constexpr uint32_t BIAS16[9] = {0x40000010u, 0x50fac9f6u, 0x45c2450du, 0x5d090f35u, 0x585d2831u, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
+    static constexpr uint32_t BIAS24[9] = {0x40000018u, 0x49782ef2u, 0x58a36795u, 0x5b8d96d0u, 0x448bbc4bu, 0x448e120eu, 0x4fa51e18u, 0x58a394deu, 0x04896758u};
+    static constexpr uint32_t BIAS40[9] = {0x40000028u, 0x5a72f8eau, 0x5e65aca4u, 0x5896a607u, 0x5ce8e47fu, 0x52421e18u, 0x5a133229u, 0x5e65f81eu, 0x078fac3fu};
+    template <int K>
+    static constexpr uint32_t bias(int i) {
+        static_assert(K == 4 || K == 16 || K == 24 || K == 40, "no bias table for this multiple of r");
+        return K == 4 ? BIAS4[i] : K == 16 ? BIAS16[i] : K == 24 ? BIAS24[i] : BIAS40[i];
+    }
+};
+
+// a * b / 2^261 mod r (lazily reduced: < a*b/2^261 + r), limbs 0..7 < 2^29
+__device__ __forceinline__ U29 u29r_mul(const U29& a, const U29& b) {
+    U29 r;
+    asm(ZKMI_MONT_MUL29_ASM
+        : [r0] "=&v"(r.l[0]), [r1] "=&v"(r.l[1]), [r2] "=&v"(r.l[2]), [r3] "=&v"(r.l[3]), [r4] "=&v"(r.l[4]), [r5] "=&v"(r.l[5]),
+          [r6] "=&v"(r.l[6]), [r7] "=&v"(r.l[7]), [r8] "=&v"(r.l[8])
+        : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]), [a5] "v"(a.l[5]), [a6] "v"(a.l[6]),
+          [a7] "v"(a.l[7]), [a8] "v"(a.l[8]), [b0] "v"(b.l[0]), [b1] "v"(b.l[1]), [b2] "v"(b.l[2]), [b3] "v"(b.l[3]), [b4] "v"(b.l[4]),
+          [b5] "v"(b.l[5]), [b6] "v"(b.l[6]), [b7] "v"(b.l[7]), [b8] "v"(b.l[8]), [p0] "s"(Fr29::P[0]), [p1] "s"(Fr29::P[1]),
+          [p2] "s"(Fr29::P[2]), [p3] "s"(Fr29::P[3]), [p4] "s"(Fr29::P[4]), [p5] "s"(Fr29::P[5]), [p6] "s"(Fr29::P[6]), [p7] "s"(Fr29::P[7]),
+          [p8] "s"(Fr29::P[8]), [ninv] "s"(Fr29::NINV)
+        : "v0", "v1", "vcc");
+    return r;
+}
+
+// a - b + K*r  (b weakly normalised and < K*r with the model's margin)
+template <int K>
+__device__ __forceinline__ U29 u29r_sub(const U29& a, const U29& b) {
+    U29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] - b.l[i] + Fr29::bias<K>(i);
+    return r;
+}
+
+// x -= q r with q estimated from the top limb (never too large): result < 2.01 r, limbs 0..7 < 2^29.  x weakly normalised.
+__device__ __forceinline__ U29 u29r_reduce(const U29& x) {
+    const uint32_t q = __umulhi(x.l[8], Fr29::QM) >> 21;
+    U29 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t acc = (uint64_t)q * Fr29::RC[i] + (uint64_t)(x.l[i] + c);  // x + q (2^261 - r); the q 2^261 leaves through the top limb
+        r.l[i] = (uint32_t)acc & Fr29::MASK;
+        c = (uint32_t)(acc >> 29);
+    }
+    uint64_t acc = (uint64_t)q * Fr29::RC[8] + (uint64_t)(x.l[8] + c);
+    r.l[8] = (uint32_t)(acc - ((uint64_t)q << 29));
+    return r;
+}
+
+// 8 x u32 image (canonical, or a lazily reduced intermediate < 2^256) -> limbs, no shift
+template <class E>
+__device__ __forceinline__ U29 u29_unpack(const E& v) {
+    U29 r;
+    const uint32_t* w = v.l;
+    r.l[0] = w[0] & 0x1fffffffu;
+    r.l[1] = __funnelshift_r(w[0], w[1], 29) & 0x1fffffffu;
+    r.l[2] = __funnelshift_r(w[1], w[2], 26) & 0x1fffffffu;
+    r.l[3] = __funnelshift_r(w[2], w[3], 23) & 0x1fffffffu;
+    r.l[4] = __funnelshift_r(w[3], w[4], 20) & 0x1fffffffu;
+    r.l[5] = __funnelshift_r(w[4], w[5], 17) & 0x1fffffffu;
+    r.l[6] = __funnelshift_r(w[5], w[6], 14) & 0x1fffffffu;
+    r.l[7] = __funnelshift_r(w[6], w[7], 11) & 0x1fffffffu;
+    r.l[8] = w[7] >> 8;
+    return r;
+}
+
+// canonical image V -> V << 5 (the multiplier form of a scaling-table entry kept in the 2^256 domain: V << 5 == t * 2^261)
+__device__ __forceinline__ U29 u29r_load5(const Fr& v) {
+    U29 r;
+    const uint32_t* w = v.l;
+    r.l[0] = (w[0] << 5) & 0x1fffffffu;
+    r.l[1] = __funnelshift_r(w[0], w[1], 24) & 0x1fffffffu;
+    r.l[2] = __funnelshift_r(w[1], w[2], 21) & 0x1fffffffu;
+    r.l[3] = __funnelshift_r(w[2], w[3], 18) & 0x1fffffffu;
+    r.l[4] = __funnelshift_r(w[3], w[4], 15) & 0x1fffffffu;
+    r.l[5] = __funnelshift_r(w[4], w[5], 12) & 0x1fffffffu;
+    r.l[6] = __funnelshift_r(w[5], w[6], 9) & 0x1fffffffu;
+    r.l[7] = __funnelshift_r(w[6], w[7], 6) & 0x1fffffffu;
+    r.l[8] = w[7] >> 3;
+    return r;
+}
+
+// x as left by u29r_reduce (< 2.01 r, limbs 0..7 < 2^29) -> 8 x u32; canonical: two conditional subtractions of r
+__device__ __forceinline__ Fr u29r_pack(const U29& t, bool canonical) {
+    Fr r;
+    r.l[0] = t.l[0] | (t.l[1] << 29);
+    r.l[1] = (t.l[1] >> 3) | (t.l[2] << 26);
+    r.l[2] = (t.l[2] >> 6) | (t.l[3] << 23);
+    r.l[3] = (t.l[3] >> 9) | (t.l[4] << 20);
+    r.l[4] = (t.l[4] >> 12) | (t.l[5] << 17);
+    r.l[5] = (t.l[5] >> 15) | (t.l[6] << 14);
+    r.l[6] = (t.l[6] >> 18) | (t.l[7] << 11);
+    r.l[7] = (t.l[7] >> 21) | (t.l[8] << 8);
+    if (canonical) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            uint32_t s[8];
+            uint64_t bw = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint64_t d = (uint64_t)r.l[i] - FrParams::MOD[i] - bw;
+                s[i] = (uint32_t)d;
+                bw = d >> 63;
+            }
+            if (!bw) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) r.l[i] = s[i];
+            }
+        }
+    }
+    return r;
+}
+
 }  // namespace zkmi

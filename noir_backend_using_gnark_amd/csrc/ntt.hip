@@ -20,11 +20,12 @@
 #include "ff.hpp"
 #include "host_ff.hpp"
 #include "ntt.hpp"
+#include "ff29.hpp"
 
 namespace zkmi {
 
 static constexpr unsigned TILE_LOG = 11;        // 2048 elements = 64 KiB of LDS per workgroup
-static constexpr unsigned K_STRIDED = 8;        // strided passes: k <= 8 with L = 8 (256-byte runs)
+static const unsigned K_STRIDED = getenv("ZKMI_NTT_KS") ? (unsigned)atoi(getenv("ZKMI_NTT_KS")) : 9;  // strided passes: k <= 9, rows of L >= 4 elements (128-byte runs); 2^20 = 11 + 9 bits = two passes
 static constexpr unsigned NTT_THREADS = 256;
 
 struct PowBasis {
@@ -52,6 +53,7 @@ struct PassArgs {
     Fr post_const;       // if has_post_const: multiply by this constant on exit
     unsigned logn, bit_lo, k, logL;
     int dif, has_post_const;
+    int canonical;       // 29-bit-limb passes: last pass of the transform -> canonical image; else a lazily reduced 256-bit intermediate
 };
 
 __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, unsigned t) {
@@ -181,6 +183,137 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 29-bit-limb passes
+// Same pass structure with the butterflies in the unsaturated representation of ff29.hpp (Fr29): 1.4x fewer instructions per
+// product, additions without carries.  Elements sit in LDS as 9 limbs (two 16-byte halves + the top limb) between the stage
+// groups of a pass and as 8 packed words at its ends; A.tw is the w * 2^261 table.  Schedules and bounds: tools/u29_ntt_model.py.
+__device__ __forceinline__ U29 lds_load9(const uint4* lo, const uint4* hi, const uint32_t* top, unsigned t) {
+    uint4 a = lo[t], b = hi[t];
+    U29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = top[t];
+    return r;
+}
+__device__ __forceinline__ void lds_store9(uint4* lo, uint4* hi, uint32_t* top, unsigned t, const U29& v) {
+    lo[t] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    hi[t] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    top[t] = v.l[8];
+}
+
+template <int G, bool DIF, unsigned THREADS>
+__device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, unsigned s0, bool first,
+                                            bool last) {
+    constexpr unsigned NE = 1u << G;
+    const unsigned L = 1u << A.logL;
+    const unsigned ql = DIF ? (A.k - s0 - G) : s0;
+    for (unsigned u = threadIdx.x; u < (E >> G); u += THREADS) {
+        const unsigned l = u & (L - 1), r = u >> A.logL;
+        const unsigned mid0 = ((r >> ql) << (ql + G)) | (r & ((1u << ql) - 1));
+        U29 x[NE];
+#pragma unroll
+        for (unsigned e = 0; e < NE; e++) {
+            const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
+            if (first) {
+                x[e] = u29_unpack(lds_load(lo, hi, t));
+                if (A.pre) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
+            } else {
+                x[e] = lds_load9(lo, hi, top, t);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < G; sl++) {
+            const unsigned bitl = DIF ? (unsigned)(G - 1 - sl) : (unsigned)sl;
+            const unsigned b = A.bit_lo + ql + bitl;
+#pragma unroll
+            for (unsigned e0 = 0; e0 < NE; e0++) {
+                if (e0 & (1u << bitl)) continue;
+                const unsigned e1 = e0 | (1u << bitl);
+                const size_t g0 = base + ((size_t)(mid0 | (e0 << ql)) << A.bit_lo) + l;
+                const size_t j = g0 & (((size_t)1 << b) - 1);
+                const U29 w = u29_unpack(gload_fr(A.tw + (j << (A.logn - 1 - b))));  // b == 0: entry 0 = 2^261 mod r, the unit
+                if (DIF) {
+                    U29 d;
+                    if (sl == 0) d = u29r_sub<16>(x[e0], x[e1]);
+                    else if (sl == 1) d = u29r_sub<24>(x[e0], x[e1]);
+                    else d = u29r_sub<40>(x[e0], x[e1]);
+                    x[e0] = u29_wnorm(u29_add(x[e0], x[e1]));
+                    x[e1] = u29r_mul(d, w);
+                } else {
+                    U29 t = u29r_mul(x[e1], w);
+                    x[e1] = u29_wnorm(u29r_sub<4>(x[e0], t));
+                    x[e0] = u29_add(x[e0], t);
+                }
+            }
+        }
+        if (DIF) {
+            x[0] = u29r_reduce(x[0]);  // the all-sums output is the only one that grows (8x per group)
+        } else {
+#pragma unroll
+            for (unsigned e = 0; e < NE; e++) x[e] = u29_wnorm(x[e]);
+        }
+#pragma unroll
+        for (unsigned e = 0; e < NE; e++) {
+            const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
+            if (last) {
+                if (A.post) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.post + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
+                else if (A.has_post_const) x[e] = u29r_mul(x[e], u29r_load5(A.post_const));
+                lds_store(lo, hi, t, u29r_pack(u29r_reduce(x[e]), A.canonical != 0));
+            } else {
+                lds_store9(lo, hi, top, t, x[e]);
+            }
+        }
+    }
+}
+
+template <int GMAX, unsigned THREADS>
+__global__ __launch_bounds__(THREADS) void k_ntt_pass29(PassArgs A) {
+    extern __shared__ uint4 lds[];
+    const unsigned E = 1u << (A.k + A.logL);
+    uint4* lo = lds;
+    uint4* hi = lds + E;
+    uint32_t* top = reinterpret_cast<uint32_t*>(lds + 2 * E);
+    const unsigned L = 1u << A.logL;
+    const unsigned lo_blks = (1u << A.bit_lo) >> A.logL;  // >= 1
+    const size_t tile = blockIdx.x;
+    const size_t hi_idx = tile / lo_blks;
+    const unsigned lo_blk = (unsigned)(tile % lo_blks);
+    const size_t base = (hi_idx << (A.bit_lo + A.k)) + ((size_t)lo_blk << A.logL);
+    uint4* g = reinterpret_cast<uint4*>(A.data);
+
+    for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
+        unsigned e = h >> 1, half = h & 1;
+        unsigned mid = e >> A.logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        uint4 v = g[gi * 2 + half];
+        (half ? hi : lo)[e] = v;
+    }
+    __syncthreads();
+
+    for (unsigned s0 = 0; s0 < A.k;) {
+        const unsigned G = (A.k - s0 >= (unsigned)GMAX) ? (unsigned)GMAX : (A.k - s0);
+        const bool first = (s0 == 0), last = (s0 + G == A.k);
+        if (A.dif) {
+            if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), true, THREADS>(A, lo, hi, top, base, E, s0, first, last);
+            else if (G == 2) ntt_group29<2, true, THREADS>(A, lo, hi, top, base, E, s0, first, last);
+            else ntt_group29<1, true, THREADS>(A, lo, hi, top, base, E, s0, first, last);
+        } else {
+            if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), false, THREADS>(A, lo, hi, top, base, E, s0, first, last);
+            else if (G == 2) ntt_group29<2, false, THREADS>(A, lo, hi, top, base, E, s0, first, last);
+            else ntt_group29<1, false, THREADS>(A, lo, hi, top, base, E, s0, first, last);
+        }
+        s0 += G;
+        __syncthreads();
+    }
+
+    for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
+        unsigned e = h >> 1, half = h & 1;
+        unsigned mid = e >> A.logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        g[gi * 2 + half] = (half ? hi : lo)[e];
+    }
+}
+
 // a[i] *= t[i]  (used when a transform has no stage to fold a scaling into: N == 1)
 __global__ void k_scale_table(Fr* a, const Fr* t, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,6 +391,10 @@ int get_domain(Slot* s, hipStream_t st, unsigned logn, unsigned need, Domain** o
     bool made = false;
     if ((need & DOM_TW) && !d->tw) { ZK_TRY(make_pow_table(s, st, &d->tw, H, logn, d->gen, HFr::one(), 0)); made = true; }
     if ((need & DOM_TW_INV) && !d->tw_inv) { ZK_TRY(make_pow_table(s, st, &d->tw_inv, H, logn, d->gen_inv, HFr::one(), 0)); made = true; }
+    // the same powers times 2^5: w * 2^261 mod r, the multiplier form of the 29-bit-limb passes
+    const HFr two5 = HFr{{32, 0, 0, 0}}.to_mont();
+    if ((need & DOM_TW) && !d->tw29) { ZK_TRY(make_pow_table(s, st, &d->tw29, H, logn, d->gen, two5, 0)); made = true; }
+    if ((need & DOM_TW_INV) && !d->tw29_inv) { ZK_TRY(make_pow_table(s, st, &d->tw29_inv, H, logn, d->gen_inv, two5, 0)); made = true; }
     if ((need & DOM_COSET) && !d->coset_tab) { ZK_TRY(make_pow_table(s, st, &d->coset_tab, N, logn, d->coset, HFr::one(), 0)); made = true; }
     if ((need & DOM_COSET_REV) && !d->coset_rev) { ZK_TRY(make_pow_table(s, st, &d->coset_rev, N, logn, d->coset, HFr::one(), 1)); made = true; }
     if ((need & DOM_COSET_INV_N) && !d->coset_inv_n) { ZK_TRY(make_pow_table(s, st, &d->coset_inv_n, N, logn, d->coset_inv, d->card_inv, 0)); made = true; }
@@ -269,8 +406,17 @@ int get_domain(Slot* s, hipStream_t st, unsigned logn, unsigned need, Domain** o
 }
 
 // Runs the log2(N) stages of one transform as a sequence of tile passes.
-static int run_passes(Slot* s, hipStream_t st, Fr* data, unsigned logn, const Fr* tw, int dif, const Fr* pre, const Fr* post,
+// radix-4 stage groups with 512 lanes per tile (4 waves per SIMD) instead of radix-8 with 256 (2 waves per SIMD): measured 8 % faster --
+// the waves of a pass spend ~40 % of their time parked on twiddle / tile loads and barriers, which more resident waves hide.
+// ZKMI_NTT_G2=0 selects the radix-8 variant (A/B switch).
+static const bool g_ntt_g2 = !(getenv("ZKMI_NTT_G2") && atoi(getenv("ZKMI_NTT_G2")) == 0);
+static const bool g_ntt_saturated = getenv("ZKMI_NTT_SAT") && atoi(getenv("ZKMI_NTT_SAT")) == 1;  // A/B switch: the 8 x 32-bit butterflies
+
+static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int inverse, int dif, const Fr* pre, const Fr* post,
                       const Fr* post_const) {
+    const unsigned logn = dom->logn;
+    const bool sat = g_ntt_saturated;
+    const Fr* tw = sat ? (inverse ? dom->tw_inv : dom->tw) : (inverse ? dom->tw29_inv : dom->tw29);
     if (logn == 0) {
         if (pre) ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3(1), dim3(64), 0, data, pre, (size_t)1);
         if (post) ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3(1), dim3(64), 0, data, post, (size_t)1);
@@ -303,9 +449,11 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, unsigned logn, const Fr
         if (A.has_post_const) A.post_const = *post_const; else A.post_const = Fr::zero();
         unsigned E = 1u << (p.k + p.logL);
         size_t tiles = ((size_t)1 << logn) / E;
-        size_t shmem = (size_t)E * 32;
+        A.canonical = (idx + 1 == npass) ? 1 : 0;
         const char* name = p.logL ? "ntt_pass_strided" : "ntt_pass_contig";
-        ZK_LAUNCH(s, st, name, k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), shmem, A);
+        if (sat) ZK_LAUNCH(s, st, name, k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 32, A);
+        else if (g_ntt_g2) ZK_LAUNCH(s, st, name, (k_ntt_pass29<2, 512>), dim3((unsigned)tiles), dim3(512), (size_t)E * 36, A);
+        else ZK_LAUNCH(s, st, name, (k_ntt_pass29<3, 256>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 36, A);
     }
     return ZK_OK;
 }
@@ -314,6 +462,8 @@ static bool g_lds_attr_set = false;
 static int ensure_lds_attr() {
     if (!g_lds_attr_set) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 32));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         g_lds_attr_set = true;
     }
     return ZK_OK;
@@ -333,12 +483,12 @@ int ntt_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn, int inverse, int de
     if (!inverse) {
         // FFT: coset scaling first -- DIF by CosetTable[i], DIT (bit-reversed memory order) by CosetTableReversed[i]
         const Fr* pre = coset ? (dif ? d->coset_tab : d->coset_rev) : nullptr;
-        return run_passes(s, st, d_a, logn, d->tw, dif, pre, nullptr, nullptr);
+        return run_passes(s, st, d_a, d, 0, dif, pre, nullptr, nullptr);
     }
     // FFTInverse: TwiddlesInv, then * CardinalityInv (and CosetTableInv[i] for DIT / CosetTableInvReversed[i] for DIF)
     const Fr* post = coset ? (dif ? d->coset_inv_n_rev : d->coset_inv_n) : nullptr;
     Fr cinv = to_dev(d->card_inv);
-    return run_passes(s, st, d_a, logn, d->tw_inv, dif, nullptr, post, &cinv);
+    return run_passes(s, st, d_a, d, 1, dif, nullptr, post, &cinv);
 }
 
 int bit_reverse_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn) {
@@ -357,15 +507,15 @@ int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned log
     ZK_TRY(get_domain(s, st, logN, DOM_TW | DOM_TW_INV | DOM_COSET_REV_N | DOM_COSET_INV_N_REV, &d));
     size_t N = (size_t)1 << logN;
     for (Fr* v : {a, b, c}) {
-        ZK_TRY(run_passes(s, st, v, logN, d->tw_inv, 1, nullptr, d->coset_rev_n, nullptr));
-        ZK_TRY(run_passes(s, st, v, logN, d->tw, 0, nullptr, nullptr, nullptr));
+        ZK_TRY(run_passes(s, st, v, d, 1, 1, nullptr, d->coset_rev_n, nullptr));
+        ZK_TRY(run_passes(s, st, v, d, 0, 0, nullptr, nullptr, nullptr));
     }
     // den = 1 / (g^N - 1)
     HFr gN = d->coset;
     for (unsigned i = 0; i < logN; i++) gN = gN.sqr();
     HFr den = (gN - HFr::one()).inv();
     ZK_LAUNCH(s, st, "h_pointwise", k_h_pointwise, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)b, (const Fr*)c, to_dev(den), N);
-    ZK_TRY(run_passes(s, st, a, logN, d->tw_inv, 1, nullptr, d->coset_inv_n_rev, nullptr));
+    ZK_TRY(run_passes(s, st, a, d, 1, 1, nullptr, d->coset_inv_n_rev, nullptr));
     return ZK_OK;
 }
 
@@ -468,8 +618,8 @@ int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* 
             return ZK_OK;
         case 1:  // blocks: rest of FFTInverse(DIF), * 1/D * g^bitrev(i), block part of FFT(DIT, coset)
             for (Fr* v : {a, b, c}) {
-                ZK_TRY(run_passes(s, st, v, logM, dM->tw_inv, 1, nullptr, tb.coset_rev_n, nullptr));
-                ZK_TRY(run_passes(s, st, v, logM, dM->tw, 0, nullptr, nullptr, nullptr));
+                ZK_TRY(run_passes(s, st, v, dM, 1, 1, nullptr, tb.coset_rev_n, nullptr));
+                ZK_TRY(run_passes(s, st, v, dM, 0, 0, nullptr, nullptr, nullptr));
             }
             return ZK_OK;
         case 2: {  // transposed: cross stages of FFT(DIT); pointwise; cross stages of the final FFTInverse(DIF, coset)
@@ -481,7 +631,7 @@ int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* 
             return launch_cross<true>(s, st, a, dD->tw_inv, logM, logg, rank);
         }
         case 3:  // block of a: rest of FFTInverse(DIF, coset) -> this rank's block of h (gnark's bit-reversed order)
-            return run_passes(s, st, a, logM, dM->tw_inv, 1, nullptr, tb.coset_inv_n_rev, nullptr);
+            return run_passes(s, st, a, dM, 1, 1, nullptr, tb.coset_inv_n_rev, nullptr);
         default: return set_err(ZK_ERR_ARG, "phase must be 0..3");
     }
 }

