@@ -13,6 +13,7 @@
 // compression) runs on the host like upstream.
 #include <stdlib.h>
 #include <chrono>
+#include <functional>
 #include <memory>
 #include <vector>
 #include <string.h>
@@ -320,15 +321,18 @@ static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm
     ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
     return ZK_OK;
 }
-static int msm5_finish(Msm5State* S, uint64_t out[96]) {
+// `early` (optional) is called as soon as the A and B1 sums are on the host -- long before K and Z finish -- so that the part of
+// the host tail that only needs them runs under the remaining GPU work.
+static int msm5_finish(Msm5State* S, uint64_t out[96], const std::function<void(const XYZZ<HFp>&, const XYZZ<HFp>&)>* early = nullptr) {
     XYZZ<HFp> m_a, m_b, m_k, m_z;
     XYZZ<HFp2> m_b2;
-    // in expected completion order, so that each host Horner overlaps the GPU work still in flight
+    // in completion order (the accumulate chain is G2.B -> A -> B1 -> K -> Z), so that host work overlaps the GPU work still in flight
     int rc = msm_g2_finish(S->jobs[4], &m_b2);
-    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[0], &m_z);
     if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[1], &m_a);
     if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[2], &m_b);
+    if (rc == ZK_OK && early) (*early)(m_a, m_b);
     if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[3], &m_k);
+    if (rc == ZK_OK) rc = msm_g1_finish(S->jobs[0], &m_z);
     msm_prep_release(&S->prep_w);
     msm_prep_release(&S->prep_h);
     for (int i = 0; i < 5; i++)
@@ -378,8 +382,20 @@ struct TailPre {
     uint32_t rk[8], sk[8];
     XYZZ<HFp> r_delta, s_delta, rs_delta;
     XYZZ<HFp2> s_delta2;
+    bool have_early = false;  // s*(A + alpha) and r*(B1 + beta) already computed (single-GPU prove: under the K / Z accumulates)
+    XYZZ<HFp> s_aalpha, r_bbeta;
 };
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void tail_early(const Groth16PK& P, TailPre* T, const XYZZ<HFp>& m_a, const XYZZ<HFp>& m_b) {
+    const double t0 = now_ms();
+    XYZZ<HFp> a_alpha = m_a, b_beta = m_b;
+    a_alpha.madd(P.alpha);
+    b_beta.madd(P.beta);
+    T->s_aalpha = scalar_mul(a_alpha.to_affine(), T->sk);
+    T->r_bbeta = scalar_mul(b_beta.to_affine(), T->rk);
+    T->have_early = true;
+    prof_host("host_tail_early", now_ms() - t0);
+}
 static void tail_pre(const Groth16PK& P, const zk_fr* r_, const zk_fr* s_, TailPre* T) {
     const double t0 = now_ms();
     HFr r, s;
@@ -420,8 +436,13 @@ static void tail_post(const Groth16PK& P, const TailPre& T, const uint64_t* part
     bs.add(T.s_delta2);
     XYZZ<HFp> krs = m_k;
     krs.add(m_z);
-    krs.add(scalar_mul(a_alpha.to_affine(), T.sk));
-    krs.add(scalar_mul(b_beta.to_affine(), T.rk));
+    if (T.have_early && n_parts == 1) {
+        krs.add(T.s_aalpha);
+        krs.add(T.r_bbeta);
+    } else {
+        krs.add(scalar_mul(a_alpha.to_affine(), T.sk));
+        krs.add(scalar_mul(b_beta.to_affine(), T.rk));
+    }
     krs.add(T.rs_delta);
     g1_compress(ar.to_affine(), proof_out);
     g2_compress(bs.to_affine(), proof_out + 32);
@@ -594,7 +615,8 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     uint64_t parts[96];
     TailPre T;
     if (rc == ZK_OK) tail_pre(P, r_, s_, &T);  // host work hidden under the GPU's
-    if (rc == ZK_OK) rc = msm5_finish(&S, parts);
+    const std::function<void(const XYZZ<HFp>&, const XYZZ<HFp>&)> early = [&](const XYZZ<HFp>& ma, const XYZZ<HFp>& mb) { tail_early(P, &T, ma, mb); };
+    if (rc == ZK_OK) rc = msm5_finish(&S, parts, &early);
     else {
         for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(g.s[i]->stream); (void)hipStreamSynchronize(g.s[i]->stream_hi); }
         msm_prep_release(&S.prep_w);
