@@ -171,7 +171,8 @@ def main():
     name, (launches, tot_ms) = max(hot.items(), key=lambda kv: kv[1][1])
     per_launch_ms = tot_ms / launches
     if name == "msm_accumulate_g1":
-        units_per_launch, bytes_per_unit = g1_units / 4.0 / world, 96.0
+        # the G1 MSMs of a proof come in launches / steps accumulate launches (A, B1, K share one: same sorted digits)
+        units_per_launch, bytes_per_unit = g1_units / world / (launches / float(args.steps)), 96.0
     elif name == "msm_accumulate_g2":
         units_per_launch, bytes_per_unit = N_loc, 160.0
     else:  # an NTT pass: 64 B per element per pass

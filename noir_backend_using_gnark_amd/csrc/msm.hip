@@ -235,11 +235,20 @@ __global__ __launch_bounds__(256) void k_task_scatter(const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------- 5. accumulate
+// Up to three MSMs over the SAME prepared scalars (Groth16: A, B1, K all pair with the wire values) go into one launch --
+// blockIdx.y selects the base array / output -- so that the machine stays full across their seams.
+struct AccBatch {
+    const void* pts[3];
+    void* partial[3];
+    uint32_t skip_below[3];
+};
 template <class F>
-__global__ __launch_bounds__(256) void k_accumulate(const Affine<F>* __restrict__ pts, const uint32_t* __restrict__ vals,
-                                                    const uint32_t* __restrict__ task_begin, const uint32_t* __restrict__ len_key_sorted,
-                                                    const uint32_t* __restrict__ task_sorted, uint32_t L, uint32_t max_tasks,
-                                                    uint32_t skip_below, XYZZ<F>* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
+                                                    const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
+                                                    uint32_t max_tasks) {
+    const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
+    XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
+    const uint32_t skip_below = batch.skip_below[blockIdx.y];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= max_tasks) return;
     uint32_t key = len_key_sorted[i];
@@ -588,61 +597,92 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     return ZK_OK;
 }
 
-// Base-side half: bucket accumulation, bucket reduction, window sums to pinned memory -- on stream `st`, which waits for
-// the preparation when it ran elsewhere.  `d_pts` is indexed by the scalar index; indices < skip_below are skipped.
+// Base-side half: bucket accumulation, bucket reduction, window sums to pinned memory.  `nb` jobs (<= 3) over the same prepared
+// scalars share ONE accumulate launch on the first job's stream (which waits for the preparation when it ran elsewhere); each
+// job's reduction tail then runs on its own stream.  `d_pts[b]` is indexed by the scalar index; indices < skip_below[b] are skipped.
 template <class F>
-static int msm_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const Affine<F>* d_pts, uint32_t skip_below, MsmJob* job) {
-    // job->gate_acc (in, optional): the accumulate kernel waits for it; job->want_done (in): record job->acc_done after it.
+static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts, const MsmPrep& R, const void* const* d_pts, const uint32_t* skip_below,
+                                MsmJob* const* jobs) {
+    // jobs[0]->gate_acc (in, optional): the accumulate kernel waits for it; any ->want_done (in): record an event after it
+    // (returned in the LAST job's acc_done, which owns it).
     typedef XYZZ<F> Pt;
     const MsmPlan& P = R.P;
-    job->s = s;
-    job->st = st;
-    job->c = P.c;
-    job->W = P.W;
-    job->empty = R.empty;
+    for (int b = 0; b < nb; b++) {
+        jobs[b]->s = sl[b];
+        jobs[b]->st = sts[b];
+        jobs[b]->c = P.c;
+        jobs[b]->W = P.W;
+        jobs[b]->empty = R.empty;
+    }
     if (R.empty) return ZK_OK;
     const unsigned W = P.W;
     const uint32_t B = P.B, L = P.L, m1 = P.m1, N1 = P.N1;
     const size_t max_tasks = P.max_tasks, lvl_elems = P.lvl_elems;
-    Pt* partial = (Pt*)s->alloc(max_tasks * sizeof(Pt));
-    Pt* lvlA[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
-    Pt* lvlS[2] = {(Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt)), (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt))};
-    if (!partial || !lvlA[0] || !lvlA[1] || !lvlS[0] || !lvlS[1])
-        return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
-    // The throughput-bound accumulate kernel runs on `job->chain` when given (the caller serialises the accumulate kernels of
+    Pt *partial[3], *lvlA[3][2], *lvlS[3][2];
+    AccBatch batch = {};
+    for (int b = 0; b < nb; b++) {
+        Slot* s = sl[b];
+        partial[b] = (Pt*)s->alloc(max_tasks * sizeof(Pt));
+        for (int k = 0; k < 2; k++) {
+            lvlA[b][k] = (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt));
+            lvlS[b][k] = (Pt*)s->alloc((lvl_elems + 64) * sizeof(Pt));
+        }
+        if (!partial[b] || !lvlA[b][0] || !lvlA[b][1] || !lvlS[b][0] || !lvlS[b][1])
+            return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
+        batch.pts[b] = d_pts[b];
+        batch.partial[b] = partial[b];
+        batch.skip_below[b] = skip_below[b];
+    }
+    // The throughput-bound accumulate kernel runs on `jobs[0]->chain` when given (the caller serialises the accumulate kernels of
     // several MSMs back to back on one stream, no event round trips between them); everything after it -- the latency-bound
-    // reduction tail -- runs on this job's own stream `st`, gated on an event.
-    hipStream_t sa = job->chain ? job->chain : st;
+    // reduction tail -- runs on each job's own stream, gated on an event.
+    MsmJob* j0 = jobs[0];
+    hipStream_t sa = j0->chain ? j0->chain : sts[0];
     if (R.ready) ZK_HIP(hipStreamWaitEvent(sa, R.ready, 0));
-    if (job->gate_acc) ZK_HIP(hipStreamWaitEvent(sa, job->gate_acc, 0));
+    if (j0->gate_acc) ZK_HIP(hipStreamWaitEvent(sa, j0->gate_acc, 0));
     // ---- 5. accumulate
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
-    ZK_LAUNCH(s, sa, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, d_pts, R.vals, R.task_begin, R.lkeys, R.tids,
-              L, (uint32_t)max_tasks, skip_below, partial);
-    if (job->chain || job->want_done) {
-        ZK_HIP(hipEventCreateWithFlags(&job->acc_done, hipEventDisableTiming));
-        ZK_HIP(hipEventRecord(job->acc_done, sa));
-        if (job->chain) ZK_HIP(hipStreamWaitEvent(st, job->acc_done, 0));
+    ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256), (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
+              R.lkeys, R.tids, L, (uint32_t)max_tasks);
+    bool want = j0->chain != nullptr || nb > 1;
+    for (int b = 0; b < nb; b++) want = want || jobs[b]->want_done;
+    if (want) {
+        hipEvent_t done;
+        ZK_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(done, sa));
+        jobs[nb - 1]->acc_done = done;
+        for (int b = 0; b < nb; b++)
+            if (sts[b] != sa) ZK_HIP(hipStreamWaitEvent(sts[b], done, 0));
     }
-    ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial, R.task_off, R.multi_list, R.num_multi);
-    // ---- 6. bucket reduce
-    ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial, R.task_off, B,
-              W, m1, lvlA[0], lvlS[0]);
-    uint32_t N = N1, sh = 0;
-    for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;  // value = sum A + 2^sh * sum j S_j
-    int cur = 0;
-    while (N > 1) {
-        uint32_t Nout = (N + 63) / 64;
-        ZK_LAUNCH(s, st, "msm_reduce_wave", (k_reduce_wave<F>), dim3(W * Nout), dim3(64), 0, (const Pt*)lvlA[cur], (const Pt*)lvlS[cur], N, W, sh,
-                  lvlA[cur ^ 1], lvlS[cur ^ 1]);
-        cur ^= 1;
-        N = Nout;
-        sh += 6;
+    for (int b = 0; b < nb; b++) {
+        Slot* s = sl[b];
+        hipStream_t st = sts[b];
+        ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
+        // ---- 6. bucket reduce
+        ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial[b], R.task_off,
+                  B, W, m1, lvlA[b][0], lvlS[b][0]);
+        uint32_t N = N1, sh = 0;
+        for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;  // value = sum A + 2^sh * sum j S_j
+        int cur = 0;
+        while (N > 1) {
+            uint32_t Nout = (N + 63) / 64;
+            ZK_LAUNCH(s, st, "msm_reduce_wave", (k_reduce_wave<F>), dim3(W * Nout), dim3(64), 0, (const Pt*)lvlA[b][cur], (const Pt*)lvlS[b][cur], N, W,
+                      sh, lvlA[b][cur ^ 1], lvlS[b][cur ^ 1]);
+            cur ^= 1;
+            N = Nout;
+            sh += 6;
+        }
+        // ---- 7. window sums -> pinned host memory (Horner happens in msm_finish)
+        ZK_TRY(s->pinned_reserve((size_t)W * sizeof(Pt)));
+        ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[b][cur], (size_t)W * sizeof(Pt), hipMemcpyDeviceToHost, st));
     }
-    // ---- 7. window sums -> pinned host memory (Horner happens in msm_finish)
-    ZK_TRY(s->pinned_reserve((size_t)W * sizeof(Pt)));
-    ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[cur], (size_t)W * sizeof(Pt), hipMemcpyDeviceToHost, st));
     return ZK_OK;
+}
+
+template <class F>
+static int msm_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const Affine<F>* d_pts, uint32_t skip_below, MsmJob* job) {
+    const void* pts = d_pts;
+    return msm_accumulate_batch<F>(1, &s, &st, R, &pts, &skip_below, &job);
 }
 
 // Whole MSM on one stream.
@@ -762,6 +802,11 @@ void msm_prep_release(MsmPrep* R) {
 }
 int msm_g1_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job) {
     return msm_accumulate<Fp>(s, st, R, (const Affine<Fp>*)d_pts, skip_below, job);
+}
+int msm_g1_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts, const MsmPrep& R, const void* const* d_pts, const uint32_t* skip_below,
+                            MsmJob* const* jobs) {
+    if (nb < 1 || nb > 3) return set_err(ZK_ERR_ARG, "accumulate batch of %d", nb);
+    return msm_accumulate_batch<Fp>(nb, sl, sts, R, d_pts, skip_below, jobs);
 }
 int msm_g2_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job) {
     return msm_accumulate<Fp2>(s, st, R, (const Affine<Fp2>*)d_pts, skip_below, job);

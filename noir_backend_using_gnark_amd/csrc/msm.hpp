@@ -61,6 +61,9 @@ int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, si
 void msm_prep_release(MsmPrep* R);
 int msm_g1_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);
 int msm_g2_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);
+// up to three G1 MSMs over the same prepared scalars in ONE accumulate launch (jobs[0]->gate_acc gates it; the last job's acc_done owns the event)
+int msm_g1_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts, const MsmPrep& R, const void* const* d_pts, const uint32_t* skip_below,
+                            MsmJob* const* jobs);
 int msm_g1_finish(const MsmJob& job, XYZZ<HFp>* out);
 int msm_g2_finish(const MsmJob& job, XYZZ<HFp2>* out);
 // Device-pointer MSMs returning the un-normalised total (host XYZZ); they synchronise `st` before returning.
