@@ -623,7 +623,8 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     in.d_wk = d_w + P.n_public;
     in.d_h = d_abc[0];
     Msm5State S;
-    if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, ev_h);
+    static const bool nogate = getenv("ZKMI_NOGATE") && atoi(getenv("ZKMI_NOGATE")) == 1;  // experiment: G2.B accumulate does not wait for computeH
+    if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);
     if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
     if (ev_h) (void)hipEventDestroy(ev_h);
     uint64_t parts[96];

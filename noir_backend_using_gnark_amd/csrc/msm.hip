@@ -664,7 +664,10 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         uint32_t N = N1, sh = 0;
         for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;  // value = sum A + 2^sh * sum j S_j
         int cur = 0;
-        while (N > 1) {
+        // the last level (<= 64 entries per window) is cheaper on the host than one more latency-bound launch, as long as the host
+        // has few windows to do (table mode: one)
+        const uint32_t host_n = (W * 64 <= 64) ? 64 : 1;
+        while (N > host_n) {
             uint32_t Nout = (N + 63) / 64;
             ZK_LAUNCH(s, st, "msm_reduce_wave", (k_reduce_wave<F>), dim3(W * Nout), dim3(64), 0, (const Pt*)lvlA[b][cur], (const Pt*)lvlS[b][cur], N, W,
                       sh, lvlA[b][cur ^ 1], lvlS[b][cur ^ 1]);
@@ -672,9 +675,13 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
             N = Nout;
             sh += 6;
         }
-        // ---- 7. window sums -> pinned host memory (Horner happens in msm_finish)
-        ZK_TRY(s->pinned_reserve((size_t)W * sizeof(Pt)));
-        ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[b][cur], (size_t)W * sizeof(Pt), hipMemcpyDeviceToHost, st));
+        // ---- 7. last-level entries -> pinned host memory (final combination and Horner happen in msm_finish)
+        jobs[b]->n_final = N;
+        jobs[b]->sh_final = sh;
+        const size_t cnt = (size_t)W * N;
+        ZK_TRY(s->pinned_reserve(2 * cnt * sizeof(Pt)));
+        ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[b][cur], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
+        if (N > 1) ZK_HIP(hipMemcpyAsync((char*)s->pinned + cnt * sizeof(Pt), lvlS[b][cur], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
     }
     return ZK_OK;
 }
@@ -701,11 +708,25 @@ static int msm_finish(const MsmJob& job, XYZZ<HF>* total_out) {
     *total_out = XYZZ<HF>::inf();
     if (job.empty) return ZK_OK;
     ZK_TRY(slot_sync(job.s, job.st));
-    const XYZZ<HF>* ws = reinterpret_cast<const XYZZ<HF>*>(job.s->pinned);
+    const unsigned N = job.n_final;
+    const XYZZ<HF>* wa = reinterpret_cast<const XYZZ<HF>*>(job.s->pinned);
+    const XYZZ<HF>* wsum = wa + (size_t)job.W * N;
     XYZZ<HF> tot = XYZZ<HF>::inf();
     for (int w = (int)job.W - 1; w >= 0; w--) {
         for (unsigned k = 0; k < job.c; k++) tot.dbl();
-        tot.add(ws[w]);
+        // window value = sum_j A_j + 2^sh * sum_j j S_j  (N = 1: just A_0)
+        XYZZ<HF> val = wa[(size_t)w * N];
+        if (N > 1) {
+            XYZZ<HF> run = XYZZ<HF>::inf(), acc = XYZZ<HF>::inf();
+            for (unsigned j = N - 1; j >= 1; j--) {
+                run.add(wsum[(size_t)w * N + j]);
+                acc.add(run);
+                val.add(wa[(size_t)w * N + j]);
+            }
+            for (unsigned k = 0; k < job.sh_final; k++) acc.dbl();
+            val.add(acc);
+        }
+        tot.add(val);
     }
     *total_out = tot;
     return ZK_OK;

@@ -42,6 +42,7 @@ struct MsmJob {
     Slot* s = nullptr;
     hipStream_t st = nullptr;
     unsigned c = 0, W = 0;
+    unsigned n_final = 1, sh_final = 0;  // entries (A_j, S_j) per window left for the host: value = sum A_j + 2^sh * sum j S_j
     bool empty = true;
     // scheduling hooks (set by the caller BEFORE launch): the throughput-bound accumulate kernel waits for `gate_acc`;
     // with `want_done` an event `acc_done` is recorded right after it (the caller destroys it).
