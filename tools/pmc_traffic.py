@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Builds profiles/pmc_traffic.json from two rocprofv3 --pmc run directories (FETCH_SIZE and WRITE_SIZE collected in separate
+passes, as MI355X_MICROARCH.md prescribes).  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE
+counts a 128-byte request as 64 bytes (guide's correction, calibrated on wide streams); the uncorrected figure is kept too."""
+import collections, csv, glob, json, re, sys
+
+NAMES = {"k_accumulate<G1>": ["msm_accumulate_g1"], "k_accumulate<G2>": ["msm_accumulate_g2"], "radix_sort_onesweep": ["msm_radix_sort(rocprim)"],
+         "k_reduce_l1<G1>": ["msm_reduce_l1"], "k_reduce_wave<G1>": ["msm_reduce_wave"], "k_ntt_pass29": ["ntt_pass_contig", "ntt_pass_strided"],
+         "k_ntt_pass": ["ntt_pass_contig", "ntt_pass_strided"], "k_msm_digits": ["msm_digits"]}
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    tot, disp = collections.defaultdict(float), collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        n = re.sub(r"void |zkmi::|rocprim::ROCPRIM_\d+_NS::|detail::", "", r["Kernel_Name"])
+        g = "<G2>" if "Fp2" in n else ("<G1>" if "FpParams" in n else "")
+        k = re.match(r"[A-Za-z0-9_]+", n).group(0)
+        k = k + g if (k + g) in NAMES else k
+        tot[k] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return {k: tot[k] / len(disp[k]) for k in tot}
+
+
+fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-cpu-baseline; hbm_bytes = "
+        "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B; calibrated for wide "
+        "streams only -- the accumulate kernel issues 64/128-B gathers, so the uncorrected figure is given too)")
+out = {}
+for k, names in NAMES.items():
+    if k in fetch and k in write:
+        for nm in names:
+            out[nm] = {"FETCH_SIZE_KB_avg": fetch[k], "WRITE_SIZE_KB_avg": write[k], "hbm_bytes_per_launch": int((2 * fetch[k] + write[k]) * 1024),
+                       "hbm_bytes_per_launch_uncorrected": int((fetch[k] + write[k]) * 1024), "rocprof_kernel": k, "note": note}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print({k: v["hbm_bytes_per_launch"] for k, v in out.items()})
