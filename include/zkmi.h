@@ -167,6 +167,25 @@ int zk_bn254_groth16_msm5_session_stream(uint64_t session, void **stream_out);
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t *partials, size_t n_partials, const zk_fr *r,
                               const zk_fr *s, uint8_t proof_out[128]);
 
+/* ---- felt-vector wire codec (the data format in front of the hot path) -------------------------------------------
+ * The reference hands witness values to the Go side as hex( u32 BE count || count x 32 B BE canonical felts )
+ * [REF src/gnark_backend_wrapper/serialize.rs:33-47,71-106; gnark_backend_ffi/internal/backend/helpers.go:24-33
+ * DeserializeFelts = hex.DecodeString + fr.Vector.UnmarshalBinary].  One kernel decodes the hex text, reverses the byte
+ * order, rejects non-canonical values like gnark-crypto ("invalid fr.Element encoding": >= r is an error, not reduced) and
+ * converts to the Montgomery image, writing the vector straight into HBM -- ready to be the `w` of zk_bn254_groth16_prove
+ * (on_device) or the scalars of zk_bn254_msm_bases.  Errors: ZK_ERR_LEN (length does not match the count), ZK_ERR_ARG
+ * (bad hex character, non-canonical felt, capacity).
+ *   decode_hex      : hex on the host -> d_out (device, capacity `cap` felts); *n_out = count.
+ *   decode_hex_dev  : the whole text already in HBM (d_text must sit 8 bytes before a 16-byte boundary; n = its count).
+ *   decode_bytes_dev: raw fr.Vector.MarshalBinary bytes in HBM (d_raw 4 bytes before a 16-byte boundary).
+ *   encode_hex      : Montgomery vector in HBM -> 8 + 64 n hex characters on the host (encode_felts), no terminator. */
+int zk_bn254_felts_decode_hex(const char *hex, size_t hex_len, void *d_out, size_t cap, size_t *n_out);
+int zk_bn254_felts_decode_hex_dev(const void *d_text, size_t text_len, void *d_out, size_t cap, size_t n, int to_mont,
+                                  void *stream);
+int zk_bn254_felts_decode_bytes_dev(const void *d_raw, size_t raw_len, void *d_out, size_t cap, size_t n, int to_mont,
+                                    void *stream);
+int zk_bn254_felts_encode_hex(const void *d_in, size_t n, char *hex_out, size_t cap);
+
 /* ---- synthetic data on the device (bench / tests; deterministic SplitMix64 streams) -------------- */
 int zk_bn254_fr_random_dev(void *d_out, size_t n, uint64_t seed, int mont, int witness_like, void *stream);
 int zk_bn254_g1_generate_dev(void *d_out, size_t n, uint64_t seed, void *stream); /* P_i = k_i * G1 */

@@ -321,9 +321,12 @@ static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w,
     return ZK_OK;
 }
 // Z side, on st0 (after whatever produced h on that stream); its accumulate goes last in the chain
-static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm5State* S) {
-    if (in.tab_h) ZK_TRY(msm_prepare_scalars_table(sl[0], st0, in.d_h, in.nz, &kMontCfg, *in.tab_h, &S->prep_h));
-    else ZK_TRY(msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h));
+static int msm5_prepare_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm5State* S) {
+    if (in.tab_h) return msm_prepare_scalars_table(sl[0], st0, in.d_h, in.nz, &kMontCfg, *in.tab_h, &S->prep_h);
+    return msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h);
+}
+static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm5State* S, bool prepared = false) {
+    if (!prepared) ZK_TRY(msm5_prepare_h(sl, st0, in, S));
     // Z's accumulate goes last on the chain stream (which then waits for prepare(h) through the event inside msm_accumulate)
     S->jobs[0].chain = S->chain;
     if (!S->chain) {
@@ -624,8 +627,15 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     in.d_h = d_abc[0];
     Msm5State S;
     static const bool nogate = getenv("ZKMI_NOGATE") && atoi(getenv("ZKMI_NOGATE")) == 1;  // experiment: G2.B accumulate does not wait for computeH
-    if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);
-    if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
+    static const bool preph_first = getenv("ZKMI_PREPH_FIRST") && atoi(getenv("ZKMI_PREPH_FIRST")) == 1;  // experiment: prepare(h) alone, before G2.B
+    if (preph_first) {
+        if (rc == ZK_OK) rc = msm5_prepare_h(g.s, st, in, &S);
+        if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, S.prep_h.ready ? S.prep_h.ready : ev_h);
+        if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S, true);
+    } else {
+        if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);
+        if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
+    }
     if (ev_h) (void)hipEventDestroy(ev_h);
     uint64_t parts[96];
     TailPre T;

@@ -452,3 +452,47 @@ def test_sharded_proof_with_rank_local_keys(G, tables):
     assert par.groth16_finalize(keys[-1], np.stack(recs), r, s) == exp
     for pk in keys:
         pk.free()
+
+
+def test_felt_vector_codec_golden_and_reference_literals(golden):
+    """DeserializeFelts / encode_felts on the device: the committed wire vectors (which include the reference's own witness literals,
+    gnark_backend_ffi/main.go:225-246: {0, 1, -1, -1, 1, 0}) decode to the Montgomery images and encode back to the same text."""
+    from noir_backend_using_gnark_amd import wire
+    w = golden["wire"]
+    felts = [h2i(x) for x in w["felts"]]
+    d, n = wire.deserialize_felts(w["encoded"])
+    assert n == len(felts)
+    assert (d.to_numpy(np.uint64, (n, 4)) == mont_limbs(felts)).all()
+    assert wire.serialize_felts(d, n) == w["encoded"]
+    # the reference's literal: -1 mod r  (main.go:233)
+    minus_one = "30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000000"
+    d, n = wire.deserialize_felts("00000002" + minus_one + "0" * 63 + "1")
+    assert (d.to_numpy(np.uint64, (2, 4)) == mont_limbs([ref.R - 1, 1])).all()
+    assert wire.deserialize_felts("00000000")[1] == 0
+
+
+@pytest.mark.parametrize("n", [1, 255, 4097, 1 << 16])
+def test_felt_vector_codec_roundtrip_vs_oracle(n):
+    from noir_backend_using_gnark_amd import wire
+    felts = ref.rand_felts(900 + n, n)
+    text = ref.felts_wire(felts).hex()
+    d, m = wire.deserialize_felts(text.upper() if n == 255 else text)   # hex.DecodeString accepts both cases
+    assert m == n
+    assert (d.to_numpy(np.uint64, (n, 4)) == mont_limbs(felts)).all()
+    assert wire.serialize_felts(d, n) == text
+
+
+def test_felt_vector_codec_errors():
+    from noir_backend_using_gnark_amd import wire
+    one = "0" * 63 + "1"
+    r_hex = "%064x" % ref.R
+    for bad in ("00000002" + one,                 # count says 2, one felt present
+                "00000001" + one + "00",          # trailing bytes
+                "00000001" + one[:-1] + "g",      # not hex
+                "00000001" + one[:-1] + "@",      # not hex (a character whose low nibble would decode)
+                "00000001" + r_hex,               # r itself: gnark-crypto rejects non-canonical encodings, it does not reduce
+                "0000000z" + one):                # bad count
+        with pytest.raises(Exception):
+            wire.deserialize_felts(bad)
+    d, n = wire.deserialize_felts("00000001" + "%064x" % (ref.R - 1))
+    assert n == 1
