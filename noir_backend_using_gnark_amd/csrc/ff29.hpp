@@ -35,10 +35,15 @@ struct Fp29 {
     static constexpr uint32_t BIAS16[9] = {0x47cfd470u, 0x50460b6au, 0x472a34eeu, 0x4d522d0cu, 0x585d977fu, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
     static constexpr uint32_t BIAS24[9] = {0x4bb7bea8u, 0x58691120u, 0x4abf4f66u, 0x43fb4393u, 0x448c6340u, 0x448e120eu, 0x4fa51e18u, 0x58a394deu, 0x04896758u};
     static constexpr uint32_t BIAS40[9] = {0x53879318u, 0x48af1c8cu, 0x51e98457u, 0x514d70a1u, 0x5ce9fac1u, 0x52421e18u, 0x5a133229u, 0x5e65f81eu, 0x078fac3fu};
+    static constexpr uint32_t BIAS32[9] = {0x4f9fa8e0u, 0x408c16d6u, 0x4e5469dfu, 0x5aa45a1au, 0x50bb2f00u, 0x5b681813u, 0x54dc2820u, 0x4b84c67eu, 0x060c89ccu};
+    static constexpr uint32_t BIAS64[9] = {0x5f3f51c0u, 0x41182daeu, 0x5ca8d3c0u, 0x5548b436u, 0x41765e03u, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au};
+    static constexpr uint32_t BIAS80[9] = {0x470f2630u, 0x515e391bu, 0x43d308b0u, 0x429ae145u, 0x59d3f585u, 0x44843c33u, 0x54266455u, 0x5ccbf03fu, 0x0f1f5881u};
+    static constexpr uint32_t PINV = 0x1b799c77u;  // p^-1 mod 2^29 (= 2^29 - NINV)
     template <int K>
     static constexpr uint32_t bias(int i) {
-        static_assert(K == 4 || K == 8 || K == 12 || K == 16 || K == 24 || K == 40, "no bias table for this multiple of p");
-        return K == 4 ? BIAS4[i] : K == 8 ? BIAS8[i] : K == 12 ? BIAS12[i] : K == 16 ? BIAS16[i] : K == 24 ? BIAS24[i] : BIAS40[i];
+        static_assert(K == 4 || K == 8 || K == 12 || K == 16 || K == 24 || K == 32 || K == 40 || K == 64 || K == 80, "no bias table for this multiple of p");
+        return K == 4 ? BIAS4[i] : K == 8 ? BIAS8[i] : K == 12 ? BIAS12[i] : K == 16 ? BIAS16[i] : K == 24 ? BIAS24[i] : K == 32 ? BIAS32[i]
+             : K == 40 ? BIAS40[i] : K == 64 ? BIAS64[i] : BIAS80[i];
     }
 };
 
@@ -464,6 +469,96 @@ __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2
     Y3.c1 = u29_mul4(R.c0, d.c1, R.c1, d.c0, nY0, PPP.c1, nY1, PPP.c0);
     A.zz = f2_mulF29(A.zz, PP, u29_neg<8>(A.zz.c1));
     A.zzz = f2_mulF29(A.zzz, PPP, u29_neg<8>(A.zzz.c1));
+    A.x = X3;
+    A.y = Y3;
+}
+
+// ---- XYZZ + XYZZ and doubling for the bucket-reduction tail (G2), fused multi-product form: every output coordinate is a direct
+// product output.  Class invariant proven by tools/u29_model.py (check_add_dbl_class_g2, exact_check_add_dbl_g2): with both
+// components of every input coordinate < 32 p and weakly normalised, every output component is again < 32 p (add: <= 20.4 p,
+// dbl: <= 22.5 p).  Operation order and bias multiples are exactly add_fp2 / dbl_fp2 of the model.
+__device__ __forceinline__ void acc29g2_load(Acc29G2& A, const XYZZ<Fp2>& c) {  // canonical image -> lazily reduced, no multiplication
+    A.inf = c.is_inf();
+    A.x = f2_load29(c.x);
+    A.y = f2_load29(c.y);
+    A.zz = f2_load29(c.zz);
+    A.zzz = f2_load29(c.zzz);
+}
+template <int K>
+__device__ __forceinline__ U29x2 f2_mulFK29(const U29x2& a, const U29x2& b) {  // fused product, a.c1 negated against K*p
+    return f2_mulF29(a, b, u29_neg<K>(a.c1));
+}
+// x (a single-product output, < 16 p) can only be == 0 mod p if (x mod 2^29) * p^-1 mod 2^29 < 16: a filter with a false-positive
+// rate of 2^-25 that never misses
+__device__ __forceinline__ bool u29_maybe_zero16(const U29& x) { return (((x.l[0] & Fp29::MASK) * Fp29::PINV) & Fp29::MASK) < 16u; }
+
+__device__ __forceinline__ void acc29g2_dbl(Acc29G2& A) {  // dbl-2008-s-1
+    if (A.inf) return;
+    const U29 one = u29_one();
+    const U29 yc0 = u29_mul(A.y.c0, one), yc1 = u29_mul(A.y.c1, one);  // contracted: keeps U = 2 Y small
+    const U29x2 U{u29_wnorm(u29_add(yc0, yc0)), u29_wnorm(u29_add(yc1, yc1))};
+    const U29 nU1 = u29_neg<4>(U.c1);
+    U29x2 V;
+    V.c0 = u29_mul2(U.c0, U.c0, nU1, U.c1);
+    V.c1 = u29_mul(u29_add(U.c0, U.c0), U.c1);
+    const U29x2 Wv = f2_mulF29(U, V, nU1);
+    const U29 nX1 = u29_neg<40>(A.x.c1);
+    const U29x2 S = f2_mulF29(A.x, V, nX1);
+    U29x2 X2;
+    X2.c0 = u29_mul2(A.x.c0, A.x.c0, nX1, A.x.c1);
+    X2.c1 = u29_mul(u29_add(A.x.c0, A.x.c0), A.x.c1);
+    const U29x2 M{u29_wnorm(u29_add(u29_add(X2.c0, X2.c0), X2.c0)), u29_wnorm(u29_add(u29_add(X2.c1, X2.c1), X2.c1))};
+    const U29 nM1 = u29_neg<40>(M.c1);
+    const U29 tX0 = u29_wnorm(u29_add(A.x.c0, A.x.c0)), tX1 = u29_wnorm(u29_add(A.x.c1, A.x.c1));
+    const U29 n2X0 = u29_neg<80>(tX0), n2X1 = u29_neg<80>(tX1);
+    U29x2 X3;  // M^2 - 2 X1 V
+    X3.c0 = u29_mul4(M.c0, M.c0, nM1, M.c1, n2X0, V.c0, tX1, V.c1);
+    X3.c1 = u29_mul3(u29_add(M.c0, M.c0), M.c1, n2X0, V.c1, n2X1, V.c0);
+    const U29x2 d = f2_sub29<24>(S, X3);
+    const U29 nW0 = u29_neg<4>(Wv.c0), nW1 = u29_neg<4>(Wv.c1);
+    U29x2 Y3;  // M (S - X3) - W Y1
+    Y3.c0 = u29_mul4(M.c0, d.c0, nM1, d.c1, nW0, A.y.c0, Wv.c1, A.y.c1);
+    Y3.c1 = u29_mul4(M.c0, d.c1, M.c1, d.c0, nW0, A.y.c1, nW1, A.y.c0);
+    A.zz = f2_mulFK29<4>(V, A.zz);
+    A.zzz = f2_mulF29(Wv, A.zzz, nW1);
+    A.x = X3;
+    A.y = Y3;
+}
+__device__ __forceinline__ void acc29g2_add(Acc29G2& A, const Acc29G2& Bq) {  // add-2008-s
+    if (Bq.inf) return;
+    if (A.inf) { A = Bq; return; }
+    const U29x2 U1 = f2_mulFK29<40>(A.x, Bq.zz), U2 = f2_mulFK29<40>(Bq.x, A.zz);
+    const U29x2 S1 = f2_mulFK29<40>(A.y, Bq.zzz), S2 = f2_mulFK29<40>(Bq.y, A.zzz);
+    const U29x2 P = f2_sub29<16>(U2, U1);
+    const U29x2 R = f2_sub29<16>(S2, S1);
+    const U29 nP1 = u29_neg<32>(P.c1), nR1 = u29_neg<32>(R.c1);
+    U29x2 PP;
+    PP.c0 = u29_mul2(P.c0, P.c0, nP1, P.c1);
+    PP.c1 = u29_mul(u29_add(P.c0, P.c0), P.c1);
+    if (u29_maybe_zero16(PP.c1)) {
+        // 2 P0 P1 == 0 mod p is NECESSARY for P == 0 (same x: doubling or P + (-P)); the canonical saturated addition is correct for
+        // every input, so it is taken whenever the filter fires
+        XYZZ<Fp2> a = acc29g2_to_xyzz(A);
+        a.add(acc29g2_to_xyzz(Bq));
+        acc29g2_load(A, a);
+        return;
+    }
+    const U29x2 PPP = f2_mulF29(P, PP, nP1);
+    const U29x2 Q = f2_mulFK29<16>(U1, PP);
+    const U29 W0 = u29_wnorm(u29_add(P.c0, u29_add(U1.c0, U1.c0))), W1 = u29_wnorm(u29_add(P.c1, u29_add(U1.c1, U1.c1)));
+    const U29 nW0 = u29_neg<64>(W0), nW1 = u29_neg<64>(W1);
+    U29x2 X3;  // R^2 - (P + 2 U1) PP
+    X3.c0 = u29_mul4(R.c0, R.c0, nR1, R.c1, nW0, PP.c0, W1, PP.c1);
+    X3.c1 = u29_mul3(u29_add(R.c0, R.c0), R.c1, nW0, PP.c1, nW1, PP.c0);
+    const U29x2 d = f2_sub29<24>(Q, X3);
+    const U29 nS0 = u29_neg<16>(S1.c0), nS1 = u29_neg<16>(S1.c1);
+    U29x2 Y3;  // R (Q - X3) - S1 PPP
+    Y3.c0 = u29_mul4(R.c0, d.c0, nR1, d.c1, nS0, PPP.c0, S1.c1, PPP.c1);
+    Y3.c1 = u29_mul4(R.c0, d.c1, R.c1, d.c0, nS0, PPP.c1, nS1, PPP.c0);
+    const U29x2 ZZ = f2_mulFK29<40>(A.zz, Bq.zz);
+    const U29x2 ZZZ = f2_mulFK29<40>(A.zzz, Bq.zzz);
+    A.zz = f2_mulFK29<16>(ZZ, PP);
+    A.zzz = f2_mulFK29<16>(ZZZ, PPP);
     A.x = X3;
     A.y = Y3;
 }

@@ -324,6 +324,45 @@ struct TailPt<Fp> {
     }
 };
 
+// G2 in the same form (fused multi-product add / dbl of ff29.hpp, model-checked) is available behind -DZKMI_G2_TAIL_U29.  Measured: correct
+// (all parity tests pass with it) but NOT faster (10.94-10.99 vs 10.82-11.02 ms per proof): these kernels hold 256 VGPRs + 142 AGPRs at one
+// wave per SIMD and are bound by the latency of their serial chains, not by instruction count -- so the canonical form stays the default.
+#ifdef ZKMI_G2_TAIL_U29
+template <>
+struct TailPt<Fp2> {
+    Acc29G2 v;
+    static __device__ __forceinline__ TailPt inf() {
+        TailPt t;
+        t.v.inf = true;
+        uint32_t* o = reinterpret_cast<uint32_t*>(&t.v);
+        for (unsigned i = 0; i < 72; i++) o[i] = 0;
+        return t;
+    }
+    static __device__ __forceinline__ TailPt load(const XYZZ<Fp2>* p) { TailPt t; acc29g2_load(t.v, gload(p)); return t; }
+    __device__ __forceinline__ void store(XYZZ<Fp2>* p) const { gstore(p, acc29g2_to_xyzz(v)); }
+    __device__ __forceinline__ void add(const TailPt& o) { acc29g2_add(v, o.v); }
+    __device__ __forceinline__ void dbl() { acc29g2_dbl(v); }
+    __device__ __forceinline__ TailPt shfl_down(unsigned d) const {
+        TailPt r;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+        uint32_t* o = reinterpret_cast<uint32_t*>(&r.v);
+#pragma unroll
+        for (unsigned i = 0; i < 72; i++) o[i] = __shfl_down(s[i], d, 64);
+        r.v.inf = __shfl_down((int)v.inf, d, 64) != 0;
+        return r;
+    }
+    __device__ __forceinline__ TailPt shfl_xor(unsigned d) const {
+        TailPt r;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+        uint32_t* o = reinterpret_cast<uint32_t*>(&r.v);
+#pragma unroll
+        for (unsigned i = 0; i < 72; i++) o[i] = __shfl_xor(s[i], d, 64);
+        r.v.inf = __shfl_xor((int)v.inf, d, 64) != 0;
+        return r;
+    }
+};
+#endif
+
 // buckets cut into several tasks: one WAVE folds the bucket's partials into the first one
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list,

@@ -435,6 +435,118 @@ def madd_fp2_fused(O, X1, Y1, ZZ1, ZZZ1, X2, Y2):
     return X3, Y3, ZZ3, ZZZ3
 
 
+# ---- G2 bucket-reduction tail: XYZZ + XYZZ and doubling over Fp2 in fused form (every output coordinate a direct product output)
+def add_fp2(O, A, Bp):
+    X1, Y1, ZZ1, ZZZ1 = A
+    X2, Y2, ZZ2, ZZZ2 = Bp
+    U1 = f2_mulF(O, X1, ZZ2, site="g2a.nin")
+    U2 = f2_mulF(O, X2, ZZ1, site="g2a.nin")
+    S1 = f2_mulF(O, Y1, ZZZ2, site="g2a.nin")
+    S2 = f2_mulF(O, Y2, ZZZ1, site="g2a.nin")
+    P = f2_sub(O, U2, U1, "g2a.P")
+    R = f2_sub(O, S2, S1, "g2a.P")
+    nP1, nR1 = O.neg(P[1], "g2a.nP"), O.neg(R[1], "g2a.nP")
+    PP = (O.mulN([(P[0], P[0]), (nP1, P[1])]), O.mul(O.add(P[0], P[0]), P[1]))
+    PPP = f2_mulF(O, P, PP, nP1)
+    Qv = f2_mulF(O, U1, PP, site="g2a.nU")
+    Wv = (O.wnorm(O.add(P[0], O.add(U1[0], U1[0]))), O.wnorm(O.add(P[1], O.add(U1[1], U1[1]))))
+    nW0, nW1 = O.neg(Wv[0], "g2a.nW"), O.neg(Wv[1], "g2a.nW")
+    X3 = (O.mulN([(R[0], R[0]), (nR1, R[1]), (nW0, PP[0]), (Wv[1], PP[1])]),
+          O.mulN([(O.add(R[0], R[0]), R[1]), (nW0, PP[1]), (nW1, PP[0])]))
+    d = f2_sub(O, Qv, X3, "g2a.d")
+    nS0, nS1 = O.neg(S1[0], "g2a.nU"), O.neg(S1[1], "g2a.nU")
+    Y3 = (O.mulN([(R[0], d[0]), (nR1, d[1]), (nS0, PPP[0]), (S1[1], PPP[1])]),
+          O.mulN([(R[0], d[1]), (R[1], d[0]), (nS0, PPP[1]), (nS1, PPP[0])]))
+    ZZ = f2_mulF(O, ZZ1, ZZ2, site="g2a.nin")
+    ZZ3 = f2_mulF(O, ZZ, PP, site="g2a.nU")
+    ZZZ = f2_mulF(O, ZZZ1, ZZZ2, site="g2a.nin")
+    ZZZ3 = f2_mulF(O, ZZZ, PPP, site="g2a.nU")
+    return X3, Y3, ZZ3, ZZZ3, PP
+
+
+def dbl_fp2(O, A, one=None):
+    X1, Y1, ZZ1, ZZZ1 = A
+    if one is None:
+        one = B((1 << RBITS) % Q + 1, limbs((1 << RBITS) % Q)) if O is BoundOps else limbs((1 << RBITS) % Q)
+    Yc = (O.mul(Y1[0], one), O.mul(Y1[1], one))          # contracted: keeps U = 2 Y small
+    U = (O.wnorm(O.add(Yc[0], Yc[0])), O.wnorm(O.add(Yc[1], Yc[1])))
+    nU1 = O.neg(U[1], "g2d.nU")
+    V = (O.mulN([(U[0], U[0]), (nU1, U[1])]), O.mul(O.add(U[0], U[0]), U[1]))
+    Wv = f2_mulF(O, U, V, nU1)
+    S = f2_mulF(O, X1, V, site="g2d.nin")
+    nX1 = O.neg(X1[1], "g2d.nin")
+    X2 = (O.mulN([(X1[0], X1[0]), (nX1, X1[1])]), O.mul(O.add(X1[0], X1[0]), X1[1]))
+    M = (O.wnorm(O.add(O.add(X2[0], X2[0]), X2[0])), O.wnorm(O.add(O.add(X2[1], X2[1]), X2[1])))
+    nM1 = O.neg(M[1], "g2d.nM")
+    tX0, tX1 = O.wnorm(O.add(X1[0], X1[0])), O.wnorm(O.add(X1[1], X1[1]))
+    n2X0, n2X1 = O.neg(tX0, "g2d.n2X"), O.neg(tX1, "g2d.n2X")
+    # X3 = M^2 - 2 X1 V, one reduction per component
+    X3 = (O.mulN([(M[0], M[0]), (nM1, M[1]), (n2X0, V[0]), (tX1, V[1])]),
+          O.mulN([(O.add(M[0], M[0]), M[1]), (n2X0, V[1]), (n2X1, V[0])]))
+    d = f2_sub(O, S, X3, "g2d.d")
+    nW0, nW1 = O.neg(Wv[0], "g2d.nW"), O.neg(Wv[1], "g2d.nW")
+    # Y3 = M (S - X3) - W Y1
+    Y3 = (O.mulN([(M[0], d[0]), (nM1, d[1]), (nW0, Y1[0]), (Wv[1], Y1[1])]),
+          O.mulN([(M[0], d[1]), (M[1], d[0]), (nW0, Y1[1]), (nW1, Y1[0])]))
+    ZZ3 = f2_mulF(O, V, ZZ1, site="g2d.nW")
+    ZZZ3 = f2_mulF(O, Wv, ZZZ1, nW1)
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def check_add_dbl_class_g2():
+    """the class "both components of all four coordinates < 32 p, weakly normalised" is closed under load, add and dbl (G2)"""
+    c1 = B(32 * Q, [MASK + 8] * (NL - 1) + [((32 * Q) >> (W * (NL - 1))) + 4])
+    cls = (c1, c1)
+    A = (cls, cls, cls, cls)
+    for name, out in (("add", add_fp2(BoundOps, A, A)[:4]), ("dbl", dbl_fp2(BoundOps, A))):
+        for c in out:
+            for comp in c:
+                assert comp.vmax <= 32 * Q, (name, comp.kp())
+                assert all(l <= MASK + 8 for l in comp.lmax[:-1]), name
+        print("  G2 %s: outputs (units of p): %s" % (name, ", ".join("%.1f/%.1f" % (c[0].kp(), c[1].kp()) for c in out)))
+
+
+def exact_check_add_dbl_g2(n=30):
+    random.seed(17)
+    f2m = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+    f2s = lambda a, b: ((a[0] - b[0]) % Q, (a[1] - b[1]) % Q)
+    def f2inv(a):
+        dd = pow((a[0] * a[0] + a[1] * a[1]) % Q, -1, Q)
+        return (a[0] * dd % Q, -a[1] * dd % Q)
+    # the chord / tangent rules are algebraic identities: random pairs need not lie on the twist (tangent uses a = 0: lam = 3 x^2 / 2 y)
+    def chord(P1, P2):
+        lam = f2m(f2s(P2[1], P1[1]), f2inv(f2s(P2[0], P1[0])))
+        x3 = f2s(f2s(f2m(lam, lam), P1[0]), P2[0])
+        return x3, f2s(f2m(lam, f2s(P1[0], x3)), P1[1])
+    def tangent(P1):
+        x2 = f2m(P1[0], P1[0])
+        lam = f2m(((3 * x2[0]) % Q, (3 * x2[1]) % Q), f2inv(((2 * P1[1][0]) % Q, (2 * P1[1][1]) % Q)))
+        x3 = f2s(f2s(f2m(lam, lam), P1[0]), P1[0])
+        return x3, f2s(f2m(lam, f2s(P1[0], x3)), P1[1])
+    rp = lambda: ((rand_fe(), rand_fe()), (rand_fe(), rand_fe()))
+    def lift(Pt):
+        z = (rand_fe(), rand_fe())
+        zz = f2m(z, z)
+        zzz = f2m(zz, z)
+        u = lambda v: (to_u29(v[0]), to_u29(v[1]))
+        return (u(f2m(Pt[0], zz)), u(f2m(Pt[1], zzz)), u(zz), u(zzz))
+    def aff(A):
+        g = lambda v: (from_u29(v[0]), from_u29(v[1]))
+        return f2m(g(A[0]), f2inv(g(A[2]))), f2m(g(A[1]), f2inv(g(A[3])))
+    accp = rp()
+    A = lift(accp)
+    for i in range(n):
+        if i % 3 == 2:
+            A = dbl_fp2(ExactOps, A)
+            accp = tangent(accp)
+        else:
+            P2 = rp()
+            A = add_fp2(ExactOps, A, lift(P2))[:4]
+            accp = chord(accp, P2)
+        assert aff(A) == accp, i
+    print("  exact G2 add/dbl chain of %d operations: ok" % n)
+
+
 def fixed_point(madd, is_f2):
     fresh = B.fresh()
     one = B(2 * Q, [MASK] * (NL - 1) + [(2 * Q) >> (W * (NL - 1))])
@@ -546,6 +658,8 @@ def main():
     fixed_point(madd_fp2_fused, True)
     print("G1 add / dbl class check:")
     check_add_dbl_class()
+    print("G2 add / dbl class check:")
+    check_add_dbl_class_g2()
     print("bias multiple per subtraction site:", SITE_K)
     for k in sorted(set(SITE_K.values())):
         print("bias %3d p:" % k, ", ".join("0x%08xu" % v for v in bias_limbs(k)))
@@ -553,6 +667,7 @@ def main():
     exact_check_g2()
     exact_check_g2(60, madd_fp2_fused)
     exact_check_add_dbl()
+    exact_check_add_dbl_g2()
     # mul unit test
     random.seed(1)
     for _ in range(2000):
