@@ -54,6 +54,7 @@ struct PassArgs {
     unsigned logn, bit_lo, k, logL;
     int dif, has_post_const;
     int canonical;       // 29-bit-limb passes: last pass of the transform -> canonical image; else a lazily reduced 256-bit intermediate
+    const Fr* tw2;       // fused inverse-then-forward pass (k_ntt_pass29_if): twiddles of the forward half
 };
 
 __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, unsigned t) {
@@ -202,8 +203,8 @@ __device__ __forceinline__ void lds_store9(uint4* lo, uint4* hi, uint32_t* top, 
 }
 
 template <int G, bool DIF, unsigned THREADS>
-__device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, unsigned s0, bool first,
-                                            bool last) {
+__device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, unsigned s0,
+                                            bool load_packed, bool apply_pre, bool apply_post, bool store_packed) {
     constexpr unsigned NE = 1u << G;
     const unsigned L = 1u << A.logL;
     const unsigned ql = DIF ? (A.k - s0 - G) : s0;
@@ -214,12 +215,8 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
 #pragma unroll
         for (unsigned e = 0; e < NE; e++) {
             const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
-            if (first) {
-                x[e] = u29_unpack(lds_load(lo, hi, t));
-                if (A.pre) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
-            } else {
-                x[e] = lds_load9(lo, hi, top, t);
-            }
+            x[e] = load_packed ? u29_unpack(lds_load(lo, hi, t)) : lds_load9(lo, hi, top, t);
+            if (apply_pre && A.pre) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
         }
 #pragma unroll
         for (int sl = 0; sl < G; sl++) {
@@ -255,14 +252,52 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
 #pragma unroll
         for (unsigned e = 0; e < NE; e++) {
             const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
-            if (last) {
+            if (apply_post) {
                 if (A.post) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.post + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
                 else if (A.has_post_const) x[e] = u29r_mul(x[e], u29r_load5(A.post_const));
-                lds_store(lo, hi, t, u29r_pack(u29r_reduce(x[e]), A.canonical != 0));
-            } else {
-                lds_store9(lo, hi, top, t, x[e]);
             }
+            if (store_packed) lds_store(lo, hi, t, u29r_pack(u29r_reduce(x[e]), A.canonical != 0));
+            else lds_store9(lo, hi, top, t, x[e]);
         }
+    }
+}
+
+// all k stages of a pass, GMAX at a time.  packed_in / packed_out: the tile sits in LDS as 8 packed words before / after.
+template <int GMAX, unsigned THREADS, bool DIF>
+__device__ __forceinline__ void ntt_stages29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, bool packed_in,
+                                             bool packed_out) {
+    for (unsigned s0 = 0; s0 < A.k;) {
+        const unsigned G = (A.k - s0 >= (unsigned)GMAX) ? (unsigned)GMAX : (A.k - s0);
+        const bool first = (s0 == 0), last = (s0 + G == A.k);
+        const bool lp = first && packed_in, sp = last && packed_out;
+        if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), DIF, THREADS>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+        else if (G == 2) ntt_group29<2, DIF, THREADS>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+        else ntt_group29<1, DIF, THREADS>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+        s0 += G;
+        __syncthreads();
+    }
+}
+
+template <unsigned THREADS>
+__device__ __forceinline__ void tile_copy_in(const PassArgs& A, uint4* lo, uint4* hi, size_t base, unsigned E) {
+    const unsigned L = 1u << A.logL;
+    const uint4* g = reinterpret_cast<const uint4*>(A.data);
+    for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
+        unsigned e = h >> 1, half = h & 1;
+        unsigned mid = e >> A.logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        (half ? hi : lo)[e] = g[gi * 2 + half];
+    }
+}
+template <unsigned THREADS>
+__device__ __forceinline__ void tile_copy_out(const PassArgs& A, const uint4* lo, const uint4* hi, size_t base, unsigned E) {
+    const unsigned L = 1u << A.logL;
+    uint4* g = reinterpret_cast<uint4*>(A.data);
+    for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
+        unsigned e = h >> 1, half = h & 1;
+        unsigned mid = e >> A.logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        g[gi * 2 + half] = (half ? hi : lo)[e];
     }
 }
 
@@ -273,45 +308,40 @@ __global__ __launch_bounds__(THREADS) void k_ntt_pass29(PassArgs A) {
     uint4* lo = lds;
     uint4* hi = lds + E;
     uint32_t* top = reinterpret_cast<uint32_t*>(lds + 2 * E);
-    const unsigned L = 1u << A.logL;
     const unsigned lo_blks = (1u << A.bit_lo) >> A.logL;  // >= 1
     const size_t tile = blockIdx.x;
     const size_t hi_idx = tile / lo_blks;
     const unsigned lo_blk = (unsigned)(tile % lo_blks);
     const size_t base = (hi_idx << (A.bit_lo + A.k)) + ((size_t)lo_blk << A.logL);
-    uint4* g = reinterpret_cast<uint4*>(A.data);
-
-    for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
-        unsigned e = h >> 1, half = h & 1;
-        unsigned mid = e >> A.logL, l = e & (L - 1);
-        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
-        uint4 v = g[gi * 2 + half];
-        (half ? hi : lo)[e] = v;
-    }
+    tile_copy_in<THREADS>(A, lo, hi, base, E);
     __syncthreads();
+    if (A.dif) ntt_stages29<GMAX, THREADS, true>(A, lo, hi, top, base, E, true, true);
+    else ntt_stages29<GMAX, THREADS, false>(A, lo, hi, top, base, E, true, true);
+    tile_copy_out<THREADS>(A, lo, hi, base, E);
+}
 
-    for (unsigned s0 = 0; s0 < A.k;) {
-        const unsigned G = (A.k - s0 >= (unsigned)GMAX) ? (unsigned)GMAX : (A.k - s0);
-        const bool first = (s0 == 0), last = (s0 + G == A.k);
-        if (A.dif) {
-            if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), true, THREADS>(A, lo, hi, top, base, E, s0, first, last);
-            else if (G == 2) ntt_group29<2, true, THREADS>(A, lo, hi, top, base, E, s0, first, last);
-            else ntt_group29<1, true, THREADS>(A, lo, hi, top, base, E, s0, first, last);
-        } else {
-            if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), false, THREADS>(A, lo, hi, top, base, E, s0, first, last);
-            else if (G == 2) ntt_group29<2, false, THREADS>(A, lo, hi, top, base, E, s0, first, last);
-            else ntt_group29<1, false, THREADS>(A, lo, hi, top, base, E, s0, first, last);
-        }
-        s0 += G;
-        __syncthreads();
-    }
-
-    for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
-        unsigned e = h >> 1, half = h & 1;
-        unsigned mid = e >> A.logL, l = e & (L - 1);
-        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
-        g[gi * 2 + half] = (half ? hi : lo)[e];
-    }
+// computeH runs FFTInverse(DIF) immediately followed by FFT(DIT, coset) on the same vector: the inverse transform ENDS with the
+// contiguous pass over the low index bits and the forward transform BEGINS with it, on the same tiles -- so the two passes are one
+// kernel: load tile, k DIF stages (A.tw), * A.post (1/N * g^bitrev(i)), k DIT stages (A.tw2), store.  One HBM round trip saved
+// per vector.
+template <int GMAX, unsigned THREADS>
+__global__ __launch_bounds__(THREADS) void k_ntt_pass29_if(PassArgs A) {
+    extern __shared__ uint4 lds[];
+    const unsigned E = 1u << (A.k + A.logL);
+    uint4* lo = lds;
+    uint4* hi = lds + E;
+    uint32_t* top = reinterpret_cast<uint32_t*>(lds + 2 * E);
+    const size_t base = (size_t)blockIdx.x << A.k;  // contiguous tiles only (bit_lo = 0, logL = 0)
+    tile_copy_in<THREADS>(A, lo, hi, base, E);
+    __syncthreads();
+    ntt_stages29<GMAX, THREADS, true>(A, lo, hi, top, base, E, true, false);   // inverse half; its post table is applied, limbs stay unpacked
+    PassArgs F = A;
+    F.tw = A.tw2;
+    F.pre = nullptr;
+    F.post = nullptr;
+    F.has_post_const = 0;
+    ntt_stages29<GMAX, THREADS, false>(F, lo, hi, top, base, E, false, true);  // forward half
+    tile_copy_out<THREADS>(A, lo, hi, base, E);
 }
 
 // a[i] *= t[i]  (used when a transform has no stage to fold a scaling into: N == 1)
@@ -412,6 +442,36 @@ int get_domain(Slot* s, hipStream_t st, unsigned logn, unsigned need, Domain** o
 static const bool g_ntt_g2 = !(getenv("ZKMI_NTT_G2") && atoi(getenv("ZKMI_NTT_G2")) == 0);
 static const bool g_ntt_saturated = getenv("ZKMI_NTT_SAT") && atoi(getenv("ZKMI_NTT_SAT")) == 1;  // A/B switch: the 8 x 32-bit butterflies
 
+struct PassPlan { unsigned bit_lo, k, logL; };
+// split of the index bits: the lowest kc bits form the contiguous pass (L = 1); the rest go to strided passes (increasing bit order)
+static std::vector<PassPlan> plan_passes(unsigned logn) {
+    unsigned kc = logn < TILE_LOG ? logn : TILE_LOG;
+    unsigned rest = logn - kc;
+    unsigned np = (rest + K_STRIDED - 1) / K_STRIDED;
+    std::vector<PassPlan> passes;
+    passes.push_back({0, kc, 0});
+    unsigned bit = kc;
+    for (unsigned i = 0; i < np; i++) {
+        unsigned k = (rest - (bit - kc) + (np - i) - 1) / (np - i);
+        unsigned logL = TILE_LOG - k;
+        if (logL > bit) logL = bit;  // rows of L consecutive low-order neighbours; the tile always holds up to 2^TILE_LOG elements
+        passes.push_back({bit, k, logL});
+        bit += k;
+    }
+    return passes;
+}
+
+static int launch_pass(Slot* s, hipStream_t st, const PassArgs& A, bool sat) {
+    unsigned E = 1u << (A.k + A.logL);
+    size_t tiles = ((size_t)1 << A.logn) / E;
+    const char* name = A.logL ? "ntt_pass_strided" : "ntt_pass_contig";
+    if (sat) ZK_LAUNCH(s, st, name, k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 32, A);
+    else if (g_ntt_g2) ZK_LAUNCH(s, st, name, (k_ntt_pass29<2, 512>), dim3((unsigned)tiles), dim3(512), (size_t)E * 36, A);
+    else ZK_LAUNCH(s, st, name, (k_ntt_pass29<3, 256>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 36, A);
+    return ZK_OK;
+}
+
+// Runs the log2(N) stages of one transform as a sequence of tile passes.
 static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int inverse, int dif, const Fr* pre, const Fr* post,
                       const Fr* post_const) {
     const unsigned logn = dom->logn;
@@ -422,38 +482,56 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int 
         if (post) ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3(1), dim3(64), 0, data, post, (size_t)1);
         return ZK_OK;  // 1/N = 1
     }
-    // split the index bits: the lowest kc bits form the contiguous pass (L = 1); the rest go to strided passes
-    unsigned kc = logn < TILE_LOG ? logn : TILE_LOG;
-    unsigned rest = logn - kc;
-    unsigned np = (rest + K_STRIDED - 1) / K_STRIDED;
-    struct P { unsigned bit_lo, k, logL; };
-    std::vector<P> passes;  // in increasing bit order
-    passes.push_back({0, kc, 0});
-    unsigned bit = kc;
-    for (unsigned i = 0; i < np; i++) {
-        unsigned k = (rest - (bit - kc) + (np - i) - 1) / (np - i);
-        unsigned logL = TILE_LOG - k;
-        if (logL > bit) logL = bit;  // rows of L consecutive low-order neighbours; the tile always holds up to 2^TILE_LOG elements
-        passes.push_back({bit, k, logL});
-        bit += k;
-    }
+    std::vector<PassPlan> passes = plan_passes(logn);
     size_t npass = passes.size();
     for (size_t idx = 0; idx < npass; idx++) {
         // DIF walks the bits from the top, DIT from the bottom
-        const P& p = dif ? passes[npass - 1 - idx] : passes[idx];
+        const PassPlan& p = dif ? passes[npass - 1 - idx] : passes[idx];
         PassArgs A;
-        A.data = data; A.tw = tw; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
+        A.data = data; A.tw = tw; A.tw2 = nullptr; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
         A.pre = (idx == 0) ? pre : nullptr;
         A.post = (idx + 1 == npass) ? post : nullptr;
         A.has_post_const = (idx + 1 == npass && post_const && !post) ? 1 : 0;
         if (A.has_post_const) A.post_const = *post_const; else A.post_const = Fr::zero();
-        unsigned E = 1u << (p.k + p.logL);
-        size_t tiles = ((size_t)1 << logn) / E;
         A.canonical = (idx + 1 == npass) ? 1 : 0;
-        const char* name = p.logL ? "ntt_pass_strided" : "ntt_pass_contig";
-        if (sat) ZK_LAUNCH(s, st, name, k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 32, A);
-        else if (g_ntt_g2) ZK_LAUNCH(s, st, name, (k_ntt_pass29<2, 512>), dim3((unsigned)tiles), dim3(512), (size_t)E * 36, A);
-        else ZK_LAUNCH(s, st, name, (k_ntt_pass29<3, 256>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 36, A);
+        ZK_TRY(launch_pass(s, st, A, sat));
+    }
+    return ZK_OK;
+}
+
+// FFTInverse(DIF) with `mid` applied at its end (1/N and whatever scaling follows), then FFT(DIT): as run_passes twice, but the two
+// contiguous passes in the middle are ONE kernel (k_ntt_pass29_if).
+static const bool g_ntt_fuse_if = !(getenv("ZKMI_NTT_FUSE") && atoi(getenv("ZKMI_NTT_FUSE")) == 0);  // A/B switch
+static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* dom, const Fr* mid) {
+    const unsigned logn = dom->logn;
+    if (g_ntt_saturated || !g_ntt_fuse_if || logn == 0) {
+        ZK_TRY(run_passes(s, st, data, dom, 1, 1, nullptr, mid, nullptr));
+        return run_passes(s, st, data, dom, 0, 0, nullptr, nullptr, nullptr);
+    }
+    std::vector<PassPlan> passes = plan_passes(logn);
+    const size_t npass = passes.size();
+    PassArgs A;
+    A.data = data; A.logn = logn; A.pre = nullptr; A.post = nullptr; A.has_post_const = 0; A.post_const = Fr::zero(); A.tw2 = nullptr;
+    for (size_t idx = npass - 1; idx >= 1; idx--) {  // strided passes of the inverse transform, top bits first
+        const PassPlan& p = passes[idx];
+        A.tw = dom->tw29_inv; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = 1; A.canonical = 0;
+        ZK_TRY(launch_pass(s, st, A, false));
+    }
+    {
+        const PassPlan& p = passes[0];
+        A.tw = dom->tw29_inv; A.tw2 = dom->tw29; A.bit_lo = 0; A.k = p.k; A.logL = 0; A.dif = 1; A.post = mid;
+        A.canonical = (npass == 1) ? 1 : 0;
+        unsigned E = 1u << p.k;
+        size_t tiles = ((size_t)1 << logn) / E;
+        if (g_ntt_g2) ZK_LAUNCH(s, st, "ntt_pass_contig_if", (k_ntt_pass29_if<2, 512>), dim3((unsigned)tiles), dim3(512), (size_t)E * 36, A);
+        else ZK_LAUNCH(s, st, "ntt_pass_contig_if", (k_ntt_pass29_if<3, 256>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 36, A);
+        A.post = nullptr;
+        A.tw2 = nullptr;
+    }
+    for (size_t idx = 1; idx < npass; idx++) {  // strided passes of the forward transform, low bits first
+        const PassPlan& p = passes[idx];
+        A.tw = dom->tw29; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = 0; A.canonical = (idx + 1 == npass) ? 1 : 0;
+        ZK_TRY(launch_pass(s, st, A, false));
     }
     return ZK_OK;
 }
@@ -464,6 +542,8 @@ static int ensure_lds_attr() {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 32));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29_if<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29_if<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         g_lds_attr_set = true;
     }
     return ZK_OK;
@@ -507,8 +587,7 @@ int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned log
     ZK_TRY(get_domain(s, st, logN, DOM_TW | DOM_TW_INV | DOM_COSET_REV_N | DOM_COSET_INV_N_REV, &d));
     size_t N = (size_t)1 << logN;
     for (Fr* v : {a, b, c}) {
-        ZK_TRY(run_passes(s, st, v, d, 1, 1, nullptr, d->coset_rev_n, nullptr));
-        ZK_TRY(run_passes(s, st, v, d, 0, 0, nullptr, nullptr, nullptr));
+        ZK_TRY(run_inverse_forward(s, st, v, d, d->coset_rev_n));
     }
     // den = 1 / (g^N - 1)
     HFr gN = d->coset;
@@ -618,8 +697,7 @@ int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* 
             return ZK_OK;
         case 1:  // blocks: rest of FFTInverse(DIF), * 1/D * g^bitrev(i), block part of FFT(DIT, coset)
             for (Fr* v : {a, b, c}) {
-                ZK_TRY(run_passes(s, st, v, dM, 1, 1, nullptr, tb.coset_rev_n, nullptr));
-                ZK_TRY(run_passes(s, st, v, dM, 0, 0, nullptr, nullptr, nullptr));
+                ZK_TRY(run_inverse_forward(s, st, v, dM, tb.coset_rev_n));
             }
             return ZK_OK;
         case 2: {  // transposed: cross stages of FFT(DIT); pointwise; cross stages of the final FFTInverse(DIF, coset)
