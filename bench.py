@@ -128,7 +128,8 @@ def main():
         sess = par.groth16_msm5_pk_begin(pk, d_w.ptr)  # digits / sort / task plan of w run under computeH and its exchanges
         side = torch.cuda.ExternalStream(par.groth16_session_stream(sess))  # the library's computeH stream, shared with torch / RCCL
         with torch.cuda.stream(side):
-            a, b, c = (t.clone() for t in t_abc)  # the prover consumes its inputs, like the single-GPU call's internal copies
+            # the prover consumes its working buffers: at N > 1 the first all-to-all already writes fresh ones, at N = 1 copy
+            a, b, c = (t.clone() for t in t_abc) if world == 1 else t_abc
             h = par.compute_h_sharded(a, b, c, log_ng, rank, world)
             rec = par.groth16_msm5_pk_end(sess, h.data_ptr(), side.cuda_stream)
             return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)

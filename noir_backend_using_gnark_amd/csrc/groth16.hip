@@ -610,13 +610,17 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     int rc = ZK_OK;
     Fr* d_abc[3] = {nullptr, nullptr, nullptr};
     const void* src[3] = {a, b, c};
+    // full-length inputs already in HBM are read in place by the first NTT pass (they stay untouched); otherwise copy / pad first
+    const bool direct = on_device && n_constraints == N && N > 1;
     for (int i = 0; i < 3 && rc == ZK_OK; i++) {
         d_abc[i] = (Fr*)s0->alloc(N * 32);
+        if (direct) continue;
         if (n_constraints && hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
         if (n_constraints < N && hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemsetAsync failed");
     }
     // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
-    if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain);
+    const Fr* in_place_src[3] = {(const Fr*)a, (const Fr*)b, (const Fr*)c};
+    if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain, direct ? in_place_src : nullptr);
     hipEvent_t ev_h = nullptr;
     if (rc == ZK_OK && hipEventCreateWithFlags(&ev_h, hipEventDisableTiming) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventCreate failed");
     if (rc == ZK_OK && hipEventRecord(ev_h, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventRecord failed");

@@ -55,6 +55,7 @@ struct PassArgs {
     int dif, has_post_const;
     int canonical;       // 29-bit-limb passes: last pass of the transform -> canonical image; else a lazily reduced 256-bit intermediate
     const Fr* tw2;       // fused inverse-then-forward pass (k_ntt_pass29_if): twiddles of the forward half
+    const Fr* src;       // 29-bit-limb passes: read the tile from here instead of `data` (first pass of an out-of-place transform) or null
 };
 
 __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, unsigned t) {
@@ -281,7 +282,7 @@ __device__ __forceinline__ void ntt_stages29(const PassArgs& A, uint4* lo, uint4
 template <unsigned THREADS>
 __device__ __forceinline__ void tile_copy_in(const PassArgs& A, uint4* lo, uint4* hi, size_t base, unsigned E) {
     const unsigned L = 1u << A.logL;
-    const uint4* g = reinterpret_cast<const uint4*>(A.data);
+    const uint4* g = reinterpret_cast<const uint4*>(A.src ? A.src : A.data);
     for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
         unsigned e = h >> 1, half = h & 1;
         unsigned mid = e >> A.logL, l = e & (L - 1);
@@ -488,7 +489,7 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int 
         // DIF walks the bits from the top, DIT from the bottom
         const PassPlan& p = dif ? passes[npass - 1 - idx] : passes[idx];
         PassArgs A;
-        A.data = data; A.tw = tw; A.tw2 = nullptr; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
+        A.data = data; A.tw = tw; A.tw2 = nullptr; A.src = nullptr; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
         A.pre = (idx == 0) ? pre : nullptr;
         A.post = (idx + 1 == npass) ? post : nullptr;
         A.has_post_const = (idx + 1 == npass && post_const && !post) ? 1 : 0;
@@ -502,9 +503,11 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int 
 // FFTInverse(DIF) with `mid` applied at its end (1/N and whatever scaling follows), then FFT(DIT): as run_passes twice, but the two
 // contiguous passes in the middle are ONE kernel (k_ntt_pass29_if).
 static const bool g_ntt_fuse_if = !(getenv("ZKMI_NTT_FUSE") && atoi(getenv("ZKMI_NTT_FUSE")) == 0);  // A/B switch
-static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* dom, const Fr* mid) {
+static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* dom, const Fr* mid, const Fr* src = nullptr) {
+    // src (optional): the input lives there and stays untouched -- the first pass reads it and writes `data`
     const unsigned logn = dom->logn;
     if (g_ntt_saturated || !g_ntt_fuse_if || logn == 0) {
+        if (src && src != data) ZK_HIP(hipMemcpyAsync(data, src, sizeof(Fr) << logn, hipMemcpyDeviceToDevice, st));
         ZK_TRY(run_passes(s, st, data, dom, 1, 1, nullptr, mid, nullptr));
         return run_passes(s, st, data, dom, 0, 0, nullptr, nullptr, nullptr);
     }
@@ -512,10 +515,12 @@ static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* 
     const size_t npass = passes.size();
     PassArgs A;
     A.data = data; A.logn = logn; A.pre = nullptr; A.post = nullptr; A.has_post_const = 0; A.post_const = Fr::zero(); A.tw2 = nullptr;
+    A.src = (src && src != data) ? src : nullptr;  // consumed by whichever pass runs first
     for (size_t idx = npass - 1; idx >= 1; idx--) {  // strided passes of the inverse transform, top bits first
         const PassPlan& p = passes[idx];
         A.tw = dom->tw29_inv; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = 1; A.canonical = 0;
         ZK_TRY(launch_pass(s, st, A, false));
+        A.src = nullptr;
     }
     {
         const PassPlan& p = passes[0];
@@ -527,6 +532,7 @@ static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* 
         else ZK_LAUNCH(s, st, "ntt_pass_contig_if", (k_ntt_pass29_if<3, 256>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 36, A);
         A.post = nullptr;
         A.tw2 = nullptr;
+        A.src = nullptr;
     }
     for (size_t idx = 1; idx < npass; idx++) {  // strided passes of the forward transform, low bits first
         const PassPlan& p = passes[idx];
@@ -581,14 +587,14 @@ int bit_reverse_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn) {
 //   3 x FFTInverse(DIF) ; 3 x FFT(DIT, coset) ; a = (a*b - c) / (g^N - 1) ; FFTInverse(a, DIF, coset)
 // The 1/N of the first inverse and the coset pre-scale g^bitrev(i) of the following forward transform are one
 // table (coset_rev_n) applied while the inverse transform stores its last stage.
-int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned logN) {
+int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned logN, const Fr* const* src) {
+    // src (optional): the three inputs live in src[0..2] (full 2^logN vectors) and are left untouched; a, b, c are then pure outputs / scratch
     ZK_TRY(ensure_lds_attr());
     Domain* d;
     ZK_TRY(get_domain(s, st, logN, DOM_TW | DOM_TW_INV | DOM_COSET_REV_N | DOM_COSET_INV_N_REV, &d));
     size_t N = (size_t)1 << logN;
-    for (Fr* v : {a, b, c}) {
-        ZK_TRY(run_inverse_forward(s, st, v, d, d->coset_rev_n));
-    }
+    Fr* vs[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) ZK_TRY(run_inverse_forward(s, st, vs[i], d, d->coset_rev_n, src ? src[i] : nullptr));
     // den = 1 / (g^N - 1)
     HFr gN = d->coset;
     for (unsigned i = 0; i < logN; i++) gN = gN.sqr();
