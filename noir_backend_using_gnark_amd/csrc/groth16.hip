@@ -248,7 +248,8 @@ struct Msm5State {
 // that the GPU is busy while the host is still enqueuing computeH and prepare(h).
 // scalar side of the four MSMs over the wire values (digits, sort, task plan) on slot 4's stream
 static int msm5_prepare_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S) {
-    hipStream_t st4 = sl[4]->stream_hi;
+    static const bool low = getenv("ZKMI_PREPW_LOW") && atoi(getenv("ZKMI_PREPW_LOW")) == 1;  // experiment: normal priority under computeH
+    hipStream_t st4 = low ? sl[4]->stream : sl[4]->stream_hi;
     if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
     if (in.tab_w) return msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w);
     return msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w);
@@ -625,7 +626,8 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     if (rc == ZK_OK && hipEventCreateWithFlags(&ev_h, hipEventDisableTiming) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventCreate failed");
     if (rc == ZK_OK && hipEventRecord(ev_h, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventRecord failed");
     Fr* d_w = (Fr*)s0->alloc(nw * 32 + 16);
-    if (rc == ZK_OK && nw && hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+    if (on_device) d_w = (Fr*)const_cast<void*>(w);  // wire values already in HBM are only read: no staging copy
+    else if (rc == ZK_OK && nw && hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
     in.d_w = d_w;
     in.d_wk = d_w + P.n_public;
     in.d_h = d_abc[0];
