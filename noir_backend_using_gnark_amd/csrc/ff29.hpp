@@ -365,6 +365,72 @@ __device__ __forceinline__ void acc29_add(Acc29& A, const Acc29& Bq) {  // add-2
     A.y = Y3;
 }
 
+// ---- the same two operations spread over a QUAD of lanes: a point addition is 14 products of dependency depth 4 (a doubling: 10 of
+// depth 3), and the last reduction tail of a proof runs on an otherwise idle machine where only the LENGTH of the serial chain counts.
+// All four lanes of a quad hold the same operands; in every round each lane multiplies a different pair and the four products are
+// broadcast back by DPP quad permutes.  Same formulas, same bias multiples, same bounds as acc29_add / acc29_dbl above.
+template <int K>
+__device__ __forceinline__ U29 u29_quad_bcast(const U29& x) {  // the value held by lane K of the quad, in all four lanes
+    U29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, false);
+    return r;
+}
+__device__ __forceinline__ U29 u29_sel4(unsigned q, const U29& a0, const U29& a1, const U29& a2, const U29& a3) {
+    // by masks, not by ?: -- hipcc turns a chain of conditional member reads into a select of ADDRESSES and parks the operands in scratch
+    const uint32_t m0 = 0u - (uint32_t)(q == 0), m1 = 0u - (uint32_t)(q == 1), m2 = 0u - (uint32_t)(q == 2), m3 = 0u - (uint32_t)(q == 3);
+    U29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (a0.l[i] & m0) | (a1.l[i] & m1) | (a2.l[i] & m2) | (a3.l[i] & m3);
+    return r;
+}
+__device__ __forceinline__ void acc29_dbl_quad(Acc29& A, unsigned q) {
+    if (A.inf) return;
+    const U29 U = u29_add(A.y, A.y);
+    U29 m = u29_mul(u29_sel4(q, U, A.x, U, U), u29_sel4(q, U, A.x, U, U));                    // round 1: U*U, X*X
+    const U29 V = u29_quad_bcast<0>(m), X2 = u29_quad_bcast<1>(m);
+    const U29 M = u29_wnorm(u29_add(u29_add(X2, X2), X2));
+    m = u29_mul(u29_sel4(q, U, A.x, M, V), u29_sel4(q, V, V, M, A.zz));                          // round 2: U*V, X*V, M*M, V*ZZ
+    const U29 Wv = u29_quad_bcast<0>(m), S = u29_quad_bcast<1>(m), ZZ3 = u29_quad_bcast<3>(m);
+    U29 t = u29_quad_bcast<2>(m);
+    t = u29_sub<8>(t, S);
+    const U29 X3 = u29_wnorm(u29_sub<8>(t, S));
+    const U29 d = u29_wnorm(u29_sub<24>(S, X3));
+    m = u29_mul(u29_sel4(q, M, Wv, Wv, M), u29_sel4(q, d, A.y, A.zzz, d));                        // round 3: M*d, W*Y, W*ZZZ
+    A.y = u29_wnorm(u29_sub<4>(u29_quad_bcast<0>(m), u29_quad_bcast<1>(m)));
+    A.zzz = u29_quad_bcast<2>(m);
+    A.zz = ZZ3;
+    A.x = X3;
+}
+__device__ __forceinline__ void acc29_add_quad(Acc29& A, const Acc29& Bq, unsigned q) {
+    if (Bq.inf) return;
+    if (A.inf) { A = Bq; return; }
+    U29 m = u29_mul(u29_sel4(q, A.x, Bq.x, A.y, Bq.y), u29_sel4(q, Bq.zz, A.zz, Bq.zzz, A.zzz));  // round 1: U1, U2, S1, S2
+    const U29 U1 = u29_quad_bcast<0>(m), S1 = u29_quad_bcast<2>(m);
+    const U29 P = u29_wnorm(u29_sub<8>(u29_quad_bcast<1>(m), U1));
+    const U29 R = u29_wnorm(u29_sub<8>(u29_quad_bcast<3>(m), S1));
+    m = u29_mul(u29_sel4(q, P, R, A.zz, A.zzz), u29_sel4(q, P, R, Bq.zz, Bq.zzz));                // round 2: P*P, R*R, ZZ1*ZZ2, ZZZ1*ZZZ2
+    const U29 PP = u29_quad_bcast<0>(m), RR = u29_quad_bcast<1>(m), ZZ12 = u29_quad_bcast<2>(m), ZZZ12 = u29_quad_bcast<3>(m);
+    if (u29_mulout3_is_zero(PP)) {
+        // same x: doubling or P + (-P); R*R is a product output (< 3 p), so the same test applies (uniform over the quad)
+        if (u29_mulout3_is_zero(RR)) acc29_dbl_quad(A, q);
+        else A.inf = true;
+        return;
+    }
+    m = u29_mul(u29_sel4(q, P, U1, ZZ12, P), PP);                                                  // round 3: P*PP, U1*PP, ZZ12*PP
+    const U29 PPP = u29_quad_bcast<0>(m), Q = u29_quad_bcast<1>(m), ZZ3 = u29_quad_bcast<2>(m);
+    U29 t = u29_wnorm(u29_sub<4>(RR, PPP));
+    t = u29_sub<4>(t, Q);
+    t = u29_sub<4>(t, Q);
+    const U29 X3 = u29_wnorm(t);
+    const U29 d = u29_wnorm(u29_sub<16>(Q, X3));
+    m = u29_mul(u29_sel4(q, R, S1, ZZZ12, R), u29_sel4(q, d, PPP, PPP, d));                        // round 4: R*d, S1*PPP, ZZZ12*PPP
+    A.y = u29_wnorm(u29_sub<4>(u29_quad_bcast<0>(m), u29_quad_bcast<1>(m)));
+    A.zzz = u29_quad_bcast<2>(m);
+    A.zz = ZZ3;
+    A.x = X3;
+}
+
 // ------------------------------------------------------------------------------------------------------------ G2 (Fp2)
 // Components are lazily reduced U29 values.  Operation order, bias multiples and the two contractions are exactly those of
 // tools/u29_model.py::madd_fp2, whose bound propagation closes at x, y < 2 p, zz, zzz < 10.6 p.

@@ -336,6 +336,11 @@ static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm
             if (S->jobs[i].acc_done) prev = S->jobs[i].acc_done;
         S->jobs[0].gate_acc = prev;
     }
+    // ZKMI_QUAD_TAIL=1 (experiment switch): wave levels of Z's reduction tail -- the only tail nothing can hide -- with four lanes per
+    // point.  Measured: those levels shrink 0.39 -> 0.27 ms under the profiler but the proof does not (10.6-10.8 ms either way), and
+    // level 1, which already fills every SIMD, gets 3x slower in that form; off by default.
+    static const bool quad_tail = getenv("ZKMI_QUAD_TAIL") && atoi(getenv("ZKMI_QUAD_TAIL")) == 1;
+    S->jobs[0].quad_tail = quad_tail;
     ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
     return ZK_OK;
 }

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32
 // product); G2 keeps the canonical saturated form.  TailPt<F> hides the difference from the three tail kernels.
 template <class F>
 struct TailPt {
+    static constexpr unsigned LPP = 1;  // lanes per point
     XYZZ<F> v;
     static __device__ __forceinline__ TailPt inf() { return TailPt{XYZZ<F>::inf()}; }
     static __device__ __forceinline__ TailPt load(const XYZZ<F>* p) { return TailPt{gload(p)}; }
@@ -298,6 +299,7 @@ struct TailPt {
 };
 template <>
 struct TailPt<Fp> {
+    static constexpr unsigned LPP = 1;
     Acc29 v;
     static __device__ __forceinline__ TailPt inf() { TailPt t; t.v.inf = true; for (int i = 0; i < 9; i++) t.v.x.l[i] = t.v.y.l[i] = t.v.zz.l[i] = t.v.zzz.l[i] = 0; return t; }
     static __device__ __forceinline__ TailPt load(const XYZZ<Fp>* p) { TailPt t; acc29_load(t.v, gload(p)); return t; }
@@ -320,6 +322,35 @@ struct TailPt<Fp> {
 #pragma unroll
         for (unsigned i = 0; i < 36; i++) o[i] = __shfl_xor(s[i], d, 64);
         r.v.inf = __shfl_xor((int)v.inf, d, 64) != 0;
+        return r;
+    }
+};
+
+// G1, four lanes per point (acc29_add_quad / acc29_dbl_quad): every lane of a quad carries the same point; 16 points per wave.
+struct TailPtQ {
+    static constexpr unsigned LPP = 4;
+    Acc29 v;
+    static __device__ __forceinline__ TailPtQ inf() { TailPtQ t; t.v.inf = true; for (int i = 0; i < 9; i++) t.v.x.l[i] = t.v.y.l[i] = t.v.zz.l[i] = t.v.zzz.l[i] = 0; return t; }
+    static __device__ __forceinline__ TailPtQ load(const XYZZ<Fp>* p) { TailPtQ t; acc29_load(t.v, gload(p)); return t; }
+    __device__ __forceinline__ void store(XYZZ<Fp>* p) const { gstore(p, acc29_to_xyzz(v)); }
+    __device__ __forceinline__ void add(const TailPtQ& o) { acc29_add_quad(v, o.v, threadIdx.x & 3u); }
+    __device__ __forceinline__ void dbl() { acc29_dbl_quad(v, threadIdx.x & 3u); }
+    __device__ __forceinline__ TailPtQ shfl_down(unsigned d) const {  // d counted in points
+        TailPtQ r;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+        uint32_t* o = reinterpret_cast<uint32_t*>(&r.v);
+#pragma unroll
+        for (unsigned i = 0; i < 36; i++) o[i] = __shfl_down(s[i], d * 4, 64);
+        r.v.inf = __shfl_down((int)v.inf, d * 4, 64) != 0;
+        return r;
+    }
+    __device__ __forceinline__ TailPtQ shfl_xor(unsigned d) const {
+        TailPtQ r;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+        uint32_t* o = reinterpret_cast<uint32_t*>(&r.v);
+#pragma unroll
+        for (unsigned i = 0; i < 36; i++) o[i] = __shfl_xor(s[i], d * 4, 64);
+        r.v.inf = __shfl_xor((int)v.inf, d * 4, 64) != 0;
         return r;
     }
 };
@@ -386,55 +417,59 @@ __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint
 // Invariant carried through the levels, per window:  value = sum_j A[j] + 2^sh * sum_j j * S[j]   (j = 0..N-1).
 // Level 1 (thread-serial, m buckets per thread): buckets X_k (weight k+1) -> A'[q] = sum_l (l+1) X_{qm+l},
 // S'[q] = sum_l X_{qm+l}; then value = sum A' + m * sum q S'.
-template <class F>
+template <class F, class PT = TailPt<F>>
 __global__ __launch_bounds__(256) void k_reduce_l1(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t B,
                                                    uint32_t W, uint32_t m, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
     uint32_t N1 = B / m;
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / PT::LPP;  // PT::LPP lanes share one chunk of m buckets
     if (g >= W * N1) return;
     uint32_t w = g / N1, q = g % N1;
     uint32_t b0 = w * B + q * m;
-    TailPt<F> run = TailPt<F>::inf(), acc = TailPt<F>::inf();
+    PT run = PT::inf(), acc = PT::inf();
     for (int l = (int)m - 1; l >= 0; l--) {
         uint32_t b = b0 + l;
         uint32_t t0 = task_off[b];
-        if (task_off[b + 1] > t0) run.add(TailPt<F>::load(partial + t0));
+        if (task_off[b + 1] > t0) run.add(PT::load(partial + t0));
         acc.add(run);
     }
-    acc.store(A_out + g);
-    run.store(S_out + g);
+    if (threadIdx.x % PT::LPP == 0) {
+        acc.store(A_out + g);
+        run.store(S_out + g);
+    }
 }
 
 // Wave-cooperative level: 64 consecutive entries per wave (lane = l).
 //   S' = sum_l S_l ;  A' = sum_l A_l + 2^sh * sum_l l * S_l ;   next shift = sh + 6
 // suffix scan of S (6 shuffle steps), per-lane doublings, one butterfly reduction.
-template <class F>
+// FAN = 64 / PT::LPP entries per wave; next shift = sh + log2(FAN).
+template <class F, class PT = TailPt<F>>
 __global__ __launch_bounds__(64) void k_reduce_wave(const XYZZ<F>* __restrict__ A_in, const XYZZ<F>* __restrict__ S_in, uint32_t N, uint32_t W,
                                                     uint32_t sh, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
-    uint32_t Nout = (N + 63) / 64;
+    constexpr uint32_t FAN = 64 / PT::LPP;
+    uint32_t Nout = (N + FAN - 1) / FAN;
     uint32_t chunk = blockIdx.x;  // W * Nout chunks
     uint32_t w = chunk / Nout, q = chunk % Nout;
-    uint32_t lane = threadIdx.x;
-    uint32_t j = q * 64 + lane;
-    TailPt<F> s = TailPt<F>::inf(), a = TailPt<F>::inf();
+    uint32_t lane = threadIdx.x / PT::LPP;
+    uint32_t j = q * FAN + lane;
+    PT s = PT::inf(), a = PT::inf();
     if (j < N) {
-        s = TailPt<F>::load(S_in + (size_t)w * N + j);
-        a = TailPt<F>::load(A_in + (size_t)w * N + j);
+        s = PT::load(S_in + (size_t)w * N + j);
+        a = PT::load(A_in + (size_t)w * N + j);
     }
     // inclusive suffix sums: s_l = sum_{u >= l} S_u
-    for (unsigned d = 1; d < 64; d <<= 1) {
-        TailPt<F> t = s.shfl_down(d);
-        if (lane + d < 64) s.add(t);
+    for (unsigned d = 1; d < FAN; d <<= 1) {
+        PT t = s.shfl_down(d);
+        if (lane + d < FAN) s.add(t);
     }
-    TailPt<F> y = s;  // lane 0 holds the plain sum S'
-    if (lane == 0) y = TailPt<F>::inf();
+    PT y = s;  // lane 0 holds the plain sum S'
+    if (lane == 0) y = PT::inf();
     for (uint32_t i = 0; i < sh; i++) y.dbl();  // 2^sh * suffix_l, in parallel on the lanes
     y.add(a);
-    for (unsigned d = 32; d > 0; d >>= 1) {
-        TailPt<F> t = y.shfl_xor(d);
+    for (unsigned d = FAN / 2; d > 0; d >>= 1) {
+        PT t = y.shfl_xor(d);
         y.add(t);
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         s.store(S_out + chunk);
         y.store(A_out + chunk);
     }
@@ -698,8 +733,13 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         hipStream_t st = sts[b];
         ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
         // ---- 6. bucket reduce
-        ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial[b], R.task_off,
-                  B, W, m1, lvlA[b][0], lvlS[b][0]);
+        bool quad = false;
+        if constexpr (sizeof(F) == sizeof(Fp)) quad = jobs[b]->quad_tail;
+        const uint32_t lpp = quad ? 4 : 1, fan = 64 / lpp, fan_log = quad ? 4 : 6;
+        // level 1 fills every SIMD with one wave already (it is throughput-bound: measured, four lanes per point make it 3x SLOWER);
+        // only the wave levels after it, which cannot fill the machine, gain from the shorter serial chain
+        ZK_LAUNCH(s, st, "msm_reduce_l1", (k_reduce_l1<F>), dim3((unsigned)(((size_t)W * N1 + 255) / 256)), dim3(256), 0, (const Pt*)partial[b], R.task_off, B, W,
+                  m1, lvlA[b][0], lvlS[b][0]);
         uint32_t N = N1, sh = 0;
         for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;  // value = sum A + 2^sh * sum j S_j
         int cur = 0;
@@ -707,12 +747,14 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         // has few windows to do (table mode: one)
         const uint32_t host_n = (W * 64 <= 64) ? 64 : 1;
         while (N > host_n) {
-            uint32_t Nout = (N + 63) / 64;
-            ZK_LAUNCH(s, st, "msm_reduce_wave", (k_reduce_wave<F>), dim3(W * Nout), dim3(64), 0, (const Pt*)lvlA[b][cur], (const Pt*)lvlS[b][cur], N, W,
-                      sh, lvlA[b][cur ^ 1], lvlS[b][cur ^ 1]);
+            uint32_t Nout = (N + fan - 1) / fan;
+            if constexpr (sizeof(F) == sizeof(Fp)) {
+                if (quad) ZK_LAUNCH(s, st, "msm_reduce_wave", (k_reduce_wave<F, TailPtQ>), dim3(W * Nout), dim3(64), 0, (const Pt*)lvlA[b][cur], (const Pt*)lvlS[b][cur], N, W, sh, lvlA[b][cur ^ 1], lvlS[b][cur ^ 1]);
+            }
+            if (!quad) ZK_LAUNCH(s, st, "msm_reduce_wave", (k_reduce_wave<F>), dim3(W * Nout), dim3(64), 0, (const Pt*)lvlA[b][cur], (const Pt*)lvlS[b][cur], N, W, sh, lvlA[b][cur ^ 1], lvlS[b][cur ^ 1]);
             cur ^= 1;
             N = Nout;
-            sh += 6;
+            sh += fan_log;
         }
         // ---- 7. last-level entries -> pinned host memory (final combination and Horner happen in msm_finish)
         jobs[b]->n_final = N;
