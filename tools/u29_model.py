@@ -67,6 +67,43 @@ def mul_exact(a, b):
     return r
 
 
+def sqr_exact(a):
+    """a * a with the cross products taken once against d = 2a (the ZKMI_MONT_SQR29_ASM schedule)."""
+    d = [2 * x for x in a]
+    assert all(x < 1 << 32 for x in d)
+    acc = 0
+    m = [0] * NL
+    r = [0] * NL
+    def column(k):
+        s = 0
+        for i in range(max(0, k - NL + 1), min(k, NL - 1) + 1):
+            j = k - i
+            if i < j:
+                s += a[i] * d[j]
+            elif i == j:
+                s += a[i] * a[i]
+        return s
+    for k in range(NL):
+        acc += column(k)
+        for j in range(k):
+            acc += m[j] * PL[k - j]
+        assert acc < 1 << 64, "column overflow"
+        m[k] = ((acc & 0xffffffff) * NINV) & MASK
+        acc += m[k] * PL[0]
+        assert acc < 1 << 64 and acc & MASK == 0
+        acc >>= W
+    for k in range(NL, 2 * NL - 1):
+        acc += column(k)
+        for j in range(k - NL + 1, NL):
+            acc += m[j] * PL[k - j]
+        assert acc < 1 << 64, "column overflow"
+        r[k - NL] = acc & MASK
+        acc >>= W
+    assert acc < 1 << 32
+    r[NL - 1] = acc
+    return r
+
+
 def mulN_exact(pairs):
     """(sum_t a_t * b_t) / 2^261 mod p, one reduction for all products (column accumulators shared)."""
     acc = 0
@@ -674,6 +711,10 @@ def main():
         a, b = rand_fe(), rand_fe()
         assert from_u29(mul_exact(to_u29(a), to_u29(b))) == a * b % Q
     print("  exact mul: ok")
+    for _ in range(2000):
+        a = [random.randrange(1 << 30) for _ in range(NL - 1)] + [random.randrange(1 << 24)]   # lazily reduced, un-normalised limbs
+        assert sqr_exact(a) == mul_exact(a, a)
+    print("  exact sqr (doubled-operand schedule) == mul(a, a): ok")
 
 
 if __name__ == "__main__":
