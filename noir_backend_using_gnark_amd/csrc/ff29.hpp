@@ -10,7 +10,7 @@
 // products of a column with no carry handling: 206 instructions per product instead of ~305; additions are 9 plain
 // v_add_u32; subtractions add a multiple of p whose limbs dominate the subtrahend's ("bias") and re-normalise in one
 // parallel pass.  Values are NOT canonical in flight: tools/u29_model.py propagates worst-case bounds through the exact
-// operation sequence of xyzz_madd29() to its fixed point (x < 13.5 p, y < 6 p, zz, zzz < 2 p, every limb < 2^32, every
+// operation sequence of xyzz_madd29() to its fixed point (x < 13.2 p, y, zz, zzz < 2 p, every limb < 2^32, every
 // column sum < 2^64) and cross-checks the limb algorithms against big integers.
 #pragma once
 #include "curve.hpp"
@@ -282,7 +282,7 @@ __device__ __forceinline__ void xyzz_madd29(Acc29& A, const Fp& px, const Fp& py
     const U29 U2 = u29_mul(x2, A.zz);
     const U29 S2 = u29_mul(y2, A.zzz);
     const U29 P = u29_wnorm(u29_sub<16>(U2, A.x));
-    const U29 R = u29_wnorm(u29_sub<8>(S2, A.y));
+    const U29 R = u29_wnorm(u29_sub<4>(S2, A.y));
     const U29 PP = u29_sqr(P);
     const U29 ZZ3 = u29_mul(A.zz, PP);
     if (u29_mulout_is_zero(ZZ3)) {
@@ -301,7 +301,7 @@ __device__ __forceinline__ void xyzz_madd29(Acc29& A, const Fp& px, const Fp& py
     t = u29_sub<4>(t, Q);
     const U29 X3 = u29_wnorm(t);
     const U29 d = u29_wnorm(u29_sub<16>(Q, X3));
-    const U29 Y3 = u29_wnorm(u29_sub<4>(u29_mul(R, d), u29_mul(A.y, PPP)));
+    const U29 Y3 = u29_mul2(R, d, u29_neg<4>(A.y), PPP);  // R d - Y1 PPP under ONE reduction: a direct product output (< 2 p)
     A.zzz = u29_mul(A.zzz, PPP);
     A.zz = ZZ3;
     A.x = X3;
@@ -347,7 +347,7 @@ __device__ __forceinline__ void acc29_dbl(Acc29& A) {  // dbl-2008-s-1
     t = u29_sub<8>(t, S);
     const U29 X3 = u29_wnorm(u29_sub<8>(t, S));
     const U29 d = u29_wnorm(u29_sub<24>(S, X3));
-    const U29 Y3 = u29_wnorm(u29_sub<4>(u29_mul(M, d), u29_mul(Wv, A.y)));
+    const U29 Y3 = u29_mul2(M, d, u29_neg<12>(Wv), A.y);
     A.zz = u29_mul(V, A.zz);
     A.zzz = u29_mul(Wv, A.zzz);
     A.x = X3;
@@ -375,7 +375,7 @@ __device__ __forceinline__ void acc29_add(Acc29& A, const Acc29& Bq) {  // add-2
     t = u29_sub<4>(t, Q);
     const U29 X3 = u29_wnorm(t);
     const U29 d = u29_wnorm(u29_sub<16>(Q, X3));
-    const U29 Y3 = u29_wnorm(u29_sub<4>(u29_mul(R, d), u29_mul(S1, PPP)));
+    const U29 Y3 = u29_mul2(R, d, u29_neg<8>(S1), PPP);
     A.zz = u29_mul(u29_mul(A.zz, Bq.zz), PP);
     A.zzz = u29_mul(u29_mul(A.zzz, Bq.zzz), PPP);
     A.x = X3;

@@ -286,7 +286,7 @@ def madd_fp(O, X1, Y1, ZZ1, ZZZ1, X2, Y2):
     t = O.sub(t, Qv, "g1.m")
     X3 = O.wnorm(t)
     d = O.wnorm(O.sub(Qv, X3, "g1.QX"))
-    Y3 = O.wnorm(O.sub(O.mul(R, d), O.mul(Y1, PPP), "g1.m"))
+    Y3 = O.mulN([(R, d), (O.neg(Y1, "g1.nY"), PPP)])   # R d - Y1 PPP under ONE reduction: a direct product output
     ZZ3 = O.mul(ZZ1, PP)
     ZZZ3 = O.mul(ZZZ1, PPP)
     return X3, Y3, ZZ3, ZZZ3
@@ -311,7 +311,7 @@ def add_fp(O, A, Bp):
     t = O.sub(t, Qv, "g1a.4")
     X3 = O.wnorm(t)
     d = O.wnorm(O.sub(Qv, X3, "g1a.16"))
-    Y3 = O.wnorm(O.sub(O.mul(R, d), O.mul(S1, PPP), "g1a.4"))
+    Y3 = O.mulN([(R, d), (O.neg(S1, "g1a.nS"), PPP)])
     ZZ3 = O.mul(O.mul(ZZ1, ZZ2), PP)
     ZZZ3 = O.mul(O.mul(ZZZ1, ZZZ2), PPP)
     return X3, Y3, ZZ3, ZZZ3
@@ -330,7 +330,7 @@ def dbl_fp(O, A):
     t = O.sub(t, S, "g1d.8")
     X3 = O.wnorm(O.sub(t, S, "g1d.8"))
     d = O.wnorm(O.sub(S, X3, "g1d.24"))
-    Y3 = O.wnorm(O.sub(O.mul(M, d), O.mul(Wv, Y1), "g1d.4"))
+    Y3 = O.mulN([(M, d), (O.neg(Wv, "g1d.nW"), Y1)])
     ZZ3 = O.mul(V, ZZ1)
     ZZZ3 = O.mul(Wv, ZZZ1)
     return X3, Y3, ZZ3, ZZZ3
