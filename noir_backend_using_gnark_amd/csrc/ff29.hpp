@@ -285,9 +285,11 @@ __device__ __forceinline__ void xyzz_madd29(Acc29& A, const Fp& px, const Fp& py
     const U29 R = u29_wnorm(u29_sub<4>(S2, A.y));
     const U29 PP = u29_sqr(P);
     const U29 ZZ3 = u29_mul(A.zz, PP);
-    if (u29_mulout_is_zero(ZZ3)) {
-        // P == 0 mod p: same x.  Doubling or P + (-P): rare, take the canonical saturated path (inline: an out-of-line
-        // call here costs the G1 kernel 25 VGPRs and a wave of occupancy).
+    if ((((ZZ3.l[0] & Fp29::MASK) * Fp29::PINV) & Fp29::MASK) < 2u) {
+        // ZZ3 = ZZ1 * P^2 is a product output < 2 p: it can only be == 0 mod p (P == 0: same x, i.e. doubling or P + (-P)) if
+        // ZZ3 / p mod 2^29 is 0 or 1 -- a three-instruction filter that never misses and fires wrongly once in 2^28.  Rare either
+        // way: take the canonical saturated path, which is correct for every input (inline: an out-of-line call here costs the G1
+        // kernel 25 VGPRs and a wave of occupancy).
         XYZZ<Fp> c = acc29_to_xyzz(A);
         c.madd(px, py);
         acc29_from_xyzz(A, c);
