@@ -167,6 +167,10 @@ int zk_bn254_groth16_msm5_session_stream(uint64_t session, void **stream_out);
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t *partials, size_t n_partials, const zk_fr *r,
                               const zk_fr *s, uint8_t proof_out[128]);
 
+/* What the MSM planner picks for n points (with / without resident window tables): window width c and the number of c-bit
+ * digits per scalar, i.e. mixed additions per scalar multiplication -- used by bench.py to turn launches into work. */
+int zk_bn254_msm_plan_info(size_t n, int window_tables, uint32_t *window_bits, uint32_t *digits);
+
 /* ---- felt-vector wire codec (the data format in front of the hot path) -------------------------------------------
  * The reference hands witness values to the Go side as hex( u32 BE count || count x 32 B BE canonical felts )
  * [REF src/gnark_backend_wrapper/serialize.rs:33-47,71-106; gnark_backend_ffi/internal/backend/helpers.go:24-33

@@ -1005,6 +1005,15 @@ static int msm_dev_impl(const void* d_points, const void* d_scalars, size_t n, c
 
 extern "C" {
 
+// what the planner picks for n points: the window width c and the number of c-bit digits per scalar (= mixed additions per scalar-mul)
+int zk_bn254_msm_plan_info(size_t n, int window_tables, uint32_t* window_bits, uint32_t* digits) {
+    if (!window_bits || !digits) return set_err(ZK_ERR_ARG, "null pointer");
+    unsigned c = window_tables ? msm_pick_window_table(n) : msm_pick_window(n);
+    *window_bits = c;
+    *digits = (255 + c - 1) / c;
+    return ZK_OK;
+}
+
 int zk_bn254_g1_msm(const zk_g1_affine* points, size_t n_points, const zk_fr* scalars, size_t n_scalars, const zk_msm_cfg* cfg, zk_g1_affine* out) {
     return msm_host_impl<0>(points, n_points, scalars, n_scalars, cfg, out);
 }
