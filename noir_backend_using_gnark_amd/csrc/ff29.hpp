@@ -529,8 +529,8 @@ __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2
     const U29x2 P = f2_sub29<4>(U2, A.x);
     const U29x2 R = f2_sub29<4>(S2, A.y);
     const U29 nP1 = u29_neg<8>(P.c1), nR1 = u29_neg<8>(R.c1);
-    U29x2 PP;
-    PP.c0 = u29_mul2(P.c0, P.c0, nP1, P.c1);
+    U29x2 PP;  // complex squaring: ((P0 + P1)(P0 - P1), 2 P0 P1) -- two products
+    PP.c0 = u29_mul(u29_add(P.c0, P.c1), u29_wnorm(u29_sub<8>(P.c0, P.c1)));
     PP.c1 = u29_mul(u29_add(P.c0, P.c0), P.c1);
     if (u29_mulout3_is_zero(PP.c1)) {
         // 2 P0 P1 == 0 mod p is NECESSARY for P == 0 (same x: doubling or P + (-P)); the canonical saturated path is correct
@@ -545,7 +545,7 @@ __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2
     const U29 W0 = u29_wnorm(u29_add(P.c0, u29_add(A.x.c0, A.x.c0))), W1 = u29_wnorm(u29_add(P.c1, u29_add(A.x.c1, A.x.c1)));
     const U29 nW0 = u29_neg<12>(W0), nW1 = u29_neg<12>(W1);
     U29x2 X3;
-    X3.c0 = u29_mul4(R.c0, R.c0, nR1, R.c1, nW0, PP.c0, W1, PP.c1);
+    X3.c0 = u29_mul3(u29_add(R.c0, R.c1), u29_wnorm(u29_sub<8>(R.c0, R.c1)), nW0, PP.c0, W1, PP.c1);  // R0^2 - R1^2 as ONE product
     X3.c1 = u29_mul3(u29_add(R.c0, R.c0), R.c1, nW0, PP.c1, nW1, PP.c0);
     const U29x2 d = f2_sub29<4>(Q, X3);
     const U29 nY0 = u29_neg<8>(A.y.c0), nY1 = u29_neg<8>(A.y.c1);

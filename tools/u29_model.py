@@ -451,15 +451,15 @@ def madd_fp2_fused(O, X1, Y1, ZZ1, ZZZ1, X2, Y2):
     R = f2_sub(O, S2, Y1, "g2f.P")
     nP1 = O.neg(P[1], "g2f.n")
     nR1 = O.neg(R[1], "g2f.n")
-    # PP = P^2 = (P0 P0 + nP1 P1, 2 P0 P1)
-    PP = (O.mulN([(P[0], P[0]), (nP1, P[1])]), O.mul(O.add(P[0], P[0]), P[1]))
+    # PP = P^2 = ((P0 + P1)(P0 - P1), 2 P0 P1): complex squaring, two products
+    PP = (O.mul(O.add(P[0], P[1]), O.wnorm(O.sub(P[0], P[1], "g2f.sq"))), O.mul(O.add(P[0], P[0]), P[1]))
     PPP = f2_mulF(O, P, PP, nP1)
     nX1 = O.neg(X1[1], "g2f.n")
     Qv = f2_mulF(O, X1, PP, nX1)
     # W = P + 2 X1 ; X3 = R^2 - W PP
     Wv = (O.wnorm(O.add(P[0], O.add(X1[0], X1[0]))), O.wnorm(O.add(P[1], O.add(X1[1], X1[1]))))
     nW0, nW1 = O.neg(Wv[0], "g2f.nW"), O.neg(Wv[1], "g2f.nW")
-    X3 = (O.mulN([(R[0], R[0]), (nR1, R[1]), (nW0, PP[0]), (Wv[1], PP[1])]),
+    X3 = (O.mulN([(O.add(R[0], R[1]), O.wnorm(O.sub(R[0], R[1], "g2f.sq"))), (nW0, PP[0]), (Wv[1], PP[1])]),
           O.mulN([(O.add(R[0], R[0]), R[1]), (nW0, PP[1]), (nW1, PP[0])]))
     d = f2_sub(O, Qv, X3, "g2f.P")
     nY0, nY1 = O.neg(Y1[0], "g2f.n"), O.neg(Y1[1], "g2f.n")
