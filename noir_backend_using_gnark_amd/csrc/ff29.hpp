@@ -39,6 +39,8 @@ struct Fp29 {
     static constexpr uint32_t BIAS64[9] = {0x5f3f51c0u, 0x41182daeu, 0x5ca8d3c0u, 0x5548b436u, 0x41765e03u, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au};
     static constexpr uint32_t BIAS80[9] = {0x470f2630u, 0x515e391bu, 0x43d308b0u, 0x429ae145u, 0x59d3f585u, 0x44843c33u, 0x54266455u, 0x5ccbf03fu, 0x0f1f5881u};
     static constexpr uint32_t PINV = 0x1b799c77u;  // p^-1 mod 2^29 (= 2^29 - NINV)
+    static constexpr uint32_t RC[9] = {0x078302b9u, 0x1efb9f49u, 0x038d5cb0u, 0x1d2add2fu, 0x0a7a2687u, 0x1d24bf3fu, 0x1f591ebeu, 0x11a3d9cbu, 0x1fcf9bb1u};  // 2^261 - p
+    static constexpr uint32_t QM = 0xa948e6d7u;    // floor(2^53 / ((p >> 232) + 1))
     template <int K>
     static constexpr uint32_t bias(int i) {
         static_assert(K == 4 || K == 8 || K == 12 || K == 16 || K == 24 || K == 32 || K == 40 || K == 64 || K == 80, "no bias table for this multiple of p");
@@ -195,6 +197,23 @@ __device__ __forceinline__ U29 u29_load(const Fp& v) {
     return r;
 }
 
+// 8 x u32 image (canonical, or a lazily reduced intermediate < 2^256) -> limbs, no shift
+template <class E>
+__device__ __forceinline__ U29 u29_unpack(const E& v) {
+    U29 r;
+    const uint32_t* w = v.l;
+    r.l[0] = w[0] & 0x1fffffffu;
+    r.l[1] = __funnelshift_r(w[0], w[1], 29) & 0x1fffffffu;
+    r.l[2] = __funnelshift_r(w[1], w[2], 26) & 0x1fffffffu;
+    r.l[3] = __funnelshift_r(w[2], w[3], 23) & 0x1fffffffu;
+    r.l[4] = __funnelshift_r(w[3], w[4], 20) & 0x1fffffffu;
+    r.l[5] = __funnelshift_r(w[4], w[5], 17) & 0x1fffffffu;
+    r.l[6] = __funnelshift_r(w[5], w[6], 14) & 0x1fffffffu;
+    r.l[7] = __funnelshift_r(w[6], w[7], 11) & 0x1fffffffu;
+    r.l[8] = w[7] >> 8;
+    return r;
+}
+
 // any lazily reduced value (< 2^260) -> canonical Montgomery-2^256 image
 __device__ __forceinline__ Fp u29_store(const U29& x) {
     U29 c;
@@ -328,14 +347,65 @@ __device__ __forceinline__ bool u29_mulout3_is_zero(const U29& x) {
     return z == 0 || e1 == 0 || e2 == 0;
 }
 
+// ---- interchange format between the G1 kernels (task partials, reduction levels): the lazily reduced value itself, made canonical
+// and packed into 8 words -- i.e. x * 2^261 mod p, NOT gnark's x * 2^256 image.  Writing it needs a partial reduction (x -= q p, q from
+// the top limb) instead of a Montgomery multiplication, reading it is a plain unpack (value < p); the host divides the handful of
+// final sums by 2^5 (msm_finish).  Infinity stays zz == 0.
+__device__ __forceinline__ U29 u29p_reduce(const U29& x) {  // x weakly normalised -> < 2.01 p, limbs 0..7 < 2^29 (as u29r_reduce, modulus p)
+    const uint32_t q = __umulhi(x.l[8], Fp29::QM) >> 21;
+    U29 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t acc = (uint64_t)q * Fp29::RC[i] + (uint64_t)(x.l[i] + c);
+        r.l[i] = (uint32_t)acc & Fp29::MASK;
+        c = (uint32_t)(acc >> 29);
+    }
+    uint64_t acc = (uint64_t)q * Fp29::RC[8] + (uint64_t)(x.l[8] + c);
+    r.l[8] = (uint32_t)(acc - ((uint64_t)q << 29));
+    return r;
+}
+__device__ __forceinline__ Fp u29p_pack(const U29& x) {  // any weakly normalised value (top limb < 2^32) -> canonical, packed
+    const U29 t = u29p_reduce(x);
+    Fp r;
+    r.l[0] = t.l[0] | (t.l[1] << 29);
+    r.l[1] = (t.l[1] >> 3) | (t.l[2] << 26);
+    r.l[2] = (t.l[2] >> 6) | (t.l[3] << 23);
+    r.l[3] = (t.l[3] >> 9) | (t.l[4] << 20);
+    r.l[4] = (t.l[4] >> 12) | (t.l[5] << 17);
+    r.l[5] = (t.l[5] >> 15) | (t.l[6] << 14);
+    r.l[6] = (t.l[6] >> 18) | (t.l[7] << 11);
+    r.l[7] = (t.l[7] >> 21) | (t.l[8] << 8);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        uint32_t s[8];
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)r.l[i] - FpParams::MOD[i] - bw;
+            s[i] = (uint32_t)d;
+            bw = d >> 63;
+        }
+        if (!bw) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) r.l[i] = s[i];
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ XYZZ<Fp> acc29_to_packed(const Acc29& A) {
+    if (A.inf) return XYZZ<Fp>::inf();
+    return XYZZ<Fp>{u29p_pack(A.x), u29p_pack(A.y), u29p_pack(A.zz), u29p_pack(A.zzz)};
+}
+
 // ---- XYZZ + XYZZ and doubling for the bucket-reduction tail (G1).  Class invariant proven by tools/u29_model.py
 // (check_add_dbl_class): with every input coordinate < 32 p and weakly normalised, every output coordinate is again < 32 p.
-__device__ __forceinline__ void acc29_load(Acc29& A, const XYZZ<Fp>& c) {  // canonical image -> lazily reduced, no multiplication
+__device__ __forceinline__ void acc29_load(Acc29& A, const XYZZ<Fp>& c) {  // interchange format (acc29_to_packed) -> limbs, value < p
     A.inf = c.is_inf();
-    A.x = u29_load(c.x);
-    A.y = u29_load(c.y);
-    A.zz = u29_load(c.zz);
-    A.zzz = u29_load(c.zzz);
+    A.x = u29_unpack(c.x);
+    A.y = u29_unpack(c.y);
+    A.zz = u29_unpack(c.zz);
+    A.zzz = u29_unpack(c.zzz);
 }
 __device__ __forceinline__ void acc29_dbl(Acc29& A) {  // dbl-2008-s-1
     if (A.inf) return;
@@ -708,23 +778,6 @@ __device__ __forceinline__ U29 u29r_reduce(const U29& x) {
     }
     uint64_t acc = (uint64_t)q * Fr29::RC[8] + (uint64_t)(x.l[8] + c);
     r.l[8] = (uint32_t)(acc - ((uint64_t)q << 29));
-    return r;
-}
-
-// 8 x u32 image (canonical, or a lazily reduced intermediate < 2^256) -> limbs, no shift
-template <class E>
-__device__ __forceinline__ U29 u29_unpack(const E& v) {
-    U29 r;
-    const uint32_t* w = v.l;
-    r.l[0] = w[0] & 0x1fffffffu;
-    r.l[1] = __funnelshift_r(w[0], w[1], 29) & 0x1fffffffu;
-    r.l[2] = __funnelshift_r(w[1], w[2], 26) & 0x1fffffffu;
-    r.l[3] = __funnelshift_r(w[2], w[3], 23) & 0x1fffffffu;
-    r.l[4] = __funnelshift_r(w[3], w[4], 20) & 0x1fffffffu;
-    r.l[5] = __funnelshift_r(w[4], w[5], 17) & 0x1fffffffu;
-    r.l[6] = __funnelshift_r(w[5], w[6], 14) & 0x1fffffffu;
-    r.l[7] = __funnelshift_r(w[6], w[7], 11) & 0x1fffffffu;
-    r.l[8] = w[7] >> 8;
     return r;
 }
 

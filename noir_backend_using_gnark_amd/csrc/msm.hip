@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32
             if (v & 1) p.y = p.y.neg();
             xyzz_madd29(acc, p.x, p.y);
         }
-        gstore(partial + t, acc29_to_xyzz(acc));
+        gstore(partial + t, acc29_to_packed(acc));  // G1 interchange format (ff29.hpp): no multiplication to leave the 2^261 domain
     } else {
         // G2: the same representation per Fp2 component
         Acc29G2 acc;
@@ -303,7 +303,7 @@ struct TailPt<Fp> {
     Acc29 v;
     static __device__ __forceinline__ TailPt inf() { TailPt t; t.v.inf = true; for (int i = 0; i < 9; i++) t.v.x.l[i] = t.v.y.l[i] = t.v.zz.l[i] = t.v.zzz.l[i] = 0; return t; }
     static __device__ __forceinline__ TailPt load(const XYZZ<Fp>* p) { TailPt t; acc29_load(t.v, gload(p)); return t; }
-    __device__ __forceinline__ void store(XYZZ<Fp>* p) const { gstore(p, acc29_to_xyzz(v)); }
+    __device__ __forceinline__ void store(XYZZ<Fp>* p) const { gstore(p, acc29_to_packed(v)); }
     __device__ __forceinline__ void add(const TailPt& o) { acc29_add(v, o.v); }
     __device__ __forceinline__ void dbl() { acc29_dbl(v); }
     __device__ __forceinline__ TailPt shfl_down(unsigned d) const {
@@ -332,7 +332,7 @@ struct TailPtQ {
     Acc29 v;
     static __device__ __forceinline__ TailPtQ inf() { TailPtQ t; t.v.inf = true; for (int i = 0; i < 9; i++) t.v.x.l[i] = t.v.y.l[i] = t.v.zz.l[i] = t.v.zzz.l[i] = 0; return t; }
     static __device__ __forceinline__ TailPtQ load(const XYZZ<Fp>* p) { TailPtQ t; acc29_load(t.v, gload(p)); return t; }
-    __device__ __forceinline__ void store(XYZZ<Fp>* p) const { gstore(p, acc29_to_xyzz(v)); }
+    __device__ __forceinline__ void store(XYZZ<Fp>* p) const { gstore(p, acc29_to_packed(v)); }
     __device__ __forceinline__ void add(const TailPtQ& o) { acc29_add_quad(v, o.v, threadIdx.x & 3u); }
     __device__ __forceinline__ void dbl() { acc29_dbl_quad(v, threadIdx.x & 3u); }
     __device__ __forceinline__ TailPtQ shfl_down(unsigned d) const {  // d counted in points
@@ -790,6 +790,18 @@ static int msm_finish(const MsmJob& job, XYZZ<HF>* total_out) {
     if (job.empty) return ZK_OK;
     ZK_TRY(slot_sync(job.s, job.st));
     const unsigned N = job.n_final;
+    if constexpr (sizeof(HF) == sizeof(HFp)) {
+        // G1 sums arrive in the kernels' interchange format x * 2^261 mod p: one multiplication by 2^-5 per coordinate gives gnark's image
+        static const HFp inv32 = HFp{{32, 0, 0, 0}}.to_mont().inv();
+        XYZZ<HFp>* w = reinterpret_cast<XYZZ<HFp>*>(job.s->pinned);
+        const size_t cnt = (size_t)job.W * N * (N > 1 ? 2 : 1);
+        for (size_t i = 0; i < cnt; i++) {
+            w[i].x = w[i].x * inv32;
+            w[i].y = w[i].y * inv32;
+            w[i].zz = w[i].zz * inv32;
+            w[i].zzz = w[i].zzz * inv32;
+        }
+    }
     const XYZZ<HF>* wa = reinterpret_cast<const XYZZ<HF>*>(job.s->pinned);
     const XYZZ<HF>* wsum = wa + (size_t)job.W * N;
     XYZZ<HF> tot = XYZZ<HF>::inf();

@@ -46,6 +46,7 @@ def test_compiled_constants_match_the_models():
     assert arrs["P"] == fp.PL and scal["NINV"] == fp.NINV
     assert scal["PINV"] == pow(fp.Q, -1, 1 << 29)
     assert arrs["ONE"] == fp.limbs((1 << fp.RBITS) % fp.Q)
+    assert arrs["RC"] == fp.RC_P and scal["QM"] == fp.QM_P
     for name, v in arrs.items():
         if name.startswith("BIAS"):
             assert v == fp.bias_limbs(int(name[4:])), name

@@ -684,6 +684,46 @@ def exact_check_g2(n=60, madd=None):
     print("  exact G2 simulation of %d chained madds: ok" % n)
 
 
+RC_P = limbs((1 << RBITS) - Q)
+QM_P = (1 << 53) // ((Q >> (W * (NL - 1))) + 1)
+
+
+def reduce_exact_p(x):
+    """x -= q p with q = mul_hi(top limb, QM_P) >> 21 (u29p_reduce): < 2.01 p, limbs 0..7 < 2^29"""
+    q = ((x[NL - 1] * QM_P) >> 32) >> 21
+    c, out = 0, [0] * NL
+    for i in range(NL):
+        assert x[i] + c < 1 << 32
+        acc = q * RC_P[i] + x[i] + c
+        assert acc < 1 << 64
+        if i < NL - 1:
+            out[i], c = acc & MASK, acc >> W
+        else:
+            out[i] = acc - (q << W)
+            assert 0 <= out[i] < 1 << 32
+    assert val(out) == val(x) - q * Q and val(out) < 2.01 * Q
+    return out
+
+
+def exact_check_interchange(n=5000):
+    """G1 interchange format: pack(reduce(x)) made canonical == x mod p, and unpacking it gives limbs of a value < p"""
+    random.seed(23)
+    for _ in range(n):
+        v = random.randrange(random.choice([1, 3, 14, 32, 200]) * Q)
+        x = limbs(v)
+        for i in range(NL - 1):
+            if x[i + 1] > 0 and random.random() < 0.3:
+                x[i] += 1 << W
+                x[i + 1] -= 1
+        y = val(reduce_exact_p(x))
+        assert y < 1 << 256
+        for _k in range(2):
+            if y >= Q:
+                y -= Q
+        assert y == v % Q
+    print("  G1 interchange format (partial reduction + pack): exact on %d samples" % n)
+
+
 def main():
     print("p limbs (29-bit):", ", ".join("0x%08x" % v for v in PL))
     print("ninv29 = 0x%08x" % NINV)
@@ -704,6 +744,7 @@ def main():
     exact_check_g2()
     exact_check_g2(60, madd_fp2_fused)
     exact_check_add_dbl()
+    exact_check_interchange()
     exact_check_add_dbl_g2()
     # mul unit test
     random.seed(1)
