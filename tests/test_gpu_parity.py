@@ -496,3 +496,29 @@ def test_felt_vector_codec_errors():
             wire.deserialize_felts(bad)
     d, n = wire.deserialize_felts("00000001" + "%064x" % (ref.R - 1))
     assert n == 1
+
+
+def test_two_process_sharded_proof_equals_single_process():
+    """The whole multi-process program (bench.py --gpus 2: one process per rank, block-sharded computeH with its exchanges, rank-local keys,
+    all-gather, finalize) run as two processes sharing this box's GPU over gloo produces the proof bytes of the single-process run on the same
+    global instance (2 x 2^12 constraints == 1 x 2^13)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "13"] + common, capture_output=True, text=True, timeout=600)
+    assert single.returncode == 0, single.stdout[-2000:] + single.stderr[-2000:]
+    sha1 = json.loads(single.stdout.strip().splitlines()[-1])["proof_sha"]
+    env = dict(os.environ, ZKMI_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--log-n", "12"] + common,
+                           capture_output=True, text=True, timeout=900, env=env)
+    assert multi.returncode == 0, multi.stdout[-2000:] + multi.stderr[-2000:]
+    out = json.loads([l for l in multi.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["proof_sha"] == sha1
