@@ -39,8 +39,8 @@ def seed_at(seed: int, per: int, offset: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="log2(constraints) per GPU")
     ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
