@@ -522,3 +522,38 @@ def test_two_process_sharded_proof_equals_single_process():
     assert multi.returncode == 0, multi.stdout[-2000:] + multi.stderr[-2000:]
     out = json.loads([l for l in multi.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["proof_sha"] == sha1
+
+
+def test_concurrent_callers_are_safe():
+    """gnark issues its MultiExp calls from several goroutines at once: four host threads calling MSMs / NTTs / a proof concurrently
+    (ctypes releases the GIL) must each get the single-threaded results."""
+    import threading
+    n = 3000
+    pts, sc = orc.g1_gen_points(81, n), orc.rand_fr(82, n)
+    want_msm = orc.g1_msm(pts, sc)
+    x = orc.rand_fr(83, 1 << 12)
+    want_ntt = orc.fr_ntt(x, False, ref.DIF)
+    pts2, sc2 = orc.g2_gen_points(84, 500), orc.rand_fr(85, 500)
+    want_g2 = orc.g2_msm(pts2, sc2)
+    errors = []
+
+    def worker(kind):
+        try:
+            for _ in range(6):
+                if kind == 0:
+                    assert (zk.g1_multi_exp(pts, sc) == want_msm).all()
+                elif kind == 1:
+                    assert (zk.Domain(1 << 12).fft(x.copy(), zk.DIF) == want_ntt).all()
+                elif kind == 2:
+                    assert (zk.g2_multi_exp(pts2, sc2) == want_g2).all()
+                else:
+                    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=9)) == want_msm).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append((kind, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 2, 3, 0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
