@@ -516,12 +516,12 @@ template <class F>
 static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab = nullptr) {
     struct Key {
         size_t n, stride;
-        unsigned c_cfg, c_tab, g2;
-        bool operator<(const Key& o) const { return std::tie(n, stride, c_cfg, c_tab, g2) < std::tie(o.n, o.stride, o.c_cfg, o.c_tab, o.g2); }
+        unsigned c_cfg, c_tab, g2, l1;
+        bool operator<(const Key& o) const { return std::tie(n, stride, c_cfg, c_tab, g2, l1) < std::tie(o.n, o.stride, o.c_cfg, o.c_tab, o.g2, o.l1); }
     };
     static std::mutex mu;
     static std::map<Key, MsmPlan> memo;
-    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32)};
+    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32), tab ? tab->l1_m : 0u};
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = memo.find(k);
@@ -570,7 +570,9 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     // mostly 0/1) by growing the task size with n
     if (P->L < (n >> 16)) P->L = (uint32_t)(n >> 16);
     P->max_tasks = (size_t)P->nb + P->total / P->L + 1;
-    P->m1 = P->B >= 8 ? 8 : P->B;  // level-1 serial chunk
+    static const unsigned l1_env = getenv("ZKMI_L1_M") ? (unsigned)atoi(getenv("ZKMI_L1_M")) : 0;  // experiment switch (power of two)
+    const unsigned l1_m = l1_env ? l1_env : (tab && tab->l1_m ? tab->l1_m : 8);
+    P->m1 = P->B >= l1_m ? l1_m : P->B;  // level-1 serial chunk
     P->N1 = P->B / P->m1;
     P->key_bits = 1;
     while (((uint64_t)1 << P->key_bits) <= P->nb) P->key_bits++;

@@ -14,6 +14,8 @@ int msm_g2_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need);
 struct MsmTable {
     unsigned c = 0;
     size_t stride = 0;
+    unsigned l1_m = 0;  // buckets per lane in the first reduction level (0: default 8).  16 does 22 % less tail work at twice the level-1
+                        // latency: right for MSMs whose tail hides under the next accumulate, wrong for the last one of a proof
 };
 unsigned msm_pick_window_table(size_t n);
 int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table);
