@@ -438,6 +438,30 @@ __global__ __launch_bounds__(256) void k_reduce_l1(const XYZZ<F>* __restrict__ p
     }
 }
 
+// Thread-serial level over m entries (A_l, S_l) per lane: 3 additions per entry instead of the ~15 of a wave level -- for tails whose
+// latency hides under another kernel.   S' = sum_l S_l ;  A' = sum_l A_l + 2^sh * sum_l l * S_l ;  next shift = sh + log2(m).
+template <class F>
+__global__ __launch_bounds__(256) void k_reduce_l2(const XYZZ<F>* __restrict__ A_in, const XYZZ<F>* __restrict__ S_in, uint32_t N, uint32_t W, uint32_t sh,
+                                                   uint32_t m, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
+    typedef TailPt<F> PT;
+    uint32_t Nout = (N + m - 1) / m;
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= W * Nout) return;
+    uint32_t w = g / Nout, q = g % Nout;
+    PT run = PT::inf(), t = PT::inf(), asum = PT::inf();
+    for (int l = (int)m - 1; l >= 0; l--) {
+        uint32_t j = q * m + (uint32_t)l;
+        if (j >= N) continue;
+        asum.add(PT::load(A_in + (size_t)w * N + j));
+        run.add(PT::load(S_in + (size_t)w * N + j));  // suffix sum S_l + ... + S_(m-1)
+        if (l >= 1) t.add(run);                        // sum over l >= 1 of the suffix sums = sum_l l * S_l
+    }
+    for (uint32_t i = 0; i < sh; i++) t.dbl();
+    asum.add(t);
+    asum.store(A_out + g);
+    run.store(S_out + g);
+}
+
 // Wave-cooperative level: 64 consecutive entries per wave (lane = l).
 //   S' = sum_l S_l ;  A' = sum_l A_l + 2^sh * sum_l l * S_l ;   next shift = sh + 6
 // suffix scan of S (6 shuffle steps), per-lane doublings, one butterfly reduction.
@@ -521,7 +545,7 @@ static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P,
     };
     static std::mutex mu;
     static std::map<Key, MsmPlan> memo;
-    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32), tab ? tab->l1_m : 0u};
+    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32), tab ? (tab->l1_m | (tab->l2_m << 8)) : 0u};
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = memo.find(k);
@@ -573,6 +597,7 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     static const unsigned l1_env = getenv("ZKMI_L1_M") ? (unsigned)atoi(getenv("ZKMI_L1_M")) : 0;  // experiment switch (power of two)
     const unsigned l1_m = l1_env ? l1_env : (tab && tab->l1_m ? tab->l1_m : 8);
     P->m1 = P->B >= l1_m ? l1_m : P->B;  // level-1 serial chunk
+    P->m2 = (tab && tab->l2_m) ? tab->l2_m : 0;
     P->N1 = P->B / P->m1;
     P->key_bits = 1;
     while (((uint64_t)1 << P->key_bits) <= P->nb) P->key_bits++;
@@ -745,6 +770,14 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         uint32_t N = N1, sh = 0;
         for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;  // value = sum A + 2^sh * sum j S_j
         int cur = 0;
+        if (P.m2 > 1 && N > 64 * P.m2) {  // second thread-serial level (tails that hide under the next accumulate)
+            uint32_t Nout = (N + P.m2 - 1) / P.m2;
+            ZK_LAUNCH(s, st, "msm_reduce_l2", (k_reduce_l2<F>), dim3((unsigned)(((size_t)W * Nout + 255) / 256)), dim3(256), 0, (const Pt*)lvlA[b][cur],
+                      (const Pt*)lvlS[b][cur], N, W, sh, P.m2, lvlA[b][cur ^ 1], lvlS[b][cur ^ 1]);
+            cur ^= 1;
+            N = Nout;
+            for (uint32_t mm = P.m2; mm > 1; mm >>= 1) sh++;
+        }
         // the last level (<= 64 entries per window) is cheaper on the host than one more latency-bound launch, as long as the host
         // has few windows to do (table mode: one)
         const uint32_t host_n = (W * 64 <= 64) ? 64 : 1;

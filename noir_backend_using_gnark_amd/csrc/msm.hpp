@@ -14,6 +14,7 @@ int msm_g2_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need);
 struct MsmTable {
     unsigned c = 0;
     size_t stride = 0;
+    unsigned l2_m = 0;  // > 0: a second thread-serial level over l2_m entries (3 additions per entry instead of ~15 in a wave level)
     unsigned l1_m = 0;  // buckets per lane in the first reduction level (0: default 8).  16 does 22 % less tail work at twice the level-1
                         // latency: right for MSMs whose tail hides under the next accumulate, wrong for the last one of a proof
 };
@@ -24,7 +25,7 @@ int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, siz
 struct MsmPlan {
     unsigned c, W, Wd, key_bits;   // W bucket sets (windows that are reduced separately); Wd digit windows (== W unless table mode)
     uint32_t table_stride;
-    uint32_t B, nb, L, m1, N1;
+    uint32_t B, nb, L, m1, N1, m2 = 0;
     size_t total, max_tasks, sort_tmp_bytes, scan_tmp_bytes, tsort_tmp_bytes, lvl_elems, need, need_prep, need_acc;
 };
 // Result of the scalar-side half of an MSM (digits, sort, bucket bounds, task plan); device arrays live in the
