@@ -164,7 +164,8 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         P.tab_h.stride = N;
         P.tab_w.l1_m = 16;  // A, B1, K, G2.B: their reduction tails hide under the next accumulate -- less work beats lower latency
         P.tab_w.l2_m = getenv("ZKMI_L2_M") ? (unsigned)atoi(getenv("ZKMI_L2_M")) : 8;  // measured: 8 -> -0.09 ms, 16 -> +0.15 ms, 32 -> +0.9 ms (the level gets too long to hide)
-        P.tab_h.l1_m = 8;   // Z finishes last: its tail is exposed
+        P.tab_h.l1_m = getenv("ZKMI_L1H_M") ? (unsigned)atoi(getenv("ZKMI_L1H_M")) : 8;   // Z finishes last: its tail is exposed
+        P.tab_h.l2_m = getenv("ZKMI_L2H_M") ? (unsigned)atoi(getenv("ZKMI_L2H_M")) : 0;
         const size_t Ww = (255 + P.tab_w.c - 1) / P.tab_w.c, Wh = (255 + P.tab_h.c - 1) / P.tab_h.c;
         const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
         size_t free_b = 0, total_b = 0;
