@@ -355,12 +355,14 @@ struct TailPtQ {
     }
 };
 
-// G2 in the same form (fused multi-product add / dbl of ff29.hpp, model-checked) is available behind -DZKMI_G2_TAIL_U29.  Measured: correct
-// (all parity tests pass with it) but NOT faster (10.94-10.99 vs 10.82-11.02 ms per proof): these kernels hold 256 VGPRs + 142 AGPRs at one
-// wave per SIMD and are bound by the latency of their serial chains, not by instruction count -- so the canonical form stays the default.
-#ifdef ZKMI_G2_TAIL_U29
+// G2 in the same form (fused multi-product add / dbl of ff29.hpp, model-checked).  With the latency-oriented tail structure it measured
+// no faster than the canonical saturated form (the kernels hold 256 VGPRs + 142 AGPRs at one wave per SIMD); with the work-oriented
+// structure of the hidden tails (16 buckets per lane, lane-serial second level) its 1.4x lower instruction count is worth ~0.07 ms per
+// proof.  -DZKMI_G2_TAIL_SAT selects the canonical form (A/B).
+#ifndef ZKMI_G2_TAIL_SAT
 template <>
 struct TailPt<Fp2> {
+    static constexpr unsigned LPP = 1;
     Acc29G2 v;
     static __device__ __forceinline__ TailPt inf() {
         TailPt t;
