@@ -331,6 +331,17 @@ static int msm5_prepare_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Ms
     return msm_prepare_scalars(sl[0], st0, in.d_h, in.nz, &kMontCfg, &S->prep_h);
 }
 static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm5State* S, bool prepared = false) {
+    // ZKMI_PREPH_LOW=1 (experiment switch): prepare(h) on slot 0's NORMAL-priority stream (it has ~7 ms of slack until Z needs it)
+    static const bool preph_low = getenv("ZKMI_PREPH_LOW") && atoi(getenv("ZKMI_PREPH_LOW")) == 1;
+    if (!prepared && preph_low && sl[0]->stream != st0) {
+        hipEvent_t ev;
+        ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(ev, st0));
+        ZK_HIP(hipStreamWaitEvent(sl[0]->stream, ev, 0));
+        (void)hipEventDestroy(ev);
+        ZK_TRY(msm5_prepare_h(sl, sl[0]->stream, in, S));
+        prepared = true;
+    }
     if (!prepared) ZK_TRY(msm5_prepare_h(sl, st0, in, S));
     // Z's accumulate goes last on the chain stream (which then waits for prepare(h) through the event inside msm_accumulate)
     S->jobs[0].chain = S->chain;
