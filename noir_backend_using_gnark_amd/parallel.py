@@ -100,6 +100,9 @@ def groth16_finalize(pk, partials: np.ndarray, r, s) -> bytes:
     return bytes(proof)
 
 
+_A2A_OK = True
+
+
 def block_exchange(x):
     """The transpose of the sharded NTT: `x` (a torch tensor, this rank's array) is cut into `world` equal chunks, chunk r
     goes to rank r and chunk s of the result is what rank s sent.  Applying it twice restores the block.
@@ -111,7 +114,19 @@ def block_exchange(x):
     world, rank = d.get_world_size(), d.get_rank()
     y = torch.empty_like(x)
     if d.get_backend() == "nccl":
-        d.all_to_all_single(y, x)
+        global _A2A_OK
+        if _A2A_OK:
+            try:
+                d.all_to_all_single(y, x)
+                return y
+            except RuntimeError as e:  # an RCCL build without all-to-all: keep the proof going on all-gather (G x the traffic), say so once
+                _A2A_OK = False
+                import sys
+                print("[zkmi] all_to_all_single failed (%s); falling back to all_gather for the NTT transposes" % str(e).splitlines()[0], file=sys.stderr)
+        full = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        d.all_gather_into_tensor(full.view(-1), x.reshape(-1))
+        chunk = x.numel() // world
+        y.view(-1).copy_(full.view(world, world, chunk)[:, rank, :].reshape(-1))
         return y
     xh = x.cpu() if x.is_cuda else x  # gloo collectives take host tensors
     rows = [torch.empty_like(xh) for _ in range(world)]
