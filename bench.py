@@ -118,6 +118,7 @@ def main():
         pk = zk.ProvingKey(log_n, N_loc, np_loc, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + np_loc * 64, g1_z,
                            small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables,
                            shard_full_z=(rank != world - 1))
+    fallback_stream = torch.cuda.Stream(priority=-1) if sharded else None
     _lib.check(L.zk_dev_sync())
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -126,7 +127,10 @@ def main():
         if not sharded:
             return zk.prove(pk, d_a, d_b, d_c, d_w, r, s, n_constraints=N_g, on_device=True)
         sess = par.groth16_msm5_pk_begin(pk, d_w.ptr)  # digits / sort / task plan of w run under computeH and its exchanges
-        side = torch.cuda.ExternalStream(par.groth16_session_stream(sess))  # the library's computeH stream, shared with torch / RCCL
+        try:
+            side = torch.cuda.ExternalStream(par.groth16_session_stream(sess))  # the library's computeH stream, shared with torch / RCCL
+        except Exception:  # a torch build without ExternalStream: any non-null stream works (the library then bridges with events)
+            side = fallback_stream
         with torch.cuda.stream(side):
             # the prover consumes its working buffers: at N > 1 the first all-to-all already writes fresh ones, at N = 1 copy
             a, b, c = (t.clone() for t in t_abc) if world == 1 else t_abc
