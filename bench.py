@@ -208,13 +208,21 @@ def main():
                 "note": "VALU-bound kernel (254-bit modular multiplies on 32-bit integer ALUs); see DESIGN.md for the ALU-issue fraction",
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
 
+    # the metric's name is BASELINE.json's, verbatim; the size this run used is in config.workload / config.constraints
+    baseline_metric = "Groth16 prove ms + BN254 G1 MSM scalar-muls/sec at 2^20 / 2^24 constraints"
+    try:
+        baseline_metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        pass
     out = {
-        "metric": "Groth16 prove ms + BN254 G1 MSM scalar-muls/sec at 2^%d constraints" % log_ng,
+        "metric": baseline_metric,
         "value": round(value, 1), "unit": "G1 scalar-muls/s (whole prove: 4 G1 MSMs + G2 MSM + 7 NTTs per step)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "prove_ms": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_ng, "constraints": N_g, "wires": N_g, "n_public": n_public,
+        "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_ng,
+                   "baseline_config": "BASELINE.json configs[1]: Synthetic R1CS 2^20 constraints, BN254 Groth16 prove on 1xMI355X (G1 MSM + Fr NTT)" if (log_ng == 20 and world == 1)
+                   else ("BASELINE.json configs[2] shape (range-sharded over %d GPUs), %d constraints" % (world, N_g) if world > 1 else "same workload at 2^%d" % log_ng), "constraints": N_g, "wires": N_g, "n_public": n_public,
                    "scalars": args.scalars, "per_gpu_constraints": N_loc,
                    "parallelism": "single GPU" if not sharded else
                    "one proof range-sharded x%d: block-sharded computeH (all-to-all transposes) + MSMs on rank-local key slices (all-gather of partial sums)" % world},
