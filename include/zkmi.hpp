@@ -1,0 +1,143 @@
+// C++ host-side mirror of the gnark-crypto / gnark interfaces that libzkmi replaces (header-only, over the C ABI of zkmi.h).
+// The reference's host language is Go (no toolchain in this image), so this is what a C++ caller -- or the cgo shim of
+// INTEGRATION.md, line for line -- writes: same names, same argument meaning, same error behaviour as
+//   gnark-crypto v0.9.1  ecc/bn254  (*G1Affine).MultiExp / (*G2Affine).MultiExp, ecc.MultiExpConfig      [REF gnark_backend_ffi/go.mod:5]
+//   gnark-crypto v0.9.1  ecc/bn254/fr/fft  NewDomain, (*Domain).FFT / FFTInverse, BitReverse, Decimation
+//   gnark v0.8.0         groth16.Prove (with the prover randomness as arguments)                          [REF gnark_backend_ffi/main.go:131]
+//   the reference's      DeserializeFelts                                                                 [REF internal/backend/helpers.go:24-33]
+// Go's `(value, error)` returns become `Error` return values (nil == ok()); nothing throws.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "zkmi.h"
+
+namespace zkmi {
+
+struct Error {
+    int code = ZK_OK;
+    std::string msg;
+    bool ok() const { return code == ZK_OK; }
+    explicit operator bool() const { return code != ZK_OK; }  // `if (err)` reads like Go's `if err != nil`
+};
+inline Error make_error(int rc) {
+    if (rc == ZK_OK) return Error{};
+    const char* m = zk_last_error();
+    return Error{rc, m ? m : ""};
+}
+
+namespace fr {
+typedef zk_fr Element;  // Montgomery, 4 x u64 little-endian limbs: gnark-crypto's memory image
+typedef std::vector<Element> Vector;
+}  // namespace fr
+
+namespace ecc {
+// ecc.MultiExpConfig{NbTasks int; ScalarsMont bool}
+struct MultiExpConfig {
+    int NbTasks = 0;
+    bool ScalarsMont = true;  // fr.Element containers hold Montgomery images
+};
+}  // namespace ecc
+
+namespace bn254 {
+
+struct G1Affine : zk_g1_affine {
+    // func (p *G1Affine) MultiExp(points []G1Affine, scalars []fr.Element, config ecc.MultiExpConfig) (*G1Affine, error)
+    // errors: "len(points) != len(scalars)" (ZK_ERR_LEN), "invalid config: config.NbTasks > 1024" (ZK_ERR_NB_TASKS)
+    Error MultiExp(const std::vector<G1Affine>& points, const fr::Vector& scalars, const ecc::MultiExpConfig& config = ecc::MultiExpConfig()) {
+        zk_msm_cfg c = {config.NbTasks, config.ScalarsMont ? 1 : 0, 0, 0};
+        return make_error(zk_bn254_g1_msm(points.data(), points.size(), scalars.data(), scalars.size(), &c, this));
+    }
+    bool IsInfinity() const {
+        for (int i = 0; i < 4; i++)
+            if (x.l[i] | y.l[i]) return false;
+        return true;
+    }
+};
+
+struct G2Affine : zk_g2_affine {
+    Error MultiExp(const std::vector<G2Affine>& points, const fr::Vector& scalars, const ecc::MultiExpConfig& config = ecc::MultiExpConfig()) {
+        zk_msm_cfg c = {config.NbTasks, config.ScalarsMont ? 1 : 0, 0, 0};
+        return make_error(zk_bn254_g2_msm(points.data(), points.size(), scalars.data(), scalars.size(), &c, this));
+    }
+};
+
+}  // namespace bn254
+
+namespace fft {
+
+enum Decimation { DIT = ZK_DIT, DIF = ZK_DIF };  // same iota order as gnark-crypto
+
+// fft.Domain: only the cardinality travels; the twiddle / coset tables are device-resident and cached per size inside libzkmi
+class Domain {
+public:
+    uint64_t Cardinality = 1;
+    // fft.NewDomain(m): next power of two >= m
+    static Domain NewDomain(uint64_t m) {
+        Domain d;
+        while (d.Cardinality < m) d.Cardinality <<= 1;
+        return d;
+    }
+    // (*Domain).FFT(a, decimation, coset...): in place; DIF natural -> bit-reversed, DIT bit-reversed -> natural
+    Error FFT(fr::Vector& a, Decimation decimation, bool coset = false) const { return run(a, 0, decimation, coset); }
+    // (*Domain).FFTInverse: same data movement with the inverse twiddles, scaled by 1/N (and the inverse coset table)
+    Error FFTInverse(fr::Vector& a, Decimation decimation, bool coset = false) const { return run(a, 1, decimation, coset); }
+
+private:
+    Error run(fr::Vector& a, int inverse, Decimation decimation, bool coset) const {
+        if (a.size() != Cardinality) return Error{ZK_ERR_ARG, "len(a) != domain.Cardinality"};
+        uint32_t log_n = 0;
+        while ((uint64_t(1) << log_n) < Cardinality) log_n++;
+        return make_error(zk_bn254_ntt(a.data(), log_n, inverse, (int)decimation, coset ? 1 : 0));
+    }
+};
+
+// fft.BitReverse(a): len(a) must be a power of two
+inline Error BitReverse(fr::Vector& a) {
+    uint32_t log_n = 0;
+    while ((size_t(1) << log_n) < a.size()) log_n++;
+    if ((size_t(1) << log_n) != a.size()) return Error{ZK_ERR_ARG, "len(a) is not a power of two"};
+    return make_error(zk_bn254_bit_reverse(a.data(), log_n));
+}
+
+}  // namespace fft
+
+namespace groth16 {
+
+// groth16.ProvingKey resident in HBM (RAII over zk_bn254_groth16_pk_load / _free)
+class ProvingKey {
+public:
+    ProvingKey() = default;
+    ProvingKey(const ProvingKey&) = delete;
+    ProvingKey& operator=(const ProvingKey&) = delete;
+    ~ProvingKey() {
+        if (handle_) zk_bn254_groth16_pk_free(handle_);
+    }
+    Error Load(const zk_groth16_pk& pk) { return make_error(zk_bn254_groth16_pk_load(&pk, &handle_)); }
+    uint64_t handle() const { return handle_; }
+
+private:
+    uint64_t handle_ = 0;
+};
+
+struct Proof {
+    uint8_t bytes[128];  // Proof.WriteTo: Ar | Bs | Krs, gnark's compressed encodings
+};
+
+// groth16.Prove after the solver: a, b, c = evaluations of the constraint system, w = wire values, (r, s) = the prover's randomness
+inline Error Prove(const ProvingKey& pk, const fr::Vector& a, const fr::Vector& b, const fr::Vector& c, const fr::Vector& w, const fr::Element& r,
+                   const fr::Element& s, Proof* proof) {
+    if (a.size() != b.size() || a.size() != c.size()) return Error{ZK_ERR_LEN, "len(a), len(b), len(c) differ"};
+    return make_error(zk_bn254_groth16_prove(pk.handle(), a.data(), b.data(), c.data(), a.size(), w.data(), &r, &s, 0, proof->bytes));
+}
+
+}  // namespace groth16
+
+// DeserializeFelts(encodedFelts string): hex(u32 BE count || count x 32 B BE) -> Montgomery vector, decoded on the device into d_out
+inline Error DeserializeFelts(const std::string& encoded, void* d_out, size_t capacity, size_t* n) {
+    return make_error(zk_bn254_felts_decode_hex(encoded.data(), encoded.size(), d_out, capacity, n));
+}
+
+}  // namespace zkmi

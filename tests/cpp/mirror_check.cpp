@@ -1,0 +1,69 @@
+// Test program for include/zkmi.hpp (the C++ host mirror): reads a blob written by tests/test_gpu_parity.py
+//   u64 n | n x 64 B G1 points | n x 32 B scalars | 64 B expected MSM | u64 log_n | 2^log_n x 32 B input | 2^log_n x 32 B expected FFT(DIF)
+// runs the gnark-crypto-shaped calls and checks results AND upstream's error behaviour.  Without arguments it only exercises the
+// error paths that need no device (used by the CPU suite).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "zkmi.hpp"
+
+using namespace zkmi;
+
+static int fail(const char* what) {
+    std::printf("FAIL: %s\n", what);
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    // upstream's two MultiExp errors come back before any device work
+    {
+        std::vector<bn254::G1Affine> pts(3);
+        fr::Vector sc(2);
+        bn254::G1Affine out;
+        Error e = out.MultiExp(pts, sc);
+        if (e.code != ZK_ERR_LEN) return fail("len(points) != len(scalars) must be ZK_ERR_LEN");
+        sc.resize(3);
+        ecc::MultiExpConfig cfg;
+        cfg.NbTasks = 1025;
+        e = out.MultiExp(pts, sc, cfg);
+        if (e.code != ZK_ERR_NB_TASKS) return fail("NbTasks > 1024 must be ZK_ERR_NB_TASKS");
+        fft::Domain d = fft::Domain::NewDomain(5);
+        if (d.Cardinality != 8) return fail("NewDomain(5).Cardinality == 8");
+        fr::Vector a(7);
+        if (!d.FFT(a, fft::DIF)) return fail("len(a) != Cardinality must fail");
+    }
+    if (argc < 2) {
+        std::printf("ok (error paths only)\n");
+        return 0;
+    }
+    std::ifstream f(argv[1], std::ios::binary);
+    if (!f) return fail("cannot open blob");
+    uint64_t n = 0, log_n = 0;
+    f.read((char*)&n, 8);
+    std::vector<bn254::G1Affine> pts(n);
+    fr::Vector sc(n);
+    bn254::G1Affine want, got;
+    f.read((char*)pts.data(), n * 64);
+    f.read((char*)sc.data(), n * 32);
+    f.read((char*)&want, 64);
+    Error e = got.MultiExp(pts, sc);
+    if (e) {
+        std::printf("MultiExp: %s\n", e.msg.c_str());
+        return 1;
+    }
+    if (std::memcmp(&got, &want, 64)) return fail("MultiExp result");
+    f.read((char*)&log_n, 8);
+    const size_t N = size_t(1) << log_n;
+    fr::Vector a(N), expect(N);
+    f.read((char*)a.data(), N * 32);
+    f.read((char*)expect.data(), N * 32);
+    fr::Vector orig = a;
+    fft::Domain dom = fft::Domain::NewDomain(N);
+    if ((e = dom.FFT(a, fft::DIF))) return fail(e.msg.c_str());
+    if (std::memcmp(a.data(), expect.data(), N * 32)) return fail("FFT(DIF) result");
+    if ((e = dom.FFTInverse(a, fft::DIT))) return fail(e.msg.c_str());   // DIF then inverse DIT: back to the input, natural order
+    if (std::memcmp(a.data(), orig.data(), N * 32)) return fail("FFTInverse(DIT) o FFT(DIF) != identity");
+    std::printf("ok\n");
+    return 0;
+}

@@ -64,3 +64,17 @@ def test_host_partial_sum_combine_matches_oracle():
         parts2[i, 24:28] = one
     assert (zb.g2_sum_partials(parts2) == orc.g2_add(orc.g2_add(p2[0], p2[1]), p2[2])).all()
     assert (zb.g1_sum_partials(np.zeros((0, 16), np.uint64)) == 0).all()
+
+
+def test_cpp_host_mirror_compiles_and_keeps_upstream_error_behaviour(tmp_path):
+    """include/zkmi.hpp (C++ mirror of the gnark-crypto interface) compiles against the C ABI, and upstream's two MultiExp errors plus
+    the domain-size check come back without touching a device."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mirror_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "mirror_check.cpp"),
+                           "-L" + os.path.join(root, "noir_backend_using_gnark_amd"), "-lzkmi", "-Wl,-rpath," + os.path.join(root, "noir_backend_using_gnark_amd"),
+                           "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

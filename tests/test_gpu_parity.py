@@ -557,3 +557,23 @@ def test_concurrent_callers_are_safe():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_cpp_host_mirror_runs_msm_and_fft(tmp_path):
+    """The C++ mirror of the gnark-crypto interface (include/zkmi.hpp: G1Affine::MultiExp, fft::Domain::FFT / FFTInverse) against the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mirror_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "mirror_check.cpp"),
+                           "-L" + os.path.join(root, "noir_backend_using_gnark_amd"), "-lzkmi", "-Wl,-rpath," + os.path.join(root, "noir_backend_using_gnark_amd"),
+                           "-o", exe])
+    n, log_n = 777, 10
+    pts, sc = orc.g1_gen_points(91, n), orc.rand_fr(92, n)
+    x = orc.rand_fr(93, 1 << log_n)
+    blob = tmp_path / "blob.bin"
+    with open(blob, "wb") as f:
+        f.write(np.uint64(n).tobytes() + pts.tobytes() + sc.tobytes() + orc.g1_msm(pts, sc).tobytes())
+        f.write(np.uint64(log_n).tobytes() + x.tobytes() + orc.fr_ntt(x, False, ref.DIF).tobytes())
+    out = subprocess.run([exe, str(blob)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
