@@ -194,9 +194,9 @@ def main():
     # mixed-addition routine alone (tools/ubench.hip: k_madd29 17.4 G/s, G1; a G2 mixed addition costs ~2.1 G1 ones)
     valu = None
     if name.startswith("msm_accumulate"):
-        # digits per scalar as the planner chose them (window tables exist up to 32 GB of tables: 2^22 constraints per GPU)
+        # digits per scalar as the planner chose them (window tables exist up to 128 GB of tables: 2^24 constraints per GPU)
         wb, dg = C.c_uint32(0), C.c_uint32(0)
-        _lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(N_loc), C.c_int(1 if (not args.no_tables and log_n <= 22) else 0), C.byref(wb), C.byref(dg)))
+        _lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(N_loc), C.c_int(1 if (not args.no_tables and log_n <= 24) else 0), C.byref(wb), C.byref(dg)))
         digits = int(dg.value)
         madds = units_per_launch * digits
         peak = 17.4e9 if name.endswith("g1") else 17.4e9 / 2.1

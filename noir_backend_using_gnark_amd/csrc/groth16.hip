@@ -170,9 +170,11 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
         size_t free_b = 0, total_b = 0;
         ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-        // measured: up to ~20 GB of tables (2^22 constraints) the gathers keep up with the ALUs; at 2^24 (77 GB) random 64-byte
-        // gathers over the tables are TLB / HBM-latency bound and the plain 16-window method is faster
-        if (bytes < free_b / 2 && bytes <= ((size_t)32 << 30)) {
+        // measured (end of round 1): tables pay at every size that fits -- 2^23: 65.8 vs 76.3 ms per proof, 2^24 (84 GB of tables): 126.8 vs
+        // 148.1 ms -- so the only limits are half of the free HBM and a 128 GB cap (an early measurement that showed the opposite at 2^24
+        // was an artefact of the task-size heuristic fixed since)
+        static const size_t cap_gb = getenv("ZKMI_TABLE_CAP_GB") ? (size_t)atoi(getenv("ZKMI_TABLE_CAP_GB")) : 128;  // experiment switch
+        if (bytes < free_b / 2 && bytes <= (cap_gb << 30)) {
             SlotGuard g;
             ZK_TRY(acquire_slot(&g.s));
             hipStream_t st = g.s->stream;
