@@ -90,6 +90,10 @@ int zk_bn254_g2_sum_xyzz(const uint64_t *partials, size_t n_partials, zk_g2_affi
 int zk_bn254_bases_register(const void *points, size_t n, int is_g2, uint64_t *handle);
 int zk_bn254_bases_free(uint64_t handle);
 int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr *scalars, size_t n, const zk_msm_cfg *cfg, void *out);
+/* the same with the points (register) / the scalars (msm) already in HBM -- KZG commits of polynomials that the NTTs left on the device.
+ * Registration builds precomputed window tables 2^(c*w)*P_i when they fit (>= 4096 bases): every commit then feeds one bucket set. */
+int zk_bn254_bases_register_dev(const void *d_points, size_t n, int is_g2, uint64_t *handle);
+int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);
 
 /* ---- NTT: (*fft.Domain).FFT / FFTInverse / fft.BitReverse ------------------------------------------------------
  * In place on a[0 .. 2^log_n).  decimation: ZK_DIF natural in -> bit-reversed out; ZK_DIT bit-reversed in ->

@@ -102,11 +102,30 @@ def g2_sum_partials(partials) -> np.ndarray:
 class ResidentBases:
     """pk / SRS bases kept in HBM across calls (zk_bn254_bases_register)."""
 
-    def __init__(self, points, is_g2: bool = False):
-        width = 16 if is_g2 else 8
-        points = _as_u64(points, width)
-        self.n, self.is_g2, self.handle = points.shape[0], is_g2, C.c_uint64(0)
+    def __init__(self, points, is_g2: bool = False, n: int | None = None):
+        """points: gnark memory images (numpy) -- or a DeviceBuffer / raw device pointer together with `n` (bases already in HBM)."""
+        self.is_g2, self.handle = is_g2, C.c_uint64(0)
+        if isinstance(points, (_lib.DeviceBuffer, int)):
+            if n is None:
+                raise ValueError("n is required with device-resident points")
+            self.n = n
+            ptr = points.ptr if isinstance(points, _lib.DeviceBuffer) else int(points)
+            check(lib().zk_bn254_bases_register_dev(C.c_void_p(ptr), C.c_size_t(n), C.c_int(int(is_g2)), C.byref(self.handle)))
+            return
+        points = _as_u64(points, 16 if is_g2 else 8)
+        self.n = points.shape[0]
         check(lib().zk_bn254_bases_register(vp(points), C.c_size_t(self.n), C.c_int(int(is_g2)), C.byref(self.handle)))
+
+    def multi_exp_dev(self, d_scalars, n: int, config: MultiExpConfig | None = None, offset: int = 0) -> np.ndarray:
+        """kzg.Commit of a polynomial that already lives in HBM (DeviceBuffer or raw device pointer)."""
+        out = np.zeros(16 if self.is_g2 else 8, dtype=np.uint64)
+        cfg = (config or MultiExpConfig())._c()
+        ptr = d_scalars.ptr if isinstance(d_scalars, _lib.DeviceBuffer) else int(d_scalars)
+        rc = lib().zk_bn254_msm_bases_dev(self.handle, C.c_size_t(offset), C.c_void_p(ptr), C.c_size_t(n), C.byref(cfg), vp(out))
+        if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_NB_TASKS):
+            raise ValueError((lib().zk_last_error() or b"").decode())
+        check(rc)
+        return out
 
     def multi_exp(self, scalars, config: MultiExpConfig | None = None, offset: int = 0) -> np.ndarray:
         scalars = _as_u64(scalars, 4)

@@ -985,6 +985,10 @@ struct Bases {
     void* d = nullptr;
     size_t n = 0;
     int is_g2 = 0;
+    // precomputed window table T[w * n + i] = 2^(c*w) * P_i (as for a resident Groth16 key): built at registration when it fits, so that
+    // every commit against the bases feeds ONE bucket set (KZG: ~10 commits per PLONK proof against the same SRS)
+    void* d_table = nullptr;
+    MsmTable tab;
 };
 static std::mutex g_bases_mu;
 static std::map<uint64_t, Bases> g_bases;
@@ -1104,7 +1108,7 @@ int zk_bn254_g2_sum_xyzz(const uint64_t* partials, size_t n_partials, zk_g2_affi
     return ZK_OK;
 }
 
-int zk_bn254_bases_register(const void* points, size_t n, int is_g2, uint64_t* handle) {
+static int bases_register(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind) {
     if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
     ZK_TRY(ensure_init());
     Bases b;
@@ -1112,21 +1116,41 @@ int zk_bn254_bases_register(const void* points, size_t n, int is_g2, uint64_t* h
     b.is_g2 = is_g2 ? 1 : 0;
     size_t bytes = n * (is_g2 ? 128 : 64);
     ZK_HIP(hipMalloc(&b.d, bytes ? bytes : 16));
-    if (bytes) ZK_HIP(hipMemcpy(b.d, points, bytes, hipMemcpyHostToDevice));
+    if (bytes) ZK_HIP(hipMemcpy(b.d, points, bytes, kind));
+    if (n >= 4096 && !(getenv("ZKMI_BASES_TABLES") && atoi(getenv("ZKMI_BASES_TABLES")) == 0)) {
+        b.tab.c = msm_pick_window_table(n);
+        b.tab.stride = n;
+        const size_t Wd = (255 + b.tab.c - 1) / b.tab.c, tbytes = Wd * n * (is_g2 ? 128 : 64);
+        size_t free_b = 0, total_b = 0;
+        ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (tbytes < free_b / 2 && tbytes <= ((size_t)64 << 30)) {
+            SlotGuard g;
+            ZK_TRY(acquire_slot(&g.s));
+            ZK_HIP(hipMalloc(&b.d_table, tbytes));
+            ZK_TRY(is_g2 ? msm_build_table_g2(g.s, g.s->stream, b.d, n, n, 0, b.tab.c, b.d_table)
+                         : msm_build_table_g1(g.s, g.s->stream, b.d, n, n, 0, b.tab.c, b.d_table));
+            ZK_TRY(slot_sync(g.s, g.s->stream));
+        }
+    }
     std::lock_guard<std::mutex> lk(g_bases_mu);
     *handle = g_next_handle++;
     g_bases[*handle] = b;
     return ZK_OK;
+}
+int zk_bn254_bases_register(const void* points, size_t n, int is_g2, uint64_t* handle) { return bases_register(points, n, is_g2, handle, hipMemcpyHostToDevice); }
+int zk_bn254_bases_register_dev(const void* d_points, size_t n, int is_g2, uint64_t* handle) {
+    return bases_register(d_points, n, is_g2, handle, hipMemcpyDeviceToDevice);
 }
 int zk_bn254_bases_free(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_bases_mu);
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
     (void)hipFree(it->second.d);
+    if (it->second.d_table) (void)hipFree(it->second.d_table);
     g_bases.erase(it);
     return ZK_OK;
 }
-int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr* scalars, size_t n, const zk_msm_cfg* cfg, void* out) {
+static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t n, const zk_msm_cfg* cfg, void* out, hipMemcpyKind kind) {
     Bases b;
     {
         std::lock_guard<std::mutex> lk(g_bases_mu);
@@ -1140,11 +1164,38 @@ int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr* scalars, siz
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     hipStream_t st = g.s->stream;
+    if (b.d_table && n && !(cfg && cfg->window_bits)) {  // window-table path (an explicit window width in cfg selects the plain method)
+        size_t np = 0, na1 = 0, na2 = 0;
+        ZK_TRY(msm_prep_need_table(n, b.tab, st, &np, &na1, &na2));
+        ZK_TRY(g.s->reserve(n * 32 + 1024 + np + (b.is_g2 ? na2 : na1)));
+        void* d_sc = g.s->alloc(n * 32 + 16);
+        if (kind == hipMemcpyDeviceToDevice) d_sc = const_cast<void*>(scalars);  // already in HBM: read in place
+        else ZK_HIP(hipMemcpyAsync(d_sc, scalars, n * 32, kind, st));
+        MsmPrep prep;
+        ZK_TRY(msm_prepare_scalars_table(g.s, st, d_sc, n, cfg, b.tab, &prep));
+        MsmJob job;
+        int rc;
+        if (b.is_g2) {
+            XYZZ<HFp2> t;
+            rc = msm_g2_accumulate(g.s, st, prep, (const char*)b.d_table + offset * 128, 0, &job);
+            if (rc == ZK_OK) rc = msm_g2_finish(job, &t);
+            if (rc == ZK_OK) write_affine(t, (zk_g2_affine*)out);
+        } else {
+            XYZZ<HFp> t;
+            rc = msm_g1_accumulate(g.s, st, prep, (const char*)b.d_table + offset * 64, 0, &job);
+            if (rc == ZK_OK) rc = msm_g1_finish(job, &t);
+            if (rc == ZK_OK) write_affine(t, (zk_g1_affine*)out);
+        }
+        if (rc != ZK_OK) (void)hipStreamSynchronize(st);
+        msm_prep_release(&prep);
+        return rc;
+    }
     size_t need = 0;
     ZK_TRY(b.is_g2 ? msm_g2_need(n, cfg, st, &need) : msm_g1_need(n, cfg, st, &need));
     ZK_TRY(g.s->reserve(n * 32 + 1024 + need));
     void* d_s = g.s->alloc(n * 32 + 16);
-    if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, hipMemcpyHostToDevice, st));
+    if (kind == hipMemcpyDeviceToDevice) d_s = const_cast<void*>(scalars);
+    else if (n) ZK_HIP(hipMemcpyAsync(d_s, scalars, n * 32, kind, st));
     if (b.is_g2) {
         XYZZ<HFp2> t;
         ZK_TRY(msm_g2_xyzz(g.s, st, (const char*)b.d + offset * 128, d_s, n, cfg, &t));
@@ -1155,6 +1206,12 @@ int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr* scalars, siz
         write_affine(t, (zk_g1_affine*)out);
     }
     return ZK_OK;
+}
+int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr* scalars, size_t n, const zk_msm_cfg* cfg, void* out) {
+    return msm_bases(handle, offset, scalars, n, cfg, out, hipMemcpyHostToDevice);
+}
+int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, void* out) {
+    return msm_bases(handle, offset, d_scalars, n, cfg, out, hipMemcpyDeviceToDevice);
 }
 
 }  // extern "C"

@@ -577,3 +577,32 @@ def test_cpp_host_mirror_runs_msm_and_fft(tmp_path):
         f.write(np.uint64(log_n).tobytes() + x.tobytes() + orc.fr_ntt(x, False, ref.DIF).tobytes())
     out = subprocess.run([exe, str(blob)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def test_registered_bases_use_window_tables_g1_g2_offsets_and_skew():
+    """zk_bn254_bases_register builds window tables for >= 4096 bases (KZG: many commits against one SRS); commits through them -- full,
+    sub-range with offset, witness-like scalars, G2, explicit window width (plain method) -- all equal the oracle."""
+    n = 6000
+    pts = orc.g1_gen_points(101, n)
+    rb = zb.ResidentBases(pts)
+    for seed, wl in ((102, False), (103, True)):
+        sc = orc.rand_fr(seed, n, witness_like=wl)
+        assert (rb.multi_exp(sc) == orc.g1_msm(pts, sc)).all()
+        assert (rb.multi_exp(sc[:4500], offset=1500) == orc.g1_msm(pts[1500:], sc[:4500])).all()
+        assert (rb.multi_exp(sc[:10], offset=5990) == orc.g1_msm(pts[5990:], sc[:10])).all()
+        assert (rb.multi_exp(sc, zk.MultiExpConfig(window_bits=11)) == orc.g1_msm(pts, sc)).all()
+    zero = np.zeros((n, 4), np.uint64)
+    assert (rb.multi_exp(zero) == 0).all()
+    rb.free()
+    # bases and scalars already in HBM (kzg.Commit of a polynomial the NTTs left on the device)
+    dp, ds = _lib.DeviceBuffer.from_numpy(pts), _lib.DeviceBuffer.from_numpy(sc)
+    rbd = zb.ResidentBases(dp, n=n)
+    assert (rbd.multi_exp_dev(ds, n) == orc.g1_msm(pts, sc)).all()
+    assert (rbd.multi_exp_dev(ds.ptr + 100 * 32, 3000, offset=100) == orc.g1_msm(pts[100:3100], sc[100:3100])).all()
+    rbd.free()
+    p2 = orc.g2_gen_points(104, 4200)
+    rb2 = zb.ResidentBases(p2, is_g2=True)
+    s2 = orc.rand_fr(105, 4200)
+    assert (rb2.multi_exp(s2) == orc.g2_msm(p2, s2)).all()
+    assert (rb2.multi_exp(s2[:1000], offset=3000) == orc.g2_msm(p2[3000:4000], s2[:1000])).all()
+    rb2.free()
