@@ -128,15 +128,20 @@ def main():
             return zk.prove(pk, d_a, d_b, d_c, d_w, r, s, n_constraints=N_g, on_device=True)
         sess = par.groth16_msm5_pk_begin(pk, d_w.ptr)  # digits / sort / task plan of w run under computeH and its exchanges
         try:
-            side = torch.cuda.ExternalStream(par.groth16_session_stream(sess))  # the library's computeH stream, shared with torch / RCCL
-        except Exception:  # a torch build without ExternalStream: any non-null stream works (the library then bridges with events)
-            side = fallback_stream
-        with torch.cuda.stream(side):
-            # the prover consumes its working buffers: at N > 1 the first all-to-all already writes fresh ones, at N = 1 copy
-            a, b, c = (t.clone() for t in t_abc) if world == 1 else t_abc
-            h = par.compute_h_sharded(a, b, c, log_ng, rank, world)
-            rec = par.groth16_msm5_pk_end(sess, h.data_ptr(), side.cuda_stream)
-            return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)
+            try:
+                side = torch.cuda.ExternalStream(par.groth16_session_stream(sess))  # the library's computeH stream, shared with torch / RCCL
+            except Exception:  # a torch build without ExternalStream: any non-null stream works (the library then bridges with events)
+                side = fallback_stream
+            with torch.cuda.stream(side):
+                # the prover consumes its working buffers: at N > 1 the first all-to-all already writes fresh ones, at N = 1 copy
+                a, b, c = (t.clone() for t in t_abc) if world == 1 else t_abc
+                h = par.compute_h_sharded(a, b, c, log_ng, rank, world)
+                live, sess = sess, None  # _end releases the session whatever it returns
+                rec = par.groth16_msm5_pk_end(live, h.data_ptr(), side.cuda_stream)
+                return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)
+        finally:
+            if sess is not None:  # computeH or an exchange raised between _begin and _end: give the five stream slots back
+                par.groth16_msm5_pk_abort(sess)
 
     def barrier():
         if world > 1:

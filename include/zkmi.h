@@ -47,14 +47,18 @@ typedef enum {
     ZK_ERR_NO_DEVICE = -3,  /* no usable gfx950 device / HIP runtime -- never falls back to the CPU */
     ZK_ERR_HIP = -4,        /* a HIP call failed; see zk_last_error() */
     ZK_ERR_ARG = -5,        /* bad argument (null pointer, size not a power of two, log_n > 28, ...) */
-    ZK_ERR_HANDLE = -6      /* unknown or freed handle */
+    ZK_ERR_HANDLE = -6,     /* unknown or freed handle (or a proving key that live msm5 sessions still use) */
+    ZK_ERR_BUSY = -7        /* no stream slot became free within the time limit (ZKMI_SLOT_TIMEOUT_S, default 120 s): a caller
+                               that holds an msm5 session (5 of the 8 slots) and asks for more would otherwise wait forever */
 } zk_status;
 
 /* mirrors ecc.MultiExpConfig{NbTasks, ScalarsMont} of gnark-crypto v0.9.1, plus device-side knobs */
 typedef struct {
     int nb_tasks;      /* accepted for compatibility; > 1024 is rejected like upstream; otherwise ignored      */
-    int scalars_mont;  /* 1: scalars are Montgomery fr.Element images (gnark's default container); 0: canonical */
-    int window_bits;   /* 0 = auto (cost model for the GPU), else c in [4, 20]                                   */
+    int scalars_mont;  /* 1: scalars are Montgomery fr.Element images; 0: regular (canonical) form -- upstream's zero value
+                          (gnark v0.8.0 calls FromMont() on the wire values / h and passes the default config)         */
+    int window_bits;   /* 0 = auto (cost model for the GPU), else c in [2, 22]; against registered bases with window
+                          tables an explicit value selects the plain (table-less) method                              */
     int reserved;
 } zk_msm_cfg;
 
@@ -93,6 +97,9 @@ int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr *scalars, siz
 /* the same with the points (register) / the scalars (msm) already in HBM -- KZG commits of polynomials that the NTTs left on the device.
  * Registration builds precomputed window tables 2^(c*w)*P_i when they fit (>= 4096 bases): every commit then feeds one bucket set. */
 int zk_bn254_bases_register_dev(const void *d_points, size_t n, int is_g2, uint64_t *handle);
+/* The same with the table geometry chosen by the caller: table_window_bits = 0 auto (tables for >= 4096 bases when they fit),
+ * -1 no tables, else c in [8, 22] (tables at any n: how the tests reach the widths the planner picks at 2^22 .. 2^26 points). */
+int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_device, int table_window_bits, uint64_t *handle);
 int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);
 
 /* ---- NTT: (*fft.Domain).FFT / FFTInverse / fft.BitReverse ------------------------------------------------------
@@ -123,9 +130,15 @@ int zk_bn254_groth16_h_shard_dev(int phase, void *d_a, void *d_b, void *d_c, uin
                                  uint32_t rank, void *stream);
 
 /* ProvingKey image (host pointers; copied to the device by zk_bn254_groth16_pk_load).  Same field names as gnark's
- * groth16.ProvingKey{G1{Alpha,Beta,Delta,A,B,K,Z}, G2{Beta,Delta,B}}; A/B/G2.B have n_wires entries (points at
- * infinity allowed -- they contribute nothing, which is what gnark's InfinityA/InfinityB filtering achieves);
- * K has n_wires - n_public; Z has 2^log_domain entries in gnark's (bit-reversed) order, N-1 are used. */
+ * groth16.ProvingKey{G1{Alpha,Beta,Delta,A,B,K,Z}, G2{Beta,Delta,B}, InfinityA, InfinityB, NbInfinityA, NbInfinityB}
+ * (gnark v0.8.0 internal/backend/bn254/groth16/setup.go; the reference reaches it at gnark_backend_ffi/main.go:121,131 and
+ * meant to pass it through backend/groth16/r1cs.go:107-143).
+ *   - gnark's layout: infinity_a / infinity_b point at the []bool images (one byte per wire, != 0: that wire's point is the point
+ *     at infinity and is NOT stored); g1_a then holds n_wires - nb_infinity_a points, g1_b and g2_b n_wires - nb_infinity_b,
+ *     exactly the slices gnark keeps.  pk_load expands them on the device (one scatter kernel) to wire-indexed arrays, so the
+ *     prover reads the full wire vector and needs no per-MSM filtering of the scalars.
+ *   - dense layout: infinity_a == infinity_b == NULL; g1_a / g1_b / g2_b have n_wires entries, (0,0) = infinity contributes nothing.
+ * K has n_wires - n_public entries; Z has 2^log_domain entries in gnark's (bit-reversed) order, N-1 are used. */
 typedef struct {
     uint32_t log_domain;
     size_t n_wires, n_public;
@@ -137,15 +150,22 @@ typedef struct {
     int flags;           /* bit 0: do NOT build the precomputed window tables 2^(c*w)*P_i (they cost ~13x the bases in HBM and
                             are what makes the resident-key MSMs ~20% cheaper; skipped automatically when HBM is short)
                             bit 1: all 2^log_domain entries of Z are used (a non-final slice of a range-sharded key) */
+    const uint8_t *infinity_a, *infinity_b; /* gnark's InfinityA / InfinityB ([]bool, HOST pointers, n_wires bytes) or NULL */
+    size_t nb_infinity_a, nb_infinity_b;    /* gnark's NbInfinityA / NbInfinityB; must equal the number of non-zero bytes */
+    int table_window_bits;                  /* 0: planner's choice; else the window width c in [8, 22] of the tables */
+    int reserved;
 } zk_groth16_pk;
 int zk_bn254_groth16_pk_load(const zk_groth16_pk *pk, uint64_t *handle);
-int zk_bn254_groth16_pk_free(uint64_t handle);
+int zk_bn254_groth16_pk_free(uint64_t handle);   /* ZK_ERR_HANDLE while an msm5 session still uses the key */
+/* Geometry of a loaded key (any out pointer may be NULL): lets a caller validate len(w) before handing a bare pointer over. */
+int zk_bn254_groth16_pk_info(uint64_t handle, size_t *n_wires, size_t *n_public, uint32_t *log_domain, int *has_tables);
 /* Prove with the prover randomness (r, s) as INPUTS (upstream draws them from crypto/rand; pinning them is what
  * makes "bit-exact proof bytes" well defined).  a, b, c: n_constraints evaluations (solver output); w: n_wires wire
  * values; all Montgomery fr.Element.  proof_out = Ar | Bs | Krs in gnark's compressed encoding (32+64+32 bytes),
  * i.e. Proof.WriteTo.  `on_device` != 0: a, b, c, w are device pointers. */
 int zk_bn254_groth16_prove(uint64_t pk_handle, const void *a, const void *b, const void *c, size_t n_constraints,
-                           const void *w, const zk_fr *r, const zk_fr *s, int on_device, uint8_t proof_out[128]);
+                           const void *w, size_t n_wires, const zk_fr *r, const zk_fr *s, int on_device, uint8_t proof_out[128]);
+/* n_wires = len(w): must equal the key's wire count (ZK_ERR_LEN otherwise -- the library reads exactly that many elements). */
 
 /* The two halves of zk_bn254_groth16_prove, exposed so that one proof can be range-sharded over several GPUs
  * (one process per GPU): every rank runs the five MSMs on ITS slice of the bases / wire values / h, the un-normalised
@@ -165,6 +185,9 @@ int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void *d_w, const void *d_
  * enqueues the rest behind `stream` and waits for the record. */
 int zk_bn254_groth16_msm5_pk_begin(uint64_t pk_handle, const void *d_w, uint64_t *session);
 int zk_bn254_groth16_msm5_pk_end(uint64_t session, const void *d_h, uint64_t out_xyzz[96], void *stream);
+/* Gives a session up without finishing it (an exception between _begin and _end): waits for the work already enqueued and
+ * releases the five stream slots.  Unknown / already ended sessions return ZK_ERR_HANDLE. */
+int zk_bn254_groth16_msm5_pk_abort(uint64_t session);
 /* The session's high-priority stream (valid until _end): run the sharded computeH and its exchanges on it -- that is the
  * stream zk_bn254_groth16_prove runs computeH on, and it never shares a hardware queue with the preparation of w. */
 int zk_bn254_groth16_msm5_session_stream(uint64_t session, void **stream_out);

@@ -37,7 +37,8 @@ namespace ecc {
 // ecc.MultiExpConfig{NbTasks int; ScalarsMont bool}
 struct MultiExpConfig {
     int NbTasks = 0;
-    bool ScalarsMont = true;  // fr.Element containers hold Montgomery images
+    bool ScalarsMont = false;  // upstream's zero value: the scalars' limbs are taken in REGULAR form (gnark v0.8.0's prover calls
+                               // FromMont() on the wire values and on h, then passes MultiExpConfig{}); true: Montgomery fr.Elements
 };
 }  // namespace ecc
 
@@ -106,7 +107,7 @@ inline Error BitReverse(fr::Vector& a) {
 
 namespace groth16 {
 
-// groth16.ProvingKey resident in HBM (RAII over zk_bn254_groth16_pk_load / _free)
+// groth16.ProvingKey resident in HBM (RAII over zk_bn254_groth16_pk_load / _free); keeps the geometry the prover validates against
 class ProvingKey {
 public:
     ProvingKey() = default;
@@ -115,22 +116,36 @@ public:
     ~ProvingKey() {
         if (handle_) zk_bn254_groth16_pk_free(handle_);
     }
-    Error Load(const zk_groth16_pk& pk) { return make_error(zk_bn254_groth16_pk_load(&pk, &handle_)); }
+    // pk.infinity_a / infinity_b (gnark's InfinityA / InfinityB) select gnark's compact A / B / G2.B layout
+    Error Load(const zk_groth16_pk& pk) {
+        Error e = make_error(zk_bn254_groth16_pk_load(&pk, &handle_));
+        if (!e.ok()) return e;
+        return make_error(zk_bn254_groth16_pk_info(handle_, &n_wires_, &n_public_, &log_domain_, nullptr));
+    }
     uint64_t handle() const { return handle_; }
+    size_t NbWires() const { return n_wires_; }
+    size_t NbPublic() const { return n_public_; }
+    uint64_t DomainCardinality() const { return uint64_t(1) << log_domain_; }
 
 private:
     uint64_t handle_ = 0;
+    size_t n_wires_ = 0, n_public_ = 0;
+    uint32_t log_domain_ = 0;
 };
 
 struct Proof {
     uint8_t bytes[128];  // Proof.WriteTo: Ar | Bs | Krs, gnark's compressed encodings
 };
 
-// groth16.Prove after the solver: a, b, c = evaluations of the constraint system, w = wire values, (r, s) = the prover's randomness
+// groth16.Prove after the solver: a, b, c = evaluations of the constraint system, w = wire values, (r, s) = the prover's randomness.
+// All four vectors hold Montgomery fr.Elements (the solver's containers).  Length errors come back as ZK_ERR_LEN -- the library
+// reads exactly NbWires() elements of w and at most DomainCardinality() of a, b, c, so nothing is read out of bounds.
 inline Error Prove(const ProvingKey& pk, const fr::Vector& a, const fr::Vector& b, const fr::Vector& c, const fr::Vector& w, const fr::Element& r,
                    const fr::Element& s, Proof* proof) {
     if (a.size() != b.size() || a.size() != c.size()) return Error{ZK_ERR_LEN, "len(a), len(b), len(c) differ"};
-    return make_error(zk_bn254_groth16_prove(pk.handle(), a.data(), b.data(), c.data(), a.size(), w.data(), &r, &s, 0, proof->bytes));
+    if (a.size() > pk.DomainCardinality()) return Error{ZK_ERR_LEN, "len(a) exceeds the domain cardinality"};
+    if (w.size() != pk.NbWires()) return Error{ZK_ERR_LEN, "len(w) != number of wires of the proving key"};
+    return make_error(zk_bn254_groth16_prove(pk.handle(), a.data(), b.data(), c.data(), a.size(), w.data(), w.size(), &r, &s, 0, proof->bytes));
 }
 
 }  // namespace groth16

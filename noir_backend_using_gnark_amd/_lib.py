@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkmi.so")
 
-ZK_OK, ZK_ERR_LEN, ZK_ERR_NB_TASKS, ZK_ERR_NO_DEVICE, ZK_ERR_HIP, ZK_ERR_ARG, ZK_ERR_HANDLE = 0, -1, -2, -3, -4, -5, -6
+ZK_OK, ZK_ERR_LEN, ZK_ERR_NB_TASKS, ZK_ERR_NO_DEVICE, ZK_ERR_HIP, ZK_ERR_ARG, ZK_ERR_HANDLE, ZK_ERR_BUSY = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class ZkmiError(RuntimeError):
@@ -25,7 +25,9 @@ class Groth16PK(C.Structure):
     _fields_ = [("log_domain", C.c_uint32), ("n_wires", C.c_size_t), ("n_public", C.c_size_t),
                 ("g1_alpha", C.c_void_p), ("g1_beta", C.c_void_p), ("g1_delta", C.c_void_p),
                 ("g1_a", C.c_void_p), ("g1_b", C.c_void_p), ("g1_k", C.c_void_p), ("g1_z", C.c_void_p),
-                ("g2_beta", C.c_void_p), ("g2_delta", C.c_void_p), ("g2_b", C.c_void_p), ("bases_on_device", C.c_int), ("flags", C.c_int)]
+                ("g2_beta", C.c_void_p), ("g2_delta", C.c_void_p), ("g2_b", C.c_void_p), ("bases_on_device", C.c_int), ("flags", C.c_int),
+                ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p), ("nb_infinity_a", C.c_size_t), ("nb_infinity_b", C.c_size_t),
+                ("table_window_bits", C.c_int), ("reserved", C.c_int)]
 
 
 # every symbol include/zkmi.h declares (tests check that the library exports exactly these)
@@ -33,12 +35,12 @@ SYMBOLS = [
     "zk_device_count", "zk_init", "zk_last_error", "zk_version",
     "zk_bn254_g1_msm", "zk_bn254_g2_msm", "zk_bn254_g1_msm_dev", "zk_bn254_g2_msm_dev",
     "zk_bn254_g1_msm_partial_dev", "zk_bn254_g2_msm_partial_dev", "zk_bn254_g1_sum_xyzz", "zk_bn254_g2_sum_xyzz",
-    "zk_bn254_msm_plan_info", "zk_bn254_bases_register", "zk_bn254_bases_register_dev", "zk_bn254_bases_free", "zk_bn254_msm_bases", "zk_bn254_msm_bases_dev",
+    "zk_bn254_msm_plan_info", "zk_bn254_bases_register", "zk_bn254_bases_register_dev", "zk_bn254_bases_register_cfg", "zk_bn254_bases_free", "zk_bn254_msm_bases", "zk_bn254_msm_bases_dev",
     "zk_bn254_ntt", "zk_bn254_ntt_dev", "zk_bn254_bit_reverse", "zk_bn254_bit_reverse_dev",
     "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev",
     "zk_bn254_felts_decode_hex", "zk_bn254_felts_decode_hex_dev", "zk_bn254_felts_decode_bytes_dev", "zk_bn254_felts_encode_hex",
-    "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_prove",
-    "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
+    "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_pk_info", "zk_bn254_groth16_prove",
+    "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_pk_abort", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_selftest_host",

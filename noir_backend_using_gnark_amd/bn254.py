@@ -28,7 +28,7 @@ DIT, DIF = 0, 1
 @dataclass
 class MultiExpConfig:
     nb_tasks: int = 0          # upstream NbTasks; > 1024 is an error like upstream, otherwise ignored on the GPU
-    scalars_mont: bool = True  # scalars are Montgomery fr.Element images (gnark's container)
+    scalars_mont: bool = False  # upstream's zero value: scalars in regular form (gnark v0.8.0 calls FromMont() before MultiExp); True = Montgomery images
     window_bits: int = 0       # 0 = auto
 
     def _c(self) -> MsmCfg:
@@ -102,19 +102,20 @@ def g2_sum_partials(partials) -> np.ndarray:
 class ResidentBases:
     """pk / SRS bases kept in HBM across calls (zk_bn254_bases_register)."""
 
-    def __init__(self, points, is_g2: bool = False, n: int | None = None):
-        """points: gnark memory images (numpy) -- or a DeviceBuffer / raw device pointer together with `n` (bases already in HBM)."""
+    def __init__(self, points, is_g2: bool = False, n: int | None = None, table_window_bits: int = 0):
+        """points: gnark memory images (numpy) -- or a DeviceBuffer / raw device pointer together with `n` (bases already in HBM).
+        table_window_bits: 0 = the planner decides (window tables for >= 4096 bases), -1 = none, else the tables' window width."""
         self.is_g2, self.handle = is_g2, C.c_uint64(0)
         if isinstance(points, (_lib.DeviceBuffer, int)):
             if n is None:
                 raise ValueError("n is required with device-resident points")
             self.n = n
             ptr = points.ptr if isinstance(points, _lib.DeviceBuffer) else int(points)
-            check(lib().zk_bn254_bases_register_dev(C.c_void_p(ptr), C.c_size_t(n), C.c_int(int(is_g2)), C.byref(self.handle)))
+            check(lib().zk_bn254_bases_register_cfg(C.c_void_p(ptr), C.c_size_t(n), C.c_int(int(is_g2)), C.c_int(1), C.c_int(table_window_bits), C.byref(self.handle)))
             return
         points = _as_u64(points, 16 if is_g2 else 8)
         self.n = points.shape[0]
-        check(lib().zk_bn254_bases_register(vp(points), C.c_size_t(self.n), C.c_int(int(is_g2)), C.byref(self.handle)))
+        check(lib().zk_bn254_bases_register_cfg(vp(points), C.c_size_t(self.n), C.c_int(int(is_g2)), C.c_int(0), C.c_int(table_window_bits), C.byref(self.handle)))
 
     def multi_exp_dev(self, d_scalars, n: int, config: MultiExpConfig | None = None, offset: int = 0) -> np.ndarray:
         """kzg.Commit of a polynomial that already lives in HBM (DeviceBuffer or raw device pointer)."""

@@ -3,6 +3,9 @@
 
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <chrono>
 #include <thread>
 
 namespace zkmi {
@@ -62,10 +65,23 @@ int ensure_init() {
     return init_locked(0);
 }
 
+// A caller that already holds slots (an msm5 session pins 5 of the 8) and asks for more than are left would wait forever:
+// waiting is bounded (ZKMI_SLOT_TIMEOUT_S, default 120 s) and ends in ZK_ERR_BUSY instead of a silent hang.
+static double slot_timeout_s() {
+    static const double t = getenv("ZKMI_SLOT_TIMEOUT_S") ? atof(getenv("ZKMI_SLOT_TIMEOUT_S")) : 120.0;
+    return t;
+}
+static bool slot_wait_expired(const std::chrono::steady_clock::time_point& t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > slot_timeout_s();
+}
+
 int acquire_slot(Slot** out) {
     ZK_TRY(ensure_init());
     Ctx& c = ctx();
-    for (;;) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++) {
+        if ((spin & 1023) == 1023 && slot_wait_expired(t0))
+            return set_err(ZK_ERR_BUSY, "no stream slot became free within %.0f s (an unfinished msm5 session? call zk_bn254_groth16_msm5_pk_abort)", slot_timeout_s());
         {
             std::lock_guard<std::mutex> lk(c.mu);
             for (int i = 0; i < Ctx::NSLOTS; i++)
@@ -84,7 +100,11 @@ int acquire_slots(int k, Slot** out) {
     ZK_TRY(ensure_init());
     Ctx& c = ctx();
     if (k > Ctx::NSLOTS) return set_err(ZK_ERR_ARG, "asked for %d stream slots, only %d exist", k, Ctx::NSLOTS);
-    for (;;) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++) {
+        if ((spin & 1023) == 1023 && slot_wait_expired(t0))
+            return set_err(ZK_ERR_BUSY, "%d stream slots did not become free within %.0f s (an unfinished msm5 session? call zk_bn254_groth16_msm5_pk_abort)", k,
+                           slot_timeout_s());
         {
             std::lock_guard<std::mutex> lk(c.mu);
             int nfree = 0;

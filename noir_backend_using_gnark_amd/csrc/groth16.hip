@@ -63,7 +63,9 @@ struct Groth16PK {
     std::shared_ptr<FixedBase<HFp>> fb_delta;
     std::shared_ptr<FixedBase<HFp2>> fb_delta2;
     void *d_a = nullptr, *d_b = nullptr, *d_k = nullptr, *d_z = nullptr, *d_b2 = nullptr;
-    bool owns = true;
+    bool owns = true;       // all five base arrays are the key's own allocations
+    bool owns_abb = false;  // (with !owns) only the expanded A / B / G2.B arrays are
+    int sessions = 0;       // live msm5 sessions holding copies of the device pointers: pk_free refuses while > 0
     // precomputed window tables T[w][i] = 2^(c*w) * P_i for the five base arrays (resident; built once at load time):
     // every window of an MSM then shares one bucket set -- ceil(255/c) * n mixed additions with c ~ 20 instead of 16 windows
     // of c = 16, one bucket reduction instead of 16, no Horner.  The K table uses wire indexing (first n_public rows = infinity).
@@ -121,12 +123,47 @@ using namespace zkmi;
 
 extern "C" {
 
+// Everything pk_load allocates, freed again on any early return (with tables at 2^24 constraints that is ~90 GB of HBM).
+struct PkAllocs {
+    std::vector<void*> ptrs;
+    bool keep = false;
+    int dev_alloc(void** d, size_t bytes) {
+        ZK_HIP(hipMalloc(d, bytes ? bytes : 16));
+        ptrs.push_back(*d);
+        return ZK_OK;
+    }
+    ~PkAllocs() {
+        if (!keep)
+            for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+// gnark's []bool image -> for every wire the index into the compact array (or ~0u for a point at infinity)
+static int infinity_map(const uint8_t* inf, size_t n_wires, size_t nb_inf, std::vector<uint32_t>* map, const char* which) {
+    map->resize(n_wires);
+    size_t j = 0, cnt = 0;
+    for (size_t i = 0; i < n_wires; i++) {
+        if (inf[i]) { (*map)[i] = 0xffffffffu; cnt++; }
+        else (*map)[i] = (uint32_t)j++;
+    }
+    if (cnt != nb_inf) return set_err(ZK_ERR_ARG, "NbInfinity%s = %zu but Infinity%s marks %zu wires", which, nb_inf, which, cnt);
+    return ZK_OK;
+}
+
 int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     if (!pk || !handle) return set_err(ZK_ERR_ARG, "null pointer");
     if (pk->log_domain > 28 || pk->n_public > pk->n_wires) return set_err(ZK_ERR_ARG, "bad proving-key geometry");
+    if (pk->n_wires >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "n_wires = %zu does not fit 31 bits", pk->n_wires);
     if (!pk->g1_alpha || !pk->g1_beta || !pk->g1_delta || !pk->g2_beta || !pk->g2_delta) return set_err(ZK_ERR_ARG, "null pk element");
+    if ((pk->infinity_a == nullptr) != (pk->infinity_b == nullptr)) return set_err(ZK_ERR_ARG, "InfinityA and InfinityB must be given together");
+    if (!pk->infinity_a && (pk->nb_infinity_a || pk->nb_infinity_b)) return set_err(ZK_ERR_ARG, "NbInfinityA/B without the bitmaps");
+    if (pk->table_window_bits && (pk->table_window_bits < 8 || pk->table_window_bits > 22))
+        return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", pk->table_window_bits);
+    const bool compact = pk->infinity_a != nullptr;
+    if (compact && (pk->nb_infinity_a > pk->n_wires || pk->nb_infinity_b > pk->n_wires)) return set_err(ZK_ERR_ARG, "NbInfinity exceeds the wire count");
     ZK_TRY(ensure_init());
     Groth16PK P;
+    PkAllocs mem;
     P.log_domain = pk->log_domain;
     P.n_wires = pk->n_wires;
     P.n_public = pk->n_public;
@@ -139,28 +176,67 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     P.fb_delta->build(P.delta);
     P.fb_delta2 = std::make_shared<FixedBase<HFp2>>();
     P.fb_delta2->build(P.delta2);
-    size_t N = (size_t)1 << pk->log_domain, nk = pk->n_wires - pk->n_public;
+    const size_t N = (size_t)1 << pk->log_domain, nw = pk->n_wires, nk = pk->n_wires - pk->n_public;
+    const size_t na = compact ? nw - pk->nb_infinity_a : nw, nbb = compact ? nw - pk->nb_infinity_b : nw;  // entries the caller's A / B arrays hold
     P.nz = (pk->flags & 2) ? N : N - 1;
-    if (pk->bases_on_device) {
+    // ---- the five base arrays, wire-indexed, resident
+    struct Up { void** d; const void* src; size_t n_src, esz; } up[5] = {{&P.d_a, pk->g1_a, na, 64}, {&P.d_b, pk->g1_b, nbb, 64}, {&P.d_k, pk->g1_k, nk, 64},
+                                                                        {&P.d_z, pk->g1_z, N, 64},   {&P.d_b2, pk->g2_b, nbb, 128}};
+    for (auto& u : up)
+        if (u.n_src && !u.src) return set_err(ZK_ERR_ARG, "null pk base array");
+    if (pk->bases_on_device && !compact) {
         P.owns = false;
-        P.d_a = (void*)pk->g1_a; P.d_b = (void*)pk->g1_b; P.d_k = (void*)pk->g1_k; P.d_z = (void*)pk->g1_z; P.d_b2 = (void*)pk->g2_b;
+        for (auto& u : up) *u.d = const_cast<void*>(u.src);
+    } else if (pk->bases_on_device) {
+        // compact A / B / G2.B already in HBM: only they are expanded into arrays of the key's own; K and Z stay the caller's
+        P.owns = false;
+        P.d_k = (void*)pk->g1_k;
+        P.d_z = (void*)pk->g1_z;
     } else {
-        struct { void** d; const void* h; size_t bytes; } up[5] = {{&P.d_a, pk->g1_a, pk->n_wires * 64}, {&P.d_b, pk->g1_b, pk->n_wires * 64},
-                                                                   {&P.d_k, pk->g1_k, nk * 64},          {&P.d_z, pk->g1_z, N * 64},
-                                                                   {&P.d_b2, pk->g2_b, pk->n_wires * 128}};
-        for (auto& u : up) {
-            if (u.bytes && !u.h) return set_err(ZK_ERR_ARG, "null pk base array");
-            ZK_HIP(hipMalloc(u.d, u.bytes ? u.bytes : 16));
-            if (u.bytes) ZK_HIP(hipMemcpy(*u.d, u.h, u.bytes, hipMemcpyHostToDevice));
+        for (int i = 2; i < 4; i++) {  // K, Z: as they are
+            ZK_TRY(mem.dev_alloc(up[i].d, up[i].n_src * up[i].esz));
+            if (up[i].n_src) ZK_HIP(hipMemcpy(*up[i].d, up[i].src, up[i].n_src * up[i].esz, hipMemcpyHostToDevice));
         }
+        if (!compact)
+            for (int i : {0, 1, 4}) {
+                ZK_TRY(mem.dev_alloc(up[i].d, up[i].n_src * up[i].esz));
+                if (up[i].n_src) ZK_HIP(hipMemcpy(*up[i].d, up[i].src, up[i].n_src * up[i].esz, hipMemcpyHostToDevice));
+            }
+    }
+    if (compact) {
+        std::vector<uint32_t> map_a, map_b;
+        ZK_TRY(infinity_map(pk->infinity_a, nw, pk->nb_infinity_a, &map_a, "A"));
+        ZK_TRY(infinity_map(pk->infinity_b, nw, pk->nb_infinity_b, &map_b, "B"));
+        SlotGuard g;
+        ZK_TRY(acquire_slot(&g.s));
+        hipStream_t st = g.s->stream;
+        const size_t stage = pk->bases_on_device ? 0 : (na * 64 + nbb * 64 + nbb * 128 + 3 * 256);
+        ZK_TRY(g.s->reserve(2 * (nw * 4 + 256) + stage + 4096));
+        uint32_t* d_ma = (uint32_t*)g.s->alloc(nw * 4 + 16);
+        uint32_t* d_mb = (uint32_t*)g.s->alloc(nw * 4 + 16);
+        if (nw) {
+            ZK_HIP(hipMemcpyAsync(d_ma, map_a.data(), nw * 4, hipMemcpyHostToDevice, st));
+            ZK_HIP(hipMemcpyAsync(d_mb, map_b.data(), nw * 4, hipMemcpyHostToDevice, st));
+        }
+        const uint32_t* maps[5] = {d_ma, d_mb, nullptr, nullptr, d_mb};
+        for (int i : {0, 1, 4}) {
+            const void* d_src = up[i].src;
+            if (!pk->bases_on_device) {
+                void* d_stage = g.s->alloc(up[i].n_src * up[i].esz + 16);
+                if (up[i].n_src) ZK_HIP(hipMemcpyAsync(d_stage, up[i].src, up[i].n_src * up[i].esz, hipMemcpyHostToDevice, st));
+                d_src = d_stage;
+            }
+            ZK_TRY(mem.dev_alloc(up[i].d, nw * up[i].esz));
+            ZK_TRY(msm_expand_bases(g.s, st, i == 4, d_src, maps[i], nw, *up[i].d));
+        }
+        ZK_TRY(slot_sync(g.s, st));
+        P.owns_abb = true;
     }
     // ---- precomputed window tables (unless disabled or HBM is short)
     if (!(pk->flags & 1) && pk->n_wires > 0 && N > 1) {
-        P.tab_w.c = msm_pick_window_table(pk->n_wires);
+        P.tab_w.c = pk->table_window_bits ? (unsigned)pk->table_window_bits : msm_pick_window_table(pk->n_wires);
         P.tab_w.stride = pk->n_wires;
-        P.tab_h.c = msm_pick_window_table(P.nz);
-        if (getenv("ZKMI_TABLE_C_W")) P.tab_w.c = (unsigned)atoi(getenv("ZKMI_TABLE_C_W"));  // experiment switches
-        if (getenv("ZKMI_TABLE_C_H")) P.tab_h.c = (unsigned)atoi(getenv("ZKMI_TABLE_C_H"));
+        P.tab_h.c = pk->table_window_bits ? (unsigned)pk->table_window_bits : msm_pick_window_table(P.nz);
         P.tab_h.stride = N;
         P.tab_w.l1_m = 16;  // A, B1, K, G2.B: their reduction tails hide under the next accumulate -- less work beats lower latency
         P.tab_w.l2_m = getenv("ZKMI_L2_M") ? (unsigned)atoi(getenv("ZKMI_L2_M")) : 8;  // measured: 8 -> -0.09 ms, 16 -> +0.15 ms, 32 -> +0.9 ms (the level gets too long to hide)
@@ -183,17 +259,20 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
                 {&P.t_k, P.d_k, nk, pk->n_wires, pk->n_public, 64, P.tab_w.c, Ww, 0}, {&P.t_z, P.d_z, P.nz, N, 0, 64, P.tab_h.c, Wh, 0},
                 {&P.t_b2, P.d_b2, pk->n_wires, pk->n_wires, 0, 128, P.tab_w.c, Ww, 1}};
             for (auto& j : jobs) {
-                ZK_HIP(hipMalloc(j.t, j.Wd * j.stride * j.esz));
+                ZK_TRY(mem.dev_alloc(j.t, j.Wd * j.stride * j.esz));
                 ZK_TRY(j.g2 ? msm_build_table_g2(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t)
                             : msm_build_table_g1(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t));
             }
             ZK_TRY(slot_sync(g.s, st));
             P.tables = true;
+        } else if (pk->table_window_bits) {
+            return set_err(ZK_ERR_HIP, "window tables of %zu bytes (c = %d) do not fit (free HBM %zu)", bytes, pk->table_window_bits, free_b);
         }
     }
     std::lock_guard<std::mutex> lk(g_pk_mu);
     *handle = g_next_pk++;
     g_pks[*handle] = P;
+    mem.keep = true;
     return ZK_OK;
 }
 
@@ -201,11 +280,28 @@ int zk_bn254_groth16_pk_free(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pks.find(handle);
     if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
-    if (it->second.owns)
-        for (void* d : {it->second.d_a, it->second.d_b, it->second.d_k, it->second.d_z, it->second.d_b2}) (void)hipFree(d);
-    if (it->second.tables)
-        for (void* d : {it->second.t_a, it->second.t_b, it->second.t_k, it->second.t_z, it->second.t_b2}) (void)hipFree(d);
+    if (it->second.sessions > 0)
+        return set_err(ZK_ERR_HANDLE, "proving key %llu is still used by %d msm5 session(s): end or abort them first", (unsigned long long)handle, it->second.sessions);
+    const Groth16PK& P = it->second;
+    if (P.owns) {
+        for (void* d : {P.d_a, P.d_b, P.d_k, P.d_z, P.d_b2}) (void)hipFree(d);
+    } else if (P.owns_abb) {
+        for (void* d : {P.d_a, P.d_b, P.d_b2}) (void)hipFree(d);
+    }
+    if (P.tables)
+        for (void* d : {P.t_a, P.t_b, P.t_k, P.t_z, P.t_b2}) (void)hipFree(d);
     g_pks.erase(it);
+    return ZK_OK;
+}
+
+int zk_bn254_groth16_pk_info(uint64_t handle, size_t* n_wires, size_t* n_public, uint32_t* log_domain, int* has_tables) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
+    if (n_wires) *n_wires = it->second.n_wires;
+    if (n_public) *n_public = it->second.n_public;
+    if (log_domain) *log_domain = it->second.log_domain;
+    if (has_tables) *has_tables = it->second.tables ? 1 : 0;
     return ZK_OK;
 }
 
@@ -522,6 +618,7 @@ int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2
 // the host is still driving computeH and its exchanges.
 struct Msm5Session {
     SlotsGuard<5> g;
+    uint64_t pk_handle = 0;
     Groth16PK P;
     Msm5Inputs in;
     Msm5State S;
@@ -529,6 +626,19 @@ struct Msm5Session {
 static std::mutex g_sess_mu;
 static std::map<uint64_t, Msm5Session*> g_sessions;
 static uint64_t g_next_session = 1;
+// a live session keeps copies of the key's device pointers: the key counts its sessions and pk_free refuses while any is open
+static void pk_session_ref(uint64_t h, int delta) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(h);
+    if (it != g_pks.end()) it->second.sessions += delta;
+}
+static void session_drain(Msm5Session* ss) {
+    for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(ss->g.s[i]->stream); (void)hipStreamSynchronize(ss->g.s[i]->stream_hi); }
+    msm_prep_release(&ss->S.prep_w);
+    msm_prep_release(&ss->S.prep_h);
+    for (int i = 0; i < 5; i++)
+        if (ss->S.jobs[i].acc_done) { (void)hipEventDestroy(ss->S.jobs[i].acc_done); ss->S.jobs[i].acc_done = nullptr; }
+}
 
 int zk_bn254_groth16_msm5_pk_begin(uint64_t pk_handle, const void* d_w, uint64_t* session) {
     if (!session) return set_err(ZK_ERR_ARG, "null pointer");
@@ -544,11 +654,31 @@ int zk_bn254_groth16_msm5_pk_begin(uint64_t pk_handle, const void* d_w, uint64_t
         ss->in.t_a = P.t_a; ss->in.t_b = P.t_b; ss->in.t_b2 = P.t_b2; ss->in.t_k = P.t_k; ss->in.t_z = P.t_z;
     }
     ZK_TRY(msm5_reserve(ss->g.s, ss->in, 0));
-    ZK_TRY(msm5_prepare_w(ss->g.s, ss->in, nullptr, &ss->S));
+    int rc = msm5_prepare_w(ss->g.s, ss->in, nullptr, &ss->S);
+    if (rc != ZK_OK) {
+        session_drain(ss.get());
+        return rc;
+    }
+    ss->pk_handle = pk_handle;
+    pk_session_ref(pk_handle, +1);
     std::lock_guard<std::mutex> lk(g_sess_mu);
     *session = g_next_session++;
     g_sessions[*session] = ss.release();
     return ZK_OK;
+}
+
+int zk_bn254_groth16_msm5_pk_abort(uint64_t session) {
+    std::unique_ptr<Msm5Session> ss;
+    {
+        std::lock_guard<std::mutex> lk(g_sess_mu);
+        auto it = g_sessions.find(session);
+        if (it == g_sessions.end()) return set_err(ZK_ERR_HANDLE, "unknown msm5 session %llu", (unsigned long long)session);
+        ss.reset(it->second);
+        g_sessions.erase(it);
+    }
+    session_drain(ss.get());
+    pk_session_ref(ss->pk_handle, -1);
+    return ZK_OK;  // ~Msm5Session releases the five slots
 }
 
 int zk_bn254_groth16_msm5_session_stream(uint64_t session, void** stream_out) {
@@ -583,12 +713,9 @@ int zk_bn254_groth16_msm5_pk_end(uint64_t session, const void* d_h, uint64_t out
     if (rc == ZK_OK) rc = msm5_accumulate_w(sl, ss->in, nullptr, &ss->S, ev);
     if (rc == ZK_OK) rc = msm5_launch_h(sl, sl[0]->stream_hi, ss->in, &ss->S);
     if (rc == ZK_OK) rc = msm5_finish(&ss->S, out_xyzz);
-    else {
-        for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(sl[i]->stream); (void)hipStreamSynchronize(sl[i]->stream_hi); }
-        msm_prep_release(&ss->S.prep_w);
-        msm_prep_release(&ss->S.prep_h);
-    }
+    else session_drain(ss.get());
     if (ev) (void)hipEventDestroy(ev);
+    pk_session_ref(ss->pk_handle, -1);
     return rc;
 }
 
@@ -606,12 +733,14 @@ int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size
     return ZK_OK;
 }
 
-int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, const void* c, size_t n_constraints, const void* w, const zk_fr* r_,
-                           const zk_fr* s_, int on_device, uint8_t proof_out[128]) {
-    if (!a || !b || !c || !w || !r_ || !s_ || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
+int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, const void* c, size_t n_constraints, const void* w, size_t n_wires,
+                           const zk_fr* r_, const zk_fr* s_, int on_device, uint8_t proof_out[128]) {
+    if (!r_ || !s_ || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
     Groth16PK P;
     ZK_TRY(lookup_pk(pk_handle, &P));
     const size_t N = (size_t)1 << P.log_domain, nw = P.n_wires, nk = P.n_wires - P.n_public;
+    if (n_wires != nw) return set_err(ZK_ERR_LEN, "len(w) = %zu != %zu wires of the proving key", n_wires, nw);
+    if ((n_constraints && (!a || !b || !c)) || (nw && !w)) return set_err(ZK_ERR_ARG, "null pointer");
     if (n_constraints > N) return set_err(ZK_ERR_ARG, "n_constraints = %zu exceeds the domain size %zu", n_constraints, N);
     SlotsGuard<5> g;
     ZK_TRY(acquire_slots(5, g.s));

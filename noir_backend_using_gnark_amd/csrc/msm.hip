@@ -942,6 +942,35 @@ int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, siz
     return build_table<Fp2>(s, st, d_pts, n, stride, offset, c, d_table);
 }
 
+// gnark keeps pk.G1.A / pk.G1.B / pk.G2.B WITHOUT their points at infinity (InfinityA / InfinityB bitmaps, setup.go); the resident key
+// is wire-indexed, so the compact array is scattered once at load time: out[i] = src_idx[i] == ~0 ? infinity (0,0) : compact[src_idx[i]].
+template <class F>
+__global__ __launch_bounds__(256) void k_expand_bases(const Affine<F>* __restrict__ compact, const uint32_t* __restrict__ src_idx, uint32_t n,
+                                                      Affine<F>* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t j = src_idx[i];
+    Affine<F> p;
+    uint4* d = reinterpret_cast<uint4*>(&p);
+    if (j == 0xffffffffu) {
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(p) / 16; k++) d[k] = make_uint4(0, 0, 0, 0);
+    } else {
+        p = gload(compact + j);
+    }
+    gstore(out + i, p);
+}
+int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, const uint32_t* d_src_idx, size_t n, void* d_out) {
+    if (!n) return ZK_OK;
+    if (is_g2)
+        ZK_LAUNCH(s, st, "pk_expand_bases_g2", (k_expand_bases<Fp2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Affine<Fp2>*)d_compact, d_src_idx,
+                  (uint32_t)n, (Affine<Fp2>*)d_out);
+    else
+        ZK_LAUNCH(s, st, "pk_expand_bases_g1", (k_expand_bases<Fp>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Affine<Fp>*)d_compact, d_src_idx,
+                  (uint32_t)n, (Affine<Fp>*)d_out);
+    return ZK_OK;
+}
+
 int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
     MsmPlan P;
     ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));  // the scalar-side plan does not depend on the group
@@ -1108,17 +1137,23 @@ int zk_bn254_g2_sum_xyzz(const uint64_t* partials, size_t n_partials, zk_g2_affi
     return ZK_OK;
 }
 
-static int bases_register(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind) {
+// table_c: 0 = planner's choice (tables for >= 4096 bases when they fit), -1 = no tables, else an explicit window width (any n)
+static int bases_register(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c) {
     if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
+    if (table_c != 0 && table_c != -1 && (table_c < 8 || table_c > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_c);
     ZK_TRY(ensure_init());
     Bases b;
     b.n = n;
     b.is_g2 = is_g2 ? 1 : 0;
     size_t bytes = n * (is_g2 ? 128 : 64);
     ZK_HIP(hipMalloc(&b.d, bytes ? bytes : 16));
+    struct Cleanup {  // an early return must not leak the bases / the table
+        Bases* b;
+        ~Cleanup() { if (b) { (void)hipFree(b->d); if (b->d_table) (void)hipFree(b->d_table); } }
+    } cleanup{&b};
     if (bytes) ZK_HIP(hipMemcpy(b.d, points, bytes, kind));
-    if (n >= 4096 && !(getenv("ZKMI_BASES_TABLES") && atoi(getenv("ZKMI_BASES_TABLES")) == 0)) {
-        b.tab.c = msm_pick_window_table(n);
+    if (n && table_c != -1 && (table_c > 0 || n >= 4096)) {
+        b.tab.c = table_c > 0 ? (unsigned)table_c : msm_pick_window_table(n);
         b.tab.stride = n;
         const size_t Wd = (255 + b.tab.c - 1) / b.tab.c, tbytes = Wd * n * (is_g2 ? 128 : 64);
         size_t free_b = 0, total_b = 0;
@@ -1130,16 +1165,22 @@ static int bases_register(const void* points, size_t n, int is_g2, uint64_t* han
             ZK_TRY(is_g2 ? msm_build_table_g2(g.s, g.s->stream, b.d, n, n, 0, b.tab.c, b.d_table)
                          : msm_build_table_g1(g.s, g.s->stream, b.d, n, n, 0, b.tab.c, b.d_table));
             ZK_TRY(slot_sync(g.s, g.s->stream));
+        } else if (table_c > 0) {
+            return set_err(ZK_ERR_HIP, "window tables of %zu bytes do not fit (free HBM %zu)", tbytes, free_b);
         }
     }
     std::lock_guard<std::mutex> lk(g_bases_mu);
     *handle = g_next_handle++;
     g_bases[*handle] = b;
+    cleanup.b = nullptr;
     return ZK_OK;
 }
-int zk_bn254_bases_register(const void* points, size_t n, int is_g2, uint64_t* handle) { return bases_register(points, n, is_g2, handle, hipMemcpyHostToDevice); }
+int zk_bn254_bases_register(const void* points, size_t n, int is_g2, uint64_t* handle) { return bases_register(points, n, is_g2, handle, hipMemcpyHostToDevice, 0); }
 int zk_bn254_bases_register_dev(const void* d_points, size_t n, int is_g2, uint64_t* handle) {
-    return bases_register(d_points, n, is_g2, handle, hipMemcpyDeviceToDevice);
+    return bases_register(d_points, n, is_g2, handle, hipMemcpyDeviceToDevice, 0);
+}
+int zk_bn254_bases_register_cfg(const void* points, size_t n, int is_g2, int on_device, int table_window_bits, uint64_t* handle) {
+    return bases_register(points, n, is_g2, handle, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, table_window_bits);
 }
 int zk_bn254_bases_free(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_bases_mu);

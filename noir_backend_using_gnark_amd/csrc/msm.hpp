@@ -22,6 +22,9 @@ unsigned msm_pick_window_table(size_t n);
 int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table);
 int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table);
 
+// out[i] = src_idx[i] == ~0u ? (0,0) : compact[src_idx[i]]  (gnark's InfinityA / InfinityB compaction undone at key load)
+int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, const uint32_t* d_src_idx, size_t n, void* d_out);
+
 struct MsmPlan {
     unsigned c, W, Wd, key_bits;   // W bucket sets (windows that are reduced separately); Wd digit windows (== W unless table mode)
     uint32_t table_stride;

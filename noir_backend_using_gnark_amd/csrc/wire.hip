@@ -19,10 +19,13 @@ enum : int { WIRE_OK = 0, WIRE_BAD_HEX = 1, WIRE_NOT_CANONICAL = 2 };
 // 4 hex characters (one little-endian word of the text) -> 2 bytes in text order (low byte = first pair); *bad |= invalid character
 __device__ __forceinline__ uint32_t hex4(uint32_t w, uint32_t* bad) {
     uint32_t nib = (w & 0x0f0f0f0fu) + ((w >> 6) & 0x01010101u) * 9u;  // '0'-'9' -> 0-9, 'a'-'f' / 'A'-'F' -> 10-15
-    // validation by re-encoding: the lower-case character of the nibble must equal the input character with bit 5 set
+    // validation by re-encoding: the lower-case character of the nibble must equal the input character -- folded to lower case
+    // (bit 5 set) ONLY where it is a letter (bit 6 set); digits are compared as they are, so that the control bytes 0x10-0x19
+    // (which `| 0x20` would map onto '0'-'9') are rejected like hex.DecodeString rejects them.  Accepted set, checked over all
+    // 256 byte values: '0'-'9', 'A'-'F', 'a'-'f'.
     uint32_t gt9 = ((nib + 0x06060606u) >> 4) & 0x01010101u;
     uint32_t enc = nib + 0x30303030u + gt9 * 0x27u;
-    *bad |= (enc ^ (w | 0x20202020u)) | (nib & 0xf0f0f0f0u);  // 'g'..'o' would give nibbles 16..24 that re-encode to themselves
+    *bad |= (enc ^ (w | ((w >> 1) & 0x20202020u))) | (nib & 0xf0f0f0f0u);  // 'g'..'o' would give nibbles 16..24 that re-encode to themselves
     uint32_t b = ((nib << 4) | (nib >> 8)) & 0x00ff00ffu;  // bytes 0 and 2 hold (n0 n1), (n2 n3)
     return (b & 0xffu) | ((b >> 8) & 0xff00u);
 }

@@ -18,13 +18,30 @@ class ProvingKey:
     Arrays are gnark memory images (numpy uint64) or, with bases_on_device=True, raw device pointers for the five
     base arrays (used by the benchmark, whose bases are generated on the device).
 
+    gnark's own layout: pass infinity_a / infinity_b (the []bool InfinityA / InfinityB, one entry per wire); g1_a then holds the
+    n_wires - NbInfinityA points gnark stores, g1_b / g2_b the n_wires - NbInfinityB ones (setup.go).  Without the bitmaps the
+    arrays are wire-indexed with (0,0) for a point at infinity.
+
     A rank of a range-sharded proof loads ITS slice as a key of its own (n_wires / n_public / log_domain describe the
     slice; shard_full_z=True on every rank but the last, whose Z slice ends with the unused N-th entry)."""
 
     def __init__(self, log_domain: int, n_wires: int, n_public: int, g1_alpha, g1_beta, g1_delta, g1_a, g1_b, g1_k, g1_z,
-                 g2_beta, g2_delta, g2_b, bases_on_device: bool = False, precompute_tables: bool = True, shard_full_z: bool = False):
+                 g2_beta, g2_delta, g2_b, bases_on_device: bool = False, precompute_tables: bool = True, shard_full_z: bool = False,
+                 infinity_a=None, infinity_b=None, table_window_bits: int = 0):
         self.log_domain, self.n_wires, self.n_public = log_domain, n_wires, n_public
         self._keep = []
+        inf_a = inf_b = 0
+        nb_a = nb_b = 0
+        if (infinity_a is None) != (infinity_b is None):
+            raise ValueError("InfinityA and InfinityB come together")
+        if infinity_a is not None:
+            ia = np.ascontiguousarray(np.asarray(infinity_a).astype(np.uint8))
+            ib = np.ascontiguousarray(np.asarray(infinity_b).astype(np.uint8))
+            if ia.size != n_wires or ib.size != n_wires:
+                raise ValueError("InfinityA / InfinityB need one entry per wire")
+            self._keep += [ia, ib]
+            inf_a, inf_b = ia.ctypes.data, ib.ctypes.data
+            nb_a, nb_b = int(np.count_nonzero(ia)), int(np.count_nonzero(ib))
 
         def host(a):
             a = np.ascontiguousarray(a, dtype=np.uint64)
@@ -38,15 +55,20 @@ class ProvingKey:
 
         pk = Groth16PK(log_domain, n_wires, n_public, host(g1_alpha), host(g1_beta), host(g1_delta), base(g1_a), base(g1_b),
                        base(g1_k), base(g1_z), host(g2_beta), host(g2_delta), base(g2_b), 1 if bases_on_device else 0,
-                       (0 if precompute_tables else 1) | (2 if shard_full_z else 0))
+                       (0 if precompute_tables else 1) | (2 if shard_full_z else 0), inf_a, inf_b, nb_a, nb_b, table_window_bits, 0)
         if bases_on_device:
             self._keep += [g1_a, g1_b, g1_k, g1_z, g2_b]  # keep DeviceBuffers alive
         self.handle = C.c_uint64(0)
         check(lib().zk_bn254_groth16_pk_load(C.byref(pk), C.byref(self.handle)))
 
+    def info(self) -> dict:
+        nw, npub, ld, tab = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0), C.c_int(0)
+        check(lib().zk_bn254_groth16_pk_info(self.handle, C.byref(nw), C.byref(npub), C.byref(ld), C.byref(tab)))
+        return dict(n_wires=int(nw.value), n_public=int(npub.value), log_domain=int(ld.value), tables=bool(tab.value))
+
     def free(self):
         if self.handle.value:
-            lib().zk_bn254_groth16_pk_free(self.handle)
+            check(lib().zk_bn254_groth16_pk_free(self.handle))
             self.handle = C.c_uint64(0)
 
 
@@ -58,20 +80,25 @@ def _ptr(x):
     return vp(np.ascontiguousarray(x, dtype=np.uint64))
 
 
-def prove(pk: ProvingKey, a, b, c, w, r, s, n_constraints: int | None = None, on_device: bool = False) -> bytes:
-    """groth16.Prove from the solver output: returns Proof.WriteTo bytes (Ar | Bs | Krs compressed, 128 B)."""
+def prove(pk: ProvingKey, a, b, c, w, r, s, n_constraints: int | None = None, on_device: bool = False, n_wires: int | None = None) -> bytes:
+    """groth16.Prove from the solver output: returns Proof.WriteTo bytes (Ar | Bs | Krs compressed, 128 B).
+    len(w) != the key's wire count is the library's error (ZK_ERR_LEN -> ValueError), like a mismatched MultiExp upstream."""
     if not on_device:
         a, b, c, w = (np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4) for v in (a, b, c, w))
         if not (a.shape == b.shape == c.shape):
             raise ValueError("a, b, c must have the same length")
-        if w.shape[0] != pk.n_wires:
-            raise ValueError("len(w) = %d != n_wires %d" % (w.shape[0], pk.n_wires))
         n_constraints = a.shape[0]
+        n_wires = w.shape[0]
+    elif n_wires is None:
+        n_wires = pk.n_wires  # device pointers carry no length: the caller vouches for n_wires elements
     r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
     s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
     proof = (C.c_uint8 * 128)()
-    check(lib().zk_bn254_groth16_prove(pk.handle, _ptr(a), _ptr(b), _ptr(c), C.c_size_t(n_constraints), _ptr(w), vp(r), vp(s),
-                                       C.c_int(int(on_device)), proof))
+    rc = lib().zk_bn254_groth16_prove(pk.handle, _ptr(a), _ptr(b), _ptr(c), C.c_size_t(n_constraints), _ptr(w), C.c_size_t(n_wires), vp(r), vp(s),
+                                      C.c_int(int(on_device)), proof)
+    if rc == _lib.ZK_ERR_LEN:
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
     return bytes(proof)
 
 

@@ -100,7 +100,11 @@ def groth16_finalize(pk, partials: np.ndarray, r, s) -> bytes:
     return bytes(proof)
 
 
-_A2A_OK = True
+def _a2a_transport() -> str:
+    """The transport of the NTT transposes is chosen ONCE, identically on every rank (an environment switch, read the same way by
+    all of them): RCCL all_to_all_single by default, ZKMI_A2A=0 selects all_gather + select (G x the traffic).  There is no
+    fall-back in the middle of a run -- ranks that disagreed on the collective would hang the job."""
+    return "all_gather" if os.environ.get("ZKMI_A2A", "1") == "0" else "all_to_all"
 
 
 def block_exchange(x):
@@ -114,15 +118,9 @@ def block_exchange(x):
     world, rank = d.get_world_size(), d.get_rank()
     y = torch.empty_like(x)
     if d.get_backend() == "nccl":
-        global _A2A_OK
-        if _A2A_OK:
-            try:
-                d.all_to_all_single(y, x)
-                return y
-            except RuntimeError as e:  # an RCCL build without all-to-all: keep the proof going on all-gather (G x the traffic), say so once
-                _A2A_OK = False
-                import sys
-                print("[zkmi] all_to_all_single failed (%s); falling back to all_gather for the NTT transposes" % str(e).splitlines()[0], file=sys.stderr)
+        if _a2a_transport() == "all_to_all":
+            d.all_to_all_single(y, x)
+            return y
         full = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
         d.all_gather_into_tensor(full.view(-1), x.reshape(-1))
         chunk = x.numel() // world
@@ -184,6 +182,11 @@ def groth16_msm5_pk_end(session: int, d_h: int, stream: int = 0) -> np.ndarray:
     out = np.zeros(96, dtype=np.uint64)
     check(lib().zk_bn254_groth16_msm5_pk_end(C.c_uint64(session), C.c_void_p(d_h), vp(out), C.c_void_p(stream)))
     return out
+
+
+def groth16_msm5_pk_abort(session: int) -> None:
+    """Gives the session up (an exception between _begin and _end): drains its streams and releases the five stream slots."""
+    check(lib().zk_bn254_groth16_msm5_pk_abort(C.c_uint64(session)))
 
 
 def groth16_session_stream(session: int) -> int:

@@ -1,5 +1,5 @@
 // Test program for include/zkmi.hpp (the C++ host mirror): reads a blob written by tests/test_gpu_parity.py
-//   u64 n | n x 64 B G1 points | n x 32 B scalars | 64 B expected MSM | u64 log_n | 2^log_n x 32 B input | 2^log_n x 32 B expected FFT(DIF)
+//   u64 n | n x 64 B G1 points | n x 32 B scalars (Montgomery) | 64 B expected MSM | n x 32 B the same scalars in regular form | u64 log_n | 2^log_n x 32 B input | 2^log_n x 32 B expected FFT(DIF)
 // runs the gnark-crypto-shaped calls and checks results AND upstream's error behaviour.  Without arguments it only exercises the
 // error paths that need no device (used by the CPU suite).
 #include <cstdio>
@@ -47,12 +47,19 @@ int main(int argc, char** argv) {
     f.read((char*)pts.data(), n * 64);
     f.read((char*)sc.data(), n * 32);
     f.read((char*)&want, 64);
-    Error e = got.MultiExp(pts, sc);
+    ecc::MultiExpConfig mont;
+    mont.ScalarsMont = true;
+    Error e = got.MultiExp(pts, sc, mont);
     if (e) {
         std::printf("MultiExp: %s\n", e.msg.c_str());
         return 1;
     }
-    if (std::memcmp(&got, &want, 64)) return fail("MultiExp result");
+    if (std::memcmp(&got, &want, 64)) return fail("MultiExp result (ScalarsMont: true)");
+    // ecc.MultiExpConfig{} -- upstream's zero value -- takes the limbs in regular form (what gnark's prover passes after FromMont())
+    f.read((char*)sc.data(), n * 32);
+    std::memset(&got, 0, sizeof got);
+    if ((e = got.MultiExp(pts, sc))) return fail(e.msg.c_str());
+    if (std::memcmp(&got, &want, 64)) return fail("MultiExp result (default config, regular-form scalars)");
     f.read((char*)&log_n, 8);
     const size_t N = size_t(1) << log_n;
     fr::Vector a(N), expect(N);

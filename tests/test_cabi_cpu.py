@@ -12,6 +12,7 @@ from oracle import bn254_ref as ref
 from oracle import oracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MONT = zb.MultiExpConfig(scalars_mont=True)
 
 
 def test_header_symbols_are_exported():
@@ -32,15 +33,15 @@ def test_no_cpu_fallback_without_gpu():
     if _lib.device_count() > 0:
         pytest.skip("a GPU is present")
     with pytest.raises(_lib.ZkmiError) as ei:
-        zb.g1_multi_exp(np.zeros((2, 8), np.uint64), np.zeros((2, 4), np.uint64))
+        zb.g1_multi_exp(np.zeros((2, 8), np.uint64), np.zeros((2, 4), np.uint64), config=MONT)
     assert ei.value.code == _lib.ZK_ERR_NO_DEVICE
     with pytest.raises(_lib.ZkmiError):
         zb.Domain(8).fft(np.zeros((8, 4), np.uint64), zb.DIF)
     # argument validation happens before the device is touched and mirrors upstream's MultiExp errors
     with pytest.raises(ValueError, match=r"len\(points\) != len\(scalars\)"):
-        zb.g1_multi_exp(np.zeros((2, 8), np.uint64), np.zeros((3, 4), np.uint64))
+        zb.g1_multi_exp(np.zeros((2, 8), np.uint64), np.zeros((3, 4), np.uint64), config=MONT)
     with pytest.raises(ValueError, match="NbTasks"):
-        zb.g2_multi_exp(np.zeros((2, 16), np.uint64), np.zeros((2, 4), np.uint64), zb.MultiExpConfig(nb_tasks=1025))
+        zb.g2_multi_exp(np.zeros((2, 16), np.uint64), np.zeros((2, 4), np.uint64), zb.MultiExpConfig(scalars_mont=True, nb_tasks=1025))
 
 
 def test_host_partial_sum_combine_matches_oracle():

@@ -15,6 +15,9 @@ from tests.helpers import (from_mont_limbs, g1_points_from_scalars, g2_points_fr
 
 pytestmark = pytest.mark.gpu
 
+# the test vectors are Montgomery fr.Element images; MultiExpConfig{} (upstream's zero value) means regular-form scalars
+MONT = zk.MultiExpConfig(scalars_mont=True)
+
 
 @pytest.fixture(scope="module", autouse=True)
 def _need_gpu():
@@ -132,38 +135,38 @@ def test_msm_golden(golden, c):
         pts1 = g1_points_from_scalars([h2i(x) for x in e["point_scalars"]])
         pts2 = g2_points_from_scalars([h2i(x) for x in e["point_scalars"]])
         sc = [h2i(x) for x in e["scalars"]]
-        cfg = zk.MultiExpConfig(window_bits=c)
+        cfg = zk.MultiExpConfig(scalars_mont=True, window_bits=c)
         assert zk.g1_multi_exp(pts1, mont_limbs(sc), cfg).tobytes().hex() == e["g1"], (e["kind"], c)
         assert zk.g2_multi_exp(pts2, mont_limbs(sc), cfg).tobytes().hex() == e["g2"], (e["kind"], c)
-        cfg2 = zk.MultiExpConfig(window_bits=c, scalars_mont=False)
+        cfg2 = zk.MultiExpConfig(window_bits=c)  # upstream default: regular-form scalars
         assert zk.g1_multi_exp(pts1, orc.ints_to_limbs(sc), cfg2).tobytes().hex() == e["g1"]
 
 
 def test_msm_errors_and_empty():
     p, s = np.zeros((3, 8), np.uint64), np.zeros((2, 4), np.uint64)
     with pytest.raises(ValueError, match=r"len\(points\) != len\(scalars\)"):
-        zk.g1_multi_exp(p, s)
+        zk.g1_multi_exp(p, s, config=MONT)
     with pytest.raises(ValueError, match="NbTasks"):
-        zk.g1_multi_exp(p, np.zeros((3, 4), np.uint64), zk.MultiExpConfig(nb_tasks=2000))
-    assert (zk.g1_multi_exp(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)) == 0).all()
-    assert (zk.g2_multi_exp(np.zeros((0, 16), np.uint64), np.zeros((0, 4), np.uint64)) == 0).all()
+        zk.g1_multi_exp(p, np.zeros((3, 4), np.uint64), zk.MultiExpConfig(scalars_mont=True, nb_tasks=2000))
+    assert (zk.g1_multi_exp(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64), config=MONT) == 0).all()
+    assert (zk.g2_multi_exp(np.zeros((0, 16), np.uint64), np.zeros((0, 4), np.uint64), config=MONT) == 0).all()
     # all-zero scalars, all-infinity points
     pts = orc.g1_gen_points(1, 10)
-    assert (zk.g1_multi_exp(pts, np.zeros((10, 4), np.uint64)) == 0).all()
-    assert (zk.g1_multi_exp(np.zeros((10, 8), np.uint64), orc.rand_fr(2, 10)) == 0).all()
+    assert (zk.g1_multi_exp(pts, np.zeros((10, 4), np.uint64), config=MONT) == 0).all()
+    assert (zk.g1_multi_exp(np.zeros((10, 8), np.uint64), orc.rand_fr(2, 10), config=MONT) == 0).all()
 
 
 @pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (63, 3), (1000, 4), (4097, 5), (1 << 16, 6)])
 def test_g1_msm_vs_oracle_uniform(n, seed):
     pts, sc = orc.g1_gen_points(seed, n), orc.rand_fr(seed + 100, n)
-    assert (zk.g1_multi_exp(pts, sc) == orc.g1_msm(pts, sc)).all()
+    assert (zk.g1_multi_exp(pts, sc, config=MONT) == orc.g1_msm(pts, sc)).all()
 
 
 @pytest.mark.parametrize("n,c", [(20000, 0), (20000, 16), (3000, 5)])
 def test_g1_msm_witness_like_heavy_buckets(n, c):
     """50% of the scalars in {0,1}: one bucket holds a quarter of all points (exercises task splitting + fold)."""
     pts, sc = orc.g1_gen_points(11, n), orc.rand_fr(12, n, witness_like=True)
-    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=c)) == orc.g1_msm(pts, sc)).all()
+    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(scalars_mont=True, window_bits=c)) == orc.g1_msm(pts, sc)).all()
 
 
 def test_g1_msm_collisions_and_cancellation():
@@ -172,19 +175,19 @@ def test_g1_msm_collisions_and_cancellation():
     base = orc.g1_gen_points(21, 4)
     pts = np.tile(base, (n // 4, 1))
     sc = np.tile(orc.rand_fr(22, 1), (n, 1))
-    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=8)) == orc.g1_msm(pts, sc)).all()
+    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(scalars_mont=True, window_bits=8)) == orc.g1_msm(pts, sc)).all()
     # scalars s and r - s on the same point cancel
     s_int = ref.rand_felts(23, n // 2)
     sc2 = mont_limbs(s_int + [(ref.R - v) % ref.R for v in s_int])
     pts2 = np.concatenate([orc.g1_gen_points(24, n // 2)] * 2)
-    assert (zk.g1_multi_exp(pts2, sc2) == 0).all()
+    assert (zk.g1_multi_exp(pts2, sc2, config=MONT) == 0).all()
     assert (orc.g1_msm(pts2, sc2) == 0).all()
 
 
 @pytest.mark.parametrize("n,witness", [(1, False), (500, False), (5000, True), (1 << 14, False)])
 def test_g2_msm_vs_oracle(n, witness):
     pts, sc = orc.g2_gen_points(31, n), orc.rand_fr(32, n, witness_like=witness)
-    assert (zk.g2_multi_exp(pts, sc) == orc.g2_msm(pts, sc)).all()
+    assert (zk.g2_multi_exp(pts, sc, config=MONT) == orc.g2_msm(pts, sc)).all()
 
 
 def test_msm_resident_bases_and_device_pointers():
@@ -192,21 +195,21 @@ def test_msm_resident_bases_and_device_pointers():
     pts, sc = orc.g1_gen_points(41, n), orc.rand_fr(42, n)
     exp = orc.g1_msm(pts, sc)
     rb = zb.ResidentBases(pts)
-    assert (rb.multi_exp(sc) == exp).all()
-    assert (rb.multi_exp(sc[100:600], offset=100) == orc.g1_msm(pts[100:600], sc[100:600])).all()
+    assert (rb.multi_exp(sc, config=MONT) == exp).all()
+    assert (rb.multi_exp(sc[100:600], offset=100, config=MONT) == orc.g1_msm(pts[100:600], sc[100:600])).all()
     with pytest.raises(ValueError):
-        rb.multi_exp(sc, offset=1)
+        rb.multi_exp(sc, offset=1, config=MONT)
     rb.free()
     dp, ds = _lib.DeviceBuffer.from_numpy(pts), _lib.DeviceBuffer.from_numpy(sc)
-    assert (zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n) == exp).all()
+    assert (zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n, config=MONT) == exp).all()
     # range-sharded partials (what two ranks would compute) combine to the same point
     h = n // 2
-    parts = np.stack([zb.g1_multi_exp_dev(dp.ptr, ds.ptr, h, partial=True),
-                      zb.g1_multi_exp_dev(dp.ptr + h * 64, ds.ptr + h * 32, n - h, partial=True)])
+    parts = np.stack([zb.g1_multi_exp_dev(dp.ptr, ds.ptr, h, partial=True, config=MONT),
+                      zb.g1_multi_exp_dev(dp.ptr + h * 64, ds.ptr + h * 32, n - h, partial=True, config=MONT)])
     assert (zb.g1_sum_partials(parts) == exp).all()
     p2 = orc.g2_gen_points(43, 300)
     d2, s2 = _lib.DeviceBuffer.from_numpy(p2), _lib.DeviceBuffer.from_numpy(sc[:300])
-    parts2 = np.stack([zb.g2_multi_exp_dev(d2.ptr, s2.ptr, 100, partial=True), zb.g2_multi_exp_dev(d2.ptr + 100 * 128, s2.ptr + 100 * 32, 200, partial=True)])
+    parts2 = np.stack([zb.g2_multi_exp_dev(d2.ptr, s2.ptr, 100, partial=True, config=MONT), zb.g2_multi_exp_dev(d2.ptr + 100 * 128, s2.ptr + 100 * 32, 200, partial=True, config=MONT)])
     assert (zb.g2_sum_partials(parts2) == orc.g2_msm(p2, sc[:300])).all()
 
 
@@ -222,15 +225,15 @@ def test_g1_msm_full_size_properties():
     dk_host = np.tile(k, (n, 1))
     _lib.check(L.zk_dev_h2d(C.c_void_p(dk.ptr), dk_host.ctypes.data_as(C.c_void_p), C.c_size_t(n * 32)))
     _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(dks.ptr), C.c_void_p(ds.ptr), C.c_void_p(dk.ptr), C.c_size_t(n), None))
-    r1 = zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n)
-    r2 = zb.g1_multi_exp_dev(dp.ptr, dks.ptr, n)
+    r1 = zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n, config=MONT)
+    r2 = zb.g1_multi_exp_dev(dp.ptr, dks.ptr, n, config=MONT)
     assert orc.g1_on_curve(r1)
     assert (orc.g1_mul(r1, k[0]) == r2).all()
     pts, sc = dp.to_numpy(np.uint64, (n, 8)), ds.to_numpy(np.uint64, (n, 4))
     assert (orc.g1_msm(pts, sc) == r1).all()
     # witness-like scalars at full size
     _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0xC), C.c_int(1), C.c_int(1), None))
-    assert (zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n) == orc.g1_msm(pts, ds.to_numpy(np.uint64, (n, 4)))).all()
+    assert (zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n, config=MONT) == orc.g1_msm(pts, ds.to_numpy(np.uint64, (n, 4)))).all()
 
 
 # ------------------------------------------------------------------------------------------------ Groth16
@@ -358,7 +361,7 @@ def test_msm_equal_and_opposite_bucket_sums(c):
         for second, pt2 in ((d + 1, P), (d + 1, negP), (d, negP)):
             pts = np.concatenate([np.stack([P, pt2]), rest_p])
             sc = mont_limbs([d, second] + rest_s)
-            cfg = zk.MultiExpConfig(window_bits=c)
+            cfg = zk.MultiExpConfig(scalars_mont=True, window_bits=c)
             assert (zk.g1_multi_exp(pts, sc, cfg) == orc.g1_msm(pts, sc)).all(), (c, d, second)
     # G2: same construction
     Pg = orc.g2_gen_points(74, 1)[0]
@@ -369,7 +372,7 @@ def test_msm_equal_and_opposite_bucket_sums(c):
     for second, pt2 in ((8, Pg), (8, negPg), (7, negPg)):
         pts = np.concatenate([np.stack([Pg, pt2]), rp])
         sc = mont_limbs([7, second] + rs)
-        assert (zk.g2_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=c)) == orc.g2_msm(pts, sc)).all(), (c, second)
+        assert (zk.g2_multi_exp(pts, sc, zk.MultiExpConfig(scalars_mont=True, window_bits=c)) == orc.g2_msm(pts, sc)).all(), (c, second)
 
 
 def _h_phase_gpu(phase, a, b, c, log_d, log_g, rank):
@@ -494,6 +497,14 @@ def test_felt_vector_codec_errors():
                 "0000000z" + one):                # bad count
         with pytest.raises(Exception):
             wire.deserialize_felts(bad)
+    # bytes that are not hex digits but whose low nibble would decode: control bytes 0x10-0x19 (which `| 0x20` folds onto '0'-'9'),
+    # NUL, and bytes >= 0x80 -- hex.DecodeString rejects them all
+    for byte in (0x10, 0x11, 0x19, 0x00, 0x80, 0xb5, 0xe1, 0x1a, 0x2f, 0x3a, 0x60, 0x67):
+        for pos in (0, 17, 63):
+            felt = bytearray(one.encode())
+            felt[pos] = byte
+            with pytest.raises(Exception):
+                wire.deserialize_felts(b"00000001" + bytes(felt))
     d, n = wire.deserialize_felts("00000001" + "%064x" % (ref.R - 1))
     assert n == 1
 
@@ -541,13 +552,13 @@ def test_concurrent_callers_are_safe():
         try:
             for _ in range(6):
                 if kind == 0:
-                    assert (zk.g1_multi_exp(pts, sc) == want_msm).all()
+                    assert (zk.g1_multi_exp(pts, sc, config=MONT) == want_msm).all()
                 elif kind == 1:
                     assert (zk.Domain(1 << 12).fft(x.copy(), zk.DIF) == want_ntt).all()
                 elif kind == 2:
-                    assert (zk.g2_multi_exp(pts2, sc2) == want_g2).all()
+                    assert (zk.g2_multi_exp(pts2, sc2, config=MONT) == want_g2).all()
                 else:
-                    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(window_bits=9)) == want_msm).all()
+                    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(scalars_mont=True, window_bits=9)) == want_msm).all()
         except Exception as e:  # noqa: BLE001
             errors.append((kind, repr(e)))
 
@@ -574,6 +585,7 @@ def test_cpp_host_mirror_runs_msm_and_fft(tmp_path):
     blob = tmp_path / "blob.bin"
     with open(blob, "wb") as f:
         f.write(np.uint64(n).tobytes() + pts.tobytes() + sc.tobytes() + orc.g1_msm(pts, sc).tobytes())
+        f.write(orc.ints_to_limbs(from_mont_limbs(sc)).tobytes())  # the same scalars in regular form (upstream's default config)
         f.write(np.uint64(log_n).tobytes() + x.tobytes() + orc.fr_ntt(x, False, ref.DIF).tobytes())
     out = subprocess.run([exe, str(blob)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
@@ -587,22 +599,22 @@ def test_registered_bases_use_window_tables_g1_g2_offsets_and_skew():
     rb = zb.ResidentBases(pts)
     for seed, wl in ((102, False), (103, True)):
         sc = orc.rand_fr(seed, n, witness_like=wl)
-        assert (rb.multi_exp(sc) == orc.g1_msm(pts, sc)).all()
-        assert (rb.multi_exp(sc[:4500], offset=1500) == orc.g1_msm(pts[1500:], sc[:4500])).all()
-        assert (rb.multi_exp(sc[:10], offset=5990) == orc.g1_msm(pts[5990:], sc[:10])).all()
-        assert (rb.multi_exp(sc, zk.MultiExpConfig(window_bits=11)) == orc.g1_msm(pts, sc)).all()
+        assert (rb.multi_exp(sc, config=MONT) == orc.g1_msm(pts, sc)).all()
+        assert (rb.multi_exp(sc[:4500], offset=1500, config=MONT) == orc.g1_msm(pts[1500:], sc[:4500])).all()
+        assert (rb.multi_exp(sc[:10], offset=5990, config=MONT) == orc.g1_msm(pts[5990:], sc[:10])).all()
+        assert (rb.multi_exp(sc, zk.MultiExpConfig(scalars_mont=True, window_bits=11)) == orc.g1_msm(pts, sc)).all()
     zero = np.zeros((n, 4), np.uint64)
-    assert (rb.multi_exp(zero) == 0).all()
+    assert (rb.multi_exp(zero, config=MONT) == 0).all()
     rb.free()
     # bases and scalars already in HBM (kzg.Commit of a polynomial the NTTs left on the device)
     dp, ds = _lib.DeviceBuffer.from_numpy(pts), _lib.DeviceBuffer.from_numpy(sc)
     rbd = zb.ResidentBases(dp, n=n)
-    assert (rbd.multi_exp_dev(ds, n) == orc.g1_msm(pts, sc)).all()
-    assert (rbd.multi_exp_dev(ds.ptr + 100 * 32, 3000, offset=100) == orc.g1_msm(pts[100:3100], sc[100:3100])).all()
+    assert (rbd.multi_exp_dev(ds, n, config=MONT) == orc.g1_msm(pts, sc)).all()
+    assert (rbd.multi_exp_dev(ds.ptr + 100 * 32, 3000, offset=100, config=MONT) == orc.g1_msm(pts[100:3100], sc[100:3100])).all()
     rbd.free()
     p2 = orc.g2_gen_points(104, 4200)
     rb2 = zb.ResidentBases(p2, is_g2=True)
     s2 = orc.rand_fr(105, 4200)
-    assert (rb2.multi_exp(s2) == orc.g2_msm(p2, s2)).all()
-    assert (rb2.multi_exp(s2[:1000], offset=3000) == orc.g2_msm(p2[3000:4000], s2[:1000])).all()
+    assert (rb2.multi_exp(s2, config=MONT) == orc.g2_msm(p2, s2)).all()
+    assert (rb2.multi_exp(s2[:1000], offset=3000, config=MONT) == orc.g2_msm(p2[3000:4000], s2[:1000])).all()
     rb2.free()

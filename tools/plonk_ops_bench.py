@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 import noir_backend_using_gnark_amd as zk  # noqa: E402
+MONT = zk.MultiExpConfig(scalars_mont=True)
 from noir_backend_using_gnark_amd import _lib  # noqa: E402
 from noir_backend_using_gnark_amd import bn254 as zb  # noqa: E402
 
@@ -29,15 +30,15 @@ _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(big.ptr), C.c_size_t(4 * n), C.c_
 dom_n, dom_4n = zk.Domain(n), zk.Domain(4 * n)
 kzg = zb.ResidentBases(srs, n=n + 3)   # kzg.SRS.G1 resident in HBM with its window tables (built once, like gnark's cached SRS)
 # warm up (domain tables, workspaces)
-ref_commit = zb.g1_multi_exp_dev(srs.ptr, polys[0].ptr, n + 3)
-assert (kzg.multi_exp_dev(polys[0], n + 3) == ref_commit).all(), "table commit != plain commit"
+ref_commit = zb.g1_multi_exp_dev(srs.ptr, polys[0].ptr, n + 3, config=MONT)
+assert (kzg.multi_exp_dev(polys[0], n + 3, config=MONT) == ref_commit).all(), "table commit != plain commit"
 dom_n.fft(polys[1], zk.DIF)
 dom_4n.fft(big, zk.DIT, True)
 _lib.check(L.zk_dev_sync())
 
 t0 = time.perf_counter()
 for i in range(10):
-    kzg.multi_exp_dev(polys[i & 1], n + 3)                          # kzg.Commit
+    kzg.multi_exp_dev(polys[i & 1], n + 3, config=MONT)                          # kzg.Commit
 t_msm = time.perf_counter() - t0
 t0 = time.perf_counter()
 for i in range(4):

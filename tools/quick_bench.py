@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 import noir_backend_using_gnark_amd as zk  # noqa: E402
+MONT = zk.MultiExpConfig(scalars_mont=True)
 from noir_backend_using_gnark_amd import _lib  # noqa: E402
 from noir_backend_using_gnark_amd import bn254 as zb  # noqa: E402
 
@@ -34,7 +35,7 @@ print("g1 generate 2^%d: %.1f ms" % (log_n, 1e3 * (time.time() - t0)))
 for witness in (0, 1):
     _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0xC), C.c_int(1), C.c_int(witness), None))
     for c in ([0] if which != "sweep" else [12, 14, 15, 16, 17, 18, 20]):
-        cfg = zk.MultiExpConfig(window_bits=c)
+        cfg = zk.MultiExpConfig(scalars_mont=True, window_bits=c)
         zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n, cfg)  # warm
         _lib.profile(False)
         t0 = time.time()
@@ -81,12 +82,12 @@ if which in ("all", "g2"):
     _lib.check(L.zk_bn254_g2_generate_dev(C.c_void_p(d2.ptr), C.c_size_t(m), C.c_uint64(0xB2), None))
     print("g2 generate %d: %.1f ms" % (m, 1e3 * (time.time() - t0)))
     _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0xC), C.c_int(1), C.c_int(0), None))
-    zb.g2_multi_exp_dev(d2.ptr, ds.ptr, m)
+    zb.g2_multi_exp_dev(d2.ptr, ds.ptr, m, config=MONT)
     t0 = time.time()
-    zb.g2_multi_exp_dev(d2.ptr, ds.ptr, m)
+    zb.g2_multi_exp_dev(d2.ptr, ds.ptr, m, config=MONT)
     wall = (time.time() - t0) * 1e3
     _lib.profile(True)
     _lib.profile_reset()
-    zb.g2_multi_exp_dev(d2.ptr, ds.ptr, m)
+    zb.g2_multi_exp_dev(d2.ptr, ds.ptr, m, config=MONT)
     show("G2 MSM %d uniform (%.1f M scalar-mul/s unprofiled)" % (m, m / wall / 1e3), wall)
     _lib.profile(False)
