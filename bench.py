@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- Groth16 prove (BN254) on synthetic R1CS data, BASELINE.json config 2 at N=1 GPU:
-"Synthetic R1CS 2^20 constraints, BN254 Groth16 prove on 1xMI355X (G1 MSM + Fr NTT)".
+"""bench.py -- Groth16 prove (BN254) on synthetic R1CS data.
 
-One step = one proof from the solver output onwards (computeH = 7 NTTs, 4 G1 MSMs, 1 G2 MSM, host tail), inputs already
-resident in HBM.  --gpus N > 1 (one process per GPU, torchrun): ONE proof over N * 2^log_n constraints, range-sharded: every
-rank owns one block of a, b, c, w, h and of the proving key (with its window tables); computeH is block-sharded (the top
-log2 N butterfly stages of each transform run on all-to-all-transposed data: 10 RCCL all_to_all_single per proof), the
-five MSMs run on the rank's slice, and an all-gather of the 768-byte partial-sum record lets every rank finish the proof.
+N = 1 (default): BASELINE.json configs[1], "Synthetic R1CS 2^20 constraints, BN254 Groth16 prove on 1xMI355X (G1 MSM + Fr NTT)".
+One step = one proof from the solver output onwards (computeH = 7 NTTs, 4 G1 MSMs, 1 G2 MSM, host tail), inputs already resident
+in HBM.  The same JSON line also carries, measured in the same run:
+  * `prove_ms_host_inputs`  the proof through the entry point a cgo caller has (host slices: a, b, c, w cross PCIe inside the call),
+  * `at_2p24`               the metric's other size (2^24 constraints on this one GPU: key with 84 GB of window tables), whose proof
+                            bytes are checked against the recombination of two half-size slices run through the table-less path
+                            (another window width, Horner, other task sizes) -- `--verify-2p24-oracle` adds the CPU oracle's bytes.
+--gpus N > 1 (one process per GPU, torchrun): ONE proof over N * 2^21 constraints, range-sharded -- N = 8 is BASELINE.json
+configs[2] (2^24 constraints).  Every rank owns one block of a, b, c, w, h and of the proving key (with its window tables); computeH
+is block-sharded (the top log2 N butterfly stages of each transform run on all-to-all-transposed data: 10 RCCL all_to_all_single
+per proof), the five MSMs run on the rank's slice, and an all-gather of the 768-byte partial-sum record lets every rank finish.
 
-Prints ONE JSON line on rank 0 (contract in the task statement): metric / value / unit follow BASELINE.json; `roofline`
-describes the dominant kernel (hipEvent pairs recorded inside libzkmi on the stream the kernels run on, live over the
-timed region); `cpu_baseline` is the CPU oracle (a restatement of gnark's algorithm, NOT the gnark binary: no Go toolchain
-here) timed on this box's host cores on the SAME proof -- whose bytes are compared with the GPU's (parity at full size).
+Prints ONE JSON line on rank 0 (contract in the task statement): metric / value / unit follow BASELINE.json; `roofline` describes the
+dominant kernel (hipEvent pairs recorded inside libzkmi on the stream the kernels run on, live over the timed region);
+`cpu_baseline` is the CPU oracle (a restatement of gnark's algorithm, NOT the gnark binary: no Go toolchain here) timed on this
+box's host cores on the SAME 2^20 proof -- whose bytes are compared with the GPU's (parity at full size).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -28,6 +34,7 @@ import numpy as np  # noqa: E402
 GOLDEN = 0x9E3779B97F4A7C15
 MASK = (1 << 64) - 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_PUBLIC = 8
 
 
 def seed_at(seed: int, per: int, offset: int) -> int:
@@ -36,22 +43,114 @@ def seed_at(seed: int, per: int, offset: int) -> int:
     return (seed + per * offset * GOLDEN) & MASK
 
 
+class Instance:
+    """One synthetic proving instance: valid curve points P_i = k_i * G as the key, a, b uniform, c = a*b on the
+    evaluation domain (h is a true quotient), w uniform or witness-like.  With world > 1 this is the rank's slice starting at `lo`."""
+
+    def __init__(self, L, lib, zk, log_n, lo, n_public, witness, tables, shard_full_z=False, full_inputs=True, torch=None):
+        self.L, self.lib, self.log_n, self.n_public = L, lib, log_n, n_public
+        N = self.N = 1 << log_n
+        dev = lib.DeviceBuffer
+
+        def gen(fn, n, esz, seed, off):
+            b = dev(n * esz)
+            lib.check(fn(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 4, off)), None))
+            return b
+
+        def gen_fr(seed, n, off, wit=0):
+            b = dev(n * 32)
+            lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 5 if wit else 4, off)), C.c_int(1), C.c_int(wit), None))
+            return b
+
+        self.g1_a, self.g1_b, self.g1_k, self.g1_z = (gen(L.zk_bn254_g1_generate_dev, N, 64, s, lo) for s in (0xA1, 0xB1, 0xC1, 0xD1))
+        self.g2_b = gen(L.zk_bn254_g2_generate_dev, N, 128, 0xB2, lo)
+        self.small = {k: gen(L.zk_bn254_g1_generate_dev, 1, 64, s, 0).to_numpy(np.uint64, (8,)) for k, s in (("alpha", 1), ("beta", 2), ("delta", 3))}
+        self.small2 = {k: gen(L.zk_bn254_g2_generate_dev, 1, 128, s, 0).to_numpy(np.uint64, (16,)) for k, s in (("beta", 8), ("delta", 9))}
+        self.d_w = gen_fr(0xC, N, lo, witness)
+        rs = gen_fr(0x23, 2, 0).to_numpy(np.uint64, (2, 4))  # pinned prover randomness (r, s)
+        self.r, self.s = rs[0].copy(), rs[1].copy()
+        self.d_a = self.d_b = self.d_c = None
+        self.t_abc = None
+        if full_inputs:
+            self.d_a, self.d_b = gen_fr(0xA, N, lo), gen_fr(0xB, N, lo)
+            self.d_c = dev(N * 32)
+            lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(self.d_c.ptr), C.c_void_p(self.d_a.ptr), C.c_void_p(self.d_b.ptr), C.c_size_t(N), None))
+        else:
+            # this rank's blocks of a, b, c live in torch tensors (RCCL moves them)
+            self.t_abc = [torch.empty((N, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+            for t, sd in zip(self.t_abc[:2], (0xA, 0xB)):
+                lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(t.data_ptr()), C.c_size_t(N), C.c_uint64(seed_at(sd, 4, lo)), C.c_int(1), C.c_int(0), None))
+            lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(self.t_abc[2].data_ptr()), C.c_void_p(self.t_abc[0].data_ptr()), C.c_void_p(self.t_abc[1].data_ptr()),
+                                            C.c_size_t(N), None))
+        self.pk = zk.ProvingKey(log_n, N, n_public, self.small["alpha"], self.small["beta"], self.small["delta"], self.g1_a, self.g1_b,
+                                self.g1_k.ptr + n_public * 64, self.g1_z, self.small2["beta"], self.small2["delta"], self.g2_b,
+                                bases_on_device=True, precompute_tables=tables, shard_full_z=shard_full_z)
+        lib.check(L.zk_dev_sync())
+
+    def g1_units(self):
+        # G1 scalar-muls per proof: A (n), B1 (n), K (n - n_public), Z (N - 1); G2: B2 (n)
+        return self.N + self.N + (self.N - self.n_public) + (self.N - 1)
+
+    def free(self):
+        self.pk.free()
+        for b in (self.g1_a, self.g1_b, self.g1_k, self.g1_z, self.g2_b, self.d_w, self.d_a, self.d_b, self.d_c):
+            if b is not None:
+                b.free()
+
+
+def two_slice_recombination(inst, par, lib, L):
+    """The proof of `inst` recomputed WITHOUT the key's window tables and without the single-call schedule: computeH, then the five
+    MSMs of each half of the wires / coefficients through zk_bn254_groth16_msm5_dev (planner's plain window width for 2^(log_n-1)
+    points, per-window bucket sets, host Horner), then zk_bn254_groth16_finalize on the two partial records."""
+    N, npub = inst.N, inst.n_public
+    d_h = lib.DeviceBuffer(N * 32)
+    lib.check(L.zk_bn254_groth16_compute_h_dev(C.c_void_p(inst.d_a.ptr), C.c_void_p(inst.d_b.ptr), C.c_void_p(inst.d_c.ptr), C.c_size_t(N),
+                                               C.c_uint32(inst.log_n), C.c_void_p(d_h.ptr), None))
+    recs = []
+    for rank in (0, 1):
+        lo, hi = rank * N // 2, (rank + 1) * N // 2
+        skip = npub if rank == 0 else 0
+        nz = (hi - lo) - (1 if rank == 1 else 0)
+        recs.append(par.groth16_msm5_local(inst.g1_a.ptr + lo * 64, inst.g1_b.ptr + lo * 64, inst.g2_b.ptr + lo * 128, inst.d_w.ptr + lo * 32, hi - lo,
+                                           inst.g1_k.ptr + (lo + skip) * 64, inst.d_w.ptr + (lo + skip) * 32, hi - lo - skip,
+                                           inst.g1_z.ptr + lo * 64, d_h.ptr + lo * 32, nz))
+    d_h.free()
+    return par.groth16_finalize(inst.pk, np.stack(recs), inst.r, inst.s)
+
+
+def oracle_proof(inst, log_n):
+    """The CPU oracle proves the SAME instance on this box's host cores (test infrastructure: the checker and the timed CPU baseline)."""
+    from oracle import oracle as orc  # the CPU oracle is used ONLY in these legs, after the timed GPU region
+    N, npub = inst.N, inst.n_public
+    cores = orc.max_threads()
+    pkd = dict(log_domain=log_n, n_wires=N, n_public=npub, g1_alpha=inst.small["alpha"], g1_beta=inst.small["beta"], g1_delta=inst.small["delta"],
+               g1_a=inst.g1_a.to_numpy(np.uint64, (N, 8)), g1_b=inst.g1_b.to_numpy(np.uint64, (N, 8)),
+               g1_k=inst.g1_k.to_numpy(np.uint64, (N, 8))[npub:], g1_z=inst.g1_z.to_numpy(np.uint64, (N, 8)),
+               g2_beta=inst.small2["beta"], g2_delta=inst.small2["delta"], g2_b=inst.g2_b.to_numpy(np.uint64, (N, 16)))
+    ha, hb, hc, hw = (d.to_numpy(np.uint64, (N, 4)) for d in (inst.d_a, inst.d_b, inst.d_c, inst.d_w))
+    t0 = time.perf_counter()
+    cpu_proof, _ = orc.groth16_prove(pkd, ha, hb, hc, hw, inst.r, inst.s, nthreads=cores)
+    return cpu_proof, time.perf_counter() - t0, cores
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=20, help="log2(constraints) per GPU")
+    ap.add_argument("--steps", type=int, default=200, help="timed proofs (default 200: ~2 s of GPU work at 2^20, enough for a utilisation sampler to see)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log-n", type=int, default=None, help="log2(constraints) per GPU (default: 20 on one GPU = configs[1]; 21 per GPU on several, so that 8 GPUs prove configs[2]'s 2^24)")
     ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tables", action="store_true", help="disable the precomputed window tables of the resident proving key")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU decomposition (sharded computeH phases + msm5_pk + all-gather + finalize) even at N=1")
+    ap.add_argument("--no-2p24", action="store_true", help="skip the second measured block (2^24 constraints on this GPU)")
+    ap.add_argument("--no-host-inputs", action="store_true", help="skip the host-input (PCIe-inclusive) measurement")
+    ap.add_argument("--verify-2p24-oracle", action="store_true", help="also check the 2^24 proof bytes against the CPU oracle (~2 min on 128 cores)")
     args = ap.parse_args()
 
     import torch
     import noir_backend_using_gnark_amd as zk
     from noir_backend_using_gnark_amd import _lib, parallel as par
-    from noir_backend_using_gnark_amd import bn254 as zb
 
     rank, world, local = par.init_distributed()
     if world != args.gpus:
@@ -62,70 +161,28 @@ def main():
     torch.cuda.set_device(local)
     _lib.require_device()
 
-    log_n = args.log_n
+    log_n = args.log_n if args.log_n is not None else (20 if world == 1 else 21)
     log_ng = log_n + (world.bit_length() - 1)
     if (1 << (log_ng - log_n)) != world:
         raise SystemExit("--gpus must be a power of two")
     N_loc, N_g = 1 << log_n, 1 << log_ng
-    n_public = 8
     witness = 1 if args.scalars == "witness" else 0
     lo, hi = par.shard_range(N_g, rank, world)  # this rank's slice of every wire-indexed / coefficient-indexed array
     assert hi - lo == N_loc
-
-    def dev(nbytes):
-        return _lib.DeviceBuffer(nbytes)
-
-    def gen_g1(seed, n, off):
-        b = dev(n * 64)
-        _lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 4, off)), None))
-        return b
-
-    def gen_g2(seed, n, off):
-        b = dev(n * 128)
-        _lib.check(L.zk_bn254_g2_generate_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 4, off)), None))
-        return b
-
-    def gen_fr(seed, n, off, wit=0):
-        b = dev(n * 32)
-        _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed_at(seed, 5 if wit else 4, off)), C.c_int(1), C.c_int(wit), None))
-        return b
-
-    # ---- synthetic proving key: valid curve points P_i = k_i * G, slices [lo, hi) of the global arrays
-    t_setup = time.time()
-    g1_a, g1_b, g1_k, g1_z = (gen_g1(s, N_loc, lo) for s in (0xA1, 0xB1, 0xC1, 0xD1))
-    g2_b = gen_g2(0xB2, N_loc, lo)
-    small = {k: gen_g1(s, 1, 0).to_numpy(np.uint64, (8,)) for k, s in (("alpha", 1), ("beta", 2), ("delta", 3))}
-    small2 = {k: gen_g2(s, 1, 0).to_numpy(np.uint64, (16,)) for k, s in (("beta", 8), ("delta", 9))}
-    # solver output: a, b uniform; c = a*b on the evaluation domain (h is a true quotient); w uniform or witness-like.
     sharded = world > 1 or args.force_sharded
-    np_loc = n_public if rank == 0 else 0  # public wires live in rank 0's slice; gnark's pk.G1.K starts at the first private wire
-    d_w = gen_fr(0xC, N_loc, lo, witness)
-    rs = gen_fr(0x23, 2, 0).to_numpy(np.uint64, (2, 4))  # pinned prover randomness (r, s)
-    r, s = rs[0].copy(), rs[1].copy()
-    if not sharded:
-        d_a, d_b = gen_fr(0xA, N_g, 0), gen_fr(0xB, N_g, 0)
-        d_c = dev(N_g * 32)
-        _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(d_c.ptr), C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_size_t(N_g), None))
-        pk = zk.ProvingKey(log_ng, N_g, n_public, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + n_public * 64, g1_z,
-                           small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables)
-    else:
-        # this rank's blocks of a, b, c live in torch tensors (RCCL moves them); the key is the rank's slice, loaded as a key of its own
-        t_abc = [torch.empty((N_loc, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
-        for t, sd in zip(t_abc[:2], (0xA, 0xB)):
-            _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(t.data_ptr()), C.c_size_t(N_loc), C.c_uint64(seed_at(sd, 4, lo)), C.c_int(1), C.c_int(0), None))
-        _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(t_abc[2].data_ptr()), C.c_void_p(t_abc[0].data_ptr()), C.c_void_p(t_abc[1].data_ptr()),
-                                         C.c_size_t(N_loc), None))
-        pk = zk.ProvingKey(log_n, N_loc, np_loc, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + np_loc * 64, g1_z,
-                           small2["beta"], small2["delta"], g2_b, bases_on_device=True, precompute_tables=not args.no_tables,
-                           shard_full_z=(rank != world - 1))
+    np_loc = N_PUBLIC if rank == 0 else 0  # public wires live in rank 0's slice; gnark's pk.G1.K starts at the first private wire
+
+    t_setup = time.time()
+    inst = Instance(L, _lib, zk, log_n, lo, np_loc if sharded else N_PUBLIC, witness, not args.no_tables,
+                    shard_full_z=(sharded and rank != world - 1), full_inputs=not sharded, torch=torch)
+    pk, d_w, r, s = inst.pk, inst.d_w, inst.r, inst.s
     fallback_stream = torch.cuda.Stream(priority=-1) if sharded else None
-    _lib.check(L.zk_dev_sync())
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     def step():
         if not sharded:
-            return zk.prove(pk, d_a, d_b, d_c, d_w, r, s, n_constraints=N_g, on_device=True)
+            return zk.prove(pk, inst.d_a, inst.d_b, inst.d_c, d_w, r, s, n_constraints=N_g, on_device=True)
         sess = par.groth16_msm5_pk_begin(pk, d_w.ptr)  # digits / sort / task plan of w run under computeH and its exchanges
         try:
             try:
@@ -134,7 +191,7 @@ def main():
                 side = fallback_stream
             with torch.cuda.stream(side):
                 # the prover consumes its working buffers: at N > 1 the first all-to-all already writes fresh ones, at N = 1 copy
-                a, b, c = (t.clone() for t in t_abc) if world == 1 else t_abc
+                a, b, c = (t.clone() for t in inst.t_abc) if world == 1 else inst.t_abc
                 h = par.compute_h_sharded(a, b, c, log_ng, rank, world)
                 live, sess = sess, None  # _end releases the session whatever it returns
                 rec = par.groth16_msm5_pk_end(live, h.data_ptr(), side.cuda_stream)
@@ -169,8 +226,7 @@ def main():
         allp = par.all_gather_limbs(np.frombuffer(proof, dtype=np.uint64))
         assert (allp == allp[0]).all(), "ranks disagree on the proof bytes"
 
-    # G1 scalar-muls per proof: A (n), B1 (n), K (n - n_public), Z (N - 1); G2: B2 (n)
-    g1_units = N_g + N_g + (N_g - n_public) + (N_g - 1)
+    g1_units = N_g + N_g + (N_g - N_PUBLIC) + (N_g - 1)
     ms_per_step = elapsed / args.steps * 1e3
     value = g1_units * args.steps / elapsed
 
@@ -188,20 +244,21 @@ def main():
     else:  # an NTT pass: 64 B per element per pass
         units_per_launch, bytes_per_unit = (N_loc if sharded else N_g), 64.0
     achieved = units_per_launch * bytes_per_unit / (per_launch_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction:
+    # tools/pmc_traffic.py) -- taken at the SAME per-GPU size and table setting, else null
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and not args.no_tables:
         try:
-            traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(name, {}).get("by_log_n", {}).get(str(log_n), {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     # the honest ceiling of this kernel is the VALU, not HBM: mixed additions per second against the measured peak of the
     # mixed-addition routine alone (tools/ubench.hip: k_madd29 17.4 G/s, G1; a G2 mixed addition costs ~2.1 G1 ones)
     valu = None
     if name.startswith("msm_accumulate"):
-        # digits per scalar as the planner chose them (window tables exist up to 128 GB of tables: 2^24 constraints per GPU)
         wb, dg = C.c_uint32(0), C.c_uint32(0)
-        _lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(N_loc), C.c_int(1 if (not args.no_tables and log_n <= 24) else 0), C.byref(wb), C.byref(dg)))
+        _lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(N_loc), C.c_int(1 if pk.info()["tables"] else 0), C.byref(wb), C.byref(dg)))
         digits = int(dg.value)
         madds = units_per_launch * digits
         peak = 17.4e9 if name.endswith("g1") else 17.4e9 / 2.1
@@ -219,39 +276,79 @@ def main():
         baseline_metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
         pass
+    if log_ng == 20 and world == 1:
+        bcfg = "BASELINE.json configs[1]: Synthetic R1CS 2^20 constraints, BN254 Groth16 prove on 1xMI355X (G1 MSM + Fr NTT)"
+    elif log_ng == 24 and world == 8:
+        bcfg = "BASELINE.json configs[2]: Synthetic R1CS 2^24 constraints, G1+G2 MSM sharded across 8xMI355X via RCCL/xGMI (2^21 per GPU)"
+    elif world > 1:
+        bcfg = "BASELINE.json configs[2] shape at %d GPUs: 2^%d constraints, 2^%d per GPU (weak scaling towards 8 x 2^21 = 2^24)" % (world, log_ng, log_n)
+    else:
+        bcfg = "configs[1] workload at 2^%d" % log_ng
     out = {
         "metric": baseline_metric,
         "value": round(value, 1), "unit": "G1 scalar-muls/s (whole prove: 4 G1 MSMs + G2 MSM + 7 NTTs per step)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "prove_ms": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_ng,
-                   "baseline_config": "BASELINE.json configs[1]: Synthetic R1CS 2^20 constraints, BN254 Groth16 prove on 1xMI355X (G1 MSM + Fr NTT)" if (log_ng == 20 and world == 1)
-                   else ("BASELINE.json configs[2] shape (range-sharded over %d GPUs), %d constraints" % (world, N_g) if world > 1 else "same workload at 2^%d" % log_ng), "constraints": N_g, "wires": N_g, "n_public": n_public,
-                   "scalars": args.scalars, "per_gpu_constraints": N_loc,
+        "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_ng, "baseline_config": bcfg, "constraints": N_g, "wires": N_g,
+                   "n_public": N_PUBLIC, "scalars": args.scalars, "per_gpu_constraints": N_loc, "window_tables": bool(pk.info()["tables"]),
                    "parallelism": "single GPU" if not sharded else
                    "one proof range-sharded x%d: block-sharded computeH (all-to-all transposes) + MSMs on rank-local key slices (all-gather of partial sums)" % world},
-        "roofline": roofline, "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16], "setup_s": round(t_setup, 2),
+        "roofline": roofline, "proof_sha": hashlib.sha256(proof).hexdigest()[:16], "setup_s": round(t_setup, 2),
     }
 
-    # ---- CPU baseline: the oracle proves the SAME instance on this box's host cores (rank 0, N=1 only)
-    if rank == 0 and not sharded and not args.no_cpu_baseline:
-        from oracle import oracle as orc  # the CPU oracle is used ONLY in this leg, as the timed baseline and the checker
-        cores = orc.max_threads()
-        pkd = dict(log_domain=log_n, n_wires=N_g, n_public=n_public, g1_alpha=small["alpha"], g1_beta=small["beta"], g1_delta=small["delta"],
-                   g1_a=g1_a.to_numpy(np.uint64, (N_g, 8)), g1_b=g1_b.to_numpy(np.uint64, (N_g, 8)),
-                   g1_k=g1_k.to_numpy(np.uint64, (N_g, 8))[n_public:], g1_z=g1_z.to_numpy(np.uint64, (N_g, 8)),
-                   g2_beta=small2["beta"], g2_delta=small2["delta"], g2_b=g2_b.to_numpy(np.uint64, (N_g, 16)))
-        ha, hb, hc, hw = (d.to_numpy(np.uint64, (N_g, 4)) for d in (d_a, d_b, d_c, d_w))
+    single = rank == 0 and not sharded
+    # ---- the same proof through the entry point a cgo caller has: host slices in, 128 bytes out (PCIe-inclusive; never `value`)
+    if single and not args.no_host_inputs:
+        ha, hb, hc, hw = (d.to_numpy(np.uint64, (N_g, 4)) for d in (inst.d_a, inst.d_b, inst.d_c, inst.d_w))
+        zk.prove(pk, ha, hb, hc, hw, r, s)
+        reps = 5
         t0 = time.perf_counter()
-        cpu_proof, _ = orc.groth16_prove(pkd, ha, hb, hc, hw, r, s, nthreads=cores)
-        cpu_s = time.perf_counter() - t0
+        for _ in range(reps):
+            hp = zk.prove(pk, ha, hb, hc, hw, r, s)
+        host_ms = (time.perf_counter() - t0) / reps * 1e3
+        out["prove_ms_host_inputs"] = {"value": round(host_ms, 3), "reps": reps, "bytes_over_pcie": int(4 * N_g * 32), "proof_matches_device_inputs": bool(hp == proof),
+                                       "note": "zk_bn254_groth16_prove(on_device=0): a, b, c, w are pageable host arrays uploaded inside the call"}
+        del ha, hb, hc, hw
+
+    # ---- CPU baseline: the oracle proves the SAME instance on this box's host cores (rank 0, N=1 only)
+    if single and not args.no_cpu_baseline:
+        cpu_proof, cpu_s, cores = oracle_proof(inst, log_n)
         out["cpu_baseline"] = {"value": round(g1_units / cpu_s, 1), "unit": out["unit"], "cores": cores, "kind": "port",
                                "sample": "1 full proof of the same instance (2^%d constraints, same seeds) by oracle/bn254_oracle.c "
                                          "(OpenMP, window-parallel Pippenger + radix-2 FFT; a restatement, not the gnark binary)" % log_n,
                                "prove_ms": round(cpu_s * 1e3, 1), "proof_bytes_match_gpu": bool(cpu_proof == proof)}
         if cpu_proof != proof:
             out["parity_error"] = "GPU proof bytes differ from the CPU oracle's"
+
+    # ---- second measured block: the metric's other size, 2^24 constraints on this GPU (BASELINE metric "at 2^20 / 2^24 constraints")
+    if single and log_n == 20 and not args.no_2p24 and not args.no_tables:
+        inst.free()
+        t1 = time.time()
+        big = Instance(L, _lib, zk, 24, 0, N_PUBLIC, witness, True)
+        setup24 = time.time() - t1
+        run24 = lambda: zk.prove(big.pk, big.d_a, big.d_b, big.d_c, big.d_w, big.r, big.s, n_constraints=big.N, on_device=True)
+        p24 = run24()
+        _lib.check(L.zk_dev_sync())
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            p24 = run24()
+        _lib.check(L.zk_dev_sync())
+        ms24 = (time.perf_counter() - t0) / reps * 1e3
+        blk = {"constraints": big.N, "prove_ms": round(ms24, 2), "value": round(big.g1_units() / (ms24 * 1e-3), 1), "unit": out["unit"], "steps": reps,
+               "warmup": 1, "setup_s": round(setup24, 2), "proof_sha": hashlib.sha256(p24).hexdigest()[:16], "window_tables": bool(big.pk.info()["tables"]),
+               "verified_by": "two-slice recombination through the table-less msm5 path + finalize (independent window width / Horner / task sizes)",
+               "proof_bytes_match_recombination": bool(two_slice_recombination(big, par, _lib, L) == p24)}
+        if not blk["proof_bytes_match_recombination"]:
+            out["parity_error"] = "2^24: single-call proof differs from the two-slice recombination"
+        if args.verify_2p24_oracle:
+            cpu_proof, cpu_s, cores = oracle_proof(big, 24)
+            blk["cpu_oracle"] = {"prove_ms": round(cpu_s * 1e3, 1), "cores": cores, "proof_bytes_match_gpu": bool(cpu_proof == p24)}
+            if cpu_proof != p24:
+                out["parity_error"] = "2^24: GPU proof bytes differ from the CPU oracle's"
+        out["at_2p24"] = blk
+        big.free()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -161,6 +161,11 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", pk->table_window_bits);
     const bool compact = pk->infinity_a != nullptr;
     if (compact && (pk->nb_infinity_a > pk->n_wires || pk->nb_infinity_b > pk->n_wires)) return set_err(ZK_ERR_ARG, "NbInfinity exceeds the wire count");
+    std::vector<uint32_t> map_a, map_b;
+    if (compact) {  // validated before anything is allocated or read
+        ZK_TRY(infinity_map(pk->infinity_a, pk->n_wires, pk->nb_infinity_a, &map_a, "A"));
+        ZK_TRY(infinity_map(pk->infinity_b, pk->n_wires, pk->nb_infinity_b, &map_b, "B"));
+    }
     ZK_TRY(ensure_init());
     Groth16PK P;
     PkAllocs mem;
@@ -204,9 +209,6 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
             }
     }
     if (compact) {
-        std::vector<uint32_t> map_a, map_b;
-        ZK_TRY(infinity_map(pk->infinity_a, nw, pk->nb_infinity_a, &map_a, "A"));
-        ZK_TRY(infinity_map(pk->infinity_b, nw, pk->nb_infinity_b, &map_b, "B"));
         SlotGuard g;
         ZK_TRY(acquire_slot(&g.s));
         hipStream_t st = g.s->stream;

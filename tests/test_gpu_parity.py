@@ -618,3 +618,246 @@ def test_registered_bases_use_window_tables_g1_g2_offsets_and_skew():
     assert (rb2.multi_exp(s2, config=MONT) == orc.g2_msm(p2, s2)).all()
     assert (rb2.multi_exp(s2[:1000], offset=3000, config=MONT) == orc.g2_msm(p2[3000:4000], s2[:1000])).all()
     rb2.free()
+
+
+# ------------------------------------------------------------------------------------------------ full-size code paths (round 2)
+# The planner picks window widths 21 / 22 (window tables at >= 2^22 points, the 2^26 MSM) and raises the task size to n >> 16 above 2^21
+# points; nothing below ran those paths in round 1.  Small n with the width FORCED reaches the same kernels and bucket geometry; the
+# full sizes are checked against the oracle where it finishes in seconds (2^22) and through size-independent properties above that.
+@pytest.mark.parametrize("c", [21, 22])
+def test_msm_plain_window_bits_21_22_vs_oracle(c):
+    n = 3000
+    pts, sc = orc.g1_gen_points(201, n), orc.rand_fr(202, n, witness_like=(c == 22))
+    assert (zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(scalars_mont=True, window_bits=c)) == orc.g1_msm(pts, sc)).all()
+    p2, s2 = orc.g2_gen_points(203, 400), orc.rand_fr(204, 400)
+    assert (zk.g2_multi_exp(p2, s2, zk.MultiExpConfig(scalars_mont=True, window_bits=c)) == orc.g2_msm(p2, s2)).all()
+    with pytest.raises(_lib.ZkmiError):
+        zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(scalars_mont=True, window_bits=23))
+
+
+@pytest.mark.parametrize("c", [8, 21, 22])
+def test_registered_bases_table_window_bits_vs_oracle(c):
+    """window tables 2^(c*w) * P_i with the widths the planner uses at 2^22 .. 2^26 points, on few points (table_window_bits knob)."""
+    n = 2500
+    pts = orc.g1_gen_points(211, n)
+    rb = zb.ResidentBases(pts, table_window_bits=c)
+    for seed, wl in ((212, False), (213, True)):
+        sc = orc.rand_fr(seed, n, witness_like=wl)
+        assert (rb.multi_exp(sc, config=MONT) == orc.g1_msm(pts, sc)).all()
+        assert (rb.multi_exp(sc[:700], config=MONT, offset=1800) == orc.g1_msm(pts[1800:], sc[:700])).all()
+    # regular-form scalars (upstream's default config) against the same tables
+    sc = orc.rand_fr(214, n)
+    assert (rb.multi_exp(orc.ints_to_limbs(from_mont_limbs(sc))) == orc.g1_msm(pts, sc)).all()
+    rb.free()
+    p2, s2 = orc.g2_gen_points(215, 300), orc.rand_fr(216, 300)
+    rb2 = zb.ResidentBases(p2, is_g2=True, table_window_bits=c)
+    assert (rb2.multi_exp(s2, config=MONT) == orc.g2_msm(p2, s2)).all()
+    rb2.free()
+    with pytest.raises(_lib.ZkmiError):
+        zb.ResidentBases(pts, table_window_bits=23)
+
+
+def _random_pk(log_n, n_wires, n_public, seed0=0):
+    N = 1 << log_n
+    return dict(log_domain=log_n, n_wires=n_wires, n_public=n_public,
+                g1_alpha=orc.g1_gen_points(seed0 + 1, 1)[0], g1_beta=orc.g1_gen_points(seed0 + 2, 1)[0], g1_delta=orc.g1_gen_points(seed0 + 3, 1)[0],
+                g1_a=orc.g1_gen_points(seed0 + 4, n_wires), g1_b=orc.g1_gen_points(seed0 + 5, n_wires), g1_k=orc.g1_gen_points(seed0 + 6, n_wires - n_public),
+                g1_z=orc.g1_gen_points(seed0 + 7, N), g2_beta=orc.g2_gen_points(seed0 + 8, 1)[0], g2_delta=orc.g2_gen_points(seed0 + 9, 1)[0],
+                g2_b=orc.g2_gen_points(seed0 + 10, n_wires))
+
+
+@pytest.mark.parametrize("c", [21, 22])
+def test_groth16_prove_with_table_window_bits_21_22(c):
+    log_n = 10
+    N = 1 << log_n
+    pkd = _random_pk(log_n, N - 2, 3)
+    a, b = orc.rand_fr(20, N), orc.rand_fr(21, N)
+    cc = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(N)])
+    w = orc.rand_fr(22, N - 2, witness_like=True)
+    r, s = orc.rand_fr(23, 1)[0], orc.rand_fr(24, 1)[0]
+    exp, _ = orc.groth16_prove(pkd, a, b, cc, w, r, s)
+    pk = zk.ProvingKey(**pkd, table_window_bits=c)
+    assert pk.info() == dict(n_wires=N - 2, n_public=3, log_domain=log_n, tables=True)
+    assert zk.prove(pk, a, b, cc, w, r, s) == exp
+    pk.free()
+
+
+def test_groth16_gnark_compact_key_layout_with_infinity_bitmaps():
+    """gnark stores pk.G1.A / pk.G1.B / pk.G2.B WITHOUT their points at infinity plus the InfinityA / InfinityB bitmaps (setup.go; the
+    reference would pass such a key through backend/groth16/r1cs.go:107-143): loading the compact arrays gives the same proof bytes as
+    the wire-indexed arrays with (0,0) placeholders -- host arrays and device-resident arrays, tables on and off."""
+    log_n = 11
+    N = 1 << log_n
+    nw, npub = N - 1, 4
+    pkd = _random_pk(log_n, nw, npub, seed0=40)
+    rng = np.random.default_rng(7)
+    inf_a = rng.random(nw) < 0.3
+    inf_b = rng.random(nw) < 0.45
+    inf_a[:3] = [True, False, True]
+    inf_b[-2:] = True
+    pkd["g1_a"][inf_a] = 0
+    pkd["g1_b"][inf_b] = 0
+    pkd["g2_b"][inf_b] = 0
+    a, b = orc.rand_fr(60, N - 7), orc.rand_fr(61, N - 7)
+    cc = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(N - 7)])
+    w = orc.rand_fr(62, nw, witness_like=True)
+    r, s = orc.rand_fr(63, 1)[0], orc.rand_fr(64, 1)[0]
+    exp, _ = orc.groth16_prove(pkd, a, b, cc, w, r, s)
+    compact = dict(pkd, g1_a=pkd["g1_a"][~inf_a], g1_b=pkd["g1_b"][~inf_b], g2_b=pkd["g2_b"][~inf_b])
+    for tables in (True, False):
+        pk = zk.ProvingKey(**compact, infinity_a=inf_a, infinity_b=inf_b, precompute_tables=tables)
+        assert zk.prove(pk, a, b, cc, w, r, s) == exp
+        pk.free()
+    # the compact arrays already in HBM
+    D = _lib.DeviceBuffer.from_numpy
+    dev = dict(compact, g1_a=D(compact["g1_a"]), g1_b=D(compact["g1_b"]), g1_k=D(compact["g1_k"]), g1_z=D(compact["g1_z"]), g2_b=D(compact["g2_b"]))
+    pk = zk.ProvingKey(**dev, infinity_a=inf_a, infinity_b=inf_b, bases_on_device=True)
+    assert zk.prove(pk, a, b, cc, w, r, s) == exp
+    pk.free()
+    # a bitmap that disagrees with NbInfinity, a wrong len(w), a short array
+    L = _lib.lib()
+    with pytest.raises(ValueError):
+        zk.ProvingKey(**compact, infinity_a=inf_a[:-1], infinity_b=inf_b)
+    pk = zk.ProvingKey(**compact, infinity_a=inf_a, infinity_b=inf_b)
+    with pytest.raises(ValueError, match=r"len\(w\)"):
+        zk.prove(pk, a, b, cc, w[:-1], r, s)
+    pk.free()
+    ia8, ib8 = np.ascontiguousarray(inf_a.astype(np.uint8)), np.ascontiguousarray(inf_b.astype(np.uint8))
+    ptr = lambda arr: arr.ctypes.data
+    raw = _lib.Groth16PK(log_n, nw, npub, ptr(pkd["g1_alpha"]), ptr(pkd["g1_beta"]), ptr(pkd["g1_delta"]), ptr(compact["g1_a"]), ptr(compact["g1_b"]),
+                         ptr(compact["g1_k"]), ptr(compact["g1_z"]), ptr(pkd["g2_beta"]), ptr(pkd["g2_delta"]), ptr(compact["g2_b"]), 0, 0,
+                         ptr(ia8), ptr(ib8), int(inf_a.sum()) + 1, int(inf_b.sum()), 0, 0)
+    h = C.c_uint64(0)
+    assert L.zk_bn254_groth16_pk_load(C.byref(raw), C.byref(h)) == _lib.ZK_ERR_ARG  # NbInfinityA does not match the bitmap
+
+
+def test_msm5_session_abort_releases_slots_and_key():
+    from noir_backend_using_gnark_amd import parallel as par
+    log_n = 9
+    N = 1 << log_n
+    pk = zk.ProvingKey(**_random_pk(log_n, N, 2))
+    d_w = _lib.DeviceBuffer.from_numpy(orc.rand_fr(1, N))
+    sess = par.groth16_msm5_pk_begin(pk, d_w.ptr)
+    assert _lib.lib().zk_bn254_groth16_pk_free(pk.handle) == _lib.ZK_ERR_HANDLE   # a live session pins the key
+    par.groth16_msm5_pk_abort(sess)
+    with pytest.raises(_lib.ZkmiError):
+        par.groth16_msm5_pk_abort(sess)
+    # all eight slots are free again: two five-slot calls in a row must not wait
+    for _ in range(2):
+        s2 = par.groth16_msm5_pk_begin(pk, d_w.ptr)
+        par.groth16_msm5_pk_abort(s2)
+    pk.free()
+
+
+def test_g1_msm_2p22_vs_oracle():
+    """n = 2^22 (4x the round-1 full-size test): plain planner choice against the multi-threaded oracle; then the same points as
+    registered bases with window tables (c = 21 at this size) and the two table widths forced."""
+    n = 1 << 22
+    L = _lib.lib()
+    dp, ds = _lib.DeviceBuffer(n * 64), _lib.DeviceBuffer(n * 32)
+    _lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(dp.ptr), C.c_size_t(n), C.c_uint64(0xE1), None))
+    _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0xE2), C.c_int(1), C.c_int(0), None))
+    pts, sc = dp.to_numpy(np.uint64, (n, 8)), ds.to_numpy(np.uint64, (n, 4))
+    want = orc.g1_msm(pts, sc)
+    assert (zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n, config=MONT) == want).all()
+    for c in (0, 22):
+        rb = zb.ResidentBases(dp, n=n, table_window_bits=c)
+        assert (rb.multi_exp_dev(ds, n, config=MONT) == want).all(), c
+        rb.free()
+
+
+def _dev_scaled(d_src, n, k_limbs):
+    """k * src elementwise on the device (src: n Montgomery scalars in HBM)."""
+    L = _lib.lib()
+    dk = _lib.DeviceBuffer.from_numpy(np.tile(k_limbs.reshape(1, 4), (n, 1)))
+    out = _lib.DeviceBuffer(n * 32)
+    _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(out.ptr), C.c_void_p(d_src.ptr if hasattr(d_src, "ptr") else d_src), C.c_void_p(dk.ptr), C.c_size_t(n), None))
+    dk.free()
+    return out
+
+
+def test_g1_msm_2p26_properties():
+    """BASELINE configs[4] size (2^26 points, window width 20+ and the n >> 16 task size): homogeneity MSM(P, k*s) == k * MSM(P, s), and the
+    window-table path over the same registered bases (c = 22: 48 GB of tables) equals the plain path -- two independent code paths."""
+    n = 1 << 26
+    L = _lib.lib()
+    dp, ds = _lib.DeviceBuffer(n * 64), _lib.DeviceBuffer(n * 32)
+    _lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(dp.ptr), C.c_size_t(n), C.c_uint64(0xF1), None))
+    _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0xF2), C.c_int(1), C.c_int(0), None))
+    k = orc.rand_fr(0xF3, 1)
+    dks = _dev_scaled(ds, n, k[0])
+    r1 = zb.g1_multi_exp_dev(dp.ptr, ds.ptr, n, config=MONT)
+    r2 = zb.g1_multi_exp_dev(dp.ptr, dks.ptr, n, config=MONT)
+    assert orc.g1_on_curve(r1) and (r1 != 0).any()
+    assert (orc.g1_mul(r1, k[0]) == r2).all()
+    # additivity over a split at an odd position: MSM(P[:m], s[:m]) + MSM(P[m:], s[m:]) == MSM(P, s)
+    m = (n // 3) | 1
+    parts = np.stack([zb.g1_multi_exp_dev(dp.ptr, ds.ptr, m, config=MONT, partial=True),
+                      zb.g1_multi_exp_dev(dp.ptr + m * 64, ds.ptr + m * 32, n - m, config=MONT, partial=True)])
+    assert (zb.g1_sum_partials(parts) == r1).all()
+    rb = zb.ResidentBases(dp, n=n)   # planner: window tables with c = 22
+    assert (rb.multi_exp_dev(ds, n, config=MONT) == r1).all()
+    assert (rb.multi_exp_dev(dks, n, config=MONT) == r2).all()
+    rb.free()
+
+
+def test_groth16_2p24_properties():
+    """BASELINE configs[2] size on one GPU (2^24 constraints; key with c = 22 window tables, 84 GB): (1) the single-call prover's bytes equal
+    the recombination of two half-size slices run through the table-less msm5 path (other window width, Horner, other task sizes) and
+    zk_bn254_groth16_finalize; (2) homogeneity of the five sums through the table path: msm5(k*w, k*h) == k * msm5(w, h)."""
+    from noir_backend_using_gnark_amd import parallel as par
+    log_n = 24
+    N = 1 << log_n
+    npub = 8
+    L = _lib.lib()
+
+    def gen(fn, n, esz, seed):
+        b = _lib.DeviceBuffer(n * esz)
+        _lib.check(fn(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed), None))
+        return b
+
+    g1_a, g1_b, g1_k, g1_z = (gen(L.zk_bn254_g1_generate_dev, N, 64, sd) for sd in (0xA1, 0xB1, 0xC1, 0xD1))
+    g2_b = gen(L.zk_bn254_g2_generate_dev, N, 128, 0xB2)
+    small = {kk: gen(L.zk_bn254_g1_generate_dev, 1, 64, sd).to_numpy(np.uint64, (8,)) for kk, sd in (("alpha", 1), ("beta", 2), ("delta", 3))}
+    small2 = {kk: gen(L.zk_bn254_g2_generate_dev, 1, 128, sd).to_numpy(np.uint64, (16,)) for kk, sd in (("beta", 8), ("delta", 9))}
+
+    def rnd(seed, n, wit=0):
+        b = _lib.DeviceBuffer(n * 32)
+        _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(b.ptr), C.c_size_t(n), C.c_uint64(seed), C.c_int(1), C.c_int(wit), None))
+        return b
+
+    d_a, d_b, d_w = rnd(0xA, N), rnd(0xB, N), rnd(0xC, N, 1)
+    d_c = _lib.DeviceBuffer(N * 32)
+    _lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(d_c.ptr), C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_size_t(N), None))
+    rs = orc.rand_fr(0x23, 2)
+    r, s = rs[0], rs[1]
+    pk = zk.ProvingKey(log_n, N, npub, small["alpha"], small["beta"], small["delta"], g1_a, g1_b, g1_k.ptr + npub * 64, g1_z,
+                       small2["beta"], small2["delta"], g2_b, bases_on_device=True)
+    assert pk.info()["tables"]
+    proof = zk.prove(pk, d_a, d_b, d_c, d_w, r, s, n_constraints=N, on_device=True)
+    # (1) two slices through the plain path
+    d_h = _lib.DeviceBuffer(N * 32)
+    _lib.check(L.zk_bn254_groth16_compute_h_dev(C.c_void_p(d_a.ptr), C.c_void_p(d_b.ptr), C.c_void_p(d_c.ptr), C.c_size_t(N), C.c_uint32(log_n),
+                                                C.c_void_p(d_h.ptr), None))
+    recs = []
+    for rank in (0, 1):
+        lo, hi = rank * N // 2, (rank + 1) * N // 2
+        skip = npub if rank == 0 else 0
+        nz = (hi - lo) - (1 if rank == 1 else 0)
+        recs.append(par.groth16_msm5_local(g1_a.ptr + lo * 64, g1_b.ptr + lo * 64, g2_b.ptr + lo * 128, d_w.ptr + lo * 32, hi - lo,
+                                           g1_k.ptr + (lo + skip) * 64, d_w.ptr + (lo + skip) * 32, hi - lo - skip,
+                                           g1_z.ptr + lo * 64, d_h.ptr + lo * 32, nz))
+    assert par.groth16_finalize(pk, np.stack(recs), r, s) == proof
+    # (2) homogeneity through the key's window tables
+    k = orc.rand_fr(0x77, 1)
+    rec1 = par.groth16_msm5_pk(pk, d_w.ptr, d_h.ptr)
+    d_kw, d_kh = _dev_scaled(d_w, N, k[0]), _dev_scaled(d_h, N, k[0])
+    rec2 = par.groth16_msm5_pk(pk, d_kw.ptr, d_kh.ptr)
+    for i in range(4):
+        p1, p2 = zb.g1_sum_partials(rec1[16 * i:16 * i + 16]), zb.g1_sum_partials(rec2[16 * i:16 * i + 16])
+        assert (p1 != 0).any() and (orc.g1_mul(p1, k[0]) == p2).all(), i
+    q1, q2 = zb.g2_sum_partials(rec1[64:96]), zb.g2_sum_partials(rec2[64:96])
+    assert (orc.g2_mul(q1, k[0]) == q2).all()
+    # and the table path's sums are the plain path's sums
+    assert (zb.g1_sum_partials(np.stack([recs[0][:16], recs[1][:16]])) == zb.g1_sum_partials(rec1[:16])).all()
+    pk.free()
