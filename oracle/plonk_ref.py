@@ -1,0 +1,501 @@
+"""CPU restatement of gnark v0.8.0's PLONK backend for BN254 -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+What is restated (all [UPSTREAM-RECALL]: gnark / gnark-crypto are un-vendored Go modules pinned at
+/root/reference/gnark_backend_ffi/go.mod:23 and :5; no Go toolchain exists here, so nothing below could be checked against
+the upstream binary -- PARITY UNPINNED, exactly like the Groth16 oracle):
+    plonk.Setup   internal/backend/bn254/plonk/setup.go    reached at /root/reference/gnark_backend_ffi/backend/plonk/plonk.go:21
+    plonk.Prove   internal/backend/bn254/plonk/prove.go    reached at backend/plonk/plonk.go:67 (the reference's ONLY live prove path:
+                                                           PlonkProveWithPK, gnark_backend_ffi/main.go:24-37)
+    plonk.Verify  internal/backend/bn254/plonk/verify.go   reached at backend/plonk/plonk.go:47
+    kzg.Commit / Open / BatchOpenSinglePoint / FoldProof / BatchVerifyMultiPoints   gnark-crypto ecc/bn254/fr/kzg/kzg.go
+    kzg.NewSRS                                                                       reached at backend/common.go:137
+    fiatshamir.Transcript (SHA-256; challenges "gamma", "beta", "alpha", "zeta")     gnark-crypto fiat-shamir/transcript.go
+    iop.BuildRatioCopyConstraint, iop.DivideByXMinusOne, (*Polynomial).Blind         gnark-crypto ecc/bn254/fr/iop
+The constraint system is the reference's own: one gate qL*xa + qR*xb + qO*xc + qM*xa*xb + qC = 0 per ACIR arithmetic opcode
+(/root/reference/gnark_backend_ffi/backend/plonk/sparse_r1cs.go:44-107).
+
+The prover's randomness (the 9 blinding scalars; upstream: fr.SetRandom) is an INPUT, which makes the proof bytes a function of
+the inputs; the Fiat-Shamir challenges are derived as upstream does unless they are pinned by the caller.
+
+What pins this file, in the absence of upstream: the verifier below is written from the verification EQUATIONS (pairing check of the
+two KZG openings + the quotient identity at zeta), so prove -> verify closing on satisfiable circuits and failing on tampered ones
+checks the prover's algebra end to end; the byte layout (Proof.WriteTo) is recall only.
+
+Python integers throughout; NTTs and MSMs may be delegated to the C oracle (oracle/bn254_oracle.c, another independent restatement)
+through `fast=True` so that 2^12-2^14-gate instances finish in seconds."""
+from __future__ import annotations
+
+import hashlib
+
+from . import bn254_ref as ref
+from .bn254_ref import DIF, DIT, FP, R, Domain, bit_reverse, g1_add, g1_mul, g1_neg, inv
+
+# ------------------------------------------------------------------------------------------------ constraint system
+
+
+class SparseR1CS:
+    """cs.SparseR1CS as the reference builds it (sparse_r1cs.go:18-107): variables = [public..., secret...] (no internal variables, no
+    ONE wire); one constraint per gate: (qL, qR, qO, qM, qC, xa, xb, xc) with qL*xa + qR*xb + qO*xc + qM*xa*xb + qC == 0."""
+
+    def __init__(self, n_public: int, n_secret: int, constraints):
+        self.n_public, self.n_secret = n_public, n_secret
+        self.constraints = [tuple(c) for c in constraints]
+
+    @property
+    def n_vars(self):
+        return self.n_public + self.n_secret
+
+    def is_satisfied(self, solution) -> bool:
+        return all((ql * solution[xa] + qr * solution[xb] + qo * solution[xc] + qm * solution[xa] * solution[xb] + qc) % R == 0
+                   for ql, qr, qo, qm, qc, xa, xb, xc in self.constraints)
+
+
+def sparse_r1cs_from_acir(acir: dict, values):
+    """The reference's lowering of an ACIR circuit (backend/plonk/sparse_r1cs.go:18-107 + backend/common.go:45-76): arithmetic opcodes
+    become gates (only MulTerms[0]; SimpleTerms of length 1 -> qO, 2 -> qL, qR, 3 -> qL, qR, qO); directives and black-box calls emit
+    nothing.  `values` = witness values 1 .. current_witness-1 in index order.  Returns (spr, solution) with the public variables first.
+    (With two or more public inputs the reference's HandleValues appends secrets once per non-matching public input, common.go:59-68 --
+    an upstream bug that is NOT reproduced: every secret appears once.)"""
+    pub = list(acir.get("public_inputs", []))
+    n_w = acir["current_witness_index"]
+    order = [i for i in range(1, n_w + 1) if i in pub] + [i for i in range(1, n_w + 1) if i not in pub]
+    order = [i for i in order if i - 1 < len(values)]
+    index = {w: k for k, w in enumerate(order)}
+    solution = [values[w - 1] % R for w in order]
+    h2i = lambda h: int(h, 16) % R
+    gates = []
+    for op in acir["opcodes"]:
+        if "Arithmetic" not in op:
+            continue
+        a = op["Arithmetic"]
+        ql = qr = qo = qm = 0
+        xa = xb = xc = 0
+        if a["mul_terms"]:
+            c, wl, wr = a["mul_terms"][0]
+            qm, xa, xb = h2i(c), index[wl], index[wr]
+        lin = a["linear_combinations"]
+        if len(lin) == 1:
+            qo, xc = h2i(lin[0][0]), index[lin[0][1]]
+        elif len(lin) >= 2:
+            ql, xa = h2i(lin[0][0]), index[lin[0][1]]
+            qr, xb = h2i(lin[1][0]), index[lin[1][1]]
+            if len(lin) == 3:
+                qo, xc = h2i(lin[2][0]), index[lin[2][1]]
+        gates.append((ql, qr, qo, qm, h2i(a["q_c"]), xa, xb, xc))
+    return SparseR1CS(len([i for i in order if i in pub]), len([i for i in order if i not in pub]), gates), solution
+
+
+# ------------------------------------------------------------------------------------------------ plumbing (python <-> C oracle)
+def _np():
+    import numpy as np
+    return np
+
+
+def ints_to_mont_np(xs, m=R):
+    np = _np()
+    return np.frombuffer(b"".join(((x % m) * ref.MONT_R % m).to_bytes(32, "little") for x in xs), dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def mont_np_to_ints(a, m=R):
+    np = _np()
+    raw = np.ascontiguousarray(a, dtype=np.uint64).tobytes()
+    rinv = inv(ref.MONT_R % m, m)
+    return [int.from_bytes(raw[i:i + 32], "little") * rinv % m for i in range(0, len(raw), 32)]
+
+
+def g1_to_np(P):
+    np = _np()
+    return np.frombuffer(ref.g1_affine_mont_bytes(P), dtype=np.uint64).copy()
+
+
+def g1_from_np(a):
+    x, y = mont_np_to_ints(_np().asarray(a, dtype=_np().uint64).reshape(2, 4), ref.Q)
+    return None if (x == 0 and y == 0) else (x, y)
+
+
+class _Backend:
+    """NTT / MSM providers: pure Python (definition-level) or the C oracle (fast=True)."""
+
+    def __init__(self, fast: bool):
+        self.fast = fast
+        if fast:
+            from . import oracle as orc
+            self.orc = orc
+
+    def ntt(self, dom: Domain, v, inverse: bool, decimation: int, coset: bool = False):
+        if not self.fast or dom.n < 64:
+            return (dom.fft_inverse if inverse else dom.fft)(v, decimation, coset)
+        return mont_np_to_ints(self.orc.fr_ntt(ints_to_mont_np(v), inverse, decimation, coset))
+
+    def msm_g1(self, srs_g1, scalars):
+        """kzg.Commit: MultiExp(srs.G1[:len(p)], p)."""
+        n = len(scalars)
+        if not self.fast or n < 64:
+            pts = srs_g1[:n] if isinstance(srs_g1, list) else [g1_from_np(srs_g1[i]) for i in range(n)]
+            return ref.msm_pippenger(FP, pts, scalars, 4) if n > 8 else ref.msm_naive(FP, pts, scalars)
+        np = _np()
+        pts = srs_g1[:n] if not isinstance(srs_g1, list) else np.stack([g1_to_np(p) for p in srs_g1[:n]])
+        return g1_from_np(self.orc.g1_msm(np.ascontiguousarray(pts), ints_to_mont_np(scalars)))
+
+
+# ------------------------------------------------------------------------------------------------ KZG
+def kzg_new_srs(size: int, alpha: int, fast: bool = False):
+    """kzg.NewSRS(size, alpha): G1[i] = alpha^i * G1, G2 = [G2, alpha * G2]  (backend/common.go:137 calls it with size 1_000_000)."""
+    if fast:
+        from . import oracle as orc
+        np = _np()
+        g = g1_to_np(ref.G1_GEN)
+        pw, out = 1, []
+        for _ in range(size):
+            out.append(orc.g1_mul(g, ints_to_mont_np([pw])[0]))
+            pw = pw * alpha % R
+        g1 = np.stack(out)
+    else:
+        g1, pw = [], 1
+        for _ in range(size):
+            g1.append(g1_mul(ref.G1_GEN, pw))
+            pw = pw * alpha % R
+    return dict(g1=g1, g2=[ref.G2_GEN, ref.g2_mul(ref.G2_GEN, alpha)])
+
+
+def poly_eval(p, x):
+    acc = 0
+    for c in reversed(p):
+        acc = (acc * x + c) % R
+    return acc
+
+
+def divide_by_x_minus_a(f, fa, a):
+    """kzg.dividePolyByXminusA: (f - f(a)) / (X - a) by synthetic division; len(result) = len(f) - 1."""
+    f = list(f)
+    f[0] = (f[0] - fa) % R
+    for i in range(len(f) - 2, -1, -1):
+        f[i] = (f[i] + f[i + 1] * a) % R
+    return f[1:]
+
+
+# ------------------------------------------------------------------------------------------------ Fiat-Shamir
+def fr_bytes(x: int) -> bytes:
+    """fr.Element.Marshal(): 32 bytes big-endian, canonical."""
+    return (x % R).to_bytes(32, "big")
+
+
+def g1_raw_bytes(P) -> bytes:
+    """G1Affine.RawBytes() / Marshal(): uncompressed X || Y big-endian (64 B); infinity = 0x40 flag + zeros."""
+    if P is None:
+        return bytes([0x40]) + bytes(63)
+    return P[0].to_bytes(32, "big") + P[1].to_bytes(32, "big")
+
+
+class Transcript:
+    """fiatshamir.NewTranscript(sha256.New(), ids...): challenge_i = H(id_i || challenge_{i-1} || bindings_i)."""
+
+    def __init__(self, *ids):
+        self.ids = list(ids)
+        self.bindings = {i: [] for i in ids}
+        self.values = {}
+
+    def bind(self, cid, b: bytes):
+        assert cid not in self.values
+        self.bindings[cid].append(bytes(b))
+
+    def compute(self, cid) -> bytes:
+        if cid in self.values:
+            return self.values[cid]
+        h = hashlib.sha256()
+        h.update(cid.encode())
+        pos = self.ids.index(cid)
+        if pos:
+            h.update(self.values[self.ids[pos - 1]])  # errPreviousChallengeNotComputed otherwise
+        for b in self.bindings[cid]:
+            h.update(b)
+        self.values[cid] = h.digest()
+        return self.values[cid]
+
+    def challenge_fr(self, cid, *points) -> int:
+        """plonk deriveRandomness: bind the points' RawBytes, compute, fr.SetBytes (big-endian, reduced mod r)."""
+        for P in points:
+            self.bind(cid, g1_raw_bytes(P))
+        return int.from_bytes(self.compute(cid), "big") % R
+
+
+def kzg_derive_gamma(point, digests, claimed_values) -> int:
+    """kzg.deriveGamma (v0.9.1): one-challenge transcript bound to the point, the digests and the claimed values."""
+    t = Transcript("gamma")
+    t.bind("gamma", fr_bytes(point))
+    for d in digests:
+        t.bind("gamma", g1_raw_bytes(d))
+    for v in claimed_values:
+        t.bind("gamma", fr_bytes(v))
+    return int.from_bytes(t.compute("gamma"), "big") % R
+
+
+# ------------------------------------------------------------------------------------------------ Setup
+def _canonical(be, dom, lagrange):
+    """Lagrange (regular) -> canonical (regular): FFTInverse(DIF) then BitReverse, as setup.go does."""
+    return bit_reverse(be.ntt(dom, lagrange, True, DIF))
+
+
+def build_permutation(spr: SparseR1CS, size: int):
+    """setup.go buildPermutation: position -> permuted position over the 3*size wire slots (L | R | O), placeholders included."""
+    npub, nc = spr.n_public, len(spr.constraints)
+    lro = [0] * (3 * size)
+    for i in range(npub):
+        lro[i] = i
+    for i, (_, _, _, _, _, xa, xb, xc) in enumerate(spr.constraints):
+        lro[npub + i] = xa
+        lro[size + npub + i] = xb
+        lro[2 * size + npub + i] = xc
+    perm = [-1] * (3 * size)
+    cycle = [-1] * max(1, spr.n_vars)
+    for i in range(3 * size):
+        if cycle[lro[i]] != -1:
+            perm[i] = cycle[lro[i]]
+        cycle[lro[i]] = i
+    for i in range(3 * size):
+        if perm[i] == -1:
+            perm[i] = cycle[lro[i]]
+    return perm
+
+
+def plonk_setup(spr: SparseR1CS, srs, fast: bool = False):
+    """plonk.Setup(spr, srs) -> (pk, vk).  pk keeps what gnark's ProvingKey keeps (canonical Ql..Qo, CQk, LQk, S1..S3, Permutation,
+    the two domains) -- the Lagrange-coset copies gnark caches are derived by whoever needs them."""
+    be = _Backend(fast)
+    npub, nc = spr.n_public, len(spr.constraints)
+    size_system = nc + npub
+    d0 = Domain(size_system)
+    d1 = Domain((8 if size_system < 6 else 4) * size_system)
+    n = d0.n
+    ql, qr, qm, qo, qk = ([0] * n for _ in range(5))
+    for i in range(npub):
+        ql[i] = R - 1  # placeholder gates  -PUB_i + qk_i = 0 ; qk_i is completed by the prover
+    for i, (cl, cr, co, cm, cc, _, _, _) in enumerate(spr.constraints):
+        ql[npub + i], qr[npub + i], qm[npub + i], qo[npub + i], qk[npub + i] = cl % R, cr % R, cm % R, co % R, cc % R
+    lqk = list(qk)
+    perm = build_permutation(spr, n)
+    u = d0.coset
+    ident = [pow(d0.gen, i, R) for i in range(n)]
+    ident = ident + [u * x % R for x in ident] + [u * u % R * x % R for x in ident]  # getIDSmallDomain
+    s_lag = [[ident[perm[j * n + i]] for i in range(n)] for j in range(3)]
+    pk = dict(spr=spr, d0=d0, d1=d1, n=n, perm=perm,
+              ql=_canonical(be, d0, ql), qr=_canonical(be, d0, qr), qm=_canonical(be, d0, qm), qo=_canonical(be, d0, qo),
+              cqk=_canonical(be, d0, qk), lqk=lqk,
+              s1=_canonical(be, d0, s_lag[0]), s2=_canonical(be, d0, s_lag[1]), s3=_canonical(be, d0, s_lag[2]), srs=srs)
+    commit = lambda p: be.msm_g1(srs["g1"], p)
+    vk = dict(size=n, size_inv=d0.card_inv, generator=d0.gen, n_public=npub, coset_shift=u, srs_g2=srs["g2"],
+              s=[commit(pk["s1"]), commit(pk["s2"]), commit(pk["s3"])],
+              ql=commit(pk["ql"]), qr=commit(pk["qr"]), qm=commit(pk["qm"]), qo=commit(pk["qo"]), qk=commit(pk["cqk"]))
+    pk["vk"] = vk
+    return pk, vk
+
+
+# ------------------------------------------------------------------------------------------------ Prove
+def evaluate_lro(spr: SparseR1CS, n: int, solution):
+    """prove.go evaluateLROSmallDomain: l, r, o in Lagrange form on the small domain (placeholders first, padding = solution[0])."""
+    s0 = solution[0] if solution else 0
+    l, r, o = [s0] * n, [s0] * n, [s0] * n
+    for i in range(spr.n_public):
+        l[i] = solution[i]
+    for i, (_, _, _, _, _, xa, xb, xc) in enumerate(spr.constraints):
+        k = spr.n_public + i
+        l[k], r[k], o[k] = solution[xa], solution[xb], solution[xc]
+    return l, r, o
+
+
+def _blind(canon, n, rnd):
+    """(*Polynomial).Blind(len(rnd) - 1): p += Q(X) * (X^n - 1) with Q's coefficients = rnd."""
+    p = list(canon) + [0] * len(rnd)
+    for i, b in enumerate(rnd):
+        p[i] = (p[i] - b) % R
+        p[n + i] = (p[n + i] + b) % R
+    return p
+
+
+def _bind_public_data(fs: Transcript, vk, public_inputs):
+    """prove.go bindPublicData: S1..S3, Ql, Qr, Qm, Qo, Qk digests (Marshal = uncompressed), then the public inputs."""
+    for d in (vk["s"][0], vk["s"][1], vk["s"][2], vk["ql"], vk["qr"], vk["qm"], vk["qo"], vk["qk"]):
+        fs.bind("gamma", g1_raw_bytes(d))
+    for w in public_inputs:
+        fs.bind("gamma", fr_bytes(w))
+
+
+def plonk_prove(pk, solution, blinders, challenges=None, fast: bool = False, trace=None):
+    """plonk.Prove(spr, pk, witness) after the solver: `solution` = values of all variables (public first).
+    blinders: 9 scalars -- (l: 2, r: 2, o: 2, z: 3), the fr.SetRandom draws of Blind(1) x3 and Blind(2) in call order.
+    challenges: None (SHA-256 Fiat-Shamir, as upstream) or dict(gamma, beta, alpha, zeta, kzg_gamma) to pin them.
+    Returns the proof dict (see plonk_proof_bytes)."""
+    be = _Backend(fast)
+    spr, d0, d1, n, vk, srs = pk["spr"], pk["d0"], pk["d1"], pk["n"], pk["vk"], pk["srs"]
+    N4, rho = d1.n, d1.n // d0.n
+    npub = spr.n_public
+    commit = lambda p: be.msm_g1(srs["g1"], p)
+    fs = Transcript("gamma", "beta", "alpha", "zeta")
+    pin = challenges or {}
+
+    # l, r, o: Lagrange -> canonical, blinded with degree-1 masks, committed
+    l_lag, r_lag, o_lag = evaluate_lro(spr, n, solution)
+    cl, cr, co = (_canonical(be, d0, v) for v in (l_lag, r_lag, o_lag))
+    bl, br, bo = _blind(cl, n, blinders[0:2]), _blind(cr, n, blinders[2:4]), _blind(co, n, blinders[4:6])
+    lro = [commit(bl), commit(br), commit(bo)]
+    _bind_public_data(fs, vk, solution[:npub])
+    gamma = fs.challenge_fr("gamma", *lro)
+    beta = fs.challenge_fr("beta")
+    gamma, beta = pin.get("gamma", gamma), pin.get("beta", beta)
+
+    # Z: the copy-constraint ratio (iop.BuildRatioCopyConstraint) on the UNblinded l, r, o; canonical, blinded with a degree-2 mask
+    u = d0.coset
+    ident = [pow(d0.gen, i, R) for i in range(n)]
+    ident = ident + [u * x % R for x in ident] + [u * u % R * x % R for x in ident]
+    perm = pk["perm"]
+    num, den = [1] * n, [1] * n
+    for i in range(n - 1):
+        a = b = 1
+        for j, w in enumerate((l_lag, r_lag, o_lag)):
+            a = a * ((w[i] + beta * ident[i + j * n] + gamma) % R) % R
+            b = b * ((w[i] + beta * ident[perm[i + j * n]] + gamma) % R) % R
+        num[i + 1], den[i + 1] = num[i] * a % R, den[i] * b % R
+    z_lag = [num[i] * inv(den[i], R) % R for i in range(n)]
+    bz = _blind(_canonical(be, d0, z_lag), n, blinders[6:9])
+    z_digest = commit(bz)
+    alpha = pin.get("alpha", fs.challenge_fr("alpha", z_digest))
+
+    # qk completed with the public inputs (Lagrange), canonical
+    qk_lag = list(solution[:npub]) + list(pk["lqk"][npub:])
+    qk_full = _canonical(be, d0, qk_lag)
+
+    # quotient on the coset of the big domain: every polynomial evaluated at g * W^i (natural index order here; gnark keeps the
+    # bit-reversed layout -- the polynomial h is the same)
+    def coset_eval(p):
+        return bit_reverse(be.ntt(d1, list(p) + [0] * (N4 - len(p)), False, DIF, True))
+
+    e_l, e_r, e_o, e_z, e_qk = (coset_eval(p) for p in (bl, br, bo, bz, qk_full))
+    e_ql, e_qr, e_qm, e_qo = (coset_eval(pk[k]) for k in ("ql", "qr", "qm", "qo"))
+    e_s1, e_s2, e_s3 = (coset_eval(pk[k]) for k in ("s1", "s2", "s3"))
+    l1_canon = [d0.card_inv] * n  # L_1 = (X^n - 1) / (n (X - 1)) = (1/n) sum X^i
+    e_l1 = coset_eval(l1_canon)
+    W = d1.gen
+    xs = [d1.coset * pow(W, i, R) % R for i in range(N4)]
+    xn_minus_one_inv = [inv((pow(xs[i], n, R) - 1) % R, R) for i in range(rho)]  # x^n takes rho values on the coset
+    uu = u * u % R
+    t = [0] * N4
+    for i in range(N4):
+        lv, rv, ov, zv, zs = e_l[i], e_r[i], e_o[i], e_z[i], e_z[(i + rho) % N4]  # z(omega * x): rho steps of W
+        ic = (e_ql[i] * lv + e_qr[i] * rv + e_qm[i] * lv % R * rv + e_qo[i] * ov + e_qk[i]) % R
+        a = (lv + beta * xs[i] + gamma) * (rv + beta * u % R * xs[i] + gamma) % R * (ov + beta * uu % R * xs[i] + gamma) % R * zv % R
+        b = (lv + beta * e_s1[i] + gamma) * (rv + beta * e_s2[i] + gamma) % R * (ov + beta * e_s3[i] + gamma) % R * zs % R
+        one = (zv - 1) * e_l1[i] % R
+        t[i] = ((one * alpha + (b - a)) % R * alpha + ic) % R * xn_minus_one_inv[i % rho] % R
+    h = be.ntt(d1, bit_reverse(t), True, DIT, True)  # coset interpolation: bit-reversed in -> natural canonical out
+    assert all(c == 0 for c in h[3 * (n + 2):]), "the constraint system is not satisfied (the quotient is not a polynomial)"
+    h1, h2, h3 = h[:n + 2], h[n + 2:2 * (n + 2)], h[2 * (n + 2):3 * (n + 2)]
+    hd = [commit(h1), commit(h2), commit(h3)]
+    zeta = pin.get("zeta", fs.challenge_fr("zeta", *hd))
+
+    # openings
+    lz, rz, oz = poly_eval(bl, zeta), poly_eval(br, zeta), poly_eval(bo, zeta)
+    zeta_sh = zeta * d0.gen % R
+    zu = poly_eval(bz, zeta_sh)
+    z_open_h = commit(divide_by_x_minus_a(bz, zu, zeta_sh))
+
+    # linearised polynomial (prove.go computeLinearizedPolynomial)
+    s1z, s2z = poly_eval(pk["s1"], zeta), poly_eval(pk["s2"], zeta)
+    c_s3 = (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma) % R * zu % R * beta % R
+    c_z = (-(lz + beta * zeta + gamma) * (rz + beta * u % R * zeta + gamma) % R * (oz + beta * uu % R * zeta + gamma)) % R
+    lag1 = (pow(zeta, n, R) - 1) * inv((zeta - 1) % R, R) % R * alpha % R * alpha % R * d0.card_inv % R
+    rl = lz * rz % R
+    lin = []
+    for i in range(len(bz)):
+        v = bz[i] * c_z % R
+        if i < n:
+            v = (v + pk["s3"][i] * c_s3) % R
+        v = v * alpha % R
+        if i < n:
+            v = (v + pk["qm"][i] * rl + pk["ql"][i] * lz + pk["qr"][i] * rz + pk["qo"][i] * oz + pk["cqk"][i]) % R
+        lin.append((v + bz[i] * lag1) % R)
+    lin_digest = commit(lin)
+
+    # folded quotient: h1 + zeta^(n+2) h2 + zeta^(2(n+2)) h3, and its digest
+    zp = pow(zeta, n + 2, R)
+    folded_h = [((h3[i] * zp + h2[i]) % R * zp + h1[i]) % R for i in range(n + 2)]
+    folded_h_digest = g1_add(g1_mul(g1_add(g1_mul(hd[2], zp), hd[1]), zp), hd[0])
+
+    # kzg.BatchOpenSinglePoint of (foldedH, linPol, l, r, o, s1, s2) at zeta
+    polys = [folded_h, lin, bl, br, bo, pk["s1"], pk["s2"]]
+    digests = [folded_h_digest, lin_digest, lro[0], lro[1], lro[2], vk["s"][0], vk["s"][1]]
+    claimed = [poly_eval(p, zeta) for p in polys]
+    kg = pin.get("kzg_gamma", kzg_derive_gamma(zeta, digests, claimed))
+    folded = [0] * max(len(p) for p in polys)
+    acc = 1
+    for p in polys:
+        for j, c in enumerate(p):
+            folded[j] = (folded[j] + c * acc) % R
+        acc = acc * kg % R
+    folded_eval = 0
+    for v in reversed(claimed):
+        folded_eval = (folded_eval * kg + v) % R
+    batch_h = commit(divide_by_x_minus_a(folded, folded_eval, zeta))
+    proof = dict(lro=lro, z=z_digest, h=hd, batch_h=batch_h, claimed=claimed, z_open_h=z_open_h, zu=zu)
+    if trace is not None:
+        trace.update(gamma=gamma, beta=beta, alpha=alpha, zeta=zeta, kzg_gamma=kg, bl=bl, br=br, bo=bo, bz=bz, h=h[:3 * (n + 2)], lin=lin,
+                     folded_h_digest=folded_h_digest, lin_digest=lin_digest)
+    return proof
+
+
+def plonk_proof_bytes(proof) -> bytes:
+    """Proof.WriteTo (marshal.go): LRO[0..2], Z, H[0..2] compressed (7 x 32 B); BatchedProof = H (32 B) | u32 BE count | claimed
+    values (7 x 32 B BE); ZShiftedOpening = H (32 B) | claimed value (32 B).  548 bytes."""
+    out = b"".join(ref.g1_compress(p) for p in (*proof["lro"], proof["z"], *proof["h"]))
+    out += ref.g1_compress(proof["batch_h"]) + len(proof["claimed"]).to_bytes(4, "big") + b"".join(fr_bytes(v) for v in proof["claimed"])
+    out += ref.g1_compress(proof["z_open_h"]) + fr_bytes(proof["zu"])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ Verify
+def _kzg_check(digest, h, value, point, g2) -> bool:
+    """e(C - v*G1 + z*H, G2) == e(H, alpha*G2)"""
+    lhs = g1_add(g1_add(digest, g1_neg(g1_mul(ref.G1_GEN, value))), g1_mul(h, point))
+    return ref.pairing_product_is_one([(lhs, g2[0]), (g1_neg(h), g2[1])])
+
+
+def plonk_verify(vk, proof, public_inputs, challenges=None) -> bool:
+    """plonk.Verify(proof, vk, publicWitness): re-derive the challenges, check the quotient identity at zeta, rebuild the linearised
+    digest from the verifying key, fold the batched opening and check the two KZG openings (at zeta and omega*zeta) by pairings."""
+    n, u = vk["size"], vk["coset_shift"]
+    fs = Transcript("gamma", "beta", "alpha", "zeta")
+    _bind_public_data(fs, vk, public_inputs)
+    gamma = fs.challenge_fr("gamma", *proof["lro"])
+    beta = fs.challenge_fr("beta")
+    alpha = fs.challenge_fr("alpha", proof["z"])
+    zeta = fs.challenge_fr("zeta", *proof["h"])
+    if challenges:
+        gamma, beta, alpha, zeta = (challenges.get(k, v) for k, v in (("gamma", gamma), ("beta", beta), ("alpha", alpha), ("zeta", zeta)))
+    zn = pow(zeta, n, R)
+    zz = (zn - 1) % R
+    # PI(zeta) = sum_i L_i(zeta) w_i ; L_i(zeta) = w^i/n * (zeta^n - 1)/(zeta - w^i)
+    pi = 0
+    for i, w in enumerate(public_inputs):
+        wi = pow(vk["generator"], i, R)
+        pi = (pi + wi * vk["size_inv"] % R * zz % R * inv((zeta - wi) % R, R) % R * w) % R
+    l1 = zz * vk["size_inv"] % R * inv((zeta - 1) % R, R) % R
+    quot, lin_z, lz, rz, oz, s1z, s2z = proof["claimed"]
+    zu = proof["zu"]
+    t = (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma) % R * (oz + gamma) % R * alpha % R * zu % R
+    lhs = (lin_z + pi + t - alpha * alpha % R * l1) % R
+    if lhs != quot * zz % R:
+        return False
+    # digests: folded quotient and linearised polynomial, from public data only
+    zp = pow(zeta, n + 2, R)
+    folded_h = g1_add(g1_mul(g1_add(g1_mul(proof["h"][2], zp), proof["h"][1]), zp), proof["h"][0])
+    uu = u * u % R
+    c_s3 = (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma) % R * zu % R * beta % R * alpha % R
+    c_z = ((-(lz + beta * zeta + gamma) * (rz + beta * u % R * zeta + gamma) % R * (oz + beta * uu % R * zeta + gamma)) % R * alpha + alpha * alpha % R * l1) % R
+    lin_digest = ref.msm_naive(FP, [vk["ql"], vk["qr"], vk["qm"], vk["qo"], vk["qk"], vk["s"][2], proof["z"]], [lz, rz, lz * rz % R, oz, 1, c_s3, c_z])
+    digests = [folded_h, lin_digest, proof["lro"][0], proof["lro"][1], proof["lro"][2], vk["s"][0], vk["s"][1]]
+    kg = (challenges or {}).get("kzg_gamma", kzg_derive_gamma(zeta, digests, proof["claimed"]))
+    fd, fe, acc = None, 0, 1
+    for d, v in zip(digests, proof["claimed"]):
+        fd = g1_add(fd, g1_mul(d, acc))
+        fe = (fe + v * acc) % R
+        acc = acc * kg % R
+    return _kzg_check(fd, proof["batch_h"], fe, zeta, vk["srs_g2"]) and _kzg_check(proof["z"], proof["z_open_h"], zu, zeta * vk["generator"] % R, vk["srs_g2"])
