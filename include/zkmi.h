@@ -194,6 +194,54 @@ int zk_bn254_groth16_msm5_session_stream(uint64_t session, void **stream_out);
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t *partials, size_t n_partials, const zk_fr *r,
                               const zk_fr *s, uint8_t proof_out[128]);
 
+/* ---- PLONK: plonk.Setup / plonk.Prove (gnark v0.8.0 internal/backend/bn254/plonk/{setup,prove}.go) ------------------------------
+ * The reference's only live prove path: PlonkProveWithPK (gnark_backend_ffi/main.go:24-37) -> plonk.Prove at
+ * backend/plonk/plonk.go:67; plonk.Setup at backend/plonk/plonk.go:21; the constraint system is one gate
+ *     qL*xa + qR*xb + qO*xc + qM*xa*xb + qK == 0
+ * per ACIR arithmetic opcode (backend/plonk/sparse_r1cs.go:44-107).  The commitments are kzg.Commit = one G1 MSM over the SRS
+ * registered with zk_bn254_bases_register* (>= domain size + 3 points; kzg.NewSRS at backend/common.go:137); the transforms are the
+ * fft.Domain calls above on the small domain n and the big domain 4n (8n below 6 gates).  Everything between the solver's output and
+ * the 548 proof bytes runs on the device except the Fiat-Shamir hashes and a few G1 scalar multiplications. */
+typedef struct {
+    size_t n_public, n_constraints, n_vars; /* spr.NbPublicVariables, len(spr.Constraints), number of variables (public first) */
+    const void *ql, *qr, *qo, *qm, *qk;     /* n_constraints fr.Elements each (Montgomery); host pointers unless coeffs_on_device */
+    const uint32_t *xa, *xb, *xc;           /* wire ids of every gate (HOST pointers) */
+    int coeffs_on_device;
+    int reserved;
+} zk_plonk_circuit;
+/* gnark's ProvingKey as plonk.Setup / ProvingKey.ReadFrom leave it: canonical (regular) Ql, Qr, Qm, Qo, CQk, S1..S3Canonical and LQk of
+ * 2^log_n entries each, Permutation of 3 * 2^log_n entries, the verifying key's digests -- plus the gates' wire ids (from the spr). */
+typedef struct {
+    uint32_t log_n;
+    size_t n_public, n_constraints, n_vars;
+    const zk_fr *ql, *qr, *qm, *qo, *cqk, *lqk, *s1, *s2, *s3;
+    const int64_t *permutation;
+    const uint32_t *xa, *xb, *xc;
+    const zk_g1_affine *vk_s /* [3] */, *vk_ql, *vk_qr, *vk_qm, *vk_qo, *vk_qk;
+} zk_plonk_pk;
+typedef struct {                 /* plonk.VerifyingKey (without the SRS) */
+    uint64_t size, n_public;     /* Domain[0].Cardinality, NbPublicVariables */
+    zk_fr size_inv, generator, coset_shift;
+    zk_g1_affine s[3], ql, qr, qm, qo, qk;
+} zk_plonk_vk;
+int zk_bn254_plonk_setup(const zk_plonk_circuit *circuit, uint64_t srs_handle, uint64_t *pk_handle, zk_plonk_vk *vk_out);
+int zk_bn254_plonk_pk_load(const zk_plonk_pk *pk, uint64_t srs_handle, uint64_t *pk_handle);
+int zk_bn254_plonk_pk_free(uint64_t pk_handle);
+/* Canonical polynomials of a resident key, for inspection: which = 0..8 -> Ql, Qr, Qm, Qo, CQk, S1, S2, S3 (canonical), LQk; n entries. */
+int zk_bn254_plonk_pk_export(uint64_t pk_handle, int which, zk_fr *out_host, size_t n);
+enum { ZK_PLONK_PROOF_BYTES = 548 }; /* Proof.WriteTo: 7 x 32 B digests | 32 B + u32 count + 7 x 32 B | 32 B + 32 B */
+/* plonk.Prove after the solver.  solution: n_vars values of all variables (public first; Montgomery; device pointer if on_device).
+ * blinders: the 9 scalars upstream draws with fr.SetRandom -- Blind(1) of l, r, o (2 each) and Blind(2) of z (3) -- as INPUTS, which is
+ * what makes the proof bytes reproducible.  challenges: NULL = SHA-256 Fiat-Shamir exactly as upstream (transcript "gamma", "beta",
+ * "alpha", "zeta" + kzg's folding "gamma"); else 5 pinned values (gamma, beta, alpha, zeta, kzg gamma; Montgomery).
+ * ZK_ERR_ARG when the solution does not satisfy the circuit (the quotient is not a polynomial; upstream fails in Solve). */
+int zk_bn254_plonk_prove(uint64_t pk_handle, const void *solution, size_t n_vars, int on_device, const zk_fr blinders[9],
+                         const zk_fr *challenges, uint8_t proof_out[ZK_PLONK_PROOF_BYTES]);
+/* synthetic data (bench / tests): qk[i] = -(ql*a + qr*b + qo*c + qm*a*b) for gate i with a, b, c = solution[xa[i]], ... -- makes any
+ * assignment of random coefficients and wires satisfiable.  All pointers are device pointers. */
+int zk_bn254_plonk_synth_qk_dev(void *d_qk, const void *d_ql, const void *d_qr, const void *d_qo, const void *d_qm, const void *d_xa,
+                                const void *d_xb, const void *d_xc, const void *d_solution, size_t n_constraints, void *stream);
+
 /* What the MSM planner picks for n points (with / without resident window tables): window width c and the number of c-bit
  * digits per scalar, i.e. mixed additions per scalar multiplication -- used by bench.py to turn launches into work. */
 int zk_bn254_msm_plan_info(size_t n, int window_tables, uint32_t *window_bits, uint32_t *digits);
@@ -222,6 +270,11 @@ int zk_bn254_fr_random_dev(void *d_out, size_t n, uint64_t seed, int mont, int w
 int zk_bn254_g1_generate_dev(void *d_out, size_t n, uint64_t seed, void *stream); /* P_i = k_i * G1 */
 int zk_bn254_g2_generate_dev(void *d_out, size_t n, uint64_t seed, void *stream); /* P_i = k_i * G2 */
 int zk_bn254_fr_mul_dev(void *d_out, const void *d_a, const void *d_b, size_t n, void *stream); /* out = a*b (Montgomery) */
+
+/* ---- kzg.NewSRS(size, alpha) (gnark-crypto ecc/bn254/fr/kzg; the reference: backend/common.go:137 with size 1_000_000, main.go:176):
+ * d_g1_out[i] = alpha^i * G1 for i < size, on the device (register it with zk_bn254_bases_register_dev); g2_out = [G2, alpha * G2] on the
+ * host.  alpha: Montgomery fr.Element (toxic waste: the caller's business, exactly as upstream's test-only constructor). */
+int zk_bn254_kzg_new_srs_dev(void *d_g1_out, size_t size, const zk_fr *alpha, zk_g2_affine g2_out[2], void *stream);
 
 /* ---- device memory plumbing for hosts without a HIP binding (ctypes tests, the cgo shim) ------------------------ */
 int zk_dev_alloc(void **d_ptr, size_t bytes);

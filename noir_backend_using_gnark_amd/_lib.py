@@ -30,6 +30,25 @@ class Groth16PK(C.Structure):
                 ("table_window_bits", C.c_int), ("reserved", C.c_int)]
 
 
+class PlonkCircuit(C.Structure):
+    _fields_ = [("n_public", C.c_size_t), ("n_constraints", C.c_size_t), ("n_vars", C.c_size_t),
+                ("ql", C.c_void_p), ("qr", C.c_void_p), ("qo", C.c_void_p), ("qm", C.c_void_p), ("qk", C.c_void_p),
+                ("xa", C.c_void_p), ("xb", C.c_void_p), ("xc", C.c_void_p), ("coeffs_on_device", C.c_int), ("reserved", C.c_int)]
+
+
+class PlonkPK(C.Structure):
+    _fields_ = [("log_n", C.c_uint32), ("n_public", C.c_size_t), ("n_constraints", C.c_size_t), ("n_vars", C.c_size_t)] + \
+               [(k, C.c_void_p) for k in ("ql", "qr", "qm", "qo", "cqk", "lqk", "s1", "s2", "s3", "permutation", "xa", "xb", "xc",
+                                          "vk_s", "vk_ql", "vk_qr", "vk_qm", "vk_qo", "vk_qk")]
+
+
+class PlonkVK(C.Structure):
+    _fields_ = [("size", C.c_uint64), ("n_public", C.c_uint64), ("size_inv", C.c_uint64 * 4), ("generator", C.c_uint64 * 4), ("coset_shift", C.c_uint64 * 4),
+                ("s", C.c_uint64 * 24), ("ql", C.c_uint64 * 8), ("qr", C.c_uint64 * 8), ("qm", C.c_uint64 * 8), ("qo", C.c_uint64 * 8), ("qk", C.c_uint64 * 8)]
+
+
+PLONK_PROOF_BYTES = 548
+
 # every symbol include/zkmi.h declares (tests check that the library exports exactly these)
 SYMBOLS = [
     "zk_device_count", "zk_init", "zk_last_error", "zk_version",
@@ -41,7 +60,8 @@ SYMBOLS = [
     "zk_bn254_felts_decode_hex", "zk_bn254_felts_decode_hex_dev", "zk_bn254_felts_decode_bytes_dev", "zk_bn254_felts_encode_hex",
     "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_pk_info", "zk_bn254_groth16_prove",
     "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_pk_abort", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
-    "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev",
+    "zk_bn254_plonk_setup", "zk_bn254_plonk_pk_load", "zk_bn254_plonk_pk_free", "zk_bn254_plonk_pk_export", "zk_bn254_plonk_prove", "zk_bn254_plonk_synth_qk_dev",
+    "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev", "zk_bn254_kzg_new_srs_dev",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_selftest_host",
 ]

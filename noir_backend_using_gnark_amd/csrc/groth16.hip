@@ -23,6 +23,7 @@
 #include "host_ff.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
+#include "proofio.hpp"
 
 namespace zkmi {
 
@@ -76,46 +77,6 @@ struct Groth16PK {
 static std::mutex g_pk_mu;
 static std::map<uint64_t, Groth16PK> g_pks;
 static uint64_t g_next_pk = 1;
-
-static void to_canonical_u32(const HFr& mont, uint32_t out[8]) {
-    HFr c = mont.from_mont();
-    memcpy(out, c.l, 32);
-}
-
-// gnark-crypto G1Affine.Bytes(): 32 B big-endian X; top bits of byte 0: 10 = y smallest, 11 = y largest, 01 = infinity
-static void fp_to_be(const HFp& mont, uint8_t out[32]) {
-    HFp c = mont.from_mont();
-    for (int i = 0; i < 4; i++)
-        for (int b = 0; b < 8; b++) out[31 - (8 * i + b)] = (uint8_t)(c.l[i] >> (8 * b));
-}
-static bool fp_lex_largest(const HFp& mont) {  // canonical value > (q-1)/2
-    HFp c = mont.from_mont();
-    uint64_t h[4];
-    for (int i = 0; i < 4; i++) h[i] = (HFpParams::MOD[i] >> 1) | (i < 3 ? HFpParams::MOD[i + 1] << 63 : 0);
-    for (int i = 3; i >= 0; i--)
-        if (c.l[i] != h[i]) return c.l[i] > h[i];
-    return false;
-}
-static void g1_compress(const Affine<HFp>& p, uint8_t out[32]) {
-    if (p.is_inf()) {
-        memset(out, 0, 32);
-        out[0] = 0x40;
-        return;
-    }
-    fp_to_be(p.x, out);
-    out[0] |= fp_lex_largest(p.y) ? 0xC0 : 0x80;
-}
-static void g2_compress(const Affine<HFp2>& p, uint8_t out[64]) {
-    if (p.is_inf()) {
-        memset(out, 0, 64);
-        out[0] = 0x40;
-        return;
-    }
-    fp_to_be(p.x.a1, out);
-    fp_to_be(p.x.a0, out + 32);
-    bool largest = p.y.a1.is_zero() ? fp_lex_largest(p.y.a0) : fp_lex_largest(p.y.a1);
-    out[0] |= largest ? 0xC0 : 0x80;
-}
 
 }  // namespace zkmi
 

@@ -25,6 +25,9 @@ int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, siz
 // out[i] = src_idx[i] == ~0u ? (0,0) : compact[src_idx[i]]  (gnark's InfinityA / InfinityB compaction undone at key load)
 int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, const uint32_t* d_src_idx, size_t n, void* d_out);
 
+// number of points / group of a registered base array (zk_bn254_bases_register*)
+int bases_info(uint64_t handle, size_t* n, int* is_g2);
+
 struct MsmPlan {
     unsigned c, W, Wd, key_bits;   // W bucket sets (windows that are reduced separately); Wd digit windows (== W unless table mode)
     uint32_t table_stride;

@@ -5,6 +5,7 @@
 
 #include "ctx.hpp"
 #include "curve.hpp"
+#include "host_ff.hpp"
 
 namespace zkmi {
 
@@ -72,6 +73,26 @@ __global__ __launch_bounds__(256) void k_generate_points(Affine<F>* out, size_t 
     out[i] = acc.to_affine();
 }
 
+// kzg.NewSRS(size, alpha) [gnark-crypto ecc/bn254/fr/kzg; the reference builds its SRS with it at gnark_backend_ffi/backend/common.go:137
+// and main.go:176]: G1[i] = alpha^i * G1.  One lane per point: alpha^i from the bits of i (alpha^(2^b) precomputed), then double-and-add.
+struct PowBits {
+    Fr pw[28];
+};
+__global__ __launch_bounds__(256) void k_kzg_srs_g1(Affine<Fp>* out, size_t n, PowBits basis, Affine<Fp> gen) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr k = Fr::one();
+    for (unsigned b = 0; b < 28; b++)
+        if ((i >> b) & 1) k = k * basis.pw[b];
+    k = k.from_mont();
+    XYZZ<Fp> acc = XYZZ<Fp>::inf();
+    for (int b = 255; b >= 0; b--) {
+        acc.dbl();
+        if ((k.l[b >> 5] >> (b & 31)) & 1) acc.madd(gen.x, gen.y);
+    }
+    out[i] = acc.to_affine();
+}
+
 static Affine<Fp> g1_generator() {
     Affine<Fp> g;
     g.x = Fp::one();
@@ -129,6 +150,38 @@ int zk_bn254_g2_generate_dev(void* d_out, size_t n, uint64_t seed, void* stream)
     if (n)
         ZK_LAUNCH(g.s, st, "g2_generate", (k_generate_points<Fp2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (Affine<Fp2>*)d_out, n, seed,
                   g2_generator());
+    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    return ZK_OK;
+}
+
+// kzg.NewSRS(size, alpha): size G1 points alpha^i * G1 into d_g1_out (device), and [G2, alpha * G2] to the host.
+int zk_bn254_kzg_new_srs_dev(void* d_g1_out, size_t size, const zk_fr* alpha, zk_g2_affine g2_out[2], void* stream) {
+    if ((size && !d_g1_out) || !alpha) return set_err(ZK_ERR_ARG, "null pointer");
+    if (size > ((size_t)1 << 28)) return set_err(ZK_ERR_ARG, "SRS size %zu exceeds 2^28", size);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    HFr a;
+    memcpy(&a, alpha, 32);
+    PowBits pb;
+    for (int b = 0; b < 28; b++) {
+        memcpy(&pb.pw[b], &a, 32);
+        a = a.sqr();
+    }
+    if (size) ZK_LAUNCH(g.s, st, "kzg_srs_g1", k_kzg_srs_g1, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, (Affine<Fp>*)d_g1_out, size, pb, g1_generator());
+    if (g2_out) {
+        Affine<Fp2> gd = g2_generator();
+        Affine<HFp2> gh;
+        memcpy(&gh, &gd, sizeof gh);
+        HFr a0;
+        memcpy(&a0, alpha, 32);
+        HFr can = a0.from_mont();
+        uint32_t k[8];
+        memcpy(k, can.l, 32);
+        Affine<HFp2> ag = scalar_mul(gh, k).to_affine();
+        memcpy(&g2_out[0], &gh, 128);
+        memcpy(&g2_out[1], &ag, 128);
+    }
     if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }

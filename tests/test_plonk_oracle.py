@@ -1,0 +1,115 @@
+"""CPU suite for the PLONK restatement (oracle/plonk_ref.py): the committed fixtures -- the reference's three demo circuits
+(gnark_backend_ffi/main.go:223-248, lowered per backend/plonk/sparse_r1cs.go:44-107) -- reproduce byte for byte, verify by pairings,
+fail when tampered with; the transcript / KZG pieces satisfy their defining identities; the C-oracle-accelerated path agrees with
+the pure-Python one."""
+import json
+import os
+
+import pytest
+
+from oracle import bn254_ref as ref
+from oracle import plonk_ref as pl
+
+R = ref.R
+HERE = os.path.dirname(os.path.abspath(__file__))
+h2i = lambda h: int(h, 16)
+
+
+@pytest.fixture(scope="module")
+def plonk_golden():
+    return json.load(open(os.path.join(HERE, "golden", "plonk_golden.json")))
+
+
+def _instance(e):
+    spr, sol = pl.sparse_r1cs_from_acir(e["acir"], [h2i(v) for v in e["values"]])
+    srs = pl.kzg_new_srs(e["srs_size"], h2i(e["srs_alpha"]))
+    return spr, sol, srs
+
+
+def test_lowering_matches_fixture_and_is_satisfied(plonk_golden):
+    for e in plonk_golden:
+        spr, sol, _ = _instance(e)
+        assert spr.n_public == e["n_public"] and spr.n_vars == e["n_vars"]
+        assert [[("%064x" % c) for c in g[:5]] + list(g[5:]) for g in spr.constraints] == e["gates"]
+        assert ["%064x" % v for v in sol] == e["solution"]
+        assert spr.is_satisfied(sol)
+    # the reference's "-1" literal (main.go:233) is r - 1
+    assert h2i(plonk_golden[0]["gates"][0][1]) == R - 1
+
+
+def test_golden_proofs_reproduce_and_verify(plonk_golden):
+    e = plonk_golden[0]
+    spr, sol, srs = _instance(e)
+    pk, vk = pl.plonk_setup(spr, srs)
+    assert {k: ref.g1_affine_mont_bytes(vk[k]).hex() for k in ("ql", "qr", "qm", "qo", "qk")} == {k: e["vk"][k] for k in ("ql", "qr", "qm", "qo", "qk")}
+    assert [ref.g1_affine_mont_bytes(p).hex() for p in vk["s"]] == e["vk"]["s"]
+    trace = {}
+    proof = pl.plonk_prove(pk, sol, [h2i(v) for v in e["blinders"]], trace=trace)
+    assert pl.plonk_proof_bytes(proof).hex() == e["proof"] and len(e["proof"]) == 2 * 548
+    assert {k: "%064x" % trace[k] for k in e["challenges"]} == e["challenges"]
+    pub = sol[:spr.n_public]
+    assert pl.plonk_verify(vk, proof, pub)
+    assert not pl.plonk_verify(vk, proof, [(pub[0] + 1) % R])                                  # another public input
+    assert not pl.plonk_verify(vk, dict(proof, claimed=[(proof["claimed"][0] + 1) % R] + proof["claimed"][1:]), pub)
+    assert not pl.plonk_verify(vk, dict(proof, z=ref.g1_add(proof["z"], ref.G1_GEN)), pub)    # another commitment
+    # pinned challenges: same entry point, other bytes, still a valid proof under the same pinned values
+    pinned = {k: h2i(v) for k, v in e["pinned_challenges"].items()}
+    proof_p = pl.plonk_prove(pk, sol, [h2i(v) for v in e["blinders"]], challenges=pinned)
+    assert pl.plonk_proof_bytes(proof_p).hex() == e["proof_pinned"] != e["proof"]
+
+
+def test_unsatisfied_witness_is_rejected(plonk_golden):
+    e = plonk_golden[1]
+    spr, sol, srs = _instance(e)
+    pk, _ = pl.plonk_setup(spr, srs)
+    bad = list(sol)
+    bad[-2] = (bad[-2] + 1) % R   # w5 (the last variable, w6, is in no gate) enters three gates
+    assert not spr.is_satisfied(bad)
+    with pytest.raises(AssertionError, match="not satisfied"):
+        pl.plonk_prove(pk, bad, [1] * 9)
+
+
+def test_transcript_and_kzg_identities():
+    import hashlib
+    t = pl.Transcript("gamma", "beta")
+    t.bind("gamma", b"\x01\x02")
+    g = t.compute("gamma")
+    assert g == hashlib.sha256(b"gamma" + b"\x01\x02").digest()
+    assert t.compute("beta") == hashlib.sha256(b"beta" + g).digest()
+    # synthetic division: f = q * (X - a) + f(a)
+    f = ref.rand_felts(5, 9)
+    a = 12345
+    fa = pl.poly_eval(f, a)
+    q = pl.divide_by_x_minus_a(f, fa, a)
+    x = 777
+    assert (pl.poly_eval(q, x) * (x - a) + fa) % R == pl.poly_eval(f, x)
+    # an opening verifies by pairings
+    srs = pl.kzg_new_srs(9, 424242)
+    be = pl._Backend(False)
+    c, h = be.msm_g1(srs["g1"], f), be.msm_g1(srs["g1"], q)
+    assert pl._kzg_check(c, h, fa, a, srs["g2"]) and not pl._kzg_check(c, h, (fa + 1) % R, a, srs["g2"])
+
+
+def test_fast_backend_equals_pure_python():
+    """2^7-row random satisfiable circuit: NTTs / MSMs through the C oracle give the pure-Python proof bytes."""
+    g = ref.SplitMix64(0x77)
+    nvars, nc, npub = 40, 100, 3
+    sol = [g.felt() for _ in range(nvars)]
+    gates = []
+    for _ in range(nc):
+        xa, xb, xc = (int(g.next() % nvars) for _ in range(3))
+        ql, qr, qo, qm = (g.felt() for _ in range(4))
+        qk = (-(ql * sol[xa] + qr * sol[xb] + qo * sol[xc] + qm * sol[xa] * sol[xb])) % R
+        gates.append((ql, qr, qo, qm, qk, xa, xb, xc))
+    spr = pl.SparseR1CS(npub, nvars - npub, gates)
+    assert spr.is_satisfied(sol)
+    srs = pl.kzg_new_srs(128 + 3, 99991, fast=True)
+    srs_py = dict(g1=[pl.g1_from_np(p) for p in srs["g1"]], g2=srs["g2"])
+    bl = ref.rand_felts(1, 9)
+    pk_f, vk_f = pl.plonk_setup(spr, srs, fast=True)
+    pk_p, vk_p = pl.plonk_setup(spr, srs_py, fast=False)
+    assert vk_f["s"] == vk_p["s"] and vk_f["qk"] == vk_p["qk"]
+    pf = pl.plonk_prove(pk_f, sol, bl, fast=True)
+    pp = pl.plonk_prove(pk_p, sol, bl, fast=False)
+    assert pl.plonk_proof_bytes(pf) == pl.plonk_proof_bytes(pp)
+    assert pl.plonk_verify(vk_f, pf, sol[:npub])
