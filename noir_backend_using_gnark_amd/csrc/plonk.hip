@@ -333,6 +333,11 @@ __global__ void k_blind(Fr* p, uint32_t n, BlindArgs B) {
     p[i] = ld(p + i) - B.b[i];
     p[n + i] = B.b[i];
 }
+// *flag |= 1 if any of a[0 .. n) is non-zero
+__global__ void k_any_nonzero(const Fr* __restrict__ a, size_t n, int* __restrict__ flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !ld(a + i).is_zero()) atomicOr(flag, 1);
+}
 // qk[i] = -(ql a + qr b + qo c + qm a b): synthetic satisfiable circuits (bench / tests)
 __global__ void k_synth_qk(Fr* qk, const Fr* ql, const Fr* qr, const Fr* qo, const Fr* qm, const uint32_t* xa, const uint32_t* xb, const uint32_t* xc,
                            const Fr* sol, size_t nc) {
@@ -825,11 +830,16 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     }
     Fr* h = P->w_big[4];
     ZK_TRY(ntt_dev(s, st, h, logN4, 1, ZK_DIT, 1));  // LagrangeCoset (bit-reversed) -> canonical (regular)
-    // the quotient has 3(n+2) coefficients iff the constraints hold; the first coefficient above that is checked (upstream fails in Solve)
-    Fr h_top;
-    ZK_HIP(hipMemcpyAsync(&h_top, h + 3 * (n + 2), sizeof(Fr), hipMemcpyDeviceToHost, st));
+    // the quotient has 3(n+2) coefficients iff the constraints hold: with a violated gate the remainder B = numerator mod (X^n - 1) is not
+    // zero and shows up as B_j / (g^N4 - 1) in EVERY block of n coefficients above -- so all of h[3(n+2) .. N4) must vanish (upstream
+    // fails earlier, in Solve)
+    int* d_flag = (int*)s->alloc(64);
+    int h_flag = 0;
+    ZK_HIP(hipMemsetAsync(d_flag, 0, 4, st));
+    ZK_LAUNCH(s, st, "plonk_quotient_check", k_any_nonzero, dim3(grid_of(N4 - 3 * (n + 2))), dim3(256), 0, (const Fr*)(h + 3 * (n + 2)), N4 - 3 * (n + 2), d_flag);
+    ZK_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st));
     for (int k = 0; k < 3; k++) ZK_TRY(commit(P, s, st, h + k * (n + 2), n + 2, &c_h[k]));
-    if (!h_top.is_zero()) return set_err(ZK_ERR_ARG, "the solution does not satisfy the constraint system (the quotient is not a polynomial)");
+    if (h_flag) return set_err(ZK_ERR_ARG, "the solution does not satisfy the constraint system (the quotient is not a polynomial)");
     for (int k = 0; k < 3; k++) fs.bind_g1(3, c_h[k]);
     HFr zeta = fs.challenge(3);
     if (challenges) zeta = pin[3];
