@@ -133,6 +133,81 @@ def oracle_proof(inst, log_n):
     return cpu_proof, time.perf_counter() - t0, cores
 
 
+def plonk_block(L, lib, log_n, reps=3):
+    """BASELINE.json configs[3]: "PLONK prove path (KZG-commit MSMs + coset NTTs) at 2^22 gates, 1xMI355X" -- the reference's only live
+    prove path (plonk.Prove, backend/plonk/plonk.go:67).  Device-generated KZG SRS (real powers of alpha: kzg.NewSRS), a synthetic
+    satisfiable circuit of 2^log_n rows (random wiring, random selectors, qK fixed per gate), plonk.Setup and plonk.Prove on the
+    device; the 548 proof bytes are then handed to the CPU oracle's VERIFIER (quotient identity + two KZG pairing checks)."""
+    from noir_backend_using_gnark_amd import bn254 as zb, plonk as zp
+    n = 1 << log_n
+    npub, nvars = 4, n // 2
+    nc = n - npub
+    alpha = 0xA1FA0123456789ABCDEF
+    t0 = time.time()
+    d_srs = lib.DeviceBuffer((n + 3) * 64)
+    a_m = np.frombuffer((alpha * (1 << 256) % R_FR).to_bytes(32, "little"), dtype=np.uint64).copy()
+    lib.check(L.zk_bn254_kzg_new_srs_dev(C.c_void_p(d_srs.ptr), C.c_size_t(n + 3), lib.vp(a_m), None, None))
+    srs = zb.ResidentBases(d_srs, n=n + 3)
+    rng = np.random.default_rng(5)
+    xa, xb, xc = (rng.integers(0, nvars, nc, dtype=np.uint32) for _ in range(3))
+    dsol = lib.DeviceBuffer(nvars * 32)
+    lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(dsol.ptr), C.c_size_t(nvars), C.c_uint64(0x51), C.c_int(1), C.c_int(1), None))
+    coef = []
+    for sd in (1, 2, 3, 4):
+        b = lib.DeviceBuffer(nc * 32)
+        lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(b.ptr), C.c_size_t(nc), C.c_uint64(sd), C.c_int(1), C.c_int(0), None))
+        coef.append(b)
+    dqk = lib.DeviceBuffer(nc * 32)
+    dx = [lib.DeviceBuffer.from_numpy(v) for v in (xa, xb, xc)]
+    lib.check(L.zk_bn254_plonk_synth_qk_dev(C.c_void_p(dqk.ptr), *[C.c_void_p(b.ptr) for b in coef], *[C.c_void_p(b.ptr) for b in dx], C.c_void_p(dsol.ptr),
+                                            C.c_size_t(nc), None))
+    t_data = time.time() - t0
+    t0 = time.time()
+    pk = zp.setup(zp.Circuit(npub, nvars, coef[0], coef[1], coef[2], coef[3], dqk, xa, xb, xc), srs)
+    t_setup = time.time() - t0
+    bl = np.arange(1, 37, dtype=np.uint64).reshape(9, 4)  # any nine scalars < r (Montgomery images of something)
+    proof = zp.prove(pk, dsol, bl)
+    lib.profile(True)
+    lib.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proof = zp.prove(pk, dsol, bl)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    lib.profile(False)
+    prof = lib.profile_read()
+    out = {"gates": n, "prove_ms": round(ms, 2), "steps": reps, "warmup": 1, "setup_ms": round(t_setup * 1e3, 1), "data_s": round(t_data, 2),
+           "kzg_commits_per_proof": 10, "ntt_per_proof": "5 x inverse(n) + 5 x coset(4n) + 1 x coset inverse(4n)",
+           "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
+           "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]}}
+    # ---- checker (CPU oracle, after the timed region): decode Proof.WriteTo and run plonk.Verify's equations
+    from oracle import bn254_ref as ref, plonk_ref as pl
+
+    def dec(b):
+        if b[0] >> 6 == 1:
+            return None
+        x = int.from_bytes(bytes([b[0] & 0x3F]) + b[1:], "big")
+        y = pow((x * x * x + 3) % ref.Q, (ref.Q + 1) // 4, ref.Q)
+        return (x, ref.Q - y if (y > (ref.Q - 1) // 2) != (b[0] >> 6 == 3) else y)
+
+    pts = [dec(proof[32 * i:32 * i + 32]) for i in range(7)]
+    claimed = [int.from_bytes(proof[260 + 32 * i:292 + 32 * i], "big") for i in range(7)]
+    pr = dict(lro=pts[0:3], z=pts[3], h=pts[4:7], batch_h=dec(proof[224:256]), claimed=claimed, z_open_h=dec(proof[484:516]), zu=int.from_bytes(proof[516:548], "big"))
+    P = pl.g1_from_np
+    vkd = pk.vk
+    vk = dict(size=n, size_inv=ref.inv(n, ref.R), generator=pl.mont_np_to_ints(vkd["generator"])[0], n_public=npub, coset_shift=5,
+              srs_g2=[ref.G2_GEN, ref.g2_mul(ref.G2_GEN, alpha)], s=[P(p) for p in vkd["s"]], ql=P(vkd["ql"]), qr=P(vkd["qr"]), qm=P(vkd["qm"]), qo=P(vkd["qo"]), qk=P(vkd["qk"]))
+    pub = pl.mont_np_to_ints(dsol.to_numpy(np.uint64, (npub, 4)))
+    out["verified_by"] = "oracle/plonk_ref.plonk_verify: Fiat-Shamir re-derived from the bytes, quotient identity at zeta, two KZG openings by pairings"
+    out["proof_verifies"] = bool(pl.plonk_verify(vk, pr, pub))
+    out["wrong_public_input_rejected"] = bool(not pl.plonk_verify(vk, pr, [(pub[0] + 1) % ref.R] + pub[1:]))
+    pk.free()
+    srs.free()
+    return out
+
+
+R_FR = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +220,8 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU decomposition (sharded computeH phases + msm5_pk + all-gather + finalize) even at N=1")
     ap.add_argument("--no-2p24", action="store_true", help="skip the second measured block (2^24 constraints on this GPU)")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the host-input (PCIe-inclusive) measurement")
+    ap.add_argument("--no-plonk", action="store_true", help="skip the PLONK block (configs[3]: plonk.Prove at 2^22 gates, verified by the oracle's pairing verifier)")
+    ap.add_argument("--plonk-log-n", type=int, default=22)
     ap.add_argument("--verify-2p24-oracle", action="store_true", help="also check the 2^24 proof bytes against the CPU oracle (~2 min on 128 cores)")
     args = ap.parse_args()
 
@@ -349,6 +426,14 @@ def main():
                 out["parity_error"] = "2^24: GPU proof bytes differ from the CPU oracle's"
         out["at_2p24"] = blk
         big.free()
+        inst = None
+    # ---- third measured block: BASELINE configs[3], the PLONK prover at 2^22 gates
+    if single and log_n == 20 and not args.no_plonk:
+        if inst is not None:
+            inst.free()
+        out["plonk_2p%d" % args.plonk_log_n] = plonk_block(L, _lib, args.plonk_log_n)
+        if not out["plonk_2p%d" % args.plonk_log_n]["proof_verifies"]:
+            out["parity_error"] = "PLONK: the proof does not verify"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
