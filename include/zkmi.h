@@ -227,6 +227,12 @@ typedef struct {                 /* plonk.VerifyingKey (without the SRS) */
 int zk_bn254_plonk_setup(const zk_plonk_circuit *circuit, uint64_t srs_handle, uint64_t *pk_handle, zk_plonk_vk *vk_out);
 int zk_bn254_plonk_pk_load(const zk_plonk_pk *pk, uint64_t srs_handle, uint64_t *pk_handle);
 int zk_bn254_plonk_pk_free(uint64_t pk_handle);
+/* plonk.ProvingKey.ReadFrom / WriteTo on gnark's bytes (is_hex / as_hex: the hex text the reference ships, internal/backend/helpers.go:49-60,
+ * 82-87): verifying key | Domain[0] | Domain[1] | Ql Qr Qm Qo CQk LQk S1 S2 S3 (u32 BE length + 32 B BE elements) | Permutation (3n raw BE
+ * int64).  The nine vectors are decoded / encoded on the device; the wire ids come from the spr the caller rebuilt (plonk.go:54). */
+int zk_bn254_plonk_pk_read(const void *data, size_t len, int is_hex, size_t n_vars, size_t n_constraints, const uint32_t *xa,
+                           const uint32_t *xb, const uint32_t *xc, uint64_t srs_handle, uint64_t *pk_handle);
+int zk_bn254_plonk_pk_write(uint64_t pk_handle, int as_hex, void *out, size_t cap, size_t *out_len);
 /* Canonical polynomials of a resident key, for inspection: which = 0..8 -> Ql, Qr, Qm, Qo, CQk, S1, S2, S3 (canonical), LQk; n entries. */
 int zk_bn254_plonk_pk_export(uint64_t pk_handle, int which, zk_fr *out_host, size_t n);
 enum { ZK_PLONK_PROOF_BYTES = 548 }; /* Proof.WriteTo: 7 x 32 B digests | 32 B + u32 count + 7 x 32 B | 32 B + 32 B */
@@ -275,6 +281,14 @@ int zk_bn254_fr_mul_dev(void *d_out, const void *d_a, const void *d_b, size_t n,
  * d_g1_out[i] = alpha^i * G1 for i < size, on the device (register it with zk_bn254_bases_register_dev); g2_out = [G2, alpha * G2] on the
  * host.  alpha: Montgomery fr.Element (toxic waste: the caller's business, exactly as upstream's test-only constructor). */
 int zk_bn254_kzg_new_srs_dev(void *d_g1_out, size_t size, const zk_fr *alpha, zk_g2_affine g2_out[2], void *stream);
+/* kzg.SRS.ReadFrom / WriteTo (what LoadSRS / SaveSRS move through srs.hex: backend/common.go:86-125, re-read on every call at
+ * backend/plonk/plonk.go:16,34,58): G2[0] | G2[1] (64 B compressed) | u32 BE count | count x 32 B compressed G1, as bytes or hex text.
+ * _read decompresses the G1 points on the device (one square root each) straight into a registered base array (window tables per
+ * table_window_bits as in zk_bn254_bases_register_cfg) and returns the two G2 points; _write is the inverse.  Errors: ZK_ERR_LEN (size
+ * does not match the count), ZK_ERR_ARG (bad hex, bad flags, x >= q, no square root, G2 point outside the r-torsion). */
+int zk_bn254_kzg_srs_read(const void *data, size_t len, int is_hex, int table_window_bits, uint64_t *handle, size_t *n_g1,
+                          zk_g2_affine g2_out[2]);
+int zk_bn254_kzg_srs_write(uint64_t handle, const zk_g2_affine g2[2], int as_hex, void *out, size_t cap, size_t *out_len);
 
 /* ---- device memory plumbing for hosts without a HIP binding (ctypes tests, the cgo shim) ------------------------ */
 int zk_dev_alloc(void **d_ptr, size_t bytes);

@@ -1,0 +1,23 @@
+// Wire formats of keys and the SRS decoded / encoded on the device (keyio.hip); used by the PLONK key reader in plonk.hip.
+#pragma once
+#include "ctx.hpp"
+#include "curve.hpp"
+#include "host_ff.hpp"
+
+namespace zkmi {
+
+// 2*n_bytes hex characters at d_text -> n_bytes bytes at d_out (both device); *d_status |= 1 on a character that is not a hex digit
+int hex_decode_dev(Slot* s, hipStream_t st, const void* d_text, size_t n_bytes, void* d_out, int* d_status);
+int hex_encode_dev(Slot* s, hipStream_t st, const void* d_bytes, size_t n_bytes, void* d_text);
+// n x 32-byte big-endian canonical fr.Elements at d_raw (any 4-byte alignment) <-> Montgomery images; *d_status |= 2 on a value >= r
+int fr_from_be_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void* d_out, int* d_status);
+int fr_to_be_dev(Slot* s, hipStream_t st, const void* d_in, size_t n, void* d_raw);
+// n x 32-byte compressed G1 points (G1Affine.Bytes()) <-> affine Montgomery images; *d_status |= 4 on an invalid encoding
+int g1_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void* d_out, int* d_status);
+int g1_compress_dev(Slot* s, hipStream_t st, const void* d_pts, size_t n, void* d_raw);
+// host: one compressed G2 point (G2Affine.Bytes()) -> affine; false on an invalid encoding / a point outside the r-torsion
+bool g2_decompress_host(const uint8_t in[64], Affine<HFp2>* out);
+// registered bases: device pointer and count
+int bases_ptr(uint64_t handle, const void** d, size_t* n, int* is_g2);
+
+}  // namespace zkmi

@@ -1023,6 +1023,15 @@ static std::mutex g_bases_mu;
 static std::map<uint64_t, Bases> g_bases;
 static uint64_t g_next_handle = 1;
 
+int bases_ptr(uint64_t handle, const void** d, size_t* n, int* is_g2) {
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
+    if (d) *d = it->second.d;
+    if (n) *n = it->second.n;
+    if (is_g2) *is_g2 = it->second.is_g2;
+    return ZK_OK;
+}
 int bases_info(uint64_t handle, size_t* n, int* is_g2) {
     std::lock_guard<std::mutex> lk(g_bases_mu);
     auto it = g_bases.find(handle);

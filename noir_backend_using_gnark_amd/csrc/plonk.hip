@@ -23,6 +23,7 @@
 #include "curve.hpp"
 #include "host_ff.hpp"
 #include "msm.hpp"
+#include "keyio.hpp"
 #include "ntt.hpp"
 #include "proofio.hpp"
 
@@ -347,6 +348,21 @@ __global__ void k_synth_qk(Fr* qk, const Fr* ql, const Fr* qr, const Fr* qo, con
     qk[i] = Fr::zero() - (ld(ql + i) * a + ld(qr + i) * b + ld(qo + i) * c + ld(qm + i) * (a * b));
 }
 
+// pk.Permutation on the wire: 3n raw big-endian int64 (encoding/binary, no length prefix) <-> uint32 slots
+__global__ void k_perm_from_be(const uint32_t* __restrict__ raw, size_t cnt, uint32_t* __restrict__ out, int* __restrict__ status) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    uint32_t hi = __builtin_bswap32(raw[2 * i]), lo = __builtin_bswap32(raw[2 * i + 1]);
+    if (hi != 0 || lo >= cnt) { atomicOr(status, 8); lo = 0; }
+    out[i] = lo;
+}
+__global__ void k_perm_to_be(const uint32_t* __restrict__ in, size_t cnt, uint32_t* __restrict__ raw) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    raw[2 * i] = 0;
+    raw[2 * i + 1] = __builtin_bswap32(in[i]);
+}
+
 // ------------------------------------------------------------------------------------------------ resident key
 struct PlonkPK {
     unsigned logn = 0, logN4 = 0, log_rho = 0;
@@ -355,6 +371,7 @@ struct PlonkPK {
     HFr gen, u, card_inv;
     // canonical (regular) polynomials of the key, n each, and LQk (Lagrange)
     Fr *ql = nullptr, *qr = nullptr, *qm = nullptr, *qo = nullptr, *cqk = nullptr, *lqk = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
+    uint32_t* perm = nullptr;  // pk.Permutation (3n), kept for ProvingKey.WriteTo
     Fr* sig = nullptr;      // S1 | S2 | S3 in Lagrange form (3n): what BuildRatioCopyConstraint reads through pk.Permutation
     Fr* e[9] = {};          // ql, qr, qm, qo, s1, s2, s3, L1, id as LagrangeCoset on the big domain, bit-reversed layout (gnark caches the first 7)
     uint32_t *xa = nullptr, *xb = nullptr, *xc = nullptr;
@@ -599,8 +616,12 @@ int zk_bn254_plonk_setup(const zk_plonk_circuit* c, uint64_t srs, uint64_t* hand
     }
     std::vector<uint32_t> perm;
     build_permutation(n, npub, nc, c->n_vars, c->xa, c->xb, c->xc, &perm);
-    uint32_t* d_perm = (uint32_t*)s->alloc(3 * n * 4 + 16);
-    if (!d_perm) return set_err(ZK_ERR_HIP, "PLONK setup workspace");
+    uint32_t* d_perm;
+    {
+        Fr* tmp;
+        ZK_TRY(pk_alloc(P.get(), &tmp, (3 * n * 4 + 31) / 32 + 1));
+        P->perm = d_perm = (uint32_t*)tmp;
+    }
     ZK_HIP(hipMemcpyAsync(d_perm, perm.data(), 3 * n * 4, hipMemcpyHostToDevice, st));
     ZK_TRY(pk_alloc(P.get(), &P->s1, n));
     ZK_TRY(pk_alloc(P.get(), &P->s2, n));
@@ -670,8 +691,12 @@ int zk_bn254_plonk_pk_load(const zk_plonk_pk* k, uint64_t srs, uint64_t* handle)
         *wid[i] = (uint32_t*)tmp;
         if (k->n_constraints) ZK_HIP(hipMemcpyAsync(*wid[i], wsrc[i], k->n_constraints * 4, hipMemcpyHostToDevice, st));
     }
-    uint32_t* d_perm = (uint32_t*)s->alloc(3 * n * 4 + 16);
-    if (!d_perm) return set_err(ZK_ERR_HIP, "PLONK key-load workspace");
+    uint32_t* d_perm;
+    {
+        Fr* tmp;
+        ZK_TRY(pk_alloc(P.get(), &tmp, (3 * n * 4 + 31) / 32 + 1));
+        P->perm = d_perm = (uint32_t*)tmp;
+    }
     ZK_HIP(hipMemcpyAsync(d_perm, perm.data(), 3 * n * 4, hipMemcpyHostToDevice, st));
     ZK_TRY(make_sigma(P.get(), s, st, d_perm));
     ZK_TRY(finish_pk(P.get(), s, st));
@@ -679,6 +704,177 @@ int zk_bn254_plonk_pk_load(const zk_plonk_pk* k, uint64_t srs, uint64_t* handle)
     memcpy(&P->vk_ql, k->vk_ql, 64); memcpy(&P->vk_qr, k->vk_qr, 64); memcpy(&P->vk_qm, k->vk_qm, 64);
     memcpy(&P->vk_qo, k->vk_qo, 64); memcpy(&P->vk_qk, k->vk_qk, 64);
     return register_pk(P.release(), handle);
+}
+
+// ---- plonk.ProvingKey.ReadFrom / WriteTo (gnark v0.8.0 internal/backend/bn254/plonk/marshal.go  [UPSTREAM-RECALL]; the reference ships the key as
+// hex of these bytes: internal/backend/helpers.go:49-60,82-87, produced at main.go:58-78, consumed at main.go:24-37):
+//   VerifyingKey.WriteTo  Size u64 | SizeInv | Generator | NbPublicVariables u64 | CosetShift | S[0..2] | Ql Qr Qm Qo Qk (compressed G1)   368 B
+//   Domain[0], Domain[1]  Cardinality u64 | CardinalityInv | Generator | GeneratorInv | FrMultiplicativeGen | FrMultiplicativeGenInv      168 B each
+//   Ql Qr Qm Qo CQk LQk S1Canonical S2Canonical S3Canonical   each u32 BE length | n x 32 B BE
+//   Permutation           3n raw big-endian int64
+static const size_t PK_HEAD = 368 + 2 * 168;
+
+static int hexval(int c) { return (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; }
+// bytes [off, off + cnt) of a payload given as raw bytes or as hex text (host side: headers and length prefixes only)
+static int payload_bytes(const void* data, size_t len, int is_hex, size_t off, size_t cnt, uint8_t* out) {
+    const size_t nbytes = is_hex ? len / 2 : len;
+    if (off + cnt > nbytes) return set_err(ZK_ERR_LEN, "proving key: truncated (%zu bytes, %zu needed)", nbytes, off + cnt);
+    const uint8_t* p = (const uint8_t*)data;
+    for (size_t i = 0; i < cnt; i++) {
+        if (!is_hex) { out[i] = p[off + i]; continue; }
+        int h = hexval(p[2 * (off + i)]), l = hexval(p[2 * (off + i) + 1]);
+        if (h < 0 || l < 0) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
+        out[i] = (uint8_t)((h << 4) | l);
+    }
+    return ZK_OK;
+}
+static uint64_t be64(const uint8_t* p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }
+
+int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_vars, size_t n_constraints, const uint32_t* xa, const uint32_t* xb,
+                           const uint32_t* xc, uint64_t srs, uint64_t* handle) {
+    if (!data || !handle || (n_constraints && (!xa || !xb || !xc))) return set_err(ZK_ERR_ARG, "null pointer");
+    if (is_hex && (len & 1)) return set_err(ZK_ERR_LEN, "proving key: odd number of hex characters");
+    const size_t nbytes = is_hex ? len / 2 : len;
+    uint8_t head[PK_HEAD];
+    ZK_TRY(payload_bytes(data, len, is_hex, 0, PK_HEAD, head));
+    const uint64_t size = be64(head), npub = be64(head + 72), card0 = be64(head + 368), card1 = be64(head + 368 + 168);
+    unsigned logn, logN4;
+    ZK_TRY(domains_for(n_constraints + npub, &logn, &logN4));
+    if (size != ((uint64_t)1 << logn) || card0 != size || card1 != ((uint64_t)1 << logN4))
+        return set_err(ZK_ERR_ARG, "proving key: domain sizes %llu / %llu / %llu do not match %zu constraints + %llu public inputs", (unsigned long long)size,
+                       (unsigned long long)card0, (unsigned long long)card1, n_constraints, (unsigned long long)npub);
+    const size_t n = (size_t)size;
+    if (nbytes != PK_HEAD + 9 * (4 + 32 * n) + 24 * n) return set_err(ZK_ERR_LEN, "proving key: %zu bytes, %zu expected for a domain of %zu", nbytes, PK_HEAD + 9 * (4 + 32 * n) + 24 * n, n);
+    for (int k = 0; k < 9; k++) {
+        uint8_t pre[4];
+        ZK_TRY(payload_bytes(data, len, is_hex, PK_HEAD + (size_t)k * (4 + 32 * n), 4, pre));
+        if ((((size_t)pre[0] << 24) | ((size_t)pre[1] << 16) | ((size_t)pre[2] << 8) | pre[3]) != n) return set_err(ZK_ERR_LEN, "proving key: vector %d does not hold %zu elements", k, n);
+    }
+    for (size_t i = 0; i < n_constraints; i++)
+        if (xa[i] >= n_vars || xb[i] >= n_vars || xc[i] >= n_vars) return set_err(ZK_ERR_ARG, "gate %zu names a wire outside the %zu variables", i, n_vars);
+    ZK_TRY(ensure_init());
+    ZK_TRY(check_srs(srs, n));
+    std::unique_ptr<PlonkPK, void (*)(PlonkPK*)> P(new PlonkPK(), pk_destroy);
+    P->logn = logn; P->logN4 = logN4; P->log_rho = logN4 - logn;
+    P->n = n; P->N4 = (size_t)1 << logN4;
+    P->n_public = (size_t)npub; P->n_constraints = n_constraints; P->n_vars = n_vars;
+    P->srs = srs;
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    Slot* s = g.s;
+    hipStream_t st = s->stream;
+    ZK_TRY(s->reserve(len + nbytes + 65536));
+    int* d_status = (int*)s->alloc(64);
+    ZK_HIP(hipMemsetAsync(d_status, 0, 4, st));
+    uint8_t* d_bytes = (uint8_t*)s->alloc(nbytes + 16);
+    if (is_hex) {
+        if (nbytes & 3) return set_err(ZK_ERR_LEN, "proving key: length is not a multiple of 4 bytes");
+        void* d_text = s->alloc(len + 16);
+        ZK_HIP(hipMemcpyAsync(d_text, data, len, hipMemcpyHostToDevice, st));
+        ZK_TRY(hex_decode_dev(s, st, d_text, nbytes, d_bytes, d_status));
+    } else {
+        ZK_HIP(hipMemcpyAsync(d_bytes, data, nbytes, hipMemcpyHostToDevice, st));
+    }
+    Fr** dst[9] = {&P->ql, &P->qr, &P->qm, &P->qo, &P->cqk, &P->lqk, &P->s1, &P->s2, &P->s3};
+    for (int k = 0; k < 9; k++) {
+        ZK_TRY(pk_alloc(P.get(), dst[k], n));
+        ZK_TRY(fr_from_be_dev(s, st, d_bytes + PK_HEAD + (size_t)k * (4 + 32 * n) + 4, n, *dst[k], d_status));
+    }
+    {
+        Fr* tmp;
+        ZK_TRY(pk_alloc(P.get(), &tmp, (3 * n * 4 + 31) / 32 + 1));
+        P->perm = (uint32_t*)tmp;
+        ZK_LAUNCH(s, st, "plonk_perm_from_be", k_perm_from_be, dim3(grid_of(3 * n)), dim3(256), 0, (const uint32_t*)(d_bytes + PK_HEAD + 9 * (4 + 32 * n)), 3 * n, P->perm, d_status);
+    }
+    // the verifying key's eight digests: compressed G1 at bytes 112 .. 368
+    Affine<Fp>* d_vk = (Affine<Fp>*)s->alloc(8 * 64 + 16);
+    ZK_TRY(g1_decompress_dev(s, st, d_bytes + 112, 8, d_vk, d_status));
+    Affine<HFp> vkp[8];
+    int h_status = 0;
+    ZK_HIP(hipMemcpyAsync(vkp, d_vk, sizeof vkp, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(&h_status, d_status, 4, hipMemcpyDeviceToHost, st));
+    ZK_TRY(slot_sync(s, st));
+    if (h_status & 1) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
+    if (h_status & 2) return set_err(ZK_ERR_ARG, "proving key: invalid fr.Element encoding (value >= r)");
+    if (h_status & 4) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G1 point in the verifying key");
+    if (h_status & 8) return set_err(ZK_ERR_ARG, "proving key: Permutation entry out of range");
+    memcpy(P->vk_s, vkp, 3 * 64);
+    P->vk_ql = vkp[3]; P->vk_qr = vkp[4]; P->vk_qm = vkp[5]; P->vk_qo = vkp[6]; P->vk_qk = vkp[7];
+    uint32_t** wid[3] = {&P->xa, &P->xb, &P->xc};
+    const uint32_t* wsrc[3] = {xa, xb, xc};
+    for (int i = 0; i < 3; i++) {
+        Fr* tmp;
+        ZK_TRY(pk_alloc(P.get(), &tmp, (n_constraints * 4 + 31) / 32 + 1));
+        *wid[i] = (uint32_t*)tmp;
+        if (n_constraints) ZK_HIP(hipMemcpyAsync(*wid[i], wsrc[i], n_constraints * 4, hipMemcpyHostToDevice, st));
+    }
+    ZK_TRY(make_sigma(P.get(), s, st, P->perm));
+    ZK_TRY(finish_pk(P.get(), s, st));
+    return register_pk(P.release(), handle);
+}
+
+int zk_bn254_plonk_pk_write(uint64_t handle, int as_hex, void* out, size_t cap, size_t* out_len) {
+    if (!out || !out_len) return set_err(ZK_ERR_ARG, "null pointer");
+    PlonkPK* P;
+    std::shared_ptr<std::mutex> mu;
+    {
+        std::lock_guard<std::mutex> lk(g_ppk_mu);
+        auto it = g_ppks.find(handle);
+        if (it == g_ppks.end()) return set_err(ZK_ERR_HANDLE, "unknown PLONK proving-key handle %llu", (unsigned long long)handle);
+        P = it->second;
+        mu = P->mu;
+    }
+    std::lock_guard<std::mutex> key_lock(*mu);
+    const size_t n = P->n, nbytes = PK_HEAD + 9 * (4 + 32 * n) + 24 * n, need = as_hex ? 2 * nbytes : nbytes;
+    *out_len = need;
+    if (cap < need) return set_err(ZK_ERR_ARG, "output holds %zu bytes, %zu needed", cap, need);
+    uint8_t head[PK_HEAD];
+    memset(head, 0, sizeof head);
+    auto put64 = [](uint8_t* p, uint64_t v) { for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (56 - 8 * i)); };
+    put64(head, n);
+    fr_to_be(P->card_inv, head + 8);
+    fr_to_be(P->gen, head + 40);
+    put64(head + 72, P->n_public);
+    fr_to_be(P->u, head + 80);
+    const Affine<HFp>* vkp[8] = {&P->vk_s[0], &P->vk_s[1], &P->vk_s[2], &P->vk_ql, &P->vk_qr, &P->vk_qm, &P->vk_qo, &P->vk_qk};
+    for (int k = 0; k < 8; k++) g1_compress(*vkp[k], head + 112 + 32 * k);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    Slot* s = g.s;
+    hipStream_t st = s->stream;
+    Domain *d0, *d1;
+    ZK_TRY(get_domain(s, st, P->logn, 0, &d0));
+    ZK_TRY(get_domain(s, st, P->logN4, 0, &d1));
+    Domain* dd[2] = {d0, d1};
+    for (int k = 0; k < 2; k++) {
+        uint8_t* o = head + 368 + 168 * k;
+        put64(o, (uint64_t)1 << dd[k]->logn);
+        fr_to_be(dd[k]->card_inv, o + 8);
+        fr_to_be(dd[k]->gen, o + 40);
+        fr_to_be(dd[k]->gen_inv, o + 72);
+        fr_to_be(dd[k]->coset, o + 104);
+        fr_to_be(dd[k]->coset_inv, o + 136);
+    }
+    ZK_TRY(s->reserve(3 * nbytes + 65536));
+    uint8_t* d_bytes = (uint8_t*)s->alloc(nbytes + 16);
+    ZK_HIP(hipMemcpyAsync(d_bytes, head, PK_HEAD, hipMemcpyHostToDevice, st));
+    const Fr* src[9] = {P->ql, P->qr, P->qm, P->qo, P->cqk, P->lqk, P->s1, P->s2, P->s3};
+    uint8_t pre[4] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n};
+    for (int k = 0; k < 9; k++) {
+        uint8_t* o = d_bytes + PK_HEAD + (size_t)k * (4 + 32 * n);
+        ZK_HIP(hipMemcpyAsync(o, pre, 4, hipMemcpyHostToDevice, st));
+        ZK_TRY(fr_to_be_dev(s, st, src[k], n, o + 4));
+    }
+    ZK_HIP(hipStreamSynchronize(st));  // `pre` and `head` live on this stack frame
+    ZK_LAUNCH(s, st, "plonk_perm_to_be", k_perm_to_be, dim3(grid_of(3 * n)), dim3(256), 0, (const uint32_t*)P->perm, 3 * n, (uint32_t*)(d_bytes + PK_HEAD + 9 * (4 + 32 * n)));
+    if (as_hex) {
+        void* d_text = s->alloc(2 * nbytes + 16);
+        ZK_TRY(hex_encode_dev(s, st, d_bytes, nbytes, d_text));
+        ZK_HIP(hipMemcpyAsync(out, d_text, 2 * nbytes, hipMemcpyDeviceToHost, st));
+    } else {
+        ZK_HIP(hipMemcpyAsync(out, d_bytes, nbytes, hipMemcpyDeviceToHost, st));
+    }
+    return slot_sync(s, st);
 }
 
 int zk_bn254_plonk_pk_free(uint64_t handle) {

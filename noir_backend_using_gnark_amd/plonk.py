@@ -42,6 +42,14 @@ class ProvingKey:
         check(lib().zk_bn254_plonk_pk_export(self.handle, C.c_int(which), vp(out), C.c_size_t(n)))
         return out
 
+    def write(self, as_hex: bool = False) -> bytes:
+        """plonk.ProvingKey.WriteTo (as_hex: the text SerializeProvingKey hands to Rust, internal/backend/helpers.go:82-87)"""
+        n = C.c_size_t(0)
+        lib().zk_bn254_plonk_pk_write(self.handle, C.c_int(int(as_hex)), C.create_string_buffer(1), C.c_size_t(0), C.byref(n))  # size query
+        buf = C.create_string_buffer(n.value)
+        check(lib().zk_bn254_plonk_pk_write(self.handle, C.c_int(int(as_hex)), buf, C.c_size_t(n.value), C.byref(n)))
+        return buf.raw[:n.value]
+
     def free(self):
         if self.handle.value:
             check(lib().zk_bn254_plonk_pk_free(self.handle))
@@ -77,6 +85,20 @@ def load_proving_key(log_n: int, n_public: int, n_vars: int, polys: dict, permut
     h = C.c_uint64(0)
     check(lib().zk_bn254_plonk_pk_load(C.byref(k), srs.handle, C.byref(h)))
     return ProvingKey(h.value, srs, vk, n_vars)
+
+
+def read_proving_key(data, n_vars: int, xa, xb, xc, srs, is_hex: bool = False) -> ProvingKey:
+    """plonk.ProvingKey.ReadFrom on gnark's bytes (or the hex text DeserializeProvingKey receives, helpers.go:49-60); the wire ids are the
+    rebuilt spr's (plonk.go:54).  The vectors are decoded on the device straight into the resident key."""
+    raw = data.encode("ascii") if isinstance(data, str) else bytes(data)
+    w = [np.ascontiguousarray(v, dtype=np.uint32) for v in (xa, xb, xc)]
+    h = C.c_uint64(0)
+    rc = lib().zk_bn254_plonk_pk_read(C.c_char_p(raw), C.c_size_t(len(raw)), C.c_int(int(is_hex)), C.c_size_t(n_vars), C.c_size_t(int(w[0].shape[0])),
+                                      w[0].ctypes.data_as(C.c_void_p), w[1].ctypes.data_as(C.c_void_p), w[2].ctypes.data_as(C.c_void_p), srs.handle, C.byref(h))
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    return ProvingKey(h.value, srs, None, n_vars)
 
 
 def prove(pk: ProvingKey, solution, blinders, challenges=None) -> bytes:

@@ -499,3 +499,162 @@ def plonk_verify(vk, proof, public_inputs, challenges=None) -> bool:
         fe = (fe + v * acc) % R
         acc = acc * kg % R
     return _kzg_check(fd, proof["batch_h"], fe, zeta, vk["srs_g2"]) and _kzg_check(proof["z"], proof["z_open_h"], zu, zeta * vk["generator"] % R, vk["srs_g2"])
+
+
+# ------------------------------------------------------------------------------------------------ wire formats
+# What the reference moves between Rust and Go as hex strings / keeps in srs.hex  [REF gnark_backend_ffi/internal/backend/helpers.go:49-94
+# (Serialize/DeserializeProvingKey, ...VerifyingKey, ...Proof), backend/common.go:86-125 (LoadSRS / SaveSRS)]: the bytes of gnark's
+# WriteTo methods.  [UPSTREAM-RECALL] gnark-crypto v0.9.1 ecc/bn254/marshal.go Encoder: integers big-endian, fr / fp elements 32 B big-endian
+# canonical, points COMPRESSED (G1 32 B, G2 64 B), slices of elements / points prefixed with a u32 big-endian length; []int64 goes through
+# encoding/binary (raw big-endian words, NO length prefix).
+def g1_decompress(b: bytes):
+    """inverse of G1Affine.Bytes(): mask 0b10 / 0b11 = compressed with the smallest / largest y, 0b01 = infinity; anything else is an error"""
+    flag = b[0] >> 6
+    if flag == 1:
+        if any(b[1:]) or b[0] & 0x3F:
+            raise ValueError("invalid infinity encoding")
+        return None
+    if flag == 0:
+        raise ValueError("uncompressed point where a compressed one is expected")
+    x = int.from_bytes(bytes([b[0] & 0x3F]) + b[1:32], "big")
+    if x >= ref.Q:
+        raise ValueError("invalid fp.Element encoding")
+    rhs = (x * x * x + 3) % ref.Q
+    y = pow(rhs, (ref.Q + 1) // 4, ref.Q)
+    if y * y % ref.Q != rhs:
+        raise ValueError("invalid compressed coordinate: square root doesn't exist")
+    if (y > (ref.Q - 1) // 2) != (flag == 3):
+        y = ref.Q - y
+    return (x, y)
+
+
+def _f2_pow(a, e):
+    r = ref.F2_ONE
+    while e:
+        if e & 1:
+            r = ref.f2_mul(r, a)
+        a = ref.f2_sqr(a)
+        e >>= 1
+    return r
+
+
+def f2_sqrt(a):
+    """square root in Fp2 = Fp[u]/(u^2+1), q = 3 mod 4 (Adj & Rodriguez-Henriquez, Alg. 9); None if a is not a square"""
+    q = ref.Q
+    if a == ref.F2_ZERO:
+        return ref.F2_ZERO
+    a1 = _f2_pow(a, (q - 3) // 4)
+    alpha = ref.f2_mul(a1, ref.f2_mul(a1, a))
+    a0 = ref.f2_mul((alpha[0], (-alpha[1]) % q), alpha)  # alpha^q * alpha (Frobenius = conjugation)
+    if a0 == (q - 1, 0):
+        return None
+    x0 = ref.f2_mul(a1, a)
+    if alpha == (q - 1, 0):
+        return ref.f2_mul((0, 1), x0)
+    b = _f2_pow(ref.f2_add(ref.F2_ONE, alpha), (q - 1) // 2)
+    return ref.f2_mul(b, x0)
+
+
+def g2_decompress(b: bytes):
+    """inverse of G2Affine.Bytes(): X.A1 || X.A0 big-endian, flags as G1; "largest" compares Y.A1 first, then Y.A0"""
+    flag = b[0] >> 6
+    if flag == 1:
+        return None
+    if flag == 0:
+        raise ValueError("uncompressed point where a compressed one is expected")
+    x1 = int.from_bytes(bytes([b[0] & 0x3F]) + b[1:32], "big")
+    x0 = int.from_bytes(b[32:64], "big")
+    if x0 >= ref.Q or x1 >= ref.Q:
+        raise ValueError("invalid fp.Element encoding")
+    x = (x0, x1)
+    rhs = ref.f2_add(ref.f2_mul(ref.f2_sqr(x), x), ref.B_G2)
+    y = f2_sqrt(rhs)
+    if y is None:
+        raise ValueError("invalid compressed coordinate: square root doesn't exist")
+    largest = ref._lex_largest_fp(y[1]) if y[1] != 0 else ref._lex_largest_fp(y[0])
+    if largest != (flag == 3):
+        y = ref.f2_neg(y)
+    return (x, y)
+
+
+def kzg_srs_bytes(srs) -> bytes:
+    """kzg.SRS.WriteTo: G2[0] | G2[1] (64 B each) | u32 BE len(G1) | G1 points (32 B each)."""
+    g1 = srs["g1"] if isinstance(srs["g1"], list) else [g1_from_np(p) for p in srs["g1"]]
+    return ref.g2_compress(srs["g2"][0]) + ref.g2_compress(srs["g2"][1]) + len(g1).to_bytes(4, "big") + b"".join(ref.g1_compress(p) for p in g1)
+
+
+def kzg_srs_from_bytes(b: bytes):
+    """kzg.SRS.ReadFrom"""
+    g2 = [g2_decompress(b[0:64]), g2_decompress(b[64:128])]
+    n = int.from_bytes(b[128:132], "big")
+    if len(b) != 132 + 32 * n:
+        raise ValueError("SRS: %d bytes, the count says %d points" % (len(b), n))
+    return dict(g1=[g1_decompress(b[132 + 32 * i:164 + 32 * i]) for i in range(n)], g2=g2)
+
+
+def _fr_vec_bytes(v) -> bytes:
+    return len(v).to_bytes(4, "big") + b"".join(fr_bytes(x) for x in v)
+
+
+def _domain_bytes(d: Domain) -> bytes:
+    """fft.Domain.WriteTo: Cardinality u64 | CardinalityInv | Generator | GeneratorInv | FrMultiplicativeGen | FrMultiplicativeGenInv"""
+    return d.n.to_bytes(8, "big") + b"".join(fr_bytes(x) for x in (d.card_inv, d.gen, d.gen_inv, d.coset, d.coset_inv))
+
+
+def plonk_vk_bytes(vk) -> bytes:
+    """plonk.VerifyingKey.WriteTo: Size u64 | SizeInv | Generator | NbPublicVariables u64 | CosetShift | S[0..2] | Ql Qr Qm Qo Qk (compressed)"""
+    out = vk["size"].to_bytes(8, "big") + fr_bytes(vk["size_inv"]) + fr_bytes(vk["generator"]) + vk["n_public"].to_bytes(8, "big") + fr_bytes(vk["coset_shift"])
+    return out + b"".join(ref.g1_compress(p) for p in (*vk["s"], vk["ql"], vk["qr"], vk["qm"], vk["qo"], vk["qk"]))
+
+
+def plonk_pk_bytes(pk) -> bytes:
+    """plonk.ProvingKey.WriteTo: the verifying key, Domain[0], Domain[1], then Ql, Qr, Qm, Qo, CQk, LQk, S1, S2, S3 as length-prefixed
+    []fr.Element and Permutation as 3n raw big-endian int64."""
+    out = plonk_vk_bytes(pk["vk"]) + _domain_bytes(pk["d0"]) + _domain_bytes(pk["d1"])
+    for k in ("ql", "qr", "qm", "qo", "cqk", "lqk", "s1", "s2", "s3"):
+        out += _fr_vec_bytes(pk[k])
+    return out + b"".join(int(p).to_bytes(8, "big", signed=True) for p in pk["perm"])
+
+
+def plonk_pk_from_bytes(b: bytes):
+    """plonk.ProvingKey.ReadFrom (the spr and the SRS are attached by the caller, as the reference does: plonk.go:53-63)"""
+    o = 0
+
+    def u64():
+        nonlocal o
+        o += 8
+        return int.from_bytes(b[o - 8:o], "big")
+
+    def fr():
+        nonlocal o
+        o += 32
+        v = int.from_bytes(b[o - 32:o], "big")
+        if v >= R:
+            raise ValueError("invalid fr.Element encoding")
+        return v
+
+    def g1():
+        nonlocal o
+        o += 32
+        return g1_decompress(b[o - 32:o])
+
+    vk = dict(size=u64(), size_inv=fr(), generator=fr(), n_public=u64(), coset_shift=fr())
+    vk["s"] = [g1(), g1(), g1()]
+    for k in ("ql", "qr", "qm", "qo", "qk"):
+        vk[k] = g1()
+    doms = []
+    for _ in range(2):
+        card = u64()
+        doms.append((card, [fr() for _ in range(5)]))
+    n = doms[0][0]
+    pk = dict(vk=vk, n=n, d0=Domain(doms[0][0]), d1=Domain(doms[1][0]))
+    for k in ("ql", "qr", "qm", "qo", "cqk", "lqk", "s1", "s2", "s3"):
+        cnt = int.from_bytes(b[o:o + 4], "big")
+        o += 4
+        if cnt != n:
+            raise ValueError("proving key: vector of %d elements, domain of %d" % (cnt, n))
+        pk[k] = [fr() for _ in range(cnt)]
+    if len(b) - o != 3 * n * 8:
+        raise ValueError("proving key: %d bytes left for the permutation, %d expected" % (len(b) - o, 3 * n * 8))
+    pk["perm"] = [int.from_bytes(b[o + 8 * i:o + 8 * i + 8], "big", signed=True) for i in range(3 * n)]
+    return pk

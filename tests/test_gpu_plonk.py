@@ -187,3 +187,97 @@ def ref_g1_decompress(b: bytes):
     if (y > (ref.Q - 1) // 2) != (flag == 3):
         y = ref.Q - y
     return (x, y)
+
+
+# ------------------------------------------------------------------------------------------------ wire formats
+def test_kzg_srs_wire_format_roundtrip_and_errors():
+    """kzg.SRS.WriteTo bytes (oracle encoder) -> zk_bn254_kzg_srs_read (G1 decompressed on the device) -> commits equal the oracle's, the G2
+    points equal, WriteTo gives the bytes back; hex text both ways; every malformed input is an error."""
+    from noir_backend_using_gnark_amd import kzg
+    n = 300
+    srs_o = pl.kzg_new_srs(n, 0xFEEDFACE12345, fast=True)
+    g1 = [pl.g1_from_np(p) for p in srs_o["g1"]]
+    g1[7] = None                                        # a point at infinity inside the slice (flag 0b01)
+    wire = pl.kzg_srs_bytes(dict(g1=g1, g2=srs_o["g2"]))
+    assert len(wire) == 132 + 32 * n
+    for data, is_hex in ((wire, False), (wire.hex(), True), (wire.hex().upper(), True)):
+        srs = kzg.read_srs(data, is_hex=is_hex)
+        assert srs.g1.n == n
+        assert srs.g2[0].tobytes() == ref.g2_affine_mont_bytes(srs_o["g2"][0]) and srs.g2[1].tobytes() == ref.g2_affine_mont_bytes(srs_o["g2"][1])
+        sc = ref.rand_felts(5, n)
+        want = ref.g1_affine_mont_bytes(pl._Backend(True).msm_g1(np.stack([pl.g1_to_np(p) for p in g1]), sc))
+        assert srs.commit(M(sc)).tobytes() == want
+        assert srs.write() == wire and srs.write(as_hex=True) == wire.hex().encode()
+        srs.free()
+    # a device-generated SRS serialises to the oracle's bytes
+    alpha = 0xABCDEF
+    dev = kzg.new_srs(64, M([alpha])[0])
+    assert dev.write() == pl.kzg_srs_bytes(pl.kzg_new_srs(64, alpha, fast=True))
+    dev.free()
+
+    def bad(mutate, hexed=False):
+        b = bytearray(wire)
+        mutate(b)
+        with pytest.raises(ValueError):
+            kzg.read_srs(bytes(b).hex() if hexed else bytes(b), is_hex=hexed)
+
+    bad(lambda b: b.__setitem__(131, b[131] ^ 1))                     # count does not match the length
+    bad(lambda b: b.__setitem__(132, b[132] & 0x3F))                  # flag 0b00: an uncompressed encoding in a compressed slice
+    bad(lambda b: b.__setitem__(slice(132 + 32, 132 + 64), bytes([0xBF]) + b"\xff" * 31))   # x >= q
+    bad(lambda b: b.__setitem__(132 + 32 * 7 + 5, 1))                 # infinity flag with a non-zero body
+    bad(lambda b: b.__setitem__(0, b[0] ^ 0x01))                      # G2[0]: another x (no point / not in the subgroup)
+    x = 4                                                             # x^3 + 3 = 67: find an x that is not on the curve
+    while pow((x ** 3 + 3) % ref.Q, (ref.Q - 1) // 2, ref.Q) == 1: x += 1
+    bad(lambda b: b.__setitem__(slice(132, 164), (x | (2 << 254)).to_bytes(32, "big")))
+    with pytest.raises(ValueError):
+        kzg.read_srs(wire[:-1])
+    with pytest.raises(ValueError):
+        kzg.read_srs(wire.hex()[:-2] + "zz", is_hex=True)
+    with pytest.raises(ValueError):
+        kzg.read_srs(wire.hex()[:-4] + "\x10\x11\x12\x13", is_hex=True)   # control bytes whose low nibbles would decode
+
+
+@pytest.mark.parametrize("nc,nvars,npub", [(4, 6, 1), (500, 120, 3)])
+def test_plonk_proving_key_wire_format(nc, nvars, npub):
+    """plonk.ProvingKey.WriteTo bytes: the device-built key serialises to the oracle's bytes; the oracle's bytes (and their hex text) load into a
+    key that proves the oracle's proof; malformed keys are errors."""
+    from noir_backend_using_gnark_amd import kzg
+    spr, sol = _random_circuit(31 + nc, nvars, nc, npub)
+    n = 1
+    while n < nc + npub: n <<= 1
+    alpha = 0x5EED0001
+    srs_o = pl.kzg_new_srs(n + 3, alpha, fast=True)
+    opk, ovk = pl.plonk_setup(spr, srs_o, fast=True)
+    wire = pl.plonk_pk_bytes(opk)
+    assert len(wire) == 704 + 9 * (4 + 32 * n) + 24 * n
+    srs = kzg.new_srs(n + 3, M([alpha])[0])
+    pk = zp.setup(_circuit(spr), srs)
+    assert pk.write() == wire
+    assert pk.write(as_hex=True) == wire.hex().encode()
+    g = spr.constraints
+    wid = ([c[5] for c in g], [c[6] for c in g], [c[7] for c in g])
+    bl = ref.rand_felts(3, 9)
+    want = pl.plonk_proof_bytes(pl.plonk_prove(opk, sol, bl, fast=True))
+    for data, is_hex in ((wire, False), (wire.hex(), True)):
+        pk2 = zp.read_proving_key(data, spr.n_vars, *wid, srs, is_hex=is_hex)
+        assert zp.prove(pk2, M(sol), M(bl)) == want
+        assert pk2.write() == wire
+        pk2.free()
+
+    def bad(mutate):
+        b = bytearray(wire)
+        mutate(b)
+        with pytest.raises(ValueError):
+            zp.read_proving_key(bytes(b), spr.n_vars, *wid, srs)
+
+    bad(lambda b: b.__setitem__(7, b[7] ^ 1))                                        # Size
+    bad(lambda b: b.__setitem__(704 + 3, b[704 + 3] ^ 1))                            # length prefix of Ql
+    bad(lambda b: b.__setitem__(slice(708, 740), ref.R.to_bytes(32, "big")))         # Ql[0] = r: not canonical
+    bad(lambda b: b.__setitem__(112, b[112] & 0x3F))                                 # vk.S[0] with flag 0b00
+    bad(lambda b: b.__setitem__(len(b) - 8, 1))                                      # Permutation entry >= 3n (high word set)
+    with pytest.raises(ValueError):
+        zp.read_proving_key(wire[:-8], spr.n_vars, *wid, srs)
+    with pytest.raises(ValueError):
+        zp.read_proving_key(wire, spr.n_vars - 1, [nvars - 1] * len(g), wid[1], wid[2], srs)   # a wire id outside the variables
+    pk.free()
+    srs.free()
