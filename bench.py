@@ -47,7 +47,9 @@ class Instance:
     """One synthetic proving instance: valid curve points P_i = k_i * G as the key, a, b uniform, c = a*b on the
     evaluation domain (h is a true quotient), w uniform or witness-like.  With world > 1 this is the rank's slice starting at `lo`."""
 
-    def __init__(self, L, lib, zk, log_n, lo, n_public, witness, tables, shard_full_z=False, full_inputs=True, torch=None):
+    def __init__(self, L, lib, zk, log_n, lo, n_public, witness, tables, shard_full_z=False, full_inputs=True, torch=None, window_shard=None,
+                 abc_block=None):
+        """window_shard=(rank, world): the whole key on every rank with this rank's table rows; abc_block=(lo, n): this rank's block of a, b, c."""
         self.L, self.lib, self.log_n, self.n_public = L, lib, log_n, n_public
         N = self.N = 1 << log_n
         dev = lib.DeviceBuffer
@@ -77,14 +79,15 @@ class Instance:
             lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(self.d_c.ptr), C.c_void_p(self.d_a.ptr), C.c_void_p(self.d_b.ptr), C.c_size_t(N), None))
         else:
             # this rank's blocks of a, b, c live in torch tensors (RCCL moves them)
-            self.t_abc = [torch.empty((N, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+            blo, bn = abc_block if abc_block else (lo, N)
+            self.t_abc = [torch.empty((bn, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
             for t, sd in zip(self.t_abc[:2], (0xA, 0xB)):
-                lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(t.data_ptr()), C.c_size_t(N), C.c_uint64(seed_at(sd, 4, lo)), C.c_int(1), C.c_int(0), None))
+                lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(t.data_ptr()), C.c_size_t(bn), C.c_uint64(seed_at(sd, 4, blo)), C.c_int(1), C.c_int(0), None))
             lib.check(L.zk_bn254_fr_mul_dev(C.c_void_p(self.t_abc[2].data_ptr()), C.c_void_p(self.t_abc[0].data_ptr()), C.c_void_p(self.t_abc[1].data_ptr()),
-                                            C.c_size_t(N), None))
+                                            C.c_size_t(bn), None))
         self.pk = zk.ProvingKey(log_n, N, n_public, self.small["alpha"], self.small["beta"], self.small["delta"], self.g1_a, self.g1_b,
                                 self.g1_k.ptr + n_public * 64, self.g1_z, self.small2["beta"], self.small2["delta"], self.g2_b,
-                                bases_on_device=True, precompute_tables=tables, shard_full_z=shard_full_z)
+                                bases_on_device=True, precompute_tables=tables, shard_full_z=shard_full_z, window_shard=window_shard)
         lib.check(L.zk_dev_sync())
 
     def g1_units(self):
@@ -217,6 +220,8 @@ def main():
     ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tables", action="store_true", help="disable the precomputed window tables of the resident proving key")
+    ap.add_argument("--shard", choices=["range", "windows"], default="range", help="multi-GPU decomposition of the MSMs: by point range (default: no scalar "
+                    "exchange) or by digit window / table row (north_star wording: whole key on every rank, h all-gathered)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU decomposition (sharded computeH phases + msm5_pk + all-gather + finalize) even at N=1")
     ap.add_argument("--no-2p24", action="store_true", help="skip the second measured block (2^24 constraints on this GPU)")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the host-input (PCIe-inclusive) measurement")
@@ -250,8 +255,12 @@ def main():
     np_loc = N_PUBLIC if rank == 0 else 0  # public wires live in rank 0's slice; gnark's pk.G1.K starts at the first private wire
 
     t_setup = time.time()
-    inst = Instance(L, _lib, zk, log_n, lo, np_loc if sharded else N_PUBLIC, witness, not args.no_tables,
-                    shard_full_z=(sharded and rank != world - 1), full_inputs=not sharded, torch=torch)
+    win = sharded and args.shard == "windows"
+    if win:  # every rank: the whole key (its own table rows), the whole w, its block of a, b, c
+        inst = Instance(L, _lib, zk, log_ng, 0, N_PUBLIC, witness, True, full_inputs=False, torch=torch, window_shard=(rank, world), abc_block=(lo, N_loc))
+    else:
+        inst = Instance(L, _lib, zk, log_n, lo, np_loc if sharded else N_PUBLIC, witness, not args.no_tables,
+                        shard_full_z=(sharded and rank != world - 1), full_inputs=not sharded, torch=torch)
     pk, d_w, r, s = inst.pk, inst.d_w, inst.r, inst.s
     fallback_stream = torch.cuda.Stream(priority=-1) if sharded else None
     torch.cuda.synchronize()
@@ -270,6 +279,8 @@ def main():
                 # the prover consumes its working buffers: at N > 1 the first all-to-all already writes fresh ones, at N = 1 copy
                 a, b, c = (t.clone() for t in inst.t_abc) if world == 1 else inst.t_abc
                 h = par.compute_h_sharded(a, b, c, log_ng, rank, world)
+                if win:
+                    h = par.all_gather_blocks(h)  # the coefficient exchange of the window mode: every rank needs the whole h
                 live, sess = sess, None  # _end releases the session whatever it returns
                 rec = par.groth16_msm5_pk_end(live, h.data_ptr(), side.cuda_stream)
                 return par.groth16_finalize(pk, par.all_gather_limbs(rec), r, s)
@@ -335,7 +346,7 @@ def main():
     valu = None
     if name.startswith("msm_accumulate"):
         wb, dg = C.c_uint32(0), C.c_uint32(0)
-        _lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(N_loc), C.c_int(1 if pk.info()["tables"] else 0), C.byref(wb), C.byref(dg)))
+        _lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(N_g if win else N_loc), C.c_int(1 if pk.info()["tables"] else 0), C.byref(wb), C.byref(dg)))
         digits = int(dg.value)
         madds = units_per_launch * digits
         peak = 17.4e9 if name.endswith("g1") else 17.4e9 / 2.1
@@ -370,6 +381,8 @@ def main():
         "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_ng, "baseline_config": bcfg, "constraints": N_g, "wires": N_g,
                    "n_public": N_PUBLIC, "scalars": args.scalars, "per_gpu_constraints": N_loc, "window_tables": bool(pk.info()["tables"]),
                    "parallelism": "single GPU" if not sharded else
+                   ("one proof window-sharded x%d: block-sharded computeH (all-to-all transposes), all-gather of h, MSMs over all wires on this rank's table rows "
+                    "(all-gather of partial sums)" % world) if win else
                    "one proof range-sharded x%d: block-sharded computeH (all-to-all transposes) + MSMs on rank-local key slices (all-gather of partial sums)" % world},
         "roofline": roofline, "proof_sha": hashlib.sha256(proof).hexdigest()[:16], "setup_s": round(t_setup, 2),
     }

@@ -149,11 +149,17 @@ typedef struct {
     int bases_on_device; /* 1: g1_a, g1_b, g1_k, g1_z, g2_b are DEVICE pointers that stay owned by the caller */
     int flags;           /* bit 0: do NOT build the precomputed window tables 2^(c*w)*P_i (they cost ~13x the bases in HBM and
                             are what makes the resident-key MSMs ~20% cheaper; skipped automatically when HBM is short)
-                            bit 1: all 2^log_domain entries of Z are used (a non-final slice of a range-sharded key) */
+                            bit 1: all 2^log_domain entries of Z are used (a non-final slice of a range-sharded key)
+                            bit 2: WINDOW-sharded key (BASELINE north_star / configs[2] wording): the key holds ALL wires, but its window
+                                   tables only the rows w = shard_rank + k * shard_count of the ceil(255/c) digit windows -- 1/shard_count
+                                   of the table memory; zk_bn254_groth16_msm5_pk then returns the partial sums over those windows of
+                                   the FULL wire / h vectors, and the records of all ranks finalize as in the range-sharded mode.
+                                   Needs the tables (an error when they do not fit). */
     const uint8_t *infinity_a, *infinity_b; /* gnark's InfinityA / InfinityB ([]bool, HOST pointers, n_wires bytes) or NULL */
     size_t nb_infinity_a, nb_infinity_b;    /* gnark's NbInfinityA / NbInfinityB; must equal the number of non-zero bytes */
     int table_window_bits;                  /* 0: planner's choice; else the window width c in [8, 22] of the tables */
     int reserved;
+    uint32_t shard_rank, shard_count;       /* flags bit 2: this rank and the number of ranks (window sharding) */
 } zk_groth16_pk;
 int zk_bn254_groth16_pk_load(const zk_groth16_pk *pk, uint64_t *handle);
 int zk_bn254_groth16_pk_free(uint64_t handle);   /* ZK_ERR_HANDLE while an msm5 session still uses the key */

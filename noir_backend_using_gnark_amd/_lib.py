@@ -27,7 +27,7 @@ class Groth16PK(C.Structure):
                 ("g1_a", C.c_void_p), ("g1_b", C.c_void_p), ("g1_k", C.c_void_p), ("g1_z", C.c_void_p),
                 ("g2_beta", C.c_void_p), ("g2_delta", C.c_void_p), ("g2_b", C.c_void_p), ("bases_on_device", C.c_int), ("flags", C.c_int),
                 ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p), ("nb_infinity_a", C.c_size_t), ("nb_infinity_b", C.c_size_t),
-                ("table_window_bits", C.c_int), ("reserved", C.c_int)]
+                ("table_window_bits", C.c_int), ("reserved", C.c_int), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
 class PlonkCircuit(C.Structure):

@@ -121,6 +121,9 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     if (pk->table_window_bits && (pk->table_window_bits < 8 || pk->table_window_bits > 22))
         return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", pk->table_window_bits);
     const bool compact = pk->infinity_a != nullptr;
+    const bool win_shard = (pk->flags & 4) != 0;
+    if (win_shard && (pk->shard_count < 1 || pk->shard_count > 64 || pk->shard_rank >= pk->shard_count)) return set_err(ZK_ERR_ARG, "bad window-shard rank / count");
+    if (win_shard && (pk->flags & 3)) return set_err(ZK_ERR_ARG, "a window-sharded key holds the whole key and needs its tables (flags bits 0 and 1 do not apply)");
     if (compact && (pk->nb_infinity_a > pk->n_wires || pk->nb_infinity_b > pk->n_wires)) return set_err(ZK_ERR_ARG, "NbInfinity exceeds the wire count");
     std::vector<uint32_t> map_a, map_b;
     if (compact) {  // validated before anything is allocated or read
@@ -201,11 +204,15 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         P.tab_w.stride = pk->n_wires;
         P.tab_h.c = pk->table_window_bits ? (unsigned)pk->table_window_bits : msm_pick_window_table(P.nz);
         P.tab_h.stride = N;
+        if (win_shard) {
+            P.tab_w.row_first = P.tab_h.row_first = pk->shard_rank;
+            P.tab_w.row_step = P.tab_h.row_step = pk->shard_count;
+        }
         P.tab_w.l1_m = 16;  // A, B1, K, G2.B: their reduction tails hide under the next accumulate -- less work beats lower latency
         P.tab_w.l2_m = getenv("ZKMI_L2_M") ? (unsigned)atoi(getenv("ZKMI_L2_M")) : 8;  // measured: 8 -> -0.09 ms, 16 -> +0.15 ms, 32 -> +0.9 ms (the level gets too long to hide)
         P.tab_h.l1_m = getenv("ZKMI_L1H_M") ? (unsigned)atoi(getenv("ZKMI_L1H_M")) : 8;   // Z finishes last: its tail is exposed
         P.tab_h.l2_m = getenv("ZKMI_L2H_M") ? (unsigned)atoi(getenv("ZKMI_L2H_M")) : 0;
-        const size_t Ww = (255 + P.tab_w.c - 1) / P.tab_w.c, Wh = (255 + P.tab_h.c - 1) / P.tab_h.c;
+        const size_t Ww = P.tab_w.rows() ? P.tab_w.rows() : 1, Wh = P.tab_h.rows() ? P.tab_h.rows() : 1;  // rows held here (all of them unless window-sharded)
         const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
         size_t free_b = 0, total_b = 0;
         ZK_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -223,15 +230,17 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
                 {&P.t_b2, P.d_b2, pk->n_wires, pk->n_wires, 0, 128, P.tab_w.c, Ww, 1}};
             for (auto& j : jobs) {
                 ZK_TRY(mem.dev_alloc(j.t, j.Wd * j.stride * j.esz));
-                ZK_TRY(j.g2 ? msm_build_table_g2(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t)
-                            : msm_build_table_g1(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t));
+                const MsmTable& tb = (&j == &jobs[3]) ? P.tab_h : P.tab_w;
+                ZK_TRY(j.g2 ? msm_build_table_g2(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t, tb.row_first, tb.row_step)
+                            : msm_build_table_g1(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t, tb.row_first, tb.row_step));
             }
             ZK_TRY(slot_sync(g.s, st));
             P.tables = true;
-        } else if (pk->table_window_bits) {
-            return set_err(ZK_ERR_HIP, "window tables of %zu bytes (c = %d) do not fit (free HBM %zu)", bytes, pk->table_window_bits, free_b);
+        } else if (pk->table_window_bits || win_shard) {
+            return set_err(ZK_ERR_HIP, "window tables of %zu bytes (c = %u) do not fit (free HBM %zu)", bytes, P.tab_w.c, free_b);
         }
     }
+    if (win_shard && !P.tables) return set_err(ZK_ERR_ARG, "a window-sharded key needs its window tables");
     std::lock_guard<std::mutex> lk(g_pk_mu);
     *handle = g_next_pk++;
     g_pks[*handle] = P;

@@ -76,8 +76,10 @@ __device__ __forceinline__ T shfl_xor_t(const T& v, unsigned d) {
 // gnark-crypto partitionScalars: digit = bits [w*c, (w+1)*c) + carry; if digit > 2^(c-1): digit -= 2^c, carry = 1.
 // Table mode (table_stride != 0; resident bases with precomputed 2^(c*w) * P_i): every window shares ONE bucket set, so the
 // key is the digit magnitude alone and the value indexes the table entry (w, i).
+// Window-sharded tables (row_step > 1): every window is still recoded (the carry runs through all of them) but only the digits of the
+// rows this rank owns -- w = row_first + k * row_step -- are emitted, as row k of the rank's table.
 __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c, unsigned W, uint32_t* keys, uint32_t* vals,
-                             uint32_t table_stride) {
+                             uint32_t table_stride, unsigned row_first, unsigned row_step) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s;
@@ -109,8 +111,11 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
         }
         size_t o = (size_t)w * n + i;
         if (table_stride) {
+            if (w < row_first || (w - row_first) % row_step) continue;
+            const unsigned wl = (w - row_first) / row_step;
+            o = (size_t)wl * n + i;
             keys[o] = mag ? (mag - 1) : sentinel;
-            vals[o] = ((w * table_stride + i) << 1) | neg;
+            vals[o] = ((wl * table_stride + i) << 1) | neg;
         } else {
             keys[o] = mag ? (w * B + (mag - 1)) : sentinel;
             vals[o] = (i << 1) | neg;
@@ -542,12 +547,12 @@ template <class F>
 static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab = nullptr) {
     struct Key {
         size_t n, stride;
-        unsigned c_cfg, c_tab, g2, l1;
-        bool operator<(const Key& o) const { return std::tie(n, stride, c_cfg, c_tab, g2, l1) < std::tie(o.n, o.stride, o.c_cfg, o.c_tab, o.g2, o.l1); }
+        unsigned c_cfg, c_tab, g2, l1, rows;
+        bool operator<(const Key& o) const { return std::tie(n, stride, c_cfg, c_tab, g2, l1, rows) < std::tie(o.n, o.stride, o.c_cfg, o.c_tab, o.g2, o.l1, o.rows); }
     };
     static std::mutex mu;
     static std::map<Key, MsmPlan> memo;
-    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32), tab ? (tab->l1_m | (tab->l2_m << 8)) : 0u};
+    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32), tab ? (tab->l1_m | (tab->l2_m << 8)) : 0u, tab ? (tab->row_first | (tab->row_step << 8)) : 0u};
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = memo.find(k);
@@ -570,12 +575,16 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     P->c = c;
     P->Wd = (255 + c - 1) / c;
     P->W = tab ? 1 : P->Wd;
+    P->row_first = tab ? tab->row_first : 0;
+    P->row_step = tab ? (tab->row_step ? tab->row_step : 1) : 1;
+    P->Wrows = tab ? tab->rows() : P->Wd;
+    if (tab && P->Wrows == 0) { memset(P, 0, sizeof *P); return ZK_OK; }  // this rank owns no window: the MSM is empty
     P->table_stride = tab ? (uint32_t)tab->stride : 0;
     P->B = 1u << (c - 1);
     P->nb = P->W * P->B;
-    P->total = n * P->Wd;
+    P->total = n * P->Wrows;
     if (P->total >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "n * windows = %zu overflows 31-bit positions", P->total);
-    if (tab && (size_t)tab->stride * P->Wd >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "table too large for 31-bit indices");
+    if (tab && (size_t)tab->stride * P->Wrows >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "table too large for 31-bit indices");
     // tasks of at most L points: 2x the mean bucket load of a uniform input, at least 32.  The top window only sees digits up to
     // (r-1) >> (c*(W-1)), so its buckets (window-per-bucket-set mode) / the lowest buckets (table mode: one bucket set) are denser
     // than that: they are simply cut into several tasks and folded by k_fold_multi.  Only when the dense population is mild (<= 4x)
@@ -626,9 +635,9 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
 static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
     out->P = P;
     out->n = n;
-    out->empty = (n == 0);
+    out->empty = (n == 0) || P.total == 0;  // no points, or a window-sharded table of which this rank owns no row
     out->ready = nullptr;
-    if (n == 0) return ZK_OK;
+    if (out->empty) return ZK_OK;
     const unsigned c = P.c, W = P.W, key_bits = P.key_bits;
     const uint32_t nb = P.nb, L = P.L;
     const size_t total = P.total, max_tasks = P.max_tasks;
@@ -656,7 +665,7 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
 
     // ---- 1. digits
     ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
-              (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride);
+              (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step);
     // ---- 2. sort (bucket key -> point index|sign)
     rocprim::double_buffer<uint32_t> kb(keys0, keys1), vb(vals0, vals1);
     {
@@ -909,66 +918,47 @@ int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, si
     return msm_prepare(s, st, P, (const Fr*)d_scalars, n, cfg, out);
 }
 
-// T[w * stride + i] = 2^(c*w) * P_i as affine points, w < Wd; rows are `stride` entries apart, entries [n, stride) of a row
-// are left untouched (the caller zeroes the buffer: (0,0) = infinity).  One-time cost per resident base array.
+// T[k * stride + i] = 2^(c*w_k) * P_i as affine points for the rows w_k = row_first + k * row_step < Wd (all rows: row_first = 0, row_step = 1);
+// rows are `stride` entries apart, entries [n, stride) of a row are left untouched (the caller zeroes the buffer: (0,0) = infinity).
+// One-time cost per resident base array.
 template <class F>
 __global__ __launch_bounds__(256) void k_build_table(const Affine<F>* __restrict__ pts, uint32_t n, uint32_t stride, uint32_t offset, unsigned c,
-                                                     unsigned Wd, Affine<F>* __restrict__ table) {
+                                                     unsigned Wd, unsigned row_first, unsigned row_step, Affine<F>* __restrict__ table) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<F> p = gload(pts + i);
-    gstore(table + offset + i, p);
     XYZZ<F> acc = XYZZ<F>::from_affine(p);
-    for (unsigned w = 1; w < Wd; w++) {
-        for (unsigned k = 0; k < c; k++) acc.dbl();
-        Affine<F> a = acc.to_affine();
-        gstore(table + (size_t)w * stride + offset + i, a);
+    unsigned k = 0;
+    for (unsigned w = 0; w < Wd; w++) {
+        if (w) {
+            for (unsigned b = 0; b < c; b++) acc.dbl();
+        }
+        if (w < row_first || (w - row_first) % row_step) continue;
+        Affine<F> a = w ? acc.to_affine() : p;
+        gstore(table + (size_t)k * stride + offset + i, a);
         acc = XYZZ<F>::from_affine(a);  // keeps zz = zzz = 1: cheaper doublings, bounded growth
+        k++;
     }
 }
 template <class F>
-static int build_table(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table) {
-    unsigned Wd = (255 + c - 1) / c;
-    ZK_HIP(hipMemsetAsync(d_table, 0, (size_t)Wd * stride * sizeof(Affine<F>), st));
-    if (n)
+static int build_table(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table, unsigned row_first,
+                       unsigned row_step) {
+    MsmTable t;
+    t.c = c; t.row_first = row_first; t.row_step = row_step ? row_step : 1;
+    unsigned Wd = (255 + c - 1) / c, rows = t.rows();
+    ZK_HIP(hipMemsetAsync(d_table, 0, (size_t)(rows ? rows : 1) * stride * sizeof(Affine<F>), st));
+    if (n && rows)
         ZK_LAUNCH(s, st, sizeof(F) == 32 ? "msm_build_table_g1" : "msm_build_table_g2", (k_build_table<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                  (const Affine<F>*)d_pts, (uint32_t)n, (uint32_t)stride, (uint32_t)offset, c, Wd, (Affine<F>*)d_table);
+                  (const Affine<F>*)d_pts, (uint32_t)n, (uint32_t)stride, (uint32_t)offset, c, Wd, row_first, t.row_step, (Affine<F>*)d_table);
     return ZK_OK;
 }
-int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table) {
-    return build_table<Fp>(s, st, d_pts, n, stride, offset, c, d_table);
+int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table, unsigned row_first,
+                       unsigned row_step) {
+    return build_table<Fp>(s, st, d_pts, n, stride, offset, c, d_table, row_first, row_step);
 }
-int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table) {
-    return build_table<Fp2>(s, st, d_pts, n, stride, offset, c, d_table);
-}
-
-// gnark keeps pk.G1.A / pk.G1.B / pk.G2.B WITHOUT their points at infinity (InfinityA / InfinityB bitmaps, setup.go); the resident key
-// is wire-indexed, so the compact array is scattered once at load time: out[i] = src_idx[i] == ~0 ? infinity (0,0) : compact[src_idx[i]].
-template <class F>
-__global__ __launch_bounds__(256) void k_expand_bases(const Affine<F>* __restrict__ compact, const uint32_t* __restrict__ src_idx, uint32_t n,
-                                                      Affine<F>* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t j = src_idx[i];
-    Affine<F> p;
-    uint4* d = reinterpret_cast<uint4*>(&p);
-    if (j == 0xffffffffu) {
-#pragma unroll
-        for (unsigned k = 0; k < sizeof(p) / 16; k++) d[k] = make_uint4(0, 0, 0, 0);
-    } else {
-        p = gload(compact + j);
-    }
-    gstore(out + i, p);
-}
-int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, const uint32_t* d_src_idx, size_t n, void* d_out) {
-    if (!n) return ZK_OK;
-    if (is_g2)
-        ZK_LAUNCH(s, st, "pk_expand_bases_g2", (k_expand_bases<Fp2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Affine<Fp2>*)d_compact, d_src_idx,
-                  (uint32_t)n, (Affine<Fp2>*)d_out);
-    else
-        ZK_LAUNCH(s, st, "pk_expand_bases_g1", (k_expand_bases<Fp>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Affine<Fp>*)d_compact, d_src_idx,
-                  (uint32_t)n, (Affine<Fp>*)d_out);
-    return ZK_OK;
+int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table, unsigned row_first,
+                       unsigned row_step) {
+    return build_table<Fp2>(s, st, d_pts, n, stride, offset, c, d_table, row_first, row_step);
 }
 
 int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {

@@ -14,13 +14,22 @@ int msm_g2_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need);
 struct MsmTable {
     unsigned c = 0;
     size_t stride = 0;
+    // window (table-row) sharding across GPUs: this table holds only the rows w = row_first + k * row_step (k = 0, 1, ...) of the ceil(255/c)
+    // digit windows, for ALL points; the MSM over it is the partial sum of those windows (the others belong to other ranks)
+    unsigned row_first = 0, row_step = 1;
+    unsigned rows() const {
+        unsigned Wd = (255 + c - 1) / c;
+        return row_first < Wd ? (Wd - 1 - row_first) / row_step + 1 : 0;
+    }
     unsigned l2_m = 0;  // > 0: a second thread-serial level over l2_m entries (3 additions per entry instead of ~15 in a wave level)
     unsigned l1_m = 0;  // buckets per lane in the first reduction level (0: default 8).  16 does 22 % less tail work at twice the level-1
                         // latency: right for MSMs whose tail hides under the next accumulate, wrong for the last one of a proof
 };
 unsigned msm_pick_window_table(size_t n);
-int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table);
-int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table);
+int msm_build_table_g1(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table, unsigned row_first = 0,
+                       unsigned row_step = 1);
+int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, size_t stride, size_t offset, unsigned c, void* d_table, unsigned row_first = 0,
+                       unsigned row_step = 1);
 
 // out[i] = src_idx[i] == ~0u ? (0,0) : compact[src_idx[i]]  (gnark's InfinityA / InfinityB compaction undone at key load)
 int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, const uint32_t* d_src_idx, size_t n, void* d_out);
@@ -30,6 +39,7 @@ int bases_info(uint64_t handle, size_t* n, int* is_g2);
 
 struct MsmPlan {
     unsigned c, W, Wd, key_bits;   // W bucket sets (windows that are reduced separately); Wd digit windows (== W unless table mode)
+    unsigned Wrows, row_first, row_step;  // table mode: rows of the table this MSM feeds (all Wd unless window-sharded)
     uint32_t table_stride;
     uint32_t B, nb, L, m1, N1, m2 = 0;
     size_t total, max_tasks, sort_tmp_bytes, scan_tmp_bytes, tsort_tmp_bytes, lvl_elems, need, need_prep, need_acc;

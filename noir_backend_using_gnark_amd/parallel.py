@@ -1,4 +1,12 @@
-"""One process per GPU: range-sharding of a proof across the GPUs of a node.
+"""One process per GPU: sharding of one proof across the GPUs of a node -- by POINT RANGE (default) or by digit WINDOW (table rows).
+
+Window mode (BASELINE north_star "MSM window buckets ... shard across the 8 GPUs"): every rank holds the whole key but only the rows
+w = rank + k * world of its window tables (zk_groth16_pk.flags bit 2), computeH stays block-sharded, the blocks of h are all-gathered
+(`all_gather_blocks`), every rank runs the five MSMs over ALL wires restricted to its windows, and the 768-byte records are all-gathered
+and finalized exactly as in range mode.  Same table memory per rank (rows/world x all points = all rows x points/world), but the scalars
+must be whole on every rank (w replicated, h all-gathered: 32 B x N x (world-1)/world per rank over xGMI) and ceil(255/c) windows do not
+divide evenly (13 rows over 8 ranks: 2,2,2,2,2,1,1,1) -- which is why range mode is the default.
+
 
 The path shards by POINT RANGE (SURVEY.md §8e "point-range-sharded"): rank g owns bases / scalars [g*n/G, (g+1)*n/G),
 runs the local Pippenger MSMs, and the only exchange is an all-gather of the un-normalised partial sums (96 limbs =
@@ -41,6 +49,29 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         d.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def window_rows(window_bits: int, rank: int, world: int) -> list[int]:
+    """Window (table-row) sharding: the digit windows w = rank, rank + world, ... of the ceil(255 / c) windows belong to `rank`."""
+    return list(range(rank, (255 + window_bits - 1) // window_bits, world))
+
+
+def all_gather_blocks(x):
+    """All ranks' blocks concatenated in rank order (the `coefficient exchange` of the window-sharded mode: every rank needs the whole h).
+    RCCL all_gather_into_tensor under nccl; gloo gathers host copies."""
+    import torch
+    d = dist()
+    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+        return x
+    world = d.get_world_size()
+    if d.get_backend() == "nccl":
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        d.all_gather_into_tensor(out, x.contiguous())
+        return out
+    xh = x.cpu() if x.is_cuda else x
+    rows = [torch.empty_like(xh) for _ in range(world)]
+    d.all_gather(rows, xh)
+    return torch.cat(rows).to(x.device)
 
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:

@@ -533,6 +533,16 @@ def test_two_process_sharded_proof_equals_single_process():
     assert multi.returncode == 0, multi.stdout[-2000:] + multi.stderr[-2000:]
     out = json.loads([l for l in multi.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["proof_sha"] == sha1
+    # the window-sharded decomposition (whole key on every rank, table rows split, h all-gathered) gives the same bytes
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--log-n", "12", "--shard", "windows"] + common,
+                           capture_output=True, text=True, timeout=900, env=env)
+    assert multi.returncode == 0, multi.stdout[-2000:] + multi.stderr[-2000:]
+    out = json.loads([l for l in multi.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["proof_sha"] == sha1 and "window-sharded" in out["config"]["parallelism"]
 
 
 def test_concurrent_callers_are_safe():
@@ -861,3 +871,64 @@ def test_groth16_2p24_properties():
     # and the table path's sums are the plain path's sums
     assert (zb.g1_sum_partials(np.stack([recs[0][:16], recs[1][:16]])) == zb.g1_sum_partials(rec1[:16])).all()
     pk.free()
+
+
+def _window_scalars(vals, c, rank, world):
+    """gnark's signed c-bit recoding of each scalar, restricted to the windows w = rank, rank + world, ...: s^(rank) = sum_w d_w 2^(c w) mod r.
+    The per-rank scalars add up to the scalar itself -- the partial MSM a window-sharded rank must return is MSM(P, s^(rank))."""
+    Wd = (255 + c - 1) // c
+    half = 1 << (c - 1)
+    out = []
+    for s in vals:
+        carry, acc = 0, 0
+        for w in range(Wd):
+            d = ((s >> (w * c)) & ((1 << c) - 1)) + carry
+            carry = 0
+            if d > half:
+                d -= 1 << c
+                carry = 1
+            if w >= rank and (w - rank) % world == 0:
+                acc += d << (w * c)
+        assert carry == 0
+        out.append(acc % ref.R)
+    return out
+
+
+@pytest.mark.parametrize("G,c", [(2, 9), (4, 13), (8, 11), (8, 22)])
+def test_window_sharded_keys_partial_sums_and_proof(G, c):
+    """Window (table-row) sharded proving keys -- what BASELINE's north_star / configs[2] name: every rank holds the whole key but only the rows
+    w = rank + k*G of its window tables.  Each rank's five partial sums equal the oracle's MSMs over the scalars restricted to that rank's
+    digit windows, and the gathered records finalize to the single-GPU / oracle proof bytes."""
+    from noir_backend_using_gnark_amd import parallel as par
+    log_n = 9
+    N = 1 << log_n
+    nw, npub = N - 1, 3
+    pkd = _random_pk(log_n, nw, npub, seed0=70)
+    a, b = orc.rand_fr(80, N), orc.rand_fr(81, N)
+    cc = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(N)])
+    w = orc.rand_fr(82, nw, witness_like=True)
+    r, s = orc.rand_fr(83, 1)[0], orc.rand_fr(84, 1)[0]
+    exp, _ = orc.groth16_prove(pkd, a, b, cc, w, r, s)
+    h = zk.compute_h(a, b, cc, log_n)
+    d_w, d_h = _lib.DeviceBuffer.from_numpy(w), _lib.DeviceBuffer.from_numpy(h)
+    w_int, h_int = from_mont_limbs(w), from_mont_limbs(h[:N - 1])
+    recs, keys = [], []
+    for rank in range(G):
+        assert par.window_rows(c, rank, G) == [x for x in range((255 + c - 1) // c) if x % G == rank]
+        pk = zk.ProvingKey(**pkd, window_shard=(rank, G), table_window_bits=c)
+        keys.append(pk)
+        rec = par.groth16_msm5_pk(pk, d_w.ptr, d_h.ptr)
+        recs.append(rec)
+        if G <= 4 or rank in (0, G - 1):   # per-rank partial sums against the oracle (A and Z: wire scalars and h scalars)
+            wr, hr = mont_limbs(_window_scalars(w_int, c, rank, G)), mont_limbs(_window_scalars(h_int, c, rank, G))
+            assert (zb.g1_sum_partials(rec[0:16]) == orc.g1_msm(pkd["g1_a"], wr)).all(), rank
+            assert (zb.g1_sum_partials(rec[48:64]) == orc.g1_msm(pkd["g1_z"][:N - 1], hr)).all(), rank
+            assert (zb.g2_sum_partials(rec[64:96]) == orc.g2_msm(pkd["g2_b"], wr)).all(), rank
+    assert par.groth16_finalize(keys[0], np.stack(recs), r, s) == exp
+    assert par.groth16_finalize(keys[-1], np.stack(recs), r, s) == exp
+    with pytest.raises(_lib.ZkmiError):
+        zk.ProvingKey(**pkd, window_shard=(G, G))
+    with pytest.raises(_lib.ZkmiError):
+        zk.ProvingKey(**pkd, window_shard=(0, G), precompute_tables=False)
+    for pk in keys:
+        pk.free()
