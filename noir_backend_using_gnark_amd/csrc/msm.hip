@@ -961,6 +961,35 @@ int msm_build_table_g2(Slot* s, hipStream_t st, const void* d_pts, size_t n, siz
     return build_table<Fp2>(s, st, d_pts, n, stride, offset, c, d_table, row_first, row_step);
 }
 
+// gnark keeps pk.G1.A / pk.G1.B / pk.G2.B WITHOUT their points at infinity (InfinityA / InfinityB bitmaps, setup.go); the resident key
+// is wire-indexed, so the compact array is scattered once at load time: out[i] = src_idx[i] == ~0 ? infinity (0,0) : compact[src_idx[i]].
+template <class F>
+__global__ __launch_bounds__(256) void k_expand_bases(const Affine<F>* __restrict__ compact, const uint32_t* __restrict__ src_idx, uint32_t n,
+                                                      Affine<F>* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t j = src_idx[i];
+    Affine<F> p;
+    uint4* d = reinterpret_cast<uint4*>(&p);
+    if (j == 0xffffffffu) {
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(p) / 16; k++) d[k] = make_uint4(0, 0, 0, 0);
+    } else {
+        p = gload(compact + j);
+    }
+    gstore(out + i, p);
+}
+int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, const uint32_t* d_src_idx, size_t n, void* d_out) {
+    if (!n) return ZK_OK;
+    if (is_g2)
+        ZK_LAUNCH(s, st, "pk_expand_bases_g2", (k_expand_bases<Fp2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Affine<Fp2>*)d_compact, d_src_idx,
+                  (uint32_t)n, (Affine<Fp2>*)d_out);
+    else
+        ZK_LAUNCH(s, st, "pk_expand_bases_g1", (k_expand_bases<Fp>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Affine<Fp>*)d_compact, d_src_idx,
+                  (uint32_t)n, (Affine<Fp>*)d_out);
+    return ZK_OK;
+}
+
 int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
     MsmPlan P;
     ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));  // the scalar-side plan does not depend on the group
