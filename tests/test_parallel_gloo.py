@@ -38,6 +38,33 @@ assert gathered.shape == (2, 16)
 total = zb.g1_sum_partials(gathered)
 assert (total == orc.g1_msm(pts, sc)).all()
 assert (gathered[rank] == rec).all()
+# ---- window (table-row) sharding: every rank takes ALL points but only the digit windows w = rank, rank + world, ...; its partial sum is the
+# MSM over the scalars restricted to those windows (gnark's signed c-bit recoding), and the partial sums add up to the whole MSM
+import torch
+c = 11
+Wd = (255 + c - 1) // c
+rows = par.window_rows(c, rank, world)
+assert rows == list(range(rank, Wd, world))
+half = 1 << (c - 1)
+mine = []
+for s in orc.from_mont_vec(sc):
+    carry, acc = 0, 0
+    for w in range(Wd):
+        d = ((s >> (w * c)) & ((1 << c) - 1)) + carry
+        carry = 0
+        if d > half:
+            d -= 1 << c
+            carry = 1
+        if w in rows:
+            acc += d << (w * c)
+    mine.append(acc %% ref.R)
+loc = orc.g1_msm(pts, orc.to_mont_vec(mine))
+gathered = par.all_gather_limbs(np.concatenate([loc, one, one]))
+assert (zb.g1_sum_partials(gathered) == orc.g1_msm(pts, sc)).all()
+# the coefficient exchange of that mode: blocks of h concatenated in rank order on every rank
+blk = torch.arange(8, dtype=torch.int64).reshape(2, 4) + 100 * rank
+full = par.all_gather_blocks(blk)
+assert full.shape == (4, 4) and (full[:2] == torch.arange(8).reshape(2, 4)).all() and (full[2:] == torch.arange(8).reshape(2, 4) + 100).all()
 par.dist().barrier()
 sys.stdout.write("rank %%d ok\n" %% rank); sys.stdout.flush()
 ''' % ROOT
@@ -55,6 +82,15 @@ def test_shard_range_covers_everything():
 def test_all_gather_single_process():
     x = np.arange(16, dtype=np.uint64)
     assert (par.all_gather_limbs(x) == x.reshape(1, 16)).all()
+
+
+def test_window_rows_partition_the_windows():
+    for c in (9, 16, 20, 22):
+        Wd = (255 + c - 1) // c
+        for world in (1, 2, 4, 8):
+            rows = [par.window_rows(c, g, world) for g in range(world)]
+            assert sorted(sum(rows, [])) == list(range(Wd))
+            assert max(map(len, rows)) - min(map(len, rows)) <= 1
 
 
 def test_two_rank_sharded_msm_gloo(tmp_path):
