@@ -125,6 +125,9 @@ int zk_bn254_groth16_compute_h_dev(const void *d_a, const void *d_b, const void 
  *   phase 1: a, b, c blocks          -> block part of FFTInverse(DIF), *1/D*g^bitrev(i), block part of FFT(DIT, coset) -> transpose
  *   phase 2: a, b, c transposed      -> cross stages of FFT(DIT); a = (a*b - c)/(g^D - 1); cross stages of FFTInverse(DIF) -> transpose a back
  *   phase 3: a block                 -> block part of FFTInverse(DIF, coset): a is this rank's block of h.
+ * Phases 0 and 1 act on each array independently and skip null pointers; phase 2 = phase 4 (cross stages of FFT(DIT), per array) followed by
+ * phase 5 (the pointwise step and the final cross stages, all three arrays) -- so that the host can pipeline the transposes of b, c under the
+ * stages of a (parallel.compute_h_sharded(pipelined=True): async collectives, one array ahead).
  * log_g = 0 degenerates to zk_bn254_groth16_compute_h_dev (no exchange).  In place; asynchronous on `stream` if given. */
 int zk_bn254_groth16_h_shard_dev(int phase, void *d_a, void *d_b, void *d_c, uint32_t log_D, uint32_t log_g,
                                  uint32_t rank, void *stream);

@@ -698,16 +698,23 @@ int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* 
     ShardTables tb;
     ZK_TRY(get_shard_tables(s, st, dD, logD, logg, rank, &tb));
     switch (phase) {
-        case 0:  // transposed a, b, c: cross stages of FFTInverse(DIF)
-            for (Fr* v : {a, b, c}) ZK_TRY(launch_cross<true>(s, st, v, dD->tw_inv, logM, logg, rank));
+        case 0:  // transposed a, b, c (any subset: null arrays are skipped): cross stages of FFTInverse(DIF)
+            for (Fr* v : {a, b, c})
+                if (v) ZK_TRY(launch_cross<true>(s, st, v, dD->tw_inv, logM, logg, rank));
             return ZK_OK;
-        case 1:  // blocks: rest of FFTInverse(DIF), * 1/D * g^bitrev(i), block part of FFT(DIT, coset)
-            for (Fr* v : {a, b, c}) {
-                ZK_TRY(run_inverse_forward(s, st, v, dM, tb.coset_rev_n));
-            }
+        case 1:  // blocks (any subset): rest of FFTInverse(DIF), * 1/D * g^bitrev(i), block part of FFT(DIT, coset)
+            for (Fr* v : {a, b, c})
+                if (v) ZK_TRY(run_inverse_forward(s, st, v, dM, tb.coset_rev_n));
             return ZK_OK;
-        case 2: {  // transposed: cross stages of FFT(DIT); pointwise; cross stages of the final FFTInverse(DIF, coset)
-            for (Fr* v : {a, b, c}) ZK_TRY(launch_cross<false>(s, st, v, dD->tw, logM, logg, rank));
+        case 4:  // first third of phase 2, per array: cross stages of FFT(DIT) on the transposed arrays given
+            for (Fr* v : {a, b, c})
+                if (v) ZK_TRY(launch_cross<false>(s, st, v, dD->tw, logM, logg, rank));
+            return ZK_OK;
+        case 2:    // transposed: cross stages of FFT(DIT); pointwise; cross stages of the final FFTInverse(DIF, coset)
+        case 5: {  // the rest of phase 2 after phase 4 ran on a, b, c: pointwise + cross stages of the final FFTInverse(DIF, coset)
+            if (!a || !b || !c) return set_err(ZK_ERR_ARG, "phase %d needs a, b and c", phase);
+            if (phase == 2)
+                for (Fr* v : {a, b, c}) ZK_TRY(launch_cross<false>(s, st, v, dD->tw, logM, logg, rank));
             HFr gN = dD->coset;
             for (unsigned i = 0; i < logD; i++) gN = gN.sqr();
             HFr den = (gN - HFr::one()).inv();
@@ -716,7 +723,7 @@ int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* 
         }
         case 3:  // block of a: rest of FFTInverse(DIF, coset) -> this rank's block of h (gnark's bit-reversed order)
             return run_passes(s, st, a, dM, 1, 1, nullptr, tb.coset_inv_n_rev, nullptr);
-        default: return set_err(ZK_ERR_ARG, "phase must be 0..3");
+        default: return set_err(ZK_ERR_ARG, "phase must be 0..5");
     }
 }
 
@@ -823,7 +830,7 @@ int zk_bn254_groth16_compute_h(const zk_fr* a, const zk_fr* b, const zk_fr* c, s
 }
 
 int zk_bn254_groth16_h_shard_dev(int phase, void* d_a, void* d_b, void* d_c, uint32_t log_D, uint32_t log_g, uint32_t rank, void* stream) {
-    if (!d_a || (phase != 3 && (!d_b || !d_c))) return set_err(ZK_ERR_ARG, "null pointer");
+    if (!d_a || ((phase == 2 || phase == 5) && (!d_b || !d_c))) return set_err(ZK_ERR_ARG, "null pointer");
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     // Give it the stream of the proof's msm5 session (zk_bn254_groth16_msm5_session_stream): a foreign stream may share a

@@ -177,19 +177,54 @@ def _h_shard_phase_hip(phase, a, b, c, log_d, log_g, rank):
                                              C.c_uint32(rank), C.c_void_p(st)))
 
 
-def compute_h_sharded(a, b, c, log_d: int, rank: int, world: int, phase=_h_shard_phase_hip, exchange=block_exchange):
+def block_exchange_async(x):
+    """block_exchange with the collective left in flight: returns (y, wait) -- call wait() before touching y.  RCCL: all_to_all_single with
+    async_op (the collective runs on RCCL's stream behind the work already queued on the current stream; wait() orders the current stream
+    behind it, the host does not block).  Anything else: the synchronous exchange."""
+    d = dist()
+    if d.is_available() and d.is_initialized() and d.get_world_size() > 1 and d.get_backend() == "nccl" and _a2a_transport() == "all_to_all":
+        import torch
+        y = torch.empty_like(x)
+        work = d.all_to_all_single(y, x, async_op=True)
+        return y, work.wait
+    return block_exchange(x), (lambda: None)
+
+
+def compute_h_sharded(a, b, c, log_d: int, rank: int, world: int, phase=_h_shard_phase_hip, exchange=block_exchange, pipelined=None,
+                      exchange_async=None):
     """gnark computeH with a, b, c, h sharded by blocks over `world` = 2^g ranks.  a, b, c: this rank's blocks (M = 2^log_d / world
     elements of 4 x int64 each; destroyed).  Returns the array holding this rank's block of h (gnark's bit-reversed order).
-    `phase` / `exchange` are injectable so that the CPU tests can run the same schedule on the oracle's arithmetic over gloo."""
+    `phase` / `exchange` are injectable so that the CPU tests can run the same schedule on the oracle's arithmetic over gloo.
+    pipelined (default: on under RCCL): the three arrays go through phases 0, 1 and the first third of phase 2 ONE ARRAY AHEAD of their
+    transposes -- while a is in its butterfly stages the all-to-all of b (then c) is in flight on RCCL's stream; 9 of the 10 exchanges overlap
+    with compute (unmeasured on hardware: this pool has one GPU per box; the schedule is covered by the gloo tests)."""
     log_g = world.bit_length() - 1
     if (1 << log_g) != world:
         raise ValueError("world size must be a power of two")
-    a, b, c = exchange(a), exchange(b), exchange(c)
-    phase(0, a, b, c, log_d, log_g, rank)
-    a, b, c = exchange(a), exchange(b), exchange(c)
-    phase(1, a, b, c, log_d, log_g, rank)
-    a, b, c = exchange(a), exchange(b), exchange(c)
-    phase(2, a, b, c, log_d, log_g, rank)
+    if pipelined is None:
+        d = dist()
+        pipelined = bool(d.is_available() and d.is_initialized() and d.get_world_size() > 1 and d.get_backend() == "nccl")
+    if not pipelined:
+        a, b, c = exchange(a), exchange(b), exchange(c)
+        phase(0, a, b, c, log_d, log_g, rank)
+        a, b, c = exchange(a), exchange(b), exchange(c)
+        phase(1, a, b, c, log_d, log_g, rank)
+        a, b, c = exchange(a), exchange(b), exchange(c)
+        phase(2, a, b, c, log_d, log_g, rank)
+        a = exchange(a)
+        phase(3, a, None, None, log_d, log_g, rank)
+        return a
+    xa = exchange_async or (block_exchange_async if exchange is block_exchange else (lambda x: (exchange(x), (lambda: None))))
+    flight = [xa(v) for v in (a, b, c)]          # transposes into phase 0, all three in flight
+    for ph in (0, 1, 4):
+        nxt = []
+        for v, wait in flight:
+            wait()
+            phase(ph, v, None, None, log_d, log_g, rank)
+            nxt.append(xa(v) if ph != 4 else (v, None))   # the transpose into the next phase starts as soon as this array is done
+        flight = nxt
+    a, b, c = (v for v, _ in flight)
+    phase(5, a, b, c, log_d, log_g, rank)
     a = exchange(a)
     phase(3, a, None, None, log_d, log_g, rank)
     return a

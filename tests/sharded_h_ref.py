@@ -76,16 +76,24 @@ def phase_int(phase, a, b, c, log_d, log_g, rank):
     w_m, w_m_inv = pow(dom.gen, G, R), pow(dom.gen_inv, G, R)
     if phase == 0:
         for v in (a, b, c):
-            cross_dif(v, dom.gen_inv, log_g, log_m, rank)
+            if v is not None:
+                cross_dif(v, dom.gen_inv, log_g, log_m, rank)
     elif phase == 1:
         for v in (a, b, c):
+            if v is None:
+                continue
             dif_inplace(v, w_m_inv)
             for j in range(M):
                 v[j] = v[j] * dom.card_inv % R * pow(dom.coset, ref.bitrev(rank * M + j, log_d), R) % R
             dit_inplace(v, w_m)
-    elif phase == 2:
+    elif phase == 4:   # first third of phase 2, per array
         for v in (a, b, c):
-            cross_dit(v, dom.gen, log_g, log_m, rank)
+            if v is not None:
+                cross_dit(v, dom.gen, log_g, log_m, rank)
+    elif phase in (2, 5):
+        if phase == 2:
+            for v in (a, b, c):
+                cross_dit(v, dom.gen, log_g, log_m, rank)
         den = ref.inv((pow(dom.coset, dom.n, R) - 1) % R, R)
         for j in range(M):
             a[j] = (a[j] * b[j] - c[j]) * den % R
@@ -113,15 +121,22 @@ def exchange_all(blocks):
     return out
 
 
-def run_virtual(phase, A, B, Cc, log_d):
+def run_virtual(phase, A, B, Cc, log_d, per_array=False):
     """Lock-step schedule of parallel.compute_h_sharded over G = len(A) virtual ranks.  phase(p, a, b, c, log_d, log_g, rank)
-    works in place on whatever array type the blocks are.  Returns the list of h blocks."""
+    works in place on whatever array type the blocks are.  Returns the list of h blocks.
+    per_array: the pipelined schedule's calls -- phases 0, 1, 4 one array at a time (b = c = None), then phase 5."""
     G = len(A)
     log_g = G.bit_length() - 1
     for p in range(3):
         A, B, Cc = exchange_all(A), exchange_all(B), exchange_all(Cc)
         for r in range(G):
-            phase(p, A[r], B[r], Cc[r], log_d, log_g, r)
+            if not per_array:
+                phase(p, A[r], B[r], Cc[r], log_d, log_g, r)
+                continue
+            for v in (A[r], B[r], Cc[r]):
+                phase(4 if p == 2 else p, v, None, None, log_d, log_g, r)
+            if p == 2:
+                phase(5, A[r], B[r], Cc[r], log_d, log_g, r)
     A = exchange_all(A)
     for r in range(G):
         phase(3, A[r], None, None, log_d, log_g, r)

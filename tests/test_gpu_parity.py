@@ -402,6 +402,9 @@ def test_sharded_compute_h_matches_single_gpu_and_oracle(log_d, G):
     H = sh.run_virtual(_h_phase_gpu, blk(a), blk(b), blk(c), log_d)
     got = np.concatenate(H)
     assert sha_image(got) == sha_image(want)
+    if log_d in (9, 13, 15):   # the pipelined schedule's per-array calls (phases 0, 1, 4 with b = c = NULL, then 5)
+        H = sh.run_virtual(_h_phase_gpu, blk(a), blk(b), blk(c), log_d, per_array=True)
+        assert sha_image(np.concatenate(H)) == sha_image(want)
 
 
 def test_sharded_compute_h_argument_errors():

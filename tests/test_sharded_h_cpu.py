@@ -40,6 +40,8 @@ def test_sharded_schedule_equals_compute_h(log_d, G):
     blk = lambda v: [list(v[r * M:(r + 1) * M]) for r in range(G)]
     H = sh.run_virtual(sh.phase_int, blk(a), blk(b), blk(c), log_d)
     assert [x for h in H for x in h] == want
+    H = sh.run_virtual(sh.phase_int, blk(a), blk(b), blk(c), log_d, per_array=True)
+    assert [x for h in H for x in h] == want
 
 
 WORKER = r'''
@@ -71,6 +73,9 @@ def phase(p, ta, tb, tc, log_d, log_g, rk):
 blk = lambda v: to_t(v[rank * M:(rank + 1) * M])
 h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase)
 assert to_i(h) == want[rank * M:(rank + 1) * M], "rank %%d block of h differs" %% rank
+# the pipelined schedule (per-array phases 0, 1, 4, then 5; transposes one array ahead) gives the same block
+h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase, pipelined=True)
+assert to_i(h) == want[rank * M:(rank + 1) * M], "rank %%d block of h differs (pipelined)" %% rank
 # exchange is an involution
 x = torch.arange(M * 4, dtype=torch.int64).reshape(M, 4) + 1000 * rank
 assert torch.equal(par.block_exchange(par.block_exchange(x)), x)
