@@ -419,7 +419,7 @@ def test_sharded_compute_h_argument_errors():
     assert _lib.lib().zk_bn254_groth16_msm5_pk_end(C.c_uint64(12345), C.c_void_p(d.ptr), _lib.vp(out), None) != 0  # unknown session
 
 
-@pytest.mark.parametrize("G,tables", [(2, True), (4, True), (4, False)])
+@pytest.mark.parametrize("G,tables", [(2, True), (4, True), (4, False), (8, True)])
 def test_sharded_proof_with_rank_local_keys(G, tables):
     """The whole multi-GPU prover, all ranks played on one GPU: every rank loads ITS slice of the key (window tables over the
     slice), runs the sharded computeH and zk_bn254_groth16_msm5_pk; the gathered records finalize to the oracle's 128 bytes."""
