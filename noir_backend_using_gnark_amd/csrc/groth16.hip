@@ -744,7 +744,10 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     }
     // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
     const Fr* in_place_src[3] = {(const Fr*)a, (const Fr*)b, (const Fr*)c};
-    if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain, direct ? in_place_src : nullptr);
+    // ZKMI_H_STREAMS=1 (experiment switch): the transforms of b and c on the (idle) high-priority streams of slots 1 and 2, next to a's
+    static const bool h_streams = getenv("ZKMI_H_STREAMS") && atoi(getenv("ZKMI_H_STREAMS")) == 1;
+    const hipStream_t side[2] = {g.s[1]->stream_hi, g.s[2]->stream_hi};
+    if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain, direct ? in_place_src : nullptr, h_streams ? side : nullptr);
     hipEvent_t ev_h = nullptr;
     if (rc == ZK_OK && hipEventCreateWithFlags(&ev_h, hipEventDisableTiming) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventCreate failed");
     if (rc == ZK_OK && hipEventRecord(ev_h, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventRecord failed");

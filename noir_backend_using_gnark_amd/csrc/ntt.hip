@@ -587,14 +587,35 @@ int bit_reverse_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn) {
 //   3 x FFTInverse(DIF) ; 3 x FFT(DIT, coset) ; a = (a*b - c) / (g^N - 1) ; FFTInverse(a, DIF, coset)
 // The 1/N of the first inverse and the coset pre-scale g^bitrev(i) of the following forward transform are one
 // table (coset_rev_n) applied while the inverse transform stores its last stage.
-int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned logN, const Fr* const* src) {
+int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned logN, const Fr* const* src, const hipStream_t* side) {
     // src (optional): the three inputs live in src[0..2] (full 2^logN vectors) and are left untouched; a, b, c are then pure outputs / scratch
+    // side (optional): two more streams -- the transforms of b and c run on them, concurrently with a's on `st` (whatever produced the inputs must
+    // be ordered before `st`): every pass is load -> butterflies -> store in lock-step over the whole machine at sizes that fit one round of
+    // workgroups, so three transforms in flight put one array's loads / stores under another's butterflies.
     ZK_TRY(ensure_lds_attr());
     Domain* d;
     ZK_TRY(get_domain(s, st, logN, DOM_TW | DOM_TW_INV | DOM_COSET_REV_N | DOM_COSET_INV_N_REV, &d));
     size_t N = (size_t)1 << logN;
     Fr* vs[3] = {a, b, c};
-    for (int i = 0; i < 3; i++) ZK_TRY(run_inverse_forward(s, st, vs[i], d, d->coset_rev_n, src ? src[i] : nullptr));
+    if (side) {
+        hipEvent_t fork, join[2];
+        ZK_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(fork, st));
+        for (int i = 0; i < 2; i++) {
+            ZK_HIP(hipStreamWaitEvent(side[i], fork, 0));
+            ZK_TRY(run_inverse_forward(s, side[i], vs[i + 1], d, d->coset_rev_n, src ? src[i + 1] : nullptr));
+            ZK_HIP(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
+            ZK_HIP(hipEventRecord(join[i], side[i]));
+        }
+        ZK_TRY(run_inverse_forward(s, st, vs[0], d, d->coset_rev_n, src ? src[0] : nullptr));
+        for (int i = 0; i < 2; i++) {
+            ZK_HIP(hipStreamWaitEvent(st, join[i], 0));
+            (void)hipEventDestroy(join[i]);
+        }
+        (void)hipEventDestroy(fork);
+    } else {
+        for (int i = 0; i < 3; i++) ZK_TRY(run_inverse_forward(s, st, vs[i], d, d->coset_rev_n, src ? src[i] : nullptr));
+    }
     // den = 1 / (g^N - 1)
     HFr gN = d->coset;
     for (unsigned i = 0; i < logN; i++) gN = gN.sqr();

@@ -28,7 +28,7 @@ struct Domain {
 int get_domain(Slot* s, hipStream_t st, unsigned logn, unsigned need, Domain** out);
 int ntt_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn, int inverse, int decimation, int coset);
 int bit_reverse_dev(Slot* s, hipStream_t st, Fr* d_a, unsigned logn);
-int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned logN, const Fr* const* src = nullptr);
+int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned logN, const Fr* const* src = nullptr, const hipStream_t* side = nullptr);
 int fr_mul_dev(Slot* s, hipStream_t st, Fr* out, const Fr* a, const Fr* b, size_t n);
 
 }  // namespace zkmi
