@@ -257,6 +257,26 @@ int zk_bn254_plonk_prove(uint64_t pk_handle, const void *solution, size_t n_vars
 int zk_bn254_plonk_synth_qk_dev(void *d_qk, const void *d_ql, const void *d_qr, const void *d_qo, const void *d_qm, const void *d_xa,
                                 const void *d_xb, const void *d_xc, const void *d_solution, size_t n_constraints, void *stream);
 
+/* ---- the callers either side of the PLONK path: the reference's exported entry points, restated over the device path -----------------------
+ * PlonkPreprocess (gnark_backend_ffi/main.go:58-78) and PlonkProveWithPK (main.go:24-37) take the ACIR as JSON (acir/acir.go:17-75), the witness
+ * values as the hex felt vector (internal/backend/helpers.go:24-33) and the key as hex of ProvingKey.WriteTo (helpers.go:49-60, 82-87); the
+ * lowering is BuildSparseR1CS / HandleValues (backend/plonk/sparse_r1cs.go:18-107, backend/common.go:45-76).  Differences: the SRS is a
+ * resident handle instead of srs.hex re-read per call; errors are codes instead of log.Fatal; outputs go to caller buffers (no terminator);
+ * the blinding scalars can be pinned (NULL = /dev/urandom); every witness is one variable (common.go:59-68's duplicates are not reproduced).
+ *   zk_plonk_preprocess: pk_hex_out == NULL only returns the sizes in *pk_len / *vk_len; pk_handle (optional) keeps the key resident.
+ *   zk_plonk_prove_with_pk: pk_hex == NULL uses the resident key pk_handle (the reference deserialises the key on every call). */
+int zk_plonk_preprocess(const char *acir_json, size_t acir_len, const char *values_hex, size_t values_len, uint64_t srs_handle,
+                        char *pk_hex_out, size_t pk_cap, size_t *pk_len, char *vk_hex_out, size_t vk_cap, size_t *vk_len,
+                        uint64_t *pk_handle);
+int zk_plonk_prove_with_pk(const char *acir_json, size_t acir_len, const char *values_hex, size_t values_len, const char *pk_hex,
+                           size_t pk_len, uint64_t pk_handle, uint64_t srs_handle, const zk_fr *blinders,
+                           char proof_hex_out[2 * ZK_PLONK_PROOF_BYTES]);
+/* BuildSparseR1CS alone: the gates of an ACIR circuit (Montgomery coefficients, variable ids with the public variables first) and the
+ * witness order (variable k holds witness order[k] + 1).  Array pointers may be NULL (first call sizes them through *n_constraints / *n_vars). */
+int zk_acir_to_sparse_r1cs(const char *acir_json, size_t acir_len, size_t n_values, size_t *n_public, size_t *n_vars,
+                           size_t *n_constraints, zk_fr *ql, zk_fr *qr, zk_fr *qo, zk_fr *qm, zk_fr *qk, uint32_t *xa, uint32_t *xb,
+                           uint32_t *xc, uint32_t *order);
+
 /* What the MSM planner picks for n points (with / without resident window tables): window width c and the number of c-bit
  * digits per scalar, i.e. mixed additions per scalar multiplication -- used by bench.py to turn launches into work. */
 int zk_bn254_msm_plan_info(size_t n, int window_tables, uint32_t *window_bits, uint32_t *digits);

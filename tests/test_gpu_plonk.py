@@ -281,3 +281,40 @@ def test_plonk_proving_key_wire_format(nc, nvars, npub):
         zp.read_proving_key(wire, spr.n_vars - 1, [nvars - 1] * len(g), wid[1], wid[2], srs)   # a wire id outside the variables
     pk.free()
     srs.free()
+
+
+# ------------------------------------------------------------------------------------------------ the reference's exported entry points
+def test_plonk_preprocess_and_prove_with_pk_on_the_reference_fixtures(plonk_golden):
+    """PlonkPreprocess / PlonkProveWithPK (gnark_backend_ffi/main.go:24-78) restated over the device path: ACIR JSON + hex witness values (+ hex
+    key) in, hex out -- the key text equals hex(oracle ProvingKey.WriteTo), the proof text equals the golden proof, with the key passed as text
+    (the reference's way) or kept resident; random blinders give a different proof that the oracle's verifier accepts."""
+    import json as js
+    from noir_backend_using_gnark_amd import frontend as fe, kzg
+    for e in plonk_golden:
+        acir = js.dumps(e["acir"])
+        values = [h2i(v) for v in e["values"]]
+        enc = ref.felts_wire(values).hex()
+        srs = kzg.new_srs(e["srs_size"], M([h2i(e["srs_alpha"])])[0])
+        spr, sol = pl.sparse_r1cs_from_acir(e["acir"], values)
+        opk, ovk = pl.plonk_setup(spr, pl.kzg_new_srs(e["srs_size"], h2i(e["srs_alpha"])))
+        pk_hex, vk_hex, h = fe.plonk_preprocess(acir, enc, srs, keep_resident=True)
+        assert pk_hex == pl.plonk_pk_bytes(opk).hex() and vk_hex == pl.plonk_vk_bytes(ovk).hex(), e["name"]
+        bl = M([h2i(v) for v in e["blinders"]])
+        assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"], e["name"]
+        assert fe.plonk_prove_with_pk(acir, enc, None, srs, blinders=bl, pk_handle=h) == e["proof"]
+        # upstream's own randomness: another proof, valid
+        p2 = bytes.fromhex(fe.plonk_prove_with_pk(acir, enc, None, srs, pk_handle=h))
+        assert p2.hex() != e["proof"]
+        pts = [ref_g1_decompress(p2[32 * i:32 * i + 32]) for i in range(7)]
+        pr = dict(lro=pts[0:3], z=pts[3], h=pts[4:7], batch_h=ref_g1_decompress(p2[224:256]), claimed=[int.from_bytes(p2[260 + 32 * i:292 + 32 * i], "big") for i in range(7)],
+                  z_open_h=ref_g1_decompress(p2[484:516]), zu=int.from_bytes(p2[516:548], "big"))
+        assert pl.plonk_verify(ovk, pr, sol[:spr.n_public])
+        # a witness that violates the circuit; a value vector of the wrong length
+        bad = list(values)
+        bad[4] = (bad[4] + 1) % R   # w5
+        with pytest.raises((ValueError, _lib.ZkmiError)):
+            fe.plonk_prove_with_pk(acir, ref.felts_wire(bad).hex(), None, srs, blinders=bl, pk_handle=h)
+        with pytest.raises((ValueError, _lib.ZkmiError)):
+            fe.plonk_prove_with_pk(acir, ref.felts_wire(values[:-1]).hex(), None, srs, blinders=bl, pk_handle=h)
+        _lib.check(_lib.lib().zk_bn254_plonk_pk_free(C.c_uint64(h)))
+        srs.free()
