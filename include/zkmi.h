@@ -176,6 +176,30 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void *a, const void *b, con
                            const void *w, size_t n_wires, const zk_fr *r, const zk_fr *s, int on_device, uint8_t proof_out[128]);
 /* n_wires = len(w): must equal the key's wire count (ZK_ERR_LEN otherwise -- the library reads exactly that many elements). */
 
+/* ---- R1CS on the device: groth16.Setup and the solver's a, b, c (gnark v0.8.0; reference: groth16.Setup at gnark_backend_ffi/main.go:121, the
+ * R1CS the reference meant to build from Noir's RawR1CS at backend/groth16/r1cs.go:9-72) ------------------------------------------------------
+ * L, R, O: sparse matrices by constraint (CSR: *_ptr has n_constraints + 1 entries starting at 0, *_idx wire ids, *_val Montgomery
+ * coefficients); wires = [ONE, public..., secret..., internal...], n_public counts the ONE wire like gnark's GetNbPublicVariables(). */
+typedef struct {
+    size_t n_constraints, n_wires, n_public;
+    const uint32_t *l_ptr, *l_idx; const zk_fr *l_val;
+    const uint32_t *r_ptr, *r_idx; const zk_fr *r_val;
+    const uint32_t *o_ptr, *o_idx; const zk_fr *o_val;
+} zk_r1cs;
+int zk_bn254_r1cs_load(const zk_r1cs *r1cs, uint64_t *handle);
+int zk_bn254_r1cs_free(uint64_t handle);
+/* a = L w, b = R w, c = O w: what r1cs.Solve leaves for a system without hints (one lane per matrix row); device pointers. */
+int zk_bn254_r1cs_eval_abc_dev(uint64_t handle, const void *d_w, size_t n_wires, void *d_a, void *d_b, void *d_c, void *stream);
+/* groth16.Setup with the toxic waste (tau, alpha, beta, gamma, delta; Montgomery, non-zero) as INPUT -- upstream draws it; pinning it is what
+ * makes a key reproducible.  The key is built in HBM (Lagrange basis at tau, transposed products, fixed-base scalar multiplications) and comes
+ * back as a resident proving key; vk_g1 (1 + n_public points: [alpha]G1, then K_i / gamma) and vk_g2 ([beta]G2, [gamma]G2, [delta]G2) on
+ * the host.  flags bit 0: no window tables. */
+int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags, uint64_t *pk_handle, zk_g1_affine *vk_g1,
+                           zk_g2_affine vk_g2[3]);
+/* groth16.Prove from the witness: a, b, c by the device solver step above, then zk_bn254_groth16_prove on resident data. */
+int zk_bn254_groth16_prove_r1cs(uint64_t r1cs_handle, uint64_t pk_handle, const void *w, size_t n_wires, const zk_fr *r,
+                                const zk_fr *s, int on_device, uint8_t proof_out[128]);
+
 /* The two halves of zk_bn254_groth16_prove, exposed so that one proof can be range-sharded over several GPUs
  * (one process per GPU): every rank runs the five MSMs on ITS slice of the bases / wire values / h, the un-normalised
  * XYZZ sums (4 x G1 = 64 limbs, then G2 = 32 limbs; order A, B1, K, Z, B2) are all-gathered, and any rank finishes.

@@ -10,7 +10,7 @@ Layout
 """
 from . import _lib  # noqa: F401
 from .bn254 import (DIF, DIT, Domain, MultiExpConfig, bit_reverse, g1_multi_exp, g2_multi_exp)  # noqa: F401
-from .groth16 import ProvingKey, compute_h, prove  # noqa: F401
+from .groth16 import R1CS, ProvingKey, compute_h, prove, prove_r1cs, setup  # noqa: F401
 from .wire import deserialize_felts, serialize_felts  # noqa: F401
 
 __all__ = ["DIF", "DIT", "Domain", "MultiExpConfig", "bit_reverse", "g1_multi_exp", "g2_multi_exp", "ProvingKey", "compute_h", "prove"]

@@ -30,6 +30,11 @@ class Groth16PK(C.Structure):
                 ("table_window_bits", C.c_int), ("reserved", C.c_int), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
+class R1CS(C.Structure):
+    _fields_ = [("n_constraints", C.c_size_t), ("n_wires", C.c_size_t), ("n_public", C.c_size_t)] + \
+               [(m + k, C.c_void_p) for m in ("l", "r", "o") for k in ("_ptr", "_idx", "_val")]
+
+
 class PlonkCircuit(C.Structure):
     _fields_ = [("n_public", C.c_size_t), ("n_constraints", C.c_size_t), ("n_vars", C.c_size_t),
                 ("ql", C.c_void_p), ("qr", C.c_void_p), ("qo", C.c_void_p), ("qm", C.c_void_p), ("qk", C.c_void_p),
@@ -59,6 +64,7 @@ SYMBOLS = [
     "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev",
     "zk_bn254_felts_decode_hex", "zk_bn254_felts_decode_hex_dev", "zk_bn254_felts_decode_bytes_dev", "zk_bn254_felts_encode_hex",
     "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_pk_info", "zk_bn254_groth16_prove",
+    "zk_bn254_r1cs_load", "zk_bn254_r1cs_free", "zk_bn254_r1cs_eval_abc_dev", "zk_bn254_groth16_setup", "zk_bn254_groth16_prove_r1cs",
     "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_pk_abort", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
     "zk_bn254_plonk_setup", "zk_bn254_plonk_pk_load", "zk_bn254_plonk_pk_free", "zk_bn254_plonk_pk_export", "zk_bn254_plonk_pk_read", "zk_bn254_plonk_pk_write", "zk_bn254_plonk_prove", "zk_bn254_plonk_synth_qk_dev",
     "zk_plonk_preprocess", "zk_plonk_prove_with_pk", "zk_acir_to_sparse_r1cs",

@@ -266,6 +266,20 @@ int zk_bn254_groth16_pk_free(uint64_t handle) {
     return ZK_OK;
 }
 
+}  // extern "C"
+namespace zkmi {
+// the key takes ownership of its five device base arrays (groth16.Setup builds them in HBM and hands them over)
+int groth16_pk_adopt(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
+    it->second.owns = true;
+    it->second.owns_abb = false;
+    return ZK_OK;
+}
+}  // namespace zkmi
+extern "C" {
+
 int zk_bn254_groth16_pk_info(uint64_t handle, size_t* n_wires, size_t* n_public, uint32_t* log_domain, int* has_tables) {
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pks.find(handle);

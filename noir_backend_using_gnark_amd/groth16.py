@@ -65,6 +65,13 @@ class ProvingKey:
         self.handle = C.c_uint64(0)
         check(lib().zk_bn254_groth16_pk_load(C.byref(pk), C.byref(self.handle)))
 
+    @classmethod
+    def from_handle(cls, handle: int, log_domain: int, n_wires: int, n_public: int):
+        """wraps a key that already lives in the library (groth16.Setup on the device)"""
+        pk = cls.__new__(cls)
+        pk.log_domain, pk.n_wires, pk.n_public, pk._keep, pk.handle = log_domain, n_wires, n_public, [], C.c_uint64(handle)
+        return pk
+
     def info(self) -> dict:
         nw, npub, ld, tab = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0), C.c_int(0)
         check(lib().zk_bn254_groth16_pk_info(self.handle, C.byref(nw), C.byref(npub), C.byref(ld), C.byref(tab)))
@@ -114,3 +121,65 @@ def compute_h(a, b, c, log_domain: int) -> np.ndarray:
     h = np.zeros((1 << log_domain, 4), dtype=np.uint64)
     check(lib().zk_bn254_groth16_compute_h(vp(a), vp(b), vp(c), C.c_size_t(a.shape[0]), C.c_uint32(log_domain), vp(h)))
     return h
+
+
+class R1CS:
+    """cs.R1CS resident in HBM: constraints (L w) o (R w) = (O w) over the wires [ONE, public..., secret..., internal...]; n_public counts the
+    ONE wire (gnark's GetNbPublicVariables).  `constraints`: list of (L, R, O), each a dict wire -> Montgomery coefficient (4 limbs)."""
+
+    def __init__(self, n_public: int, n_wires: int, constraints):
+        self.n_public, self.n_wires, self.n_constraints = n_public, n_wires, len(constraints)
+        mats = []
+        for m in range(3):
+            ptr, idx, val = [0], [], []
+            for con in constraints:
+                for wire, coeff in con[m].items():
+                    idx.append(wire)
+                    val.append(np.asarray(coeff, dtype=np.uint64).reshape(4))
+                ptr.append(len(idx))
+            mats.append((np.asarray(ptr, dtype=np.uint32), np.asarray(idx, dtype=np.uint32), np.ascontiguousarray(np.stack(val)) if val else np.zeros((0, 4), np.uint64)))
+        self._keep = mats
+        raw = _lib.R1CS(self.n_constraints, n_wires, n_public, *[a.ctypes.data for mat in mats for a in mat])
+        self.handle = C.c_uint64(0)
+        check(lib().zk_bn254_r1cs_load(C.byref(raw), C.byref(self.handle)))
+
+    def eval_abc(self, w) -> tuple:
+        """a, b, c = L w, R w, O w on the device (the solver's output for a system without hints) -> numpy"""
+        w = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
+        dw = _lib.DeviceBuffer.from_numpy(w)
+        out = [_lib.DeviceBuffer(max(self.n_constraints, 1) * 32) for _ in range(3)]
+        rc = lib().zk_bn254_r1cs_eval_abc_dev(self.handle, C.c_void_p(dw.ptr), C.c_size_t(w.shape[0]), *[C.c_void_p(o.ptr) for o in out], None)
+        if rc == _lib.ZK_ERR_LEN:
+            raise ValueError((lib().zk_last_error() or b"").decode())
+        check(rc)
+        return tuple(o.to_numpy(np.uint64, (self.n_constraints, 4)) for o in out)
+
+    def free(self):
+        if self.handle.value:
+            check(lib().zk_bn254_r1cs_free(self.handle))
+            self.handle = C.c_uint64(0)
+
+
+def setup(r1cs: R1CS, toxic, precompute_tables: bool = True):
+    """groth16.Setup(r1cs) with the toxic waste (tau, alpha, beta, gamma, delta; (5, 4) Montgomery) as input -> (ProvingKey, vk dict)."""
+    tx = np.ascontiguousarray(toxic, dtype=np.uint64).reshape(5, 4)
+    h = C.c_uint64(0)
+    vk1 = np.zeros((1 + r1cs.n_public, 8), np.uint64)
+    vk2 = np.zeros((3, 16), np.uint64)
+    check(lib().zk_bn254_groth16_setup(r1cs.handle, vp(tx), C.c_int(0 if precompute_tables else 1), C.byref(h), vp(vk1), vp(vk2)))
+    log_n = max(r1cs.n_constraints - 1, 0).bit_length()
+    pk = ProvingKey.from_handle(h.value, log_n, r1cs.n_wires, r1cs.n_public)
+    return pk, dict(g1_alpha=vk1[0], g1_k=vk1[1:], g2_beta=vk2[0], g2_gamma=vk2[1], g2_delta=vk2[2])
+
+
+def prove_r1cs(r1cs: R1CS, pk: ProvingKey, w, r, s) -> bytes:
+    """groth16.Prove(r1cs, pk, witness): the full wire vector in, a / b / c on the device, 128 proof bytes out."""
+    w = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+    s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+    proof = (C.c_uint8 * 128)()
+    rc = lib().zk_bn254_groth16_prove_r1cs(r1cs.handle, pk.handle, vp(w), C.c_size_t(w.shape[0]), vp(r), vp(s), C.c_int(0), proof)
+    if rc == _lib.ZK_ERR_LEN:
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    return bytes(proof)
