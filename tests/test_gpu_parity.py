@@ -973,11 +973,9 @@ def test_groth16_setup_and_prove_from_r1cs_on_device(golden):
         dev.free()
 
 
-def test_r1cs_spmv_and_setup_at_2p16_constraints():
-    """A 2^16-constraint random R1CS (3 entries per row and matrix): the device's a, b, c equal a numpy-free big-int evaluation on sampled rows,
-    and the proof made with the device-built key verifies... through the prover's own consistency: prove_r1cs == prove on (a, b, c) the oracle
-    evaluates, against the oracle's proof with the device key exported through the proof equation is out of reach here -- so the check is the
-    oracle C prover on the SAME base arrays is not available; instead the witness is made satisfying and the quotient's top coefficient is zero."""
+def test_r1cs_sparse_mat_vec_at_2p12_constraints():
+    """The solver step on a 2^12-constraint random R1CS (3 + 3 + 2 entries per row): the device's a, b, c = L w, R w, O w equal the oracle's
+    big-integer evaluation element for element."""
     g = ref.SplitMix64(0x99)
     nc, nw, npub = 1 << 12, 3000, 4
     w = [1] + [g.felt() for _ in range(nw - 1)]
