@@ -301,6 +301,12 @@ int zk_acir_to_sparse_r1cs(const char *acir_json, size_t acir_len, size_t n_valu
                            size_t *n_constraints, zk_fr *ql, zk_fr *qr, zk_fr *qo, zk_fr *qm, zk_fr *qk, uint32_t *xa, uint32_t *xb,
                            uint32_t *xc, uint32_t *order);
 
+/* buildR1CS of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:9-72; payload RawR1CS, src/gnark_backend_wrapper/groth16/
+ * acir_to_r1cs.rs:18-60) on a JSON RawR1CS: a resident R1CS plus the full wire vector [ONE, public, secret, product variables] in HBM
+ * (*d_witness, n_wires Montgomery elements; release with zk_dev_free) -- feed them to zk_bn254_groth16_setup / zk_bn254_groth16_prove_r1cs
+ * (on_device = 1).  See frontend.hip for the points where the reference's sketch is made well-defined. */
+int zk_groth16_r1cs_from_raw(const char *raw_json, size_t len, uint64_t *r1cs_handle, void **d_witness, size_t *n_wires, size_t *n_public);
+
 /* What the MSM planner picks for n points (with / without resident window tables): window width c and the number of c-bit
  * digits per scalar, i.e. mixed additions per scalar multiplication -- used by bench.py to turn launches into work. */
 int zk_bn254_msm_plan_info(size_t n, int window_tables, uint32_t *window_bits, uint32_t *digits);

@@ -359,6 +359,132 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
     return ZK_OK;
 }
 
+// buildR1CS of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:9-72, commented out there; payload RawR1CS of
+// src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60: {"gates":[{"mul_terms":[{"coefficient","multiplicand","multiplier"}],"add_terms":
+// [{"coefficient","sum"}],"constant_term"}],"public_inputs","values" (hex felt vector),"num_variables","num_constraints"}): every mul term gets an
+// internal product variable p with (1 * multiplicand) * (1 * multiplier) = coefficient * p; every gate ends in
+// (1 * ONE) * (sum coefficient * p + sum coefficient * x + constant * ONE) = 0.  Made well-defined where the sketch is not: wires = [ONE, public
+// witnesses in witness order, the other witnesses, product variables]; values[w - 1] is witness w; the constant term IS in the sum (the sketch
+// drops it); a mul term with coefficient 0 emits nothing.  Out: a resident R1CS (zk_bn254_r1cs_*) and the full wire vector in HBM
+// (*d_witness: n_wires Montgomery elements, to be released with zk_dev_free) -- ready for zk_bn254_groth16_setup / _prove_r1cs(on_device = 1).
+int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_handle, void** d_witness, size_t* n_wires, size_t* n_public) {
+    if (!raw_json || !r1cs_handle || !d_witness) return set_err(ZK_ERR_ARG, "null pointer");
+    JParser P{raw_json, raw_json + len, ""};
+    JVal root;
+    if (!P.value(&root) || root.kind != JVal::OBJ) return set_err(ZK_ERR_ARG, "RawR1CS JSON: %s", P.err.empty() ? "not an object" : P.err.c_str());
+    const JVal *gates = root.get("gates"), *pubs = root.get("public_inputs"), *vals = root.get("values");
+    if (!gates || gates->kind != JVal::ARR || !vals || vals->kind != JVal::STR) return set_err(ZK_ERR_ARG, "RawR1CS JSON: gates / values missing");
+    // witness values: hex felt vector, decoded on the host here (they feed the host-side solver step for the product variables)
+    const std::string& vh = vals->str;
+    size_t n = 0;
+    ZK_TRY(count_from_hex(vh.data(), vh.size(), &n));
+    if (vh.size() != 8 + 64 * n) return set_err(ZK_ERR_LEN, "felt vector: %zu characters, the count says %zu felts", vh.size(), n);
+    std::vector<HFr> wv(1, HFr::one());
+    std::vector<bool> is_pub(n + 1, false);
+    if (pubs && pubs->kind == JVal::ARR)
+        for (auto& e : pubs->arr) {
+            uint32_t w;
+            if (!as_index(e, &w)) return set_err(ZK_ERR_ARG, "RawR1CS JSON: bad public input");
+            if (w >= 1 && w <= n) is_pub[w] = true;
+        }
+    std::vector<uint32_t> wire(n + 1, 0);
+    size_t npub = 1;
+    auto felt_at = [&](size_t w, HFr* out) -> bool {  // canonical values only, like fr.Vector.UnmarshalBinary
+        uint64_t t[4];
+        for (int i = 0; i < 4; i++) {
+            uint64_t v = 0;
+            for (int b = 0; b < 16; b++) {
+                int c = vh[8 + 64 * (w - 1) + 16 * (3 - i) + b], d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1;
+                if (d < 0) return false;
+                v = (v << 4) | (uint64_t)d;
+            }
+            t[i] = v;
+        }
+        if (HFr::geq_mod(t)) return false;
+        *out = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+        return true;
+    };
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t w = 1; w <= n; w++)
+            if (is_pub[w] == (pass == 0)) {
+                HFr v;
+                if (!felt_at(w, &v)) return set_err(ZK_ERR_ARG, "felt vector: invalid hex character or fr.Element encoding");
+                wire[w] = (uint32_t)wv.size();
+                wv.push_back(v);
+                if (pass == 0) npub++;
+            }
+    auto wire_of = [&](const JVal* v, uint32_t* out) -> bool {
+        uint32_t w;
+        if (!v || !as_index(*v, &w) || w < 1 || w > n) return false;
+        *out = wire[w];
+        return true;
+    };
+    std::vector<uint32_t> ptr[3], idx[3];
+    std::vector<HFr> val[3];
+    for (int m = 0; m < 3; m++) ptr[m].push_back(0);
+    auto end_row = [&]() { for (int m = 0; m < 3; m++) ptr[m].push_back((uint32_t)idx[m].size()); };
+    const HFr one = HFr::one();
+    for (auto& g : gates->arr) {
+        const JVal *mt = g.get("mul_terms"), *at = g.get("add_terms"), *kt = g.get("constant_term");
+        if (g.kind != JVal::OBJ || !mt || !at || !kt || mt->kind != JVal::ARR || at->kind != JVal::ARR || kt->kind != JVal::STR) return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed gate");
+        std::vector<std::pair<uint32_t, HFr>> terms;
+        auto add_term = [&](uint32_t x, const HFr& c) {
+            for (auto& t : terms)
+                if (t.first == x) { t.second = t.second + c; return; }
+            terms.emplace_back(x, c);
+        };
+        for (auto& t : mt->arr) {
+            const JVal* cj = t.get("coefficient");
+            HFr c;
+            uint32_t a, b;
+            if (t.kind != JVal::OBJ || !cj || cj->kind != JVal::STR || !felt_from_hex(cj->str, &c) || !wire_of(t.get("multiplicand"), &a) || !wire_of(t.get("multiplier"), &b))
+                return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed mul term");
+            if (c.is_zero()) continue;
+            const uint32_t p = (uint32_t)wv.size();
+            wv.push_back(wv[a] * wv[b] * c.inv());  // the solver's step for this internal variable
+            idx[0].push_back(a); val[0].push_back(one);
+            idx[1].push_back(b); val[1].push_back(one);
+            idx[2].push_back(p); val[2].push_back(c);
+            end_row();
+            add_term(p, c);
+        }
+        for (auto& t : at->arr) {
+            const JVal* cj = t.get("coefficient");
+            HFr c;
+            uint32_t x;
+            if (t.kind != JVal::OBJ || !cj || cj->kind != JVal::STR || !felt_from_hex(cj->str, &c) || !wire_of(t.get("sum"), &x)) return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed add term");
+            add_term(x, c);
+        }
+        HFr k;
+        if (!felt_from_hex(kt->str, &k)) return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed constant term");
+        if (!k.is_zero()) add_term(0, k);
+        idx[0].push_back(0); val[0].push_back(one);
+        for (auto& t : terms) { idx[1].push_back(t.first); val[1].push_back(t.second); }
+        end_row();
+    }
+    zk_r1cs r;
+    memset(&r, 0, sizeof r);
+    r.n_constraints = ptr[0].size() - 1;
+    r.n_wires = wv.size();
+    r.n_public = npub;
+    r.l_ptr = ptr[0].data(); r.l_idx = idx[0].data(); r.l_val = (const zk_fr*)val[0].data();
+    r.r_ptr = ptr[1].data(); r.r_idx = idx[1].data(); r.r_val = (const zk_fr*)val[1].data();
+    r.o_ptr = ptr[2].data(); r.o_idx = idx[2].data(); r.o_val = (const zk_fr*)val[2].data();
+    ZK_TRY(zk_bn254_r1cs_load(&r, r1cs_handle));
+    void* d = nullptr;
+    int rc = zk_dev_alloc(&d, wv.size() * 32);
+    if (rc == ZK_OK) rc = zk_dev_h2d(d, wv.data(), wv.size() * 32);
+    if (rc != ZK_OK) {
+        if (d) (void)zk_dev_free(d);
+        (void)zk_bn254_r1cs_free(*r1cs_handle);
+        return rc;
+    }
+    *d_witness = d;
+    if (n_wires) *n_wires = wv.size();
+    if (n_public) *n_public = npub;
+    return ZK_OK;
+}
+
 // The lowering alone, for inspection / tests: gates of an ACIR circuit as the reference's BuildSparseR1CS emits them.  Any out pointer may be
 // NULL; arrays need *n_constraints (first call with NULL arrays to size them) entries; coefficients come back as Montgomery fr.Elements.
 int zk_acir_to_sparse_r1cs(const char* acir_json, size_t acir_len, size_t n_values, size_t* n_public, size_t* n_vars, size_t* n_constraints, zk_fr* ql, zk_fr* qr,

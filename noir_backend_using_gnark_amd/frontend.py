@@ -59,3 +59,18 @@ def acir_to_sparse_r1cs(acir_json: str, n_values: int) -> dict:
     order = np.zeros(nvars.value, np.uint32)
     check(lib().zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(n_values), None, None, None, *[vp(x) for x in co], *[vp(x) for x in wi], vp(order)))
     return dict(n_public=npub.value, n_vars=nvars.value, ql=co[0], qr=co[1], qo=co[2], qm=co[3], qk=co[4], xa=wi[0], xb=wi[1], xc=wi[2], order=order)
+
+
+def groth16_r1cs_from_raw(raw_json: str):
+    """buildR1CS on the reference's RawR1CS JSON (backend/groth16/r1cs.go:9-72, src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60)
+    -> (groth16.R1CS resident in HBM, DeviceBuffer holding the full wire vector [ONE, public, secret, product variables])."""
+    from .groth16 import R1CS
+    a = _b(raw_json)
+    h, d, nw, npub = C.c_uint64(0), C.c_void_p(0), C.c_size_t(0), C.c_size_t(0)
+    rc = lib().zk_groth16_r1cs_from_raw(C.c_char_p(a), C.c_size_t(len(a)), C.byref(h), C.byref(d), C.byref(nw), C.byref(npub))
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    buf = _lib.DeviceBuffer.__new__(_lib.DeviceBuffer)
+    buf.ptr, buf.nbytes = int(d.value), nw.value * 32
+    return R1CS.from_handle(h.value, npub.value, nw.value, -1), buf

@@ -143,6 +143,12 @@ class R1CS:
         self.handle = C.c_uint64(0)
         check(lib().zk_bn254_r1cs_load(C.byref(raw), C.byref(self.handle)))
 
+    @classmethod
+    def from_handle(cls, handle: int, n_public: int, n_wires: int, n_constraints: int):
+        r = cls.__new__(cls)
+        r.n_public, r.n_wires, r.n_constraints, r._keep, r.handle = n_public, n_wires, n_constraints, [], C.c_uint64(handle)
+        return r
+
     def eval_abc(self, w) -> tuple:
         """a, b, c = L w, R w, O w on the device (the solver's output for a system without hints) -> numpy"""
         w = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
@@ -173,12 +179,17 @@ def setup(r1cs: R1CS, toxic, precompute_tables: bool = True):
 
 
 def prove_r1cs(r1cs: R1CS, pk: ProvingKey, w, r, s) -> bytes:
-    """groth16.Prove(r1cs, pk, witness): the full wire vector in, a / b / c on the device, 128 proof bytes out."""
-    w = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
+    """groth16.Prove(r1cs, pk, witness): the full wire vector in (numpy, or a DeviceBuffer already in HBM), a / b / c on the device, 128 bytes out."""
+    on_dev = isinstance(w, _lib.DeviceBuffer)
+    if on_dev:
+        wp, nw = C.c_void_p(w.ptr), r1cs.n_wires
+    else:
+        w = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
+        wp, nw = vp(w), w.shape[0]
     r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
     s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
     proof = (C.c_uint8 * 128)()
-    rc = lib().zk_bn254_groth16_prove_r1cs(r1cs.handle, pk.handle, vp(w), C.c_size_t(w.shape[0]), vp(r), vp(s), C.c_int(0), proof)
+    rc = lib().zk_bn254_groth16_prove_r1cs(r1cs.handle, pk.handle, wp, C.c_size_t(nw), vp(r), vp(s), C.c_int(int(on_dev)), proof)
     if rc == _lib.ZK_ERR_LEN:
         raise ValueError((lib().zk_last_error() or b"").decode())
     check(rc)

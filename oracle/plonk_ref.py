@@ -658,3 +658,40 @@ def plonk_pk_from_bytes(b: bytes):
         raise ValueError("proving key: %d bytes left for the permutation, %d expected" % (len(b) - o, 3 * n * 8))
     pk["perm"] = [int.from_bytes(b[o + 8 * i:o + 8 * i + 8], "big", signed=True) for i in range(3 * n)]
     return pk
+
+
+# ------------------------------------------------------------------------------------------------ RawR1CS (the reference's Groth16 payload)
+def r1cs_from_raw(raw: dict):
+    """buildR1CS of the reference's intended Groth16 FFI  [REF gnark_backend_ffi/backend/groth16/r1cs.go:9-72 (commented out), payload
+    src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60]: every mul term gets an internal product variable p with
+    (1 * multiplicand) * (1 * multiplier) = coefficient * p, every gate ends in (1 * ONE) * (sum coefficient * p + sum coefficient * x + constant * ONE) = 0.
+    Made well-defined where the sketch is not: wires = [ONE, public witnesses in witness order, the other witnesses, product variables];
+    values[w - 1] is witness w; the gate's constant term IS part of the sum (the sketch drops it); a mul term with coefficient 0 emits nothing.
+    Returns (bn254_ref.R1CS, full wire values)."""
+    values = ref.felts_unwire(bytes.fromhex(raw["values"])) if isinstance(raw["values"], str) else list(raw["values"])
+    n = len(values)
+    pub = [w for w in raw.get("public_inputs", []) if 1 <= w <= n]
+    order = [w for w in range(1, n + 1) if w in pub] + [w for w in range(1, n + 1) if w not in pub]
+    wire = {w: 1 + k for k, w in enumerate(order)}
+    wvals = [1] + [values[w - 1] % R for w in order]
+    h2i = lambda h: int(h, 16) % R
+    cons = []
+    for g in raw["gates"]:
+        terms = {}
+        for t in g["mul_terms"]:
+            c = h2i(t["coefficient"])
+            if c == 0:
+                continue
+            a, b = wire[t["multiplicand"]], wire[t["multiplier"]]
+            p = len(wvals)
+            wvals.append(wvals[a] * wvals[b] % R * inv(c, R) % R)
+            cons.append(({a: 1}, {b: 1}, {p: c}))
+            terms[p] = (terms.get(p, 0) + c) % R
+        for t in g["add_terms"]:
+            x = wire[t["sum"]]
+            terms[x] = (terms.get(x, 0) + h2i(t["coefficient"])) % R
+        k = h2i(g["constant_term"])
+        if k:
+            terms[0] = (terms.get(0, 0) + k) % R
+        cons.append(({0: 1}, terms, {}))
+    return ref.R1CS(1 + len(pub), len(wvals) - 1 - len(pub), cons), wvals

@@ -991,3 +991,41 @@ def test_r1cs_sparse_mat_vec_at_2p12_constraints():
     ea, eb, ec = r1.eval_abc(w)
     assert from_mont_limbs(a) == ea and from_mont_limbs(b) == eb and from_mont_limbs(c) == ec
     dev.free()
+
+
+def test_groth16_from_raw_r1cs_json():
+    """The reference's intended Groth16 payload (RawR1CS JSON, src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60) through buildR1CS
+    (backend/groth16/r1cs.go:9-72, restated in frontend.hip and in oracle/plonk_ref.r1cs_from_raw), Setup and Prove on the device: the proof bytes
+    equal the oracle's on the same (toxic waste, r, s) and the oracle's pairing verifier accepts them."""
+    import json as js
+    from noir_backend_using_gnark_amd import frontend as fe
+    from oracle import plonk_ref as pl
+    hx = lambda v: "%064x" % (v % ref.R)
+    w1, w2 = 7, 11
+    w3 = w1 * w2 % ref.R
+    w4 = (2 * w3 * w1 + 3 * w2 + 5) % ref.R
+    values = [w1, w2, w3, w4, 123456789]
+    raw = {"gates": [{"mul_terms": [{"coefficient": hx(1), "multiplicand": 1, "multiplier": 2}], "add_terms": [{"coefficient": hx(-1), "sum": 3}], "constant_term": hx(0)},
+                     {"mul_terms": [{"coefficient": hx(2), "multiplicand": 3, "multiplier": 1}, {"coefficient": hx(0), "multiplicand": 5, "multiplier": 5}],
+                      "add_terms": [{"coefficient": hx(3), "sum": 2}, {"coefficient": hx(-1), "sum": 4}], "constant_term": hx(5)}],
+           "public_inputs": [4, 2], "values": ref.felts_wire(values).hex(), "num_variables": 6, "num_constraints": 2}
+    r1, wv = pl.r1cs_from_raw(raw)
+    a, b, c = r1.eval_abc(wv)
+    assert all((x * y - z) % ref.R == 0 for x, y, z in zip(a, b, c)) and r1.n_public == 3 and len(r1.constraints) == 4
+    tox, rs = tuple(ref.rand_felts(0xA0, 5)), tuple(ref.rand_felts(0xA1, 2))
+    opk, ovk = ref.groth16_setup(r1, *tox)
+    proof = ref.groth16_prove(opk, r1.n_public, a, b, c, wv, *rs)
+    assert ref.groth16_verify(ovk, proof, wv[:r1.n_public])
+    want = ref.groth16_proof_bytes(*proof)
+    dev, d_w = fe.groth16_r1cs_from_raw(js.dumps(raw))
+    assert (dev.n_public, dev.n_wires) == (r1.n_public, r1.n_wires)
+    assert from_mont_limbs(d_w.to_numpy(np.uint64, (dev.n_wires, 4))) == wv
+    pk, vk = zk.setup(dev, mont_limbs(list(tox)))
+    assert zk.prove_r1cs(dev, pk, d_w, mont_limbs([rs[0]])[0], mont_limbs([rs[1]])[0]) == want
+    assert [p.tobytes() for p in vk["g1_k"]] == [ref.g1_affine_mont_bytes(p) for p in ovk["g1_ic"]]
+    for bad in ("{}", '{"gates": [], "values": "zz"}', js.dumps(dict(raw, values=raw["values"][:-2])),
+                js.dumps(dict(raw, gates=[{"mul_terms": [{"coefficient": hx(1), "multiplicand": 9, "multiplier": 1}], "add_terms": [], "constant_term": hx(0)}]))):
+        with pytest.raises(ValueError):
+            fe.groth16_r1cs_from_raw(bad)
+    pk.free()
+    dev.free()
