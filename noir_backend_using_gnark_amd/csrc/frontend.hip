@@ -362,9 +362,10 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
 // buildR1CS of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:9-72, commented out there; payload RawR1CS of
 // src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60: {"gates":[{"mul_terms":[{"coefficient","multiplicand","multiplier"}],"add_terms":
 // [{"coefficient","sum"}],"constant_term"}],"public_inputs","values" (hex felt vector),"num_variables","num_constraints"}): every mul term gets an
-// internal product variable p with (1 * multiplicand) * (1 * multiplier) = coefficient * p; every gate ends in
+// internal product variable p with (1 * multiplicand) * (1 * multiplier) = 1 * p; every gate ends in
 // (1 * ONE) * (sum coefficient * p + sum coefficient * x + constant * ONE) = 0.  Made well-defined where the sketch is not: wires = [ONE, public
-// witnesses in witness order, the other witnesses, product variables]; values[w - 1] is witness w; the constant term IS in the sum (the sketch
+// witnesses in witness order, the other witnesses, product variables]; values[w - 1] is witness w; the product variable is the plain product (the
+// sketch puts the coefficient on the product constraint's output AND on the term, which cancels it); the constant term IS in the sum (the sketch
 // drops it); a mul term with coefficient 0 emits nothing.  Out: a resident R1CS (zk_bn254_r1cs_*) and the full wire vector in HBM
 // (*d_witness: n_wires Montgomery elements, to be released with zk_dev_free) -- ready for zk_bn254_groth16_setup / _prove_r1cs(on_device = 1).
 int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_handle, void** d_witness, size_t* n_wires, size_t* n_public) {
@@ -441,10 +442,10 @@ int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_ha
                 return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed mul term");
             if (c.is_zero()) continue;
             const uint32_t p = (uint32_t)wv.size();
-            wv.push_back(wv[a] * wv[b] * c.inv());  // the solver's step for this internal variable
+            wv.push_back(wv[a] * wv[b]);  // the solver's step for this internal variable
             idx[0].push_back(a); val[0].push_back(one);
             idx[1].push_back(b); val[1].push_back(one);
-            idx[2].push_back(p); val[2].push_back(c);
+            idx[2].push_back(p); val[2].push_back(one);
             end_row();
             add_term(p, c);
         }

@@ -664,9 +664,10 @@ def plonk_pk_from_bytes(b: bytes):
 def r1cs_from_raw(raw: dict):
     """buildR1CS of the reference's intended Groth16 FFI  [REF gnark_backend_ffi/backend/groth16/r1cs.go:9-72 (commented out), payload
     src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60]: every mul term gets an internal product variable p with
-    (1 * multiplicand) * (1 * multiplier) = coefficient * p, every gate ends in (1 * ONE) * (sum coefficient * p + sum coefficient * x + constant * ONE) = 0.
+    (1 * multiplicand) * (1 * multiplier) = 1 * p, every gate ends in (1 * ONE) * (sum coefficient * p + sum coefficient * x + constant * ONE) = 0.
     Made well-defined where the sketch is not: wires = [ONE, public witnesses in witness order, the other witnesses, product variables];
-    values[w - 1] is witness w; the gate's constant term IS part of the sum (the sketch drops it); a mul term with coefficient 0 emits nothing.
+    values[w - 1] is witness w; the product variable is the plain product (the sketch puts the coefficient on the product constraint's output AND
+    on the term, which cancels it); the gate's constant term IS part of the sum (the sketch drops it); a mul term with coefficient 0 emits nothing.
     Returns (bn254_ref.R1CS, full wire values)."""
     values = ref.felts_unwire(bytes.fromhex(raw["values"])) if isinstance(raw["values"], str) else list(raw["values"])
     n = len(values)
@@ -684,8 +685,8 @@ def r1cs_from_raw(raw: dict):
                 continue
             a, b = wire[t["multiplicand"]], wire[t["multiplier"]]
             p = len(wvals)
-            wvals.append(wvals[a] * wvals[b] % R * inv(c, R) % R)
-            cons.append(({a: 1}, {b: 1}, {p: c}))
+            wvals.append(wvals[a] * wvals[b] % R)
+            cons.append(({a: 1}, {b: 1}, {p: 1}))
             terms[p] = (terms.get(p, 0) + c) % R
         for t in g["add_terms"]:
             x = wire[t["sum"]]
