@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -405,6 +406,28 @@ static int commit(const PlonkPK* P, Slot* s, hipStream_t st, const Fr* d_p, size
     ZK_TRY(slot_sync(s, st));  // the MSM runs on a stream slot of its own
     return zk_bn254_msm_bases_dev(P->srs, 0, d_p, len, &kMont, out);
 }
+
+// A commitment in flight on a host thread of its own (the MSM entry point is synchronous and re-entrant: each call takes a stream slot), so that
+// independent commitments -- l, r, o; h1, h2, h3; the opening of z next to the linearised polynomial -- and the transforms the main stream keeps
+// issuing overlap on the GPU: the bandwidth-bound scalar preparation (digits, sort, task plan) of one MSM runs under the ALU-bound accumulate of another.
+struct AsyncCommit {
+    std::thread th;
+    int rc = ZK_OK;
+    std::string err;
+    Affine<HFp> out;
+    void start(const PlonkPK* P, const Fr* d_p, size_t len) {
+        th = std::thread([this, P, d_p, len] {
+            rc = zk_bn254_msm_bases_dev(P->srs, 0, d_p, len, &kMont, &out);
+            if (rc != ZK_OK) err = zk_last_error();
+        });
+    }
+    int join() {
+        if (th.joinable()) th.join();
+        return rc == ZK_OK ? ZK_OK : set_err(rc, "%s", err.c_str());
+    }
+    ~AsyncCommit() { if (th.joinable()) th.join(); }
+};
+static const bool g_plonk_serial = getenv("ZKMI_PLONK_SERIAL") && atoi(getenv("ZKMI_PLONK_SERIAL")) == 1;  // A/B switch: commitments one after the other
 
 // Lagrange (regular) -> canonical (regular) on the small domain, in place: FFTInverse(DIF) + BitReverse, as setup.go / iop.ToCanonical do
 static int to_canonical(Slot* s, hipStream_t st, Fr* d, unsigned logn) {
@@ -959,7 +982,25 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         B.b[0] = to_dev(bl[2 * k]); B.b[1] = to_dev(bl[2 * k + 1]); B.b[2] = Fr::zero();
         ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, can3[k], (uint32_t)n, B);
     }
-    for (int k = 0; k < 3; k++) ZK_TRY(commit(P, s, st, can3[k], n + 2, &c_lro[k]));
+    // the three commitments run on threads of their own while this stream already evaluates l, r, o on the big coset (no challenge needed for that)
+    const Fr* small5[5] = {bl_, br_, bo_, bz_, qkc};
+    const size_t len5[5] = {n + 2, n + 2, n + 2, n + 3, n};
+    if (g_plonk_serial) {
+        for (int k = 0; k < 3; k++) ZK_TRY(commit(P, s, st, can3[k], n + 2, &c_lro[k]));
+        for (int k = 0; k < 3; k++) ZK_TRY(to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P));
+    } else {
+        AsyncCommit ac[3];
+        ZK_TRY(slot_sync(s, st));
+        for (int k = 0; k < 3; k++) ac[k].start(P, can3[k], n + 2);
+        int rc = ZK_OK;
+        for (int k = 0; k < 3 && rc == ZK_OK; k++) rc = to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P);
+        for (int k = 0; k < 3; k++) {
+            int r2 = ac[k].join();
+            if (rc == ZK_OK) rc = r2;
+            c_lro[k] = ac[k].out;
+        }
+        ZK_TRY(rc);
+    }
 
     // ---- gamma, beta (transcript "gamma" binds the verifying key and the public inputs, then the three digests)
     FsTranscript fs{"gamma", "beta", "alpha", "zeta"};
@@ -990,20 +1031,29 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         for (int i = 0; i < 3; i++) B.b[i] = to_dev(bl[6 + i]);
         ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, bz_, (uint32_t)n, B);
     }
-    ZK_TRY(commit(P, s, st, bz_, n + 3, &c_z));
+    // commitment to z on its own thread; meanwhile: qk completed with the public inputs (canonical), z and qk on the big coset
+    {
+        AsyncCommit az;
+        ZK_TRY(slot_sync(s, st));
+        if (g_plonk_serial) ZK_TRY(commit(P, s, st, bz_, n + 3, &c_z));
+        else az.start(P, bz_, n + 3);
+        int rc = ZK_OK;
+        if (hipMemcpyAsync(qkc, P->lqk, n * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+        if (rc == ZK_OK && npub && hipMemcpyAsync(qkc, d_sol, npub * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+        if (rc == ZK_OK) rc = to_canonical(s, st, qkc, logn);
+        for (int k = 3; k < 5 && rc == ZK_OK; k++) rc = to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P);
+        if (!g_plonk_serial) {
+            int r2 = az.join();
+            if (rc == ZK_OK) rc = r2;
+            c_z = az.out;
+        }
+        ZK_TRY(rc);
+    }
     fs.bind_g1(2, c_z);
     HFr alpha = fs.challenge(2);
     if (challenges) alpha = pin[2];
 
-    // ---- qk completed with the public inputs, canonical
-    ZK_HIP(hipMemcpyAsync(qkc, P->lqk, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    if (npub) ZK_HIP(hipMemcpyAsync(qkc, d_sol, npub * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    ZK_TRY(to_canonical(s, st, qkc, logn));
-
     // ---- quotient on the coset of the big domain
-    const Fr* small5[5] = {bl_, br_, bo_, bz_, qkc};
-    const size_t len5[5] = {n + 2, n + 2, n + 2, n + 3, n};
-    for (int k = 0; k < 5; k++) ZK_TRY(to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P));
     {
         QuotArgs A;
         A.el = P->w_big[0]; A.er = P->w_big[1]; A.eo = P->w_big[2]; A.ez = P->w_big[3]; A.eqk = P->w_big[4];
@@ -1034,7 +1084,20 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     ZK_HIP(hipMemsetAsync(d_flag, 0, 4, st));
     ZK_LAUNCH(s, st, "plonk_quotient_check", k_any_nonzero, dim3(grid_of(N4 - 3 * (n + 2))), dim3(256), 0, (const Fr*)(h + 3 * (n + 2)), N4 - 3 * (n + 2), d_flag);
     ZK_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st));
-    for (int k = 0; k < 3; k++) ZK_TRY(commit(P, s, st, h + k * (n + 2), n + 2, &c_h[k]));
+    if (g_plonk_serial) {
+        for (int k = 0; k < 3; k++) ZK_TRY(commit(P, s, st, h + k * (n + 2), n + 2, &c_h[k]));
+    } else {
+        AsyncCommit ah[3];
+        ZK_TRY(slot_sync(s, st));
+        for (int k = 0; k < 3; k++) ah[k].start(P, h + k * (n + 2), n + 2);
+        int rc = ZK_OK;
+        for (int k = 0; k < 3; k++) {
+            int r2 = ah[k].join();
+            if (rc == ZK_OK) rc = r2;
+            c_h[k] = ah[k].out;
+        }
+        ZK_TRY(rc);
+    }
     if (h_flag) return set_err(ZK_ERR_ARG, "the solution does not satisfy the constraint system (the quotient is not a polynomial)");
     for (int k = 0; k < 3; k++) fs.bind_g1(3, c_h[k]);
     HFr zeta = fs.challenge(3);
@@ -1048,7 +1111,10 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     ZK_TRY(poly_divide_dev(s, st, bz_, n + 3, zeta_sh, SB, quo, d_vals + 5));
     HFr ev[8];
     ZK_HIP(hipMemcpyAsync(ev, d_vals, 6 * sizeof(Fr), hipMemcpyDeviceToHost, st));
-    ZK_TRY(commit(P, s, st, quo, n + 2, &c_zopen));  // synchronises: ev[] is valid
+    ZK_TRY(slot_sync(s, st));  // ev[] is valid, the quotient of z is complete
+    AsyncCommit azo;
+    if (g_plonk_serial) ZK_TRY(commit(P, s, st, quo, n + 2, &c_zopen));
+    else azo.start(P, quo, n + 2);  // joined at the end of the proof: nothing below depends on it
     const HFr lz = ev[0], rz = ev[1], oz = ev[2], s1z = ev[3], s2z = ev[4], zu = ev[5];
 
     // ---- linearised polynomial
@@ -1118,6 +1184,10 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     ZK_TRY(poly_divide_dev(s, st, fold, n + 3, zeta, SB, fold, d_vals + 8));
     ZK_TRY(commit(P, s, st, fold, n + 2, &c_batch));
 
+    if (!g_plonk_serial) {
+        ZK_TRY(azo.join());
+        c_zopen = azo.out;
+    }
     // ---- Proof.WriteTo
     uint8_t* o = proof_out;
     for (const Affine<HFp>* d : {&c_lro[0], &c_lro[1], &c_lro[2], &c_z, &c_h[0], &c_h[1], &c_h[2]}) { g1_compress(*d, o); o += 32; }
