@@ -56,6 +56,8 @@ struct PassArgs {
     int canonical;       // 29-bit-limb passes: last pass of the transform -> canonical image; else a lazily reduced 256-bit intermediate
     const Fr* tw2;       // fused inverse-then-forward pass (k_ntt_pass29_if): twiddles of the forward half
     const Fr* src;       // 29-bit-limb passes: read the tile from here instead of `data` (first pass of an out-of-place transform) or null
+    uint32_t tw_and;     // EXPERIMENT (ZKMI_NTT_TWMASK): twiddle index mask -- 0xffffffff in production; a small mask makes every twiddle load an L1 hit
+                         // (wrong results, right timing): the upper bound of what any twiddle-staging scheme could gain
 };
 
 __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, unsigned t) {
@@ -229,7 +231,7 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
                 const unsigned e1 = e0 | (1u << bitl);
                 const size_t g0 = base + ((size_t)(mid0 | (e0 << ql)) << A.bit_lo) + l;
                 const size_t j = g0 & (((size_t)1 << b) - 1);
-                const U29 w = u29_unpack(gload_fr(A.tw + (j << (A.logn - 1 - b))));  // b == 0: entry 0 = 2^261 mod r, the unit
+                const U29 w = u29_unpack(gload_fr(A.tw + ((j << (A.logn - 1 - b)) & A.tw_and)));  // b == 0: entry 0 = 2^261 mod r, the unit
                 if (DIF) {
                     U29 d;
                     if (sl == 0) d = u29r_sub<16>(x[e0], x[e1]);
@@ -462,7 +464,10 @@ static std::vector<PassPlan> plan_passes(unsigned logn) {
     return passes;
 }
 
-static int launch_pass(Slot* s, hipStream_t st, const PassArgs& A, bool sat) {
+static const uint32_t g_tw_and = getenv("ZKMI_NTT_TWMASK") ? (uint32_t)strtoul(getenv("ZKMI_NTT_TWMASK"), nullptr, 0) : 0xffffffffu;
+static int launch_pass(Slot* s, hipStream_t st, const PassArgs& A_, bool sat) {
+    PassArgs A = A_;
+    A.tw_and = g_tw_and;
     unsigned E = 1u << (A.k + A.logL);
     size_t tiles = ((size_t)1 << A.logn) / E;
     const char* name = A.logL ? "ntt_pass_strided" : "ntt_pass_contig";
@@ -515,6 +520,7 @@ static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* 
     const size_t npass = passes.size();
     PassArgs A;
     A.data = data; A.logn = logn; A.pre = nullptr; A.post = nullptr; A.has_post_const = 0; A.post_const = Fr::zero(); A.tw2 = nullptr;
+    A.tw_and = g_tw_and;
     A.src = (src && src != data) ? src : nullptr;  // consumed by whichever pass runs first
     for (size_t idx = npass - 1; idx >= 1; idx--) {  // strided passes of the inverse transform, top bits first
         const PassPlan& p = passes[idx];

@@ -848,6 +848,11 @@ int zk_bn254_plonk_pk_write(uint64_t handle, int as_hex, void* out, size_t cap, 
         mu = P->mu;
     }
     std::lock_guard<std::mutex> key_lock(*mu);
+    {
+        std::lock_guard<std::mutex> lk(g_ppk_mu);
+        auto it = g_ppks.find(handle);
+        if (it == g_ppks.end() || it->second != P) return set_err(ZK_ERR_HANDLE, "PLONK proving key %llu was freed", (unsigned long long)handle);
+    }
     const size_t n = P->n, nbytes = PK_HEAD + 9 * (4 + 32 * n) + 24 * n, need = as_hex ? 2 * nbytes : nbytes;
     *out_len = need;
     if (cap < need) return set_err(ZK_ERR_ARG, "output holds %zu bytes, %zu needed", cap, need);
@@ -938,8 +943,13 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         P = it->second;
         mu = P->mu;
     }
-    if (n_vars != P->n_vars) return set_err(ZK_ERR_LEN, "len(solution) = %zu != %zu variables of the constraint system", n_vars, P->n_vars);
     std::lock_guard<std::mutex> proof_lock(*mu);
+    {   // the key may have been freed between the lookup and the lock (pk_free waits on this mutex and then destroys it)
+        std::lock_guard<std::mutex> lk(g_ppk_mu);
+        auto it = g_ppks.find(handle);
+        if (it == g_ppks.end() || it->second != P) return set_err(ZK_ERR_HANDLE, "PLONK proving key %llu was freed", (unsigned long long)handle);
+    }
+    if (n_vars != P->n_vars) return set_err(ZK_ERR_LEN, "len(solution) = %zu != %zu variables of the constraint system", n_vars, P->n_vars);
     const size_t n = P->n, N4 = P->N4, npub = P->n_public;
     const unsigned logn = P->logn, logN4 = P->logN4;
     SlotGuard g;
