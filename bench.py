@@ -211,6 +211,65 @@ def plonk_block(L, lib, log_n, reps=3):
 R_FR = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 
 
+def micro_block(L, lib, zk, log_n):
+    """BASELINE.json configs[4] on one GPU: standalone G1 MSM and Fr NTT of 2^log_n, inputs resident in HBM.  Each figure is tied to a check that is not
+    the same code path run twice: the MSM equals the recombination of two partial MSMs split at an odd position AND the window-table path over the same
+    points registered as resident bases; the transform inverts.  (tools/micro_bench.py is the stand-alone version.)"""
+    from noir_backend_using_gnark_amd import bn254 as zb
+    MONT = zk.MultiExpConfig(scalars_mont=True)
+    n = 1 << log_n
+    pts, sc = lib.DeviceBuffer(n * 64), lib.DeviceBuffer(n * 32)
+    lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(pts.ptr), C.c_size_t(n), C.c_uint64(0xB1), None))
+    lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(sc.ptr), C.c_size_t(n), C.c_uint64(0xC), C.c_int(1), C.c_int(0), None))
+    rb = zb.ResidentBases(pts, n=n)
+    r0 = zb.g1_multi_exp_dev(pts.ptr, sc.ptr, n, config=MONT)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = zb.g1_multi_exp_dev(pts.ptr, sc.ptr, n, config=MONT)
+    dt = (time.perf_counter() - t0) / reps
+    m = (n // 3) | 1
+    parts = np.stack([zb.g1_multi_exp_dev(pts.ptr, sc.ptr, m, config=MONT, partial=True), zb.g1_multi_exp_dev(pts.ptr + m * 64, sc.ptr + m * 32, n - m, config=MONT, partial=True)])
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rt = rb.multi_exp_dev(sc, n, config=MONT)
+    dt_tab = (time.perf_counter() - t0) / reps
+    rb.free()
+    out = {"points": n, "g1_msm_ms": round(dt * 1e3, 2), "g1_scalar_muls_per_s": round(n / dt, 1), "g1_msm_hbm_frac": round(96 * n / dt / 8e12, 5),
+           "g1_msm_window_tables_ms": round(dt_tab * 1e3, 2), "equals_split_recombination": bool((zb.g1_sum_partials(parts) == r).all() and (r == r0).all()),
+           "equals_window_table_path": bool((rt == r).all())}
+    dom = zk.Domain(n)
+    head = sc.to_numpy(np.uint64, (4096, 4))
+    dom.fft(sc, zk.DIF)
+    dom.fft_inverse(sc, zk.DIT)
+    out["ntt_inverse_of_forward_is_identity"] = bool((sc.to_numpy(np.uint64, (4096, 4)) == head).all())
+    t0 = time.perf_counter()
+    for _ in range(5):
+        lib.check(L.zk_bn254_ntt_dev(C.c_void_p(sc.ptr), C.c_uint32(log_n), C.c_int(0), C.c_int(zk.DIF), C.c_int(0), C.c_void_p(0)))
+    lib.check(L.zk_dev_sync())
+    dtn = (time.perf_counter() - t0) / 5
+    out.update(ntt_ms=round(dtn * 1e3, 3), ntt_elements_per_s=round(n / dtn, 1), ntt_hbm_frac=round(64 * n / dtn / 8e12, 5))
+    pts.free()
+    sc.free()
+    return out
+
+
+def srs_block(lib, n=1_000_000):
+    """SURVEY §8 row f1: kzg.SRS.ReadFrom of the reference's SRS size (10^6 points, backend/common.go:137) with the G1 points decompressed on the device;
+    check: WriteTo(ReadFrom(x)) == x."""
+    from noir_backend_using_gnark_amd import kzg
+    srs = kzg.new_srs(n, np.array([0x1234567, 0x89abcdef, 0x1111, 0x0222], dtype=np.uint64), table_window_bits=-1)
+    raw = srs.write()
+    srs.free()
+    kzg.read_srs(raw, table_window_bits=-1).free()
+    t0 = time.perf_counter()
+    s2 = kzg.read_srs(raw, table_window_bits=-1)
+    dt = time.perf_counter() - t0
+    ok = s2.write() == raw
+    s2.free()
+    return {"points": n, "read_ms": round(dt * 1e3, 2), "points_per_s": round(n / dt, 1), "bytes": len(raw), "write_of_read_is_identity": bool(ok)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +286,7 @@ def main():
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the host-input (PCIe-inclusive) measurement")
     ap.add_argument("--no-plonk", action="store_true", help="skip the PLONK block (configs[3]: plonk.Prove at 2^22 gates, verified by the oracle's pairing verifier)")
     ap.add_argument("--plonk-log-n", type=int, default=22)
+    ap.add_argument("--no-micro", action="store_true", help="skip the configs[4] block (2^26-point G1 MSM + 2^26 NTT) and the SRS-load block")
     ap.add_argument("--verify-2p24-oracle", action="store_true", help="also check the 2^24 proof bytes against the CPU oracle (~2 min on 128 cores)")
     args = ap.parse_args()
 
@@ -447,6 +507,15 @@ def main():
         out["plonk_2p%d" % args.plonk_log_n] = plonk_block(L, _lib, args.plonk_log_n)
         if not out["plonk_2p%d" % args.plonk_log_n]["proof_verifies"]:
             out["parity_error"] = "PLONK: the proof does not verify"
+        inst = None
+    # ---- configs[4] (standalone 2^26 MSM / NTT) and the SRS load of the reference's size
+    if single and log_n == 20 and not args.no_micro:
+        if inst is not None:
+            inst.free()
+        out["micro_2p26"] = micro_block(L, _lib, zk, 26)
+        out["srs_read_1e6"] = srs_block(_lib)
+        if not (out["micro_2p26"]["equals_split_recombination"] and out["micro_2p26"]["equals_window_table_path"] and out["srs_read_1e6"]["write_of_read_is_identity"]):
+            out["parity_error"] = "micro-benchmark cross-check failed"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
