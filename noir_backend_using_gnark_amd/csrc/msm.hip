@@ -93,6 +93,7 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
     const uint32_t B = 1u << (c - 1);
     const uint32_t sentinel = table_stride ? B : W * B;
     uint32_t carry = 0;
+    unsigned next_row = row_first, wl = 0;  // table mode: the next window this rank owns and its row in the rank's table
     for (unsigned w = 0; w < W; w++) {
         unsigned bit = w * c, limb = bit >> 5, off = bit & 31;
         uint64_t v = 0;
@@ -111,11 +112,12 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
         }
         size_t o = (size_t)w * n + i;
         if (table_stride) {
-            if (w < row_first || (w - row_first) % row_step) continue;
-            const unsigned wl = (w - row_first) / row_step;
+            if (w != next_row) continue;
             o = (size_t)wl * n + i;
             keys[o] = mag ? (mag - 1) : sentinel;
             vals[o] = ((wl * table_stride + i) << 1) | neg;
+            next_row += row_step;
+            wl++;
         } else {
             keys[o] = mag ? (w * B + (mag - 1)) : sentinel;
             vals[o] = (i << 1) | neg;
