@@ -403,17 +403,45 @@ struct TailPt<Fp2> {
 };
 #endif
 
-// buckets cut into several tasks: one WAVE folds the bucket's partials into the first one
+// buckets cut into several tasks: the bucket's partials are folded into the first one.  A bucket can hold a large share of all points (real
+// witnesses are mostly 0 / 1; in table mode a top window of only a few bits -- c = 21 leaves 2 -- sends EVERY point to one of four buckets), i.e.
+// thousands of partials: they are cut into segments of `seg` partials, one wave folds one segment into the segment's first partial (blockIdx.y =
+// segment), and a second launch folds the <= 64 segment heads -- instead of one wave walking the whole list (156 serial rounds of 64 at 2^22 / c = 21).
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list,
-                                                    const uint32_t* num_multi) {
+                                                    const uint32_t* num_multi, uint32_t seg) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nm = *num_multi, sg = blockIdx.y;
+    for (uint32_t m = blockIdx.x * 4 + wave; m < nm; m += gridDim.x * 4) {
+        uint32_t b = multi_list[m];
+        uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        const uint32_t head = t0 + sg * seg;
+        if (head >= t1) continue;
+        TailPt<F> acc = TailPt<F>::inf();
+        for (uint32_t s0 = head; s0 < t1; s0 += gridDim.y * seg) {  // segments sg, sg + 64, ... (more than 64 segments: > 65,536 partials in one bucket)
+            const uint32_t s1 = min(s0 + seg, t1);
+            for (uint32_t t = s0 + lane; t < s1; t += 64) acc.add(TailPt<F>::load(partial + t));
+        }
+        for (unsigned d = 32; d > 0; d >>= 1) {
+            TailPt<F> o = acc.shfl_down(d);
+            if (lane < d) acc.add(o);
+        }
+        if (lane == 0) acc.store(partial + head);
+    }
+}
+// second level: the heads of a bucket's segments (lane = segment) into the bucket's first partial
+template <class F>
+__global__ __launch_bounds__(256) void k_fold_heads(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list, const uint32_t* num_multi,
+                                                    uint32_t seg) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nm = *num_multi;
     for (uint32_t m = blockIdx.x * 4 + wave; m < nm; m += gridDim.x * 4) {
         uint32_t b = multi_list[m];
         uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        uint32_t nseg = min((t1 - t0 + seg - 1) / seg, 64u);
+        if (nseg <= 1) continue;
         TailPt<F> acc = TailPt<F>::inf();
-        for (uint32_t t = t0 + lane; t < t1; t += 64) acc.add(TailPt<F>::load(partial + t));
+        if (lane < nseg) acc = TailPt<F>::load(partial + t0 + lane * seg);
         for (unsigned d = 32; d > 0; d >>= 1) {
             TailPt<F> o = acc.shfl_down(d);
             if (lane < d) acc.add(o);
@@ -771,7 +799,14 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     for (int b = 0; b < nb; b++) {
         Slot* s = sl[b];
         hipStream_t st = sts[b];
-        ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
+        {
+            // segments of 1024 partials, 64 segment slots per bucket (blockIdx.y); only when a bucket CAN exceed one segment
+            const uint32_t seg = 1024;
+            const size_t max_tasks_per_bucket = (size_t)P.total / L + 1;
+            const unsigned nseg = max_tasks_per_bucket > seg ? 64u : 1u;
+            ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024, nseg), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi, seg);
+            if (nseg > 1) ZK_LAUNCH(s, st, "msm_fold_heads", (k_fold_heads<F>), dim3(256), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi, seg);
+        }
         // ---- 6. bucket reduce
         bool quad = false;
         if constexpr (sizeof(F) == sizeof(Fp)) quad = jobs[b]->quad_tail;
@@ -1194,6 +1229,9 @@ static int bases_register(const void* points, size_t n, int is_g2, uint64_t* han
     if (n && table_c != -1 && (table_c > 0 || n >= 4096)) {
         b.tab.c = table_c > 0 ? (unsigned)table_c : msm_pick_window_table(n);
         b.tab.stride = n;
+        // experiment switches: level sizes of the reduction tail of commits against registered bases (0 = the latency-structured default)
+        b.tab.l1_m = getenv("ZKMI_BASES_L1M") ? (unsigned)atoi(getenv("ZKMI_BASES_L1M")) : 0;
+        b.tab.l2_m = getenv("ZKMI_BASES_L2M") ? (unsigned)atoi(getenv("ZKMI_BASES_L2M")) : 0;
         const size_t Wd = (255 + b.tab.c - 1) / b.tab.c, tbytes = Wd * n * (is_g2 ? 128 : 64);
         size_t free_b = 0, total_b = 0;
         ZK_HIP(hipMemGetInfo(&free_b, &total_b));
