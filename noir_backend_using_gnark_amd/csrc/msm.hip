@@ -403,46 +403,24 @@ struct TailPt<Fp2> {
 };
 #endif
 
-// buckets cut into several tasks: the bucket's partials are folded into the first one.  A bucket can hold a large share of all points (real
-// witnesses are mostly 0 / 1; in table mode a top window of only a few bits -- c = 21 leaves 2 -- sends EVERY point to one of four buckets), i.e.
-// thousands of partials: they are cut into segments of `seg` partials, one wave folds one segment into the segment's first partial (blockIdx.y =
-// segment), and a second launch folds the <= 64 segment heads -- instead of one wave walking the whole list (156 serial rounds of 64 at 2^22 / c = 21).
+// buckets cut into several tasks: one WAVE folds the bucket's partials into the first one.  Most split buckets have 2 - 4 partials (the dense
+// population under a narrow top window), so the butterfly only runs the levels the count needs: 2 additions for 3 partials instead of 6.
+// (Measured and rejected, round 2: giant buckets -- 0/1-heavy witnesses -- folded by up to 64 waves in segments + a second launch over the segment
+// heads: the 64x larger grid costs more than the serial rounds it saves; PLONK 2^22 87.6 -> 90.9 ms.)
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list,
-                                                    const uint32_t* num_multi, uint32_t seg) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t nm = *num_multi, sg = blockIdx.y;
-    for (uint32_t m = blockIdx.x * 4 + wave; m < nm; m += gridDim.x * 4) {
-        uint32_t b = multi_list[m];
-        uint32_t t0 = task_off[b], t1 = task_off[b + 1];
-        const uint32_t head = t0 + sg * seg;
-        if (head >= t1) continue;
-        TailPt<F> acc = TailPt<F>::inf();
-        for (uint32_t s0 = head; s0 < t1; s0 += gridDim.y * seg) {  // segments sg, sg + 64, ... (more than 64 segments: > 65,536 partials in one bucket)
-            const uint32_t s1 = min(s0 + seg, t1);
-            for (uint32_t t = s0 + lane; t < s1; t += 64) acc.add(TailPt<F>::load(partial + t));
-        }
-        for (unsigned d = 32; d > 0; d >>= 1) {
-            TailPt<F> o = acc.shfl_down(d);
-            if (lane < d) acc.add(o);
-        }
-        if (lane == 0) acc.store(partial + head);
-    }
-}
-// second level: the heads of a bucket's segments (lane = segment) into the bucket's first partial
-template <class F>
-__global__ __launch_bounds__(256) void k_fold_heads(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list, const uint32_t* num_multi,
-                                                    uint32_t seg) {
+                                                    const uint32_t* num_multi) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nm = *num_multi;
     for (uint32_t m = blockIdx.x * 4 + wave; m < nm; m += gridDim.x * 4) {
         uint32_t b = multi_list[m];
         uint32_t t0 = task_off[b], t1 = task_off[b + 1];
-        uint32_t nseg = min((t1 - t0 + seg - 1) / seg, 64u);
-        if (nseg <= 1) continue;
         TailPt<F> acc = TailPt<F>::inf();
-        if (lane < nseg) acc = TailPt<F>::load(partial + t0 + lane * seg);
-        for (unsigned d = 32; d > 0; d >>= 1) {
+        for (uint32_t t = t0 + lane; t < t1; t += 64) acc.add(TailPt<F>::load(partial + t));
+        const uint32_t cnt = min(t1 - t0, 64u);  // lanes that hold something (uniform over the wave)
+        unsigned first = 32;
+        while (first >= cnt && first > 0) first >>= 1;  // largest power of two below cnt
+        for (unsigned d = first; d > 0; d >>= 1) {
             TailPt<F> o = acc.shfl_down(d);
             if (lane < d) acc.add(o);
         }
@@ -799,14 +777,7 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     for (int b = 0; b < nb; b++) {
         Slot* s = sl[b];
         hipStream_t st = sts[b];
-        {
-            // segments of 1024 partials, 64 segment slots per bucket (blockIdx.y); only when a bucket CAN exceed one segment
-            const uint32_t seg = 1024;
-            const size_t max_tasks_per_bucket = (size_t)P.total / L + 1;
-            const unsigned nseg = max_tasks_per_bucket > seg ? 64u : 1u;
-            ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024, nseg), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi, seg);
-            if (nseg > 1) ZK_LAUNCH(s, st, "msm_fold_heads", (k_fold_heads<F>), dim3(256), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi, seg);
-        }
+        ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
         // ---- 6. bucket reduce
         bool quad = false;
         if constexpr (sizeof(F) == sizeof(Fp)) quad = jobs[b]->quad_tail;
