@@ -8,8 +8,9 @@
 //   * a, b, c = L w, R w, O w: one lane per row of each matrix (CSR), coalesced over the row pointers -- the "sparse mat-vec" of SURVEY §8(f)3
 //   * Setup from explicit toxic waste (tau, alpha, beta, gamma, delta -- upstream draws them; pinning them is what makes a key reproducible):
 //     Lagrange basis at tau (closed form + one inversion per element), A_i(tau) / B_i(tau) / C_i(tau) as the TRANSPOSED products (one lane per
-//     wire over the CSC form built on the host), K / Z scalars, then the fixed-base scalar multiplications [x]G1 / [x]G2 (double-and-add, one
-//     lane per point) straight into a resident proving key (window tables included) -- nothing is staged through the host.
+//     wire over the CSC form built on the host), K / Z scalars, then the fixed-base scalar multiplications [x]G1 / [x]G2 (util.hip: 8-bit windows over
+//     a 32 x 255 table of the generator, one shared inversion per lane) straight into a resident proving key (window tables included) -- nothing is
+//     staged through the host.
 #include <string.h>
 
 #include <algorithm>
@@ -20,6 +21,7 @@
 #include "ctx.hpp"
 #include "curve.hpp"
 #include "ff.hpp"
+#include "fixedbase.hpp"
 #include "host_ff.hpp"
 #include "ntt.hpp"
 
@@ -111,39 +113,6 @@ __global__ void k_z_scalars(PowTab tau_pw, uint32_t N, unsigned logN, Fr scale, 
         if ((i >> b) & 1) acc = acc * tau_pw.pw[b];
     uint32_t r = logN ? (__brev(i) >> (32 - logN)) : 0;
     out[r] = acc;
-}
-// [x_i] G for Montgomery scalars x_i: double-and-add from the top bit, affine out ((0,0) for x = 0)
-template <class F>
-__global__ __launch_bounds__(256) void k_fixed_base_mul(const Fr* __restrict__ scalars, size_t n, Affine<F> gen, Affine<F>* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr k = ldf(scalars + i).from_mont();
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int b = 255; b >= 0; b--) {
-        acc.dbl();
-        if ((k.l[b >> 5] >> (b & 31)) & 1) acc.madd(gen.x, gen.y);
-    }
-    out[i] = acc.to_affine();
-}
-
-static Affine<Fp> gen_g1() {
-    Affine<Fp> g;
-    g.x = Fp::one();
-    g.y = Fp::one() + Fp::one();
-    return g;
-}
-static Affine<Fp2> gen_g2() {
-    static const uint32_t X0[8] = {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu};
-    static const uint32_t X1[8] = {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u};
-    static const uint32_t Y0[8] = {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u};
-    static const uint32_t Y1[8] = {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u};
-    Affine<Fp2> g;
-    Fp t;
-    memcpy(t.l, X0, 32); g.x.a0 = t.to_mont();
-    memcpy(t.l, X1, 32); g.x.a1 = t.to_mont();
-    memcpy(t.l, Y0, 32); g.y.a0 = t.to_mont();
-    memcpy(t.l, Y1, 32); g.y.a1 = t.to_mont();
-    return g;
 }
 static unsigned gridn(size_t n) { return (unsigned)((n + 255) / 256); }
 
@@ -308,17 +277,16 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
     ZK_HIP(hipMalloc(&d_z, N * 64));
     ZK_HIP(hipMalloc(&d_b2, (nw ? nw : 1) * 128));
     ZK_HIP(hipMalloc(&d_ic, npub * 64));
-    const Affine<Fp> G = gen_g1();
-    const Affine<Fp2> H = gen_g2();
-    ZK_LAUNCH(s, st, "setup_fixed_base_g1", (k_fixed_base_mul<Fp>), dim3(gridn(nw)), dim3(256), 0, (const Fr*)abc, nw, G, (Affine<Fp>*)d_a);
-    ZK_LAUNCH(s, st, "setup_fixed_base_g1", (k_fixed_base_mul<Fp>), dim3(gridn(nw)), dim3(256), 0, (const Fr*)(abc + nw), nw, G, (Affine<Fp>*)d_b);
-    if (nk) ZK_LAUNCH(s, st, "setup_fixed_base_g1", (k_fixed_base_mul<Fp>), dim3(gridn(nk)), dim3(256), 0, (const Fr*)(ksc + npub), nk, G, (Affine<Fp>*)d_k);
-    ZK_LAUNCH(s, st, "setup_fixed_base_g1", (k_fixed_base_mul<Fp>), dim3(gridn(npub)), dim3(256), 0, (const Fr*)ksc, npub, G, (Affine<Fp>*)d_ic);
-    ZK_LAUNCH(s, st, "setup_fixed_base_g1", (k_fixed_base_mul<Fp>), dim3(gridn(N)), dim3(256), 0, (const Fr*)zsc, N, G, (Affine<Fp>*)d_z);
-    ZK_LAUNCH(s, st, "setup_fixed_base_g2", (k_fixed_base_mul<Fp2>), dim3(gridn(nw)), dim3(256), 0, (const Fr*)(abc + nw), nw, H, (Affine<Fp2>*)d_b2);
+    // fixed-base scalar multiplications by the generators (util.hip: 8-bit windows, shared inversion)
+    ZK_TRY(fixed_base_mul_scalars(s, st, 0, abc, nw, d_a));
+    ZK_TRY(fixed_base_mul_scalars(s, st, 0, abc + nw, nw, d_b));
+    if (nk) ZK_TRY(fixed_base_mul_scalars(s, st, 0, ksc + npub, nk, d_k));
+    ZK_TRY(fixed_base_mul_scalars(s, st, 0, ksc, npub, d_ic));
+    ZK_TRY(fixed_base_mul_scalars(s, st, 0, zsc, N, d_z));
+    ZK_TRY(fixed_base_mul_scalars(s, st, 1, abc + nw, nw, d_b2));
     // the handful of single points: host scalar multiplications
     auto mul1 = [](const HFr& k, Affine<HFp>* o) {
-        Affine<Fp> gd = gen_g1();
+        Affine<Fp> gd = generator_g1();
         Affine<HFp> gh;
         memcpy(&gh, &gd, sizeof gh);
         uint32_t kk[8];
@@ -327,7 +295,7 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
         *o = scalar_mul(gh, kk).to_affine();
     };
     auto mul2 = [](const HFr& k, Affine<HFp2>* o) {
-        Affine<Fp2> gd = gen_g2();
+        Affine<Fp2> gd = generator_g2();
         Affine<HFp2> gh;
         memcpy(&gh, &gd, sizeof gh);
         uint32_t kk[8];

@@ -3,8 +3,12 @@
 // and oracle/bn254_oracle.c `orc_rand_fr` / `orc_g1_gen_points`, so small cases can be cross-checked bit for bit.
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "ctx.hpp"
 #include "curve.hpp"
+#include "fixedbase.hpp"
 #include "host_ff.hpp"
 
 namespace zkmi {
@@ -59,38 +63,71 @@ __global__ void k_fr_random(Fr* out, size_t n, uint64_t seed, int mont, int witn
     out[i] = x;
 }
 
-// P_i = k_i * G, k_i = i-th element of the uniform stream; affine output (one Fermat inversion per thread)
-template <class F>
-__global__ __launch_bounds__(256) void k_generate_points(Affine<F>* out, size_t n, uint64_t seed, Affine<F> gen) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr k = rand_fr_canonical(seed, i, 0);
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int b = 255; b >= 0; b--) {
-        acc.dbl();
-        if ((k.l[b >> 5] >> (b & 31)) & 1) acc.madd(gen.x, gen.y);
-    }
-    out[i] = acc.to_affine();
-}
-
-// kzg.NewSRS(size, alpha) [gnark-crypto ecc/bn254/fr/kzg; the reference builds its SRS with it at gnark_backend_ffi/backend/common.go:137
-// and main.go:176]: G1[i] = alpha^i * G1.  One lane per point: alpha^i from the bits of i (alpha^(2^b) precomputed), then double-and-add.
+// ---------------------------------------------------------------------------------------------- fixed-base scalar multiplication
+// [k_i] G for many scalars and ONE base (the generator): 8-bit windows over a table T[w][d] = d * 2^(8w) * G (32 x 255 affine points: 0.5 MB for
+// G1, 1 MB for G2, built once on the host), i.e. at most 32 mixed additions per point instead of 255 doublings + ~128 additions; every lane takes
+// PTS points and converts them to affine with ONE shared inversion (Montgomery's trick).  Used by kzg.NewSRS, groth16.Setup and the synthetic
+// point generator.  Scalar sources: an array of Montgomery scalars, the SplitMix64 stream, or the powers alpha^i.
 struct PowBits {
     Fr pw[28];
 };
-__global__ __launch_bounds__(256) void k_kzg_srs_g1(Affine<Fp>* out, size_t n, PowBits basis, Affine<Fp> gen) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr k = Fr::one();
-    for (unsigned b = 0; b < 28; b++)
-        if ((i >> b) & 1) k = k * basis.pw[b];
-    k = k.from_mont();
-    XYZZ<Fp> acc = XYZZ<Fp>::inf();
-    for (int b = 255; b >= 0; b--) {
-        acc.dbl();
-        if ((k.l[b >> 5] >> (b & 31)) & 1) acc.madd(gen.x, gen.y);
+struct ScalarSrc {
+    int kind;            // 0: scalars[i] (Montgomery)   1: SplitMix64 stream `seed`, element i (canonical)   2: alpha^i from `basis` (alpha^(2^b), Montgomery)
+    const Fr* scalars;
+    uint64_t seed;
+    PowBits basis;
+};
+__device__ __forceinline__ Fr scalar_at(const ScalarSrc& S, size_t i) {  // canonical (non-Montgomery) scalar i
+    if (S.kind == 1) return rand_fr_canonical(S.seed, i, 0);
+    if (S.kind == 2) {
+        Fr k = Fr::one();
+        for (unsigned b = 0; b < 28; b++)
+            if ((i >> b) & 1) k = k * S.basis.pw[b];
+        return k.from_mont();
     }
-    out[i] = acc.to_affine();
+    const uint4* q = reinterpret_cast<const uint4*>(S.scalars + i);
+    uint4 a = q[0], b = q[1];
+    Fr k;
+    k.l[0] = a.x; k.l[1] = a.y; k.l[2] = a.z; k.l[3] = a.w;
+    k.l[4] = b.x; k.l[5] = b.y; k.l[6] = b.z; k.l[7] = b.w;
+    return k.from_mont();
+}
+template <class F, int PTS>
+__global__ __launch_bounds__(256) void k_fixed_base(ScalarSrc S, size_t n, const Affine<F>* __restrict__ table, Affine<F>* __restrict__ out) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ<F> acc[PTS];
+    F pre[PTS];
+    F run = F::one();
+#pragma unroll
+    for (int p = 0; p < PTS; p++) {
+        const size_t i = g + (size_t)p * T;  // strided over the lanes: coalesced stores
+        acc[p] = XYZZ<F>::inf();
+        if (i < n) {
+            Fr k = scalar_at(S, i);
+            for (int w = 0; w < 32; w++) {
+                uint32_t d = (k.l[w >> 2] >> (8 * (w & 3))) & 255u;
+                if (d) {
+                    Affine<F> t = table[w * 255 + (d - 1)];
+                    acc[p].madd(t.x, t.y);
+                }
+            }
+        }
+        pre[p] = run;
+        if (!acc[p].is_inf()) run = run * (acc[p].zz * acc[p].zzz);
+    }
+    F inv = run.inv();  // one inversion for the lane's PTS points
+#pragma unroll
+    for (int p = PTS - 1; p >= 0; p--) {
+        const size_t i = g + (size_t)p * T;
+        Affine<F> a = Affine<F>::inf();
+        if (!acc[p].is_inf()) {
+            F zi = inv * pre[p];                      // 1 / (zz * zzz) of point p
+            inv = inv * (acc[p].zz * acc[p].zzz);
+            a.x = acc[p].x * (zi * acc[p].zzz);
+            a.y = acc[p].y * (zi * acc[p].zz);
+        }
+        if (i < n) out[i] = a;
+    }
 }
 
 static Affine<Fp> g1_generator() {
@@ -114,6 +151,59 @@ static Affine<Fp2> g2_generator() {
     return g;
 }
 
+// T[w * 255 + (d - 1)] = d * 2^(8w) * gen, built on the host (8,160 points: ~10 ms for G1) and kept on the device for the life of the process
+template <class HF, class F>
+static int fixed_base_table(const Affine<F>& gen_dev, Affine<F>** d_out) {
+    Affine<HF> gen;
+    memcpy(&gen, &gen_dev, sizeof gen);
+    std::vector<XYZZ<HF>> pts(32 * 255);
+    XYZZ<HF> base = XYZZ<HF>::from_affine(gen);
+    for (int w = 0; w < 32; w++) {
+        XYZZ<HF> acc = XYZZ<HF>::inf();
+        for (int d = 1; d < 256; d++) {
+            acc.add(base);
+            pts[w * 255 + d - 1] = acc;
+        }
+        for (int i = 0; i < 8; i++) base.dbl();
+    }
+    std::vector<Affine<HF>> aff(pts.size());
+    for (size_t i = 0; i < pts.size(); i++) aff[i] = pts[i].to_affine();
+    ZK_HIP(hipMalloc((void**)d_out, aff.size() * sizeof(Affine<F>)));
+    ZK_HIP(hipMemcpy(*d_out, aff.data(), aff.size() * sizeof(Affine<F>), hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+static std::mutex g_fb_mu;
+static Affine<Fp>* g_fb_g1 = nullptr;
+static Affine<Fp2>* g_fb_g2 = nullptr;
+
+// out[i] = [k_i] G1 / G2 for the scalar source S (declared in fixedbase.hpp for the other translation units)
+int fixed_base_mul(Slot* s, hipStream_t st, int is_g2, const ScalarSrc& S, size_t n, void* d_out) {
+    if (!n) return ZK_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_fb_mu);
+        if (!is_g2 && !g_fb_g1) ZK_TRY((fixed_base_table<HFp, Fp>(g1_generator(), &g_fb_g1)));
+        if (is_g2 && !g_fb_g2) ZK_TRY((fixed_base_table<HFp2, Fp2>(g2_generator(), &g_fb_g2)));
+    }
+    if (is_g2) {
+        constexpr int PTS = 2;
+        size_t lanes = (n + PTS - 1) / PTS;
+        ZK_LAUNCH(s, st, "fixed_base_g2", (k_fixed_base<Fp2, PTS>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, S, n, (const Affine<Fp2>*)g_fb_g2, (Affine<Fp2>*)d_out);
+    } else {
+        constexpr int PTS = 4;
+        size_t lanes = (n + PTS - 1) / PTS;
+        ZK_LAUNCH(s, st, "fixed_base_g1", (k_fixed_base<Fp, PTS>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, S, n, (const Affine<Fp>*)g_fb_g1, (Affine<Fp>*)d_out);
+    }
+    return ZK_OK;
+}
+int fixed_base_mul_scalars(Slot* s, hipStream_t st, int is_g2, const Fr* d_scalars, size_t n, void* d_out) {
+    ScalarSrc S = {};
+    S.kind = 0;
+    S.scalars = d_scalars;
+    return fixed_base_mul(s, st, is_g2, S, n, d_out);
+}
+Affine<Fp> generator_g1() { return g1_generator(); }
+Affine<Fp2> generator_g2() { return g2_generator(); }
+
 }  // namespace zkmi
 
 using namespace zkmi;
@@ -135,9 +225,10 @@ int zk_bn254_g1_generate_dev(void* d_out, size_t n, uint64_t seed, void* stream)
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
-    if (n)
-        ZK_LAUNCH(g.s, st, "g1_generate", (k_generate_points<Fp>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (Affine<Fp>*)d_out, n, seed,
-                  g1_generator());
+    ScalarSrc S = {};
+    S.kind = 1;
+    S.seed = seed;
+    ZK_TRY(fixed_base_mul(g.s, st, 0, S, n, d_out));
     if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
@@ -147,9 +238,10 @@ int zk_bn254_g2_generate_dev(void* d_out, size_t n, uint64_t seed, void* stream)
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
-    if (n)
-        ZK_LAUNCH(g.s, st, "g2_generate", (k_generate_points<Fp2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (Affine<Fp2>*)d_out, n, seed,
-                  g2_generator());
+    ScalarSrc S = {};
+    S.kind = 1;
+    S.seed = seed;
+    ZK_TRY(fixed_base_mul(g.s, st, 1, S, n, d_out));
     if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
@@ -163,12 +255,13 @@ int zk_bn254_kzg_new_srs_dev(void* d_g1_out, size_t size, const zk_fr* alpha, zk
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
     HFr a;
     memcpy(&a, alpha, 32);
-    PowBits pb;
+    ScalarSrc S = {};
+    S.kind = 2;
     for (int b = 0; b < 28; b++) {
-        memcpy(&pb.pw[b], &a, 32);
+        memcpy(&S.basis.pw[b], &a, 32);
         a = a.sqr();
     }
-    if (size) ZK_LAUNCH(g.s, st, "kzg_srs_g1", k_kzg_srs_g1, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, (Affine<Fp>*)d_g1_out, size, pb, g1_generator());
+    ZK_TRY(fixed_base_mul(g.s, st, 0, S, size, d_g1_out));
     if (g2_out) {
         Affine<Fp2> gd = g2_generator();
         Affine<HFp2> gh;
