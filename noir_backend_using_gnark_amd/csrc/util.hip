@@ -166,8 +166,20 @@ static int fixed_base_table(const Affine<F>& gen_dev, Affine<F>** d_out) {
         }
         for (int i = 0; i < 8; i++) base.dbl();
     }
+    // to affine with ONE inversion (Montgomery's trick over zz * zzz; no entry is the point at infinity: d * 2^(8w) < r)
     std::vector<Affine<HF>> aff(pts.size());
-    for (size_t i = 0; i < pts.size(); i++) aff[i] = pts[i].to_affine();
+    std::vector<HF> pre(pts.size());
+    HF run = HF::one();
+    for (size_t i = 0; i < pts.size(); i++) {
+        pre[i] = run;
+        run = run * (pts[i].zz * pts[i].zzz);
+    }
+    HF inv = run.inv();
+    for (size_t i = pts.size(); i-- > 0;) {
+        HF zi = inv * pre[i];
+        inv = inv * (pts[i].zz * pts[i].zzz);
+        aff[i] = Affine<HF>{pts[i].x * (zi * pts[i].zzz), pts[i].y * (zi * pts[i].zz)};
+    }
     ZK_HIP(hipMalloc((void**)d_out, aff.size() * sizeof(Affine<F>)));
     ZK_HIP(hipMemcpy(*d_out, aff.data(), aff.size() * sizeof(Affine<F>), hipMemcpyHostToDevice));
     return ZK_OK;
