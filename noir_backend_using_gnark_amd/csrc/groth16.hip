@@ -342,12 +342,15 @@ static int msm5_prepare_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Ms
     if (in.tab_w) return msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w);
     return msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w);
 }
-static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc);
+// `between` (optional): called once the G2.B accumulate is enqueued, with its completion event; it may enqueue work that must own the machine
+// next (computeH when the inputs came from the host) and return the event the A accumulate has to wait for instead.
+typedef std::function<int(hipEvent_t g2_done, hipEvent_t* gate_next)> BetweenFn;
+static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc, const BetweenFn* between = nullptr);
 static int msm5_launch_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc = nullptr) {
     ZK_TRY(msm5_prepare_w(sl, in, ev_w, S));
     return msm5_accumulate_w(sl, in, ev_w, S, gate_first_acc);
 }
-static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc) {
+static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc, const BetweenFn* between) {
     hipStream_t st4 = sl[4]->stream_hi;
     size_t j = 0;
     const bool share_k = k_shares_w(in, &j);
@@ -375,6 +378,7 @@ static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w,
     S->jobs[4].want_done = true;
     ZK_TRY(msm_g2_accumulate(sl[4], st4, S->prep_w, in.tab_w ? in.t_b2 : in.d_b2, 0, &S->jobs[4]));
     hipEvent_t prev = S->jobs[4].acc_done;
+    if (between) ZK_TRY((*between)(S->jobs[4].acc_done, &prev));
     // ZKMI_BATCH_ACC=1 (experiment switch): A, B1, K -- which read the same sorted digits -- in ONE accumulate launch (grid.y = 3).
     // Measured 0.25 ms SLOWER per proof than the chained launches (11.2 vs 10.95 ms): the kernel itself runs at 0.70 of the madd
     // peak instead of 0.61, but the three reduction tails then all start late and pile up under Z instead of hiding one by one.
@@ -750,37 +754,71 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     const void* src[3] = {a, b, c};
     // full-length inputs already in HBM are read in place by the first NTT pass (they stay untouched); otherwise copy / pad first
     const bool direct = on_device && n_constraints == N && N > 1;
-    for (int i = 0; i < 3 && rc == ZK_OK; i++) {
-        d_abc[i] = (Fr*)s0->alloc(N * 32);
-        if (direct) continue;
-        if (n_constraints && hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
-        if (n_constraints < N && hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemsetAsync failed");
-    }
+    // Host inputs (what a cgo caller has): 128 bytes per constraint cross PCIe inside the call.  Order: w first (32 B / wire), its scalar preparation
+    // and the G2.B accumulate -- none of which needs a, b, c -- run while a, b, c (96 B / constraint) are still uploading; computeH then takes the
+    // machine BETWEEN the G2.B and A accumulates (under an accumulate kernel it would be starved).  ZKMI_HOST_ORDER=0 restores computeH-first.
+    static const bool host_order_on = !(getenv("ZKMI_HOST_ORDER") && atoi(getenv("ZKMI_HOST_ORDER")) == 0);
+    const bool host_order = !on_device && host_order_on && nw > 0 && N > 1;
+    Fr* d_w = (Fr*)s0->alloc(nw * 32 + 16);
+    for (int i = 0; i < 3; i++) d_abc[i] = (Fr*)s0->alloc(N * 32);
+    if (on_device) d_w = (Fr*)const_cast<void*>(w);  // wire values already in HBM are only read: no staging copy
+    auto upload_abc = [&]() -> int {
+        for (int i = 0; i < 3; i++) {
+            if (direct) continue;
+            if (n_constraints && hipMemcpyAsync(d_abc[i], src[i], n_constraints * 32, kind, st) != hipSuccess) return set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+            if (n_constraints < N && hipMemsetAsync(d_abc[i] + n_constraints, 0, (N - n_constraints) * 32, st) != hipSuccess) return set_err(ZK_ERR_HIP, "hipMemsetAsync failed");
+        }
+        return ZK_OK;
+    };
     // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
     const Fr* in_place_src[3] = {(const Fr*)a, (const Fr*)b, (const Fr*)c};
     // ZKMI_H_STREAMS=1 (experiment switch): the transforms of b and c on the (idle) high-priority streams of slots 1 and 2, next to a's
     static const bool h_streams = getenv("ZKMI_H_STREAMS") && atoi(getenv("ZKMI_H_STREAMS")) == 1;
     const hipStream_t side[2] = {g.s[1]->stream_hi, g.s[2]->stream_hi};
-    if (rc == ZK_OK) rc = compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain, direct ? in_place_src : nullptr, h_streams ? side : nullptr);
     hipEvent_t ev_h = nullptr;
-    if (rc == ZK_OK && hipEventCreateWithFlags(&ev_h, hipEventDisableTiming) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventCreate failed");
-    if (rc == ZK_OK && hipEventRecord(ev_h, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipEventRecord failed");
-    Fr* d_w = (Fr*)s0->alloc(nw * 32 + 16);
-    if (on_device) d_w = (Fr*)const_cast<void*>(w);  // wire values already in HBM are only read: no staging copy
-    else if (rc == ZK_OK && nw && hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
-    in.d_w = d_w;
-    in.d_wk = d_w + P.n_public;
-    in.d_h = d_abc[0];
+    auto run_compute_h = [&]() -> int {
+        ZK_TRY(compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain, direct ? in_place_src : nullptr, h_streams ? side : nullptr));
+        ZK_HIP(hipEventCreateWithFlags(&ev_h, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(ev_h, st));
+        return ZK_OK;
+    };
     Msm5State S;
     static const bool nogate = getenv("ZKMI_NOGATE") && atoi(getenv("ZKMI_NOGATE")) == 1;  // experiment: G2.B accumulate does not wait for computeH
     static const bool preph_first = getenv("ZKMI_PREPH_FIRST") && atoi(getenv("ZKMI_PREPH_FIRST")) == 1;  // experiment: prepare(h) alone, before G2.B
-    if (preph_first) {
-        if (rc == ZK_OK) rc = msm5_prepare_h(g.s, st, in, &S);
-        if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, S.prep_h.ready ? S.prep_h.ready : ev_h);
-        if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S, true);
-    } else {
-        if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);
+    if (host_order) {
+        if (hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+        in.d_w = d_w;
+        in.d_wk = d_w + P.n_public;
+        in.d_h = d_abc[0];
+        if (rc == ZK_OK) rc = msm5_prepare_w(g.s, in, nullptr, &S);
+        if (rc == ZK_OK) rc = upload_abc();  // the host blocks here while the GPU sorts the digits of w
+        const BetweenFn between = [&](hipEvent_t g2_done, hipEvent_t* gate_next) -> int {
+            if (g2_done) ZK_HIP(hipStreamWaitEvent(st, g2_done, 0));
+            ZK_TRY(run_compute_h());
+            *gate_next = ev_h;
+            return ZK_OK;
+        };
+        if (rc == ZK_OK) rc = msm5_accumulate_w(g.s, in, nullptr, &S, nullptr, &between);
         if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
+    } else {
+        // Order on the GPU:  [computeH  ||  upload + prepare(w)]  ->  G2.B acc -> A acc -> B1 acc -> K acc -> Z acc  (reduce tails and
+        // prepare(h) run underneath the accumulate kernels).  computeH goes FIRST and alone with the bandwidth-bound sort of w:
+        // measured, an NTT launched underneath an accumulate kernel is starved (1.3 ms -> 8 ms) because the long-running accumulate
+        // workgroups never free enough wave slots, and the Z chain then finishes late.
+        rc = upload_abc();
+        if (rc == ZK_OK) rc = run_compute_h();
+        if (!on_device && rc == ZK_OK && nw && hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+        in.d_w = d_w;
+        in.d_wk = d_w + P.n_public;
+        in.d_h = d_abc[0];
+        if (preph_first) {
+            if (rc == ZK_OK) rc = msm5_prepare_h(g.s, st, in, &S);
+            if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, S.prep_h.ready ? S.prep_h.ready : ev_h);
+            if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S, true);
+        } else {
+            if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);
+            if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
+        }
     }
     if (ev_h) (void)hipEventDestroy(ev_h);
     uint64_t parts[96];
