@@ -150,6 +150,109 @@ inline Error Prove(const ProvingKey& pk, const fr::Vector& a, const fr::Vector& 
 
 }  // namespace groth16
 
+namespace kzg {
+
+// kzg.SRS with the G1 side resident in HBM (RAII over the registered base array).  kzg.NewSRS / (*SRS).ReadFrom / WriteTo / kzg.Commit.
+class SRS {
+public:
+    SRS() = default;
+    SRS(const SRS&) = delete;
+    SRS& operator=(const SRS&) = delete;
+    ~SRS() {
+        if (handle_) zk_bn254_bases_free(handle_);
+    }
+    // kzg.NewSRS(size, alpha): alpha^i * G1 generated on the device; alpha is a Montgomery fr.Element
+    Error New(uint64_t size, const fr::Element& alpha) {
+        void* d = nullptr;
+        Error e = make_error(zk_dev_alloc(&d, size * 64));
+        if (!e.ok()) return e;
+        e = make_error(zk_bn254_kzg_new_srs_dev(d, size, &alpha, G2, nullptr));
+        if (e.ok()) e = make_error(zk_bn254_bases_register_dev(d, size, 0, &handle_));
+        zk_dev_free(d);
+        if (e.ok()) size_ = size;
+        return e;
+    }
+    // (*SRS).ReadFrom on the bytes of WriteTo (hex = true: the text of srs.hex); the G1 points are decompressed on the device
+    Error ReadFrom(const void* data, size_t len, bool hex = false) {
+        size_t n = 0;
+        Error e = make_error(zk_bn254_kzg_srs_read(data, len, hex ? 1 : 0, 0, &handle_, &n, G2));
+        if (e.ok()) size_ = n;
+        return e;
+    }
+    Error WriteTo(std::vector<uint8_t>* out, bool hex = false) const {
+        size_t need = (132 + 32 * size_) * (hex ? 2 : 1), n = 0;
+        out->resize(need);
+        return make_error(zk_bn254_kzg_srs_write(handle_, G2, hex ? 1 : 0, out->data(), out->size(), &n));
+    }
+    // kzg.Commit(p, srs) = MultiExp(srs.G1[:len(p)], p); p holds Montgomery fr.Elements
+    Error Commit(const fr::Vector& p, zk_g1_affine* digest) const {
+        if (p.size() > size_) return Error{ZK_ERR_LEN, "kzg: invalid polynomial size (larger than SRS or == 0)"};
+        zk_msm_cfg c = {0, 1, 0, 0};
+        return make_error(zk_bn254_msm_bases(handle_, 0, p.data(), p.size(), &c, digest));
+    }
+    uint64_t handle() const { return handle_; }
+    uint64_t Size() const { return size_; }
+    zk_g2_affine G2[2] = {};
+
+private:
+    uint64_t handle_ = 0;
+    uint64_t size_ = 0;
+};
+
+}  // namespace kzg
+
+namespace plonk {
+
+// plonk.ProvingKey resident in HBM; plonk.Setup / ReadFrom / WriteTo / plonk.Prove (the reference's live path: backend/plonk/plonk.go:21,67)
+class ProvingKey {
+public:
+    ProvingKey() = default;
+    ProvingKey(const ProvingKey&) = delete;
+    ProvingKey& operator=(const ProvingKey&) = delete;
+    ~ProvingKey() {
+        if (handle_) zk_bn254_plonk_pk_free(handle_);
+    }
+    // plonk.Setup(spr, srs): the gates as BuildSparseR1CS emits them (backend/plonk/sparse_r1cs.go:44-107)
+    Error Setup(const zk_plonk_circuit& spr, const kzg::SRS& srs) {
+        n_vars_ = spr.n_vars;
+        return make_error(zk_bn254_plonk_setup(&spr, srs.handle(), &handle_, &Vk));
+    }
+    // ProvingKey.ReadFrom on gnark's bytes (or their hex text) + the wire ids of the rebuilt spr
+    Error ReadFrom(const void* data, size_t len, bool hex, size_t n_vars, const std::vector<uint32_t>& xa, const std::vector<uint32_t>& xb, const std::vector<uint32_t>& xc,
+                   const kzg::SRS& srs) {
+        if (xa.size() != xb.size() || xa.size() != xc.size()) return Error{ZK_ERR_LEN, "wire-id arrays differ in length"};
+        n_vars_ = n_vars;
+        return make_error(zk_bn254_plonk_pk_read(data, len, hex ? 1 : 0, n_vars, xa.size(), xa.data(), xb.data(), xc.data(), srs.handle(), &handle_));
+    }
+    Error WriteTo(std::vector<uint8_t>* out, bool hex = false) const {
+        size_t n = 0;
+        uint8_t dummy = 0;
+        zk_bn254_plonk_pk_write(handle_, hex ? 1 : 0, &dummy, 0, &n);  // size query
+        out->resize(n);
+        return make_error(zk_bn254_plonk_pk_write(handle_, hex ? 1 : 0, out->data(), out->size(), &n));
+    }
+    uint64_t handle() const { return handle_; }
+    size_t NbVariables() const { return n_vars_; }
+    zk_plonk_vk Vk = {};
+
+private:
+    uint64_t handle_ = 0;
+    size_t n_vars_ = 0;
+};
+
+struct Proof {
+    uint8_t bytes[ZK_PLONK_PROOF_BYTES];  // Proof.WriteTo
+};
+
+// plonk.Prove after spr.Solve: solution = the values of all variables (public first), blinders = the nine fr.SetRandom draws of Blind(),
+// challenges = nullptr (SHA-256 Fiat-Shamir as upstream) or five pinned values
+inline Error Prove(const ProvingKey& pk, const fr::Vector& solution, const fr::Element blinders[9], Proof* proof, const fr::Element* challenges = nullptr) {
+    if (solution.size() != pk.NbVariables()) return Error{ZK_ERR_LEN, "len(solution) != number of variables of the constraint system"};
+    return make_error(zk_bn254_plonk_prove(pk.handle(), solution.data(), solution.size(), 0, blinders, challenges, proof->bytes));
+}
+
+}  // namespace plonk
+
 // DeserializeFelts(encodedFelts string): hex(u32 BE count || count x 32 B BE) -> Montgomery vector, decoded on the device into d_out
 inline Error DeserializeFelts(const std::string& encoded, void* d_out, size_t capacity, size_t* n) {
     return make_error(zk_bn254_felts_decode_hex(encoded.data(), encoded.size(), d_out, capacity, n));

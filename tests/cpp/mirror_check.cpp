@@ -33,6 +33,20 @@ int main(int argc, char** argv) {
         fr::Vector a(7);
         if (!d.FFT(a, fft::DIF)) return fail("len(a) != Cardinality must fail");
     }
+    // the PLONK / KZG mirrors validate lengths before any pointer crosses the C ABI
+    {
+        kzg::SRS srs;
+        fr::Vector p(4);
+        zk_g1_affine d;
+        if (srs.Commit(p, &d).code != ZK_ERR_LEN) return fail("kzg.Commit with a polynomial larger than the SRS must be ZK_ERR_LEN");
+        plonk::ProvingKey pk;
+        plonk::Proof pr;
+        fr::Vector sol(3);
+        fr::Element bl[9] = {};
+        if (plonk::Prove(pk, sol, bl, &pr).code != ZK_ERR_LEN) return fail("plonk.Prove with a solution of the wrong length must be ZK_ERR_LEN");
+        std::vector<uint32_t> xa(2), xb(1), xc(2);
+        if (pk.ReadFrom("", 0, false, 3, xa, xb, xc, srs).code != ZK_ERR_LEN) return fail("ReadFrom with ragged wire-id arrays must be ZK_ERR_LEN");
+    }
     if (argc < 2) {
         std::printf("ok (error paths only)\n");
         return 0;
