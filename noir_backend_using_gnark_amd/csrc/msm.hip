@@ -1059,6 +1059,16 @@ int bases_ptr(uint64_t handle, const void** d, size_t* n, int* is_g2) {
     if (is_g2) *is_g2 = it->second.is_g2;
     return ZK_OK;
 }
+// window table of a registered base array (null when it was registered without one)
+int bases_table(uint64_t handle, const void** d_table, MsmTable* tab, size_t* n) {
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
+    if (d_table) *d_table = it->second.d_table;
+    if (tab) *tab = it->second.tab;
+    if (n) *n = it->second.n;
+    return ZK_OK;
+}
 int bases_info(uint64_t handle, size_t* n, int* is_g2) {
     std::lock_guard<std::mutex> lk(g_bases_mu);
     auto it = g_bases.find(handle);

@@ -36,6 +36,8 @@ int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, 
 
 // number of points / group of a registered base array (zk_bn254_bases_register*)
 int bases_info(uint64_t handle, size_t* n, int* is_g2);
+struct MsmTable;
+int bases_table(uint64_t handle, const void** d_table, MsmTable* tab, size_t* n);  // window table of a registered base array (null: none)
 
 struct MsmPlan {
     unsigned c, W, Wd, key_bits;   // W bucket sets (windows that are reduced separately); Wd digit windows (== W unless table mode)

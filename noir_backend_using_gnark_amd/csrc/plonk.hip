@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -427,6 +428,79 @@ struct AsyncCommit {
     }
     ~AsyncCommit() { if (th.joinable()) th.join(); }
 };
+// The commitments of one proof as a CHAIN (the schedule of Groth16's msm5): every MSM prepares its scalars (digits, radix sort, task plan --
+// bandwidth-bound) on a stream of its own as soon as its polynomial exists, while the accumulate kernels (ALU-bound, each wants the whole
+// machine) run ONE AT A TIME in issue order, gated by the previous one's completion event; the reduction tails and the next preparation run
+// underneath.  Needs the SRS's window table; otherwise the thread-per-commit fallback above is used.
+struct CommitChain {
+    static constexpr int NJ = 3;
+    const PlonkPK* P = nullptr;
+    const void* d_table = nullptr;
+    MsmTable tab;
+    SlotsGuard<NJ> g;
+    MsmPrep prep[NJ];
+    MsmJob job[NJ];
+    bool live[NJ] = {};
+    hipEvent_t last_acc = nullptr;   // completion of the most recently enqueued accumulate (owned by the job that recorded it)
+    bool ok = false;
+
+    int init(const PlonkPK* P_, size_t max_len) {
+        P = P_;
+        size_t n = 0;
+        ZK_TRY(bases_table(P->srs, &d_table, &tab, &n));
+        if (!d_table) return ZK_OK;  // no table: the caller falls back
+        ZK_TRY(acquire_slots(NJ, g.s));
+        size_t np = 0, na = 0;
+        ZK_TRY(msm_prep_need_table(max_len, tab, g.s[0]->stream, &np, &na, nullptr));
+        for (int i = 0; i < NJ; i++) ZK_TRY(g.s[i]->reserve(np + na + 65536));
+        ok = true;
+        return ZK_OK;
+    }
+    // d_p must be complete on `producer` (an event is recorded there and awaited by the commit's stream)
+    int start(int k, hipStream_t producer, const Fr* d_p, size_t len) {
+        Slot* s = g.s[k];
+        s->reset();
+        hipEvent_t ev;
+        ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(ev, producer));
+        ZK_HIP(hipStreamWaitEvent(s->stream, ev, 0));
+        (void)hipEventDestroy(ev);
+        job[k] = MsmJob();
+        ZK_TRY(msm_prepare_scalars_table(s, s->stream, d_p, len, &kMont, tab, &prep[k]));
+        live[k] = true;
+        job[k].gate_acc = last_acc;
+        job[k].want_done = true;
+        ZK_TRY(msm_g1_accumulate(s, s->stream, prep[k], d_table, 0, &job[k]));
+        if (job[k].acc_done) last_acc = job[k].acc_done;
+        return ZK_OK;
+    }
+    int finish(int k, Affine<HFp>* out) {
+        XYZZ<HFp> t;
+        int rc = msm_g1_finish(job[k], &t);
+        release(k);
+        ZK_TRY(rc);
+        *out = t.to_affine();
+        return ZK_OK;
+    }
+    void release(int k) {
+        if (!live[k]) return;
+        msm_prep_release(&prep[k]);
+        if (job[k].acc_done) {
+            if (last_acc == job[k].acc_done) last_acc = nullptr;  // the accumulate has completed (finish synchronised): nothing to wait for
+            (void)hipEventDestroy(job[k].acc_done);
+            job[k].acc_done = nullptr;
+        }
+        live[k] = false;
+    }
+    ~CommitChain() {
+        for (int k = 0; k < NJ; k++)
+            if (live[k]) {
+                (void)hipStreamSynchronize(g.s[k]->stream);
+                release(k);
+            }
+    }
+};
+static const bool g_plonk_chain = !(getenv("ZKMI_PLONK_CHAIN") && atoi(getenv("ZKMI_PLONK_CHAIN")) == 0);  // A/B switch
 static const bool g_plonk_serial = getenv("ZKMI_PLONK_SERIAL") && atoi(getenv("ZKMI_PLONK_SERIAL")) == 1;  // A/B switch: commitments one after the other
 
 // Lagrange (regular) -> canonical (regular) on the small domain, in place: FFTInverse(DIF) + BitReverse, as setup.go / iop.ToCanonical do
@@ -980,9 +1054,40 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     // ---- l, r, o
     ZK_LAUNCH(s, st, "plonk_gather_lro", k_gather_lro, dim3(grid_of(n)), dim3(256), 0, d_sol, (const uint32_t*)P->xa, (const uint32_t*)P->xb, (const uint32_t*)P->xc,
               (uint32_t)npub, (uint32_t)P->n_constraints, (uint32_t)n, l_lag, r_lag, o_lag);
+    std::vector<HFr> pub(npub);
+    if (npub) ZK_HIP(hipMemcpyAsync(pub.data(), d_sol, npub * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    ZK_TRY(slot_sync(s, st));  // the public inputs are on the host (the transcript binds them); the stream is still almost empty here
     Fr* lag3[3] = {l_lag, r_lag, o_lag};
     Fr* can3[3] = {bl_, br_, bo_};
     Affine<HFp> c_lro[3], c_z, c_h[3], c_zopen, c_lin, c_batch;
+    CommitChain chain;
+    if (g_plonk_chain && !g_plonk_serial) ZK_TRY(chain.init(P, n + 3));
+    // a group of independent commitments + the work the main stream does meanwhile
+    auto commit_group = [&](int cnt, const Fr* const* polys, const size_t* lens, Affine<HFp>* outs, const std::function<int()>& meanwhile) -> int {
+        if (chain.ok) {
+            for (int k = 0; k < cnt; k++) ZK_TRY(chain.start(k, st, polys[k], lens[k]));
+            int rc = meanwhile();
+            for (int k = 0; k < cnt; k++) {
+                int r2 = chain.finish(k, &outs[k]);
+                if (rc == ZK_OK) rc = r2;
+            }
+            return rc;
+        }
+        if (g_plonk_serial) {
+            for (int k = 0; k < cnt; k++) ZK_TRY(commit(P, s, st, polys[k], lens[k], &outs[k]));
+            return meanwhile();
+        }
+        AsyncCommit ac[3];
+        ZK_TRY(slot_sync(s, st));
+        for (int k = 0; k < cnt; k++) ac[k].start(P, polys[k], lens[k]);
+        int rc = meanwhile();
+        for (int k = 0; k < cnt; k++) {
+            int r2 = ac[k].join();
+            if (rc == ZK_OK) rc = r2;
+            outs[k] = ac[k].out;
+        }
+        return rc;
+    };
     for (int k = 0; k < 3; k++) {
         ZK_HIP(hipMemcpyAsync(can3[k], lag3[k], n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ZK_HIP(hipMemsetAsync(can3[k] + n, 0, 8 * sizeof(Fr), st));
@@ -992,30 +1097,20 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         B.b[0] = to_dev(bl[2 * k]); B.b[1] = to_dev(bl[2 * k + 1]); B.b[2] = Fr::zero();
         ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, can3[k], (uint32_t)n, B);
     }
-    // the three commitments run on threads of their own while this stream already evaluates l, r, o on the big coset (no challenge needed for that)
+    // the three commitments, while this stream already evaluates l, r, o on the big coset (no challenge needed for that)
     const Fr* small5[5] = {bl_, br_, bo_, bz_, qkc};
     const size_t len5[5] = {n + 2, n + 2, n + 2, n + 3, n};
-    if (g_plonk_serial) {
-        for (int k = 0; k < 3; k++) ZK_TRY(commit(P, s, st, can3[k], n + 2, &c_lro[k]));
-        for (int k = 0; k < 3; k++) ZK_TRY(to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P));
-    } else {
-        AsyncCommit ac[3];
-        ZK_TRY(slot_sync(s, st));
-        for (int k = 0; k < 3; k++) ac[k].start(P, can3[k], n + 2);
-        int rc = ZK_OK;
-        for (int k = 0; k < 3 && rc == ZK_OK; k++) rc = to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P);
-        for (int k = 0; k < 3; k++) {
-            int r2 = ac[k].join();
-            if (rc == ZK_OK) rc = r2;
-            c_lro[k] = ac[k].out;
-        }
-        ZK_TRY(rc);
+    {
+        const Fr* polys[3] = {bl_, br_, bo_};
+        const size_t lens[3] = {n + 2, n + 2, n + 2};
+        ZK_TRY(commit_group(3, polys, lens, c_lro, [&]() -> int {
+            for (int k = 0; k < 3; k++) ZK_TRY(to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P));
+            return ZK_OK;
+        }));
     }
 
     // ---- gamma, beta (transcript "gamma" binds the verifying key and the public inputs, then the three digests)
     FsTranscript fs{"gamma", "beta", "alpha", "zeta"};
-    std::vector<HFr> pub(npub);
-    if (npub) ZK_HIP(hipMemcpy(pub.data(), d_sol, npub * sizeof(Fr), hipMemcpyDeviceToHost));
     for (const Affine<HFp>* d : {&P->vk_s[0], &P->vk_s[1], &P->vk_s[2], &P->vk_ql, &P->vk_qr, &P->vk_qm, &P->vk_qo, &P->vk_qk}) fs.bind_g1(0, *d);
     for (const HFr& w : pub) fs.bind_fr(0, w);
     for (int k = 0; k < 3; k++) fs.bind_g1(0, c_lro[k]);
@@ -1041,23 +1136,17 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         for (int i = 0; i < 3; i++) B.b[i] = to_dev(bl[6 + i]);
         ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, bz_, (uint32_t)n, B);
     }
-    // commitment to z on its own thread; meanwhile: qk completed with the public inputs (canonical), z and qk on the big coset
+    // commitment to z; meanwhile: qk completed with the public inputs (canonical), z and qk on the big coset
     {
-        AsyncCommit az;
-        ZK_TRY(slot_sync(s, st));
-        if (g_plonk_serial) ZK_TRY(commit(P, s, st, bz_, n + 3, &c_z));
-        else az.start(P, bz_, n + 3);
-        int rc = ZK_OK;
-        if (hipMemcpyAsync(qkc, P->lqk, n * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
-        if (rc == ZK_OK && npub && hipMemcpyAsync(qkc, d_sol, npub * sizeof(Fr), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
-        if (rc == ZK_OK) rc = to_canonical(s, st, qkc, logn);
-        for (int k = 3; k < 5 && rc == ZK_OK; k++) rc = to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P);
-        if (!g_plonk_serial) {
-            int r2 = az.join();
-            if (rc == ZK_OK) rc = r2;
-            c_z = az.out;
-        }
-        ZK_TRY(rc);
+        const Fr* polys[1] = {bz_};
+        const size_t lens[1] = {n + 3};
+        ZK_TRY(commit_group(1, polys, lens, &c_z, [&]() -> int {
+            ZK_HIP(hipMemcpyAsync(qkc, P->lqk, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+            if (npub) ZK_HIP(hipMemcpyAsync(qkc, d_sol, npub * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+            ZK_TRY(to_canonical(s, st, qkc, logn));
+            for (int k = 3; k < 5; k++) ZK_TRY(to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P));
+            return ZK_OK;
+        }));
     }
     fs.bind_g1(2, c_z);
     HFr alpha = fs.challenge(2);
@@ -1094,19 +1183,11 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     ZK_HIP(hipMemsetAsync(d_flag, 0, 4, st));
     ZK_LAUNCH(s, st, "plonk_quotient_check", k_any_nonzero, dim3(grid_of(N4 - 3 * (n + 2))), dim3(256), 0, (const Fr*)(h + 3 * (n + 2)), N4 - 3 * (n + 2), d_flag);
     ZK_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st));
-    if (g_plonk_serial) {
-        for (int k = 0; k < 3; k++) ZK_TRY(commit(P, s, st, h + k * (n + 2), n + 2, &c_h[k]));
-    } else {
-        AsyncCommit ah[3];
-        ZK_TRY(slot_sync(s, st));
-        for (int k = 0; k < 3; k++) ah[k].start(P, h + k * (n + 2), n + 2);
-        int rc = ZK_OK;
-        for (int k = 0; k < 3; k++) {
-            int r2 = ah[k].join();
-            if (rc == ZK_OK) rc = r2;
-            c_h[k] = ah[k].out;
-        }
-        ZK_TRY(rc);
+    {
+        const Fr* polys[3] = {h, h + (n + 2), h + 2 * (n + 2)};
+        const size_t lens[3] = {n + 2, n + 2, n + 2};
+        ZK_TRY(commit_group(3, polys, lens, c_h, []() -> int { return ZK_OK; }));
+        if (chain.ok) ZK_TRY(slot_sync(s, st));  // h_flag (chain mode does not synchronise this stream)
     }
     if (h_flag) return set_err(ZK_ERR_ARG, "the solution does not satisfy the constraint system (the quotient is not a polynomial)");
     for (int k = 0; k < 3; k++) fs.bind_g1(3, c_h[k]);
@@ -1122,9 +1203,10 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     HFr ev[8];
     ZK_HIP(hipMemcpyAsync(ev, d_vals, 6 * sizeof(Fr), hipMemcpyDeviceToHost, st));
     ZK_TRY(slot_sync(s, st));  // ev[] is valid, the quotient of z is complete
-    AsyncCommit azo;
-    if (g_plonk_serial) ZK_TRY(commit(P, s, st, quo, n + 2, &c_zopen));
-    else azo.start(P, quo, n + 2);  // joined at the end of the proof: nothing below depends on it
+    AsyncCommit azo;  // the opening of z: finished / joined at the end of the proof, nothing below depends on it
+    if (chain.ok) ZK_TRY(chain.start(0, st, quo, n + 2));
+    else if (g_plonk_serial) ZK_TRY(commit(P, s, st, quo, n + 2, &c_zopen));
+    else azo.start(P, quo, n + 2);
     const HFr lz = ev[0], rz = ev[1], oz = ev[2], s1z = ev[3], s2z = ev[4], zu = ev[5];
 
     // ---- linearised polynomial
@@ -1142,7 +1224,8 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         A.n = (uint32_t)n; A.len = (uint32_t)(n + 3);
         ZK_LAUNCH(s, st, "plonk_linearized", k_linearized, dim3(grid_of(n + 3)), dim3(256), 0, A);
     }
-    ZK_TRY(commit(P, s, st, lin, n + 3, &c_lin));
+    if (chain.ok) ZK_TRY(chain.start(1, st, lin, n + 3));  // finished below, after the folded quotient and the last two evaluations are enqueued
+    else ZK_TRY(commit(P, s, st, lin, n + 3, &c_lin));
 
     // ---- folded quotient h1 + zeta^(n+2) h2 + zeta^(2(n+2)) h3 and its digest
     HFr zp = HFr::one();
@@ -1170,6 +1253,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     ZK_TRY(poly_eval_dev(s, st, lin, n + 3, zeta, SB, d_vals + 7));
     ZK_HIP(hipMemcpyAsync(ev + 6, d_vals + 6, 2 * sizeof(Fr), hipMemcpyDeviceToHost, st));
     ZK_TRY(slot_sync(s, st));
+    if (chain.ok) ZK_TRY(chain.finish(1, &c_lin));
     const HFr claimed[7] = {ev[6], ev[7], lz, rz, oz, s1z, s2z};
     const Affine<HFp> digests[7] = {c_fh, c_lin, c_lro[0], c_lro[1], c_lro[2], P->vk_s[0], P->vk_s[1]};
     HFr kg;
@@ -1192,11 +1276,16 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     }
     // dividePolyByXminusA(folded, foldedEvaluations, zeta): the recurrence yields the same quotient (folded(zeta) = sum gamma^i v_i)
     ZK_TRY(poly_divide_dev(s, st, fold, n + 3, zeta, SB, fold, d_vals + 8));
-    ZK_TRY(commit(P, s, st, fold, n + 2, &c_batch));
-
-    if (!g_plonk_serial) {
-        ZK_TRY(azo.join());
-        c_zopen = azo.out;
+    if (chain.ok) {
+        ZK_TRY(chain.start(2, st, fold, n + 2));
+        ZK_TRY(chain.finish(0, &c_zopen));
+        ZK_TRY(chain.finish(2, &c_batch));
+    } else {
+        ZK_TRY(commit(P, s, st, fold, n + 2, &c_batch));
+        if (!g_plonk_serial) {
+            ZK_TRY(azo.join());
+            c_zopen = azo.out;
+        }
     }
     // ---- Proof.WriteTo
     uint8_t* o = proof_out;
