@@ -463,10 +463,12 @@ struct CommitChain {
         hipEvent_t ev;
         ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         ZK_HIP(hipEventRecord(ev, producer));
-        ZK_HIP(hipStreamWaitEvent(s->stream, ev, 0));
+        static const bool prep_hi = !(getenv("ZKMI_PLONK_PREP_HI") && atoi(getenv("ZKMI_PLONK_PREP_HI")) == 0);  // A/B switch
+        hipStream_t sp = prep_hi ? s->stream_hi : s->stream;  // the preparation at high priority: its sort must get wave slots under a running accumulate
+        ZK_HIP(hipStreamWaitEvent(sp, ev, 0));
         (void)hipEventDestroy(ev);
         job[k] = MsmJob();
-        ZK_TRY(msm_prepare_scalars_table(s, s->stream, d_p, len, &kMont, tab, &prep[k]));
+        ZK_TRY(msm_prepare_scalars_table(s, sp, d_p, len, &kMont, tab, &prep[k]));
         live[k] = true;
         job[k].gate_acc = last_acc;
         job[k].want_done = true;
@@ -495,12 +497,17 @@ struct CommitChain {
     ~CommitChain() {
         for (int k = 0; k < NJ; k++)
             if (live[k]) {
+                (void)hipStreamSynchronize(g.s[k]->stream_hi);
                 (void)hipStreamSynchronize(g.s[k]->stream);
                 release(k);
             }
     }
 };
-static const bool g_plonk_chain = !(getenv("ZKMI_PLONK_CHAIN") && atoi(getenv("ZKMI_PLONK_CHAIN")) == 0);  // A/B switch
+// Measured (round 2, 2^22 gates, one box, alternating runs): chain 88.5 - 91.1 ms against 86.8 - 89.7 ms for the thread-per-commit mode, with the preparation
+// at normal or high priority and with latency- or work-structured tails -- rocPRIM's onesweep sort does not make progress underneath a running accumulate
+// kernel (its look-back tiles spin for wave slots), so "sort under accumulate" buys nothing here and the strict one-at-a-time order costs the overlap the
+// threads get by accident.  Off by default; ZKMI_PLONK_CHAIN=1 selects it.
+static const bool g_plonk_chain = getenv("ZKMI_PLONK_CHAIN") && atoi(getenv("ZKMI_PLONK_CHAIN")) == 1;
 static const bool g_plonk_serial = getenv("ZKMI_PLONK_SERIAL") && atoi(getenv("ZKMI_PLONK_SERIAL")) == 1;  // A/B switch: commitments one after the other
 
 // Lagrange (regular) -> canonical (regular) on the small domain, in place: FFTInverse(DIF) + BitReverse, as setup.go / iop.ToCanonical do
