@@ -200,6 +200,20 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
 int zk_bn254_groth16_prove_r1cs(uint64_t r1cs_handle, uint64_t pk_handle, const void *w, size_t n_wires, const zk_fr *r,
                                 const zk_fr *s, int on_device, uint8_t proof_out[128]);
 
+/* ---- Groth16 key wire formats (gnark v0.8.0 groth16 marshal.go): what the reference's intended Groth16 FFI moves as hex --
+ * ProveWithPK(rawR1CS, encodedProvingKey) -> provingKey.ReadFrom at gnark_backend_ffi/backend/groth16/r1cs.go:107-143; Preprocess -> both keys at
+ * r1cs.go:214-266.  ProvingKey.WriteTo (compressed points): Domain 168 B | G1.Alpha, Beta, Delta | G1.A, G1.B, G1.Z, G1.K (u32 count + 32 B each) |
+ * G2.Beta, Delta | G2.B (u32 count + 64 B each) | nbWires, NbInfinityA, NbInfinityB (u64) | InfinityA, InfinityB (nbWires bytes each).
+ *   pk_read : every point is decompressed ON THE DEVICE (G1: one square root; G2: an Fp2 square root + the r-torsion check gnark-crypto's Decoder
+ *             applies), then the key is loaded like zk_bn254_groth16_pk_load's gnark layout.  flags: bit 0 = no window tables.
+ *   pk_write: out == NULL only returns the size in *out_len.  A / B / G2.B leave without their points at infinity.
+ *   vk_write: VerifyingKey.WriteTo = [alpha]1 [beta]1 [beta]2 [gamma]2 [delta]1 [delta]2 u32 len(K) K, from zk_bn254_groth16_setup's vk_g1 (n_k =
+ *             n_public points after [alpha]1) / vk_g2 and the resident key. */
+int zk_bn254_groth16_pk_read(const void *data, size_t len, int is_hex, int flags, int table_window_bits, uint64_t *handle);
+int zk_bn254_groth16_pk_write(uint64_t handle, int as_hex, void *out, size_t cap, size_t *out_len);
+int zk_bn254_groth16_vk_write(uint64_t pk_handle, const zk_g1_affine *vk_g1, size_t n_k, const zk_g2_affine vk_g2[3], int as_hex, void *out,
+                              size_t cap, size_t *out_len);
+
 /* The two halves of zk_bn254_groth16_prove, exposed so that one proof can be range-sharded over several GPUs
  * (one process per GPU): every rank runs the five MSMs on ITS slice of the bases / wire values / h, the un-normalised
  * XYZZ sums (4 x G1 = 64 limbs, then G2 = 32 limbs; order A, B1, K, Z, B2) are all-gathered, and any rank finishes.
@@ -306,6 +320,18 @@ int zk_acir_to_sparse_r1cs(const char *acir_json, size_t acir_len, size_t n_valu
  * (*d_witness, n_wires Montgomery elements; release with zk_dev_free) -- feed them to zk_bn254_groth16_setup / zk_bn254_groth16_prove_r1cs
  * (on_device = 1).  See frontend.hip for the points where the reference's sketch is made well-defined. */
 int zk_groth16_r1cs_from_raw(const char *raw_json, size_t len, uint64_t *r1cs_handle, void **d_witness, size_t *n_wires, size_t *n_public);
+/* The exported entry points of that FFI, restated over the device path (errors are codes instead of log.Fatal; outputs go to caller buffers, no
+ * terminator; randomness may be pinned, NULL = /dev/urandom as upstream draws it):
+ *   zk_groth16_preprocess      Preprocess    (r1cs.go:214-266): groth16.Setup -> hex(ProvingKey.WriteTo), hex(VerifyingKey.WriteTo); toxic = tau, alpha,
+ *                              beta, gamma, delta.  pk_hex_out == NULL only returns the sizes; pk_handle (optional) keeps the key resident.
+ *   zk_groth16_prove_with_pk   ProveWithPK   (r1cs.go:107-143): hex key (or pk_handle when pk_hex == NULL) -> 256 hex characters of Proof.WriteTo;
+ *                              rs = the prover's (r, s).
+ *   zk_groth16_prove_with_meta ProveWithMeta (r1cs.go:74-105): Setup + Prove, the key never leaves HBM. */
+int zk_groth16_preprocess(const char *raw_json, size_t raw_len, const zk_fr *toxic, char *pk_hex_out, size_t pk_cap, size_t *pk_len,
+                          char *vk_hex_out, size_t vk_cap, size_t *vk_len, uint64_t *pk_handle);
+int zk_groth16_prove_with_pk(const char *raw_json, size_t raw_len, const char *pk_hex, size_t pk_len, uint64_t pk_handle, const zk_fr *rs,
+                             char proof_hex_out[256]);
+int zk_groth16_prove_with_meta(const char *raw_json, size_t raw_len, const zk_fr *toxic, const zk_fr *rs, char proof_hex_out[256]);
 
 /* What the MSM planner picks for n points (with / without resident window tables): window width c and the number of c-bit
  * digits per scalar, i.e. mixed additions per scalar multiplication -- used by bench.py to turn launches into work. */

@@ -486,6 +486,98 @@ int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_ha
     return ZK_OK;
 }
 
+// uniform-enough field elements for prover randomness / toxic waste (upstream: fr.SetRandom's rejection sampling over crypto/rand)
+static int random_frs(HFr* out, int n, bool nonzero) {
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f) return set_err(ZK_ERR_ARG, "no randomness source");
+    for (int i = 0; i < n; i++) {
+        uint64_t t[4];
+        do {
+            if (fread(t, 1, 32, f) != 32) { fclose(f); return set_err(ZK_ERR_ARG, "no randomness source"); }
+            t[3] &= 0x3fffffffffffffffULL;
+        } while (HFr::geq_mod(t) || (nonzero && !(t[0] | t[1] | t[2] | t[3])));  // rejection: r > 2^253, at most ~1.3 draws on average
+        out[i] = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+    }
+    fclose(f);
+    return ZK_OK;
+}
+
+namespace {
+struct RawInstance {  // a RawR1CS lowered and resident; released on scope exit
+    uint64_t r1cs = 0;
+    void* d_w = nullptr;
+    size_t n_wires = 0, n_public = 0;
+    ~RawInstance() {
+        if (d_w) (void)zk_dev_free(d_w);
+        if (r1cs) (void)zk_bn254_r1cs_free(r1cs);
+    }
+};
+void hex_of(const uint8_t* b, size_t n, char* o) {
+    static const char* dg = "0123456789abcdef";
+    for (size_t i = 0; i < n; i++) { o[2 * i] = dg[b[i] >> 4]; o[2 * i + 1] = dg[b[i] & 15]; }
+}
+}  // namespace
+
+// Preprocess of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:214-266): RawR1CS JSON -> groth16.Setup -> hex(ProvingKey.WriteTo),
+// hex(VerifyingKey.WriteTo).  toxic: tau, alpha, beta, gamma, delta (Montgomery, non-zero) or NULL (/dev/urandom, as upstream draws them).
+// pk_hex_out == NULL: only the sizes (the key is built to learn NbInfinityA / NbInfinityB).  pk_handle (optional) keeps the key resident.
+int zk_groth16_preprocess(const char* raw_json, size_t raw_len, const zk_fr* toxic, char* pk_hex_out, size_t pk_cap, size_t* pk_len, char* vk_hex_out, size_t vk_cap,
+                          size_t* vk_len, uint64_t* pk_handle) {
+    if (!raw_json || !pk_len || !vk_len) return set_err(ZK_ERR_ARG, "null pointer");
+    RawInstance I;
+    ZK_TRY(zk_groth16_r1cs_from_raw(raw_json, raw_len, &I.r1cs, &I.d_w, &I.n_wires, &I.n_public));
+    HFr tx[5];
+    if (toxic) memcpy(tx, toxic, sizeof tx);
+    else ZK_TRY(random_frs(tx, 5, true));
+    std::vector<zk_g1_affine> vk_g1(1 + I.n_public);
+    zk_g2_affine vk_g2[3];
+    uint64_t h = 0;
+    ZK_TRY(zk_bn254_groth16_setup(I.r1cs, (const zk_fr*)tx, 0, &h, vk_g1.data(), vk_g2));
+    int rc = zk_bn254_groth16_pk_write(h, 1, pk_hex_out, pk_cap, pk_len);
+    if (rc == ZK_OK) rc = zk_bn254_groth16_vk_write(h, vk_g1.data(), I.n_public, vk_g2, 1, pk_hex_out ? vk_hex_out : nullptr, vk_cap, vk_len);
+    if (rc == ZK_OK && pk_handle && pk_hex_out) *pk_handle = h;
+    else (void)zk_bn254_groth16_pk_free(h);
+    return rc;
+}
+
+// ProveWithPK (r1cs.go:107-143): RawR1CS JSON + hex(ProvingKey.WriteTo) -> hex(Proof.WriteTo) (256 characters, no terminator).  pk_hex may be NULL when
+// pk_handle names a resident key (the reference deserialises the key on every call).  rs: the prover's (r, s) or NULL (/dev/urandom).
+int zk_groth16_prove_with_pk(const char* raw_json, size_t raw_len, const char* pk_hex, size_t pk_len, uint64_t pk_handle, const zk_fr* rs, char proof_hex_out[256]) {
+    if (!raw_json || !proof_hex_out || (!pk_hex && !pk_handle)) return set_err(ZK_ERR_ARG, "null pointer");
+    RawInstance I;
+    ZK_TRY(zk_groth16_r1cs_from_raw(raw_json, raw_len, &I.r1cs, &I.d_w, &I.n_wires, &I.n_public));
+    uint64_t h = pk_handle;
+    if (pk_hex) ZK_TRY(zk_bn254_groth16_pk_read(pk_hex, pk_len, 1, 0, 0, &h));
+    HFr r2[2];
+    int rc = ZK_OK;
+    if (rs) memcpy(r2, rs, sizeof r2);
+    else rc = random_frs(r2, 2, false);
+    uint8_t proof[128];
+    if (rc == ZK_OK) rc = zk_bn254_groth16_prove_r1cs(I.r1cs, h, I.d_w, I.n_wires, (const zk_fr*)&r2[0], (const zk_fr*)&r2[1], 1, proof);
+    if (pk_hex) (void)zk_bn254_groth16_pk_free(h);
+    if (rc == ZK_OK) hex_of(proof, 128, proof_hex_out);
+    return rc;
+}
+
+// ProveWithMeta (r1cs.go:74-105): Setup and Prove in one call (the proving key never leaves HBM).
+int zk_groth16_prove_with_meta(const char* raw_json, size_t raw_len, const zk_fr* toxic, const zk_fr* rs, char proof_hex_out[256]) {
+    if (!raw_json || !proof_hex_out) return set_err(ZK_ERR_ARG, "null pointer");
+    RawInstance I;
+    ZK_TRY(zk_groth16_r1cs_from_raw(raw_json, raw_len, &I.r1cs, &I.d_w, &I.n_wires, &I.n_public));
+    HFr tx[5], r2[2];
+    if (toxic) memcpy(tx, toxic, sizeof tx);
+    else ZK_TRY(random_frs(tx, 5, true));
+    if (rs) memcpy(r2, rs, sizeof r2);
+    else ZK_TRY(random_frs(r2, 2, false));
+    uint64_t h = 0;
+    ZK_TRY(zk_bn254_groth16_setup(I.r1cs, (const zk_fr*)tx, 1, &h, nullptr, nullptr));  // one proof: window tables would cost more than they save
+    uint8_t proof[128];
+    int rc = zk_bn254_groth16_prove_r1cs(I.r1cs, h, I.d_w, I.n_wires, (const zk_fr*)&r2[0], (const zk_fr*)&r2[1], 1, proof);
+    (void)zk_bn254_groth16_pk_free(h);
+    if (rc == ZK_OK) hex_of(proof, 128, proof_hex_out);
+    return rc;
+}
+
 // The lowering alone, for inspection / tests: gates of an ACIR circuit as the reference's BuildSparseR1CS emits them.  Any out pointer may be
 // NULL; arrays need *n_constraints (first call with NULL arrays to size them) entries; coefficients come back as Montgomery fr.Elements.
 int zk_acir_to_sparse_r1cs(const char* acir_json, size_t acir_len, size_t n_values, size_t* n_public, size_t* n_vars, size_t* n_constraints, zk_fr* ql, zk_fr* qr,

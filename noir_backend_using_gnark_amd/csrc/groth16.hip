@@ -21,6 +21,7 @@
 #include "ctx.hpp"
 #include "curve.hpp"
 #include "host_ff.hpp"
+#include "keyio.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
 #include "proofio.hpp"
@@ -275,6 +276,18 @@ int groth16_pk_adopt(uint64_t handle) {
     if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
     it->second.owns = true;
     it->second.owns_abb = false;
+    return ZK_OK;
+}
+int groth16_pk_view(uint64_t handle, Groth16View* v) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
+    const Groth16PK& P = it->second;
+    v->log_domain = P.log_domain;
+    v->n_wires = P.n_wires; v->n_public = P.n_public; v->nz = P.nz;
+    v->alpha = P.alpha; v->beta = P.beta; v->delta = P.delta;
+    v->beta2 = P.beta2; v->delta2 = P.delta2;
+    v->d_a = P.d_a; v->d_b = P.d_b; v->d_k = P.d_k; v->d_z = P.d_z; v->d_b2 = P.d_b2;
     return ZK_OK;
 }
 }  // namespace zkmi

@@ -15,6 +15,8 @@
 #include "ff.hpp"
 #include "keyio.hpp"
 #include "msm.hpp"
+#include "ntt.hpp"
+#include "proofio.hpp"
 
 namespace zkmi {
 
@@ -137,6 +139,112 @@ __global__ void k_g1_compress(const Affine<Fp>* __restrict__ pts, size_t n, uint
     store_be32(raw + 8 * i, x);
 }
 
+
+// ---- G2 points on the device (a Groth16 proving key holds one per wire)
+__device__ __forceinline__ Fp2 f2_pow_dev(Fp2 a, const uint32_t e[8]) {
+    Fp2 r = Fp2::one();
+    for (int i = 0; i < 254; i++) {
+        if ((e[i >> 5] >> (i & 31)) & 1) r = r * a;
+        a = a.sqr();
+    }
+    return r;
+}
+// square root in Fp2 = Fp[u]/(u^2 + 1), q = 3 mod 4 (Adj & Rodriguez-Henriquez, Alg. 9): two 254-bit exponentiations
+__device__ bool f2_sqrt_dev(const Fp2& a, Fp2* out) {
+    if (a.is_zero()) { *out = a; return true; }
+    const uint32_t E1[8] = {0xb61f3f51u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};  // (q - 3) / 4
+    const uint32_t E2[8] = {0x6c3e7ea3u, 0x9e10460bu, 0xb438e546u, 0xcbc0b548u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};  // (q - 1) / 2
+    const Fp2 minus_one = Fp2{Fp::zero() - Fp::one(), Fp::zero()};
+    Fp2 a1 = f2_pow_dev(a, E1);
+    Fp2 alpha = a1 * (a1 * a);
+    Fp2 a0 = Fp2{alpha.a0, alpha.a1.neg()} * alpha;
+    if (a0 == minus_one) return false;
+    Fp2 x0 = a1 * a;
+    if (alpha == minus_one) {
+        *out = Fp2{Fp::zero(), Fp::one()} * x0;
+    } else {
+        Fp2 b = f2_pow_dev(Fp2::one() + alpha, E2);
+        *out = b * x0;
+    }
+    return out->sqr() == a;
+}
+__device__ __forceinline__ bool f2_lex_largest_dev(const Fp2& y) {  // gnark-crypto: compares A1 first, A0 when A1 = 0
+    return y.a1.is_zero() ? fp_lex_largest_dev(y.a0.from_mont()) : fp_lex_largest_dev(y.a1.from_mont());
+}
+// G2Affine.SetBytes on a compressed encoding (X.A1 | X.A0 big-endian, flags on the first byte) with the subgroup check the gnark-crypto Decoder
+// applies by default (r * P = infinity: the twist has a cofactor).  bt = 3 / (9 + u), Montgomery.
+__global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restrict__ raw, size_t n, Fp2 bt, Affine<Fp2>* __restrict__ out, int* __restrict__ status) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp x1 = load_be32<Fp>(raw + 16 * i), x0 = load_be32<Fp>(raw + 16 * i + 8);
+    const uint32_t flag = x1.l[7] >> 30;
+    x1.l[7] &= 0x3fffffffu;
+    Affine<Fp2> p = Affine<Fp2>::inf();
+    if (flag == 1) {
+        if (!x1.is_zero() || !x0.is_zero()) atomicOr(status, 8);
+        out[i] = p;
+        return;
+    }
+    if (flag == 0 || geq_mod<FpParams>(x1.l) || geq_mod<FpParams>(x0.l)) {
+        atomicOr(status, 8);
+        out[i] = p;
+        return;
+    }
+    Fp2 x{x0.to_mont(), x1.to_mont()};
+    Fp2 rhs = x.sqr() * x + bt, y;
+    if (!f2_sqrt_dev(rhs, &y)) {
+        atomicOr(status, 8);
+        out[i] = p;
+        return;
+    }
+    if (f2_lex_largest_dev(y) != (flag == 3)) y = y.neg();
+    p.x = x;
+    p.y = y;
+    const uint32_t rk[8] = {FrParams::MOD[0], FrParams::MOD[1], FrParams::MOD[2], FrParams::MOD[3], FrParams::MOD[4], FrParams::MOD[5], FrParams::MOD[6], FrParams::MOD[7]};
+    if (!scalar_mul(p, rk).is_inf()) {
+        atomicOr(status, 16);
+        out[i] = Affine<Fp2>::inf();
+        return;
+    }
+    out[i] = p;
+}
+// idx == nullptr: point i; else point idx[i] (a key is stored wire-indexed and written without its points at infinity)
+__global__ void k_g2_compress(const Affine<Fp2>* __restrict__ pts, const uint32_t* __restrict__ idx, size_t n, uint32_t* __restrict__ raw) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<Fp2> p = pts[idx ? idx[i] : i];
+    Fp x1 = Fp::zero(), x0 = Fp::zero();
+    uint32_t flag = 1;
+    if (!p.is_inf()) {
+        x1 = p.x.a1.from_mont();
+        x0 = p.x.a0.from_mont();
+        flag = f2_lex_largest_dev(p.y) ? 3 : 2;
+    }
+    x1.l[7] |= flag << 30;
+    store_be32(raw + 16 * i, x1);
+    store_be32(raw + 16 * i + 8, x0);
+}
+__global__ void k_g1_compress_idx(const Affine<Fp>* __restrict__ pts, const uint32_t* __restrict__ idx, size_t n, uint32_t* __restrict__ raw) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<Fp> p = pts[idx[i]];
+    Fp x = Fp::zero();
+    uint32_t flag = 1;
+    if (!p.is_inf()) {
+        x = p.x.from_mont();
+        flag = fp_lex_largest_dev(p.y.from_mont()) ? 3 : 2;
+    }
+    x.l[7] |= flag << 30;
+    store_be32(raw + 8 * i, x);
+}
+// InfinityA / InfinityB of a wire-indexed array: one byte per point
+template <class F>
+__global__ void k_inf_flags(const Affine<F>* __restrict__ pts, size_t n, uint8_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = pts[i].is_inf() ? 1 : 0;
+}
+
 static unsigned grid1(size_t n) { return (unsigned)((n + 255) / 256); }
 
 int hex_decode_dev(Slot* s, hipStream_t st, const void* d_text, size_t n_bytes, void* d_out, int* d_status) {
@@ -163,6 +271,30 @@ int g1_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void
 }
 int g1_compress_dev(Slot* s, hipStream_t st, const void* d_pts, size_t n, void* d_raw) {
     if (n) ZK_LAUNCH(s, st, "g1_compress", k_g1_compress, dim3(grid1(n)), dim3(256), 0, (const Affine<Fp>*)d_pts, n, (uint32_t*)d_raw);
+    return ZK_OK;
+}
+
+int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void* d_out, int* d_status) {
+    HFp nine = HFp::zero(), three = HFp::one() + HFp::one() + HFp::one();
+    for (int i = 0; i < 3; i++) nine = nine + three;
+    const HFp2 bt = HFp2{three, HFp::zero()} * HFp2{nine, HFp::one()}.inv();
+    Fp2 btd;
+    memcpy(&btd, &bt, sizeof btd);
+    if (n) ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, (Affine<Fp2>*)d_out, d_status);
+    return ZK_OK;
+}
+int g2_compress_dev(Slot* s, hipStream_t st, const void* d_pts, const uint32_t* d_idx, size_t n, void* d_raw) {
+    if (n) ZK_LAUNCH(s, st, "g2_compress", k_g2_compress, dim3(grid1(n)), dim3(256), 0, (const Affine<Fp2>*)d_pts, d_idx, n, (uint32_t*)d_raw);
+    return ZK_OK;
+}
+int g1_compress_idx_dev(Slot* s, hipStream_t st, const void* d_pts, const uint32_t* d_idx, size_t n, void* d_raw) {
+    if (n) ZK_LAUNCH(s, st, "g1_compress", k_g1_compress_idx, dim3(grid1(n)), dim3(256), 0, (const Affine<Fp>*)d_pts, d_idx, n, (uint32_t*)d_raw);
+    return ZK_OK;
+}
+int inf_flags_dev(Slot* s, hipStream_t st, int is_g2, const void* d_pts, size_t n, void* d_out) {
+    if (!n) return ZK_OK;
+    if (is_g2) ZK_LAUNCH(s, st, "inf_flags", k_inf_flags<Fp2>, dim3(grid1(n)), dim3(256), 0, (const Affine<Fp2>*)d_pts, n, (uint8_t*)d_out);
+    else ZK_LAUNCH(s, st, "inf_flags", k_inf_flags<Fp>, dim3(grid1(n)), dim3(256), 0, (const Affine<Fp>*)d_pts, n, (uint8_t*)d_out);
     return ZK_OK;
 }
 
@@ -334,5 +466,299 @@ int zk_bn254_kzg_srs_write(uint64_t handle, const zk_g2_affine g2[2], int as_hex
     }
     return slot_sync(s, st);
 }
+
+// ---- Groth16 keys (gnark v0.8.0 internal/backend/bn254/groth16/marshal.go  [UPSTREAM-RECALL]) -- what the reference's intended Groth16 FFI moves as hex:
+// ProveWithPK(rawR1CS, encodedProvingKey) -> provingKey.ReadFrom  [REF gnark_backend_ffi/backend/groth16/r1cs.go:107-143], Preprocess -> both keys
+// out [REF r1cs.go:214-266].  ProvingKey.WriteTo (compressed):
+//   Domain.WriteTo 168 B | G1.Alpha, G1.Beta, G1.Delta 3 x 32 | G1.A, G1.B, G1.Z, G1.K each u32 count + 32 B per point | G2.Beta, G2.Delta 2 x 64
+//   | G2.B u32 count + 64 B per point | nbWires u64 | NbInfinityA u64 | NbInfinityB u64 | InfinityA, InfinityB: nbWires bytes (0 / 1) each, no prefix
+// A, B, G2.B are stored WITHOUT their points at infinity (that is what the bitmaps are for); the public-wire count is nbWires - len(K).
+namespace {
+struct Blob {  // the caller's buffer: bytes, or their hex text
+    const uint8_t* p;
+    size_t len;
+    bool hex;
+    size_t nbytes() const { return hex ? len / 2 : len; }
+    bool get(size_t off, size_t n, uint8_t* dst) const {
+        if (off > nbytes() || n > nbytes() - off) return false;
+        if (!hex) { memcpy(dst, p + off, n); return true; }
+        for (size_t i = 0; i < n; i++) {
+            int v = 0;
+            for (int k = 0; k < 2; k++) {
+                const int c = p[2 * (off + i) + k], d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1;
+                if (d < 0) return false;
+                v = (v << 4) | d;
+            }
+            dst[i] = (uint8_t)v;
+        }
+        return true;
+    }
+    bool u32(size_t off, size_t* v) const {
+        uint8_t b[4];
+        if (!get(off, 4, b)) return false;
+        *v = ((size_t)b[0] << 24) | ((size_t)b[1] << 16) | ((size_t)b[2] << 8) | b[3];
+        return true;
+    }
+    bool u64(size_t off, uint64_t* v) const {
+        uint8_t b[8];
+        if (!get(off, 8, b)) return false;
+        *v = 0;
+        for (int i = 0; i < 8; i++) *v = (*v << 8) | b[i];
+        return true;
+    }
+};
+void put_be(uint8_t* o, uint64_t v, int n) { for (int i = 0; i < n; i++) o[i] = (uint8_t)(v >> (8 * (n - 1 - i))); }
+void domain_bytes(const Domain* d, uint8_t o[168]) {
+    put_be(o, (uint64_t)1 << d->logn, 8);
+    fr_to_be(d->card_inv, o + 8);
+    fr_to_be(d->gen, o + 40);
+    fr_to_be(d->gen_inv, o + 72);
+    fr_to_be(d->coset, o + 104);
+    fr_to_be(d->coset_inv, o + 136);
+}
+struct DevFree {
+    std::vector<void*> ptrs;
+    bool keep = false;
+    int alloc(void** d, size_t bytes) {
+        ZK_HIP(hipMalloc(d, bytes ? bytes : 16));
+        ptrs.push_back(*d);
+        return ZK_OK;
+    }
+    ~DevFree() { if (!keep) for (void* q : ptrs) (void)hipFree(q); }
+};
+}  // namespace
+
+// groth16.ProvingKey.ReadFrom on the bytes (or hex text) of ProvingKey.WriteTo: every point is decompressed on the device (G1: one square root; G2:
+// an Fp2 square root and the subgroup check), A / B / G2.B are expanded to the wire-indexed resident layout and the window tables are built as in
+// zk_bn254_groth16_pk_load.  flags: bit 0 of zk_groth16_pk.flags (no window tables); table_window_bits as there.
+int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags, int table_window_bits, uint64_t* handle) {
+    if (!data || !handle) return set_err(ZK_ERR_ARG, "null pointer");
+    if (flags & ~1) return set_err(ZK_ERR_ARG, "only flag bit 0 (no window tables) applies to a key read from its wire format");
+    if (is_hex && (len & 1)) return set_err(ZK_ERR_LEN, "proving key: odd number of hex characters");
+    const Blob B{(const uint8_t*)data, len, is_hex != 0};
+    const size_t nbytes = B.nbytes();
+    const char* trunc = "proving key: truncated or invalid hex in the header fields";
+    uint64_t card = 0;
+    if (!B.u64(0, &card)) return set_err(ZK_ERR_LEN, "%s", trunc);
+    unsigned logN = 0;
+    while (logN < 28 && ((uint64_t)1 << logN) < card) logN++;
+    if (card == 0 || ((uint64_t)1 << logN) != card) return set_err(ZK_ERR_ARG, "proving key: domain cardinality %llu is not a power of two <= 2^28", (unsigned long long)card);
+    // section offsets
+    size_t off = 168 + 96, cnt[5] = {0, 0, 0, 0, 0}, at[5] = {0, 0, 0, 0, 0};  // A, B, Z, K, G2.B
+    for (int k = 0; k < 4; k++) {
+        if (!B.u32(off, &cnt[k])) return set_err(ZK_ERR_LEN, "%s", trunc);
+        at[k] = off + 4;
+        if (cnt[k] > (nbytes - at[k]) / 32) return set_err(ZK_ERR_LEN, "proving key: %zu bytes cannot hold a slice of %zu G1 points", nbytes, cnt[k]);
+        off = at[k] + 32 * cnt[k];
+    }
+    const size_t at_g2 = off;
+    off += 128;
+    if (!B.u32(off, &cnt[4])) return set_err(ZK_ERR_LEN, "%s", trunc);
+    at[4] = off + 4;
+    if (cnt[4] > (nbytes - at[4]) / 64) return set_err(ZK_ERR_LEN, "proving key: %zu bytes cannot hold a slice of %zu G2 points", nbytes, cnt[4]);
+    off = at[4] + 64 * cnt[4];
+    uint64_t nw = 0, nia = 0, nib = 0;
+    if (!B.u64(off, &nw) || !B.u64(off + 8, &nia) || !B.u64(off + 16, &nib)) return set_err(ZK_ERR_LEN, "%s", trunc);
+    const size_t at_bm = off + 24;
+    if (nw >= ((uint64_t)1 << 31) || nbytes != at_bm + 2 * nw) return set_err(ZK_ERR_LEN, "proving key: %zu bytes, the fields say %llu wires (%zu bytes)", nbytes, (unsigned long long)nw, at_bm + 2 * (size_t)nw);
+    if (nia > nw || nib > nw || cnt[0] != nw - nia || cnt[1] != nw - nib || cnt[4] != nw - nib) return set_err(ZK_ERR_ARG, "proving key: the point counts do not match NbInfinityA / NbInfinityB");
+    if (cnt[2] != card || cnt[3] > nw) return set_err(ZK_ERR_ARG, "proving key: Z holds %zu points for a domain of %llu, K %zu for %llu wires", cnt[2], (unsigned long long)card, cnt[3], (unsigned long long)nw);
+    std::vector<uint8_t> ia(nw ? nw : 1), ib(nw ? nw : 1);
+    if (!B.get(at_bm, nw, ia.data()) || !B.get(at_bm + nw, nw, ib.data())) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
+    for (size_t i = 0; i < nw; i++)
+        if (ia[i] > 1 || ib[i] > 1) return set_err(ZK_ERR_ARG, "proving key: a bool that is neither 0 nor 1");
+    uint8_t dom_in[168], dom_ok[168];
+    if (!B.get(0, 168, dom_in)) return set_err(ZK_ERR_LEN, "%s", trunc);
+
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    Slot* s = g.s;
+    hipStream_t st = s->stream;
+    Domain* dom;
+    ZK_TRY(get_domain(s, st, logN, 0, &dom));
+    domain_bytes(dom, dom_ok);
+    if (memcmp(dom_in, dom_ok, 168)) return set_err(ZK_ERR_ARG, "proving key: the domain is not gnark-crypto's radix-2 domain of that size");
+    // everything up to the bitmaps goes to the device (a multiple of 4 bytes by construction)
+    ZK_TRY(s->reserve((is_hex ? 2 * at_bm : 0) + at_bm + 4096));
+    int* d_status = (int*)s->alloc(64);
+    uint8_t* d_bytes = (uint8_t*)s->alloc(at_bm + 16);
+    ZK_HIP(hipMemsetAsync(d_status, 0, 4, st));
+    if (is_hex) {
+        void* d_text = s->alloc(2 * at_bm + 16);
+        ZK_HIP(hipMemcpyAsync(d_text, data, 2 * at_bm, hipMemcpyHostToDevice, st));
+        ZK_TRY(hex_decode_dev(s, st, d_text, at_bm, d_bytes, d_status));
+    } else {
+        ZK_HIP(hipMemcpyAsync(d_bytes, data, at_bm, hipMemcpyHostToDevice, st));
+    }
+    DevFree tmp, own;  // tmp: the compact A / B / G2.B and the five single points; own: K and Z, adopted by the key
+    void *d_a = nullptr, *d_b = nullptr, *d_b2 = nullptr, *d_k = nullptr, *d_z = nullptr, *d_single = nullptr;
+    ZK_TRY(tmp.alloc(&d_a, cnt[0] * 64));
+    ZK_TRY(tmp.alloc(&d_b, cnt[1] * 64));
+    ZK_TRY(tmp.alloc(&d_b2, cnt[4] * 128));
+    ZK_TRY(tmp.alloc(&d_single, 3 * 64 + 2 * 128));
+    ZK_TRY(own.alloc(&d_z, cnt[2] * 64));
+    ZK_TRY(own.alloc(&d_k, cnt[3] * 64));
+    ZK_TRY(g1_decompress_dev(s, st, d_bytes + 168, 3, d_single, d_status));
+    ZK_TRY(g2_decompress_dev(s, st, d_bytes + at_g2, 2, (uint8_t*)d_single + 192, d_status));
+    void* g1_dst[4] = {d_a, d_b, d_z, d_k};
+    for (int k = 0; k < 4; k++) ZK_TRY(g1_decompress_dev(s, st, d_bytes + at[k], cnt[k], g1_dst[k], d_status));
+    ZK_TRY(g2_decompress_dev(s, st, d_bytes + at[4], cnt[4], d_b2, d_status));
+    uint8_t single[3 * 64 + 2 * 128];
+    int h_status = 0;
+    ZK_HIP(hipMemcpyAsync(single, d_single, sizeof single, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(&h_status, d_status, 4, hipMemcpyDeviceToHost, st));
+    ZK_TRY(slot_sync(s, st));
+    if (h_status & 1) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
+    if (h_status & 4) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G1 point (bad flags, x >= q, or no square root)");
+    if (h_status & 8) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G2 point (bad flags, coordinate >= q, or no square root)");
+    if (h_status & 16) return set_err(ZK_ERR_ARG, "proving key: a G2 point outside the r-torsion subgroup");
+    s->reset();
+    release_slot(g.s);  // pk_load takes slots of its own
+    g.s = nullptr;
+    zk_groth16_pk pk;
+    memset(&pk, 0, sizeof pk);
+    pk.log_domain = logN;
+    pk.n_wires = nw;
+    pk.n_public = nw - cnt[3];
+    pk.g1_alpha = (const zk_g1_affine*)single;
+    pk.g1_beta = (const zk_g1_affine*)(single + 64);
+    pk.g1_delta = (const zk_g1_affine*)(single + 128);
+    pk.g2_beta = (const zk_g2_affine*)(single + 192);
+    pk.g2_delta = (const zk_g2_affine*)(single + 320);
+    pk.g1_a = (const zk_g1_affine*)d_a;
+    pk.g1_b = (const zk_g1_affine*)d_b;
+    pk.g1_k = (const zk_g1_affine*)d_k;
+    pk.g1_z = (const zk_g1_affine*)d_z;
+    pk.g2_b = (const zk_g2_affine*)d_b2;
+    pk.bases_on_device = 1;
+    pk.flags = flags;
+    pk.infinity_a = ia.data();
+    pk.infinity_b = ib.data();
+    pk.nb_infinity_a = nia;
+    pk.nb_infinity_b = nib;
+    pk.table_window_bits = table_window_bits;
+    ZK_TRY(zk_bn254_groth16_pk_load(&pk, handle));
+    ZK_TRY(groth16_pk_adopt(*handle));  // K and Z were allocated here for the key; A / B / G2.B are its own expanded arrays already
+    own.keep = true;
+    return ZK_OK;
+}
+
+// groth16.ProvingKey.WriteTo of a resident key: bytes (or hex text) into out; *out_len = bytes needed / written (out == NULL: size query).
+int zk_bn254_groth16_pk_write(uint64_t handle, int as_hex, void* out, size_t cap, size_t* out_len) {
+    if (!out_len) return set_err(ZK_ERR_ARG, "null pointer");
+    Groth16View v;
+    ZK_TRY(groth16_pk_view(handle, &v));
+    const size_t N = (size_t)1 << v.log_domain, nw = v.n_wires, nk = nw - v.n_public;
+    if (v.nz != N - 1 && N > 1) return set_err(ZK_ERR_ARG, "a range-sharded slice of a key has no gnark wire format");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    Slot* s = g.s;
+    hipStream_t st = s->stream;
+    // InfinityA / InfinityB from the wire-indexed arrays
+    ZK_TRY(s->reserve(2 * nw + 4096));
+    uint8_t* d_flags = (uint8_t*)s->alloc(2 * nw + 16);
+    std::vector<uint8_t> ia(nw ? nw : 1), ib(nw ? nw : 1);
+    ZK_TRY(inf_flags_dev(s, st, 0, v.d_a, nw, d_flags));
+    ZK_TRY(inf_flags_dev(s, st, 0, v.d_b, nw, d_flags + nw));
+    if (nw) {
+        ZK_HIP(hipMemcpyAsync(ia.data(), d_flags, nw, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipMemcpyAsync(ib.data(), d_flags + nw, nw, hipMemcpyDeviceToHost, st));
+    }
+    ZK_TRY(slot_sync(s, st));
+    std::vector<uint32_t> idx_a, idx_b;
+    for (size_t i = 0; i < nw; i++) {
+        if (!ia[i]) idx_a.push_back((uint32_t)i);
+        if (!ib[i]) idx_b.push_back((uint32_t)i);
+    }
+    const size_t na = idx_a.size(), nb = idx_b.size();
+    const size_t at_a = 168 + 96 + 4, at_b = at_a + 32 * na + 4, at_z = at_b + 32 * nb + 4, at_k = at_z + 32 * N + 4, at_g2 = at_k + 32 * nk, at_b2 = at_g2 + 128 + 4,
+                 at_cnt = at_b2 + 64 * nb, at_bm = at_cnt + 24, nbytes = at_bm + 2 * nw, need = as_hex ? 2 * nbytes : nbytes;
+    *out_len = need;
+    if (!out) return ZK_OK;
+    if (cap < need) return set_err(ZK_ERR_ARG, "output holds %zu bytes, %zu needed", cap, need);
+    s->reset();
+    const size_t padded = align_up(nbytes, 4);
+    ZK_TRY(s->reserve(3 * padded + 4 * (na + nb) + 65536));
+    uint8_t* d_bytes = (uint8_t*)s->alloc(padded + 16);
+    uint32_t* d_ia = (uint32_t*)s->alloc(4 * na + 16);
+    uint32_t* d_ib = (uint32_t*)s->alloc(4 * nb + 16);
+    if (na) ZK_HIP(hipMemcpyAsync(d_ia, idx_a.data(), 4 * na, hipMemcpyHostToDevice, st));
+    if (nb) ZK_HIP(hipMemcpyAsync(d_ib, idx_b.data(), 4 * nb, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemsetAsync(d_bytes + (padded - 4), 0, 4, st));
+    // host-built pieces: the head (domain, three G1 points, count of A), the counts, the two G2 points, the trailer
+    Domain* dom;
+    ZK_TRY(get_domain(s, st, v.log_domain, 0, &dom));
+    std::vector<uint8_t> head(at_a), mid(128 + 4), trailer(24 + 2 * nw);
+    domain_bytes(dom, head.data());
+    g1_compress(v.alpha, head.data() + 168);
+    g1_compress(v.beta, head.data() + 200);
+    g1_compress(v.delta, head.data() + 232);
+    put_be(head.data() + 264, na, 4);
+    uint8_t c_b[4], c_z[4], c_k[4];
+    put_be(c_b, nb, 4);
+    put_be(c_z, N, 4);
+    put_be(c_k, nk, 4);
+    g2_compress(v.beta2, mid.data());
+    g2_compress(v.delta2, mid.data() + 64);
+    put_be(mid.data() + 128, nb, 4);
+    put_be(trailer.data(), nw, 8);
+    put_be(trailer.data() + 8, nw - na, 8);
+    put_be(trailer.data() + 16, nw - nb, 8);
+    if (nw) {
+        memcpy(trailer.data() + 24, ia.data(), nw);
+        memcpy(trailer.data() + 24 + nw, ib.data(), nw);
+    }
+    ZK_HIP(hipMemcpyAsync(d_bytes, head.data(), at_a, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_bytes + at_b - 4, c_b, 4, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_bytes + at_z - 4, c_z, 4, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_bytes + at_k - 4, c_k, 4, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_bytes + at_g2, mid.data(), 132, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_bytes + at_cnt, trailer.data(), trailer.size(), hipMemcpyHostToDevice, st));
+    ZK_TRY(g1_compress_idx_dev(s, st, v.d_a, d_ia, na, d_bytes + at_a));
+    ZK_TRY(g1_compress_idx_dev(s, st, v.d_b, d_ib, nb, d_bytes + at_b));
+    ZK_TRY(g1_compress_dev(s, st, v.d_z, N, d_bytes + at_z));
+    ZK_TRY(g1_compress_dev(s, st, v.d_k, nk, d_bytes + at_k));
+    ZK_TRY(g2_compress_dev(s, st, v.d_b2, d_ib, nb, d_bytes + at_b2));
+    if (as_hex) {
+        void* d_text = s->alloc(2 * padded + 16);
+        ZK_TRY(hex_encode_dev(s, st, d_bytes, padded, d_text));
+        ZK_HIP(hipMemcpyAsync(out, d_text, 2 * nbytes, hipMemcpyDeviceToHost, st));
+    } else {
+        ZK_HIP(hipMemcpyAsync(out, d_bytes, nbytes, hipMemcpyDeviceToHost, st));
+    }
+    return slot_sync(s, st);  // the host staging vectors live until here
+}
+
+// groth16.VerifyingKey.WriteTo (compressed): [alpha]1, [beta]1, [beta]2, [gamma]2, [delta]1, [delta]2, u32 len(K), K  -- from what
+// zk_bn254_groth16_setup returns (vk_g1 = [alpha]1 then the n_k = n_public points K; vk_g2 = [beta]2, [gamma]2, [delta]2) and the resident
+// proving key ([beta]1, [delta]1).  Host only: 292 + 32 * n_k bytes.
+int zk_bn254_groth16_vk_write(uint64_t pk_handle, const zk_g1_affine* vk_g1, size_t n_k, const zk_g2_affine vk_g2[3], int as_hex, void* out, size_t cap,
+                              size_t* out_len) {
+    if (!vk_g1 || !vk_g2 || !out_len) return set_err(ZK_ERR_ARG, "null pointer");
+    Groth16View v;
+    ZK_TRY(groth16_pk_view(pk_handle, &v));
+    if (n_k != v.n_public) return set_err(ZK_ERR_LEN, "verifying key: %zu K points, the key has %zu public wires", n_k, v.n_public);
+    const size_t nbytes = 292 + 32 * n_k, need = as_hex ? 2 * nbytes : nbytes;
+    *out_len = need;
+    if (!out) return ZK_OK;
+    if (cap < need) return set_err(ZK_ERR_ARG, "output holds %zu bytes, %zu needed", cap, need);
+    std::vector<uint8_t> b(nbytes);
+    const Affine<HFp>* g1 = (const Affine<HFp>*)vk_g1;
+    const Affine<HFp2>* g2 = (const Affine<HFp2>*)vk_g2;
+    g1_compress(g1[0], b.data());
+    g1_compress(v.beta, b.data() + 32);
+    g2_compress(g2[0], b.data() + 64);
+    g2_compress(g2[1], b.data() + 128);
+    g1_compress(v.delta, b.data() + 192);
+    g2_compress(g2[2], b.data() + 224);
+    put_be(b.data() + 288, n_k, 4);
+    for (size_t i = 0; i < n_k; i++) g1_compress(g1[1 + i], b.data() + 292 + 32 * i);
+    if (!as_hex) { memcpy(out, b.data(), nbytes); return ZK_OK; }
+    static const char* dg = "0123456789abcdef";
+    char* o = (char*)out;
+    for (size_t i = 0; i < nbytes; i++) { o[2 * i] = dg[b[i] >> 4]; o[2 * i + 1] = dg[b[i] & 15]; }
+    return ZK_OK;
+}
+
 
 }  // extern "C"

@@ -2,6 +2,10 @@
     PlonkPreprocess(acirJSON, encodedValues) -> (hex pk, hex vk)          -> plonk_preprocess
     PlonkProveWithPK(acirJSON, encodedValues, encodedProvingKey) -> hex   -> plonk_prove_with_pk
     BuildSparseR1CS (backend/plonk/sparse_r1cs.go:18-107)                 -> acir_to_sparse_r1cs
+and of the intended Groth16 FFI (backend/groth16/r1cs.go:74-266, commented out upstream):
+    Preprocess(rawR1CS) -> (hex pk, hex vk)                               -> groth16_preprocess
+    ProveWithPK(rawR1CS, encodedProvingKey) -> hex proof                  -> groth16_prove_with_pk
+    ProveWithMeta(rawR1CS) -> hex proof                                   -> groth16_prove_with_meta
 Strings in, strings out, like the Rust side sees them (src/gnark_backend_wrapper/plonk/mod.rs:19-23, 207); the SRS is a resident
 `kzg.SRS` instead of the srs.hex file the reference re-reads on every call.  Everything dispatches to libzkmi.so."""
 from __future__ import annotations
@@ -74,3 +78,52 @@ def groth16_r1cs_from_raw(raw_json: str):
     buf = _lib.DeviceBuffer.__new__(_lib.DeviceBuffer)
     buf.ptr, buf.nbytes = int(d.value), nw.value * 32
     return R1CS.from_handle(h.value, npub.value, nw.value, -1), buf
+
+
+def _fr_arr(x, n):
+    return None if x is None else np.ascontiguousarray(x, dtype=np.uint64).reshape(n, 4)
+
+
+def groth16_preprocess(raw_json: str, toxic=None, keep_resident: bool = False):
+    """Preprocess (r1cs.go:214-266): groth16.Setup on the RawR1CS -> (pk_hex, vk_hex[, resident key handle]).  toxic: (5, 4) Montgomery tau, alpha,
+    beta, gamma, delta; None draws them like upstream (then the sizing call and the real one build different keys of the same size)."""
+    a = _b(raw_json)
+    tx = _fr_arr(toxic, 5)
+    pk_len, vk_len = C.c_size_t(0), C.c_size_t(0)
+    rc = lib().zk_groth16_preprocess(C.c_char_p(a), C.c_size_t(len(a)), vp(tx) if tx is not None else None, None, C.c_size_t(0), C.byref(pk_len), None, C.c_size_t(0),
+                                     C.byref(vk_len), None)
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    pk, vk = C.create_string_buffer(pk_len.value), C.create_string_buffer(vk_len.value)
+    h = C.c_uint64(0)
+    check(lib().zk_groth16_preprocess(C.c_char_p(a), C.c_size_t(len(a)), vp(tx) if tx is not None else None, pk, C.c_size_t(pk_len.value), C.byref(pk_len), vk,
+                                      C.c_size_t(vk_len.value), C.byref(vk_len), C.byref(h) if keep_resident else None))
+    out = (pk.raw[:pk_len.value].decode(), vk.raw[:vk_len.value].decode())
+    return out + (h.value,) if keep_resident else out
+
+
+def groth16_prove_with_pk(raw_json: str, encoded_pk: str | None, rs=None, pk_handle: int = 0) -> str:
+    """ProveWithPK (r1cs.go:107-143) -> hex of Proof.WriteTo (256 characters).  encoded_pk=None proves with the resident key `pk_handle`."""
+    a = _b(raw_json)
+    k = _b(encoded_pk) if encoded_pk is not None else None
+    r2 = _fr_arr(rs, 2)
+    out = C.create_string_buffer(256)
+    rc = lib().zk_groth16_prove_with_pk(C.c_char_p(a), C.c_size_t(len(a)), C.c_char_p(k) if k is not None else None, C.c_size_t(len(k) if k is not None else 0),
+                                        C.c_uint64(pk_handle), vp(r2) if r2 is not None else None, out)
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    return out.raw.decode()
+
+
+def groth16_prove_with_meta(raw_json: str, toxic=None, rs=None) -> str:
+    """ProveWithMeta (r1cs.go:74-105): Setup + Prove in one call -> hex of Proof.WriteTo."""
+    a = _b(raw_json)
+    tx, r2 = _fr_arr(toxic, 5), _fr_arr(rs, 2)
+    out = C.create_string_buffer(256)
+    rc = lib().zk_groth16_prove_with_meta(C.c_char_p(a), C.c_size_t(len(a)), vp(tx) if tx is not None else None, vp(r2) if r2 is not None else None, out)
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    return out.raw.decode()

@@ -72,6 +72,45 @@ class ProvingKey:
         pk.log_domain, pk.n_wires, pk.n_public, pk._keep, pk.handle = log_domain, n_wires, n_public, [], C.c_uint64(handle)
         return pk
 
+    @classmethod
+    def read_from(cls, data, is_hex: bool | None = None, precompute_tables: bool = True, table_window_bits: int = 0):
+        """groth16.ProvingKey.ReadFrom on the bytes of ProvingKey.WriteTo (or their hex text, the form the reference's ProveWithPK receives:
+        backend/groth16/r1cs.go:107-128): points are decompressed on the device."""
+        raw = data.encode("ascii") if isinstance(data, str) else bytes(data)
+        if is_hex is None:
+            is_hex = isinstance(data, str)
+        h = C.c_uint64(0)
+        rc = lib().zk_bn254_groth16_pk_read(C.c_char_p(raw), C.c_size_t(len(raw)), C.c_int(int(is_hex)), C.c_int(0 if precompute_tables else 1),
+                                            C.c_int(table_window_bits), C.byref(h))
+        if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+            raise ValueError((lib().zk_last_error() or b"").decode())
+        check(rc)
+        pk = cls.from_handle(h.value, 0, 0, 0)
+        i = pk.info()
+        pk.log_domain, pk.n_wires, pk.n_public = i["log_domain"], i["n_wires"], i["n_public"]
+        return pk
+
+    def write_to(self, as_hex: bool = False):
+        """groth16.ProvingKey.WriteTo (compressed points; A / B / G2.B without their points at infinity + InfinityA / InfinityB) -> bytes, or hex str"""
+        n = C.c_size_t(0)
+        check(lib().zk_bn254_groth16_pk_write(self.handle, C.c_int(int(as_hex)), None, C.c_size_t(0), C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        check(lib().zk_bn254_groth16_pk_write(self.handle, C.c_int(int(as_hex)), buf, C.c_size_t(n.value), C.byref(n)))
+        return buf.raw[:n.value].decode() if as_hex else buf.raw[:n.value]
+
+    def vk_write_to(self, vk: dict, as_hex: bool = False):
+        """groth16.VerifyingKey.WriteTo from setup()'s vk dict (this key supplies [beta]1 and [delta]1)"""
+        g1 = np.ascontiguousarray(np.concatenate([np.asarray(vk["g1_alpha"], np.uint64).reshape(1, 8), np.asarray(vk["g1_k"], np.uint64).reshape(-1, 8)]))
+        g2 = np.ascontiguousarray(np.stack([np.asarray(vk[k], np.uint64).reshape(16) for k in ("g2_beta", "g2_gamma", "g2_delta")]))
+        n = C.c_size_t(0)
+        cap = 2 * (292 + 32 * (g1.shape[0] - 1))
+        buf = C.create_string_buffer(cap)
+        rc = lib().zk_bn254_groth16_vk_write(self.handle, vp(g1), C.c_size_t(g1.shape[0] - 1), vp(g2), C.c_int(int(as_hex)), buf, C.c_size_t(cap), C.byref(n))
+        if rc == _lib.ZK_ERR_LEN:
+            raise ValueError((lib().zk_last_error() or b"").decode())
+        check(rc)
+        return buf.raw[:n.value].decode() if as_hex else buf.raw[:n.value]
+
     def info(self) -> dict:
         nw, npub, ld, tab = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0), C.c_int(0)
         check(lib().zk_bn254_groth16_pk_info(self.handle, C.byref(nw), C.byref(npub), C.byref(ld), C.byref(tab)))

@@ -555,8 +555,9 @@ def f2_sqrt(a):
     return ref.f2_mul(b, x0)
 
 
-def g2_decompress(b: bytes):
-    """inverse of G2Affine.Bytes(): X.A1 || X.A0 big-endian, flags as G1; "largest" compares Y.A1 first, then Y.A0"""
+def g2_decompress(b: bytes, subgroup_check: bool = True):
+    """inverse of G2Affine.Bytes(): X.A1 || X.A0 big-endian, flags as G1; "largest" compares Y.A1 first, then Y.A0.  The gnark-crypto Decoder
+    checks r-torsion membership by default (the twist has a cofactor): restated as r * P = infinity."""
     flag = b[0] >> 6
     if flag == 1:
         return None
@@ -574,6 +575,8 @@ def g2_decompress(b: bytes):
     largest = ref._lex_largest_fp(y[1]) if y[1] != 0 else ref._lex_largest_fp(y[0])
     if largest != (flag == 3):
         y = ref.f2_neg(y)
+    if subgroup_check and ref.ec_mul(ref.FP2, (x, y), R) is not None:
+        raise ValueError("invalid point: subgroup check failed")
     return (x, y)
 
 
@@ -658,6 +661,93 @@ def plonk_pk_from_bytes(b: bytes):
         raise ValueError("proving key: %d bytes left for the permutation, %d expected" % (len(b) - o, 3 * n * 8))
     pk["perm"] = [int.from_bytes(b[o + 8 * i:o + 8 * i + 8], "big", signed=True) for i in range(3 * n)]
     return pk
+
+
+# ---- Groth16 keys: what ProveWithPK / Preprocess of the reference's intended Groth16 FFI move as hex
+# [REF gnark_backend_ffi/backend/groth16/r1cs.go:107-143 (hex of ProvingKey.WriteTo -> provingKey.ReadFrom), :214-266 (Preprocess: both keys out)]
+def groth16_pk_compact(pk):
+    """oracle key (wire-indexed A / B / G2.B with None at infinity) -> gnark's stored form: the slices without their points at infinity plus
+    InfinityA / InfinityB  [UPSTREAM-RECALL gnark v0.8.0 internal/backend/bn254/groth16/setup.go: `if a.IsZero() { InfinityA[i] = true; n++ }`]"""
+    inf_a = [P is None for P in pk["g1_a"]]
+    inf_b = [P is None for P in pk["g1_b"]]
+    assert inf_b == [P is None for P in pk["g2_b"]]
+    return dict(pk, g1_a=[P for P in pk["g1_a"] if P is not None], g1_b=[P for P in pk["g1_b"] if P is not None],
+                g2_b=[P for P in pk["g2_b"] if P is not None], infinity_a=inf_a, infinity_b=inf_b)
+
+
+def groth16_pk_bytes(pk) -> bytes:
+    """groth16.ProvingKey.WriteTo (raw = false)  [UPSTREAM-RECALL gnark v0.8.0 internal/backend/bn254/groth16/marshal.go]: Domain.WriteTo, then
+    through the gnark-crypto Encoder: G1.Alpha, G1.Beta, G1.Delta, G1.A, G1.B, G1.Z, G1.K, G2.Beta, G2.Delta, G2.B, nbWires u64, NbInfinityA u64,
+    NbInfinityB u64, InfinityA, InfinityB -- the two []bool go through encoding/binary: one byte (0 / 1) per wire and NO length prefix (which is
+    why nbWires is written in front of them).  Takes the wire-indexed oracle key or its compact form."""
+    if "infinity_a" not in pk:
+        pk = groth16_pk_compact(pk)
+    g1s = lambda v: len(v).to_bytes(4, "big") + b"".join(ref.g1_compress(P) for P in v)
+    out = _domain_bytes(pk["domain"]) + b"".join(ref.g1_compress(pk[k]) for k in ("g1_alpha", "g1_beta", "g1_delta"))
+    out += g1s(pk["g1_a"]) + g1s(pk["g1_b"]) + g1s(pk["g1_z"]) + g1s(pk["g1_k"])
+    out += ref.g2_compress(pk["g2_beta"]) + ref.g2_compress(pk["g2_delta"])
+    out += len(pk["g2_b"]).to_bytes(4, "big") + b"".join(ref.g2_compress(P) for P in pk["g2_b"])
+    nw = len(pk["infinity_a"])
+    out += nw.to_bytes(8, "big") + sum(pk["infinity_a"]).to_bytes(8, "big") + sum(pk["infinity_b"]).to_bytes(8, "big")
+    return out + bytes(int(x) for x in pk["infinity_a"]) + bytes(int(x) for x in pk["infinity_b"])
+
+
+def groth16_pk_from_bytes(b: bytes):
+    """groth16.ProvingKey.ReadFrom -> the compact form (g1_a / g1_b / g2_b without their points at infinity + the bitmaps)"""
+    o = 0
+
+    def take(k):
+        nonlocal o
+        if o + k > len(b):
+            raise ValueError("proving key: truncated")
+        o += k
+        return b[o - k:o]
+
+    card = int.from_bytes(take(8), "big")
+    dom_rest = take(160)
+    if card == 0 or card & (card - 1) or _domain_bytes(Domain(card))[8:] != dom_rest:
+        raise ValueError("proving key: not a radix-2 domain of gnark-crypto's")
+    pk = dict(domain=Domain(card))
+    for k in ("g1_alpha", "g1_beta", "g1_delta"):
+        pk[k] = g1_decompress(take(32))
+
+    def g1s():
+        n = int.from_bytes(take(4), "big")
+        return [g1_decompress(take(32)) for _ in range(n)]
+
+    pk["g1_a"], pk["g1_b"], pk["g1_z"], pk["g1_k"] = g1s(), g1s(), g1s(), g1s()
+    pk["g2_beta"], pk["g2_delta"] = g2_decompress(take(64)), g2_decompress(take(64))
+    n = int.from_bytes(take(4), "big")
+    pk["g2_b"] = [g2_decompress(take(64)) for _ in range(n)]
+    nw, na, nb = (int.from_bytes(take(8), "big") for _ in range(3))
+    ia, ib = take(nw), take(nw)
+    if o != len(b):
+        raise ValueError("proving key: %d trailing bytes" % (len(b) - o))
+    if any(x > 1 for x in ia + ib):
+        raise ValueError("proving key: a bool that is neither 0 nor 1")
+    pk["infinity_a"], pk["infinity_b"] = [bool(x) for x in ia], [bool(x) for x in ib]
+    if sum(ia) != na or sum(ib) != nb or len(pk["g1_a"]) != nw - na or len(pk["g1_b"]) != nw - nb or len(pk["g2_b"]) != nw - nb:
+        raise ValueError("proving key: the point counts do not match InfinityA / InfinityB")
+    if len(pk["g1_z"]) != card or len(pk["g1_k"]) > nw:
+        raise ValueError("proving key: bad Z / K length")
+    return pk
+
+
+def groth16_pk_expand(pk):
+    """compact form -> wire-indexed (None at infinity), the layout bn254_ref.groth16_prove takes"""
+    out = dict(pk)
+    for key, inf in (("g1_a", "infinity_a"), ("g1_b", "infinity_b"), ("g2_b", "infinity_b")):
+        it = iter(pk[key])
+        out[key] = [None if f else next(it) for f in pk[inf]]
+    return out
+
+
+def groth16_vk_bytes(vk) -> bytes:
+    """groth16.VerifyingKey.WriteTo (raw = false)  [UPSTREAM-RECALL gnark v0.8.0 marshal.go: "[alpha]1,[beta]1,[beta]2,[gamma]2,[delta]1,[delta]2,
+    uint32(len(Kvk)),[Kvk]1"]; the oracle's vk carries g1_beta / g1_delta only through the proving key, so they are passed in it."""
+    out = ref.g1_compress(vk["g1_alpha"]) + ref.g1_compress(vk["g1_beta"]) + ref.g2_compress(vk["g2_beta"]) + ref.g2_compress(vk["g2_gamma"])
+    out += ref.g1_compress(vk["g1_delta"]) + ref.g2_compress(vk["g2_delta"])
+    return out + len(vk["g1_ic"]).to_bytes(4, "big") + b"".join(ref.g1_compress(P) for P in vk["g1_ic"])
 
 
 # ------------------------------------------------------------------------------------------------ RawR1CS (the reference's Groth16 payload)
