@@ -122,6 +122,21 @@ public:
         if (!e.ok()) return e;
         return make_error(zk_bn254_groth16_pk_info(handle_, &n_wires_, &n_public_, &log_domain_, nullptr));
     }
+    // (*ProvingKey).ReadFrom on the bytes of WriteTo (hex = true: the text the reference's ProveWithPK receives, backend/groth16/r1cs.go:107-128);
+    // every point is decompressed on the device
+    Error ReadFrom(const void* data, size_t len, bool hex = false) {
+        Error e = make_error(zk_bn254_groth16_pk_read(data, len, hex ? 1 : 0, 0, 0, &handle_));
+        if (!e.ok()) return e;
+        return make_error(zk_bn254_groth16_pk_info(handle_, &n_wires_, &n_public_, &log_domain_, nullptr));
+    }
+    // (*ProvingKey).WriteTo: compressed points, A / B / G2.B without their points at infinity, then InfinityA / InfinityB
+    Error WriteTo(std::vector<uint8_t>* out, bool hex = false) const {
+        size_t need = 0;
+        Error e = make_error(zk_bn254_groth16_pk_write(handle_, hex ? 1 : 0, nullptr, 0, &need));
+        if (!e.ok()) return e;
+        out->resize(need);
+        return make_error(zk_bn254_groth16_pk_write(handle_, hex ? 1 : 0, out->data(), out->size(), &need));
+    }
     uint64_t handle() const { return handle_; }
     size_t NbWires() const { return n_wires_; }
     size_t NbPublic() const { return n_public_; }

@@ -47,6 +47,20 @@ int main(int argc, char** argv) {
         std::vector<uint32_t> xa(2), xb(1), xc(2);
         if (pk.ReadFrom("", 0, false, 3, xa, xb, xc, srs).code != ZK_ERR_LEN) return fail("ReadFrom with ragged wire-id arrays must be ZK_ERR_LEN");
     }
+    // groth16.ProvingKey.ReadFrom: a truncated / malformed image is refused while its header is parsed, before any device work
+    {
+        groth16::ProvingKey pk;
+        const uint8_t three[3] = {0, 0, 16};
+        if (pk.ReadFrom(three, 3).code != ZK_ERR_LEN) return fail("ReadFrom of 3 bytes must be ZK_ERR_LEN");
+        uint8_t head[300] = {};
+        head[7] = 17;  // a cardinality that is not a power of two
+        if (pk.ReadFrom(head, sizeof head).code != ZK_ERR_ARG) return fail("ReadFrom with cardinality 17 must be ZK_ERR_ARG");
+        if (pk.ReadFrom("0g", 2, true).code != ZK_ERR_LEN) return fail("ReadFrom of a 2-character hex text must be ZK_ERR_LEN");
+        fr::Vector a(2), w(5);
+        fr::Element r = {}, s = {};
+        groth16::Proof pr;
+        if (groth16::Prove(pk, a, a, a, w, r, s, &pr).code != ZK_ERR_LEN) return fail("groth16.Prove with len(a) > the (unloaded) key's domain must be ZK_ERR_LEN");
+    }
     if (argc < 2) {
         std::printf("ok (error paths only)\n");
         return 0;
