@@ -446,6 +446,8 @@ def main():
                    "one proof range-sharded x%d: block-sharded computeH (all-to-all transposes) + MSMs on rank-local key slices (all-gather of partial sums)" % world},
         "roofline": roofline, "proof_sha": hashlib.sha256(proof).hexdigest()[:16], "setup_s": round(t_setup, 2),
     }
+    if par.dist().is_available() and par.dist().is_initialized():
+        out["config"]["collectives"] = par.dist().get_backend()  # "nccl" = RCCL carried the exchanges of this run
 
     single = rank == 0 and not sharded
     # ---- the same proof through the entry point a cgo caller has: host slices in, 128 bytes out (PCIe-inclusive; never `value`)

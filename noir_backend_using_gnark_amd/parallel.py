@@ -39,7 +39,7 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     import torch.distributed as d
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not d.is_initialized():
+    if (world > 1 or _force_collectives()) and not d.is_initialized():
         if backend is None:
             # ZKMI_DIST_BACKEND=gloo: several ranks may then share one GPU (tensors are staged through the host) -- used to
             # exercise the whole multi-process path on a one-GPU box; RCCL refuses two ranks on one device
@@ -47,8 +47,23 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # only without a launcher (the forced world of one rank)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         d.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _force_collectives() -> bool:
+    """ZKMI_FORCE_COLLECTIVES=1: a world of ONE rank still goes through every collective (RCCL executes them as local copies) -- the only way to run
+    the RCCL call pattern (dtypes, async work handles, stream ordering against libzkmi's kernels) on a one-GPU box; tests/test_gpu_rccl_world1.py."""
+    return os.environ.get("ZKMI_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _no_peers(d) -> bool:
+    return not (d.is_available() and d.is_initialized()) or (d.get_world_size() == 1 and not _force_collectives())
 
 
 def window_rows(window_bits: int, rank: int, world: int) -> list[int]:
@@ -61,7 +76,7 @@ def all_gather_blocks(x):
     RCCL all_gather_into_tensor under nccl; gloo gathers host copies."""
     import torch
     d = dist()
-    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+    if _no_peers(d):
         return x
     world = d.get_world_size()
     if d.get_backend() == "nccl":
@@ -84,7 +99,7 @@ def all_gather_limbs(local: np.ndarray) -> np.ndarray:
     import torch
     d = dist()
     local = np.ascontiguousarray(local, dtype=np.uint64).reshape(-1)
-    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+    if _no_peers(d):
         return local.reshape(1, -1)
     world = d.get_world_size()
     t = torch.from_numpy(local.view(np.int64).copy())
@@ -144,7 +159,7 @@ def block_exchange(x):
     RCCL all_to_all_single under nccl; gloo (no all-to-all) gathers and selects -- CPU tests only."""
     import torch
     d = dist()
-    if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+    if _no_peers(d):
         return x
     world, rank = d.get_world_size(), d.get_rank()
     y = torch.empty_like(x)
@@ -182,7 +197,7 @@ def block_exchange_async(x):
     async_op (the collective runs on RCCL's stream behind the work already queued on the current stream; wait() orders the current stream
     behind it, the host does not block).  Anything else: the synchronous exchange."""
     d = dist()
-    if d.is_available() and d.is_initialized() and d.get_world_size() > 1 and d.get_backend() == "nccl" and _a2a_transport() == "all_to_all":
+    if not _no_peers(d) and d.get_backend() == "nccl" and _a2a_transport() == "all_to_all":
         import torch
         y = torch.empty_like(x)
         work = d.all_to_all_single(y, x, async_op=True)
@@ -203,7 +218,7 @@ def compute_h_sharded(a, b, c, log_d: int, rank: int, world: int, phase=_h_shard
         raise ValueError("world size must be a power of two")
     if pipelined is None:
         d = dist()
-        pipelined = bool(d.is_available() and d.is_initialized() and d.get_world_size() > 1 and d.get_backend() == "nccl")
+        pipelined = bool(not _no_peers(d) and d.get_backend() == "nccl")
     if not pipelined:
         a, b, c = exchange(a), exchange(b), exchange(c)
         phase(0, a, b, c, log_d, log_g, rank)

@@ -548,6 +548,32 @@ def test_two_process_sharded_proof_equals_single_process():
     assert out["n_gpus"] == 2 and out["proof_sha"] == sha1 and "window-sharded" in out["config"]["parallelism"]
 
 
+def test_rccl_executes_the_collectives_of_the_sharded_proof_world_of_one():
+    """RCCL itself (torch.distributed backend "nccl") carries every collective of the multi-GPU program -- the pipelined async all_to_all_single
+    transposes of computeH on the library's stream, all_gather_into_tensor of h (window mode) and of the partial-sum records -- in a world of ONE rank
+    (ZKMI_FORCE_COLLECTIVES=1: RCCL refuses two ranks on one device, and this pool has one GPU per box).  What this pins on hardware: the dtypes and
+    shapes RCCL is handed, the async work handles, and the stream ordering between RCCL's stream and libzkmi's kernels; the proof bytes must equal the
+    single-call prover's.  What it cannot show: anything about xGMI traffic or scaling."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--log-n", "14"]
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert single.returncode == 0, single.stdout[-2000:] + single.stderr[-2000:]
+    sha1 = json.loads(single.stdout.strip().splitlines()[-1])["proof_sha"]
+    env = dict(os.environ, ZKMI_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1")
+    env.pop("ZKMI_DIST_BACKEND", None)
+    for shard in ("range", "windows"):
+        run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-sharded", "--shard", shard] + common, capture_output=True, text=True,
+                             timeout=900, env=env)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+        out = json.loads([l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1])
+        assert out["proof_sha"] == sha1, shard
+        assert out["config"].get("collectives") == "nccl", out["config"]
+
+
 def test_concurrent_callers_are_safe():
     """gnark issues its MultiExp calls from several goroutines at once: four host threads calling MSMs / NTTs / a proof concurrently
     (ctypes releases the GIL) must each get the single-threaded results."""
