@@ -1,4 +1,6 @@
 // libzkmi runtime: device init, stream slots, arenas, profiling, device-memory plumbing entry points.
+#include <vector>
+
 #include "ctx.hpp"
 
 #include <string.h>
@@ -50,6 +52,24 @@ static int init_locked(int device) {
         }
     }
     c.ready = true;
+    return ZK_OK;
+}
+
+// Experiment: a pair of CU-masked streams per slot.  ZKMI_CU_SPLIT=k gives the scalar preparation (digits, sort, plan: bandwidth-bound, needs wave slots to
+// make progress) k CUs of its own -- bits i with i % (256 / k) == 0 of the CU mask -- and the accumulate kernels the others.
+int masked_streams(Slot* s) {
+    static const int k = getenv("ZKMI_CU_SPLIT") ? atoi(getenv("ZKMI_CU_SPLIT")) : 0;
+    if (k <= 0 || s->stream_prep) return ZK_OK;
+    const int ncu = ctx().num_cus, words = (ncu + 31) / 32;
+    static const int mode = getenv("ZKMI_CU_SPLIT_MODE") ? atoi(getenv("ZKMI_CU_SPLIT_MODE")) : 0;  // 0: every (ncu/k)-th bit; 1: the first k bits
+    std::vector<uint32_t> mp(words, 0), ma(words, 0);
+    const int step = ncu / k > 0 ? ncu / k : 1;
+    for (int i = 0; i < ncu; i++) {
+        const bool prep = mode == 1 ? i < k : (i % step == 0 && i / step < k);
+        (prep ? mp : ma)[i >> 5] |= 1u << (i & 31);
+    }
+    ZK_HIP(hipExtStreamCreateWithCUMask(&s->stream_prep, (uint32_t)words, mp.data()));
+    ZK_HIP(hipExtStreamCreateWithCUMask(&s->stream_acc, (uint32_t)words, ma.data()));
     return ZK_OK;
 }
 

@@ -38,6 +38,7 @@ struct ProfEntry {
 struct Slot {
     hipStream_t stream = nullptr;     // normal priority
     hipStream_t stream_hi = nullptr;  // high priority (critical-path chains of a proof)
+    hipStream_t stream_prep = nullptr, stream_acc = nullptr;  // experiment (ZKMI_CU_SPLIT=k): CU-masked pair -- k CUs for scalar preparation, the rest for accumulates
     char* arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
     void* pinned = nullptr;
@@ -73,6 +74,7 @@ int ensure_init();                  // lazy device init; ZK_ERR_NO_DEVICE if the
 int acquire_slot(Slot** out);       // blocks (spins) until a slot is free
 int acquire_slots(int k, Slot** out); // k slots at once (all or nothing: no partial holds, hence no deadlock)
 void release_slot(Slot* s);
+int masked_streams(Slot* s);         // creates stream_prep / stream_acc on first use; ZK_OK with both left null when ZKMI_CU_SPLIT is unset
 int slot_sync(Slot* s, hipStream_t st);  // synchronize + fold pending profile events
 
 struct SlotGuard {

@@ -100,30 +100,29 @@ __global__ void k_z_terms(const Fr* __restrict__ l, const Fr* __restrict__ r, co
     num[i] = (lv + beta * w) * (rv + beta_u * w) * (ov + beta_uu * w);
     den[i] = (lv + beta * ld(sig + i)) * (rv + beta * ld(sig + n + i)) * (ov + beta * ld(sig + 2 * (size_t)n + i));
 }
-// fr.BatchInvert: a[i] <- 1 / a[i] (0 stays 0); K elements per lane (strided, coalesced) share one Fermat inversion
-constexpr int BINV_K = 8;
-__global__ __launch_bounds__(256) void k_batch_inverse(Fr* __restrict__ a, size_t n) {
-    size_t T = (size_t)gridDim.x * blockDim.x, g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Fr v[BINV_K], pre[BINV_K];
+// fr.BatchInvert: a[i] <- 1 / a[i] (0 stays 0); BINV_K elements per lane (strided, coalesced) share one Fermat inversion (~380 products, paid per
+// WAVE whatever the lanes do): 3 + 380 / BINV_K products per element.  The prefix products of the forward sweep go through `scratch` (n elements, 160 B of
+// traffic per element in all) instead of registers, which is what lets BINV_K be 32 (8 in registers: 1.9 ms at 2^22 elements; 32: see DESIGN 3.8).
+constexpr int BINV_K = 32;
+__global__ __launch_bounds__(256) void k_batch_inverse(Fr* __restrict__ a, size_t n, Fr* __restrict__ scratch) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr acc = Fr::one();
-#pragma unroll
     for (int k = 0; k < BINV_K; k++) {
-        size_t i = g + k * T;
-        v[k] = i < n ? ld(a + i) : Fr::one();
-        if (v[k].is_zero()) v[k] = Fr::one();  // handled on the way back
-        pre[k] = acc;
-        acc = acc * v[k];
+        const size_t i = g + k * T;
+        if (i >= n) break;
+        Fr v = ld(a + i);
+        if (v.is_zero()) v = Fr::one();  // handled on the way back
+        scratch[i] = acc;
+        acc = acc * v;
     }
     Fr inv = acc.inv();
-#pragma unroll
     for (int k = BINV_K - 1; k >= 0; k--) {
-        size_t i = g + k * T;
-        Fr out = inv * pre[k];
-        inv = inv * v[k];
-        if (i < n) {
-            bool z = ld(a + i).is_zero();
-            a[i] = z ? Fr::zero() : out;
-        }
+        const size_t i = g + k * T;
+        if (i >= n) continue;
+        const Fr v = ld(a + i);
+        if (v.is_zero()) continue;  // a zero stays a zero and took no part in the product
+        a[i] = inv * ld(scratch + i);
+        inv = inv * v;
     }
 }
 
@@ -465,6 +464,9 @@ struct CommitChain {
         ZK_HIP(hipEventRecord(ev, producer));
         static const bool prep_hi = !(getenv("ZKMI_PLONK_PREP_HI") && atoi(getenv("ZKMI_PLONK_PREP_HI")) == 0);  // A/B switch
         hipStream_t sp = prep_hi ? s->stream_hi : s->stream;  // the preparation at high priority: its sort must get wave slots under a running accumulate
+        ZK_TRY(masked_streams(s));
+        hipStream_t sa = s->stream;
+        if (s->stream_prep) { sp = s->stream_prep; sa = s->stream_acc; }  // experiment ZKMI_CU_SPLIT: disjoint CU sets instead of priorities
         ZK_HIP(hipStreamWaitEvent(sp, ev, 0));
         (void)hipEventDestroy(ev);
         job[k] = MsmJob();
@@ -472,7 +474,7 @@ struct CommitChain {
         live[k] = true;
         job[k].gate_acc = last_acc;
         job[k].want_done = true;
-        ZK_TRY(msm_g1_accumulate(s, s->stream, prep[k], d_table, 0, &job[k]));
+        ZK_TRY(msm_g1_accumulate(s, sa, prep[k], d_table, 0, &job[k]));
         if (job[k].acc_done) last_acc = job[k].acc_done;
         return ZK_OK;
     }
@@ -499,6 +501,7 @@ struct CommitChain {
             if (live[k]) {
                 (void)hipStreamSynchronize(g.s[k]->stream_hi);
                 (void)hipStreamSynchronize(g.s[k]->stream);
+                if (g.s[k]->stream_prep) { (void)hipStreamSynchronize(g.s[k]->stream_prep); (void)hipStreamSynchronize(g.s[k]->stream_acc); }
                 release(k);
             }
     }
@@ -1130,7 +1133,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
               (uint32_t)n, to_dev(beta), to_dev(beta * u), to_dev(beta * uu), to_dev(gamma), num, den);
     {
         size_t lanes = (n + BINV_K - 1) / BINV_K;
-        ZK_LAUNCH(s, st, "plonk_batch_inverse", k_batch_inverse, dim3(grid_of(lanes)), dim3(256), 0, den, n);
+        ZK_LAUNCH(s, st, "plonk_batch_inverse", k_batch_inverse, dim3(grid_of(lanes)), dim3(256), 0, den, n, W + 14 * S);
     }
     ZK_LAUNCH(s, st, "plonk_pscan_local", k_pscan_local, dim3(SB.nb), dim3(256), 0, (const Fr*)num, (const Fr*)den, n, SB.K, SB.t, SB.b);
     ZK_LAUNCH(s, st, "plonk_pscan_blocks", k_pscan_blocks, dim3(1), dim3(1024), 0, SB.b, SB.nb);
