@@ -106,3 +106,68 @@ def test_acir_lowering_matches_the_oracle_on_the_reference_fixtures():
     two = {"current_witness_index": 4, "public_inputs": [3, 1], "opcodes": [{"Arithmetic": {"mul_terms": [["01", 1, 2]], "linear_combinations": [["%064x" % (ref.R - 1), 3]], "q_c": "00"}}]}
     got = fe.acir_to_sparse_r1cs(json.dumps(two), 4)
     assert got["n_public"] == 2 and got["n_vars"] == 4 and list(got["order"]) == [0, 2, 1, 3] and (got["xa"][0], got["xb"][0], got["xc"][0]) == (0, 2, 1)
+
+
+def test_host_parsers_survive_mutated_inputs():
+    """Mutation fuzz of everything in libzkmi that parses caller-supplied text on the host, through the C ABI, without a GPU: the ACIR JSON reader and
+    lowering (zk_acir_to_sparse_r1cs), the RawR1CS reader (zk_groth16_r1cs_from_raw: parses completely, then fails for want of a device) and the header
+    walk of the Groth16 key reader (zk_bn254_groth16_pk_read).  Every call must come back with a status code -- never crash, hang or read past its input
+    (the inputs are exact-size bytes objects, so an over-read trips on ctypes' copies often enough to show)."""
+    import ctypes as C
+    import json
+    import random
+    L = _lib.lib()
+    rnd = random.Random(0xF022)
+    ok_codes = {_lib.ZK_OK, _lib.ZK_ERR_ARG, _lib.ZK_ERR_LEN, _lib.ZK_ERR_NO_DEVICE}
+
+    def mutate(b: bytes) -> bytes:
+        b = bytearray(b)
+        for _ in range(rnd.randint(1, 4)):
+            kind = rnd.randint(0, 5)
+            if not b:
+                break
+            p = rnd.randrange(len(b))
+            if kind == 0:
+                b[p] = rnd.randrange(256)
+            elif kind == 1:
+                del b[p:p + rnd.randint(1, 40)]
+            elif kind == 2:
+                b[p:p] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 8)))
+            elif kind == 3:
+                b = b[:p]
+            elif kind == 4:
+                b[p:p] = rnd.choice([b"[", b"{", b'"', b"]", b"}", b",", b":", b"-1", b"99999999999999999999", b"1e9", b"\\u0000", b"null"])
+            else:
+                q = rnd.randrange(len(b))
+                b[p], b[q] = b[q], b[p]
+        return bytes(b)
+
+    fixtures = json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_golden.json")))
+    acirs = [json.dumps(e["acir"]).encode() for e in fixtures]
+    npub, nvars, nc = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    seen = set()
+    for it in range(3000):
+        a = mutate(acirs[it % len(acirs)])
+        rc = L.zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(rnd.choice([0, 1, 6, 7, 1000])), C.byref(npub), C.byref(nvars), C.byref(nc), *([None] * 9))
+        assert rc in ok_codes, (rc, a)
+        seen.add(rc)
+    assert _lib.ZK_OK in seen and _lib.ZK_ERR_ARG in seen  # some mutants stay valid circuits, most do not
+    hx = lambda v: "%064x" % (v % ref.R)
+    raw = json.dumps({"gates": [{"mul_terms": [{"coefficient": hx(1), "multiplicand": 1, "multiplier": 2}], "add_terms": [{"coefficient": hx(-1), "sum": 3}], "constant_term": hx(0)}],
+                      "public_inputs": [2], "values": ref.felts_wire([3, 5, 15]).hex(), "num_variables": 4, "num_constraints": 1}).encode()
+    h, d, nw, npb = C.c_uint64(0), C.c_void_p(0), C.c_size_t(0), C.c_size_t(0)
+    for it in range(2000):
+        a = mutate(raw)
+        rc = L.zk_groth16_r1cs_from_raw(C.c_char_p(a), C.c_size_t(len(a)), C.byref(h), C.byref(d), C.byref(nw), C.byref(npb))
+        assert rc in ok_codes and (rc != _lib.ZK_OK or _lib.device_count() > 0), (rc, a)
+        if rc == _lib.ZK_OK:  # only with a GPU present
+            L.zk_bn254_r1cs_free(h)
+            L.zk_dev_free(d)
+    key = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_wire_golden.json")))[1]["pk_hex"])
+    for it in range(2000):
+        is_hex = it & 1
+        a = mutate(key.hex().encode() if is_hex else key)
+        rc = L.zk_bn254_groth16_pk_read(C.c_char_p(a), C.c_size_t(len(a)), C.c_int(is_hex), C.c_int(1), C.c_int(0), C.byref(h))
+        assert rc in ok_codes, (rc, len(a))
+        if rc == _lib.ZK_OK:
+            L.zk_bn254_groth16_pk_free(h)
