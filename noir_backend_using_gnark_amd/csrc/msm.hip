@@ -947,17 +947,37 @@ __global__ __launch_bounds__(256) void k_build_table(const Affine<F>* __restrict
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<F> p = gload(pts + i);
+    if (p.is_inf()) return;  // the caller zeroed the table: (0, 0) in every row
+    // The doubling chain runs through all rows in XYZZ and the rows this table holds are normalised TOGETHER: one inversion per point instead of one per
+    // entry (Montgomery's trick over the <= 32 rows of a lane; the per-row coordinates live in private memory) -- 20 doublings + ~37 products per entry
+    // instead of 20 doublings + ~385.
+    constexpr int MAXR = 32;  // ceil(255 / c), c >= 8
+    F xs[MAXR], ys[MAXR], zs[MAXR], ws[MAXR], pre[MAXR];
     XYZZ<F> acc = XYZZ<F>::from_affine(p);
-    unsigned k = 0;
+    int k = 0;
     for (unsigned w = 0; w < Wd; w++) {
         if (w) {
             for (unsigned b = 0; b < c; b++) acc.dbl();
         }
         if (w < row_first || (w - row_first) % row_step) continue;
-        Affine<F> a = w ? acc.to_affine() : p;
-        gstore(table + (size_t)k * stride + offset + i, a);
-        acc = XYZZ<F>::from_affine(a);  // keeps zz = zzz = 1: cheaper doublings, bounded growth
+        xs[k] = acc.x; ys[k] = acc.y; zs[k] = acc.zz; ws[k] = acc.zzz;
         k++;
+    }
+    F run = F::one();
+    for (int j = 0; j < k; j++) {
+        pre[j] = run;
+        run = run * (zs[j] * ws[j]);  // non-zero for points of odd order: a doubling cannot reach infinity
+    }
+    if (run.is_zero()) {  // a caller-supplied point of even order (outside the prime-order subgroup): row by row
+        for (int j = 0; j < k; j++) gstore(table + (size_t)j * stride + offset + i, XYZZ<F>{xs[j], ys[j], zs[j], ws[j]}.to_affine());
+        return;
+    }
+    F inv = run.inv();
+    for (int j = k - 1; j >= 0; j--) {
+        const F t = inv * pre[j];  // 1 / (zz * zzz) of row j
+        inv = inv * (zs[j] * ws[j]);
+        Affine<F> a{xs[j] * (t * ws[j]), ys[j] * (t * zs[j])};  // x / zz, y / zzz
+        gstore(table + (size_t)j * stride + offset + i, a);
     }
 }
 template <class F>
