@@ -7,6 +7,7 @@
 // The point of doing it here: a compressed point costs a square root (one 254-bit exponentiation: y = (x^3 + 3)^((q+1)/4)), 10^6 of
 // them per SRS load on the CPU path; on the device the decoded points land directly in the resident-bases layout (and its window tables)
 // and the SRS is read ONCE.  Byte / integer work next to ~380 field products per point.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -173,7 +174,23 @@ __device__ __forceinline__ bool f2_lex_largest_dev(const Fp2& y) {  // gnark-cry
 }
 // G2Affine.SetBytes on a compressed encoding (X.A1 | X.A0 big-endian, flags on the first byte) with the subgroup check the gnark-crypto Decoder
 // applies by default (r * P = infinity: the twist has a cofactor).  bt = 3 / (9 + u), Montgomery.
-__global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restrict__ raw, size_t n, Fp2 bt, Affine<Fp2>* __restrict__ out, int* __restrict__ status) {
+// r-torsion membership on the twist as gnark-crypto tests it (G2Jac.IsInSubGroup): psi(P) == [6 x0^2] P, where psi is the untwist-Frobenius-twist
+// endomorphism (x, y) -> (conj(x) * gx, conj(y) * gy), gx = xi^((q-1)/3), gy = xi^((q-1)/2), xi = 9 + u, which acts on G2 as multiplication by
+// q = t - 1 = 6 x0^2 (mod r); x0 = 4965661367192848881.  A 127-bit scalar multiplication instead of the 254 bits of r * P.
+struct PsiConsts { Fp2 gx, gy; };
+__device__ __forceinline__ bool g2_in_subgroup_dev(const Affine<Fp2>& p, const PsiConsts& K) {
+    const uint32_t k6x2[8] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u, 0, 0, 0, 0};  // 6 x0^2 = 147946756881789318990833708069417712966
+    XYZZ<Fp2> rp = XYZZ<Fp2>::inf();
+    for (int i = 126; i >= 0; i--) {
+        rp.dbl();
+        if ((k6x2[i >> 5] >> (i & 31)) & 1) rp.madd(p);
+    }
+    if (rp.is_inf()) return false;
+    const Fp2 px = Fp2{p.x.a0, p.x.a1.neg()} * K.gx, py = Fp2{p.y.a0, p.y.a1.neg()} * K.gy;
+    return rp.x == px * rp.zz && rp.y == py * rp.zzz;
+}
+__global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restrict__ raw, size_t n, Fp2 bt, PsiConsts psi, int full_check, Affine<Fp2>* __restrict__ out,
+                                                       int* __restrict__ status) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fp x1 = load_be32<Fp>(raw + 16 * i), x0 = load_be32<Fp>(raw + 16 * i + 8);
@@ -200,8 +217,14 @@ __global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restric
     if (f2_lex_largest_dev(y) != (flag == 3)) y = y.neg();
     p.x = x;
     p.y = y;
-    const uint32_t rk[8] = {FrParams::MOD[0], FrParams::MOD[1], FrParams::MOD[2], FrParams::MOD[3], FrParams::MOD[4], FrParams::MOD[5], FrParams::MOD[6], FrParams::MOD[7]};
-    if (!scalar_mul(p, rk).is_inf()) {
+    bool member;
+    if (full_check) {  // ZKMI_G2_FULL_SUBGROUP_CHECK=1: the definition, r * P == infinity (A/B switch, twice the work)
+        const uint32_t rk[8] = {FrParams::MOD[0], FrParams::MOD[1], FrParams::MOD[2], FrParams::MOD[3], FrParams::MOD[4], FrParams::MOD[5], FrParams::MOD[6], FrParams::MOD[7]};
+        member = scalar_mul(p, rk).is_inf();
+    } else {
+        member = g2_in_subgroup_dev(p, psi);
+    }
+    if (!member) {
         atomicOr(status, 16);
         out[i] = Affine<Fp2>::inf();
         return;
@@ -274,13 +297,22 @@ int g1_compress_dev(Slot* s, hipStream_t st, const void* d_pts, size_t n, void* 
     return ZK_OK;
 }
 
+static HFp2 f2_pow(HFp2 a, const uint64_t e[4]);
 int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void* d_out, int* d_status) {
     HFp nine = HFp::zero(), three = HFp::one() + HFp::one() + HFp::one();
     for (int i = 0; i < 3; i++) nine = nine + three;
     const HFp2 bt = HFp2{three, HFp::zero()} * HFp2{nine, HFp::one()}.inv();
     Fp2 btd;
     memcpy(&btd, &bt, sizeof btd);
-    if (n) ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, (Affine<Fp2>*)d_out, d_status);
+    // psi's coefficients: xi^((q-1)/3), xi^((q-1)/2)
+    static const uint64_t E3[4] = {0x69602eb24829a9c2ULL, 0xdd2b2385cd7b4384ULL, 0xe81ac1e7808072c9ULL, 0x10216f7ba065e00dULL};
+    static const uint64_t E2h[4] = {0x9e10460b6c3e7ea3ULL, 0xcbc0b548b438e546ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL};
+    const HFp2 xi{nine, HFp::one()}, gx = f2_pow(xi, E3), gy = f2_pow(xi, E2h);
+    PsiConsts psi;
+    memcpy(&psi.gx, &gx, sizeof gx);
+    memcpy(&psi.gy, &gy, sizeof gy);
+    static const int full = getenv("ZKMI_G2_FULL_SUBGROUP_CHECK") ? atoi(getenv("ZKMI_G2_FULL_SUBGROUP_CHECK")) : 0;
+    if (n) ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, psi, full, (Affine<Fp2>*)d_out, d_status);
     return ZK_OK;
 }
 int g2_compress_dev(Slot* s, hipStream_t st, const void* d_pts, const uint32_t* d_idx, size_t n, void* d_raw) {
