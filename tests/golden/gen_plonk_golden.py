@@ -68,6 +68,7 @@ def main():
                         srs_alpha=hx(alpha), srs_size=len(srs["g1"]), blinders=[hx(v) for v in blinders],
                         vk={kk: b.g1_affine_mont_bytes(vk[kk]).hex() for kk in ("ql", "qr", "qm", "qo", "qk")} | {"s": [b.g1_affine_mont_bytes(p).hex() for p in vk["s"]]},
                         challenges={kk: hx(trace[kk]) for kk in ("gamma", "beta", "alpha", "zeta", "kzg_gamma")},
+                        vk_hex=pl.plonk_vk_bytes(vk).hex(), pk_hex=pl.plonk_pk_bytes(pk).hex(),  # VerifyingKey.WriteTo / ProvingKey.WriteTo images
                         proof=pl.plonk_proof_bytes(proof).hex(), verified_by_pairing=True,
                         pinned_challenges={kk: hx(v) for kk, v in pinned.items()}, proof_pinned=pl.plonk_proof_bytes(proof_p).hex()))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plonk_golden.json")

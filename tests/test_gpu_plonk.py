@@ -299,6 +299,7 @@ def test_plonk_preprocess_and_prove_with_pk_on_the_reference_fixtures(plonk_gold
         opk, ovk = pl.plonk_setup(spr, pl.kzg_new_srs(e["srs_size"], h2i(e["srs_alpha"])))
         pk_hex, vk_hex, h = fe.plonk_preprocess(acir, enc, srs, keep_resident=True)
         assert pk_hex == pl.plonk_pk_bytes(opk).hex() and vk_hex == pl.plonk_vk_bytes(ovk).hex(), e["name"]
+        assert pk_hex == e["pk_hex"] and vk_hex == e["vk_hex"], e["name"]  # the committed key images (what tools/go_pin feeds to gnark)
         bl = M([h2i(v) for v in e["blinders"]])
         assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"], e["name"]
         assert fe.plonk_prove_with_pk(acir, enc, None, srs, blinders=bl, pk_handle=h) == e["proof"]

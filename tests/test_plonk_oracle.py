@@ -43,6 +43,9 @@ def test_golden_proofs_reproduce_and_verify(plonk_golden):
     pk, vk = pl.plonk_setup(spr, srs)
     assert {k: ref.g1_affine_mont_bytes(vk[k]).hex() for k in ("ql", "qr", "qm", "qo", "qk")} == {k: e["vk"][k] for k in ("ql", "qr", "qm", "qo", "qk")}
     assert [ref.g1_affine_mont_bytes(p).hex() for p in vk["s"]] == e["vk"]["s"]
+    assert pl.plonk_vk_bytes(vk).hex() == e["vk_hex"] and pl.plonk_pk_bytes(pk).hex() == e["pk_hex"] and e["pk_hex"].startswith(e["vk_hex"])
+    back = pl.plonk_pk_from_bytes(bytes.fromhex(e["pk_hex"]))
+    assert back["perm"] == list(pk["perm"]) and back["ql"] == list(pk["ql"]) and back["s3"] == list(pk["s3"])
     trace = {}
     proof = pl.plonk_prove(pk, sol, [h2i(v) for v in e["blinders"]], trace=trace)
     assert pl.plonk_proof_bytes(proof).hex() == e["proof"] and len(e["proof"]) == 2 * 548
