@@ -214,6 +214,20 @@ int zk_bn254_groth16_pk_write(uint64_t handle, int as_hex, void *out, size_t cap
 int zk_bn254_groth16_vk_write(uint64_t pk_handle, const zk_g1_affine *vk_g1, size_t n_k, const zk_g2_affine vk_g2[3], int as_hex, void *out,
                               size_t cap, size_t *out_len);
 
+/* ---- Verification on the HOST (SURVEY 8f keeps it last: O(1) next to a proof, no device work, ~10 ms on one core) -- the counterpart of the reference's
+ * PlonkVerifyWithVK (gnark_backend_ffi/main.go:44-56 -> backend/plonk/plonk.go:28-51) and of the intended Groth16 VerifyWithVK (backend/groth16/r1cs.go:176-212).
+ * Inputs are gnark's wire images (Proof.WriteTo, VerifyingKey.WriteTo as bytes or hex text) and the public witness as Montgomery fr.Elements (Groth16: without
+ * the constant wire).  *accepted = 1 / 0 for well-formed inputs; what gnark's ReadFrom rejects is ZK_ERR_ARG / ZK_ERR_LEN.
+ *   zk_bn254_groth16_verify : e(Ar, Bs) == e(alpha, beta) e(sum w_i K_i, gamma) e(Krs, delta)
+ *   zk_bn254_plonk_verify   : gnark v0.8.0 plonk.Verify -- challenges from the SHA-256 transcript, quotient identity at zeta, two KZG checks against
+ *                             srs_g2 = the SRS's ([1]2, [alpha]2) (zk_bn254_kzg_srs_read / _new_srs_dev return them)
+ *   zk_bn254_pairing_check  : prod_i e(p_i, q_i) == 1 (optimal ate over the host field types; building block of the two above) */
+int zk_bn254_groth16_verify(const uint8_t proof[128], const void *vk, size_t vk_len, int vk_is_hex, const zk_fr *public_inputs, size_t n_public,
+                            int *accepted);
+int zk_bn254_plonk_verify(const uint8_t proof[548] /* ZK_PLONK_PROOF_BYTES */, const void *vk, size_t vk_len, int vk_is_hex, const zk_g2_affine srs_g2[2],
+                          const zk_fr *public_inputs, size_t n_public, int *accepted);
+int zk_bn254_pairing_check(const zk_g1_affine *p, const zk_g2_affine *q, size_t n, int *is_one);
+
 /* The two halves of zk_bn254_groth16_prove, exposed so that one proof can be range-sharded over several GPUs
  * (one process per GPU): every rank runs the five MSMs on ITS slice of the bases / wire values / h, the un-normalised
  * XYZZ sums (4 x G1 = 64 limbs, then G2 = 32 limbs; order A, B1, K, Z, B2) are all-gathered, and any rank finishes.

@@ -266,7 +266,26 @@ inline Error Prove(const ProvingKey& pk, const fr::Vector& solution, const fr::E
     return make_error(zk_bn254_plonk_prove(pk.handle(), solution.data(), solution.size(), 0, blinders, challenges, proof->bytes));
 }
 
+// plonk.Verify(proof, vk, publicWitness) on the host: vk = the bytes of VerifyingKey.WriteTo, srs supplies the two G2 points InitKZG attaches.
+// *accepted <- the verdict; malformed encodings come back as errors (what upstream's ReadFrom returns).
+inline Error Verify(const Proof& proof, const std::vector<uint8_t>& vk, const kzg::SRS& srs, const fr::Vector& public_witness, bool* accepted) {
+    int ok = 0;
+    Error e = make_error(zk_bn254_plonk_verify(proof.bytes, vk.data(), vk.size(), 0, srs.G2, public_witness.data(), public_witness.size(), &ok));
+    *accepted = ok != 0;
+    return e;
+}
+
 }  // namespace plonk
+
+namespace groth16 {
+// groth16.Verify(proof, vk, publicWitness) on the host: vk = the bytes of VerifyingKey.WriteTo; the public witness excludes the constant wire
+inline Error Verify(const Proof& proof, const std::vector<uint8_t>& vk, const fr::Vector& public_witness, bool* accepted) {
+    int ok = 0;
+    Error e = make_error(zk_bn254_groth16_verify(proof.bytes, vk.data(), vk.size(), 0, public_witness.data(), public_witness.size(), &ok));
+    *accepted = ok != 0;
+    return e;
+}
+}  // namespace groth16
 
 // DeserializeFelts(encodedFelts string): hex(u32 BE count || count x 32 B BE) -> Montgomery vector, decoded on the device into d_out
 inline Error DeserializeFelts(const std::string& encoded, void* d_out, size_t capacity, size_t* n) {

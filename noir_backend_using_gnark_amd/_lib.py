@@ -65,6 +65,7 @@ SYMBOLS = [
     "zk_bn254_felts_decode_hex", "zk_bn254_felts_decode_hex_dev", "zk_bn254_felts_decode_bytes_dev", "zk_bn254_felts_encode_hex",
     "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_pk_info", "zk_bn254_groth16_prove",
     "zk_bn254_groth16_pk_read", "zk_bn254_groth16_pk_write", "zk_bn254_groth16_vk_write",
+    "zk_bn254_groth16_verify", "zk_bn254_plonk_verify", "zk_bn254_pairing_check",
     "zk_bn254_r1cs_load", "zk_bn254_r1cs_free", "zk_bn254_r1cs_eval_abc_dev", "zk_bn254_groth16_setup", "zk_bn254_groth16_prove_r1cs",
     "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_pk_abort", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
     "zk_bn254_plonk_setup", "zk_bn254_plonk_pk_load", "zk_bn254_plonk_pk_free", "zk_bn254_plonk_pk_export", "zk_bn254_plonk_pk_read", "zk_bn254_plonk_pk_write", "zk_bn254_plonk_prove", "zk_bn254_plonk_synth_qk_dev",

@@ -61,6 +61,17 @@ int main(int argc, char** argv) {
         groth16::Proof pr;
         if (groth16::Prove(pk, a, a, a, w, r, s, &pr).code != ZK_ERR_LEN) return fail("groth16.Prove with len(a) > the (unloaded) key's domain must be ZK_ERR_LEN");
     }
+    // the verifiers run on the host: a truncated verifying key is an error, not a verdict
+    {
+        groth16::Proof gp = {};
+        plonk::Proof pp = {};
+        kzg::SRS srs;
+        bool ok = true;
+        std::vector<uint8_t> short_vk(100);
+        fr::Vector none;
+        if (groth16::Verify(gp, short_vk, none, &ok).code != ZK_ERR_LEN || ok) return fail("groth16.Verify with a 100-byte key must be ZK_ERR_LEN");
+        if (plonk::Verify(pp, short_vk, srs, none, &ok).code != ZK_ERR_LEN || ok) return fail("plonk.Verify with a 100-byte key must be ZK_ERR_LEN");
+    }
     if (argc < 2) {
         std::printf("ok (error paths only)\n");
         return 0;

@@ -171,3 +171,23 @@ def test_host_parsers_survive_mutated_inputs():
         assert rc in ok_codes, (rc, len(a))
         if rc == _lib.ZK_OK:
             L.zk_bn254_groth16_pk_free(h)
+
+
+def test_go_abi_shim_exports_the_reference_symbols():
+    """libgnark_backend.so (csrc/goffi.cpp) exports exactly the names the reference's Rust side binds: src/gnark_backend_wrapper/plonk/mod.rs:10-25 and
+    groth16/mod.rs:14-20; PlonkVerifyWithMeta / VerifyWithMeta answer `false` without touching a device (main.go:40-42)."""
+    import ctypes as C
+    so = os.path.join(ROOT, "noir_backend_using_gnark_amd", "libgnark_backend.so")
+    assert os.path.exists(so), "build it: make -C noir_backend_using_gnark_amd/csrc"
+    L = C.CDLL(so)
+    for name in ("PlonkVerifyWithMeta", "PlonkProveWithMeta", "PlonkVerifyWithVK", "PlonkProveWithPK", "PlonkPreprocess",
+                 "VerifyWithMeta", "ProveWithMeta", "VerifyWithVK", "ProveWithPK", "Preprocess"):
+        assert hasattr(L, name), name
+
+    class GoString(C.Structure):
+        _fields_ = [("p", C.c_char_p), ("n", C.c_ssize_t)]
+    L.PlonkVerifyWithMeta.restype = C.c_ubyte
+    g = GoString(b"x", 1)
+    assert L.PlonkVerifyWithMeta(g, g, g) == 0
+    L.VerifyWithMeta.restype = C.c_ubyte
+    assert L.VerifyWithMeta(g, g) == 0
