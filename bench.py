@@ -203,6 +203,15 @@ def plonk_block(L, lib, log_n, reps=3):
     out["verified_by"] = "oracle/plonk_ref.plonk_verify: Fiat-Shamir re-derived from the bytes, quotient identity at zeta, two KZG openings by pairings"
     out["proof_verifies"] = bool(pl.plonk_verify(vk, pr, pub))
     out["wrong_public_input_rejected"] = bool(not pl.plonk_verify(vk, pr, [(pub[0] + 1) % ref.R] + pub[1:]))
+    # the product's own host-side verifier (zk_bn254_plonk_verify) on the same bytes, with the key image it would get from the wire: same verdicts, timed
+    from noir_backend_using_gnark_amd import verify as zv
+    g2 = np.stack([np.frombuffer(ref.g2_affine_mont_bytes(q), dtype=np.uint64) for q in vk["srs_g2"]])
+    vkb = pl.plonk_vk_bytes(vk)
+    pub_m = dsol.to_numpy(np.uint64, (npub, 4))
+    t0 = time.perf_counter()
+    acc = zv.plonk_verify(proof, vkb, g2, pub_m)
+    out["host_verify"] = {"accepts": bool(acc), "ms": round((time.perf_counter() - t0) * 1e3, 2),
+                          "rejects_wrong_public_input": bool(not zv.plonk_verify(proof, vkb, g2, pl.ints_to_mont_np([(pub[0] + 1) % ref.R] + pub[1:])))}
     pk.free()
     srs.free()
     return out
