@@ -117,9 +117,9 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
             fclose(f);
         }
         size_t n = 0;
-        if (!text.empty()) {
-            must(zk_bn254_kzg_srs_read(text.data(), text.size(), 1, 0, &g_srs.handle, &n, g_srs.g2), "LoadSRS");
-        } else {  // SRS wasn't generated so we generate it (common.go:130-141)
+        // LoadSRS: a missing file, a decoding error or a malformed SRS all mean "generate a new one" upstream (common.go:128-141: any err of LoadSRS)
+        const bool loaded = !text.empty() && zk_bn254_kzg_srs_read(text.data(), text.size(), 1, 0, &g_srs.handle, &n, g_srs.g2) == ZK_OK;
+        if (!loaded) {
             uint64_t a[4];
             FILE* r = fopen("/dev/urandom", "rb");
             if (!r || fread(a, 1, 32, r) != 32) { fprintf(stderr, "no randomness source\n"); exit(1); }

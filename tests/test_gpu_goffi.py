@@ -92,6 +92,21 @@ def test_groth16_exports_end_to_end(tmp_path):
     assert len(opk["infinity_a"]) == r1.n_wires and len(opk["g1_k"]) == r1.n_wires - r1.n_public
 
 
+def test_a_corrupt_srs_file_is_replaced(tmp_path):
+    """LoadSRS failing for any reason means `generate and save` upstream (common.go:128-141): a truncated srs.hex is overwritten by a fresh SRS and the
+    call succeeds."""
+    e = json.load(open(os.path.join(HERE, "golden", "plonk_golden.json")))[1]
+    cfg = tmp_path / "cfg" / "noir-lang"
+    os.makedirs(cfg, exist_ok=True)
+    (cfg / "srs.hex").write_text("00ff" * 40)
+    values = [h2i(v) for v in e["values"]]
+    job = dict(what="plonk", acir=json.dumps(e["acir"]), values=ref.felts_wire(values).hex(), values_wrong_public=ref.felts_wire(values).hex(),
+               random_values=ref.felts_wire(values).hex())
+    a = run_worker(tmp_path, job, "corrupt")
+    assert a["verifies"] == 1
+    assert len((cfg / "srs.hex").read_text()) == 2 * (132 + 32 * 64)
+
+
 def test_errors_end_the_process_like_log_fatal(tmp_path):
     e = json.load(open(os.path.join(HERE, "golden", "plonk_golden.json")))[0]
     out = run_worker(tmp_path, dict(what="fatal", acir=json.dumps(e["acir"]), values=ref.felts_wire([h2i(v) for v in e["values"]]).hex()), "fatal", expect_fail=True)
