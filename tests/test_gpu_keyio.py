@@ -227,3 +227,59 @@ def test_groth16_ffi_preprocess_prove_with_pk_and_with_meta():
             fe.groth16_prove_with_pk(rj, bad_pk, mont_limbs(list(rs)))
     with pytest.raises(ValueError):
         fe.groth16_preprocess("{}")
+
+
+def test_groth16_setup_prove_verify_chain_at_2p15_constraints():
+    """The whole Groth16 life cycle on the product side at a size the big-integer oracle cannot set up in test time: a satisfied random R1CS with 2^15
+    constraints -> groth16.Setup on the device (pinned toxic waste) -> VerifyingKey.WriteTo / ProvingKey.WriteTo -> ReadFrom of the key image ->
+    Prove from the witness -> the HOST verifier (pairings) accepts the 128 bytes under the written verifying key and rejects another public input, a
+    proof with swapped points and the proof of another (r, s) against a key from other toxic waste.  A wrong Setup, Prove, key codec or verifier
+    breaks the pairing equation."""
+    from noir_backend_using_gnark_amd import verify as zv
+    g = ref.SplitMix64(0x515)
+    nc, n_in, npub = 1 << 15, 500, 4                      # wires: [ONE, 3 public, 497 secret inputs, 2^15 products]
+    w = [1] + [g.felt() for _ in range(n_in - 1)]
+    one = mont_limbs([1])[0]
+    coeff_cache = {}
+
+    def co(v):
+        if v not in coeff_cache:
+            coeff_cache[v] = mont_limbs([v])[0]
+        return coeff_cache[v]
+
+    cons = []
+    for j in range(nc):
+        la, lb, ra, rb = (int(g.next() % n_in) for _ in range(4))
+        c1, c2 = 1 + int(g.next() % 7), 1 + int(g.next() % 7)
+        L = {la: co(c1)}
+        L[lb] = co((c2 + (c1 if lb == la else 0)) % ref.R)
+        Rr = {ra: one}
+        if rb != ra:
+            Rr[rb] = one
+        lv = (c1 * w[la] + c2 * w[lb]) % ref.R
+        rv = (w[ra] + (w[rb] if rb != ra else 0)) % ref.R
+        cons.append((L, Rr, {n_in + j: one}))
+        w.append(lv * rv % ref.R)
+    r1 = zk.R1CS(npub, len(w), cons)
+    wm = mont_limbs(w)
+    tox = mont_limbs(ref.rand_felts(0x70C5, 5))
+    pk, vk = zk.setup(r1, tox)
+    vkb = pk.vk_write_to(vk)
+    img = pk.write_to()
+    pk.free()
+    rk = zk.ProvingKey.read_from(img)
+    r, s = mont_limbs(ref.rand_felts(0x70C6, 2))
+    proof = zk.prove_r1cs(r1, rk, wm, r, s)
+    pub = wm[1:npub]
+    assert zv.groth16_verify(proof, vkb, pub)
+    bad = pub.copy()
+    bad[0] = mont_limbs([(w[1] + 1) % ref.R])[0]
+    assert not zv.groth16_verify(proof, vkb, bad)
+    assert not zv.groth16_verify(proof[96:] + proof[32:96] + proof[:32], vkb, pub)      # Ar and Krs swapped
+    pk2, vk2 = zk.setup(r1, mont_limbs(ref.rand_felts(0x70C7, 5)))
+    assert not zv.groth16_verify(proof, pk2.vk_write_to(vk2), pub)                       # a key from other toxic waste
+    p2 = zk.prove_r1cs(r1, pk2, wm, r, s)
+    assert zv.groth16_verify(p2, pk2.vk_write_to(vk2), pub) and p2 != proof
+    for k in (rk, pk2):
+        k.free()
+    r1.free()

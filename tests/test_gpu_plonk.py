@@ -319,3 +319,14 @@ def test_plonk_preprocess_and_prove_with_pk_on_the_reference_fixtures(plonk_gold
             fe.plonk_prove_with_pk(acir, ref.felts_wire(values[:-1]).hex(), None, srs, blinders=bl, pk_handle=h)
         _lib.check(_lib.lib().zk_bn254_plonk_pk_free(C.c_uint64(h)))
         srs.free()
+
+
+def test_plonk_2p20_gates_accepted_by_both_verifiers():
+    """Size-independent property at 2^20 gates (the block bench.py runs at 2^22, configs[3]): a proof of a synthetic circuit made on the device is accepted
+    by the oracle's pairing verifier AND by the product's host-side verifier reading the wire images; both reject another public input."""
+    import ctypes as C
+    import bench
+    L = _lib.lib()
+    d = bench.plonk_block(L, _lib, 20, reps=1)
+    assert d["gates"] == 1 << 20 and d["proof_verifies"] and d["wrong_public_input_rejected"]
+    assert d["host_verify"]["accepts"] and d["host_verify"]["rejects_wrong_public_input"]
