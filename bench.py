@@ -263,6 +263,63 @@ def micro_block(L, lib, zk, log_n):
     return out
 
 
+def micro_sharded_block(L, lib, zk, par, torch, log_total, rank, world):
+    """BASELINE.json configs[4] on `world` GPUs: a 2^log_total-point G1 MSM range-sharded over the ranks (each its slice of points and scalars, one all-gather
+    of partial sums) and a 2^log_total-point FFT block-sharded over them (parallel.ntt_sharded: two all-to-all transposes per transform).  Checks: every rank
+    holds the same MSM result and it equals the recombination of the slices cut at an odd position; FFTInverse(DIT) . FFT(DIF) is the identity on every block."""
+    from noir_backend_using_gnark_amd import bn254 as zb
+    MONT = zk.MultiExpConfig(scalars_mont=True)
+    n = 1 << log_total
+    n_loc = n // world
+    lo = rank * n_loc
+    pts = lib.DeviceBuffer(n_loc * 64)
+    lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(pts.ptr), C.c_size_t(n_loc), C.c_uint64(seed_at(0xB1, 4, lo)), None))
+    sc = torch.empty((n_loc, 4), dtype=torch.int64, device="cuda")
+    lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(sc.data_ptr()), C.c_size_t(n_loc), C.c_uint64(seed_at(0xC, 4, lo)), C.c_int(1), C.c_int(0), None))
+    lib.check(L.zk_dev_sync())
+
+    def sync():
+        torch.cuda.synchronize()
+        lib.check(L.zk_dev_sync())
+        if world > 1 or par._force_collectives():
+            par.dist().barrier()
+
+    r0 = par.sharded_g1_multi_exp(pts.ptr, sc.data_ptr(), n_loc, MONT)
+    reps = 3
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = par.sharded_g1_multi_exp(pts.ptr, sc.data_ptr(), n_loc, MONT)
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    m = (n_loc // 3) | 1
+    two = np.stack([zb.g1_multi_exp_dev(pts.ptr, sc.data_ptr(), m, config=MONT, partial=True),
+                    zb.g1_multi_exp_dev(pts.ptr + m * 64, sc.data_ptr() + m * 32, n_loc - m, config=MONT, partial=True)])
+    local = zb.g1_sum_partials(two)                                  # this rank's slice, computed the other way
+    one = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)   # 1 in Montgomery form (Fp)
+    rec = np.concatenate([local, one, one]) if local.any() else np.zeros(16, np.uint64)
+    recomb = zb.g1_sum_partials(par.all_gather_limbs(rec))
+    same = par.all_gather_limbs(r)
+    out = {"points": n, "ranks": world, "g1_msm_ms": round(dt * 1e3, 2), "g1_scalar_muls_per_s": round(n / dt, 1),
+           "msm_same_on_every_rank": bool((same == same[0]).all() and (r == r0).all()), "msm_equals_odd_split_recombination": bool((recomb == r).all())}
+    # FFT(DIF) then FFTInverse(DIT): identity
+    x0 = sc.clone()
+    y = par.ntt_sharded(sc.clone(), log_total, rank, world, inverse=False, decimation=zk.DIF)
+    z = par.ntt_sharded(y, log_total, rank, world, inverse=True, decimation=zk.DIT)
+    torch.cuda.synchronize()
+    out["ntt_inverse_of_forward_is_identity"] = bool(torch.equal(z, x0))
+    work = sc.clone()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        work = par.ntt_sharded(work, log_total, rank, world, inverse=False, decimation=zk.DIF)
+    sync()
+    dtn = (time.perf_counter() - t0) / reps
+    out.update(ntt_ms=round(dtn * 1e3, 3), ntt_elements_per_s=round(n / dtn, 1), ntt_exchanges_per_transform=2 if world > 1 else 0)
+    pts.free()
+    return out
+
+
 def srs_block(lib, n=1_000_000):
     """SURVEY §8 row f1: kzg.SRS.ReadFrom of the reference's SRS size (10^6 points, backend/common.go:137) with the G1 points decompressed on the device;
     check: WriteTo(ReadFrom(x)) == x."""
@@ -296,6 +353,7 @@ def main():
     ap.add_argument("--no-plonk", action="store_true", help="skip the PLONK block (configs[3]: plonk.Prove at 2^22 gates, verified by the oracle's pairing verifier)")
     ap.add_argument("--plonk-log-n", type=int, default=22)
     ap.add_argument("--no-micro", action="store_true", help="skip the configs[4] block (2^26-point G1 MSM + 2^26 NTT) and the SRS-load block")
+    ap.add_argument("--micro-log-n", type=int, default=26, help="log2 of the points of the sharded configs[4] block at N > 1 (total over all ranks)")
     ap.add_argument("--verify-2p24-oracle", action="store_true", help="also check the 2^24 proof bytes against the CPU oracle (~2 min on 128 cores)")
     args = ap.parse_args()
 
@@ -527,6 +585,13 @@ def main():
         out["srs_read_1e6"] = srs_block(_lib)
         if not (out["micro_2p26"]["equals_split_recombination"] and out["micro_2p26"]["equals_window_table_path"] and out["srs_read_1e6"]["write_of_read_is_identity"]):
             out["parity_error"] = "micro-benchmark cross-check failed"
+    # ---- configs[4] on several GPUs: the 2^26-point MSM range-sharded and the 2^26-point FFT block-sharded over the ranks
+    if (world > 1 or (args.force_sharded and par._force_collectives())) and not args.no_micro:
+        inst.free()
+        blk = micro_sharded_block(L, _lib, zk, par, torch, args.micro_log_n, rank, world)
+        out["micro_2p%d_sharded" % args.micro_log_n] = blk
+        if not (blk["msm_same_on_every_rank"] and blk["msm_equals_odd_split_recombination"] and blk["ntt_inverse_of_forward_is_identity"]):
+            out["parity_error"] = "sharded micro-benchmark cross-check failed"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

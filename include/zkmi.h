@@ -132,6 +132,17 @@ int zk_bn254_groth16_compute_h_dev(const void *d_a, const void *d_b, const void 
 int zk_bn254_groth16_h_shard_dev(int phase, void *d_a, void *d_b, void *d_c, uint32_t log_D, uint32_t log_g,
                                  uint32_t rank, void *stream);
 
+/* A standalone (*Domain).FFT / FFTInverse sharded by blocks over G = 2^log_g GPUs (BASELINE configs[4] on several GPUs; the decomposition of the sharded
+ * computeH above, for any of the eight mode combinations).  Rank rho holds block rho of the STORED order (natural for DIF input / DIT output, bit-reversed for
+ * DIF output / DIT input); the library never communicates -- the host runs the steps with its all-to-all transposes (X) in between:
+ *     FFT(DIF):        [2 if coset]  X  0  X  1              FFT(DIT):         1  X  0  X
+ *     FFTInverse(DIF):               X  0  X  1              FFTInverse(DIT):  1  X  0  X  [2 if coset]
+ *   step 0: the log_g cross stages on TRANSPOSED data;  step 1: the size-M transform of the block, with 1/D and the coset factors that can ride on it;
+ *   step 2: the coset factor g^(+-i) on the natural-order block where it cannot (a no-op in the other modes).  log_g <= 3; in place; asynchronous on
+ *   `stream` if given.  noir_backend_using_gnark_amd/parallel.py: ntt_sharded. */
+int zk_bn254_ntt_shard_dev(int step, void *d_a, uint32_t log_D, uint32_t log_g, uint32_t rank, int inverse, int decimation, int coset,
+                           void *stream);
+
 /* ProvingKey image (host pointers; copied to the device by zk_bn254_groth16_pk_load).  Same field names as gnark's
  * groth16.ProvingKey{G1{Alpha,Beta,Delta,A,B,K,Z}, G2{Beta,Delta,B}, InfinityA, InfinityB, NbInfinityA, NbInfinityB}
  * (gnark v0.8.0 internal/backend/bn254/groth16/setup.go; the reference reaches it at gnark_backend_ffi/main.go:121,131 and

@@ -61,7 +61,7 @@ SYMBOLS = [
     "zk_bn254_g1_msm_partial_dev", "zk_bn254_g2_msm_partial_dev", "zk_bn254_g1_sum_xyzz", "zk_bn254_g2_sum_xyzz",
     "zk_bn254_msm_plan_info", "zk_bn254_bases_register", "zk_bn254_bases_register_dev", "zk_bn254_bases_register_cfg", "zk_bn254_bases_free", "zk_bn254_msm_bases", "zk_bn254_msm_bases_dev",
     "zk_bn254_ntt", "zk_bn254_ntt_dev", "zk_bn254_bit_reverse", "zk_bn254_bit_reverse_dev",
-    "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev",
+    "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev", "zk_bn254_ntt_shard_dev",
     "zk_bn254_felts_decode_hex", "zk_bn254_felts_decode_hex_dev", "zk_bn254_felts_decode_bytes_dev", "zk_bn254_felts_encode_hex",
     "zk_bn254_groth16_pk_load", "zk_bn254_groth16_pk_free", "zk_bn254_groth16_pk_info", "zk_bn254_groth16_prove",
     "zk_bn254_groth16_pk_read", "zk_bn254_groth16_pk_write", "zk_bn254_groth16_vk_write",

@@ -617,7 +617,8 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
         uint64_t top_max = shift >= 192 ? (r_top64 >> (shift - 192)) : ~0ULL;
         if (top_max < P->B && top_max > 0) {
             size_t dense = n / (size_t)top_max + 1 + (tab ? mean : 0);  // table mode: the top window's points come on top of the others
-            if (dense > mean && dense <= 4 * mean + 8) mean = dense;
+            static const size_t dense_max = getenv("ZKMI_L_DENSE") ? (size_t)atoi(getenv("ZKMI_L_DENSE")) : 4;  // experiment switch: 0 = always cut dense buckets
+            if (dense > mean && dense <= dense_max * mean + 8 && dense_max) mean = dense;
         }
     }
     P->L = (uint32_t)(mean * 2 < 32 ? 32 : mean * 2);

@@ -694,6 +694,7 @@ static int launch_cross(Slot* s, hipStream_t st, Fr* T, const Fr* tw, unsigned l
 
 struct ShardTables {
     Fr *coset_rev_n = nullptr, *coset_inv_n_rev = nullptr;  // this rank's M-entry slices of the size-D tables
+    Fr *coset_nat = nullptr, *coset_rev = nullptr, *coset_inv_n_nat = nullptr;  // standalone sharded transforms (lazily): g^i, g^bitrev(i), g^-i / D
 };
 static std::mutex g_shard_mu;
 static std::map<uint64_t, ShardTables> g_shard_tables;
@@ -751,6 +752,54 @@ int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* 
         case 3:  // block of a: rest of FFTInverse(DIF, coset) -> this rank's block of h (gnark's bit-reversed order)
             return run_passes(s, st, a, dM, 1, 1, nullptr, tb.coset_inv_n_rev, nullptr);
         default: return set_err(ZK_ERR_ARG, "phase must be 0..5");
+    }
+}
+
+// One step of a standalone transform sharded by blocks over G = 2^g ranks (BASELINE configs[4] on several GPUs; the same decomposition as computeH's):
+// (*Domain).FFT / FFTInverse over D = G * M points, rank rho holding block rho of the STORED order (natural for DIF input / DIT output, bit-reversed
+// for DIF output / DIT input).  The host sequences the steps with its all-to-all transposes (X):
+//     FFT(DIF):         [SCALE if coset]  X  CROSS  X  BLOCK             FFT(DIT):         BLOCK  X  CROSS  X
+//     FFTInverse(DIF):                    X  CROSS  X  BLOCK             FFTInverse(DIT):  BLOCK  X  CROSS  X  [SCALE if coset]
+//   step 0 CROSS: the g stages on the top index bits, on transposed data;  step 1 BLOCK: the size-M transform of the block with whatever scaling
+//   can ride on it (1/D always; g^bitrev(i) before a forward DIT, g^-bitrev(i) after an inverse DIF);  step 2 SCALE: the coset factor that must act on
+//   the natural-order block outside the block transform (g^i before a forward DIF's cross stages, g^-i after an inverse DIT's).
+int ntt_shard_step(Slot* s, hipStream_t st, int step, Fr* a, unsigned logD, unsigned logg, unsigned rank, int inverse, int dif, int coset) {
+    if (logg > 3 || logD < 2 * logg || logD > 28) return set_err(ZK_ERR_ARG, "bad shard geometry (log_D = %u, log_g = %u)", logD, logg);
+    if (rank >= (1u << logg)) return set_err(ZK_ERR_ARG, "rank %u out of range", rank);
+    ZK_TRY(ensure_lds_attr());
+    const unsigned logM = logD - logg;
+    const size_t M = (size_t)1 << logM;
+    Domain *dD, *dM;
+    ZK_TRY(get_domain(s, st, logD, logg ? (DOM_TW | DOM_TW_INV) : 0u, &dD));
+    ZK_TRY(get_domain(s, st, logM, DOM_TW | DOM_TW_INV, &dM));
+    ShardTables tb;
+    ZK_TRY(get_shard_tables(s, st, dD, logD, logg, rank, &tb));
+    if (coset) {
+        std::lock_guard<std::mutex> lk(g_shard_mu);
+        ShardTables& t = g_shard_tables[((uint64_t)logD << 32) | ((uint64_t)logg << 16) | rank];
+        if (!t.coset_nat) {
+            ZK_TRY(make_pow_table(s, st, &t.coset_nat, M, logD, dD->coset, HFr::one(), 0, (size_t)rank * M));
+            ZK_TRY(make_pow_table(s, st, &t.coset_rev, M, logD, dD->coset, HFr::one(), 1, (size_t)rank * M));
+            ZK_TRY(make_pow_table(s, st, &t.coset_inv_n_nat, M, logD, dD->coset_inv, HFr::one(), 0, (size_t)rank * M));
+            ZK_HIP(hipStreamSynchronize(st));
+        }
+        tb = t;
+    }
+    const Fr cinv = to_dev(dD->card_inv);  // 1/D: the block transform is linear, so the whole scaling rides on it
+    switch (step) {
+        case 0:
+            return dif ? launch_cross<true>(s, st, a, inverse ? dD->tw_inv : dD->tw, logM, logg, rank)
+                       : launch_cross<false>(s, st, a, inverse ? dD->tw_inv : dD->tw, logM, logg, rank);
+        case 1:
+            if (!inverse) return run_passes(s, st, a, dM, 0, dif, (coset && !dif) ? tb.coset_rev : nullptr, nullptr, nullptr);
+            return run_passes(s, st, a, dM, 1, dif, nullptr, (coset && dif) ? tb.coset_inv_n_rev : nullptr, &cinv);
+        case 2: {
+            if (!coset || (!inverse && !dif) || (inverse && dif)) return ZK_OK;  // nothing left outside the block transform
+            const Fr* t = inverse ? tb.coset_inv_n_nat : tb.coset_nat;
+            ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, a, t, M);
+            return ZK_OK;
+        }
+        default: return set_err(ZK_ERR_ARG, "step must be 0 (cross), 1 (block) or 2 (scale)");
     }
 }
 
@@ -866,6 +915,17 @@ int zk_bn254_groth16_h_shard_dev(int phase, void* d_a, void* d_b, void* d_c, uin
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
     ZK_TRY(compute_h_shard_phase(g.s, st, phase, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, log_D, log_g, rank));
     if (!stream) ZK_TRY(slot_sync(g.s, st));  // in place, no workspace: a caller-provided stream stays asynchronous (profiled or not)
+    return ZK_OK;
+}
+
+int zk_bn254_ntt_shard_dev(int step, void* d_a, uint32_t log_D, uint32_t log_g, uint32_t rank, int inverse, int decimation, int coset, void* stream) {
+    if (!d_a) return set_err(ZK_ERR_ARG, "null data pointer");
+    if (decimation != ZK_DIT && decimation != ZK_DIF) return set_err(ZK_ERR_ARG, "decimation must be ZK_DIT or ZK_DIF");
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
+    ZK_TRY(ntt_shard_step(g.s, st, step, (Fr*)d_a, log_D, log_g, rank, inverse ? 1 : 0, decimation == ZK_DIF, coset ? 1 : 0));
+    if (!stream) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 

@@ -245,6 +245,43 @@ def compute_h_sharded(a, b, c, log_d: int, rank: int, world: int, phase=_h_shard
     return a
 
 
+def _ntt_shard_step_hip(step, a, log_d, log_g, rank, inverse, decimation, coset):
+    """zk_bn254_ntt_shard_dev on a torch CUDA tensor, asynchronous on torch's current stream."""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    if not st:
+        torch.cuda.current_stream().synchronize()
+    check(lib().zk_bn254_ntt_shard_dev(C.c_int(step), C.c_void_p(a.data_ptr()), C.c_uint32(log_d), C.c_uint32(log_g), C.c_uint32(rank), C.c_int(int(inverse)),
+                                       C.c_int(int(decimation)), C.c_int(int(coset)), C.c_void_p(st)))
+
+
+def ntt_sharded(x, log_d: int, rank: int, world: int, inverse: bool = False, decimation: int = 1, coset: bool = False, step=_ntt_shard_step_hip,
+                exchange=block_exchange):
+    """(*Domain).FFT / FFTInverse over 2^log_d points sharded by blocks over `world` = 2^g ranks (BASELINE configs[4] on several GPUs): x = this rank's
+    block of the stored order (M = 2^log_d / world rows of 4 x int64; transformed in place where no exchange intervenes).  decimation: 0 = DIT
+    (bit-reversed in, natural out), 1 = DIF (natural in, bit-reversed out), gnark's numbering.  Two all-to-all transposes per transform.  `step` /
+    `exchange` are injectable (CPU tests run the same schedule on the oracle's arithmetic)."""
+    log_g = world.bit_length() - 1
+    if (1 << log_g) != world:
+        raise ValueError("world size must be a power of two")
+    args = (log_d, log_g, rank, inverse, decimation, coset)
+    if decimation == 1:  # DIF: cross stages first
+        if coset and not inverse:
+            step(2, x, *args)
+        x = exchange(x)
+        step(0, x, *args)
+        x = exchange(x)
+        step(1, x, *args)
+        return x
+    step(1, x, *args)    # DIT: the block transform first
+    x = exchange(x)
+    step(0, x, *args)
+    x = exchange(x)
+    if coset and inverse:
+        step(2, x, *args)
+    return x
+
+
 def groth16_msm5_pk(pk, d_w: int, d_h: int, stream: int = 0) -> np.ndarray:
     """The five MSMs of this rank's slice against its resident key slice `pk` (window tables included) -> 96-limb record."""
     out = np.zeros(96, dtype=np.uint64)

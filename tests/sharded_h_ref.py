@@ -141,3 +141,55 @@ def run_virtual(phase, A, B, Cc, log_d, per_array=False):
     for r in range(G):
         phase(3, A[r], None, None, log_d, log_g, r)
     return A
+
+
+def ntt_step_int(step, a, log_d, log_g, rank, inverse, decimation, coset):
+    """Big-integer restatement of zk_bn254_ntt_shard_dev's three steps (include/zkmi.h), in place on this rank's list."""
+    dom = ref.Domain(1 << log_d)
+    log_m = log_d - log_g
+    M, G = 1 << log_m, 1 << log_g
+    w_d = dom.gen_inv if inverse else dom.gen
+    w_m = pow(w_d, G, R)
+    if step == 0:
+        (cross_dif if decimation == ref.DIF else cross_dit)(a, w_d, log_g, log_m, rank)
+    elif step == 1:
+        if not inverse and coset and decimation == ref.DIT:
+            for j in range(M):
+                a[j] = a[j] * pow(dom.coset, ref.bitrev(rank * M + j, log_d), R) % R
+        (dif_inplace if decimation == ref.DIF else dit_inplace)(a, w_m)
+        if inverse:
+            for j in range(M):
+                f = dom.card_inv
+                if coset and decimation == ref.DIF:
+                    f = f * pow(dom.coset_inv, ref.bitrev(rank * M + j, log_d), R) % R
+                a[j] = a[j] * f % R
+    elif step == 2:
+        if coset and ((not inverse and decimation == ref.DIF) or (inverse and decimation == ref.DIT)):
+            base = dom.coset_inv if inverse else dom.coset
+            for j in range(M):
+                a[j] = a[j] * pow(base, rank * M + j, R) % R
+    else:
+        raise ValueError(step)
+
+
+def run_virtual_ntt(step, X, log_d, inverse, decimation, coset):
+    """Lock-step schedule of parallel.ntt_sharded over G = len(X) virtual ranks (step(step, a, log_d, log_g, rank, inverse, decimation, coset) works in
+    place on whatever the blocks are).  Returns the list of output blocks."""
+    G = len(X)
+    log_g = G.bit_length() - 1
+    run = lambda st, B: [step(st, B[r], log_d, log_g, r, inverse, decimation, coset) for r in range(G)]
+    if decimation == 1:
+        if coset and not inverse:
+            run(2, X)
+        X = exchange_all(X)
+        run(0, X)
+        X = exchange_all(X)
+        run(1, X)
+        return X
+    run(1, X)
+    X = exchange_all(X)
+    run(0, X)
+    X = exchange_all(X)
+    if coset and inverse:
+        run(2, X)
+    return X

@@ -407,6 +407,42 @@ def test_sharded_compute_h_matches_single_gpu_and_oracle(log_d, G):
         assert sha_image(np.concatenate(H)) == sha_image(want)
 
 
+def _ntt_step_gpu(step, a, log_d, log_g, rank, inverse, decimation, coset):
+    """One step of the sharded standalone transform through the C ABI, in place on a numpy block (M, 4)."""
+    da = _lib.DeviceBuffer.from_numpy(a)
+    _lib.check(_lib.lib().zk_bn254_ntt_shard_dev(C.c_int(step), C.c_void_p(da.ptr), C.c_uint32(log_d), C.c_uint32(log_g), C.c_uint32(rank), C.c_int(int(inverse)),
+                                                 C.c_int(int(decimation)), C.c_int(int(coset)), None))
+    a[...] = da.to_numpy(np.uint64, a.shape)
+
+
+@pytest.mark.parametrize("log_d,G", [(6, 8), (10, 2), (12, 1), (13, 4), (15, 8), (20, 8), (21, 4)])
+def test_sharded_standalone_ntt_matches_single_gpu_all_modes(log_d, G):
+    """zk_bn254_ntt_shard_dev (BASELINE configs[4] on several GPUs): the steps of parallel.ntt_sharded played for all G ranks in lock-step on one GPU give
+    the single-GPU (*Domain).FFT / FFTInverse bit for bit, for all eight mode combinations (the four computeH uses at the two largest sizes); the smallest
+    size also against the oracle."""
+    from tests import sharded_h_ref as sh
+    n = 1 << log_d
+    M = n // G
+    x = orc.rand_fr(600 + log_d, n)
+    dom = zk.Domain(n)
+    modes = [(i, d, c) for i in (0, 1) for d in (zk.DIT, zk.DIF) for c in (0, 1)]
+    if log_d >= 20:
+        modes = [(0, zk.DIF, 1), (1, zk.DIF, 0), (0, zk.DIT, 1), (1, zk.DIT, 1)]
+    for inverse, dec, coset in modes:
+        want = x.copy()
+        (dom.fft_inverse if inverse else dom.fft)(want, dec, bool(coset))
+        if log_d == 6:
+            assert (want == orc.fr_ntt(x, bool(inverse), dec, bool(coset))).all()
+        blocks = [x[r * M:(r + 1) * M].copy() for r in range(G)]
+        out = sh.run_virtual_ntt(_ntt_step_gpu, blocks, log_d, bool(inverse), dec, bool(coset))
+        assert sha_image(np.concatenate(out)) == sha_image(want), (log_d, G, inverse, dec, coset)
+    d = _lib.DeviceBuffer(64 * 32)
+    call = lambda st, ld, lg, rk, dec=zk.DIF: _lib.lib().zk_bn254_ntt_shard_dev(C.c_int(st), C.c_void_p(d.ptr), C.c_uint32(ld), C.c_uint32(lg), C.c_uint32(rk), C.c_int(0),
+                                                                             C.c_int(dec), C.c_int(0), None)
+    assert call(3, 6, 1, 0) == _lib.ZK_ERR_ARG and call(0, 6, 4, 0) == _lib.ZK_ERR_ARG and call(0, 6, 1, 2) == _lib.ZK_ERR_ARG and call(0, 6, 1, 0, 7) == _lib.ZK_ERR_ARG
+    assert call(0, 3, 2, 0) == _lib.ZK_ERR_ARG  # fewer than G columns per rank
+
+
 def test_sharded_compute_h_argument_errors():
     d = _lib.DeviceBuffer(64 * 32)
     call = lambda ph, ld, lg, rk: _lib.lib().zk_bn254_groth16_h_shard_dev(C.c_int(ph), C.c_void_p(d.ptr), C.c_void_p(d.ptr), C.c_void_p(d.ptr),
@@ -525,7 +561,7 @@ def test_two_process_sharded_proof_equals_single_process():
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--micro-log-n", "14"]
     single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "13"] + common, capture_output=True, text=True, timeout=600)
     assert single.returncode == 0, single.stdout[-2000:] + single.stderr[-2000:]
     sha1 = json.loads(single.stdout.strip().splitlines()[-1])["proof_sha"]
@@ -536,6 +572,10 @@ def test_two_process_sharded_proof_equals_single_process():
     assert multi.returncode == 0, multi.stdout[-2000:] + multi.stderr[-2000:]
     out = json.loads([l for l in multi.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["proof_sha"] == sha1
+    # configs[4] over the two ranks: the range-sharded MSM agrees on both ranks and with its odd-split recombination, the block-sharded FFT inverts
+    ms = out["micro_2p14_sharded"]
+    assert ms["ranks"] == 2 and ms["msm_same_on_every_rank"] and ms["msm_equals_odd_split_recombination"] and ms["ntt_inverse_of_forward_is_identity"]
+    assert "parity_error" not in out
     # the window-sharded decomposition (whole key on every rank, table rows split, h all-gathered) gives the same bytes
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -559,7 +599,7 @@ def test_rccl_executes_the_collectives_of_the_sharded_proof_world_of_one():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--log-n", "14"]
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--log-n", "14", "--micro-log-n", "16"]
     single = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
     assert single.returncode == 0, single.stdout[-2000:] + single.stderr[-2000:]
     sha1 = json.loads(single.stdout.strip().splitlines()[-1])["proof_sha"]
@@ -572,6 +612,8 @@ def test_rccl_executes_the_collectives_of_the_sharded_proof_world_of_one():
         out = json.loads([l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1])
         assert out["proof_sha"] == sha1, shard
         assert out["config"].get("collectives") == "nccl", out["config"]
+        ms = out["micro_2p16_sharded"]  # the standalone sharded MSM / FFT: their all-gather and the two all-to-alls per transform through RCCL as well
+        assert ms["msm_same_on_every_rank"] and ms["msm_equals_odd_split_recombination"] and ms["ntt_inverse_of_forward_is_identity"]
 
 
 def test_concurrent_callers_are_safe():

@@ -93,3 +93,26 @@ def test_two_rank_sharded_compute_h_gloo(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+@pytest.mark.parametrize("log_d,G", [(6, 1), (6, 2), (6, 4), (7, 8), (4, 4)])
+def test_sharded_standalone_ntt_schedule_all_modes(log_d, G):
+    """parallel.ntt_sharded's schedule (steps + two transposes; include/zkmi.h zk_bn254_ntt_shard_dev) on big integers over virtual ranks equals the
+    oracle's (*Domain).FFT / FFTInverse for all eight mode combinations -- and the product's own driver runs the same sequence (checked by playing it
+    for one rank at G = 1, where the exchanges are the identity)."""
+    from noir_backend_using_gnark_amd import parallel as par
+    D = 1 << log_d
+    M = D // G
+    dom = ref.Domain(D)
+    x = ref.rand_felts(0x77 + log_d, D)
+    for inverse in (False, True):
+        for dec in (ref.DIT, ref.DIF):
+            for coset in (False, True):
+                want = (dom.fft_inverse if inverse else dom.fft)(x, dec, coset)
+                blocks = [list(x[r * M:(r + 1) * M]) for r in range(G)]
+                out = sh.run_virtual_ntt(sh.ntt_step_int, blocks, log_d, inverse, dec, coset)
+                assert [v for b in out for v in b] == want, (inverse, dec, coset)
+                if G == 1:
+                    a = list(x)
+                    got = par.ntt_sharded(a, log_d, 0, 1, inverse, dec, coset, step=sh.ntt_step_int, exchange=lambda v: v)
+                    assert got == want
