@@ -76,6 +76,18 @@ assert to_i(h) == want[rank * M:(rank + 1) * M], "rank %%d block of h differs" %
 # the pipelined schedule (per-array phases 0, 1, 4, then 5; transposes one array ahead) gives the same block
 h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase, pipelined=True)
 assert to_i(h) == want[rank * M:(rank + 1) * M], "rank %%d block of h differs (pipelined)" %% rank
+# the standalone sharded transform through the product's driver and exchange code: all eight modes
+def nstep(st, t, log_d, log_g, rk, inverse, dec, coset):
+    l = to_i(t)
+    sh.ntt_step_int(st, l, log_d, log_g, rk, inverse, dec, coset)
+    t.copy_(to_t(l))
+dom = ref.Domain(D)
+for inverse in (False, True):
+    for dec in (ref.DIT, ref.DIF):
+        for coset in (False, True):
+            want_n = (dom.fft_inverse if inverse else dom.fft)(a, dec, coset)
+            got = par.ntt_sharded(blk(a), log_d, rank, world, inverse, dec, coset, step=nstep)
+            assert to_i(got) == want_n[rank * M:(rank + 1) * M], (rank, inverse, dec, coset)
 # exchange is an involution
 x = torch.arange(M * 4, dtype=torch.int64).reshape(M, 4) + 1000 * rank
 assert torch.equal(par.block_exchange(par.block_exchange(x)), x)
