@@ -373,6 +373,13 @@ __global__ void k_h_pointwise(Fr* a, const Fr* b, const Fr* c, Fr den, size_t n)
     a[i] = x * den;
 }
 
+// h = (u - c) * den: the last step of computeH when c stays in coefficient form (see compute_h_inplace)
+__global__ void k_h_final(Fr* u, const Fr* c, Fr den, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u[i] = (gload_fr(u + i) - gload_fr(c + i)) * den;
+}
+
 __global__ void k_fr_mul(Fr* out, const Fr* a, const Fr* b, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gload_fr(a + i) * gload_fr(b + i);
@@ -479,14 +486,19 @@ static int launch_pass(Slot* s, hipStream_t st, const PassArgs& A_, bool sat) {
 
 // Runs the log2(N) stages of one transform as a sequence of tile passes.
 static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int inverse, int dif, const Fr* pre, const Fr* post,
-                      const Fr* post_const) {
+                      const Fr* post_const, const Fr* src = nullptr) {
     const unsigned logn = dom->logn;
     const bool sat = g_ntt_saturated;
     const Fr* tw = sat ? (inverse ? dom->tw_inv : dom->tw) : (inverse ? dom->tw29_inv : dom->tw29);
     if (logn == 0) {
+        if (src && src != data) ZK_HIP(hipMemcpyAsync(data, src, sizeof(Fr), hipMemcpyDeviceToDevice, st));
         if (pre) ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3(1), dim3(64), 0, data, pre, (size_t)1);
         if (post) ZK_LAUNCH(s, st, "ntt_scale", k_scale_table, dim3(1), dim3(64), 0, data, post, (size_t)1);
         return ZK_OK;  // 1/N = 1
+    }
+    if (sat && src && src != data) {  // the saturated kernels (A/B switch) work in place only
+        ZK_HIP(hipMemcpyAsync(data, src, sizeof(Fr) << logn, hipMemcpyDeviceToDevice, st));
+        src = nullptr;
     }
     std::vector<PassPlan> passes = plan_passes(logn);
     size_t npass = passes.size();
@@ -494,7 +506,7 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int 
         // DIF walks the bits from the top, DIT from the bottom
         const PassPlan& p = dif ? passes[npass - 1 - idx] : passes[idx];
         PassArgs A;
-        A.data = data; A.tw = tw; A.tw2 = nullptr; A.src = nullptr; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
+        A.data = data; A.tw = tw; A.tw2 = nullptr; A.src = (idx == 0 && src && src != data) ? src : nullptr; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
         A.pre = (idx == 0) ? pre : nullptr;
         A.post = (idx + 1 == npass) ? post : nullptr;
         A.has_post_const = (idx + 1 == npass && post_const && !post) ? 1 : 0;
@@ -603,6 +615,22 @@ int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned log
     ZK_TRY(get_domain(s, st, logN, DOM_TW | DOM_TW_INV | DOM_COSET_REV_N | DOM_COSET_INV_N_REV, &d));
     size_t N = (size_t)1 << logN;
     Fr* vs[3] = {a, b, c};
+    // By linearity (exact field arithmetic, so bit for bit for ANY input): FFTInverse(coset)((a'b' - c') den) = den (FFTInverse(coset)(a'b') - FFTInverse(c)),
+    // where c' = FFT(coset)(FFTInverse(c)) -- the coset transform of c and its way back cancel.  c therefore only needs its first FFTInverse(DIF)
+    // (coefficients, bit-reversed like the result): six transforms instead of gnark's seven.  ZKMI_H_SKIP_C=0 restores the literal sequence.
+    static const bool skip_c = !(getenv("ZKMI_H_SKIP_C") && atoi(getenv("ZKMI_H_SKIP_C")) == 0);
+    if (skip_c && !side && logN > 0) {
+        const Fr cinv = to_dev(d->card_inv);
+        for (int i = 0; i < 2; i++) ZK_TRY(run_inverse_forward(s, st, vs[i], d, d->coset_rev_n, src ? src[i] : nullptr));
+        ZK_TRY(run_passes(s, st, c, d, 1, 1, nullptr, nullptr, &cinv, src ? src[2] : nullptr));
+        ZK_LAUNCH(s, st, "fr_mul", k_fr_mul, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)a, (const Fr*)b, N);
+        ZK_TRY(run_passes(s, st, a, d, 1, 1, nullptr, d->coset_inv_n_rev, nullptr));
+        HFr gN = d->coset;
+        for (unsigned i = 0; i < logN; i++) gN = gN.sqr();
+        const HFr den = (gN - HFr::one()).inv();
+        ZK_LAUNCH(s, st, "h_final", k_h_final, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)c, to_dev(den), N);
+        return ZK_OK;
+    }
     if (side) {
         hipEvent_t fork, join[2];
         ZK_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
