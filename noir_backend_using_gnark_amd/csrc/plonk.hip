@@ -100,6 +100,25 @@ __global__ void k_z_terms(const Fr* __restrict__ l, const Fr* __restrict__ r, co
     num[i] = (lv + beta * w) * (rv + beta_u * w) * (ov + beta_uu * w);
     den[i] = (lv + beta * ld(sig + i)) * (rv + beta * ld(sig + n + i)) * (ov + beta * ld(sig + 2 * (size_t)n + i));
 }
+// qk completed with the public inputs, on the big coset, WITHOUT transforming it per proof: completed qk = qk + sum_i d_i L_i with d_i = w_i - LQk[i] (the public
+// rows), and L_i(x) = L_0(x w^-i): on the coset x_j = g W^j (w = W^rho, rho = 4 or 8) that is the key's L_0 table read rho i places earlier.  Tables are in bit-reversed layout:
+// entry p belongs to j = bitrev(p).  Linear and exact, hence the same values as FFT(coset)(canonical(LQk with the public inputs)) -- for any input.
+constexpr uint32_t PLONK_PI_DIRECT_MAX = 32;
+__global__ __launch_bounds__(256) void k_qk_coset(const Fr* __restrict__ e_cqk, const Fr* __restrict__ e_l1, const Fr* __restrict__ sol, const Fr* __restrict__ lqk,
+                                                  uint32_t npub, unsigned logN4, unsigned log_rho, Fr* __restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N4 = (size_t)1 << logN4;
+    if (p >= N4) return;
+    const uint32_t j = __brev((uint32_t)p) >> (32 - logN4);
+    Fr v = ld(e_cqk + p);
+    for (uint32_t i = 0; i < npub; i++) {
+        const Fr d = ld(sol + i) - ld(lqk + i);
+        const uint32_t q = __brev((j - (i << log_rho)) & (uint32_t)(N4 - 1)) >> (32 - logN4);  // w = W^rho, rho = N4 / n
+        v = v + d * ld(e_l1 + q);
+    }
+    out[p] = v;
+}
+
 // fr.BatchInvert: a[i] <- 1 / a[i] (0 stays 0); BINV_K elements per lane (strided, coalesced) share one Fermat inversion (~380 products, paid per
 // WAVE whatever the lanes do): 3 + 380 / BINV_K products per element.  The prefix products of the forward sweep go through `scratch` (n elements, 160 B of
 // traffic per element in all) instead of registers, which is what lets BINV_K be 32 (8 in registers: 1.9 ms at 2^22 elements; 32: see DESIGN 3.8).
@@ -374,6 +393,7 @@ struct PlonkPK {
     Fr *ql = nullptr, *qr = nullptr, *qm = nullptr, *qo = nullptr, *cqk = nullptr, *lqk = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
     uint32_t* perm = nullptr;  // pk.Permutation (3n), kept for ProvingKey.WriteTo
     Fr* sig = nullptr;      // S1 | S2 | S3 in Lagrange form (3n): what BuildRatioCopyConstraint reads through pk.Permutation
+    Fr* e_cqk = nullptr;    // CQk (qk WITHOUT the public inputs) as LagrangeCoset on the big domain: per proof only the public inputs' share is added (k_qk_coset)
     Fr* e[9] = {};          // ql, qr, qm, qo, s1, s2, s3, L1, id as LagrangeCoset on the big domain, bit-reversed layout (gnark caches the first 7)
     uint32_t *xa = nullptr, *xb = nullptr, *xc = nullptr;
     Affine<HFp> vk_s[3], vk_ql, vk_qr, vk_qm, vk_qo, vk_qk;
@@ -601,6 +621,8 @@ static int finish_pk(PlonkPK* P, Slot* s, hipStream_t st) {
         ZK_HIP(hipStreamSynchronize(st));
     }
     ZK_TRY(ntt_dev(s, st, P->e[8], P->logN4, 0, ZK_DIF, 1));
+    ZK_TRY(pk_alloc(P, &P->e_cqk, N4));
+    ZK_TRY(to_big_coset(s, st, P->e_cqk, P->cqk, n, P));
     for (int k = 0; k < 5; k++) ZK_TRY(pk_alloc(P, &P->w_big[k], N4));
     ZK_TRY(pk_alloc(P, &P->w_small, 16 * (n + 8)));
     P->mu = std::make_shared<std::mutex>();
@@ -1151,6 +1173,13 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         const Fr* polys[1] = {bz_};
         const size_t lens[1] = {n + 3};
         ZK_TRY(commit_group(1, polys, lens, &c_z, [&]() -> int {
+            static const bool qk_ntt = getenv("ZKMI_PLONK_QK_NTT") && atoi(getenv("ZKMI_PLONK_QK_NTT")) == 1;  // A/B switch: the literal sequence
+            if (!qk_ntt && npub <= PLONK_PI_DIRECT_MAX && logN4 >= 2) {
+                ZK_TRY(to_big_coset(s, st, P->w_big[3], small5[3], len5[3], P));
+                ZK_LAUNCH(s, st, "plonk_qk_coset", k_qk_coset, dim3(grid_of(P->N4)), dim3(256), 0, (const Fr*)P->e_cqk, (const Fr*)P->e[7], (const Fr*)d_sol, (const Fr*)P->lqk,
+                          (uint32_t)npub, logN4, P->log_rho, P->w_big[4]);
+                return ZK_OK;
+            }
             ZK_HIP(hipMemcpyAsync(qkc, P->lqk, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
             if (npub) ZK_HIP(hipMemcpyAsync(qkc, d_sol, npub * sizeof(Fr), hipMemcpyDeviceToDevice, st));
             ZK_TRY(to_canonical(s, st, qkc, logn));
