@@ -128,6 +128,11 @@ int zk_bn254_groth16_compute_h_dev(const void *d_a, const void *d_b, const void 
  * Phases 0 and 1 act on each array independently and skip null pointers; phase 2 = phase 4 (cross stages of FFT(DIT), per array) followed by
  * phase 5 (the pointwise step and the final cross stages, all three arrays) -- so that the host can pipeline the transposes of b, c under the
  * stages of a (parallel.compute_h_sharded(pipelined=True): async collectives, one array ahead).
+ * The six-transform schedule (default of parallel.compute_h_sharded; exact by linearity): c stays in coefficient form --
+ *   phase 6: blocks given (c)    -> rest of FFTInverse(DIF) with 1/D: block of the coefficients, bit-reversed order (no further transpose of c)
+ *   phase 7: a, b transposed, after phase 4 on each -> a = a*b; cross stages of FFTInverse(DIF) on a            -> transpose a back
+ *   phase 8: a block + c block   -> block part of FFTInverse(DIF, coset) on a; a = (a - c)/(g^D - 1): this rank's block of h.
+ *   Order: transpose a, b, c; 0 each; transpose each; 1 on a, b and 6 on c; transpose a, b; 4 on a, b; 7; transpose a; 8  -- 9 transposes instead of 10.
  * log_g = 0 degenerates to zk_bn254_groth16_compute_h_dev (no exchange).  In place; asynchronous on `stream` if given. */
 int zk_bn254_groth16_h_shard_dev(int phase, void *d_a, void *d_b, void *d_c, uint32_t log_D, uint32_t log_g,
                                  uint32_t rank, void *stream);

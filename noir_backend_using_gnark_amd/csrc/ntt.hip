@@ -779,7 +779,27 @@ int compute_h_shard_phase(Slot* s, hipStream_t st, int phase, Fr* a, Fr* b, Fr* 
         }
         case 3:  // block of a: rest of FFTInverse(DIF, coset) -> this rank's block of h (gnark's bit-reversed order)
             return run_passes(s, st, a, dM, 1, 1, nullptr, tb.coset_inv_n_rev, nullptr);
-        default: return set_err(ZK_ERR_ARG, "phase must be 0..5");
+        // ---- the six-transform schedule (c stays in coefficient form: compute_h_inplace's shortcut, sharded; one transpose and two transforms of c fewer)
+        case 6: {  // blocks (any subset; the schedule uses it for c): rest of FFTInverse(DIF) with 1/D -> block of the coefficients, bit-reversed order
+            const Fr cinv = to_dev(dD->card_inv);
+            for (Fr* v : {a, b, c})
+                if (v) ZK_TRY(run_passes(s, st, v, dM, 1, 1, nullptr, nullptr, &cinv));
+            return ZK_OK;
+        }
+        case 7:  // transposed a, b (after phase 4 on each): a = a * b, then the cross stages of the final FFTInverse(DIF, coset) on a
+            if (!a || !b) return set_err(ZK_ERR_ARG, "phase 7 needs a and b");
+            ZK_LAUNCH(s, st, "fr_mul", k_fr_mul, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, a, (const Fr*)a, (const Fr*)b, M);
+            return launch_cross<true>(s, st, a, dD->tw_inv, logM, logg, rank);
+        case 8: {  // block of a and block of c's coefficients (phase 6): rest of FFTInverse(DIF, coset), then h = (a - c) / (g^D - 1)
+            if (!a || !c) return set_err(ZK_ERR_ARG, "phase 8 needs a and c");
+            ZK_TRY(run_passes(s, st, a, dM, 1, 1, nullptr, tb.coset_inv_n_rev, nullptr));
+            HFr gN = dD->coset;
+            for (unsigned i = 0; i < logD; i++) gN = gN.sqr();
+            const HFr den = (gN - HFr::one()).inv();
+            ZK_LAUNCH(s, st, "h_final", k_h_final, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, a, (const Fr*)c, to_dev(den), M);
+            return ZK_OK;
+        }
+        default: return set_err(ZK_ERR_ARG, "phase must be 0..8");
     }
 }
 
@@ -934,7 +954,7 @@ int zk_bn254_groth16_compute_h(const zk_fr* a, const zk_fr* b, const zk_fr* c, s
 }
 
 int zk_bn254_groth16_h_shard_dev(int phase, void* d_a, void* d_b, void* d_c, uint32_t log_D, uint32_t log_g, uint32_t rank, void* stream) {
-    if (!d_a || ((phase == 2 || phase == 5) && (!d_b || !d_c))) return set_err(ZK_ERR_ARG, "null pointer");
+    if ((!d_a && phase != 6) || ((phase == 2 || phase == 5) && (!d_b || !d_c))) return set_err(ZK_ERR_ARG, "null pointer");
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     // Give it the stream of the proof's msm5 session (zk_bn254_groth16_msm5_session_stream): a foreign stream may share a

@@ -206,7 +206,7 @@ def block_exchange_async(x):
 
 
 def compute_h_sharded(a, b, c, log_d: int, rank: int, world: int, phase=_h_shard_phase_hip, exchange=block_exchange, pipelined=None,
-                      exchange_async=None):
+                      exchange_async=None, six_transforms=None):
     """gnark computeH with a, b, c, h sharded by blocks over `world` = 2^g ranks.  a, b, c: this rank's blocks (M = 2^log_d / world
     elements of 4 x int64 each; destroyed).  Returns the array holding this rank's block of h (gnark's bit-reversed order).
     `phase` / `exchange` are injectable so that the CPU tests can run the same schedule on the oracle's arithmetic over gloo.
@@ -219,6 +219,36 @@ def compute_h_sharded(a, b, c, log_d: int, rank: int, world: int, phase=_h_shard
     if pipelined is None:
         d = dist()
         pipelined = bool(not _no_peers(d) and d.get_backend() == "nccl")
+    if six_transforms is None:
+        six_transforms = os.environ.get("ZKMI_H_SKIP_C", "1") != "0"
+    if six_transforms:
+        # c stays in coefficient form (exact by linearity: csrc/ntt.hip compute_h_inplace): c only goes through the first inverse transform (two transposes,
+        # phases 0 and 6) and is subtracted from this rank's block of the result in phase 8 -- 9 array transposes instead of 10, two transforms of c fewer
+        xa = exchange_async or (block_exchange_async if (pipelined and exchange is block_exchange) else (lambda x: (exchange(x), (lambda: None))))
+        flight = [xa(v) for v in (a, b, c)]
+        nxt = []
+        for v, wait in flight:                       # cross stages of FFTInverse(DIF), one array ahead of the transposes
+            wait()
+            phase(0, v, None, None, log_d, log_g, rank)
+            nxt.append(xa(v))
+        (a, wa), (b, wb), (c, wc) = nxt
+        ab = []
+        for v, wait in ((a, wa), (b, wb)):           # blocks of a, b: rest of the inverse, scaling, block part of FFT(DIT, coset); then transposed again
+            wait()
+            phase(1, v, None, None, log_d, log_g, rank)
+            ab.append(xa(v))
+        wc()
+        phase(6, c, None, None, log_d, log_g, rank)  # block of c: its coefficients -- stays here
+        out = []
+        for v, wait in ab:
+            wait()
+            phase(4, v, None, None, log_d, log_g, rank)
+            out.append(v)
+        a, b = out
+        phase(7, a, b, None, log_d, log_g, rank)
+        a = exchange(a)
+        phase(8, a, None, c, log_d, log_g, rank)
+        return a
     if not pipelined:
         a, b, c = exchange(a), exchange(b), exchange(c)
         phase(0, a, b, c, log_d, log_g, rank)

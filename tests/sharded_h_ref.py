@@ -102,6 +102,22 @@ def phase_int(phase, a, b, c, log_d, log_g, rank):
         dif_inplace(a, w_m_inv)
         for j in range(M):
             a[j] = a[j] * dom.card_inv % R * pow(dom.coset_inv, ref.bitrev(rank * M + j, log_d), R) % R
+    elif phase == 6:   # the six-transform schedule: block of the coefficients of any array given (c)
+        for v in (a, b, c):
+            if v is None:
+                continue
+            dif_inplace(v, w_m_inv)
+            for j in range(M):
+                v[j] = v[j] * dom.card_inv % R
+    elif phase == 7:   # transposed a, b after phase 4: product, then the cross stages of the final inverse
+        for j in range(M):
+            a[j] = a[j] * b[j] % R
+        cross_dif(a, dom.gen_inv, log_g, log_m, rank)
+    elif phase == 8:   # block of a, block of c's coefficients: rest of FFTInverse(DIF, coset), h = (a - c) / (g^D - 1)
+        den = ref.inv((pow(dom.coset, dom.n, R) - 1) % R, R)
+        dif_inplace(a, w_m_inv)
+        for j in range(M):
+            a[j] = (a[j] * dom.card_inv % R * pow(dom.coset_inv, ref.bitrev(rank * M + j, log_d), R) - c[j]) * den % R
     else:
         raise ValueError(phase)
 
@@ -193,3 +209,27 @@ def run_virtual_ntt(step, X, log_d, inverse, decimation, coset):
     if coset and inverse:
         run(2, X)
     return X
+
+
+def run_virtual_six(phase, A, B, Cc, log_d):
+    """Lock-step schedule of parallel.compute_h_sharded(six_transforms=True) over G = len(A) virtual ranks: c only through phases 0 and 6."""
+    G = len(A)
+    log_g = G.bit_length() - 1
+    A, B, Cc = exchange_all(A), exchange_all(B), exchange_all(Cc)
+    for r in range(G):
+        for v in (A[r], B[r], Cc[r]):
+            phase(0, v, None, None, log_d, log_g, r)
+    A, B, Cc = exchange_all(A), exchange_all(B), exchange_all(Cc)
+    for r in range(G):
+        phase(1, A[r], None, None, log_d, log_g, r)
+        phase(1, B[r], None, None, log_d, log_g, r)
+        phase(6, Cc[r], None, None, log_d, log_g, r)
+    A, B = exchange_all(A), exchange_all(B)
+    for r in range(G):
+        phase(4, A[r], None, None, log_d, log_g, r)
+        phase(4, B[r], None, None, log_d, log_g, r)
+        phase(7, A[r], B[r], None, log_d, log_g, r)
+    A = exchange_all(A)
+    for r in range(G):
+        phase(8, A[r], None, Cc[r], log_d, log_g, r)
+    return A

@@ -405,6 +405,9 @@ def test_sharded_compute_h_matches_single_gpu_and_oracle(log_d, G):
     if log_d in (9, 13, 15):   # the pipelined schedule's per-array calls (phases 0, 1, 4 with b = c = NULL, then 5)
         H = sh.run_virtual(_h_phase_gpu, blk(a), blk(b), blk(c), log_d, per_array=True)
         assert sha_image(np.concatenate(H)) == sha_image(want)
+    # the six-transform schedule (c in coefficient form: phases 0, 1, 4, 6, 7, 8; 9 transposes) -- the default of parallel.compute_h_sharded
+    H = sh.run_virtual_six(_h_phase_gpu, blk(a), blk(b), blk(c), log_d)
+    assert sha_image(np.concatenate(H)) == sha_image(want)
 
 
 def _ntt_step_gpu(step, a, log_d, log_g, rank, inverse, decimation, coset):
@@ -449,7 +452,7 @@ def test_sharded_compute_h_argument_errors():
                                                                           C.c_uint32(ld), C.c_uint32(lg), C.c_uint32(rk), None)
     assert call(0, 6, 4, 0) != 0      # more than 8 ranks
     assert call(0, 6, 2, 4) != 0      # rank out of range
-    assert call(7, 6, 1, 0) != 0      # unknown phase
+    assert call(9, 6, 1, 0) != 0      # unknown phase (0..8 exist)
     assert call(0, 3, 2, 0) != 0      # blocks smaller than the number of ranks
     out = np.zeros(96, np.uint64)
     assert _lib.lib().zk_bn254_groth16_msm5_pk_end(C.c_uint64(12345), C.c_void_p(d.ptr), _lib.vp(out), None) != 0  # unknown session

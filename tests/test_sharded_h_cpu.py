@@ -42,6 +42,8 @@ def test_sharded_schedule_equals_compute_h(log_d, G):
     assert [x for h in H for x in h] == want
     H = sh.run_virtual(sh.phase_int, blk(a), blk(b), blk(c), log_d, per_array=True)
     assert [x for h in H for x in h] == want
+    H = sh.run_virtual_six(sh.phase_int, blk(a), blk(b), blk(c), log_d)   # c in coefficient form: 9 transposes, same h for ANY a, b, c
+    assert [x for h in H for x in h] == want
 
 
 WORKER = r'''
@@ -71,10 +73,12 @@ def phase(p, ta, tb, tc, log_d, log_g, rk):
         if t is not None: t.copy_(to_t(l))
 
 blk = lambda v: to_t(v[rank * M:(rank + 1) * M])
-h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase)
+h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase)   # default: the six-transform schedule
+assert to_i(h) == want[rank * M:(rank + 1) * M], "rank %%d block of h differs (six transforms)" %% rank
+h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase, six_transforms=False)
 assert to_i(h) == want[rank * M:(rank + 1) * M], "rank %%d block of h differs" %% rank
 # the pipelined schedule (per-array phases 0, 1, 4, then 5; transposes one array ahead) gives the same block
-h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase, pipelined=True)
+h = par.compute_h_sharded(blk(a), blk(b), blk(c), log_d, rank, world, phase=phase, pipelined=True, six_transforms=False)
 assert to_i(h) == want[rank * M:(rank + 1) * M], "rank %%d block of h differs (pipelined)" %% rank
 # the standalone sharded transform through the product's driver and exchange code: all eight modes
 def nstep(st, t, log_d, log_g, rk, inverse, dec, coset):
