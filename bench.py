@@ -179,7 +179,7 @@ def plonk_block(L, lib, log_n, reps=3):
     lib.profile(False)
     prof = lib.profile_read()
     out = {"gates": n, "prove_ms": round(ms, 2), "steps": reps, "warmup": 1, "setup_ms": round(t_setup * 1e3, 1), "data_s": round(t_data, 2),
-           "kzg_commits_per_proof": 10, "ntt_per_proof": "4 x inverse(n) + 4 x coset(4n) + 1 x coset inverse(4n) (gnark's fifth pair -- qk with the public inputs -- is one element-wise kernel here)",
+           "kzg_commits_per_proof": "10 (9 as MSMs; the linearised polynomial's digest by linearity from the verifying key and [Z])", "ntt_per_proof": "4 x inverse(n) + 4 x coset(4n) + 1 x coset inverse(4n) (gnark's fifth pair -- qk with the public inputs -- is one element-wise kernel here)",
            "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
            "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]}}
     # ---- checker (CPU oracle, after the timed region): decode Proof.WriteTo and run plonk.Verify's equations

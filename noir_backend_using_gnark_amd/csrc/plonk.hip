@@ -397,6 +397,9 @@ struct PlonkPK {
     Fr* e[9] = {};          // ql, qr, qm, qo, s1, s2, s3, L1, id as LagrangeCoset on the big domain, bit-reversed layout (gnark caches the first 7)
     uint32_t *xa = nullptr, *xb = nullptr, *xc = nullptr;
     Affine<HFp> vk_s[3], vk_ql, vk_qr, vk_qm, vk_qo, vk_qk;
+    // the verifying-key digests are known to be the commitments of THIS key's polynomials under ITS SRS (Setup computed them, or a proof has confirmed it):
+    // the digest of the linearised polynomial may then be taken by linearity (seven scalar multiplications on the host) instead of an n-point MSM
+    bool vk_consistent = false;
     // per-proof workspace (one proof at a time per key)
     Fr *w_big[5] = {}, *w_small = nullptr;
     std::shared_ptr<std::mutex> mu;
@@ -766,6 +769,7 @@ int zk_bn254_plonk_setup(const zk_plonk_circuit* c, uint64_t srs, uint64_t* hand
     const Fr* cm[8] = {P->s1, P->s2, P->s3, P->ql, P->qr, P->qm, P->qo, P->cqk};
     Affine<HFp>* cmo[8] = {&P->vk_s[0], &P->vk_s[1], &P->vk_s[2], &P->vk_ql, &P->vk_qr, &P->vk_qm, &P->vk_qo, &P->vk_qk};
     for (int k = 0; k < 8; k++) ZK_TRY(commit(P.get(), s, st, cm[k], n, cmo[k]));
+    P->vk_consistent = true;
     if (vk) {
         memset(vk, 0, sizeof *vk);
         vk->size = n;
@@ -1249,6 +1253,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     const HFr lz = ev[0], rz = ev[1], oz = ev[2], s1z = ev[3], s2z = ev[4], zu = ev[5];
 
     // ---- linearised polynomial
+    HFr lin_cz, lin_cs3, lin_lag;
     {
         const HFr one = HFr::one();
         HFr c_s3 = (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma) * zu * beta;
@@ -1256,6 +1261,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         HFr zn = zeta;
         for (unsigned i = 0; i < logn; i++) zn = zn.sqr();
         HFr lag = (zn - one) * (zeta - one).inv() * alpha * alpha * P->card_inv;
+        lin_cz = c_zz; lin_cs3 = c_s3; lin_lag = lag;
         LinArgs A;
         A.bz = bz_; A.s3 = P->s3; A.ql = P->ql; A.qr = P->qr; A.qm = P->qm; A.qo = P->qo; A.cqk = P->cqk; A.out = lin;
         A.c_z = to_dev(c_zz); A.c_s3 = to_dev(c_s3); A.alpha = to_dev(alpha); A.rl = to_dev(lz * rz); A.lz = to_dev(lz); A.rz = to_dev(rz); A.oz = to_dev(oz);
@@ -1263,7 +1269,32 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         A.n = (uint32_t)n; A.len = (uint32_t)(n + 3);
         ZK_LAUNCH(s, st, "plonk_linearized", k_linearized, dim3(grid_of(n + 3)), dim3(256), 0, A);
     }
-    if (chain.ok) ZK_TRY(chain.start(1, st, lin, n + 3));  // finished below, after the folded quotient and the last two evaluations are enqueued
+    // Digest of the linearised polynomial.  It is a linear combination of polynomials whose commitments exist already -- the verifying key's and the proof's [Z] --
+    // so commit(lin) = (alpha c_z + lag) [Z] + alpha c_s3 [S3] + lz rz [Qm] + lz [Ql] + rz [Qr] + oz [Qo] + [Qk]: the same group element as gnark's kzg.Commit of the
+    // polynomial, for seven scalar multiplications on the host (while the GPU runs the kernels above) instead of an (n + 3)-point MSM.  Only for keys whose
+    // digests are known to be consistent: Setup's, or -- for a key read from its wire image -- once a first proof has computed both and found them equal.
+    // ZKMI_PLONK_LIN_MSM=1 forces the literal commitment (A/B switch).
+    static const bool lin_msm = getenv("ZKMI_PLONK_LIN_MSM") && atoi(getenv("ZKMI_PLONK_LIN_MSM")) == 1;
+    Affine<HFp> c_lin_by_linearity;
+    {
+        const HFr cz_tot = alpha * lin_cz + lin_lag, cs3_tot = alpha * lin_cs3;
+        auto mul = [](const Affine<HFp>& p, const HFr& k) {
+            uint32_t c[8];
+            to_canonical_u32(k, c);
+            return scalar_mul(p, c);
+        };
+        XYZZ<HFp> acc = mul(c_z, cz_tot);
+        acc.add(mul(P->vk_s[2], cs3_tot));
+        acc.add(mul(P->vk_qm, lz * rz));
+        acc.add(mul(P->vk_ql, lz));
+        acc.add(mul(P->vk_qr, rz));
+        acc.add(mul(P->vk_qo, oz));
+        acc.madd(P->vk_qk);
+        c_lin_by_linearity = acc.to_affine();
+    }
+    const bool lin_direct = P->vk_consistent && !lin_msm;
+    if (lin_direct) c_lin = c_lin_by_linearity;
+    else if (chain.ok) ZK_TRY(chain.start(1, st, lin, n + 3));  // finished below, after the folded quotient and the last two evaluations are enqueued
     else ZK_TRY(commit(P, s, st, lin, n + 3, &c_lin));
 
     // ---- folded quotient h1 + zeta^(n+2) h2 + zeta^(2(n+2)) h3 and its digest
@@ -1292,7 +1323,9 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     ZK_TRY(poly_eval_dev(s, st, lin, n + 3, zeta, SB, d_vals + 7));
     ZK_HIP(hipMemcpyAsync(ev + 6, d_vals + 6, 2 * sizeof(Fr), hipMemcpyDeviceToHost, st));
     ZK_TRY(slot_sync(s, st));
-    if (chain.ok) ZK_TRY(chain.finish(1, &c_lin));
+    if (chain.ok && !lin_direct) ZK_TRY(chain.finish(1, &c_lin));
+    if (!lin_direct && !lin_msm && c_lin.x == c_lin_by_linearity.x && c_lin.y == c_lin_by_linearity.y)
+        const_cast<PlonkPK*>(P)->vk_consistent = true;  // (the key's workspace mutex is held for the whole proof) from the next proof on: by linearity
     const HFr claimed[7] = {ev[6], ev[7], lz, rz, oz, s1z, s2z};
     const Affine<HFp> digests[7] = {c_fh, c_lin, c_lro[0], c_lro[1], c_lro[2], P->vk_s[0], P->vk_s[1]};
     HFr kg;

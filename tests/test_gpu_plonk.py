@@ -125,7 +125,8 @@ def test_plonk_random_circuits_vs_oracle(nc, nvars, npub):
     polys = {k: M(opk[k]) for k in ("ql", "qr", "qm", "qo", "cqk", "lqk", "s1", "s2", "s3")}
     g = spr.constraints
     pk2 = zp.load_proving_key(opk["d0"].logn, npub, spr.n_vars, polys, opk["perm"], [c[5] for c in g], [c[6] for c in g], [c[7] for c in g], pk.vk, rb)
-    assert zp.prove(pk2, M(sol), M(bl)) == want
+    assert zp.prove(pk2, M(sol), M(bl)) == want   # a loaded key: the linearised digest by MSM, and compared with the value obtained by linearity
+    assert zp.prove(pk2, M(sol), M(bl)) == want   # ... which this second proof then uses (the digests proved consistent)
     pk2.free()
     pk.free()
     rb.free()
