@@ -530,6 +530,22 @@ def main():
                                        "note": "zk_bn254_groth16_prove(on_device=0): a, b, c, w are pageable host arrays uploaded inside the call"}
         del ha, hb, hc, hw
 
+    # ---- the same key with a witness-like wire vector (SURVEY 8d cfg2's second distribution: 50 % in {0, 1}, 25 % < 2^32, 25 % uniform): giant buckets, split tasks, folds
+    if single and not args.no_host_inputs and args.scalars == "uniform":
+        d_w2 = _lib.DeviceBuffer(N_g * 32)
+        _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(d_w2.ptr), C.c_size_t(N_g), C.c_uint64(seed_at(0xC, 5, 0)), C.c_int(1), C.c_int(1), None))
+        run_w = lambda: zk.prove(pk, inst.d_a, inst.d_b, inst.d_c, d_w2, r, s, n_constraints=N_g, on_device=True)
+        pw0 = run_w()
+        reps = 20
+        _lib.check(L.zk_dev_sync())
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pw = run_w()
+        w_ms = (time.perf_counter() - t0) / reps * 1e3
+        out["prove_ms_witness_like_scalars"] = {"value": round(w_ms, 3), "reps": reps, "deterministic": bool(pw == pw0),
+                                                "note": "same key and a, b, c; wire values 50 % in {0, 1}, 25 % below 2^32, 25 % uniform (bytes checked against the oracle in tests/test_gpu_parity.py at 2^14)"}
+        d_w2.free()
+
     # ---- CPU baseline: the oracle proves the SAME instance on this box's host cores (rank 0, N=1 only)
     if single and not args.no_cpu_baseline:
         cpu_proof, cpu_s, cores = oracle_proof(inst, log_n)

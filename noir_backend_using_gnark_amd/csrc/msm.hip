@@ -153,10 +153,35 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ keys, uint32_t tota
 }
 
 // ---------------------------------------------------------------------------------------- 4. task plan
-__global__ void k_task_plan(const uint32_t* start, uint32_t nb, uint32_t L, uint32_t* ntasks, uint32_t* multi_list, uint32_t* num_multi) {
+// The task length is chosen ON THE DEVICE from what the sorted digits look like (ctl[1] = largest bucket, ctl[2] <- the length): the host's L -- sized for
+// uniform scalars -- is only the maximum.  Real witnesses are mostly 0 / 1 / small values: few non-zero digits, a handful of giant buckets.  The accumulate
+// kernel then is not throughput- but LATENCY-bound by its longest tasks (one lane adds L points one after the other, ~5 us each), so the length shrinks with
+// the work there is -- 4x what would give every resident lane one task -- but never so far that the largest bucket falls into more than 2048 partial sums
+// (one wave folds them, 64 per round).  Uniform inputs keep the host's L.
+__global__ __launch_bounds__(256) void k_bucket_stats(const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ ctl) {
+    __shared__ uint32_t wmax[4];
+    uint32_t len = 0;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) len = max(len, start[b + 1] - start[b]);
+    for (int d = 32; d > 0; d >>= 1) len = max(len, (uint32_t)__shfl_down((int)len, d, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        len = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (len) atomicMax(&ctl[1], len);
+    }
+}
+__global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t* __restrict__ ctl) {
+    const uint32_t nnz = start[nb], biggest = ctl[1];
+    uint32_t lw = 4 * ((nnz + lanes - 1) / lanes);
+    uint32_t lg = (biggest + 2047) / 2048;
+    uint32_t L = max(max(lw, lg), Lmin);
+    ctl[2] = min(L, Lmax);
+}
+__global__ void k_task_plan(const uint32_t* start, uint32_t nb, const uint32_t* __restrict__ ctl, uint32_t* ntasks, uint32_t* multi_list, uint32_t* num_multi) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
     if (b == nb) { ntasks[b] = 0; return; }
+    const uint32_t L = ctl[2];
     uint32_t cnt = start[b + 1] - start[b];
     uint32_t t = (cnt + L - 1) / L;
     ntasks[b] = t;
@@ -172,9 +197,10 @@ __global__ void k_task_plan(const uint32_t* start, uint32_t nb, uint32_t L, uint
 // balances lanes, results never depend on it (every task writes its own partial sum).
 constexpr uint32_t TS_BINS = 2048;
 
-__global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t L,
-                                                   uint32_t max_tasks, uint32_t bshift, uint32_t nbins, uint32_t* __restrict__ task_begin,
-                                                   uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t Lmax,
+                                                   const uint32_t* __restrict__ ctl, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
+                                                   uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
+    const uint32_t L = ctl[2];  // the length the plan cut the buckets with; keys stay relative to Lmax (the accumulate kernel's argument)
     __shared__ uint32_t h[TS_BINS];
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
     __syncthreads();
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ 
             uint32_t begin = start[b] + (t - task_off[b]) * L;
             uint32_t end = min(begin + L, start[b + 1]);
             task_begin[t] = begin;
-            uint32_t key = L - (end - begin);  // 0 = longest
+            uint32_t key = Lmax - (end - begin);  // 0 = longest possible
             len_key[t] = key;
             atomicAdd(&h[key >> bshift], 1u);
         }
@@ -625,7 +651,11 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     // one wave folds the partials of a split bucket: bound their number (a bucket can hold up to n points -- real witnesses are
     // mostly 0/1) by growing the task size with n
     if (P->L < (n >> 16)) P->L = (uint32_t)(n >> 16);
-    P->max_tasks = (size_t)P->nb + P->total / P->L + 1;
+    // the device may shorten the tasks down to Lmin when the digits turn out sparse / skewed (k_pick_len): the task arrays are sized for that
+    static const bool adaptive = !(getenv("ZKMI_ADAPTIVE_L") && atoi(getenv("ZKMI_ADAPTIVE_L")) == 0);
+    P->Lmin = adaptive ? (P->L / 4 > 32 ? P->L / 4 : 32) : P->L;
+    if (P->Lmin > P->L) P->Lmin = P->L;
+    P->max_tasks = (size_t)P->nb + P->total / P->Lmin + 1;
     static const unsigned l1_env = getenv("ZKMI_L1_M") ? (unsigned)atoi(getenv("ZKMI_L1_M")) : 0;  // experiment switch (power of two)
     const unsigned l1_m = l1_env ? l1_env : (tab && tab->l1_m ? tab->l1_m : 8);
     P->m1 = P->B >= l1_m ? l1_m : P->B;  // level-1 serial chunk
@@ -700,7 +730,9 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, keys, (uint32_t)total, nb, start);
     // ---- 4. plan
     ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
-    ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, L, ntasks, multi_list, num_multi);
+    if (P.Lmin < L) ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats, dim3(nb / 4096 ? (nb / 4096 > 512 ? 512 : nb / 4096) : 1), dim3(256), 0, (const uint32_t*)start, nb, bins);
+    ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), bins);
+    ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
     {
         if (ctx().profiling) prof_begin(s, st, "msm_task_scan(rocprim)");
         hipError_t e = rocprim::exclusive_scan(scan_tmp, scan_tmp_bytes, ntasks, task_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
@@ -712,7 +744,7 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     while ((L >> bshift) >= TS_BINS) bshift++;
     const uint32_t nbins = (L >> bshift) + 1;
     const unsigned tgrid = (unsigned)((max_tasks + 255) / 256);
-    ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill, dim3(tgrid), dim3(256), 0, (const uint32_t*)start, (const uint32_t*)task_off, nb, L,
+    ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill, dim3(tgrid), dim3(256), 0, (const uint32_t*)start, (const uint32_t*)task_off, nb, L, (const uint32_t*)bins,
               (uint32_t)max_tasks, bshift, nbins, task_begin, lkey0, hist);
     ZK_LAUNCH(s, st, "msm_task_bins", k_task_bins, dim3(1), dim3(256), 0, hist, nbins);
     ZK_LAUNCH(s, st, "msm_task_scatter", k_task_scatter, dim3(tgrid), dim3(256), 0, (const uint32_t*)lkey0, (uint32_t)max_tasks, bshift, nbins, hist,

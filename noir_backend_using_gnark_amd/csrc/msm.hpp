@@ -44,6 +44,7 @@ struct MsmPlan {
     unsigned Wrows, row_first, row_step;  // table mode: rows of the table this MSM feeds (all Wd unless window-sharded)
     uint32_t table_stride;
     uint32_t B, nb, L, m1, N1, m2 = 0;
+    uint32_t Lmin = 0;  // the shortest task length the device may choose (k_pick_len); the task arrays are sized for it
     size_t total, max_tasks, sort_tmp_bytes, scan_tmp_bytes, tsort_tmp_bytes, lvl_elems, need, need_prep, need_acc;
 };
 // Result of the scalar-side half of an MSM (digits, sort, bucket bounds, task plan); device arrays live in the
