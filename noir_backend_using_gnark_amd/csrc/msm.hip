@@ -170,10 +170,11 @@ __global__ __launch_bounds__(256) void k_bucket_stats(const uint32_t* __restrict
         if (len) atomicMax(&ctl[1], len);
     }
 }
-__global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t* __restrict__ ctl) {
+__global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t factor, uint32_t cap,
+                           uint32_t* __restrict__ ctl) {
     const uint32_t nnz = start[nb], biggest = ctl[1];
-    uint32_t lw = 4 * ((nnz + lanes - 1) / lanes);
-    uint32_t lg = (biggest + 2047) / 2048;
+    uint32_t lw = factor * ((nnz + lanes - 1) / lanes);
+    uint32_t lg = (biggest + cap - 1) / cap;
     uint32_t L = max(max(lw, lg), Lmin);
     ctl[2] = min(L, Lmax);
 }
@@ -653,7 +654,8 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     if (P->L < (n >> 16)) P->L = (uint32_t)(n >> 16);
     // the device may shorten the tasks down to Lmin when the digits turn out sparse / skewed (k_pick_len): the task arrays are sized for that
     static const bool adaptive = !(getenv("ZKMI_ADAPTIVE_L") && atoi(getenv("ZKMI_ADAPTIVE_L")) == 0);
-    P->Lmin = adaptive ? (P->L / 4 > 32 ? P->L / 4 : 32) : P->L;
+    static const uint32_t lmin_div = getenv("ZKMI_L_MIN_DIV") ? (uint32_t)atoi(getenv("ZKMI_L_MIN_DIV")) : 4;  // experiment switch
+    P->Lmin = adaptive ? (P->L / lmin_div > 32 ? P->L / lmin_div : 32) : P->L;
     if (P->Lmin > P->L) P->Lmin = P->L;
     P->max_tasks = (size_t)P->nb + P->total / P->Lmin + 1;
     static const unsigned l1_env = getenv("ZKMI_L1_M") ? (unsigned)atoi(getenv("ZKMI_L1_M")) : 0;  // experiment switch (power of two)
@@ -731,7 +733,9 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     // ---- 4. plan
     ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
     if (P.Lmin < L) ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats, dim3(nb / 4096 ? (nb / 4096 > 512 ? 512 : nb / 4096) : 1), dim3(256), 0, (const uint32_t*)start, nb, bins);
-    ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), bins);
+    static const uint32_t l_factor = getenv("ZKMI_L_FACTOR") ? (uint32_t)atoi(getenv("ZKMI_L_FACTOR")) : 4;     // experiment switches
+    static const uint32_t l_cap = getenv("ZKMI_L_GIANT_CAP") ? (uint32_t)atoi(getenv("ZKMI_L_GIANT_CAP")) : 2048;
+    ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, bins);
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
     {
         if (ctx().profiling) prof_begin(s, st, "msm_task_scan(rocprim)");
