@@ -158,10 +158,27 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ keys, uint32_t tota
 // kernel then is not throughput- but LATENCY-bound by its longest tasks (one lane adds L points one after the other, ~5 us each), so the length shrinks with
 // the work there is -- 4x what would give every resident lane one task -- but never so far that the largest bucket falls into more than 2048 partial sums
 // (one wave folds them, 64 per round).  Uniform inputs keep the host's L.
+// Giant buckets (0 / 1-heavy witnesses put a quarter of all points into ONE bucket): their partial sums are folded by up to 64 waves over segments
+// (k_fold_giant) before k_fold_multi folds the segment heads -- which is what lets the task length drop to 32 for sparse inputs without a serial fold of
+// thousands of partial sums.  ctl layout (the 256-byte header of the bin counters): [0] split buckets, [1] largest bucket, [2] task length, [3] buckets above
+// GIANT_POINTS points, [4] giant buckets listed, [8 .. 8 + GIANT_MAX) their ids.
+constexpr uint32_t GIANT_T = 256;         // partial sums above which a bucket counts as giant
+constexpr uint32_t GIANT_MAX = 48;        // giants listed; any further ones fold serially as before
+constexpr uint32_t GIANT_POINTS = 8192;   // = GIANT_T tasks of the shortest length
+__device__ __forceinline__ uint32_t giant_seg(uint32_t cnt) {  // segment length: a multiple of 64 such that there are at most 64 segments
+    const uint32_t s = ((cnt + 63) / 64 + 63) / 64 * 64;
+    return s < 64 ? 64 : s;
+}
 __global__ __launch_bounds__(256) void k_bucket_stats(const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ ctl) {
     __shared__ uint32_t wmax[4];
     uint32_t len = 0;
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) len = max(len, start[b + 1] - start[b]);
+    uint32_t big = 0;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+        const uint32_t l = start[b + 1] - start[b];
+        len = max(len, l);
+        big += l > GIANT_POINTS ? 1u : 0u;
+    }
+    if (big) atomicAdd(&ctl[3], big);
     for (int d = 32; d > 0; d >>= 1) len = max(len, (uint32_t)__shfl_down((int)len, d, 64));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = len;
     __syncthreads();
@@ -173,7 +190,10 @@ __global__ __launch_bounds__(256) void k_bucket_stats(const uint32_t* __restrict
 __global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t factor, uint32_t cap,
                            uint32_t* __restrict__ ctl) {
     const uint32_t nnz = start[nb], biggest = ctl[1];
-    uint32_t lw = factor * ((nnz + lanes - 1) / lanes);
+    const uint32_t q = (nnz + lanes - 1) / lanes;
+    uint32_t lw = factor * q;
+    if (2 * lw < Lmax) lw = (factor / 2 ? factor / 2 : 1) * q;  // sparse digits: the accumulate kernel is latency-bound -- go shorter still
+    if (ctl[3] > GIANT_MAX) cap = cap > 2048 ? 2048 : cap;       // more giants than k_fold_giant takes: keep their serial folds short
     uint32_t lg = (biggest + cap - 1) / cap;
     uint32_t L = max(max(lw, lg), Lmin);
     ctl[2] = min(L, Lmax);
@@ -187,6 +207,10 @@ __global__ void k_task_plan(const uint32_t* start, uint32_t nb, const uint32_t* 
     uint32_t t = (cnt + L - 1) / L;
     ntasks[b] = t;
     if (t > 1) multi_list[atomicAdd(num_multi, 1u)] = b;
+    if (t > GIANT_T) {
+        const uint32_t gi = atomicAdd(&num_multi[4], 1u);
+        if (gi < GIANT_MAX) num_multi[8 + gi] = b;
+    }
 }
 
 // One record per task (thread t < total tasks): where its points start in the sorted array, and a sort key that orders
@@ -446,6 +470,29 @@ struct TailPt<Fp2> {
 // population under a narrow top window), so the butterfly only runs the levels the count needs: 2 additions for 3 partials instead of 6.
 // (Measured and rejected, round 2: giant buckets -- 0/1-heavy witnesses -- folded by up to 64 waves in segments + a second launch over the segment
 // heads: the 64x larger grid costs more than the serial rounds it saves; PLONK 2^22 87.6 -> 90.9 ms.)
+// first pass over the listed giant buckets: wave `seg` of giant `gi` folds its segment of the bucket's partial sums into the segment's first slot
+template <class F>
+__global__ __launch_bounds__(256) void k_fold_giant(XYZZ<F>* partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ctl) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t gi = blockIdx.x / 16, seg = (blockIdx.x % 16) * 4 + wave;
+    const uint32_t ng = min(ctl[4], GIANT_MAX);
+    if (gi >= ng) return;
+    const uint32_t b = ctl[8 + gi];
+    const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+    const uint32_t S = giant_seg(t1 - t0);
+    const uint32_t lo = t0 + seg * S, hi = min(lo + S, t1);
+    if (lo >= t1 || hi - lo < 2) return;  // nothing, or a single partial sum: it already sits in the segment's first slot
+    TailPt<F> acc = TailPt<F>::inf();
+    for (uint32_t t = lo + lane; t < hi; t += 64) acc.add(TailPt<F>::load(partial + t));
+    const uint32_t cnt = min(hi - lo, 64u);
+    unsigned first = 32;
+    while (first >= cnt && first > 0) first >>= 1;
+    for (unsigned d = first; d > 0; d >>= 1) {
+        TailPt<F> o = acc.shfl_down(d);
+        if (lane < d) acc.add(o);
+    }
+    if (lane == 0) acc.store(partial + lo);
+}
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list,
                                                     const uint32_t* num_multi) {
@@ -455,8 +502,20 @@ __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint
         uint32_t b = multi_list[m];
         uint32_t t0 = task_off[b], t1 = task_off[b + 1];
         TailPt<F> acc = TailPt<F>::inf();
-        for (uint32_t t = t0 + lane; t < t1; t += 64) acc.add(TailPt<F>::load(partial + t));
-        const uint32_t cnt = min(t1 - t0, 64u);  // lanes that hold something (uniform over the wave)
+        uint32_t nheld = t1 - t0;  // partial sums this wave folds
+        bool listed = false;
+        if (nheld > GIANT_T) {  // a giant that k_fold_giant has reduced to its segment heads?
+            const uint32_t ng = min(num_multi[4], GIANT_MAX);
+            listed = __ballot(lane < ng && num_multi[8 + lane] == b) != 0;
+        }
+        if (listed) {
+            const uint32_t S = giant_seg(nheld);
+            nheld = (nheld + S - 1) / S;  // <= 64 heads
+            if (lane < nheld) acc = TailPt<F>::load(partial + t0 + lane * S);
+        } else {
+            for (uint32_t t = t0 + lane; t < t1; t += 64) acc.add(TailPt<F>::load(partial + t));
+        }
+        const uint32_t cnt = min(nheld, 64u);  // lanes that hold something (uniform over the wave)
         unsigned first = 32;
         while (first >= cnt && first > 0) first >>= 1;  // largest power of two below cnt
         for (unsigned d = first; d > 0; d >>= 1) {
@@ -654,7 +713,7 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     if (P->L < (n >> 16)) P->L = (uint32_t)(n >> 16);
     // the device may shorten the tasks down to Lmin when the digits turn out sparse / skewed (k_pick_len): the task arrays are sized for that
     static const bool adaptive = !(getenv("ZKMI_ADAPTIVE_L") && atoi(getenv("ZKMI_ADAPTIVE_L")) == 0);
-    static const uint32_t lmin_div = getenv("ZKMI_L_MIN_DIV") ? (uint32_t)atoi(getenv("ZKMI_L_MIN_DIV")) : 4;  // experiment switch
+    static const uint32_t lmin_div = getenv("ZKMI_L_MIN_DIV") ? (uint32_t)atoi(getenv("ZKMI_L_MIN_DIV")) : 8;  // experiment switch
     P->Lmin = adaptive ? (P->L / lmin_div > 32 ? P->L / lmin_div : 32) : P->L;
     if (P->Lmin > P->L) P->Lmin = P->L;
     P->max_tasks = (size_t)P->nb + P->total / P->Lmin + 1;
@@ -734,7 +793,7 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
     if (P.Lmin < L) ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats, dim3(nb / 4096 ? (nb / 4096 > 512 ? 512 : nb / 4096) : 1), dim3(256), 0, (const uint32_t*)start, nb, bins);
     static const uint32_t l_factor = getenv("ZKMI_L_FACTOR") ? (uint32_t)atoi(getenv("ZKMI_L_FACTOR")) : 4;     // experiment switches
-    static const uint32_t l_cap = getenv("ZKMI_L_GIANT_CAP") ? (uint32_t)atoi(getenv("ZKMI_L_GIANT_CAP")) : 2048;
+    static const uint32_t l_cap = getenv("ZKMI_L_GIANT_CAP") ? (uint32_t)atoi(getenv("ZKMI_L_GIANT_CAP")) : 16384;
     ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, bins);
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
     {
@@ -826,6 +885,7 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     for (int b = 0; b < nb; b++) {
         Slot* s = sl[b];
         hipStream_t st = sts[b];
+        ZK_LAUNCH(s, st, "msm_fold_giant", (k_fold_giant<F>), dim3(GIANT_MAX * 16), dim3(256), 0, partial[b], R.task_off, (const uint32_t*)R.num_multi);  // exits at once without giants
         ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
         // ---- 6. bucket reduce
         bool quad = false;

@@ -184,6 +184,35 @@ def test_g1_msm_collisions_and_cancellation():
     assert (orc.g1_msm(pts2, sc2) == 0).all()
 
 
+@pytest.mark.parametrize("kind", ["all_ones", "sixty_values", "hundreds_of_values", "half_ones_half_uniform", "one_and_minus_one"])
+def test_msm_giant_buckets_plain_and_table_paths(kind):
+    """Extremely skewed scalars -- what makes buckets of tens of thousands of points: the device then shortens the tasks and folds the giant buckets'
+    partial sums with many waves over segments (k_pick_len, k_fold_giant); more giants than the list holds fall back to the serial fold.  Plain MSM and
+    the window-table path (one bucket set for all windows), G1 at 2^17 and G2 at 2^14 points, against the oracle."""
+    n = 1 << 17
+    g = ref.SplitMix64(0x61A7)
+    if kind == "all_ones":
+        vals = [1] * n
+    elif kind == "sixty_values":            # 60 giant buckets in the lowest window: more than the giant list's 48 entries
+        vals = [1 + int(g.next() % 60) for _ in range(n)]
+    elif kind == "hundreds_of_values":      # ~400 buckets of ~330 points: split buckets, no giants
+        vals = [1 + int(g.next() % 400) for _ in range(n)]
+    elif kind == "half_ones_half_uniform":
+        vals = [1 if i & 1 else g.felt() for i in range(n)]
+    else:                                   # 1 and r - 1: two giant buckets with opposite signs in every window of the signed recoding
+        vals = [1 if g.next() & 1 else ref.R - 1 for _ in range(n)]
+    sc = mont_limbs(vals)
+    pts = orc.g1_gen_points(0x900 + len(kind), n)
+    want = orc.g1_msm(pts, sc)
+    assert (zk.g1_multi_exp(pts, sc, config=MONT) == want).all(), kind
+    rb = zb.ResidentBases(pts)              # window tables: every window feeds one bucket set
+    assert (rb.multi_exp(sc, config=MONT) == want).all(), kind
+    rb.free()
+    m = 1 << 14
+    p2 = orc.g2_gen_points(0x910 + len(kind), m)
+    assert (zk.g2_multi_exp(p2, sc[:m], config=MONT) == orc.g2_msm(p2, sc[:m])).all(), kind
+
+
 @pytest.mark.parametrize("n,witness", [(1, False), (500, False), (5000, True), (1 << 14, False)])
 def test_g2_msm_vs_oracle(n, witness):
     pts, sc = orc.g2_gen_points(31, n), orc.rand_fr(32, n, witness_like=witness)
