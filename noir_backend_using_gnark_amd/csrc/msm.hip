@@ -468,8 +468,8 @@ struct TailPt<Fp2> {
 
 // buckets cut into several tasks: one WAVE folds the bucket's partials into the first one.  Most split buckets have 2 - 4 partials (the dense
 // population under a narrow top window), so the butterfly only runs the levels the count needs: 2 additions for 3 partials instead of 6.
-// (Measured and rejected, round 2: giant buckets -- 0/1-heavy witnesses -- folded by up to 64 waves in segments + a second launch over the segment
-// heads: the 64x larger grid costs more than the serial rounds it saves; PLONK 2^22 87.6 -> 90.9 ms.)
+// (Measured earlier in round 2: EVERY split bucket folded by up to 64 waves in segments + a second launch over the segment heads -- the 64x larger grid costs
+// more than the serial rounds it saves, PLONK 2^22 87.6 -> 90.9 ms.  What runs now is the targeted form: only the listed giants, a fixed grid of 768 workgroups.)
 // first pass over the listed giant buckets: wave `seg` of giant `gi` folds its segment of the bucket's partial sums into the segment's first slot
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_giant(XYZZ<F>* partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ctl) {
