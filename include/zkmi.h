@@ -310,6 +310,8 @@ int zk_bn254_plonk_pk_free(uint64_t pk_handle);
 int zk_bn254_plonk_pk_read(const void *data, size_t len, int is_hex, size_t n_vars, size_t n_constraints, const uint32_t *xa,
                            const uint32_t *xb, const uint32_t *xc, uint64_t srs_handle, uint64_t *pk_handle);
 int zk_bn254_plonk_pk_write(uint64_t pk_handle, int as_hex, void *out, size_t cap, size_t *out_len);
+/* Shape of a resident key (any out pointer may be NULL): Domain[0].Cardinality, NbPublicVariables, number of gates, number of variables. */
+int zk_bn254_plonk_pk_info(uint64_t pk_handle, size_t *domain_size, size_t *n_public, size_t *n_constraints, size_t *n_vars);
 /* Canonical polynomials of a resident key, for inspection: which = 0..8 -> Ql, Qr, Qm, Qo, CQk, S1, S2, S3 (canonical), LQk; n entries. */
 int zk_bn254_plonk_pk_export(uint64_t pk_handle, int which, zk_fr *out_host, size_t n);
 enum { ZK_PLONK_PROOF_BYTES = 548 }; /* Proof.WriteTo: 7 x 32 B digests | 32 B + u32 count + 7 x 32 B | 32 B + 32 B */
@@ -330,18 +332,29 @@ int zk_bn254_plonk_synth_qk_dev(void *d_qk, const void *d_ql, const void *d_qr, 
  * values as the hex felt vector (internal/backend/helpers.go:24-33) and the key as hex of ProvingKey.WriteTo (helpers.go:49-60, 82-87); the
  * lowering is BuildSparseR1CS / HandleValues (backend/plonk/sparse_r1cs.go:18-107, backend/common.go:45-76).  Differences: the SRS is a
  * resident handle instead of srs.hex re-read per call; errors are codes instead of log.Fatal; outputs go to caller buffers (no terminator);
- * the blinding scalars can be pinned (NULL = /dev/urandom); every witness is one variable (common.go:59-68's duplicates are not reproduced).
+ * the blinding scalars can be pinned (NULL = /dev/urandom).
+ * layout: how witnesses become constraint-system variables --
+ *   ZK_ACIR_LAYOUT_REFERENCE             HandleValues exactly as written (backend/common.go:45-76): public variables in witness order, then one
+ *                                        SECRET variable per (witness, non-matching public input) when there are public inputs -- so with |P| >= 2
+ *                                        public inputs a private witness has |P| variables, a public one |P| - 1 secret copies besides its public
+ *                                        variable -- and the gates name the LAST variable added for a witness (indexMap, last write wins); a term
+ *                                        that names a witness without a variable gets variable 0 (Go's map zero value).  Keys and proofs made this
+ *                                        way are the reference's own; libgnark_backend.so uses it.
+ *   ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS   public witnesses first, then the others, one variable each; unknown witnesses are an error.  Identical to
+ *                                        the reference layout for zero or one public input.
  *   zk_plonk_preprocess: pk_hex_out == NULL only returns the sizes in *pk_len / *vk_len; pk_handle (optional) keeps the key resident.
- *   zk_plonk_prove_with_pk: pk_hex == NULL uses the resident key pk_handle (the reference deserialises the key on every call). */
-int zk_plonk_preprocess(const char *acir_json, size_t acir_len, const char *values_hex, size_t values_len, uint64_t srs_handle,
-                        char *pk_hex_out, size_t pk_cap, size_t *pk_len, char *vk_hex_out, size_t vk_cap, size_t *vk_len,
-                        uint64_t *pk_handle);
-int zk_plonk_prove_with_pk(const char *acir_json, size_t acir_len, const char *values_hex, size_t values_len, const char *pk_hex,
-                           size_t pk_len, uint64_t pk_handle, uint64_t srs_handle, const zk_fr *blinders,
+ *   zk_plonk_prove_with_pk: pk_hex == NULL uses the resident key pk_handle (the reference deserialises the key on every call); ZK_ERR_ARG when the
+ *                           key's public / variable / gate counts are not the circuit's. */
+enum { ZK_ACIR_LAYOUT_REFERENCE = 0, ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS = 1 };
+int zk_plonk_preprocess(const char *acir_json, size_t acir_len, const char *values_hex, size_t values_len, int layout,
+                        uint64_t srs_handle, char *pk_hex_out, size_t pk_cap, size_t *pk_len, char *vk_hex_out, size_t vk_cap,
+                        size_t *vk_len, uint64_t *pk_handle);
+int zk_plonk_prove_with_pk(const char *acir_json, size_t acir_len, const char *values_hex, size_t values_len, int layout,
+                           const char *pk_hex, size_t pk_len, uint64_t pk_handle, uint64_t srs_handle, const zk_fr *blinders,
                            char proof_hex_out[2 * ZK_PLONK_PROOF_BYTES]);
 /* BuildSparseR1CS alone: the gates of an ACIR circuit (Montgomery coefficients, variable ids with the public variables first) and the
  * witness order (variable k holds witness order[k] + 1).  Array pointers may be NULL (first call sizes them through *n_constraints / *n_vars). */
-int zk_acir_to_sparse_r1cs(const char *acir_json, size_t acir_len, size_t n_values, size_t *n_public, size_t *n_vars,
+int zk_acir_to_sparse_r1cs(const char *acir_json, size_t acir_len, size_t n_values, int layout, size_t *n_public, size_t *n_vars,
                            size_t *n_constraints, zk_fr *ql, zk_fr *qr, zk_fr *qo, zk_fr *qm, zk_fr *qk, uint32_t *xa, uint32_t *xb,
                            uint32_t *xc, uint32_t *order);
 

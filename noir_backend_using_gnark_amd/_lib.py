@@ -7,6 +7,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+# Measurement tooling only (tools/, bench.py --experiments): ZKMI_USE_EXPERIMENTS_LIB=1 loads libzkmi_exp.so, the build with the A/B switches of
+# DESIGN.md compiled in (`make -C csrc EXPERIMENTS=1`).  The product library itself reads no experiment variable (csrc/ctx.hpp).
+if os.environ.get("ZKMI_USE_EXPERIMENTS_LIB") == "1":
+    LIB_PATH = os.path.join(_HERE, "libzkmi_exp.so")
 
 ZK_OK, ZK_ERR_LEN, ZK_ERR_NB_TASKS, ZK_ERR_NO_DEVICE, ZK_ERR_HIP, ZK_ERR_ARG, ZK_ERR_HANDLE, ZK_ERR_BUSY = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -69,7 +73,7 @@ SYMBOLS = [
     "zk_bn254_r1cs_load", "zk_bn254_r1cs_free", "zk_bn254_r1cs_eval_abc_dev", "zk_bn254_groth16_setup", "zk_bn254_groth16_prove_r1cs",
     "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_pk_abort", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
     "zk_bn254_plonk_setup", "zk_bn254_plonk_pk_load", "zk_bn254_plonk_pk_free", "zk_bn254_plonk_pk_export", "zk_bn254_plonk_pk_read", "zk_bn254_plonk_pk_write", "zk_bn254_plonk_prove", "zk_bn254_plonk_synth_qk_dev",
-    "zk_plonk_preprocess", "zk_plonk_prove_with_pk", "zk_acir_to_sparse_r1cs", "zk_groth16_r1cs_from_raw",
+    "zk_plonk_preprocess", "zk_plonk_prove_with_pk", "zk_bn254_plonk_pk_info", "zk_acir_to_sparse_r1cs", "zk_groth16_r1cs_from_raw",
     "zk_groth16_preprocess", "zk_groth16_prove_with_pk", "zk_groth16_prove_with_meta",
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev", "zk_bn254_kzg_new_srs_dev", "zk_bn254_kzg_srs_read", "zk_bn254_kzg_srs_write",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",

@@ -58,10 +58,10 @@ static int init_locked(int device) {
 // Experiment: a pair of CU-masked streams per slot.  ZKMI_CU_SPLIT=k gives the scalar preparation (digits, sort, plan: bandwidth-bound, needs wave slots to
 // make progress) k CUs of its own -- bits i with i % (256 / k) == 0 of the CU mask -- and the accumulate kernels the others.
 int masked_streams(Slot* s) {
-    static const int k = getenv("ZKMI_CU_SPLIT") ? atoi(getenv("ZKMI_CU_SPLIT")) : 0;
+    static const int k = ZK_EXP("ZKMI_CU_SPLIT", 0);
     if (k <= 0 || s->stream_prep) return ZK_OK;
     const int ncu = ctx().num_cus, words = (ncu + 31) / 32;
-    static const int mode = getenv("ZKMI_CU_SPLIT_MODE") ? atoi(getenv("ZKMI_CU_SPLIT_MODE")) : 0;  // 0: every (ncu/k)-th bit; 1: the first k bits
+    static const int mode = ZK_EXP("ZKMI_CU_SPLIT_MODE", 0);  // 0: every (ncu/k)-th bit; 1: the first k bits
     std::vector<uint32_t> mp(words, 0), ma(words, 0);
     const int step = ncu / k > 0 ? ncu / k : 1;
     for (int i = 0; i < ncu; i++) {
@@ -88,7 +88,7 @@ int ensure_init() {
 // A caller that already holds slots (an msm5 session pins 5 of the 8) and asks for more than are left would wait forever:
 // waiting is bounded (ZKMI_SLOT_TIMEOUT_S, default 120 s) and ends in ZK_ERR_BUSY instead of a silent hang.
 static double slot_timeout_s() {
-    static const double t = getenv("ZKMI_SLOT_TIMEOUT_S") ? atof(getenv("ZKMI_SLOT_TIMEOUT_S")) : 120.0;
+    static const double t = (double)zk_env_bounded("ZKMI_SLOT_TIMEOUT_S", 120, 1, 86400);  // whole seconds, 1 s .. 1 day
     return t;
 }
 static bool slot_wait_expired(const std::chrono::steady_clock::time_point& t0) {

@@ -13,6 +13,31 @@
 
 #include "../../include/zkmi.h"
 
+// ---- environment variables ---------------------------------------------------------------------------------------------------------
+// The shipped library is loaded into the prover's process (nargo, through libgnark_backend.so): nothing a stray environment variable says may change a
+// result or crash it.  It reads exactly two variables, both validated and neither able to affect a result: ZKMI_TABLE_CAP_GB (groth16.hip: upper bound of
+// the window tables of a resident key) and ZKMI_SLOT_TIMEOUT_S (ctx.hip).  Every A/B switch of the measurements in DESIGN.md is a ZK_EXP(name, default):
+// the default, as a constant, unless the library is built with -DZKMI_EXPERIMENTS (`make EXPERIMENTS=1` -> libzkmi_exp.so, never shipped), where the
+// variable is read.  tests/test_cabi_cpu.py asserts that libzkmi.so contains no other ZKMI_* string.
+#ifdef ZKMI_EXPERIMENTS
+#include <stdlib.h>
+static inline long zk_exp_env(const char* name, long dflt) {
+    const char* v = getenv(name);
+    return v && *v ? strtol(v, nullptr, 0) : dflt;
+}
+#define ZK_EXP(name, dflt) zk_exp_env(name, (long)(dflt))
+#else
+#define ZK_EXP(name, dflt) (dflt)
+#endif
+// a validated setting: an integer in [lo, hi], anything else (unset, not a number, out of range) is the default
+static inline long zk_env_bounded(const char* name, long dflt, long lo, long hi) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    char* e = nullptr;
+    const long x = strtol(v, &e, 10);
+    return (e && *e == 0 && x >= lo && x <= hi) ? x : dflt;
+}
+
 namespace zkmi {
 
 extern thread_local std::string g_err;

@@ -12,8 +12,10 @@
 //     Serialize / DeserializeProvingKey, VerifyingKey internal/backend/helpers.go:49-94 (plonk.hip / keyio.hip, on the device)
 // Differences, on purpose: the SRS is a handle the caller keeps resident (the reference re-reads srs.hex on every call, plonk.go:16,34,58);
 // failures are error codes (the reference log.Fatal()s); the nine blinding scalars can be pinned (NULL: drawn from the OS generator like
-// upstream's fr.SetRandom); with two or more public inputs every witness becomes ONE variable (the reference's HandleValues appends a secret
-// variable once per non-matching public input, common.go:59-68 -- an upstream bug that is not reproduced).
+// upstream's fr.SetRandom).  Variable layout: ZK_ACIR_LAYOUT_REFERENCE (the default, what libgnark_backend.so uses) reproduces HandleValues
+// literally -- with two or more public inputs it appends one secret variable per (witness, non-matching public input) and the gates use the
+// LAST copy (common.go:59-68), so keys and proofs are interchangeable with the reference's; ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS is the layout
+// without the duplicates (the two coincide for zero or one public input).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -119,9 +121,10 @@ struct JParser {
             }
         }
         if (*p == '"') { v->kind = JVal::STR; return str(&v->str); }
-        if (!strncmp(p, "true", 4) && end - p >= 4) { v->kind = JVal::BOOL; v->b = true; p += 4; return true; }
-        if (!strncmp(p, "false", 5) && end - p >= 5) { v->kind = JVal::BOOL; p += 5; return true; }
-        if (!strncmp(p, "null", 4) && end - p >= 4) { p += 4; return true; }
+        // the length test comes first: the text is a GoString payload, not NUL-terminated
+        if (end - p >= 4 && !memcmp(p, "true", 4)) { v->kind = JVal::BOOL; v->b = true; p += 4; return true; }
+        if (end - p >= 5 && !memcmp(p, "false", 5)) { v->kind = JVal::BOOL; p += 5; return true; }
+        if (end - p >= 4 && !memcmp(p, "null", 4)) { p += 4; return true; }
         char* e = nullptr;
         std::string tmp(p, (size_t)(end - p) < 40 ? end : p + 40);
         v->num = strtod(tmp.c_str(), &e);
@@ -169,7 +172,8 @@ static bool as_index(const JVal& v, uint32_t* out) {
 }
 
 // BuildSparseR1CS (sparse_r1cs.go:18-107) + HandleValues (common.go:45-76).  n_values = number of witness values handed over (witnesses 1..n).
-static int lower_acir(const char* json, size_t len, size_t n_values, Gates* G) {
+static int lower_acir(const char* json, size_t len, size_t n_values, int layout, Gates* G) {
+    if (layout != ZK_ACIR_LAYOUT_REFERENCE && layout != ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS) return set_err(ZK_ERR_ARG, "unknown ACIR variable layout %d", layout);
     JParser P{json, json + len, ""};
     JVal root;
     if (!P.value(&root) || root.kind != JVal::OBJ) return set_err(ZK_ERR_ARG, "ACIR JSON: %s", P.err.empty() ? "not an object" : P.err.c_str());
@@ -183,21 +187,56 @@ static int lower_acir(const char* json, size_t len, size_t n_values, Gates* G) {
             if (!as_index(e, &w)) return set_err(ZK_ERR_ARG, "ACIR JSON: bad public input");
             pub.push_back(w);
         }
-    // variables: public witnesses first (in witness order), then the others; index[w] = variable of witness w (1-based)
+    // index[w] = variable of witness w (1-based); -1 = none
     std::vector<int64_t> index(n_values + 1, -1);
-    std::vector<bool> is_pub(n_values + 1, false);
-    for (uint32_t w : pub)
-        if (w >= 1 && w <= n_values) is_pub[w] = true;
     G->order.clear();
-    for (size_t w = 1; w <= n_values; w++)
-        if (is_pub[w]) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
-    G->n_public = G->order.size();
-    for (size_t w = 1; w <= n_values; w++)
-        if (!is_pub[w]) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
+    const bool exact = layout == ZK_ACIR_LAYOUT_REFERENCE;
+    if (exact) {
+        // HandleValues, literally (common.go:45-76).  Loop 1: one public variable per (witness, matching public input), in witness order.  Loop 2: with
+        // public inputs, one SECRET variable per (witness, NON-matching public input) -- i.e. |P| copies of a private witness, |P| - 1 copies of a public
+        // one -- and indexMap keeps the last index assigned, so that with |P| >= 2 every gate names a secret copy; without public inputs one secret
+        // variable per witness.  cs.AddPublicVariable / AddSecretVariable number the variables public first, then secret, in the order of the calls.
+        const size_t k = pub.size();
+        size_t n_sec = 0;
+        for (size_t w = 1; w <= n_values; w++) {
+            size_t same = 0;
+            for (uint32_t p : pub) same += p == w;
+            n_sec += k ? k - same : 1;
+        }
+        if (n_sec + n_values * k >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "HandleValues: %zu witnesses x %zu public inputs make too many variables", n_values, k);
+        for (size_t w = 1; w <= n_values; w++)
+            for (uint32_t p : pub)
+                if (p == w) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
+        G->n_public = G->order.size();
+        for (size_t w = 1; w <= n_values; w++) {
+            if (k) {
+                for (uint32_t p : pub)
+                    if (p != w) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
+            } else {
+                index[w] = (int64_t)G->order.size();
+                G->order.push_back((uint32_t)(w - 1));
+            }
+        }
+    } else {
+        // one variable per witness: public witnesses first (in witness order), then the others
+        std::vector<bool> is_pub(n_values + 1, false);
+        for (uint32_t w : pub)
+            if (w >= 1 && w <= n_values) is_pub[w] = true;
+        for (size_t w = 1; w <= n_values; w++)
+            if (is_pub[w]) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
+        G->n_public = G->order.size();
+        for (size_t w = 1; w <= n_values; w++)
+            if (!is_pub[w]) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
+    }
     G->n_vars = G->order.size();
     auto var_of = [&](const JVal& v, uint32_t* out) -> bool {
         uint32_t w;
-        if (!as_index(v, &w) || w < 1 || w > n_values) return false;  // the reference's map lookup would silently yield variable 0
+        if (!as_index(v, &w)) return false;
+        if (w < 1 || w > n_values || index[w] < 0) {
+            if (!exact) return false;
+            *out = 0;  // the reference's map lookup of a witness that has no variable yields the zero value: variable 0 (sparse_r1cs.go:53-54)
+            return true;
+        }
         *out = (uint32_t)index[w];
         return true;
     };
@@ -270,14 +309,14 @@ extern "C" {
 // PlonkPreprocess (main.go:58-78): ACIR + the witness-value vector (only its length and the public/secret split matter to Setup) -> hex of
 // ProvingKey.WriteTo and hex of VerifyingKey.WriteTo (= the first 368 bytes of the former).  pk_hex_out may be NULL with pk_cap = 0 to query
 // the sizes.  The key also stays resident: *pk_handle (optional) can be handed to zk_bn254_plonk_prove directly.
-int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, uint64_t srs_handle, char* pk_hex_out, size_t pk_cap,
-                        size_t* pk_len, char* vk_hex_out, size_t vk_cap, size_t* vk_len, uint64_t* pk_handle) {
+int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, uint64_t srs_handle, char* pk_hex_out,
+                        size_t pk_cap, size_t* pk_len, char* vk_hex_out, size_t vk_cap, size_t* vk_len, uint64_t* pk_handle) {
     if (!acir_json || !values_hex || !pk_len || !vk_len) return set_err(ZK_ERR_ARG, "null pointer");
     size_t n_values = 0;
     ZK_TRY(count_from_hex(values_hex, values_len, &n_values));
     if (values_len != 8 + 64 * n_values) return set_err(ZK_ERR_LEN, "felt vector: %zu characters, the count says %zu felts", values_len, n_values);
     Gates G;
-    ZK_TRY(lower_acir(acir_json, acir_len, n_values, &G));
+    ZK_TRY(lower_acir(acir_json, acir_len, n_values, layout, &G));
     // sizes first (a call with pk_hex_out == NULL only asks for them): domain n = next power of two >= gates + public inputs
     size_t n = 1;
     while (n < G.xa.size() + G.n_public) n <<= 1;
@@ -299,13 +338,13 @@ int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* valu
 // PlonkProveWithPK (main.go:24-37): ACIR + hex witness values + hex proving key -> hex of Proof.WriteTo (2 * 548 characters, no terminator).
 // pk_hex may be NULL when pk_handle names a resident key (zk_plonk_preprocess / zk_bn254_plonk_pk_read) -- the reference deserialises the
 // key on every call.  blinders: 9 scalars or NULL (drawn from /dev/urandom, as upstream draws them with fr.SetRandom).
-int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, const char* pk_hex, size_t pk_len, uint64_t pk_handle,
-                           uint64_t srs_handle, const zk_fr* blinders, char proof_hex_out[2 * ZK_PLONK_PROOF_BYTES]) {
+int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, const char* pk_hex, size_t pk_len,
+                           uint64_t pk_handle, uint64_t srs_handle, const zk_fr* blinders, char proof_hex_out[2 * ZK_PLONK_PROOF_BYTES]) {
     if (!acir_json || !values_hex || !proof_hex_out || (!pk_hex && !pk_handle)) return set_err(ZK_ERR_ARG, "null pointer");
     size_t n_values = 0;
     ZK_TRY(count_from_hex(values_hex, values_len, &n_values));
     Gates G;
-    ZK_TRY(lower_acir(acir_json, acir_len, n_values, &G));
+    ZK_TRY(lower_acir(acir_json, acir_len, n_values, layout, &G));
     ZK_TRY(ensure_init());
     // witness values: DeserializeFelts on the device, then the public-first gather (BuildWitnesses)
     void *d_vals = nullptr, *d_sol = nullptr, *d_order = nullptr;
@@ -327,6 +366,16 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
     }
     uint64_t h = pk_handle;
     if (pk_hex) ZK_TRY(zk_bn254_plonk_pk_read(pk_hex, pk_len, 1, G.n_vars, G.xa.size(), G.xa.data(), G.xb.data(), G.xc.data(), srs_handle, &h));
+    {   // the key must be the key of THIS circuit: same public / variable / gate counts (a key of another shape would read the solution out of bounds)
+        size_t kp = 0, kv = 0, kc = 0;
+        int rc = zk_bn254_plonk_pk_info(h, nullptr, &kp, &kc, &kv);
+        if (rc == ZK_OK && (kp != G.n_public || kv != G.n_vars || kc != G.xa.size()))
+            rc = set_err(ZK_ERR_ARG, "proving key is for %zu public / %zu variables / %zu gates, the circuit has %zu / %zu / %zu", kp, kv, kc, G.n_public, G.n_vars, G.xa.size());
+        if (rc != ZK_OK) {
+            if (pk_hex) (void)zk_bn254_plonk_pk_free(h);
+            return rc;
+        }
+    }
     zk_fr rnd[9];
     if (!blinders) {
         FILE* f = fopen("/dev/urandom", "rb");
@@ -580,11 +629,11 @@ int zk_groth16_prove_with_meta(const char* raw_json, size_t raw_len, const zk_fr
 
 // The lowering alone, for inspection / tests: gates of an ACIR circuit as the reference's BuildSparseR1CS emits them.  Any out pointer may be
 // NULL; arrays need *n_constraints (first call with NULL arrays to size them) entries; coefficients come back as Montgomery fr.Elements.
-int zk_acir_to_sparse_r1cs(const char* acir_json, size_t acir_len, size_t n_values, size_t* n_public, size_t* n_vars, size_t* n_constraints, zk_fr* ql, zk_fr* qr,
-                           zk_fr* qo, zk_fr* qm, zk_fr* qk, uint32_t* xa, uint32_t* xb, uint32_t* xc, uint32_t* order) {
+int zk_acir_to_sparse_r1cs(const char* acir_json, size_t acir_len, size_t n_values, int layout, size_t* n_public, size_t* n_vars, size_t* n_constraints, zk_fr* ql,
+                           zk_fr* qr, zk_fr* qo, zk_fr* qm, zk_fr* qk, uint32_t* xa, uint32_t* xb, uint32_t* xc, uint32_t* order) {
     if (!acir_json) return set_err(ZK_ERR_ARG, "null pointer");
     Gates G;
-    ZK_TRY(lower_acir(acir_json, acir_len, n_values, &G));
+    ZK_TRY(lower_acir(acir_json, acir_len, n_values, layout, &G));
     if (n_public) *n_public = G.n_public;
     if (n_vars) *n_vars = G.n_vars;
     if (n_constraints) *n_constraints = G.xa.size();

@@ -13,13 +13,16 @@
 // Differences kept from libzkmi's own entry points (zk_plonk_*, zk_groth16_*): errors end the process with the message on stderr, as the reference's
 // log.Fatal does; the SRS of backend/common.go:78-144 (hex(kzg.SRS.WriteTo) at <user config dir>/noir-lang/srs.hex, created with a random alpha and
 // 1,000,000 points when missing) is read ONCE per process and kept resident instead of being re-read on every call (plonk.go:16,34,58).
-// ZKMI_SRS_SIZE overrides the size of a newly created SRS (tests).  Plain C++ on the C ABI: no HIP in this file.
+// ZKMI_SRS_SIZE overrides the size of a newly created SRS (tests; validated: 4 .. 2^28).  Plain C++ on the C ABI: no HIP in this file.
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/file.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <mutex>
 #include <string>
@@ -105,10 +108,25 @@ std::string srs_path() {  // os.UserConfigDir() on Linux: $XDG_CONFIG_HOME, else
     }
     return dir + "/noir-lang/srs.hex";
 }
+// Text that hex.DecodeString accepts (LoadSRS: common.go:96-99): only then does the reference keep the file.
+bool is_hex_text(const std::string& t) {
+    if (t.empty() || (t.size() & 1)) return false;
+    for (unsigned char c : t)
+        if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F'))) return false;
+    return true;
+}
 void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
     std::lock_guard<std::mutex> lk(g_srs.mu);
     if (!g_srs.ready) {
         const std::string path = srs_path();
+        const std::string dir = path.substr(0, path.rfind('/'));
+        (void)mkdir(dir.substr(0, dir.rfind('/')).c_str(), 0755);
+        (void)mkdir(dir.c_str(), 0755);
+        // One process at a time decides between "load" and "generate + save": two first calls racing (the tests start workers side by side) would
+        // otherwise draw two alphas, and whichever file survives invalidates the keys the other process hands out.
+        const int lock_fd = open((path + ".lock").c_str(), O_CREAT | O_RDWR, 0644);
+        if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
+        struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); } } } unlock{lock_fd};
         std::string text;
         if (FILE* f = fopen(path.c_str(), "rb")) {
             char buf[1 << 16];
@@ -116,10 +134,13 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
             while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k);
             fclose(f);
         }
-        size_t n = 0;
-        // LoadSRS: a missing file, a decoding error or a malformed SRS all mean "generate a new one" upstream (common.go:128-141: any err of LoadSRS)
-        const bool loaded = !text.empty() && zk_bn254_kzg_srs_read(text.data(), text.size(), 1, 0, &g_srs.handle, &n, g_srs.g2) == ZK_OK;
-        if (!loaded) {
+        // LoadSRS fails -- and TryLoadSRS generates a new SRS -- exactly when the file cannot be read or is not hex (common.go:92-99, 129-141); it ignores what
+        // ReadFrom makes of the bytes.  Here a file that IS hex is never replaced: a malformed SRS in it, or a device / memory failure while decoding it,
+        // ends the process and leaves the file (and every key issued against it) alone.
+        if (is_hex_text(text)) {
+            size_t n = 0;
+            must(zk_bn254_kzg_srs_read(text.data(), text.size(), 1, 0, &g_srs.handle, &n, g_srs.g2), "LoadSRS");
+        } else {
             uint64_t a[4];
             FILE* r = fopen("/dev/urandom", "rb");
             if (!r || fread(a, 1, 32, r) != 32) { fprintf(stderr, "no randomness source\n"); exit(1); }
@@ -128,24 +149,28 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
             zk_fr alpha;                    // bits read AS a Montgomery image are as good a secret as 252 random bits read as a value
             memcpy(&alpha, a, 32);
             const char* sz = getenv("ZKMI_SRS_SIZE");
-            const size_t size = sz && atol(sz) > 0 ? (size_t)atol(sz) : 1000000;
+            const long req = sz ? atol(sz) : 0;
+            if (sz && (req < 4 || req > (1L << 28))) { fprintf(stderr, "ZKMI_SRS_SIZE = %s outside [4, 2^28]\n", sz); exit(1); }
+            const size_t size = req ? (size_t)req : 1000000;
             void* d = nullptr;
             must(zk_dev_alloc(&d, size * 64), "NewSRS");
             must(zk_bn254_kzg_new_srs_dev(d, size, &alpha, g_srs.g2, nullptr), "NewSRS");
             must(zk_bn254_bases_register_dev(d, size, 0, &g_srs.handle), "NewSRS");
             (void)zk_dev_free(d);
-            // SaveSRS
+            // SaveSRS: the whole text goes to a temporary file that is renamed over srs.hex, so that no reader ever sees half of it
             const size_t cap = 2 * (132 + 32 * size);
             std::string out(cap, '\0');
             size_t len = 0;
             must(zk_bn254_kzg_srs_write(g_srs.handle, g_srs.g2, 1, &out[0], cap, &len), "SaveSRS");
-            const std::string dir = path.substr(0, path.rfind('/'));
-            (void)mkdir(dir.substr(0, dir.rfind('/')).c_str(), 0755);
-            (void)mkdir(dir.c_str(), 0755);
-            if (FILE* f = fopen(path.c_str(), "wb")) {
-                (void)fwrite(out.data(), 1, len, f);
-                fclose(f);
-            }  // like upstream, a failure to save is not an error: the SRS is usable for this process
+            const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+            bool saved = false;
+            if (FILE* f = fopen(tmp.c_str(), "wb")) {
+                saved = fwrite(out.data(), 1, len, f) == len;
+                saved = (fflush(f) == 0) && saved;
+                saved = (fclose(f) == 0) && saved;
+                saved = saved && rename(tmp.c_str(), path.c_str()) == 0;
+                if (!saved) (void)unlink(tmp.c_str());
+            }  // like upstream (SaveSRS's error is dropped, common.go:141), a failure to save is not an error: the SRS is usable for this process
         }
         g_srs.ready = true;
     }
@@ -191,7 +216,7 @@ bool to_mont(const std::vector<std::vector<uint8_t>>& be, std::vector<zk_fr>* ou
 
 std::string plonk_prove(GoString acir, const std::string& values, const char* pk_hex, size_t pk_len, uint64_t pk_handle, uint64_t srs) {
     std::string proof(2 * ZK_PLONK_PROOF_BYTES, '\0');
-    must(zk_plonk_prove_with_pk(acir.p, (size_t)acir.n, values.data(), values.size(), pk_hex, pk_len, pk_handle, srs, nullptr, &proof[0]), "PlonkProveWithPK");
+    must(zk_plonk_prove_with_pk(acir.p, (size_t)acir.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, pk_hex, pk_len, pk_handle, srs, nullptr, &proof[0]), "PlonkProveWithPK");
     return proof;
 }
 
@@ -212,9 +237,9 @@ KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {
     try_load_srs(&srs, g2);
     const std::string values = unquote(encodedRandomValues);
     size_t pk_len = 0, vk_len = 0;
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkPreprocess");
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkPreprocess");
     std::string pk(pk_len, '\0'), vk(vk_len, '\0');
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), srs, &pk[0], pk.size(), &pk_len, &vk[0], vk.size(), &vk_len, nullptr), "PlonkPreprocess");
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, &pk[0], pk.size(), &pk_len, &vk[0], vk.size(), &vk_len, nullptr), "PlonkPreprocess");
     return KeyPair{c_string(pk), c_string(vk)};
 }
 
@@ -224,9 +249,9 @@ char* PlonkProveWithMeta(GoString acirJSON, GoString encodedValues) {
     try_load_srs(&srs, g2);
     const std::string values = unquote(encodedValues);
     size_t pk_len = 0, vk_len = 0;
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkProveWithMeta");
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkProveWithMeta");
     std::string pk(pk_len, '\0');
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), srs, &pk[0], pk.size(), &pk_len, nullptr, 0, &vk_len, &h), "PlonkProveWithMeta");
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, &pk[0], pk.size(), &pk_len, nullptr, 0, &vk_len, &h), "PlonkProveWithMeta");
     const std::string proof = plonk_prove(acirJSON, values, nullptr, 0, h, srs);
     (void)zk_bn254_plonk_pk_free(h);
     return c_string(proof);
@@ -245,9 +270,9 @@ unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoStri
     std::vector<std::vector<uint8_t>> values;
     if (!felts_from_hex(unquote(encodedPublicInputs), &values)) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }
     size_t n_public = 0, n_vars = 0, n_cons = 0;
-    must(zk_acir_to_sparse_r1cs(acirJSON.p, (size_t)acirJSON.n, values.size(), &n_public, &n_vars, &n_cons, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "BuildSparseR1CS");
+    must(zk_acir_to_sparse_r1cs(acirJSON.p, (size_t)acirJSON.n, values.size(), ZK_ACIR_LAYOUT_REFERENCE, &n_public, &n_vars, &n_cons, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "BuildSparseR1CS");
     std::vector<uint32_t> order(n_vars ? n_vars : 1);
-    must(zk_acir_to_sparse_r1cs(acirJSON.p, (size_t)acirJSON.n, values.size(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, order.data()), "BuildSparseR1CS");
+    must(zk_acir_to_sparse_r1cs(acirJSON.p, (size_t)acirJSON.n, values.size(), ZK_ACIR_LAYOUT_REFERENCE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, order.data()), "BuildSparseR1CS");
     std::vector<std::vector<uint8_t>> pub_be;
     for (size_t k = 0; k < n_public; k++) pub_be.push_back(values[order[k]]);
     std::vector<zk_fr> pub;

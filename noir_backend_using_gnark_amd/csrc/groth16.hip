@@ -210,9 +210,9 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
             P.tab_w.row_step = P.tab_h.row_step = pk->shard_count;
         }
         P.tab_w.l1_m = 16;  // A, B1, K, G2.B: their reduction tails hide under the next accumulate -- less work beats lower latency
-        P.tab_w.l2_m = getenv("ZKMI_L2_M") ? (unsigned)atoi(getenv("ZKMI_L2_M")) : 8;  // measured: 8 -> -0.09 ms, 16 -> +0.15 ms, 32 -> +0.9 ms (the level gets too long to hide)
-        P.tab_h.l1_m = getenv("ZKMI_L1H_M") ? (unsigned)atoi(getenv("ZKMI_L1H_M")) : 8;   // Z finishes last: its tail is exposed
-        P.tab_h.l2_m = getenv("ZKMI_L2H_M") ? (unsigned)atoi(getenv("ZKMI_L2H_M")) : 0;
+        P.tab_w.l2_m = (unsigned)ZK_EXP("ZKMI_L2_M", 8);  // measured: 8 -> -0.09 ms, 16 -> +0.15 ms, 32 -> +0.9 ms (the level gets too long to hide)
+        P.tab_h.l1_m = (unsigned)ZK_EXP("ZKMI_L1H_M", 8);   // Z finishes last: its tail is exposed
+        P.tab_h.l2_m = (unsigned)ZK_EXP("ZKMI_L2H_M", 0);
         const size_t Ww = P.tab_w.rows() ? P.tab_w.rows() : 1, Wh = P.tab_h.rows() ? P.tab_h.rows() : 1;  // rows held here (all of them unless window-sharded)
         const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
         size_t free_b = 0, total_b = 0;
@@ -220,7 +220,7 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         // measured (end of round 1): tables pay at every size that fits -- 2^23: 65.8 vs 76.3 ms per proof, 2^24 (84 GB of tables): 126.8 vs
         // 148.1 ms -- so the only limits are half of the free HBM and a 128 GB cap (an early measurement that showed the opposite at 2^24
         // was an artefact of the task-size heuristic fixed since)
-        static const size_t cap_gb = getenv("ZKMI_TABLE_CAP_GB") ? (size_t)atoi(getenv("ZKMI_TABLE_CAP_GB")) : 128;  // experiment switch
+        static const size_t cap_gb = (size_t)zk_env_bounded("ZKMI_TABLE_CAP_GB", 128, 0, 1024);  // 0 = never build tables; the result does not depend on it
         if (bytes < free_b / 2 && bytes <= (cap_gb << 30)) {
             SlotGuard g;
             ZK_TRY(acquire_slot(&g.s));
@@ -349,7 +349,7 @@ struct Msm5State {
 // that the GPU is busy while the host is still enqueuing computeH and prepare(h).
 // scalar side of the four MSMs over the wire values (digits, sort, task plan) on slot 4's stream
 static int msm5_prepare_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S) {
-    static const bool low = getenv("ZKMI_PREPW_LOW") && atoi(getenv("ZKMI_PREPW_LOW")) == 1;  // experiment: normal priority under computeH
+    static const bool low = ZK_EXP("ZKMI_PREPW_LOW", 0) == 1;  // experiment: normal priority under computeH
     hipStream_t st4 = low ? sl[4]->stream : sl[4]->stream_hi;
     if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
     if (in.tab_w) return msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w);
@@ -371,7 +371,7 @@ static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w,
     // for all accumulate kernels removes the ~0.15 ms event gaps but delays prepare(h) -- rocPRIM's onesweep sort spins on
     // look-back tiles that cannot get a wave slot under an accumulate kernel -- and ends up slower)
     // ZKMI_CHAIN=1 (experiment switch): all accumulate kernels back to back on ONE stream, tails on the jobs' own streams
-    static const bool one_chain = getenv("ZKMI_CHAIN") && atoi(getenv("ZKMI_CHAIN")) == 1;
+    static const bool one_chain = ZK_EXP("ZKMI_CHAIN", 0) == 1;
     if (one_chain && (in.tab_w || share_k)) {
         hipStream_t chain = sl[4]->stream;
         S->jobs[4].gate_acc = gate_first_acc;
@@ -395,7 +395,7 @@ static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w,
     // ZKMI_BATCH_ACC=1 (experiment switch): A, B1, K -- which read the same sorted digits -- in ONE accumulate launch (grid.y = 3).
     // Measured 0.25 ms SLOWER per proof than the chained launches (11.2 vs 10.95 ms): the kernel itself runs at 0.70 of the madd
     // peak instead of 0.61, but the three reduction tails then all start late and pile up under Z instead of hiding one by one.
-    static const bool batch_acc = getenv("ZKMI_BATCH_ACC") && atoi(getenv("ZKMI_BATCH_ACC")) == 1;
+    static const bool batch_acc = ZK_EXP("ZKMI_BATCH_ACC", 0) == 1;
     if (batch_acc && (in.tab_w || share_k)) {
         Slot* bs[3] = {sl[1], sl[2], sl[3]};
         hipStream_t bst[3] = {sl[1]->stream, sl[2]->stream, sl[3]->stream};
@@ -433,7 +433,7 @@ static int msm5_prepare_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Ms
 }
 static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm5State* S, bool prepared = false) {
     // ZKMI_PREPH_LOW=1 (experiment switch): prepare(h) on slot 0's NORMAL-priority stream (it has ~7 ms of slack until Z needs it)
-    static const bool preph_low = getenv("ZKMI_PREPH_LOW") && atoi(getenv("ZKMI_PREPH_LOW")) == 1;
+    static const bool preph_low = ZK_EXP("ZKMI_PREPH_LOW", 0) == 1;
     if (!prepared && preph_low && sl[0]->stream != st0) {
         hipEvent_t ev;
         ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -455,7 +455,7 @@ static int msm5_launch_h(Slot* sl[5], hipStream_t st0, const Msm5Inputs& in, Msm
     // ZKMI_QUAD_TAIL=1 (experiment switch): wave levels of Z's reduction tail -- the only tail nothing can hide -- with four lanes per
     // point.  Measured: those levels shrink 0.39 -> 0.27 ms under the profiler but the proof does not (10.6-10.8 ms either way), and
     // level 1, which already fills every SIMD, gets 3x slower in that form; off by default.
-    static const bool quad_tail = getenv("ZKMI_QUAD_TAIL") && atoi(getenv("ZKMI_QUAD_TAIL")) == 1;
+    static const bool quad_tail = ZK_EXP("ZKMI_QUAD_TAIL", 0) == 1;
     S->jobs[0].quad_tail = quad_tail;
     ZK_TRY(msm_g1_accumulate(sl[0], st0, S->prep_h, in.tab_h ? in.t_z : in.d_z, 0, &S->jobs[0]));
     return ZK_OK;
@@ -770,7 +770,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     // Host inputs (what a cgo caller has): 128 bytes per constraint cross PCIe inside the call.  Order: w first (32 B / wire), its scalar preparation
     // and the G2.B accumulate -- none of which needs a, b, c -- run while a, b, c (96 B / constraint) are still uploading; computeH then takes the
     // machine BETWEEN the G2.B and A accumulates (under an accumulate kernel it would be starved).  ZKMI_HOST_ORDER=0 restores computeH-first.
-    static const bool host_order_on = !(getenv("ZKMI_HOST_ORDER") && atoi(getenv("ZKMI_HOST_ORDER")) == 0);
+    static const bool host_order_on = (ZK_EXP("ZKMI_HOST_ORDER", 1) != 0);
     const bool host_order = !on_device && host_order_on && nw > 0 && N > 1;
     Fr* d_w = (Fr*)s0->alloc(nw * 32 + 16);
     for (int i = 0; i < 3; i++) d_abc[i] = (Fr*)s0->alloc(N * 32);
@@ -786,7 +786,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     // h = computeH(a, b, c), left in d_abc[0] (bit-reversed order, like upstream; pk.G1.Z is stored to match)
     const Fr* in_place_src[3] = {(const Fr*)a, (const Fr*)b, (const Fr*)c};
     // ZKMI_H_STREAMS=1 (experiment switch): the transforms of b and c on the (idle) high-priority streams of slots 1 and 2, next to a's
-    static const bool h_streams = getenv("ZKMI_H_STREAMS") && atoi(getenv("ZKMI_H_STREAMS")) == 1;
+    static const bool h_streams = ZK_EXP("ZKMI_H_STREAMS", 0) == 1;
     const hipStream_t side[2] = {g.s[1]->stream_hi, g.s[2]->stream_hi};
     hipEvent_t ev_h = nullptr;
     auto run_compute_h = [&]() -> int {
@@ -796,8 +796,8 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
         return ZK_OK;
     };
     Msm5State S;
-    static const bool nogate = getenv("ZKMI_NOGATE") && atoi(getenv("ZKMI_NOGATE")) == 1;  // experiment: G2.B accumulate does not wait for computeH
-    static const bool preph_first = getenv("ZKMI_PREPH_FIRST") && atoi(getenv("ZKMI_PREPH_FIRST")) == 1;  // experiment: prepare(h) alone, before G2.B
+    static const bool nogate = ZK_EXP("ZKMI_NOGATE", 0) == 1;  // experiment: G2.B accumulate does not wait for computeH
+    static const bool preph_first = ZK_EXP("ZKMI_PREPH_FIRST", 0) == 1;  // experiment: prepare(h) alone, before G2.B
     if (host_order) {
         if (hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
         in.d_w = d_w;

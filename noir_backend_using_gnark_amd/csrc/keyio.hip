@@ -311,7 +311,7 @@ int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void
     PsiConsts psi;
     memcpy(&psi.gx, &gx, sizeof gx);
     memcpy(&psi.gy, &gy, sizeof gy);
-    static const int full = getenv("ZKMI_G2_FULL_SUBGROUP_CHECK") ? atoi(getenv("ZKMI_G2_FULL_SUBGROUP_CHECK")) : 0;
+    static const int full = ZK_EXP("ZKMI_G2_FULL_SUBGROUP_CHECK", 0);
     if (n) ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, psi, full, (Affine<Fp2>*)d_out, d_status);
     return ZK_OK;
 }
@@ -381,7 +381,12 @@ static bool fp_from_be(const uint8_t in[32], HFp* out) {
 bool g2_decompress_host(const uint8_t in[64], Affine<HFp2>* out) {
     const unsigned flag = in[0] >> 6;
     *out = Affine<HFp2>::inf();
-    if (flag == 1) return true;
+    if (flag == 1) {  // infinity: canonical only -- every other bit zero, as g1_decompress_host and gnark-crypto's SetBytes require
+        if (in[0] & 0x3f) return false;
+        for (int i = 1; i < 64; i++)
+            if (in[i]) return false;
+        return true;
+    }
     if (flag == 0) return false;
     uint8_t b[64];
     memcpy(b, in, 64);

@@ -23,6 +23,7 @@
 // addition is 10 Fp products of ~136 quarter-rate v_mad_u64_u32 each -- see DESIGN.md for both fractions.
 #include <string.h>
 
+#include <algorithm>
 #include <tuple>
 
 #include <rocprim/rocprim.hpp>
@@ -42,7 +43,7 @@ using SortWide = rocprim::radix_sort_config<rocprim::default_config, rocprim::de
                                                                                 rocprim::block_radix_rank_algorithm::match>>;
 static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, rocprim::double_buffer<uint32_t>& kb, rocprim::double_buffer<uint32_t>& vb, size_t n, unsigned key_bits,
                              hipStream_t st) {
-    static const int cfg = getenv("ZKMI_SORT_CFG") ? atoi(getenv("ZKMI_SORT_CFG")) : 0;
+    static const int cfg = ZK_EXP("ZKMI_SORT_CFG", 0);
     if (cfg == 1) return rocprim::radix_sort_pairs<SortWide>(tmp, tmp_bytes, kb, vb, n, 0, key_bits, st);
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, n, 0, key_bits, st);
 }
@@ -703,7 +704,7 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
         uint64_t top_max = shift >= 192 ? (r_top64 >> (shift - 192)) : ~0ULL;
         if (top_max < P->B && top_max > 0) {
             size_t dense = n / (size_t)top_max + 1 + (tab ? mean : 0);  // table mode: the top window's points come on top of the others
-            static const size_t dense_max = getenv("ZKMI_L_DENSE") ? (size_t)atoi(getenv("ZKMI_L_DENSE")) : 4;  // experiment switch: 0 = always cut dense buckets
+            static const size_t dense_max = (size_t)ZK_EXP("ZKMI_L_DENSE", 4);  // experiment switch: 0 = always cut dense buckets
             if (dense > mean && dense <= dense_max * mean + 8 && dense_max) mean = dense;
         }
     }
@@ -712,13 +713,14 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     // mostly 0/1) by growing the task size with n
     if (P->L < (n >> 16)) P->L = (uint32_t)(n >> 16);
     // the device may shorten the tasks down to Lmin when the digits turn out sparse / skewed (k_pick_len): the task arrays are sized for that
-    static const bool adaptive = !(getenv("ZKMI_ADAPTIVE_L") && atoi(getenv("ZKMI_ADAPTIVE_L")) == 0);
-    static const uint32_t lmin_div = getenv("ZKMI_L_MIN_DIV") ? (uint32_t)atoi(getenv("ZKMI_L_MIN_DIV")) : 8;  // experiment switch
+    static const bool adaptive = (ZK_EXP("ZKMI_ADAPTIVE_L", 1) != 0);
+    static const uint32_t lmin_div = (uint32_t)std::max<long>(1, ZK_EXP("ZKMI_L_MIN_DIV", 8));  // experiment switch
     P->Lmin = adaptive ? (P->L / lmin_div > 32 ? P->L / lmin_div : 32) : P->L;
     if (P->Lmin > P->L) P->Lmin = P->L;
     P->max_tasks = (size_t)P->nb + P->total / P->Lmin + 1;
-    static const unsigned l1_env = getenv("ZKMI_L1_M") ? (unsigned)atoi(getenv("ZKMI_L1_M")) : 0;  // experiment switch (power of two)
-    const unsigned l1_m = l1_env ? l1_env : (tab && tab->l1_m ? tab->l1_m : 8);
+    static const unsigned l1_env = (unsigned)ZK_EXP("ZKMI_L1_M", 0);  // experiment switch (power of two)
+    unsigned l1_m = l1_env ? l1_env : (tab && tab->l1_m ? tab->l1_m : 8);
+    while (l1_m & (l1_m - 1)) l1_m &= l1_m - 1;  // a power of two (N1 = B / m1 must be exact)
     P->m1 = P->B >= l1_m ? l1_m : P->B;  // level-1 serial chunk
     P->m2 = (tab && tab->l2_m) ? tab->l2_m : 0;
     P->N1 = P->B / P->m1;
@@ -792,8 +794,8 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     // ---- 4. plan
     ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
     if (P.Lmin < L) ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats, dim3(nb / 4096 ? (nb / 4096 > 512 ? 512 : nb / 4096) : 1), dim3(256), 0, (const uint32_t*)start, nb, bins);
-    static const uint32_t l_factor = getenv("ZKMI_L_FACTOR") ? (uint32_t)atoi(getenv("ZKMI_L_FACTOR")) : 4;     // experiment switches
-    static const uint32_t l_cap = getenv("ZKMI_L_GIANT_CAP") ? (uint32_t)atoi(getenv("ZKMI_L_GIANT_CAP")) : 16384;
+    static const uint32_t l_factor = (uint32_t)ZK_EXP("ZKMI_L_FACTOR", 4);     // experiment switches
+    static const uint32_t l_cap = (uint32_t)ZK_EXP("ZKMI_L_GIANT_CAP", 16384);
     ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, bins);
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
     {
@@ -1340,8 +1342,8 @@ static int bases_register(const void* points, size_t n, int is_g2, uint64_t* han
         b.tab.c = table_c > 0 ? (unsigned)table_c : msm_pick_window_table(n);
         b.tab.stride = n;
         // experiment switches: level sizes of the reduction tail of commits against registered bases (0 = the latency-structured default)
-        b.tab.l1_m = getenv("ZKMI_BASES_L1M") ? (unsigned)atoi(getenv("ZKMI_BASES_L1M")) : 0;
-        b.tab.l2_m = getenv("ZKMI_BASES_L2M") ? (unsigned)atoi(getenv("ZKMI_BASES_L2M")) : 0;
+        b.tab.l1_m = (unsigned)ZK_EXP("ZKMI_BASES_L1M", 0);
+        b.tab.l2_m = (unsigned)ZK_EXP("ZKMI_BASES_L2M", 0);
         const size_t Wd = (255 + b.tab.c - 1) / b.tab.c, tbytes = Wd * n * (is_g2 ? 128 : 64);
         size_t free_b = 0, total_b = 0;
         ZK_HIP(hipMemGetInfo(&free_b, &total_b));

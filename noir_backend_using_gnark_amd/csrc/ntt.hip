@@ -16,6 +16,8 @@
 // (a 254-bit Montgomery product is ~136 quarter-rate v_mad_u64_u32), not HBM-bound -- see DESIGN.md.
 #include <vector>
 
+#include <algorithm>
+
 #include "ctx.hpp"
 #include "ff.hpp"
 #include "host_ff.hpp"
@@ -25,7 +27,7 @@
 namespace zkmi {
 
 static constexpr unsigned TILE_LOG = 11;        // 2048 elements = 64 KiB of LDS per workgroup
-static const unsigned K_STRIDED = getenv("ZKMI_NTT_KS") ? (unsigned)atoi(getenv("ZKMI_NTT_KS")) : 9;  // strided passes: k <= 9, rows of L >= 4 elements (128-byte runs); 2^20 = 11 + 9 bits = two passes
+static const unsigned K_STRIDED = (unsigned)std::min<long>(9, std::max<long>(2, ZK_EXP("ZKMI_NTT_KS", 9)));  // strided passes: k <= 9, rows of L >= 4 elements (128-byte runs); 2^20 = 11 + 9 bits = two passes
 static constexpr unsigned NTT_THREADS = 256;
 
 struct PowBasis {
@@ -449,8 +451,8 @@ int get_domain(Slot* s, hipStream_t st, unsigned logn, unsigned need, Domain** o
 // radix-4 stage groups with 512 lanes per tile (4 waves per SIMD) instead of radix-8 with 256 (2 waves per SIMD): measured 8 % faster --
 // the waves of a pass spend ~40 % of their time parked on twiddle / tile loads and barriers, which more resident waves hide.
 // ZKMI_NTT_G2=0 selects the radix-8 variant (A/B switch).
-static const bool g_ntt_g2 = !(getenv("ZKMI_NTT_G2") && atoi(getenv("ZKMI_NTT_G2")) == 0);
-static const bool g_ntt_saturated = getenv("ZKMI_NTT_SAT") && atoi(getenv("ZKMI_NTT_SAT")) == 1;  // A/B switch: the 8 x 32-bit butterflies
+static const bool g_ntt_g2 = (ZK_EXP("ZKMI_NTT_G2", 1) != 0);
+static const bool g_ntt_saturated = ZK_EXP("ZKMI_NTT_SAT", 0) == 1;  // A/B switch: the 8 x 32-bit butterflies
 
 struct PassPlan { unsigned bit_lo, k, logL; };
 // split of the index bits: the lowest kc bits form the contiguous pass (L = 1); the rest go to strided passes (increasing bit order)
@@ -471,7 +473,7 @@ static std::vector<PassPlan> plan_passes(unsigned logn) {
     return passes;
 }
 
-static const uint32_t g_tw_and = getenv("ZKMI_NTT_TWMASK") ? (uint32_t)strtoul(getenv("ZKMI_NTT_TWMASK"), nullptr, 0) : 0xffffffffu;
+static const uint32_t g_tw_and = (uint32_t)ZK_EXP("ZKMI_NTT_TWMASK", 0xffffffffL);
 static int launch_pass(Slot* s, hipStream_t st, const PassArgs& A_, bool sat) {
     PassArgs A = A_;
     A.tw_and = g_tw_and;
@@ -519,7 +521,7 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int 
 
 // FFTInverse(DIF) with `mid` applied at its end (1/N and whatever scaling follows), then FFT(DIT): as run_passes twice, but the two
 // contiguous passes in the middle are ONE kernel (k_ntt_pass29_if).
-static const bool g_ntt_fuse_if = !(getenv("ZKMI_NTT_FUSE") && atoi(getenv("ZKMI_NTT_FUSE")) == 0);  // A/B switch
+static const bool g_ntt_fuse_if = (ZK_EXP("ZKMI_NTT_FUSE", 1) != 0);  // A/B switch
 static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* dom, const Fr* mid, const Fr* src = nullptr) {
     // src (optional): the input lives there and stays untouched -- the first pass reads it and writes `data`
     const unsigned logn = dom->logn;
@@ -618,7 +620,7 @@ int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned log
     // By linearity (exact field arithmetic, so bit for bit for ANY input): FFTInverse(coset)((a'b' - c') den) = den (FFTInverse(coset)(a'b') - FFTInverse(c)),
     // where c' = FFT(coset)(FFTInverse(c)) -- the coset transform of c and its way back cancel.  c therefore only needs its first FFTInverse(DIF)
     // (coefficients, bit-reversed like the result): six transforms instead of gnark's seven.  ZKMI_H_SKIP_C=0 restores the literal sequence.
-    static const bool skip_c = !(getenv("ZKMI_H_SKIP_C") && atoi(getenv("ZKMI_H_SKIP_C")) == 0);
+    static const bool skip_c = (ZK_EXP("ZKMI_H_SKIP_C", 1) != 0);
     if (skip_c && !side && logN > 0) {
         const Fr cinv = to_dev(d->card_inv);
         for (int i = 0; i < 2; i++) ZK_TRY(run_inverse_forward(s, st, vs[i], d, d->coset_rev_n, src ? src[i] : nullptr));

@@ -485,7 +485,7 @@ struct CommitChain {
         hipEvent_t ev;
         ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         ZK_HIP(hipEventRecord(ev, producer));
-        static const bool prep_hi = !(getenv("ZKMI_PLONK_PREP_HI") && atoi(getenv("ZKMI_PLONK_PREP_HI")) == 0);  // A/B switch
+        static const bool prep_hi = (ZK_EXP("ZKMI_PLONK_PREP_HI", 1) != 0);  // A/B switch
         hipStream_t sp = prep_hi ? s->stream_hi : s->stream;  // the preparation at high priority: its sort must get wave slots under a running accumulate
         ZK_TRY(masked_streams(s));
         hipStream_t sa = s->stream;
@@ -533,8 +533,8 @@ struct CommitChain {
 // at normal or high priority and with latency- or work-structured tails -- rocPRIM's onesweep sort does not make progress underneath a running accumulate
 // kernel (its look-back tiles spin for wave slots), so "sort under accumulate" buys nothing here and the strict one-at-a-time order costs the overlap the
 // threads get by accident.  Off by default; ZKMI_PLONK_CHAIN=1 selects it.
-static const bool g_plonk_chain = getenv("ZKMI_PLONK_CHAIN") && atoi(getenv("ZKMI_PLONK_CHAIN")) == 1;
-static const bool g_plonk_serial = getenv("ZKMI_PLONK_SERIAL") && atoi(getenv("ZKMI_PLONK_SERIAL")) == 1;  // A/B switch: commitments one after the other
+static const bool g_plonk_chain = ZK_EXP("ZKMI_PLONK_CHAIN", 0) == 1;
+static const bool g_plonk_serial = ZK_EXP("ZKMI_PLONK_SERIAL", 0) == 1;  // A/B switch: commitments one after the other
 
 // Lagrange (regular) -> canonical (regular) on the small domain, in place: FFTInverse(DIF) + BitReverse, as setup.go / iop.ToCanonical do
 static int to_canonical(Slot* s, hipStream_t st, Fr* d, unsigned logn) {
@@ -667,6 +667,14 @@ static int register_pk(PlonkPK* P, uint64_t* handle) {
     return ZK_OK;
 }
 
+// Key headers come from untrusted bytes (PlonkProveWithPK hands over whatever the caller sends): NbPublicVariables must fit the variables the
+// circuit has -- the prover reads that many elements of the solution -- and neither count may be large enough to wrap the sum below.
+static int check_counts(uint64_t n_public, size_t n_vars, size_t n_constraints) {
+    if (n_public > n_vars) return set_err(ZK_ERR_ARG, "proving key: %llu public inputs but %zu variables", (unsigned long long)n_public, n_vars);
+    if (n_public >= ((uint64_t)1 << 28) || n_constraints >= ((size_t)1 << 28)) return set_err(ZK_ERR_ARG, "proving key: %llu public inputs + %zu constraints exceed the Fr two-adicity 2^28", (unsigned long long)n_public, n_constraints);
+    return ZK_OK;
+}
+
 static int domains_for(size_t size_system, unsigned* logn, unsigned* logN4) {
     if (size_system < 2) return set_err(ZK_ERR_ARG, "PLONK needs at least 2 rows (constraints + public inputs)");
     unsigned ln = 0;
@@ -790,9 +798,12 @@ int zk_bn254_plonk_pk_load(const zk_plonk_pk* k, uint64_t srs, uint64_t* handle)
         !k->vk_qm || !k->vk_qo || !k->vk_qk || (k->n_constraints && (!k->xa || !k->xb || !k->xc)))
         return set_err(ZK_ERR_ARG, "null pointer");
     unsigned logn, logN4;
+    ZK_TRY(check_counts(k->n_public, k->n_vars, k->n_constraints));
     ZK_TRY(domains_for(k->n_constraints + k->n_public, &logn, &logN4));
     if (logn != k->log_n) return set_err(ZK_ERR_ARG, "log_n = %u does not match %zu constraints + %zu public inputs", k->log_n, k->n_constraints, k->n_public);
     const size_t n = (size_t)1 << logn;
+    for (size_t i = 0; i < k->n_constraints; i++)
+        if (k->xa[i] >= k->n_vars || k->xb[i] >= k->n_vars || k->xc[i] >= k->n_vars) return set_err(ZK_ERR_ARG, "gate %zu names a wire outside the %zu variables", i, k->n_vars);
     std::vector<uint32_t> perm(3 * n);
     for (size_t i = 0; i < 3 * n; i++) {
         if (k->permutation[i] < 0 || (size_t)k->permutation[i] >= 3 * n) return set_err(ZK_ERR_ARG, "Permutation[%zu] out of range", i);
@@ -872,7 +883,8 @@ int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_va
     ZK_TRY(payload_bytes(data, len, is_hex, 0, PK_HEAD, head));
     const uint64_t size = be64(head), npub = be64(head + 72), card0 = be64(head + 368), card1 = be64(head + 368 + 168);
     unsigned logn, logN4;
-    ZK_TRY(domains_for(n_constraints + npub, &logn, &logN4));
+    ZK_TRY(check_counts(npub, n_vars, n_constraints));
+    ZK_TRY(domains_for(n_constraints + (size_t)npub, &logn, &logN4));
     if (size != ((uint64_t)1 << logn) || card0 != size || card1 != ((uint64_t)1 << logN4))
         return set_err(ZK_ERR_ARG, "proving key: domain sizes %llu / %llu / %llu do not match %zu constraints + %llu public inputs", (unsigned long long)size,
                        (unsigned long long)card0, (unsigned long long)card1, n_constraints, (unsigned long long)npub);
@@ -1013,6 +1025,18 @@ int zk_bn254_plonk_pk_write(uint64_t handle, int as_hex, void* out, size_t cap, 
         ZK_HIP(hipMemcpyAsync(out, d_bytes, nbytes, hipMemcpyDeviceToHost, st));
     }
     return slot_sync(s, st);
+}
+
+int zk_bn254_plonk_pk_info(uint64_t handle, size_t* domain_size, size_t* n_public, size_t* n_constraints, size_t* n_vars) {
+    std::lock_guard<std::mutex> lk(g_ppk_mu);
+    auto it = g_ppks.find(handle);
+    if (it == g_ppks.end()) return set_err(ZK_ERR_HANDLE, "unknown PLONK proving key %llu", (unsigned long long)handle);
+    const PlonkPK* P = it->second;
+    if (domain_size) *domain_size = P->n;
+    if (n_public) *n_public = P->n_public;
+    if (n_constraints) *n_constraints = P->n_constraints;
+    if (n_vars) *n_vars = P->n_vars;
+    return ZK_OK;
 }
 
 int zk_bn254_plonk_pk_free(uint64_t handle) {
@@ -1177,7 +1201,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         const Fr* polys[1] = {bz_};
         const size_t lens[1] = {n + 3};
         ZK_TRY(commit_group(1, polys, lens, &c_z, [&]() -> int {
-            static const bool qk_ntt = getenv("ZKMI_PLONK_QK_NTT") && atoi(getenv("ZKMI_PLONK_QK_NTT")) == 1;  // A/B switch: the literal sequence
+            static const bool qk_ntt = ZK_EXP("ZKMI_PLONK_QK_NTT", 0) == 1;  // A/B switch: the literal sequence
             if (!qk_ntt && npub <= PLONK_PI_DIRECT_MAX && logN4 >= 2) {
                 ZK_TRY(to_big_coset(s, st, P->w_big[3], small5[3], len5[3], P));
                 ZK_LAUNCH(s, st, "plonk_qk_coset", k_qk_coset, dim3(grid_of(P->N4)), dim3(256), 0, (const Fr*)P->e_cqk, (const Fr*)P->e[7], (const Fr*)d_sol, (const Fr*)P->lqk,
@@ -1274,7 +1298,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     // polynomial, for seven scalar multiplications on the host (while the GPU runs the kernels above) instead of an (n + 3)-point MSM.  Only for keys whose
     // digests are known to be consistent: Setup's, or -- for a key read from its wire image -- once a first proof has computed both and found them equal.
     // ZKMI_PLONK_LIN_MSM=1 forces the literal commitment (A/B switch).
-    static const bool lin_msm = getenv("ZKMI_PLONK_LIN_MSM") && atoi(getenv("ZKMI_PLONK_LIN_MSM")) == 1;
+    static const bool lin_msm = ZK_EXP("ZKMI_PLONK_LIN_MSM", 0) == 1;
     Affine<HFp> c_lin_by_linearity;
     {
         const HFr cz_tot = alpha * lin_cz + lin_lag, cs3_tot = alpha * lin_cs3;

@@ -54,7 +54,8 @@ struct R1csDev {
     std::vector<void*> allocs;
 };
 static std::mutex g_r1cs_mu;
-static std::map<uint64_t, R1csDev*> g_r1cs;
+// shared ownership: a call that looked a system up keeps it alive even if another thread frees the handle meanwhile
+static std::map<uint64_t, std::shared_ptr<R1csDev>> g_r1cs;
 static uint64_t g_next_r1cs = 1;
 
 static void r1cs_destroy(R1csDev* r) {
@@ -116,7 +117,7 @@ __global__ void k_z_scalars(PowTab tau_pw, uint32_t N, unsigned logN, Fr scale, 
 }
 static unsigned gridn(size_t n) { return (unsigned)((n + 255) / 256); }
 
-static int lookup_r1cs(uint64_t h, R1csDev** out) {
+static int lookup_r1cs(uint64_t h, std::shared_ptr<R1csDev>* out) {
     std::lock_guard<std::mutex> lk(g_r1cs_mu);
     auto it = g_r1cs.find(h);
     if (it == g_r1cs.end()) return set_err(ZK_ERR_HANDLE, "unknown R1CS handle %llu", (unsigned long long)h);
@@ -189,12 +190,12 @@ int zk_bn254_r1cs_load(const zk_r1cs* r, uint64_t* handle) {
     }
     std::lock_guard<std::mutex> lk(g_r1cs_mu);
     *handle = g_next_r1cs++;
-    g_r1cs[*handle] = D.release();
+    g_r1cs[*handle] = std::shared_ptr<R1csDev>(D.release(), r1cs_destroy);
     return ZK_OK;
 }
 
 int zk_bn254_r1cs_free(uint64_t handle) {
-    R1csDev* D;
+    std::shared_ptr<R1csDev> D;  // destroyed here, or by the last call still using it
     {
         std::lock_guard<std::mutex> lk(g_r1cs_mu);
         auto it = g_r1cs.find(handle);
@@ -202,14 +203,14 @@ int zk_bn254_r1cs_free(uint64_t handle) {
         D = it->second;
         g_r1cs.erase(it);
     }
-    r1cs_destroy(D);
     return ZK_OK;
 }
 
 // a = L w, b = R w, c = O w (n_constraints each), everything in HBM
 int zk_bn254_r1cs_eval_abc_dev(uint64_t handle, const void* d_w, size_t n_wires, void* d_a, void* d_b, void* d_c, void* stream) {
-    R1csDev* D;
-    ZK_TRY(lookup_r1cs(handle, &D));
+    std::shared_ptr<R1csDev> Dref;
+    ZK_TRY(lookup_r1cs(handle, &Dref));
+    R1csDev* D = Dref.get();
     if (n_wires != D->n_wires) return set_err(ZK_ERR_LEN, "len(w) = %zu != %zu wires of the constraint system", n_wires, D->n_wires);
     if (!d_w || !d_a || !d_b || !d_c) return set_err(ZK_ERR_ARG, "null pointer");
     SlotGuard g;
@@ -228,8 +229,9 @@ int zk_bn254_r1cs_eval_abc_dev(uint64_t handle, const void* d_w, size_t n_wires,
 // vk_g1 = [alpha]G1 followed by the n_public points K_i / gamma (gnark's vk.G1.K), vk_g2 = [beta]G2, [gamma]G2, [delta]G2.
 int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags, uint64_t* pk_handle, zk_g1_affine* vk_g1, zk_g2_affine vk_g2[3]) {
     if (!toxic || !pk_handle) return set_err(ZK_ERR_ARG, "null pointer");
-    R1csDev* D;
-    ZK_TRY(lookup_r1cs(r1cs_handle, &D));
+    std::shared_ptr<R1csDev> Dref;
+    ZK_TRY(lookup_r1cs(r1cs_handle, &Dref));
+    R1csDev* D = Dref.get();
     HFr tx[5];
     memcpy(tx, toxic, sizeof tx);
     for (int i = 0; i < 5; i++)
@@ -338,8 +340,9 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
 // zk_bn254_groth16_prove on resident data.  w: all wire values [ONE, public..., secret..., internal...] (Montgomery); on_device as there.
 int zk_bn254_groth16_prove_r1cs(uint64_t r1cs_handle, uint64_t pk_handle, const void* w, size_t n_wires, const zk_fr* r, const zk_fr* s_, int on_device,
                                 uint8_t proof_out[128]) {
-    R1csDev* D;
-    ZK_TRY(lookup_r1cs(r1cs_handle, &D));
+    std::shared_ptr<R1csDev> Dref;
+    ZK_TRY(lookup_r1cs(r1cs_handle, &Dref));
+    R1csDev* D = Dref.get();
     if (n_wires != D->n_wires) return set_err(ZK_ERR_LEN, "len(w) = %zu != %zu wires of the constraint system", n_wires, D->n_wires);
     if (!w || !r || !s_ || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
     ZK_TRY(ensure_init());

@@ -18,31 +18,35 @@ from . import _lib
 from ._lib import check, lib, vp
 
 
+# how witnesses become variables (include/zkmi.h): HandleValues as written (backend/common.go:45-76) / one variable per witness
+LAYOUT_REFERENCE, LAYOUT_ONE_VAR_PER_WITNESS = 0, 1
+
+
 def _b(s) -> bytes:
     return s.encode("ascii") if isinstance(s, str) else bytes(s)
 
 
-def plonk_preprocess(acir_json: str, encoded_values: str, srs, keep_resident: bool = False):
+def plonk_preprocess(acir_json: str, encoded_values: str, srs, keep_resident: bool = False, layout: int = LAYOUT_REFERENCE):
     """-> (pk_hex, vk_hex[, resident ProvingKey handle])"""
     a, v = _b(acir_json), _b(encoded_values)
     pk_len, vk_len = C.c_size_t(0), C.c_size_t(0)
-    check(lib().zk_plonk_preprocess(C.c_char_p(a), C.c_size_t(len(a)), C.c_char_p(v), C.c_size_t(len(v)), srs.handle, None, C.c_size_t(0), C.byref(pk_len),
+    check(lib().zk_plonk_preprocess(C.c_char_p(a), C.c_size_t(len(a)), C.c_char_p(v), C.c_size_t(len(v)), C.c_int(layout), srs.handle, None, C.c_size_t(0), C.byref(pk_len),
                                     None, C.c_size_t(0), C.byref(vk_len), None))
     pk, vk = C.create_string_buffer(pk_len.value), C.create_string_buffer(vk_len.value)
     h = C.c_uint64(0)
-    check(lib().zk_plonk_preprocess(C.c_char_p(a), C.c_size_t(len(a)), C.c_char_p(v), C.c_size_t(len(v)), srs.handle, pk, C.c_size_t(pk_len.value), C.byref(pk_len),
+    check(lib().zk_plonk_preprocess(C.c_char_p(a), C.c_size_t(len(a)), C.c_char_p(v), C.c_size_t(len(v)), C.c_int(layout), srs.handle, pk, C.c_size_t(pk_len.value), C.byref(pk_len),
                                     vk, C.c_size_t(vk_len.value), C.byref(vk_len), C.byref(h) if keep_resident else None))
     out = (pk.raw[:pk_len.value].decode(), vk.raw[:vk_len.value].decode())
     return out + (h.value,) if keep_resident else out
 
 
-def plonk_prove_with_pk(acir_json: str, encoded_values: str, encoded_pk: str | None, srs, blinders=None, pk_handle: int = 0) -> str:
+def plonk_prove_with_pk(acir_json: str, encoded_values: str, encoded_pk: str | None, srs, blinders=None, pk_handle: int = 0, layout: int = LAYOUT_REFERENCE) -> str:
     """-> hex of Proof.WriteTo.  encoded_pk=None proves with the resident key `pk_handle`; blinders=None draws them like upstream."""
     a, v = _b(acir_json), _b(encoded_values)
     k = _b(encoded_pk) if encoded_pk is not None else None
     bl = None if blinders is None else np.ascontiguousarray(blinders, dtype=np.uint64).reshape(9, 4)
     out = C.create_string_buffer(2 * _lib.PLONK_PROOF_BYTES)
-    rc = lib().zk_plonk_prove_with_pk(C.c_char_p(a), C.c_size_t(len(a)), C.c_char_p(v), C.c_size_t(len(v)), C.c_char_p(k) if k is not None else None,
+    rc = lib().zk_plonk_prove_with_pk(C.c_char_p(a), C.c_size_t(len(a)), C.c_char_p(v), C.c_size_t(len(v)), C.c_int(layout), C.c_char_p(k) if k is not None else None,
                                       C.c_size_t(len(k) if k is not None else 0), C.c_uint64(pk_handle), srs.handle, vp(bl) if bl is not None else None, out)
     if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
         raise ValueError((lib().zk_last_error() or b"").decode())
@@ -50,18 +54,18 @@ def plonk_prove_with_pk(acir_json: str, encoded_values: str, encoded_pk: str | N
     return out.raw.decode()
 
 
-def acir_to_sparse_r1cs(acir_json: str, n_values: int) -> dict:
+def acir_to_sparse_r1cs(acir_json: str, n_values: int, layout: int = LAYOUT_REFERENCE) -> dict:
     """BuildSparseR1CS + HandleValues: gates (Montgomery coefficients, variable ids) and the witness order (variable k = witness order[k] + 1)."""
     a = _b(acir_json)
     npub, nvars, nc = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-    rc = lib().zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(n_values), C.byref(npub), C.byref(nvars), C.byref(nc), *([None] * 9))
+    rc = lib().zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(n_values), C.c_int(layout), C.byref(npub), C.byref(nvars), C.byref(nc), *([None] * 9))
     if rc == _lib.ZK_ERR_ARG:
         raise ValueError((lib().zk_last_error() or b"").decode())
     check(rc)
     co = [np.zeros((nc.value, 4), np.uint64) for _ in range(5)]
     wi = [np.zeros(nc.value, np.uint32) for _ in range(3)]
     order = np.zeros(nvars.value, np.uint32)
-    check(lib().zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(n_values), None, None, None, *[vp(x) for x in co], *[vp(x) for x in wi], vp(order)))
+    check(lib().zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(n_values), C.c_int(layout), None, None, None, *[vp(x) for x in co], *[vp(x) for x in wi], vp(order)))
     return dict(n_public=npub.value, n_vars=nvars.value, ql=co[0], qr=co[1], qo=co[2], qm=co[3], qk=co[4], xa=wi[0], xb=wi[1], xc=wi[2], order=order)
 
 

@@ -50,17 +50,48 @@ class SparseR1CS:
                    for ql, qr, qo, qm, qc, xa, xb, xc in self.constraints)
 
 
-def sparse_r1cs_from_acir(acir: dict, values):
+def handle_values(public_inputs, n_values: int, layout: str = "reference"):
+    """HandleValues (backend/common.go:45-76) on witnesses 1 .. n_values: -> (order, index_map, n_public) where variable k holds witness order[k]
+    (public variables first: cs.AddPublicVariable numbers them 0 .., cs.AddSecretVariable continues after them [UPSTREAM-RECALL gnark v0.8.0
+    constraint/system.go]) and index_map[w] is the variable the gates use for witness w.
+
+    layout="reference" follows the two loops literally: loop 1 (common.go:48-58) adds a public variable for every (witness, equal public input)
+    pair, in witness order; loop 2 (common.go:59-74) adds, when there ARE public inputs, a SECRET variable for every (witness, DIFFERENT public
+    input) pair -- |P| copies of a private witness, |P| - 1 copies of a public one -- else one per witness; indexMap[i] is overwritten each time,
+    so the last variable added for a witness is the one the gates name.  For |P| <= 1 this is one variable per witness.
+    layout="one_var" is that one-variable-per-witness layout for any |P| (what HandleValues presumably meant)."""
+    pub = list(public_inputs)
+    order, index = [], {}
+    if layout == "reference":
+        for i in range(1, n_values + 1):
+            for p in pub:
+                if i == p:
+                    index[i] = len(order)
+                    order.append(i)
+        n_public = len(order)
+        for i in range(1, n_values + 1):
+            if pub:
+                for p in pub:
+                    if i != p:
+                        index[i] = len(order)
+                        order.append(i)
+            else:
+                index[i] = len(order)
+                order.append(i)
+        return order, index, n_public
+    assert layout == "one_var", layout
+    order = [i for i in range(1, n_values + 1) if i in pub] + [i for i in range(1, n_values + 1) if i not in pub]
+    return order, {w: k for k, w in enumerate(order)}, len([i for i in order if i in pub])
+
+
+def sparse_r1cs_from_acir(acir: dict, values, layout: str = "reference"):
     """The reference's lowering of an ACIR circuit (backend/plonk/sparse_r1cs.go:18-107 + backend/common.go:45-76): arithmetic opcodes
-    become gates (only MulTerms[0]; SimpleTerms of length 1 -> qO, 2 -> qL, qR, 3 -> qL, qR, qO); directives and black-box calls emit
-    nothing.  `values` = witness values 1 .. current_witness-1 in index order.  Returns (spr, solution) with the public variables first.
-    (With two or more public inputs the reference's HandleValues appends secrets once per non-matching public input, common.go:59-68 --
-    an upstream bug that is NOT reproduced: every secret appears once.)"""
-    pub = list(acir.get("public_inputs", []))
-    n_w = acir["current_witness_index"]
-    order = [i for i in range(1, n_w + 1) if i in pub] + [i for i in range(1, n_w + 1) if i not in pub]
-    order = [i for i in order if i - 1 < len(values)]
-    index = {w: k for k, w in enumerate(order)}
+    become gates (only MulTerms[0]; SimpleTerms of length 1 -> qO, 2 -> qL, qR, 3 -> qL, qR, qO, any other length -> none); directives and
+    black-box calls emit nothing.  `values` = the witness values handed over (witness i = values[i - 1]).  Returns (spr, solution) with the
+    public variables first; the variable layout is handle_values(..., layout).  In the reference layout a term naming a witness that has
+    no variable gets variable 0 -- Go's map lookup yields the zero value (sparse_r1cs.go:53-54) -- in "one_var" that is a KeyError."""
+    order, index, n_public = handle_values(acir.get("public_inputs", []), len(values), layout)
+    var = (lambda w: index.get(w, 0)) if layout == "reference" else (lambda w: index[w])
     solution = [values[w - 1] % R for w in order]
     h2i = lambda h: int(h, 16) % R
     gates = []
@@ -72,17 +103,17 @@ def sparse_r1cs_from_acir(acir: dict, values):
         xa = xb = xc = 0
         if a["mul_terms"]:
             c, wl, wr = a["mul_terms"][0]
-            qm, xa, xb = h2i(c), index[wl], index[wr]
+            qm, xa, xb = h2i(c), var(wl), var(wr)
         lin = a["linear_combinations"]
         if len(lin) == 1:
-            qo, xc = h2i(lin[0][0]), index[lin[0][1]]
-        elif len(lin) >= 2:
-            ql, xa = h2i(lin[0][0]), index[lin[0][1]]
-            qr, xb = h2i(lin[1][0]), index[lin[1][1]]
+            qo, xc = h2i(lin[0][0]), var(lin[0][1])
+        elif len(lin) in (2, 3):
+            ql, xa = h2i(lin[0][0]), var(lin[0][1])
+            qr, xb = h2i(lin[1][0]), var(lin[1][1])
             if len(lin) == 3:
-                qo, xc = h2i(lin[2][0]), index[lin[2][1]]
+                qo, xc = h2i(lin[2][0]), var(lin[2][1])
         gates.append((ql, qr, qo, qm, h2i(a["q_c"]), xa, xb, xc))
-    return SparseR1CS(len([i for i in order if i in pub]), len([i for i in order if i not in pub]), gates), solution
+    return SparseR1CS(n_public, len(order) - n_public, gates), solution
 
 
 # ------------------------------------------------------------------------------------------------ plumbing (python <-> C oracle)

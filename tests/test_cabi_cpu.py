@@ -87,10 +87,13 @@ def test_acir_lowering_matches_the_oracle_on_the_reference_fixtures():
     import json
     from noir_backend_using_gnark_amd import frontend as fe
     from oracle import plonk_ref as pl
-    for e in json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_golden.json"))):
+    fixtures = json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_golden.json")))
+    for e in fixtures:
         values = [int(v, 16) for v in e["values"]]
         spr, sol = pl.sparse_r1cs_from_acir(e["acir"], values)
         got = fe.acir_to_sparse_r1cs(json.dumps(e["acir"]), len(values))
+        one = fe.acir_to_sparse_r1cs(json.dumps(e["acir"]), len(values), fe.LAYOUT_ONE_VAR_PER_WITNESS)   # zero or one public input: the layouts coincide
+        assert all((got[k] == one[k]).all() if hasattr(got[k], "all") else got[k] == one[k] for k in got)
         assert got["n_public"] == spr.n_public and got["n_vars"] == spr.n_vars
         g = spr.constraints
         for k, name in enumerate(("ql", "qr", "qo", "qm", "qk")):
@@ -99,13 +102,78 @@ def test_acir_lowering_matches_the_oracle_on_the_reference_fixtures():
         assert [values[i] for i in got["order"]] == sol
     # malformed inputs are errors, not crashes
     for bad in ("", "[]", '{"opcodes": 3}', '{"opcodes":[{"Foo":{}}],"public_inputs":[]}', '{"opcodes":[{"Arithmetic":{"mul_terms":[["zz",1,2]],"linear_combinations":[],"q_c":"00"}}]}',
-                '{"opcodes":[{"Arithmetic":{"mul_terms":[],"linear_combinations":[["01",99]],"q_c":"00"}}],"public_inputs":[]}', '{"opcodes":[' + "[" * 100):
-        with pytest.raises(ValueError):
-            fe.acir_to_sparse_r1cs(bad, 6)
-    # two public inputs: each witness is one variable, the public ones first in witness order
+                '{"opcodes":[' + "[" * 100, '{"opcodes":[],"public_inputs":[1.5]}', '{"opcodes":[{"Arithmetic":{"mul_terms":[],"linear_combinations":[["01",-3]],"q_c":"00"}}]}'):
+        for layout in (fe.LAYOUT_REFERENCE, fe.LAYOUT_ONE_VAR_PER_WITNESS):
+            with pytest.raises(ValueError):
+                fe.acir_to_sparse_r1cs(bad, 6, layout)
+    with pytest.raises(ValueError):
+        fe.acir_to_sparse_r1cs(json.dumps(fixtures[0]["acir"]), 6, 7)   # no such layout
+    # a term naming a witness without a variable: the reference's map lookup yields variable 0 (sparse_r1cs.go:53-54); the other layout refuses
+    ghost = '{"opcodes":[{"Arithmetic":{"mul_terms":[],"linear_combinations":[["01",99]],"q_c":"00"}}],"public_inputs":[]}'
+    got = fe.acir_to_sparse_r1cs(ghost, 6)
+    assert got["n_vars"] == 6 and int(got["xc"][0]) == 0
+    assert pl.sparse_r1cs_from_acir(json.loads(ghost) | {"current_witness_index": 6}, [1] * 6)[0].constraints[0][7] == 0
+    with pytest.raises(ValueError):
+        fe.acir_to_sparse_r1cs(ghost, 6, fe.LAYOUT_ONE_VAR_PER_WITNESS)
+    # four linear terms: no case of handleArithmeticOpcode matches (sparse_r1cs.go:58-90) -- the gate keeps only q_c
+    four = '{"opcodes":[{"Arithmetic":{"mul_terms":[],"linear_combinations":[["01",1],["01",2],["01",3],["01",4]],"q_c":"05"}}],"public_inputs":[]}'
+    got = fe.acir_to_sparse_r1cs(four, 4)
+    ospr, _ = pl.sparse_r1cs_from_acir(json.loads(four), [1, 2, 3, 4])
+    assert ospr.constraints[0] == (0, 0, 0, 0, 5, 0, 0, 0) and (got["ql"] == 0).all() and (got["qr"] == 0).all() and (got["qo"] == 0).all() and (got["qk"] == pl.ints_to_mont_np([5])).all()
+
+
+def test_handle_values_layouts_match_the_oracle_for_two_and_three_public_inputs():
+    """HandleValues (backend/common.go:45-76) literally -- one secret variable per (witness, non-matching public input), the gates on the LAST copy --
+    against oracle/plonk_ref.handle_values and the committed fixture (tests/golden/plonk_multi_public_golden.json), next to the one-variable-per-witness
+    layout; hand-checked on public_inputs = [3, 1] over four witnesses."""
+    import json
+    from noir_backend_using_gnark_amd import frontend as fe
+    from oracle import plonk_ref as pl
     two = {"current_witness_index": 4, "public_inputs": [3, 1], "opcodes": [{"Arithmetic": {"mul_terms": [["01", 1, 2]], "linear_combinations": [["%064x" % (ref.R - 1), 3]], "q_c": "00"}}]}
-    got = fe.acir_to_sparse_r1cs(json.dumps(two), 4)
+    got = fe.acir_to_sparse_r1cs(json.dumps(two), 4, fe.LAYOUT_ONE_VAR_PER_WITNESS)
     assert got["n_public"] == 2 and got["n_vars"] == 4 and list(got["order"]) == [0, 2, 1, 3] and (got["xa"][0], got["xb"][0], got["xc"][0]) == (0, 2, 1)
+    # reference: publics w1, w3 | w1: copy for p=3 | w2: copies for p=3, p=1 | w3: copy for p=1 | w4: two copies  -> 8 variables, gates on the last copies
+    got = fe.acir_to_sparse_r1cs(json.dumps(two), 4)
+    assert got["n_public"] == 2 and got["n_vars"] == 8 and list(got["order"]) == [0, 2, 0, 1, 1, 2, 3, 3] and (got["xa"][0], got["xb"][0], got["xc"][0]) == (2, 4, 5)
+    # duplicates in public_inputs make duplicate public variables (loop 1 runs per pair), and zero copies against themselves
+    dup = dict(two, public_inputs=[2, 2])
+    got = fe.acir_to_sparse_r1cs(json.dumps(dup), 4)
+    o, idx, npub = pl.handle_values([2, 2], 4)
+    assert got["n_public"] == npub == 2 and list(got["order"]) == [w - 1 for w in o] == [1, 1, 0, 0, 2, 2, 3, 3] and (got["xa"][0], got["xb"][0], got["xc"][0]) == (idx[1], idx[2], idx[3]) == (3, 1, 5)
+    names = {"reference": fe.LAYOUT_REFERENCE, "one_var": fe.LAYOUT_ONE_VAR_PER_WITNESS}
+    for e in json.load(open(os.path.join(ROOT, "tests", "golden", "plonk_multi_public_golden.json"))):
+        values = [int(v, 16) for v in e["values"]]
+        for lname, lay in e["layouts"].items():
+            spr, sol = pl.sparse_r1cs_from_acir(e["acir"], values, layout=lname)
+            got = fe.acir_to_sparse_r1cs(json.dumps(e["acir"]), len(values), names[lname])
+            assert got["n_public"] == spr.n_public == lay["n_public"] and got["n_vars"] == spr.n_vars == lay["n_vars"], (e["name"], lname)
+            assert list(got["order"]) == lay["order"] and [values[i] for i in got["order"]] == sol == [int(v, 16) for v in lay["solution"]]
+            g = spr.constraints
+            assert [[("%064x" % c) for c in q[:5]] + list(q[5:]) for q in g] == lay["gates"]
+            for k, name in enumerate(("ql", "qr", "qo", "qm", "qk")):
+                assert (got[name] == pl.ints_to_mont_np([c[k] for c in g])).all(), name
+            assert [list(got[n]) for n in ("xa", "xb", "xc")] == [[c[5] for c in g], [c[6] for c in g], [c[7] for c in g]]
+        assert e["layouts"]["reference"]["n_vars"] > e["layouts"]["one_var"]["n_vars"] == len(values)
+
+
+def test_shipped_libraries_have_no_experiment_switches():
+    """The product libraries are loaded into the prover's process: no environment variable may change a result or crash them.  libzkmi.so reads exactly two
+    validated settings (csrc/ctx.hpp), libgnark_backend.so one (the size of a newly created SRS); every A/B switch of DESIGN.md is compiled out unless the
+    library is built with -DZKMI_EXPERIMENTS (libzkmi_exp.so, measurement tooling) -- checked on the strings the binaries contain."""
+    import re
+
+    def names(path):
+        return set(re.findall(rb"ZKMI_[A-Z0-9_]+", open(path, "rb").read()))
+
+    pkg = os.path.join(ROOT, "noir_backend_using_gnark_amd")
+    assert names(os.path.join(pkg, "libzkmi.so")) == {b"ZKMI_TABLE_CAP_GB", b"ZKMI_SLOT_TIMEOUT_S"}
+    assert names(os.path.join(pkg, "libgnark_backend.so")) == {b"ZKMI_SRS_SIZE"}
+    # and the sources read the environment nowhere else
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            src = open(os.path.join(pkg, "csrc", f)).read()
+            for m in re.finditer(r'getenv\("([A-Z_0-9]+)"\)', src):
+                assert m.group(1) in ("ZKMI_SRS_SIZE", "XDG_CONFIG_HOME", "HOME"), (f, m.group(1))
 
 
 def test_host_parsers_survive_mutated_inputs():
@@ -148,7 +216,7 @@ def test_host_parsers_survive_mutated_inputs():
     seen = set()
     for it in range(3000):
         a = mutate(acirs[it % len(acirs)])
-        rc = L.zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(rnd.choice([0, 1, 6, 7, 1000])), C.byref(npub), C.byref(nvars), C.byref(nc), *([None] * 9))
+        rc = L.zk_acir_to_sparse_r1cs(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(rnd.choice([0, 1, 6, 7, 1000])), C.c_int(it & 1), C.byref(npub), C.byref(nvars), C.byref(nc), *([None] * 9))
         assert rc in ok_codes, (rc, a)
         seen.add(rc)
     assert _lib.ZK_OK in seen and _lib.ZK_ERR_ARG in seen  # some mutants stay valid circuits, most do not

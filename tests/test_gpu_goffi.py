@@ -92,19 +92,75 @@ def test_groth16_exports_end_to_end(tmp_path):
     assert len(opk["infinity_a"]) == r1.n_wires and len(opk["g1_k"]) == r1.n_wires - r1.n_public
 
 
-def test_a_corrupt_srs_file_is_replaced(tmp_path):
-    """LoadSRS failing for any reason means `generate and save` upstream (common.go:128-141): a truncated srs.hex is overwritten by a fresh SRS and the
-    call succeeds."""
+def test_only_an_unreadable_or_non_hex_srs_file_is_replaced(tmp_path):
+    """LoadSRS fails -- and TryLoadSRS generates and saves a new SRS -- exactly when srs.hex cannot be read or is not hex (common.go:86-104, 127-141); what
+    ReadFrom makes of hex that is not an SRS is ignored there and the prover then dies on the broken SRS.  Here: a non-hex file is replaced and the call
+    succeeds; a file that IS hex but not an SRS ends the process and is left exactly as it was (regenerating would silently invalidate every key issued
+    against the old SRS); no temporary file is left behind by the save."""
     e = json.load(open(os.path.join(HERE, "golden", "plonk_golden.json")))[1]
     cfg = tmp_path / "cfg" / "noir-lang"
     os.makedirs(cfg, exist_ok=True)
-    (cfg / "srs.hex").write_text("00ff" * 40)
     values = [h2i(v) for v in e["values"]]
     job = dict(what="plonk", acir=json.dumps(e["acir"]), values=ref.felts_wire(values).hex(), values_wrong_public=ref.felts_wire(values).hex(),
                random_values=ref.felts_wire(values).hex())
-    a = run_worker(tmp_path, job, "corrupt")
+    (cfg / "srs.hex").write_text("this is not hex\n")
+    a = run_worker(tmp_path, job, "nonhex")
     assert a["verifies"] == 1
     assert len((cfg / "srs.hex").read_text()) == 2 * (132 + 32 * 64)
+    assert sorted(p.name for p in cfg.iterdir()) == ["srs.hex", "srs.hex.lock"]
+    (cfg / "srs.hex").write_text("00ff" * 40)
+    out = run_worker(tmp_path, job, "truncated", expect_fail=True)
+    assert out.returncode == 1 and "LoadSRS" in out.stderr
+    assert (cfg / "srs.hex").read_text() == "00ff" * 40
+
+
+def test_concurrent_first_calls_agree_on_one_srs(tmp_path):
+    """Two processes that both find no srs.hex (the reference's tests start provers side by side) must end up with ONE SRS: the second waits for the first
+    one's file instead of drawing its own alpha, so each accepts the other's proof under the other's key."""
+    import threading
+    e = json.load(open(os.path.join(HERE, "golden", "plonk_golden.json")))[1]
+    os.makedirs(tmp_path / "cfg", exist_ok=True)
+    values = [h2i(v) for v in e["values"]]
+    job = dict(what="plonk", acir=json.dumps(e["acir"]), values=ref.felts_wire(values).hex(), values_wrong_public=ref.felts_wire(values).hex(),
+               random_values=ref.felts_wire(values).hex())
+    res = {}
+    ts = [threading.Thread(target=lambda k=k: res.__setitem__(k, run_worker(tmp_path, job, "race%d" % k))) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert res[0]["verifies"] == 1 and res[1]["verifies"] == 1
+    assert res[0]["vk"] == res[1]["vk"] and res[0]["pk"] == res[1]["pk"]   # same SRS => same Setup output
+    c = run_worker(tmp_path, dict(job, pk=res[0]["pk"], vk=res[0]["vk"], proof=res[1]["proof"]), "race_cross")
+    assert c["verifies"] == 1
+
+
+def test_plonk_exports_use_the_reference_variable_layout_for_several_public_inputs(tmp_path):
+    """public_inputs = [1, 2] and [1, 2, 5] through Go's ABI: the key bytes PlonkPreprocess returns are those of the oracle's literal HandleValues
+    (backend/common.go:45-76) under the SRS the shim wrote -- NOT those of the one-variable-per-witness layout -- and PlonkVerifyWithVK accepts the proof with
+    the public values picked in witness order, rejects another public value."""
+    os.makedirs(tmp_path / "cfg", exist_ok=True)
+    for k, e in enumerate(json.load(open(os.path.join(HERE, "golden", "plonk_multi_public_golden.json")))):
+        values = [h2i(v) for v in e["values"]]
+        wrong = list(values)
+        p0 = e["acir"]["public_inputs"][-1]
+        wrong[p0 - 1] = (wrong[p0 - 1] + 1) % ref.R
+        job = dict(what="plonk", acir=json.dumps(e["acir"]), values=ref.felts_wire(values).hex(), values_wrong_public=ref.felts_wire(wrong).hex(),
+                   random_values=ref.felts_wire(ref.rand_felts(91 + k, len(values))).hex())
+        a = run_worker(tmp_path, job, "multi%d" % k)
+        assert a["verifies"] == 1 and a["verifies_wrong_public"] == 0, e["name"]
+        srs = pl.kzg_srs_from_bytes(bytes.fromhex((tmp_path / "cfg" / "noir-lang" / "srs.hex").read_text()))
+        spr, sol = pl.sparse_r1cs_from_acir(e["acir"], values, layout="reference")
+        assert (spr.n_public, spr.n_vars) == (e["layouts"]["reference"]["n_public"], e["layouts"]["reference"]["n_vars"])
+        opk, ovk = pl.plonk_setup(spr, srs)
+        assert pl.plonk_pk_bytes(opk).hex() == a["pk"] and pl.plonk_vk_bytes(ovk).hex() == a["vk"], e["name"]
+        spr1, _ = pl.sparse_r1cs_from_acir(e["acir"], values, layout="one_var")
+        assert pl.plonk_pk_bytes(pl.plonk_setup(spr1, srs)[0]).hex() != a["pk"]
+        p2 = bytes.fromhex(a["proof"])
+        pts = [pl.g1_decompress(p2[32 * i:32 * i + 32]) for i in range(7)]
+        pr = dict(lro=pts[0:3], z=pts[3], h=pts[4:7], batch_h=pl.g1_decompress(p2[224:256]), claimed=[int.from_bytes(p2[260 + 32 * i:292 + 32 * i], "big") for i in range(7)],
+                  z_open_h=pl.g1_decompress(p2[484:516]), zu=int.from_bytes(p2[516:548], "big"))
+        assert pl.plonk_verify(ovk, pr, sol[:spr.n_public])
 
 
 def test_errors_end_the_process_like_log_fatal(tmp_path):

@@ -322,6 +322,40 @@ def test_plonk_preprocess_and_prove_with_pk_on_the_reference_fixtures(plonk_gold
         srs.free()
 
 
+def test_plonk_exports_reproduce_handle_values_for_two_and_three_public_inputs():
+    """The reference's variable layout with SEVERAL public inputs (backend/common.go:45-76: one secret variable per (witness, non-matching public input),
+    gates on the last copy): key, verifying key and proof bytes of zk_plonk_preprocess / zk_plonk_prove_with_pk equal the oracle's literal restatement
+    (tests/golden/plonk_multi_public_golden.json, layout "reference" -- the default); the one-variable-per-witness layout gives its own, different bytes;
+    a key made in one layout is refused with a circuit lowered in the other."""
+    import json as js
+    from noir_backend_using_gnark_amd import frontend as fe, kzg
+    names = {"reference": fe.LAYOUT_REFERENCE, "one_var": fe.LAYOUT_ONE_VAR_PER_WITNESS}
+    for e in js.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plonk_multi_public_golden.json"))):
+        acir = js.dumps(e["acir"])
+        values = [h2i(v) for v in e["values"]]
+        enc = ref.felts_wire(values).hex()
+        bl = M([h2i(v) for v in e["blinders"]])
+        keys = {}
+        for lname, lay in e["layouts"].items():
+            srs = kzg.new_srs(lay["srs_size"], M([h2i(e["srs_alpha"])])[0])
+            pk_hex, vk_hex, h = fe.plonk_preprocess(acir, enc, srs, keep_resident=True, layout=names[lname])
+            assert pk_hex == lay["pk_hex"] and vk_hex == lay["vk_hex"], (e["name"], lname)
+            assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl, layout=names[lname]) == lay["proof"], (e["name"], lname)
+            assert fe.plonk_prove_with_pk(acir, enc, None, srs, blinders=bl, pk_handle=h, layout=names[lname]) == lay["proof"]
+            keys[lname] = (pk_hex, srs, h)
+        # the default IS the reference layout
+        pk_hex, srs, h = keys["reference"]
+        assert fe.plonk_preprocess(acir, enc, srs)[0] == pk_hex and fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["layouts"]["reference"]["proof"]
+        # crossing the layouts: the key's variable count is not the circuit's
+        with pytest.raises((ValueError, _lib.ZkmiError)):
+            fe.plonk_prove_with_pk(acir, enc, keys["one_var"][0], srs, blinders=bl)
+        with pytest.raises((ValueError, _lib.ZkmiError)):
+            fe.plonk_prove_with_pk(acir, enc, None, srs, blinders=bl, pk_handle=keys["one_var"][2])
+        for _, s_, h_ in keys.values():
+            _lib.check(_lib.lib().zk_bn254_plonk_pk_free(C.c_uint64(h_)))
+            s_.free()
+
+
 def test_plonk_2p20_gates_accepted_by_both_verifiers():
     """Size-independent property at 2^20 gates (the block bench.py runs at 2^22, configs[3]): a proof of a synthetic circuit made on the device is accepted
     by the oracle's pairing verifier AND by the product's host-side verifier reading the wire images; both reject another public input."""
