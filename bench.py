@@ -181,7 +181,9 @@ def plonk_block(L, lib, log_n, reps=3):
     out = {"gates": n, "prove_ms": round(ms, 2), "steps": reps, "warmup": 1, "setup_ms": round(t_setup * 1e3, 1), "data_s": round(t_data, 2),
            "kzg_commits_per_proof": "10 (9 as MSMs; the linearised polynomial's digest by linearity from the verifying key and [Z])", "ntt_per_proof": "4 x inverse(n) + 4 x coset(4n) + 1 x coset inverse(4n) (gnark's fifth pair -- qk with the public inputs -- is one element-wise kernel here)",
            "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
-           "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]}}
+           "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]},
+           # every commitment is one accumulate launch over ~n scalars against the SRS's window table; the transforms' passes work on n (small domain) or 4n points
+           "roofline": block_roofline(prof, reps, n, 0, 4 * n, log_n)}
     # ---- checker (CPU oracle, after the timed region): decode Proof.WriteTo and run plonk.Verify's equations
     from oracle import bn254_ref as ref, plonk_ref as pl
 
@@ -218,6 +220,125 @@ def plonk_block(L, lib, log_n, reps=3):
 
 
 R_FR = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+HAND_WRITTEN_HOT = ("msm_accumulate_g1", "msm_accumulate_g2", "ntt_pass_contig", "ntt_pass_strided", "msm_sort_pass", "msm_sort_hist")
+
+
+def dominant_by_time(prof, steps):
+    """The kernel with the largest total time in the timed region, whatever it is -- library kernels included (rocPRIM's radix sort is timed as one event pair
+    around the whole library call; every other entry is one kernel).  `roofline` below prices the dominant HAND-WRITTEN hot kernel; when this entry names
+    another kernel, that one is the larger consumer of kernel time."""
+    if not prof:
+        return None
+    name, (launches, tot) = max(prof.items(), key=lambda kv: kv[1][1])
+    return {"kernel": name, "ms_per_step": round(tot / steps, 4), "launches_per_step": round(launches / steps, 2), "hand_written": "rocprim" not in name}
+
+
+def block_roofline(prof, steps, g1_units_per_launch, g2_units_per_launch, ntt_elems_per_launch, log_key, tables=True):
+    """`roofline` for one measured block (same definition as the headline's): dominant hand-written hot kernel by total time, achieved = algorithmic bytes
+    per launch / average launch duration (event pairs inside libzkmi on the stream of the launch), traffic from profiles/pmc_traffic.json at that size."""
+    hot = {k: v for k, v in prof.items() if k in HAND_WRITTEN_HOT[:4]}
+    if not hot:
+        return None
+    name, (launches, tot_ms) = max(hot.items(), key=lambda kv: kv[1][1])
+    per = tot_ms / launches
+    units, bpu = {"msm_accumulate_g1": (g1_units_per_launch, 96.0), "msm_accumulate_g2": (g2_units_per_launch, 160.0)}.get(name, (ntt_elems_per_launch, 64.0))
+    achieved = units * bpu / (per * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath) and tables:
+        try:
+            traffic = json.load(open(tpath)).get(name, {}).get("by_log_n", {}).get(str(log_key), {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "avg_launch_ms": round(per, 4), "launches": launches, "units_per_launch": int(units), "algorithmic_bytes_per_unit": bpu,
+            "dominant_by_time": dominant_by_time(prof, steps),
+            "kernel_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]}}
+
+
+def inner_boundary_block(L, lib, zk, par, inst, proof):
+    """north_star's literal flow: gnark itself keeps running groth16.Prove and calls the replacement at its gnark-crypto call sites -- MultiExp x5 and
+    (*Domain).FFT / FFTInverse x7 -- through the inner C ABI with HOST slices (zk_bn254_msm_bases against base arrays registered once
+    per key, zk_bn254_ntt in place on the caller's slice).  Timed here call by call, scalars / coefficients crossing PCIe inside every call:
+      * the seven transforms of computeH in gnark's order: FFTInverse(DIF) x3, FFT(DIT, coset) x3, then FFTInverse(DIF, coset) (on one of the arrays: the
+        pointwise step between them is gnark's own Go code and is not part of the boundary);
+      * the five MultiExp calls, one after the other and -- as gnark issues them -- from five concurrent host threads.
+    Check: the proof assembled from the five affine results (h from the fused computeH entry point) through zk_bn254_groth16_finalize equals the bytes of
+    the single-call prover."""
+    import threading
+    from noir_backend_using_gnark_amd import bn254 as zb, groth16 as zg
+    N, npub = inst.N, inst.n_public
+    MONT = zk.MultiExpConfig(scalars_mont=True)
+    ha, hb, hc, hw = (d.to_numpy(np.uint64, (N, 4)) for d in (inst.d_a, inst.d_b, inst.d_c, inst.d_w))
+    t0 = time.perf_counter()
+    bases = [zb.ResidentBases(inst.g1_a, n=N), zb.ResidentBases(inst.g1_b, n=N), zb.ResidentBases(inst.g1_k.ptr + npub * 64, n=N - npub),
+             zb.ResidentBases(inst.g1_z, n=N), zb.ResidentBases(inst.g2_b, is_g2=True, n=N)]
+    lib.check(L.zk_dev_sync())
+    reg_s = time.perf_counter() - t0
+    dom = zk.Domain(N)
+    h = zg.compute_h(ha, hb, hc, inst.log_n)
+    scal = [hw, hw, hw[npub:], h[:N - 1], hw]
+
+    def ntt7():
+        a, b, c = ha.copy(), hb.copy(), hc.copy()
+        ts = []
+        for f in ([lambda v=v: dom.fft_inverse(v, zk.DIF) for v in (a, b, c)] + [lambda v=v: dom.fft(v, zk.DIT, True) for v in (a, b, c)] +
+                  [lambda: dom.fft_inverse(a, zk.DIF, True)]):
+            t = time.perf_counter()
+            f()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return ts
+
+    def msm5_seq():
+        out, ts = [], []
+        for bs, sc in zip(bases, scal):
+            t = time.perf_counter()
+            out.append(bs.multi_exp(sc, config=MONT))
+            ts.append((time.perf_counter() - t) * 1e3)
+        return out, ts
+
+    def msm5_conc():
+        out = [None] * 5
+        th = [threading.Thread(target=lambda k=k: out.__setitem__(k, bases[k].multi_exp(scal[k], config=MONT))) for k in range(5)]
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return out, (time.perf_counter() - t) * 1e3
+
+    ntt7(), msm5_seq(), msm5_conc()  # warm: domain tables, workspaces
+    reps = 3
+    ntt_ms = np.mean([ntt7() for _ in range(reps)], axis=0)
+    seq = [msm5_seq() for _ in range(reps)]
+    msm_ms = np.mean([t for _, t in seq], axis=0)
+    conc = [msm5_conc() for _ in range(reps)]
+    conc_ms = float(np.mean([t for _, t in conc]))
+    # the proof from the five affine results: XYZZ records (x, y, 1, 1), infinity = all zero
+    one = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)   # 1 in Montgomery form (Fp)
+    zero = np.zeros(4, np.uint64)
+
+    def record(res):
+        parts = []
+        for k, p in enumerate(res):
+            if not p.any():
+                parts.append(np.zeros(32 if k == 4 else 16, np.uint64))
+            else:
+                parts.append(np.concatenate([p, one, zero, one, zero] if k == 4 else [p, one, one]))
+        return np.concatenate(parts)
+
+    ok = all(par.groth16_finalize(inst.pk, record(res)[None, :], inst.r, inst.s) == proof for res in (seq[-1][0], conc[-1][0]))
+    for bs in bases:
+        bs.free()
+    return {"what": "the same 2^%d proof's hot operations through the inner C ABI with host slices, call by call (zk_bn254_ntt x7, zk_bn254_msm_bases x5)" % inst.log_n,
+            "ntt_calls_ms": [round(float(x), 3) for x in ntt_ms], "ntt_total_ms": round(float(ntt_ms.sum()), 3),
+            "msm_calls_ms": dict(zip(("A", "B1", "K", "Z", "B2"), (round(float(x), 3) for x in msm_ms))), "msm_total_sequential_ms": round(float(msm_ms.sum()), 3),
+            "msm_total_five_threads_ms": round(conc_ms, 3), "total_ms": round(float(ntt_ms.sum()) + conc_ms, 3), "reps": reps,
+            "bytes_over_pcie_per_proof": int(7 * 2 * N * 32 + 5 * N * 32), "bases_register_s_once_per_key": round(reg_s, 3),
+            "proof_from_these_results_matches_single_call": bool(ok),
+            "note": "PCIe-inclusive (never `value`); excludes gnark's own Go code between the calls (the pointwise step of computeH, the solver, the host tail)"}
+
+
 
 
 def micro_block(L, lib, zk, log_n):
@@ -448,7 +569,7 @@ def main():
     # ---- roofline of the dominant kernel (by total time over the timed region)
     # restricted to the hand-written hot kernels of the path; with the five MSMs of a proof running on concurrent
     # streams an event pair also sees the time a kernel spends sharing the machine, exactly as rocprofv3 does
-    hot = {k: v for k, v in prof.items() if k in ("msm_accumulate_g1", "msm_accumulate_g2", "ntt_pass_contig", "ntt_pass_strided")}
+    hot = {k: v for k, v in prof.items() if k in HAND_WRITTEN_HOT[:4]}
     name, (launches, tot_ms) = max(hot.items(), key=lambda kv: kv[1][1])
     per_launch_ms = tot_ms / launches
     if name == "msm_accumulate_g1":
@@ -481,7 +602,7 @@ def main():
                 "frac": round(madds / (per_launch_ms * 1e-3) / peak, 4), "window_bits": int(wb.value), "peak_source": "tools/ubench.hip k_madd29, 4 waves/SIMD: 17.44 G madd/s (9,017 cycles per wave)"}
     roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "avg_launch_ms": round(per_launch_ms, 4), "launches": launches, "valu": valu,
+                "avg_launch_ms": round(per_launch_ms, 4), "launches": launches, "valu": valu, "dominant_by_time": dominant_by_time(prof, args.steps),
                 "note": "VALU-bound kernel (254-bit modular multiplies on 32-bit integer ALUs); see DESIGN.md for the ALU-issue fraction",
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
 
@@ -530,6 +651,12 @@ def main():
                                        "note": "zk_bn254_groth16_prove(on_device=0): a, b, c, w are pageable host arrays uploaded inside the call"}
         del ha, hb, hc, hw
 
+    # ---- the same proof's hot operations through the INNER boundary, call by call, with host slices (north_star's literal flow)
+    if single and not args.no_host_inputs and log_n <= 22:
+        out["inner_boundary_2p%d" % log_n] = inner_boundary_block(L, _lib, zk, par, inst, proof)
+        if not out["inner_boundary_2p%d" % log_n]["proof_from_these_results_matches_single_call"]:
+            out["parity_error"] = "inner boundary: the proof assembled from separate MultiExp calls differs from the single-call prover's"
+
     # ---- the same key with a witness-like wire vector (SURVEY 8d cfg2's second distribution: 50 % in {0, 1}, 25 % < 2^32, 25 % uniform): giant buckets, split tasks, folds
     if single and not args.no_host_inputs and args.scalars == "uniform":
         d_w2 = _lib.DeviceBuffer(N_g * 32)
@@ -566,15 +693,21 @@ def main():
         p24 = run24()
         _lib.check(L.zk_dev_sync())
         reps = 5
+        _lib.profile(True)
+        _lib.profile_reset()
         t0 = time.perf_counter()
         for _ in range(reps):
             p24 = run24()
         _lib.check(L.zk_dev_sync())
         ms24 = (time.perf_counter() - t0) / reps * 1e3
+        _lib.profile(False)
+        prof24 = _lib.profile_read()
         blk = {"constraints": big.N, "prove_ms": round(ms24, 2), "value": round(big.g1_units() / (ms24 * 1e-3), 1), "unit": out["unit"], "steps": reps,
                "warmup": 1, "setup_s": round(setup24, 2), "proof_sha": hashlib.sha256(p24).hexdigest()[:16], "window_tables": bool(big.pk.info()["tables"]),
                "verified_by": "two-slice recombination through the table-less msm5 path + finalize (independent window width / Horner / task sizes)",
                "proof_bytes_match_recombination": bool(two_slice_recombination(big, par, _lib, L) == p24)}
+        n24 = prof24.get("msm_accumulate_g1", (1, 0))[0]
+        blk["roofline"] = block_roofline(prof24, reps, big.g1_units() / max(1.0, n24 / float(reps)), big.N, big.N, 24)
         if not blk["proof_bytes_match_recombination"]:
             out["parity_error"] = "2^24: single-call proof differs from the two-slice recombination"
         if args.verify_2p24_oracle:

@@ -29,6 +29,20 @@ static inline long zk_exp_env(const char* name, long dflt) {
 #else
 #define ZK_EXP(name, dflt) (dflt)
 #endif
+// Wave priority of the short kernels (scalar preparation, transforms, reduction tails).  A SIMD arbitrates VALU issue by priority, then AGE
+// (MI355X_MICROARCH.md "Two waves per SIMD"): next to the long-lived waves of an accumulate kernel -- always older -- a young wave only gets the issue
+// slots they leave, which is why these kernels took 3-6x their stand-alone time inside a proof.  -DZKMI_PRIO_HI=n (1..3) raises them above the
+// accumulate kernels (priority 0); 0 compiles the call away.
+#ifndef ZKMI_PRIO_HI
+#define ZKMI_PRIO_HI 0
+#endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ void prio_hi() {
+#if ZKMI_PRIO_HI
+    __builtin_amdgcn_s_setprio(ZKMI_PRIO_HI);
+#endif
+}
+#endif
 // a validated setting: an integer in [lo, hi], anything else (unset, not a number, out of range) is the default
 static inline long zk_env_bounded(const char* name, long dflt, long lo, long hi) {
     const char* v = getenv(name);

@@ -33,6 +33,7 @@
 #include "ff29.hpp"
 #include "host_ff.hpp"
 #include "msm.hpp"
+#include "radix.hpp"
 
 namespace zkmi {
 
@@ -46,6 +47,30 @@ static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, rocprim::double_buffe
     static const int cfg = ZK_EXP("ZKMI_SORT_CFG", 0);
     if (cfg == 1) return rocprim::radix_sort_pairs<SortWide>(tmp, tmp_bytes, kb, vb, n, 0, key_bits, st);
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, n, 0, key_bits, st);
+}
+
+// The hand-written sort of radix.hpp (no workgroup ever waits for another one), same contract as sort_pairs: sorted pairs end up in kb / vb's current buffers.
+static int rs_sort_pairs(Slot* s, hipStream_t st, void* tmp, rocprim::double_buffer<uint32_t>& kb, rocprim::double_buffer<uint32_t>& vb, size_t n, unsigned key_bits) {
+    const RsPlan R = rs_plan(n, key_bits);
+    uint32_t* tile_hist = (uint32_t*)tmp;
+    uint32_t* ghist = tile_hist + (size_t)RS_MAX_BINS * R.ntiles;
+    uint32_t* gbase = ghist + RS_MAX_PASSES * RS_MAX_BINS;
+    RsArgs A;
+    A.npass = R.npass;
+    for (unsigned p = 0; p < RS_MAX_PASSES; p++) { A.shift[p] = R.shift[p]; A.bits[p] = R.bits[p]; }
+    const unsigned nt = (unsigned)R.ntiles;
+    ZK_HIP(hipMemsetAsync(ghist, 0, RS_MAX_PASSES * RS_MAX_BINS * 4, st));
+    ZK_LAUNCH(s, st, "msm_sort_hist", k_rs_hist, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (uint32_t)n, A, nt, ghist, tile_hist);
+    ZK_LAUNCH(s, st, "msm_sort_bases", k_rs_bases, dim3(1), dim3(RS_MAX_BINS), 0, (const uint32_t*)ghist, gbase, R.npass);
+    for (unsigned p = 0; p < R.npass; p++) {
+        if (p) ZK_LAUNCH(s, st, "msm_sort_hist", k_rs_tile_hist, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (uint32_t)n, R.shift[p], R.bits[p], nt, tile_hist);
+        ZK_LAUNCH(s, st, "msm_sort_scan", k_rs_scan_rows, dim3(1u << R.bits[p]), dim3(256), 0, tile_hist, nt);
+        ZK_LAUNCH(s, st, "msm_sort_pass", k_rs_scatter, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (const uint32_t*)vb.current(), kb.alternate(), vb.alternate(),
+                  (uint32_t)n, R.shift[p], R.bits[p], nt, (const uint32_t*)tile_hist, (const uint32_t*)(gbase + p * RS_MAX_BINS));
+        kb.swap();
+        vb.swap();
+    }
+    return ZK_OK;
 }
 
 // ---------------------------------------------------------------------------------------- wide global loads/stores
@@ -93,6 +118,7 @@ __device__ __forceinline__ T shfl_xor_t(const T& v, unsigned d) {
 // rows this rank owns -- w = row_first + k * row_step -- are emitted, as row k of the rank's table.
 __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c, unsigned W, uint32_t* keys, uint32_t* vals,
                              uint32_t table_stride, unsigned row_first, unsigned row_step) {
+    prio_hi();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s;
@@ -143,6 +169,7 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
 // One lane per bucket, ~log2(total) dependent L2 hits each: no serial gap-filling loops whatever the key distribution
 // (the top window leaves ~20k empty buckets in a row for uniform scalars).
 __global__ void k_bucket_bounds(const uint32_t* __restrict__ keys, uint32_t total, uint32_t nb, uint32_t* __restrict__ start) {
+    prio_hi();
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
     uint32_t lo = 0, hi = total;  // answer in [lo, hi]
@@ -171,6 +198,7 @@ __device__ __forceinline__ uint32_t giant_seg(uint32_t cnt) {  // segment length
     return s < 64 ? 64 : s;
 }
 __global__ __launch_bounds__(256) void k_bucket_stats(const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ ctl) {
+    prio_hi();
     __shared__ uint32_t wmax[4];
     uint32_t len = 0;
     uint32_t big = 0;
@@ -190,6 +218,7 @@ __global__ __launch_bounds__(256) void k_bucket_stats(const uint32_t* __restrict
 }
 __global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t factor, uint32_t cap,
                            uint32_t* __restrict__ ctl) {
+    prio_hi();
     const uint32_t nnz = start[nb], biggest = ctl[1];
     const uint32_t q = (nnz + lanes - 1) / lanes;
     uint32_t lw = factor * q;
@@ -200,6 +229,7 @@ __global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint
     ctl[2] = min(L, Lmax);
 }
 __global__ void k_task_plan(const uint32_t* start, uint32_t nb, const uint32_t* __restrict__ ctl, uint32_t* ntasks, uint32_t* multi_list, uint32_t* num_multi) {
+    prio_hi();
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
     if (b == nb) { ntasks[b] = 0; return; }
@@ -226,6 +256,7 @@ constexpr uint32_t TS_BINS = 2048;
 __global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t Lmax,
                                                    const uint32_t* __restrict__ ctl, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
                                                    uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
+    prio_hi();
     const uint32_t L = ctl[2];  // the length the plan cut the buckets with; keys stay relative to Lmax (the accumulate kernel's argument)
     __shared__ uint32_t h[TS_BINS];
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
@@ -259,6 +290,7 @@ __global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ 
 
 // exclusive scan of the <= TS_BINS bin counts, in place (one workgroup)
 __global__ __launch_bounds__(256) void k_task_bins(uint32_t* __restrict__ hist, uint32_t nbins) {
+    prio_hi();
     __shared__ uint32_t part[256];
     constexpr uint32_t PER = TS_BINS / 256;
     uint32_t v[PER], sum = 0;
@@ -288,6 +320,7 @@ __global__ __launch_bounds__(256) void k_task_bins(uint32_t* __restrict__ hist, 
 __global__ __launch_bounds__(256) void k_task_scatter(const uint32_t* __restrict__ len_key, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ len_key_sorted,
                                                       uint32_t* __restrict__ task_sorted) {
+    prio_hi();
     __shared__ uint32_t h[TS_BINS], base[TS_BINS];
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
     __syncthreads();
@@ -313,19 +346,10 @@ struct AccBatch {
     void* partial[3];
     uint32_t skip_below[3];
 };
+// one task: the points vals[begin .. end) summed into partial[t]
 template <class F>
-__global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
-                                                    const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
-                                                    uint32_t max_tasks) {
-    const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
-    XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
-    const uint32_t skip_below = batch.skip_below[blockIdx.y];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= max_tasks) return;
-    uint32_t key = len_key_sorted[i];
-    if (key == 0xffffffffu) return;
-    uint32_t t = task_sorted[i];
-    uint32_t begin = task_begin[t], end = begin + (L - key);
+__device__ __forceinline__ void acc_task(const Affine<F>* __restrict__ pts, XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ vals, uint32_t skip_below,
+                                         uint32_t t, uint32_t begin, uint32_t end) {
     if constexpr (sizeof(F) == sizeof(Fp)) {
         // G1: unsaturated 9 x 29-bit accumulator (ff29.hpp); converted back to gnark's image once per task
         Acc29 acc;
@@ -350,6 +374,49 @@ __global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32
             xyzz_madd29(acc, p.x, p.y);
         }
         gstore(partial + t, acc29g2_to_xyzz(acc));
+    }
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
+                                                    const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
+                                                    uint32_t max_tasks) {
+    const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
+    XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
+    const uint32_t skip_below = batch.skip_below[blockIdx.y];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_tasks) return;
+    uint32_t key = len_key_sorted[i];
+    if (key == 0xffffffffu) return;
+    uint32_t t = task_sorted[i];
+    uint32_t begin = task_begin[t];
+    acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
+}
+// The same work from a RESIDENT grid of a fixed number of workgroups per CU: every wave draws chunks of 64 consecutive sorted tasks from a counter
+// (longest first, so the machine drains evenly) until the padding behind the real tasks begins.  The point is not the loop but the OCCUPANCY: the mixed
+// addition keeps 97 % of its rate with two waves per SIMD instead of four (tools/ubench2.hip), and a grid that never holds more than that leaves half of
+// every SIMD's registers and wave slots free for the kernels that have to make progress underneath -- the next MSM's sort (whose look-back tiles spin
+// while they wait for a slot), the transforms, the reduction tails.  The one-lane-per-task kernel above fills every slot the moment one frees up.
+template <class F>
+__global__ __launch_bounds__(256) void k_accumulate_resident(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
+                                                             const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
+                                                             uint32_t max_tasks, uint32_t* __restrict__ next_chunk) {
+    const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
+    XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
+    const uint32_t skip_below = batch.skip_below[blockIdx.y];
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_chunk + blockIdx.y, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= max_tasks) return;
+        if (len_key_sorted[base] == 0xffffffffu) return;  // the real tasks fill [0, total): everything from here on is padding
+        const uint32_t i = base + lane;
+        if (i >= max_tasks) continue;
+        const uint32_t key = len_key_sorted[i];
+        if (key == 0xffffffffu) continue;
+        const uint32_t t = task_sorted[i];
+        const uint32_t begin = task_begin[t];
+        acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
     }
 }
 
@@ -474,6 +541,7 @@ struct TailPt<Fp2> {
 // first pass over the listed giant buckets: wave `seg` of giant `gi` folds its segment of the bucket's partial sums into the segment's first slot
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_giant(XYZZ<F>* partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ ctl) {
+    prio_hi();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t gi = blockIdx.x / 16, seg = (blockIdx.x % 16) * 4 + wave;
     const uint32_t ng = min(ctl[4], GIANT_MAX);
@@ -497,6 +565,7 @@ __global__ __launch_bounds__(256) void k_fold_giant(XYZZ<F>* partial, const uint
 template <class F>
 __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint32_t* task_off, const uint32_t* multi_list,
                                                     const uint32_t* num_multi) {
+    prio_hi();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nm = *num_multi;
     for (uint32_t m = blockIdx.x * 4 + wave; m < nm; m += gridDim.x * 4) {
@@ -534,6 +603,7 @@ __global__ __launch_bounds__(256) void k_fold_multi(XYZZ<F>* partial, const uint
 template <class F, class PT = TailPt<F>>
 __global__ __launch_bounds__(256) void k_reduce_l1(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t B,
                                                    uint32_t W, uint32_t m, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
+    prio_hi();
     uint32_t N1 = B / m;
     uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / PT::LPP;  // PT::LPP lanes share one chunk of m buckets
     if (g >= W * N1) return;
@@ -557,6 +627,7 @@ __global__ __launch_bounds__(256) void k_reduce_l1(const XYZZ<F>* __restrict__ p
 template <class F>
 __global__ __launch_bounds__(256) void k_reduce_l2(const XYZZ<F>* __restrict__ A_in, const XYZZ<F>* __restrict__ S_in, uint32_t N, uint32_t W, uint32_t sh,
                                                    uint32_t m, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
+    prio_hi();
     typedef TailPt<F> PT;
     uint32_t Nout = (N + m - 1) / m;
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -583,6 +654,7 @@ __global__ __launch_bounds__(256) void k_reduce_l2(const XYZZ<F>* __restrict__ A
 template <class F, class PT = TailPt<F>>
 __global__ __launch_bounds__(64) void k_reduce_wave(const XYZZ<F>* __restrict__ A_in, const XYZZ<F>* __restrict__ S_in, uint32_t N, uint32_t W,
                                                     uint32_t sh, XYZZ<F>* __restrict__ A_out, XYZZ<F>* __restrict__ S_out) {
+    prio_hi();
     constexpr uint32_t FAN = 64 / PT::LPP;
     uint32_t Nout = (N + FAN - 1) / FAN;
     uint32_t chunk = blockIdx.x;  // W * Nout chunks
@@ -610,6 +682,160 @@ __global__ __launch_bounds__(64) void k_reduce_wave(const XYZZ<F>* __restrict__ 
     if (threadIdx.x == 0) {
         s.store(S_out + chunk);
         y.store(A_out + chunk);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- fused tail
+// Hand-off between waves of ONE kernel without anybody waiting: every producer wave stores its result, releases it and adds 1 to the counter of the
+// group it belongs to; the wave whose add came LAST -- told by the value the add returned -- acquires and goes on with the group's entries.  Nobody spins,
+// so the pattern cannot deadlock however few of the kernel's waves are resident at a time (a grid barrier could, under the accumulate kernel of the next
+// MSM).  Form per MI355X_MICROARCH.md "inter-workgroup visibility": plain stores -> vmcnt(0) -> agent release -> vmcnt(0) (asm: the compiler may drop the
+// wait behind the write-back) -> agent-scope atomic add; the last arriver: agent acquire -> vmcnt(0) -> plain loads.
+__device__ __forceinline__ bool arrive_is_last(uint32_t* counter, uint32_t expected) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t old = 0;
+    if ((threadIdx.x & 63) == 0) old = atomicAdd(counter, 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old + 1 != expected) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return true;
+}
+
+// one wave level on registers: 64 entries (A_l, S_l), lane = l, entries past `cnt` are infinity;
+//   S' = sum_l S_l ;  A' = sum_l A_l + 2^sh * sum_l l * S_l      -> lane 0 holds (y = A', s = S')
+template <class PT>
+__device__ __forceinline__ void wave_level(PT& s, PT& a, PT& y, uint32_t lane, uint32_t sh) {
+    for (unsigned d = 1; d < 64; d <<= 1) {  // inclusive suffix sums: s_l = sum_{u >= l} S_u
+        PT t = s.shfl_down(d);
+        if (lane + d < 64) s.add(t);
+    }
+    y = s;
+    if (lane == 0) y = PT::inf();
+    for (uint32_t i = 0; i < sh; i++) y.dbl();
+    y.add(a);
+    for (unsigned d = 32; d > 0; d >>= 1) {
+        PT t = y.shfl_xor(d);
+        y.add(t);
+    }
+}
+
+// The whole bucket reduction of one MSM in ONE launch (was: level 1, an optional lane-serial level 2 and one launch per wave level, each gated on the one
+// before): wave v takes 64 * m consecutive buckets -- each lane the running sums over m of them (level 1), the wave level on the 64 lane results in
+// registers -- and stores ONE entry; the last of every 64 waves to finish (arrive_is_last) runs the next wave level on the group's entries, and so on until
+// at most host_n entries per window are left.  Needs 64 | B / m (one wave never straddles two windows).
+// Level entries live at lvlA/lvlS + level offset (levels of different groups are alive at the same time); the final entries go to outA / outS.
+template <class F>
+__global__ __launch_bounds__(64) void k_tail_fused(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t B, uint32_t W, uint32_t m,
+                                                   uint32_t sh0, uint32_t host_n, XYZZ<F>* lvlA, XYZZ<F>* lvlS, XYZZ<F>* __restrict__ outA,
+                                                   XYZZ<F>* __restrict__ outS, uint32_t* counters) {
+    prio_hi();
+    typedef TailPt<F> PT;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t N1 = B / m, waves_per_window = N1 / 64;
+    const uint32_t w = blockIdx.x / waves_per_window;
+    uint32_t idx = blockIdx.x % waves_per_window;  // this wave's entry within its window at the current level
+    PT s, a, y;
+    {   // level 1 on the lane's m buckets (weights 1 .. m inside the chunk): a = sum_l (l+1) X_l, s = sum_l X_l
+        const uint32_t b0 = w * B + (idx * 64 + lane) * m;
+        PT run = PT::inf(), acc = PT::inf();
+        for (int l = (int)m - 1; l >= 0; l--) {
+            const uint32_t b = b0 + (uint32_t)l;
+            const uint32_t t0 = task_off[b];
+            if (task_off[b + 1] > t0) run.add(PT::load(partial + t0));
+            acc.add(run);
+        }
+        s = run;
+        a = acc;
+    }
+    uint32_t sh = sh0, N = waves_per_window;
+    size_t level_off = 0;
+    uint32_t* cnt = counters;
+    for (;;) {
+        wave_level(s, a, y, lane, sh);  // lane 0: (y, s) = the entry of this wave at the level with N entries per window
+        sh += 6;
+        XYZZ<F>*dA = lvlA + level_off, *dS = lvlS + level_off;
+        const bool last_level = N <= host_n;
+        if (last_level) { dA = outA; dS = outS; }
+        if (lane == 0) {
+            y.store(dA + (size_t)w * N + idx);
+            s.store(dS + (size_t)w * N + idx);
+        }
+        if (last_level) return;
+        const uint32_t groups = (N + 63) / 64, g = idx / 64, gsize = min(64u, N - g * 64);
+        if (!arrive_is_last(cnt + w * groups + g, gsize)) return;
+        // this wave carries the group on: entries g * 64 + lane of the level just written
+        s = PT::inf();
+        a = PT::inf();
+        if (lane < gsize) {
+            s = PT::load(dS + (size_t)w * N + g * 64 + lane);
+            a = PT::load(dA + (size_t)w * N + g * 64 + lane);
+        }
+        level_off += (size_t)W * N;
+        cnt += W * groups;
+        N = groups;
+        idx = g;
+    }
+}
+
+// The two fold kernels in one launch: the first GIANT_MAX * 64 waves each fold one segment of a listed giant bucket and the last of a giant's segment waves
+// to finish (arrive_is_last) folds the segment heads; every wave then takes its share of the other split buckets.  No launch that only finds out on the
+// device that there is nothing to do.
+template <class F>
+__global__ __launch_bounds__(256) void k_fold_fused(XYZZ<F>* partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ multi_list,
+                                                    const uint32_t* __restrict__ ctl, uint32_t* giant_cnt) {
+    prio_hi();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const uint32_t ng = min(ctl[4], GIANT_MAX);
+    for (uint32_t item = gw; item < ng * 64; item += nwaves) {
+        const uint32_t gi = item / 64, seg = item % 64;
+        const uint32_t b = ctl[8 + gi];
+        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        const uint32_t S = giant_seg(t1 - t0);
+        const uint32_t nseg = (t1 - t0 + S - 1) / S;
+        const uint32_t lo = t0 + seg * S, hi = min(lo + S, t1);
+        if (lo >= t1) continue;
+        if (hi - lo >= 2) {
+            TailPt<F> acc = TailPt<F>::inf();
+            for (uint32_t t = lo + lane; t < hi; t += 64) acc.add(TailPt<F>::load(partial + t));
+            const uint32_t cnt = min(hi - lo, 64u);
+            unsigned first = 32;
+            while (first >= cnt && first > 0) first >>= 1;
+            for (unsigned d = first; d > 0; d >>= 1) {
+                TailPt<F> o = acc.shfl_down(d);
+                if (lane < d) acc.add(o);
+            }
+            if (lane == 0) acc.store(partial + lo);
+        }
+        if (!arrive_is_last(giant_cnt + gi, nseg)) continue;
+        TailPt<F> acc = TailPt<F>::inf();
+        if (lane < nseg) acc = TailPt<F>::load(partial + t0 + lane * S);
+        unsigned first = 32;
+        while (first >= nseg && first > 0) first >>= 1;
+        for (unsigned d = first; d > 0; d >>= 1) {
+            TailPt<F> o = acc.shfl_down(d);
+            if (lane < d) acc.add(o);
+        }
+        if (lane == 0) acc.store(partial + t0);
+    }
+    const uint32_t nm = ctl[0];
+    for (uint32_t mi = gw; mi < nm; mi += nwaves) {
+        const uint32_t b = multi_list[mi];
+        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
+        if (t1 - t0 > GIANT_T && __ballot(lane < ng && ctl[8 + lane] == b) != 0) continue;  // a listed giant: folded above
+        TailPt<F> acc = TailPt<F>::inf();
+        for (uint32_t t = t0 + lane; t < t1; t += 64) acc.add(TailPt<F>::load(partial + t));
+        const uint32_t cnt = min(t1 - t0, 64u);
+        unsigned first = 32;
+        while (first >= cnt && first > 0) first >>= 1;
+        for (unsigned d = first; d > 0; d >>= 1) {
+            TailPt<F> o = acc.shfl_down(d);
+            if (lane < d) acc.add(o);
+        }
+        if (lane == 0) acc.store(partial + t0);
     }
 }
 
@@ -730,6 +956,7 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
         rocprim::double_buffer<uint32_t> kb(nullptr, nullptr), vb(nullptr, nullptr);
         hipError_t e = sort_pairs(nullptr, P->sort_tmp_bytes, kb, vb, P->total, P->key_bits, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs sizing: %s", hipGetErrorString(e));
+        P->sort_tmp_bytes = std::max(P->sort_tmp_bytes, rs_plan(P->total, P->key_bits).tmp_bytes);
         e = rocprim::exclusive_scan(nullptr, P->scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P->nb + 1,
                                     rocprim::plus<uint32_t>(), st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan sizing: %s", hipGetErrorString(e));
@@ -782,7 +1009,10 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
               (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step);
     // ---- 2. sort (bucket key -> point index|sign)
     rocprim::double_buffer<uint32_t> kb(keys0, keys1), vb(vals0, vals1);
-    {
+    static const bool own_sort = ZK_EXP("ZKMI_SORT", 0) != 0;  // 1: radix.hpp; 0: rocPRIM's onesweep
+    if (own_sort) {
+        ZK_TRY(rs_sort_pairs(s, st, sort_tmp, kb, vb, total, key_bits));
+    } else {
         if (ctx().profiling) prof_begin(s, st, "msm_radix_sort(rocprim)");
         hipError_t e = sort_pairs(sort_tmp, sort_tmp_bytes, kb, vb, total, key_bits, st);
         if (ctx().profiling) prof_end(s, st);
@@ -872,8 +1102,19 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     if (j0->gate_acc) ZK_HIP(hipStreamWaitEvent(sa, j0->gate_acc, 0));
     // ---- 5. accumulate
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
-    ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3((unsigned)((max_tasks + 255) / 256), (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
-              R.lkeys, R.tids, L, (uint32_t)max_tasks);
+    // workgroups per CU of the resident form (0 = one lane per task, as many workgroups as there are tasks)
+    static const unsigned wg_g1 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G1", 0), wg_g2 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G2", 0);
+    const unsigned wg_per_cu = sizeof(F) == 32 ? wg_g1 : wg_g2;
+    const unsigned full_grid = (unsigned)((max_tasks + 255) / 256);
+    if (wg_per_cu && full_grid > wg_per_cu * (unsigned)ctx().num_cus) {
+        uint32_t* next_chunk = (uint32_t*)sl[0]->alloc(16);
+        if (!next_chunk) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
+        ZK_HIP(hipMemsetAsync(next_chunk, 0, 16, sa));
+        ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
+                  R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
+    } else {
+        ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
+    }
     bool want = j0->chain != nullptr || nb > 1;
     for (int b = 0; b < nb; b++) want = want || jobs[b]->want_done;
     if (want) {
@@ -884,11 +1125,43 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         for (int b = 0; b < nb; b++)
             if (sts[b] != sa) ZK_HIP(hipStreamWaitEvent(sts[b], done, 0));
     }
+    static const bool fuse_fold = ZK_EXP("ZKMI_FUSE_FOLD", 0) != 0, fuse_tail = ZK_EXP("ZKMI_FUSE_TAIL", 0) != 0;
     for (int b = 0; b < nb; b++) {
         Slot* s = sl[b];
         hipStream_t st = sts[b];
-        ZK_LAUNCH(s, st, "msm_fold_giant", (k_fold_giant<F>), dim3(GIANT_MAX * 16), dim3(256), 0, partial[b], R.task_off, (const uint32_t*)R.num_multi);  // exits at once without giants
-        ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
+        // counters of the fused kernels' hand-offs (per job: the tails of MSMs that share one preparation run side by side): [0, GIANT_MAX) giants,
+        // [64, 64 + TAIL_COUNTERS) groups of the reduction levels
+        constexpr uint32_t TAIL_COUNTERS = 4096;
+        uint32_t* counters = (uint32_t*)s->alloc((64 + TAIL_COUNTERS) * 4);
+        if (!counters) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
+        if (fuse_fold || fuse_tail) ZK_HIP(hipMemsetAsync(counters, 0, (64 + TAIL_COUNTERS) * 4, st));
+        if (fuse_fold) {
+            ZK_LAUNCH(s, st, "msm_fold", (k_fold_fused<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, (const uint32_t*)R.num_multi, counters);
+        } else {
+            ZK_LAUNCH(s, st, "msm_fold_giant", (k_fold_giant<F>), dim3(GIANT_MAX * 16), dim3(256), 0, partial[b], R.task_off, (const uint32_t*)R.num_multi);  // exits at once without giants
+            ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
+        }
+        // ---- 6. bucket reduce, fused: level 1 + every wave level in one launch (no lane-serial second level: m = m1 buckets per lane)
+        bool fused_ok = fuse_tail && !(sizeof(F) == sizeof(Fp) && jobs[b]->quad_tail) && N1 % 64 == 0;
+        if (fused_ok) {
+            const uint32_t host_n1 = (W * 64 <= 64) ? 64 : 1;
+            uint32_t N = N1 / 64, sh = 6, ncnt = 0;
+            for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;
+            for (uint32_t n = N; n > host_n1; n = (n + 63) / 64) ncnt += W * ((n + 63) / 64);
+            if (ncnt > TAIL_COUNTERS) fused_ok = false;
+            else {
+                ZK_LAUNCH(s, st, "msm_tail", (k_tail_fused<F>), dim3(W * (N1 / 64)), dim3(64), 0, (const Pt*)partial[b], R.task_off, B, W, m1, sh - 6, host_n1, lvlA[b][0],
+                          lvlS[b][0], lvlA[b][1], lvlS[b][1], counters + 64);
+                while (N > host_n1) { N = (N + 63) / 64; sh += 6; }
+                jobs[b]->n_final = N;
+                jobs[b]->sh_final = sh;
+                const size_t cnt = (size_t)W * N;
+                ZK_TRY(s->pinned_reserve(2 * cnt * sizeof(Pt)));
+                ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
+                if (N > 1) ZK_HIP(hipMemcpyAsync((char*)s->pinned + cnt * sizeof(Pt), lvlS[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
+                continue;
+            }
+        }
         // ---- 6. bucket reduce
         bool quad = false;
         if constexpr (sizeof(F) == sizeof(Fp)) quad = jobs[b]->quad_tail;

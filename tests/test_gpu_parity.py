@@ -914,6 +914,43 @@ def test_g1_msm_2p26_properties():
     rb.free()
 
 
+def test_ntt_2p26_identity_and_sharded_equivalence():
+    """BASELINE configs[4] size, the transform: at 2^26 points (three passes, 2 GiB in HBM) FFTInverse(DIT) . FFT(DIF) is the identity on the device, and
+    the 8-rank block-sharded schedule (zk_bn254_ntt_shard_dev: cross stages on transposed data, size-2^23 block transforms, two all-to-all transposes,
+    radix-8 columns), played by this one GPU for all ranks, gives the single-GPU FFT(DIF) bit for bit."""
+    from tests import sharded_h_ref as sh
+    log_n, G = 26, 8
+    n = 1 << log_n
+    d = _lib.DeviceBuffer(n * 32)
+    _lib.check(_lib.lib().zk_bn254_fr_random_dev(C.c_void_p(d.ptr), C.c_size_t(n), C.c_uint64(0x26), C.c_int(1), C.c_int(0), None))
+    x0 = d.to_numpy(np.uint64, (n, 4))
+    dom = zk.Domain(n)
+    dom.fft(d, zk.DIF)
+    want = sha_image(d.to_numpy(np.uint64, (n, 4)))
+    dom.fft_inverse(d, zk.DIT)
+    assert (d.to_numpy(np.uint64, (n, 4)) == x0).all()
+    d.free()
+    M = n // G
+    blocks = [x0[r * M:(r + 1) * M].copy() for r in range(G)]
+    del x0
+    out = sh.run_virtual_ntt(_ntt_step_gpu, blocks, log_n, False, zk.DIF, False)
+    assert sha_image(np.concatenate(out)) == want
+
+
+def test_groth16_2p20_proof_bytes_vs_oracle():
+    """BASELINE configs[1] itself inside the suite (bench.py re-checks it after its timed region): the 128 proof bytes of the synthetic 2^20-constraint
+    instance -- resident key with window tables, the whole single-call schedule -- equal the bytes the CPU oracle (oracle/bn254_oracle.c, OpenMP) computes
+    for the same key, a, b, c, w, r, s; for uniform and for witness-like wire values (giant buckets, adaptive task lengths)."""
+    import bench
+    L = _lib.lib()
+    for witness in (0, 1):
+        inst = bench.Instance(L, _lib, zk, 20, 0, bench.N_PUBLIC, witness, True)
+        got = zk.prove(inst.pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True)
+        want, _, _ = bench.oracle_proof(inst, 20)
+        inst.free()
+        assert got == want, "witness-like" if witness else "uniform"
+
+
 def test_groth16_2p24_properties():
     """BASELINE configs[2] size on one GPU (2^24 constraints; key with c = 22 window tables, 84 GB): (1) the single-call prover's bytes equal
     the recombination of two half-size slices run through the table-less msm5 path (other window width, Horner, other task sizes) and
