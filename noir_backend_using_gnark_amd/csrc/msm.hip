@@ -10,7 +10,8 @@
 // Device pipeline (all on one stream, no host round trip until the window sums come back):
 //   1. k_msm_digits      scalars (Montgomery or canonical) -> signed c-bit digits (gnark's partitionScalars recoding);
 //                        one (bucket key, point index|sign) pair per non-zero digit, zero digits get a sentinel key
-//   2. radix sort        rocprim radix_sort_pairs on the ~log2(W * 2^(c-1)) key bits  (a library sort; the hot kernel is 3)
+//   2. radix sort        radix.hpp: LSD passes of <= 8 key bits over the ~log2(W * 2^(c-1)) key bits, per-tile histograms + row scans + ballot-ranked
+//                        scatters; no workgroup waits for another one (rounds 1-2 called rocPRIM's onesweep here, whose look-back tiles spin)
 //   3. k_bucket_bounds   bucket -> [start, end) in the sorted array
 //   4. k_task_plan       buckets are cut into tasks of <= L points so that one giant bucket (scalars 0/1 dominate real
 //                        witnesses) cannot serialise the GPU; exclusive scan -> task offsets
@@ -25,8 +26,11 @@
 
 #include <algorithm>
 #include <tuple>
+#include <type_traits>
 
-#include <rocprim/rocprim.hpp>
+#ifdef ZKMI_EXPERIMENTS
+#include <rocprim/rocprim.hpp>  // A/B only (ZKMI_SORT=0 / ZKMI_SCAN=0): the shipped library contains no library kernel
+#endif
 
 #include "ctx.hpp"
 #include "curve.hpp"
@@ -37,20 +41,32 @@
 
 namespace zkmi {
 
-// The scalar-preparation sort: rocPRIM's onesweep.  ZKMI_SORT_CFG=1 (experiment switch) selects 1024-lane tiles of 8 items instead of the library's
+// two buffers and which one is current (what a sort pass swaps)
+struct PingPong {
+    uint32_t* b[2];
+    int cur = 0;
+    PingPong(uint32_t* x, uint32_t* y) : b{x, y} {}
+    uint32_t* current() const { return b[cur]; }
+    uint32_t* alternate() const { return b[cur ^ 1]; }
+    void swap() { cur ^= 1; }
+};
+#ifdef ZKMI_EXPERIMENTS
+// rocPRIM's onesweep radix sort, kept for A/B runs only (ZKMI_SORT=0).  ZKMI_SORT_CFG=1 selects 1024-lane tiles of 8 items instead of the library's
 // tuned default for (u32, u32): alone it is 6-17 % faster (tools/sort_bench.hip: 0.323 against 0.391 ms for the 13.6 M digits of a 2^20 MSM).
 using SortWide = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 8,
                                                                                 rocprim::block_radix_rank_algorithm::match>>;
-static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, rocprim::double_buffer<uint32_t>& kb, rocprim::double_buffer<uint32_t>& vb, size_t n, unsigned key_bits,
-                             hipStream_t st) {
+static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, PingPong& kb, PingPong& vb, size_t n, unsigned key_bits, hipStream_t st) {
     static const int cfg = ZK_EXP("ZKMI_SORT_CFG", 0);
-    if (cfg == 1) return rocprim::radix_sort_pairs<SortWide>(tmp, tmp_bytes, kb, vb, n, 0, key_bits, st);
-    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, n, 0, key_bits, st);
+    rocprim::double_buffer<uint32_t> k2(kb.current(), kb.alternate()), v2(vb.current(), vb.alternate());
+    hipError_t e = cfg == 1 ? rocprim::radix_sort_pairs<SortWide>(tmp, tmp_bytes, k2, v2, n, 0, key_bits, st) : rocprim::radix_sort_pairs(tmp, tmp_bytes, k2, v2, n, 0, key_bits, st);
+    if (tmp && k2.current() != kb.current()) { kb.swap(); vb.swap(); }
+    return e;
 }
+#endif
 
 // The hand-written sort of radix.hpp (no workgroup ever waits for another one), same contract as sort_pairs: sorted pairs end up in kb / vb's current buffers.
-static int rs_sort_pairs(Slot* s, hipStream_t st, void* tmp, rocprim::double_buffer<uint32_t>& kb, rocprim::double_buffer<uint32_t>& vb, size_t n, unsigned key_bits) {
+static int rs_sort_pairs(Slot* s, hipStream_t st, void* tmp, PingPong& kb, PingPong& vb, size_t n, unsigned key_bits) {
     const RsPlan R = rs_plan(n, key_bits);
     uint32_t* tile_hist = (uint32_t*)tmp;
     uint32_t* ghist = tile_hist + (size_t)RS_MAX_BINS * R.ntiles;
@@ -70,6 +86,16 @@ static int rs_sort_pairs(Slot* s, hipStream_t st, void* tmp, rocprim::double_buf
         kb.swap();
         vb.swap();
     }
+    return ZK_OK;
+}
+
+// exclusive scan of n u32 counters (radix.hpp): out may alias in
+static int xs_exclusive_scan(Slot* s, hipStream_t st, void* tmp, const uint32_t* in, uint32_t* out, size_t n) {
+    const unsigned nt = (unsigned)((n + XS_TILE - 1) / XS_TILE);
+    uint32_t* sums = (uint32_t*)tmp;
+    ZK_LAUNCH(s, st, "msm_task_scan", k_xs_sums, dim3(nt), dim3(XS_THREADS), 0, in, (uint32_t)n, sums);
+    ZK_LAUNCH(s, st, "msm_task_scan", k_xs_scan_sums, dim3(1), dim3(XS_THREADS), 0, sums, nt);
+    ZK_LAUNCH(s, st, "msm_task_scan", k_xs_apply, dim3(nt), dim3(XS_THREADS), 0, in, (uint32_t)n, (const uint32_t*)sums, out);
     return ZK_OK;
 }
 
@@ -376,6 +402,72 @@ __device__ __forceinline__ void acc_task(const Affine<F>* __restrict__ pts, XYZZ
         gstore(partial + t, acc29g2_to_xyzz(acc));
     }
 }
+#ifdef ZKMI_EXPERIMENTS  // measured and not adopted: neutral -- the kernel is issue-bound, not latency-bound
+// The same task with the gathers taken off the critical path.  In acc_task every mixed addition starts with two DEPENDENT global loads -- the sorted
+// index, then the point it names (a 64- / 128-byte gather out of a multi-GB window table: an HBM access every time) -- and the wave sits in s_waitcnt for
+// both: with four waves per SIMD that is just hidden on an idle GPU and no longer once a sort or a transform keeps the memory system busy (the kernel's
+// rate inside a proof: 0.67 of the routine's, 0.83 alone).  Here the point of step j + 1 is in flight WHILE step j is computed: it travels by LDS-DMA
+// (global_load_lds_dwordx4: per-lane source address, wave-uniform LDS base + lane * 16 -- a gather into a lane-linear image, no VGPR destination, so the
+// kernel stays under 128 registers and keeps its four waves per SIMD), the index of step j + 2 with it.  One staging slot per lane: it is read into
+// registers (ds_read_b128) before the next DMA is issued.  LDS: 4 KB (G1) / 8 KB (G2) per wave.
+template <class F>
+__device__ __forceinline__ void acc_task_pf(const Affine<F>* __restrict__ pts, XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ vals,
+                                            uint32_t skip_below, uint32_t t, uint32_t begin, uint32_t end, uint4* stage /* this wave's: Q x 64 x 16 B */) {
+    constexpr int Q = sizeof(Affine<F>) / 16;
+    const uint32_t lane = threadIdx.x & 63;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](uint32_t v) {
+        const uint4* g = reinterpret_cast<const uint4*>(pts + (v >> 1));
+#pragma unroll
+        for (int q = 0; q < Q; q++) __builtin_amdgcn_global_load_lds((const void*)(g + q), (lds_ptr)(stage + q * 64), 16, 0, 0);
+    };
+    typename std::conditional<sizeof(F) == sizeof(Fp), Acc29, Acc29G2>::type acc;
+    acc.inf = true;
+    uint32_t j = begin, v_cur = 0, v_next = 0;
+    if (j < end) v_cur = vals[j];
+    if (j + 1 < end) v_next = vals[j + 1];
+    if (j < end && (v_cur >> 1) >= skip_below) issue(v_cur);
+    while (j < end) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the point of step j has landed in the slot, v_next is here
+        const bool use = (v_cur >> 1) >= skip_below;  // scalars shared with an MSM whose first bases do not exist (pk.G1.K vs w)
+        Affine<F> p;
+        if (use) {
+            uint4* d = reinterpret_cast<uint4*>(&p);
+#pragma unroll
+            for (int q = 0; q < Q; q++) d[q] = stage[q * 64 + lane];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is free again
+        uint32_t v_nn = 0;
+        if (j + 2 < end) v_nn = vals[j + 2];
+        if (j + 1 < end && (v_next >> 1) >= skip_below) issue(v_next);
+        if (use) {
+            if (v_cur & 1) p.y = p.y.neg();
+            xyzz_madd29(acc, p.x, p.y);
+        }
+        v_cur = v_next;
+        v_next = v_nn;
+        j++;
+    }
+    if constexpr (sizeof(F) == sizeof(Fp)) gstore(partial + t, acc29_to_packed(acc));
+    else gstore(partial + t, acc29g2_to_xyzz(acc));
+}
+template <class F>
+__global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accumulate_pf(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
+                                                       const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
+                                                       uint32_t max_tasks) {
+    __shared__ uint4 stage[4][sizeof(Affine<F>) / 16 * 64];
+    const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
+    XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
+    const uint32_t skip_below = batch.skip_below[blockIdx.y];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_tasks) return;
+    uint32_t key = len_key_sorted[i];
+    if (key == 0xffffffffu) return;
+    uint32_t t = task_sorted[i];
+    uint32_t begin = task_begin[t];
+    acc_task_pf<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key), stage[threadIdx.x >> 6]);
+}
+#endif
 template <class F>
 __global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
                                                     const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
@@ -391,6 +483,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32
     uint32_t begin = task_begin[t];
     acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
 }
+#ifdef ZKMI_EXPERIMENTS  // measured and not adopted: 3-7 % slower at every size
 // The same work from a RESIDENT grid of a fixed number of workgroups per CU: every wave draws chunks of 64 consecutive sorted tasks from a counter
 // (longest first, so the machine drains evenly) until the padding behind the real tasks begins.  The point is not the loop but the OCCUPANCY: the mixed
 // addition keeps 97 % of its rate with two waves per SIMD instead of four (tools/ubench2.hip), and a grid that never holds more than that leaves half of
@@ -419,6 +512,7 @@ __global__ __launch_bounds__(256) void k_accumulate_resident(AccBatch batch, con
         acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------- tail arithmetic
 // The reduction tail adds XYZZ points to XYZZ points.  G1 uses the 29-bit-limb form (ff29.hpp: 1.4x fewer instructions per
@@ -685,6 +779,7 @@ __global__ __launch_bounds__(64) void k_reduce_wave(const XYZZ<F>* __restrict__ 
     }
 }
 
+#ifdef ZKMI_EXPERIMENTS  // measured and not adopted: the fused fold is neutral, the fused tail costs 0.6 ms per 2^20 proof
 // ---------------------------------------------------------------------------------------- fused tail
 // Hand-off between waves of ONE kernel without anybody waiting: every producer wave stores its result, releases it and adds 1 to the counter of the
 // group it belongs to; the wave whose add came LAST -- told by the value the add returned -- acquires and goes on with the group's entries.  Nobody spins,
@@ -838,6 +933,7 @@ __global__ __launch_bounds__(256) void k_fold_fused(XYZZ<F>* partial, const uint
         if (lane == 0) acc.store(partial + t0);
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------- host side
 template <class HF> struct HostOf;
@@ -952,15 +1048,20 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     P->N1 = P->B / P->m1;
     P->key_bits = 1;
     while (((uint64_t)1 << P->key_bits) <= P->nb) P->key_bits++;
-    {
-        rocprim::double_buffer<uint32_t> kb(nullptr, nullptr), vb(nullptr, nullptr);
-        hipError_t e = sort_pairs(nullptr, P->sort_tmp_bytes, kb, vb, P->total, P->key_bits, st);
+    P->sort_tmp_bytes = rs_plan(P->total, P->key_bits).tmp_bytes;
+    P->scan_tmp_bytes = xs_tmp_bytes((size_t)P->nb + 1);
+#ifdef ZKMI_EXPERIMENTS
+    {   // the library's workspaces, when an A/B run selects it
+        PingPong kb(nullptr, nullptr), vb(nullptr, nullptr);
+        size_t lib_sort = 0, lib_scan = 0;
+        hipError_t e = sort_pairs(nullptr, lib_sort, kb, vb, P->total, P->key_bits, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs sizing: %s", hipGetErrorString(e));
-        P->sort_tmp_bytes = std::max(P->sort_tmp_bytes, rs_plan(P->total, P->key_bits).tmp_bytes);
-        e = rocprim::exclusive_scan(nullptr, P->scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P->nb + 1,
-                                    rocprim::plus<uint32_t>(), st);
+        e = rocprim::exclusive_scan(nullptr, lib_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P->nb + 1, rocprim::plus<uint32_t>(), st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan sizing: %s", hipGetErrorString(e));
+        P->sort_tmp_bytes = std::max(P->sort_tmp_bytes, lib_sort);
+        P->scan_tmp_bytes = std::max(P->scan_tmp_bytes, lib_scan);
     }
+#endif
     P->lvl_elems = (size_t)P->W * P->N1;  // level-1 outputs; later levels are 64x smaller
     P->tsort_tmp_bytes = TS_BINS * 4;  // bin counters of the task counting sort
     P->need_prep = 5 * align_up(P->max_tasks * 4, 256) + align_up(P->tsort_tmp_bytes + 16, 256) + 4 * align_up(P->total * 4, 256) +
@@ -1008,16 +1109,19 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
               (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step);
     // ---- 2. sort (bucket key -> point index|sign)
-    rocprim::double_buffer<uint32_t> kb(keys0, keys1), vb(vals0, vals1);
-    static const bool own_sort = ZK_EXP("ZKMI_SORT", 0) != 0;  // 1: radix.hpp; 0: rocPRIM's onesweep
-    if (own_sort) {
-        ZK_TRY(rs_sort_pairs(s, st, sort_tmp, kb, vb, total, key_bits));
-    } else {
+    PingPong kb(keys0, keys1), vb(vals0, vals1);
+    bool own_sort = true, own_scan = true;
+#ifdef ZKMI_EXPERIMENTS
+    own_sort = ZK_EXP("ZKMI_SORT", 1) != 0;  // 0: rocPRIM's onesweep (A/B)
+    own_scan = ZK_EXP("ZKMI_SCAN", 1) != 0;  // 0: rocPRIM's single-pass scan (A/B)
+    if (!own_sort) {
         if (ctx().profiling) prof_begin(s, st, "msm_radix_sort(rocprim)");
         hipError_t e = sort_pairs(sort_tmp, sort_tmp_bytes, kb, vb, total, key_bits, st);
         if (ctx().profiling) prof_end(s, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
     }
+#endif
+    if (own_sort) ZK_TRY(rs_sort_pairs(s, st, sort_tmp, kb, vb, total, key_bits));
     const uint32_t* keys = kb.current();
     // ---- 3. bucket bounds
     ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, keys, (uint32_t)total, nb, start);
@@ -1028,12 +1132,15 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     static const uint32_t l_cap = (uint32_t)ZK_EXP("ZKMI_L_GIANT_CAP", 16384);
     ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, bins);
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
-    {
+#ifdef ZKMI_EXPERIMENTS
+    if (!own_scan) {
         if (ctx().profiling) prof_begin(s, st, "msm_task_scan(rocprim)");
         hipError_t e = rocprim::exclusive_scan(scan_tmp, scan_tmp_bytes, ntasks, task_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
         if (ctx().profiling) prof_end(s, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
     }
+#endif
+    if (own_scan) ZK_TRY(xs_exclusive_scan(s, st, scan_tmp, ntasks, task_off, (size_t)nb + 1));
     // ---- 4b. per-task records, ordered by decreasing length (counting sort on L - len)
     uint32_t bshift = 0;
     while ((L >> bshift) >= TS_BINS) bshift++;
@@ -1102,19 +1209,26 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     if (j0->gate_acc) ZK_HIP(hipStreamWaitEvent(sa, j0->gate_acc, 0));
     // ---- 5. accumulate
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
-    // workgroups per CU of the resident form (0 = one lane per task, as many workgroups as there are tasks)
-    static const unsigned wg_g1 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G1", 0), wg_g2 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G2", 0);
-    const unsigned wg_per_cu = sizeof(F) == 32 ? wg_g1 : wg_g2;
     const unsigned full_grid = (unsigned)((max_tasks + 255) / 256);
-    if (wg_per_cu && full_grid > wg_per_cu * (unsigned)ctx().num_cus) {
-        uint32_t* next_chunk = (uint32_t*)sl[0]->alloc(16);
-        if (!next_chunk) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
-        ZK_HIP(hipMemsetAsync(next_chunk, 0, 16, sa));
-        ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
-                  R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
-    } else {
-        ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
+    bool launched = false;
+#ifdef ZKMI_EXPERIMENTS
+    {   // workgroups per CU of the resident form (0 = one lane per task, as many workgroups as there are tasks); LDS-DMA prefetch of the next point
+        static const unsigned wg_g1 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G1", 0), wg_g2 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G2", 0);
+        const unsigned wg_per_cu = sizeof(F) == 32 ? wg_g1 : wg_g2;
+        if (wg_per_cu && full_grid > wg_per_cu * (unsigned)ctx().num_cus) {
+            uint32_t* next_chunk = (uint32_t*)sl[0]->alloc(16);
+            if (!next_chunk) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
+            ZK_HIP(hipMemsetAsync(next_chunk, 0, 16, sa));
+            ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
+                      R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
+            launched = true;
+        } else if (ZK_EXP(sizeof(F) == 32 ? "ZKMI_ACC_PF_G1" : "ZKMI_ACC_PF_G2", 0) != 0) {
+            ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_pf<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
+            launched = true;
+        }
     }
+#endif
+    if (!launched) ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
     bool want = j0->chain != nullptr || nb > 1;
     for (int b = 0; b < nb; b++) want = want || jobs[b]->want_done;
     if (want) {
@@ -1125,42 +1239,55 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         for (int b = 0; b < nb; b++)
             if (sts[b] != sa) ZK_HIP(hipStreamWaitEvent(sts[b], done, 0));
     }
-    static const bool fuse_fold = ZK_EXP("ZKMI_FUSE_FOLD", 0) != 0, fuse_tail = ZK_EXP("ZKMI_FUSE_TAIL", 0) != 0;
     for (int b = 0; b < nb; b++) {
         Slot* s = sl[b];
         hipStream_t st = sts[b];
-        // counters of the fused kernels' hand-offs (per job: the tails of MSMs that share one preparation run side by side): [0, GIANT_MAX) giants,
-        // [64, 64 + TAIL_COUNTERS) groups of the reduction levels
-        constexpr uint32_t TAIL_COUNTERS = 4096;
-        uint32_t* counters = (uint32_t*)s->alloc((64 + TAIL_COUNTERS) * 4);
-        if (!counters) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
-        if (fuse_fold || fuse_tail) ZK_HIP(hipMemsetAsync(counters, 0, (64 + TAIL_COUNTERS) * 4, st));
-        if (fuse_fold) {
-            ZK_LAUNCH(s, st, "msm_fold", (k_fold_fused<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, (const uint32_t*)R.num_multi, counters);
-        } else {
+        bool folded = false;
+#ifdef ZKMI_EXPERIMENTS
+        {
+            static const bool fuse_fold = ZK_EXP("ZKMI_FUSE_FOLD", 0) != 0, fuse_tail = ZK_EXP("ZKMI_FUSE_TAIL", 0) != 0;
+            // counters of the fused kernels' hand-offs (per job: the tails of MSMs that share one preparation run side by side): [0, GIANT_MAX) giants,
+            // [64, 64 + TAIL_COUNTERS) groups of the reduction levels
+            constexpr uint32_t TAIL_COUNTERS = 4096;
+            uint32_t* counters = nullptr;
+            if (fuse_fold || fuse_tail) {
+                counters = (uint32_t*)s->alloc((64 + TAIL_COUNTERS) * 4);
+                if (!counters) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
+                ZK_HIP(hipMemsetAsync(counters, 0, (64 + TAIL_COUNTERS) * 4, st));
+            }
+            if (fuse_fold) {
+                ZK_LAUNCH(s, st, "msm_fold", (k_fold_fused<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, (const uint32_t*)R.num_multi, counters);
+                folded = true;
+            }
+            // bucket reduce, fused: level 1 + every wave level in one launch (no lane-serial second level: m = m1 buckets per lane)
+            bool fused_ok = fuse_tail && !(sizeof(F) == sizeof(Fp) && jobs[b]->quad_tail) && N1 % 64 == 0;
+            if (fused_ok) {
+                const uint32_t host_n1 = (W * 64 <= 64) ? 64 : 1;
+                uint32_t N = N1 / 64, sh = 6, ncnt = 0;
+                for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;
+                for (uint32_t n = N; n > host_n1; n = (n + 63) / 64) ncnt += W * ((n + 63) / 64);
+                if (ncnt <= TAIL_COUNTERS) {
+                    if (!folded) {
+                        ZK_LAUNCH(s, st, "msm_fold_giant", (k_fold_giant<F>), dim3(GIANT_MAX * 16), dim3(256), 0, partial[b], R.task_off, (const uint32_t*)R.num_multi);
+                        ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
+                    }
+                    ZK_LAUNCH(s, st, "msm_tail", (k_tail_fused<F>), dim3(W * (N1 / 64)), dim3(64), 0, (const Pt*)partial[b], R.task_off, B, W, m1, sh - 6, host_n1, lvlA[b][0],
+                              lvlS[b][0], lvlA[b][1], lvlS[b][1], counters + 64);
+                    while (N > host_n1) { N = (N + 63) / 64; sh += 6; }
+                    jobs[b]->n_final = N;
+                    jobs[b]->sh_final = sh;
+                    const size_t cnt = (size_t)W * N;
+                    ZK_TRY(s->pinned_reserve(2 * cnt * sizeof(Pt)));
+                    ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
+                    if (N > 1) ZK_HIP(hipMemcpyAsync((char*)s->pinned + cnt * sizeof(Pt), lvlS[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
+                    continue;
+                }
+            }
+        }
+#endif
+        if (!folded) {
             ZK_LAUNCH(s, st, "msm_fold_giant", (k_fold_giant<F>), dim3(GIANT_MAX * 16), dim3(256), 0, partial[b], R.task_off, (const uint32_t*)R.num_multi);  // exits at once without giants
             ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
-        }
-        // ---- 6. bucket reduce, fused: level 1 + every wave level in one launch (no lane-serial second level: m = m1 buckets per lane)
-        bool fused_ok = fuse_tail && !(sizeof(F) == sizeof(Fp) && jobs[b]->quad_tail) && N1 % 64 == 0;
-        if (fused_ok) {
-            const uint32_t host_n1 = (W * 64 <= 64) ? 64 : 1;
-            uint32_t N = N1 / 64, sh = 6, ncnt = 0;
-            for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;
-            for (uint32_t n = N; n > host_n1; n = (n + 63) / 64) ncnt += W * ((n + 63) / 64);
-            if (ncnt > TAIL_COUNTERS) fused_ok = false;
-            else {
-                ZK_LAUNCH(s, st, "msm_tail", (k_tail_fused<F>), dim3(W * (N1 / 64)), dim3(64), 0, (const Pt*)partial[b], R.task_off, B, W, m1, sh - 6, host_n1, lvlA[b][0],
-                          lvlS[b][0], lvlA[b][1], lvlS[b][1], counters + 64);
-                while (N > host_n1) { N = (N + 63) / 64; sh += 6; }
-                jobs[b]->n_final = N;
-                jobs[b]->sh_final = sh;
-                const size_t cnt = (size_t)W * N;
-                ZK_TRY(s->pinned_reserve(2 * cnt * sizeof(Pt)));
-                ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
-                if (N > 1) ZK_HIP(hipMemcpyAsync((char*)s->pinned + cnt * sizeof(Pt), lvlS[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
-                continue;
-            }
         }
         // ---- 6. bucket reduce
         bool quad = false;

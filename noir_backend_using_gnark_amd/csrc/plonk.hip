@@ -232,9 +232,42 @@ __global__ __launch_bounds__(256) void k_hscan_local(const Fr* __restrict__ f, s
     if (tcarry) tcarry[gt] = threadIdx.x < 255 ? sh[threadIdx.x + 1] : Fr::zero();
     if (threadIdx.x == 0) btot[blockIdx.x] = val;
 }
+// Several polynomials at the SAME point in one launch (plonk.Prove evaluates l, r, o, s1, s2 and then foldedH, linPol at zeta: seven evaluations that are two
+// launches each -- a lane-Horner pass and a single-workgroup block scan that is pure latency): blockIdx.y selects the polynomial.
+constexpr int HSCAN_BATCH_MAX = 8;
+struct HscanBatch {
+    const Fr* f[HSCAN_BATCH_MAX];
+    size_t len[HSCAN_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void k_hscan_local_batch(HscanBatch Bt, uint32_t K, Fr a, Fr A, uint32_t nb, Fr* __restrict__ btot) {
+    __shared__ Fr sh[256];
+    const Fr* __restrict__ f = Bt.f[blockIdx.y];
+    const size_t len = Bt.len[blockIdx.y];
+    size_t gt = (size_t)blockIdx.x * 256 + threadIdx.x, base = gt * K;
+    Fr acc = Fr::zero();
+    for (int k = (int)K - 1; k >= 0; k--) {
+        size_t i = base + (size_t)k;
+        acc = acc * a;
+        if (i < len) acc = acc + ld(f + i);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    Fr val = acc, Ad = A;
+    for (unsigned d = 1; d < 256; d <<= 1) {
+        Fr o = threadIdx.x + d < 256 ? sh[threadIdx.x + d] : Fr::zero();
+        __syncthreads();
+        val = val + Ad * o;
+        sh[threadIdx.x] = val;
+        __syncthreads();
+        Ad = Ad.sqr();
+    }
+    if (threadIdx.x == 0) btot[(size_t)blockIdx.y * nb + blockIdx.x] = val;
+}
 // pass 2: one block; btot[b] <- C_b = sum_{b' > b} btot[b'] * M^(b'-b-1) (M = A^256); *total = S_0 = f(a).
 __global__ __launch_bounds__(1024) void k_hscan_blocks(Fr* __restrict__ btot, uint32_t nb, Fr M, Fr* __restrict__ total) {
     __shared__ Fr sh[1024];
+    btot += (size_t)blockIdx.x * nb;  // batched form: one workgroup per polynomial, rows of nb block totals, results in total[blockIdx.x]
+    if (total) total += blockIdx.x;
     Fr carry = Fr::zero();  // S at the start of the chunk above
     uint32_t nchunks = (nb + 1023) / 1024;
     Fr M1024 = M;
@@ -553,7 +586,7 @@ struct ScanBufs {
     uint32_t K = 0, nb = 0;
     Fr *t = nullptr, *b = nullptr, *total = nullptr;
 };
-static size_t scan_need(size_t len) { return (len / 8 + 4096) * sizeof(Fr) + 8192; }
+static size_t scan_need(size_t len) { return (len / 8 + 4096) * sizeof(Fr) + 8192 + (size_t)8 * (len / 2048 + 2) * sizeof(Fr); }
 static int scan_bufs(Slot* s, size_t len, ScanBufs* B) {
     uint32_t K = (uint32_t)((len + 256 * 1024 - 1) / (256 * 1024));
     if (K < 8) K = 8;
@@ -561,13 +594,14 @@ static int scan_bufs(Slot* s, size_t len, ScanBufs* B) {
     B->K = K;
     B->nb = (uint32_t)((T + 255) / 256);
     B->t = (Fr*)s->alloc((size_t)B->nb * 256 * sizeof(Fr));
-    B->b = (Fr*)s->alloc((size_t)B->nb * sizeof(Fr) + 64);
+    B->b = (Fr*)s->alloc((size_t)HSCAN_BATCH_MAX * B->nb * sizeof(Fr) + 64);  // HSCAN_BATCH_MAX rows: poly_eval_batch_dev
     B->total = (Fr*)s->alloc(64);
     if (!B->t || !B->b || !B->total) return set_err(ZK_ERR_HIP, "PLONK scan workspace was not reserved");
     return ZK_OK;
 }
-// f(a) -> *d_out (device), asynchronous
-static int poly_eval_dev(Slot* s, hipStream_t st, const Fr* f, size_t len, const HFr& a, const ScanBufs& B, Fr* d_out) {
+// f_k(a) -> d_out[k] for cnt <= HSCAN_BATCH_MAX polynomials, two launches in all
+static int poly_eval_batch_dev(Slot* s, hipStream_t st, const Fr* const* f, const size_t* len, int cnt, const HFr& a, const ScanBufs& B, Fr* d_out) {
+    if (cnt < 1 || cnt > HSCAN_BATCH_MAX) return set_err(ZK_ERR_ARG, "evaluation batch of %d", cnt);
     HFr A = HFr::one(), M;
     {
         HFr base = a;
@@ -575,8 +609,10 @@ static int poly_eval_dev(Slot* s, hipStream_t st, const Fr* f, size_t len, const
         M = A;
         for (int i = 0; i < 8; i++) M = M.sqr();
     }
-    ZK_LAUNCH(s, st, "plonk_horner_local", k_hscan_local, dim3(B.nb), dim3(256), 0, f, len, B.K, to_dev(a), to_dev(A), (Fr*)nullptr, B.b);
-    ZK_LAUNCH(s, st, "plonk_horner_blocks", k_hscan_blocks, dim3(1), dim3(1024), 0, B.b, B.nb, to_dev(M), d_out);
+    HscanBatch Bt;
+    for (int k = 0; k < HSCAN_BATCH_MAX; k++) { Bt.f[k] = f[k < cnt ? k : 0]; Bt.len[k] = len[k < cnt ? k : 0]; }
+    ZK_LAUNCH(s, st, "plonk_horner_local", k_hscan_local_batch, dim3(B.nb, (unsigned)cnt), dim3(256), 0, Bt, B.K, to_dev(a), to_dev(A), B.nb, B.b);
+    ZK_LAUNCH(s, st, "plonk_horner_blocks", k_hscan_blocks, dim3((unsigned)cnt), dim3(1024), 0, B.b, B.nb, to_dev(M), d_out);
     return ZK_OK;
 }
 // q = (f - f(a)) / (X - a) (len - 1 coefficients; q may alias f; q[len-1] is set to 0), f(a) -> *d_eval
@@ -1265,7 +1301,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     const HFr zeta_sh = zeta * P->gen;
     const Fr* ev_p[5] = {bl_, br_, bo_, P->s1, P->s2};
     const size_t ev_len[5] = {n + 2, n + 2, n + 2, n, n};
-    for (int k = 0; k < 5; k++) ZK_TRY(poly_eval_dev(s, st, ev_p[k], ev_len[k], zeta, SB, d_vals + k));
+    ZK_TRY(poly_eval_batch_dev(s, st, ev_p, ev_len, 5, zeta, SB, d_vals));
     ZK_TRY(poly_divide_dev(s, st, bz_, n + 3, zeta_sh, SB, quo, d_vals + 5));
     HFr ev[8];
     ZK_HIP(hipMemcpyAsync(ev, d_vals, 6 * sizeof(Fr), hipMemcpyDeviceToHost, st));
@@ -1343,8 +1379,11 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     const Affine<HFp> c_fh = fhd.to_affine();
 
     // ---- kzg.BatchOpenSinglePoint of (foldedH, linPol, l, r, o, s1, s2) at zeta
-    ZK_TRY(poly_eval_dev(s, st, fh, n + 2, zeta, SB, d_vals + 6));
-    ZK_TRY(poly_eval_dev(s, st, lin, n + 3, zeta, SB, d_vals + 7));
+    {
+        const Fr* const p2[2] = {fh, lin};
+        const size_t l2[2] = {n + 2, n + 3};
+        ZK_TRY(poly_eval_batch_dev(s, st, p2, l2, 2, zeta, SB, d_vals + 6));
+    }
     ZK_HIP(hipMemcpyAsync(ev + 6, d_vals + 6, 2 * sizeof(Fr), hipMemcpyDeviceToHost, st));
     ZK_TRY(slot_sync(s, st));
     if (chain.ok && !lin_direct) ZK_TRY(chain.finish(1, &c_lin));

@@ -225,4 +225,65 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------- exclusive scan (u32), three short launches
+// out[i] = sum of in[0 .. i): per-tile sums -> one workgroup scans them -> per-tile scan with its base.  (The library alternative, rocPRIM's single-pass scan,
+// chains its tiles through look-back like the sort did.)  in == out is allowed.
+constexpr unsigned XS_THREADS = 256, XS_IPT = 8, XS_TILE = XS_THREADS * XS_IPT;
+static inline size_t xs_tmp_bytes(size_t n) { return ((n + XS_TILE - 1) / XS_TILE + 1) * 4 + 256; }
+
+__device__ __forceinline__ uint32_t xs_block_exclusive(uint32_t v, uint32_t* total) {  // exclusive scan of one value per thread over the workgroup
+    __shared__ uint32_t sh[XS_THREADS];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (unsigned d = 1; d < XS_THREADS; d <<= 1) {
+        const uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const uint32_t incl = sh[threadIdx.x];
+    if (total) *total = sh[XS_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+__global__ __launch_bounds__(XS_THREADS) void k_xs_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums) {
+    prio_hi();
+    const uint32_t base = blockIdx.x * XS_TILE + threadIdx.x * XS_IPT;
+    uint32_t v = 0;
+#pragma unroll
+    for (unsigned k = 0; k < XS_IPT; k++)
+        if (base + k < n) v += in[base + k];
+    uint32_t total;
+    (void)xs_block_exclusive(v, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(XS_THREADS) void k_xs_scan_sums(uint32_t* __restrict__ sums, uint32_t ntiles) {
+    prio_hi();
+    uint32_t carry = 0;
+    for (uint32_t lo = 0; lo < ntiles; lo += XS_THREADS) {
+        const uint32_t i = lo + threadIdx.x;
+        const uint32_t v = i < ntiles ? sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = xs_block_exclusive(v, &total);
+        if (i < ntiles) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+__global__ __launch_bounds__(XS_THREADS) void k_xs_apply(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ sums, uint32_t* __restrict__ out) {
+    prio_hi();
+    const uint32_t base = blockIdx.x * XS_TILE + threadIdx.x * XS_IPT;
+    uint32_t x[XS_IPT], v = 0;
+#pragma unroll
+    for (unsigned k = 0; k < XS_IPT; k++) {
+        x[k] = base + k < n ? in[base + k] : 0;
+        v += x[k];
+    }
+    uint32_t run = sums[blockIdx.x] + xs_block_exclusive(v, nullptr);
+#pragma unroll
+    for (unsigned k = 0; k < XS_IPT; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += x[k];
+    }
+}
+
 }  // namespace zkmi

@@ -2,13 +2,20 @@
 """Merges into profiles/pmc_traffic.json the per-kernel HBM traffic of two rocprofv3 --pmc run directories (FETCH_SIZE and WRITE_SIZE
 collected in separate passes, as MI355X_MICROARCH.md prescribes), keyed by the per-GPU problem size the runs used:
     pmc_traffic.py <fetch_dir> <write_dir> profiles/pmc_traffic.json <log_n> [label]
--> json[kernel]["by_log_n"][log_n] (bench.py reports `roofline.traffic` only for the size it is running).  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE
-counts a 128-byte request as 64 bytes (guide's correction, calibrated on wide streams); the uncorrected figure is kept too."""
+-> json[kernel]["by_log_n"][log_n] (bench.py reports `roofline.traffic` only for the size it is running).  HBM bytes per launch = (f * FETCH_SIZE + WRITE_SIZE) * 1024 with the
+gfx950 correction f calibrated PER ACCESS PATTERN (tools/gather_calib.hip, profiles/r03_gather_calib.json: known 4 GiB per launch): f = 2 for wide coalesced streams (the guide's
+case: FETCH_SIZE counts a 128-byte request as 64 bytes), f = 2 for 128-byte random gathers (k_accumulate<G2>) and for 64-byte records read by consecutive lanes, but f = 1 for
+64-byte gathers at random indices (k_accumulate<G1>'s window-table reads: FETCH_SIZE = 0.9997 of the known bytes).  The uncorrected figure is kept too."""
 import collections, csv, glob, json, re, sys
 
-NAMES = {"k_accumulate<G1>": ["msm_accumulate_g1"], "k_accumulate<G2>": ["msm_accumulate_g2"], "radix_sort_onesweep": ["msm_radix_sort(rocprim)"],
+NAMES = {"k_accumulate<G1>": ["msm_accumulate_g1"], "k_accumulate<G2>": ["msm_accumulate_g2"], "k_accumulate_pf<G1>": ["msm_accumulate_g1"], "k_accumulate_pf<G2>": ["msm_accumulate_g2"],
+         "k_rs_scatter": ["msm_sort_pass"], "radix_sort_onesweep": ["msm_radix_sort(rocprim)"],
          "k_reduce_l1<G1>": ["msm_reduce_l1"], "k_reduce_wave<G1>": ["msm_reduce_wave"], "k_ntt_pass29": ["ntt_pass_contig", "ntt_pass_strided"],
          "k_ntt_pass": ["ntt_pass_contig", "ntt_pass_strided"], "k_msm_digits": ["msm_digits"]}
+
+
+# FETCH_SIZE correction by access pattern (profiles/r03_gather_calib.json); everything else: wide streams, 2
+FETCH_FACTOR = {"k_accumulate<G1>": 1.0, "k_accumulate_pf<G1>": 1.0}
 
 
 def per_kernel(d, counter):
@@ -28,8 +35,8 @@ def per_kernel(d, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-cpu-baseline; hbm_bytes = "
-        "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B requests as 64 B; calibrated for wide "
-        "streams only -- the accumulate kernel issues 64/128-B gathers, so the uncorrected figure is given too)")
+        "(f*FETCH_SIZE + WRITE_SIZE)*1024, f calibrated per access pattern on known byte counts (tools/gather_calib.hip): 2 for streams and 128-B gathers, "
+        "1 for k_accumulate<G1>'s random 64-B gathers; the uncorrected figure is given too")
 log_n = sys.argv[4]
 label = sys.argv[5] if len(sys.argv) > 5 else ""
 try:
@@ -41,7 +48,8 @@ shown = {}
 for k, names in NAMES.items():
     if k in fetch and k in write:
         for nm in names:
-            e = {"FETCH_SIZE_KB_avg": fetch[k], "WRITE_SIZE_KB_avg": write[k], "hbm_bytes_per_launch": int((2 * fetch[k] + write[k]) * 1024),
+            f = FETCH_FACTOR.get(k, 2.0)
+            e = {"FETCH_SIZE_KB_avg": fetch[k], "WRITE_SIZE_KB_avg": write[k], "hbm_bytes_per_launch": int((f * fetch[k] + write[k]) * 1024), "fetch_correction_factor": f,
                  "hbm_bytes_per_launch_uncorrected": int((fetch[k] + write[k]) * 1024), "rocprof_kernel": k, "taken_at": label}
             out.setdefault(nm, {"by_log_n": {}})["by_log_n"][log_n] = e
             shown[nm] = e["hbm_bytes_per_launch"]
