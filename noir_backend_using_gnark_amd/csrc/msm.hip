@@ -1260,7 +1260,9 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
                 folded = true;
             }
             // bucket reduce, fused: level 1 + every wave level in one launch (no lane-serial second level: m = m1 buckets per lane)
-            bool fused_ok = fuse_tail && !(sizeof(F) == sizeof(Fp) && jobs[b]->quad_tail) && N1 % 64 == 0;
+            // ZKMI_FUSE_TAIL=2: only the latency-structured tails (no lane-serial second level: the exposed ones -- Z's in a Groth16 proof, every commitment's in PLONK)
+            static const bool exposed_only = ZK_EXP("ZKMI_FUSE_TAIL", 0) == 2;
+            bool fused_ok = fuse_tail && !(exposed_only && P.m2 > 1) && !(sizeof(F) == sizeof(Fp) && jobs[b]->quad_tail) && N1 % 64 == 0;
             if (fused_ok) {
                 const uint32_t host_n1 = (W * 64 <= 64) ? 64 : 1;
                 uint32_t N = N1 / 64, sh = 6, ncnt = 0;

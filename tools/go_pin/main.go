@@ -18,6 +18,13 @@
 //	                                    548-byte proofs (this re-derives gamma, beta, alpha, zeta from the bytes: it pins the proof layout,
 //	                                    the transcript and the verifying-key image at once); ProvingKey round trip as for Groth16
 //
+//	6. HandleValues (f3)                the REFERENCE'S OWN lowering -- plonk_backend.BuildSparseR1CS of gnark_backend_ffi/backend/plonk, which calls
+//	                                    backend.HandleValues (backend/common.go:45-76) -- run on the fixtures with two and three public inputs
+//	                                    (tests/golden/plonk_multi_public_golden.json), then upstream's plonk.Setup on the fixture's SRS: variable counts,
+//	                                    witness order and the ProvingKey / VerifyingKey bytes must be the fixture's layout "reference" (what
+//	                                    libgnark_backend.so produces); the proofs of both layouts must verify under their keys.  go.mod points the
+//	                                    module gnark_backend_ffi at a checkout of the reference (replace directive: adjust the path).
+//
 // Every line printed is "PASS ..." or "FAIL ..."; the exit status is the number of failures.  When all pass, DESIGN.md's "parity unpinned"
 // can be struck: the oracle is then pinned by upstream itself.
 package main
@@ -41,6 +48,9 @@ import (
 	"github.com/consensys/gnark/backend/groth16"
 	"github.com/consensys/gnark/backend/plonk"
 	"github.com/consensys/gnark/backend/witness"
+
+	"gnark_backend_ffi/acir"
+	plonk_backend "gnark_backend_ffi/backend/plonk"
 )
 
 var failures int
@@ -373,6 +383,69 @@ func checkPlonk(cases []plonkCase) {
 	}
 }
 
+type multiPublicLayout struct {
+	NPublic  int      `json:"n_public"`
+	NVars    int      `json:"n_vars"`
+	SrsSize  uint64   `json:"srs_size"`
+	Solution []string `json:"solution"`
+	Proof    string   `json:"proof"`
+	VkHex    string   `json:"vk_hex"`
+	PkHex    string   `json:"pk_hex"`
+}
+
+type multiPublicCase struct {
+	Name     string                       `json:"name"`
+	Acir     json.RawMessage              `json:"acir"`
+	Values   []string                     `json:"values"`
+	SrsAlpha string                       `json:"srs_alpha"`
+	Layouts  map[string]multiPublicLayout `json:"layouts"`
+}
+
+// the reference's own BuildSparseR1CS / HandleValues on circuits with several public inputs, against the fixture's layout "reference"
+func checkHandleValues(cases []multiPublicCase) {
+	var flat []plonkCase
+	for _, c := range cases {
+		ref := c.Layouts["reference"]
+		var circuit acir.ACIR
+		must(json.Unmarshal(c.Acir, &circuit))
+		values := make(fr.Vector, len(c.Values))
+		for i := range values {
+			values[i] = frFromHex(c.Values[i])
+		}
+		spr, pub, sec := plonk_backend.BuildSparseR1CS(circuit, values)
+		report(spr.GetNbPublicVariables() == ref.NPublic && spr.GetNbPublicVariables()+spr.GetNbSecretVariables() == ref.NVars,
+			"HandleValues %s: %d public + %d secret variables (fixture: %d of %d)", c.Name, spr.GetNbPublicVariables(), spr.GetNbSecretVariables(), ref.NPublic, ref.NVars)
+		got := append(append(fr.Vector{}, pub...), sec...)
+		same := len(got) == len(ref.Solution)
+		for i := 0; same && i < len(got); i++ {
+			w := frFromHex(ref.Solution[i])
+			same = w.Equal(&got[i])
+		}
+		report(same, "HandleValues %s: the witness vector (public, then secret) is the fixture's solution", c.Name)
+		srs, err := kzg.NewSRS(ref.SrsSize, bigFromHex(c.SrsAlpha))
+		must(err)
+		pk, vk, err := plonk.Setup(spr, srs)
+		report(err == nil, "plonk.Setup on the reference's constraint system %s (%v)", c.Name, err)
+		if err != nil {
+			continue
+		}
+		var pb, vb bytes.Buffer
+		_, err = pk.WriteTo(&pb)
+		must(err)
+		_, err = vk.WriteTo(&vb)
+		must(err)
+		report(bytes.Equal(vb.Bytes(), unhex(ref.VkHex)), "reference lowering + plonk.Setup: VerifyingKey bytes == fixture (layout reference) %s", c.Name)
+		report(bytes.Equal(pb.Bytes(), unhex(ref.PkHex)), "reference lowering + plonk.Setup: ProvingKey bytes == fixture (layout reference) %s", c.Name)
+		one := c.Layouts["one_var"]
+		report(!bytes.Equal(pb.Bytes(), unhex(one.PkHex)), "the one-variable-per-witness layout is a different key %s", c.Name)
+		for lname, l := range c.Layouts {
+			flat = append(flat, plonkCase{Name: c.Name + "/" + lname, NPublic: l.NPublic, Solution: l.Solution, SrsAlpha: c.SrsAlpha, SrsSize: l.SrsSize, Proof: l.Proof,
+				VkHex: l.VkHex, PkHex: l.PkHex})
+		}
+	}
+	checkPlonk(flat)
+}
+
 func main() {
 	dir := "../../tests/golden"
 	if len(os.Args) > 1 {
@@ -390,6 +463,9 @@ func main() {
 	checkFFT(&g)
 	checkGroth16(&g, gw)
 	checkPlonk(pc)
+	var mp []multiPublicCase
+	load(filepath.Join(dir, "plonk_multi_public_golden.json"), &mp)
+	checkHandleValues(mp)
 	fmt.Printf("%d failure(s)\n", failures)
 	os.Exit(failures)
 }
