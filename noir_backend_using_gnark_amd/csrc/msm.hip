@@ -489,10 +489,11 @@ __global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32
 // addition keeps 97 % of its rate with two waves per SIMD instead of four (tools/ubench2.hip), and a grid that never holds more than that leaves half of
 // every SIMD's registers and wave slots free for the kernels that have to make progress underneath -- the next MSM's sort (whose look-back tiles spin
 // while they wait for a slot), the transforms, the reduction tails.  The one-lane-per-task kernel above fills every slot the moment one frees up.
-template <class F>
-__global__ __launch_bounds__(256) void k_accumulate_resident(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
+template <class F, bool PF>
+__global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accumulate_resident(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
                                                              const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
                                                              uint32_t max_tasks, uint32_t* __restrict__ next_chunk) {
+    __shared__ uint4 stage[PF ? 4 : 1][PF ? sizeof(Affine<F>) / 16 * 64 : 1];  // PF: the LDS-DMA staging slots of acc_task_pf
     const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
     XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
     const uint32_t skip_below = batch.skip_below[blockIdx.y];
@@ -509,7 +510,8 @@ __global__ __launch_bounds__(256) void k_accumulate_resident(AccBatch batch, con
         if (key == 0xffffffffu) continue;
         const uint32_t t = task_sorted[i];
         const uint32_t begin = task_begin[t];
-        acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
+        if constexpr (PF) acc_task_pf<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key), stage[threadIdx.x >> 6]);
+        else acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
     }
 }
 #endif
@@ -1219,8 +1221,12 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
             uint32_t* next_chunk = (uint32_t*)sl[0]->alloc(16);
             if (!next_chunk) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
             ZK_HIP(hipMemsetAsync(next_chunk, 0, 16, sa));
-            ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
-                      R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
+            if (ZK_EXP(sizeof(F) == 32 ? "ZKMI_ACC_PF_G1" : "ZKMI_ACC_PF_G2", 0) != 0)
+                ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F, true>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
+                          R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
+            else
+                ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F, false>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
+                          R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
             launched = true;
         } else if (ZK_EXP(sizeof(F) == 32 ? "ZKMI_ACC_PF_G1" : "ZKMI_ACC_PF_G2", 0) != 0) {
             ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_pf<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
