@@ -130,6 +130,30 @@ __device__ __forceinline__ U29 u29_mul4(const U29& a0, const U29& b0, const U29&
     return r;
 }
 
+// Two INDEPENDENT products (squarings) in one block, instruction streams interleaved (gen_ff29_asm.py emit_pair): same instructions as two u29_mul,
+// but the wave has two multiply-add chains in flight instead of one.
+#define ZK29_X2_IN(t, N, A)                                                                                                                \
+    [N##0_##t] "v"(A.l[0]), [N##1_##t] "v"(A.l[1]), [N##2_##t] "v"(A.l[2]), [N##3_##t] "v"(A.l[3]), [N##4_##t] "v"(A.l[4]),                \
+        [N##5_##t] "v"(A.l[5]), [N##6_##t] "v"(A.l[6]), [N##7_##t] "v"(A.l[7]), [N##8_##t] "v"(A.l[8])
+#define ZK29_X2_OUT(t, r)                                                                                                                  \
+    [r0_##t] "=&v"(r.l[0]), [r1_##t] "=&v"(r.l[1]), [r2_##t] "=&v"(r.l[2]), [r3_##t] "=&v"(r.l[3]), [r4_##t] "=&v"(r.l[4]),                 \
+        [r5_##t] "=&v"(r.l[5]), [r6_##t] "=&v"(r.l[6]), [r7_##t] "=&v"(r.l[7]), [r8_##t] "=&v"(r.l[8])
+__device__ __forceinline__ void u29_mul_x2(const U29& a0, const U29& b0, const U29& a1, const U29& b1, U29& r0, U29& r1) {
+    asm(ZKMI_MONT_MUL29_X2_ASM
+        : ZK29_X2_OUT(0, r0), ZK29_X2_OUT(1, r1)
+        : ZK29_X2_IN(0, a, a0), ZK29_X2_IN(0, b, b0), ZK29_X2_IN(1, a, a1), ZK29_X2_IN(1, b, b1), ZK29_SG
+        : "v0", "v1", "v2", "v3", "vcc");
+}
+__device__ __forceinline__ void u29_sqr_x2(const U29& a0, const U29& a1, U29& r0, U29& r1) {
+    U29 d0, d1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { d0.l[i] = a0.l[i] + a0.l[i]; d1.l[i] = a1.l[i] + a1.l[i]; }
+    asm(ZKMI_MONT_SQR29_X2_ASM
+        : ZK29_X2_OUT(0, r0), ZK29_X2_OUT(1, r1)
+        : ZK29_X2_IN(0, a, a0), ZK29_X2_IN(0, d, d0), ZK29_X2_IN(1, a, a1), ZK29_X2_IN(1, d, d1), ZK29_SG
+        : "v0", "v1", "v2", "v3", "vcc");
+}
+
 // K*p - a, weakly normalised  (a weakly normalised, < K*p)
 template <int K>
 __device__ __forceinline__ U29 u29_neg(const U29& a) {
@@ -298,6 +322,38 @@ __device__ __forceinline__ void xyzz_madd29(Acc29& A, const Fp& px, const Fp& py
         A.inf = false;
         return;
     }
+#ifdef ZKMI_MUL_PAIR
+    // the same ten products, eight of them issued as four interleaved pairs of INDEPENDENT ones: (U2, S2), (P^2, R^2), (ZZ1 PP, P PP), (X1 PP, ZZZ1 PPP)
+    U29 U2, S2;
+    u29_mul_x2(x2, A.zz, y2, A.zzz, U2, S2);
+    const U29 P = u29_wnorm(u29_sub<16>(U2, A.x));
+    const U29 R = u29_wnorm(u29_sub<4>(S2, A.y));
+    U29 PP, RR;
+    u29_sqr_x2(P, R, PP, RR);
+    U29 ZZ3, PPP;
+    u29_mul_x2(A.zz, PP, P, PP, ZZ3, PPP);
+    if ((((ZZ3.l[0] & Fp29::MASK) * Fp29::PINV) & Fp29::MASK) < 2u) {
+        XYZZ<Fp> c = acc29_to_xyzz(A);
+        c.madd(px, py);
+        acc29_from_xyzz(A, c);
+        return;
+    }
+    {
+        U29 Q, ZZZ3;
+        u29_mul_x2(A.x, PP, A.zzz, PPP, Q, ZZZ3);
+        U29 t = u29_wnorm(u29_sub<4>(RR, PPP));
+        t = u29_sub<4>(t, Q);
+        t = u29_sub<4>(t, Q);
+        const U29 X3 = u29_wnorm(t);
+        const U29 d = u29_wnorm(u29_sub<16>(Q, X3));
+        const U29 Y3 = u29_mul2(R, d, u29_neg<4>(A.y), PPP);
+        A.zzz = ZZZ3;
+        A.zz = ZZ3;
+        A.x = X3;
+        A.y = Y3;
+        return;
+    }
+#else
     const U29 U2 = u29_mul(x2, A.zz);
     const U29 S2 = u29_mul(y2, A.zzz);
     const U29 P = u29_wnorm(u29_sub<16>(U2, A.x));
@@ -327,6 +383,7 @@ __device__ __forceinline__ void xyzz_madd29(Acc29& A, const Fp& px, const Fp& py
     A.zz = ZZ3;
     A.x = X3;
     A.y = Y3;
+#endif
 }
 
 // m < 3p is a direct product output: m == 0 mod p ?

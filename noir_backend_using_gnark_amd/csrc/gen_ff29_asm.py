@@ -99,8 +99,39 @@ def emit_sqr():
     return L
 
 
+def rename_stream(lines, t):
+    """Operands of one single-product stream renamed for slot t of a two-product block: %[aI] -> %[aI_t], %[bI] / %[dI] / %[rI] likewise;
+    slot 1 accumulates in v[2:3] instead of v[0:1] (modulus limbs and ninv are shared)."""
+    import re
+    out = []
+    for l in lines:
+        l = re.sub(r"%\[([abdr])(\d)\]", lambda m: "%%[%s%s_%d]" % (m.group(1), m.group(2), t), l)
+        if t == 1:
+            l = l.replace("v[0:1]", "v[2:3]").replace(" v0", " v2")
+        out.append(l)
+    return out
+
+
+def emit_pair(sqr=False):
+    """TWO INDEPENDENT products in one block, their instruction streams interleaved one to one: every product is a single dependent chain of
+    multiply-adds on one accumulator, and four waves per SIMD do not quite cover that chain's latency (990 cycles per product at 4 waves, 915 at 8:
+    tools/ubench4.hip) -- a second, independent chain in the same wave does, at no extra instruction."""
+    a = rename_stream(emit_sqr() if sqr else emit(1), 0)
+    b = rename_stream(emit_sqr() if sqr else emit(1), 1)
+    out = []
+    for x, y in zip(a, b):
+        out += [x, y]
+    return out
+
+
 def main():
     print("// GENERATED by gen_ff29_asm.py -- do not edit; see that file for the schedule.")
+    for name, lines in (("ZKMI_MONT_MUL29_X2_ASM", emit_pair(False)), ("ZKMI_MONT_SQR29_X2_ASM", emit_pair(True))):
+        print("// two independent %s interleaved: %d instructions" % ("squarings" if "SQR" in name else "products", len(lines)))
+        print("#define %s \\" % name)
+        for i, l in enumerate(lines):
+            end = " \\" if i + 1 < len(lines) else ""
+            print('    "%s\\n\\t"%s' % (l, end))
     lines = emit_sqr()
     print("// squaring: %d instructions: %d v_mad_u64_u32" % (len(lines), sum("v_mad_u64" in l for l in lines)))
     print("#define ZKMI_MONT_SQR29_ASM \\")

@@ -468,8 +468,13 @@ __global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accu
     acc_task_pf<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key), stage[threadIdx.x >> 6]);
 }
 #endif
+#ifdef ZKMI_MUL_PAIR
+#define ZK_ACC_BOUNDS __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2))  // the paired products want 136 VGPRs: hold the kernel at four waves per SIMD
+#else
+#define ZK_ACC_BOUNDS __launch_bounds__(256)
+#endif
 template <class F>
-__global__ __launch_bounds__(256) void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
+__global__ ZK_ACC_BOUNDS void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
                                                     const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
                                                     uint32_t max_tasks) {
     const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
