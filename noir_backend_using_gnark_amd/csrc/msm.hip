@@ -503,10 +503,21 @@ __global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accu
     XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
     const uint32_t skip_below = batch.skip_below[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
-    for (;;) {
+    // next_chunk == nullptr: STATIC serpentine assignment instead of the counter -- wave v of V takes chunk v in round 0, chunk 2V - 1 - v in round 1, 2V + v in
+    // round 2, ...: with the tasks sorted by decreasing length every wave's total is nearly the same (a 2^20-point MSM has only ~2 tasks per lane, so WHICH two
+    // matters: longest with shortest)
+    const uint32_t V = gridDim.x * 4, v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t round = 0;; round++) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(next_chunk + blockIdx.y, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
+        if (next_chunk) {
+            if (lane == 0) base = atomicAdd(next_chunk + blockIdx.y, 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+        } else {
+            base = ((round & 1) ? (round + 1) * V - 1 - v : round * V + v) * 64u;
+            if (round * V * 64u >= max_tasks) return;
+            if (len_key_sorted[min(round * V * 64u, max_tasks - 1)] == 0xffffffffu) return;  // the whole round is padding
+            if (base >= max_tasks || len_key_sorted[base] == 0xffffffffu) continue;        // this wave's chunk of a partly filled round
+        }
         if (base >= max_tasks) return;
         if (len_key_sorted[base] == 0xffffffffu) return;  // the real tasks fill [0, total): everything from here on is padding
         const uint32_t i = base + lane;
@@ -1223,9 +1234,10 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         static const unsigned wg_g1 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G1", 0), wg_g2 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G2", 0);
         const unsigned wg_per_cu = sizeof(F) == 32 ? wg_g1 : wg_g2;
         if (wg_per_cu && full_grid > wg_per_cu * (unsigned)ctx().num_cus) {
-            uint32_t* next_chunk = (uint32_t*)sl[0]->alloc(16);
-            if (!next_chunk) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
-            ZK_HIP(hipMemsetAsync(next_chunk, 0, 16, sa));
+            static const bool serpentine = ZK_EXP("ZKMI_ACC_SERP", 0) != 0;  // static longest-with-shortest assignment instead of the chunk counter
+            uint32_t* next_chunk = serpentine ? nullptr : (uint32_t*)sl[0]->alloc(16);
+            if (!serpentine && !next_chunk) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
+            if (next_chunk) ZK_HIP(hipMemsetAsync(next_chunk, 0, 16, sa));
             if (ZK_EXP(sizeof(F) == 32 ? "ZKMI_ACC_PF_G1" : "ZKMI_ACC_PF_G2", 0) != 0)
                 ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F, true>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
                           R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
