@@ -1,4 +1,6 @@
 // Radix sort of (bucket key, point index | sign) pairs for the MSM's scalar preparation -- hand-written for gfx950, no library call.
+// Part of the replacement of gnark-crypto v0.9.1 `MultiExp` (ecc/bn254/multiexp.go: partitionScalars + one goroutine per window walking ALL points;
+// reached from /root/reference/gnark_backend_ffi/main.go:131 and backend/plonk/plonk.go:21,67): here every bucket becomes a contiguous run instead.
 //
 // Why not rocPRIM's radix_sort_pairs (rounds 1-2): its onesweep passes chain the tiles of a pass through decoupled look-back -- a tile SPINS until its
 // predecessor has published a prefix.  Alone on the GPU that is the fastest known scheme (0.39 ms for the 13.6 M digits of a 2^20-point MSM); inside a proof
