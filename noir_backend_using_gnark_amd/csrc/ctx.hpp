@@ -31,8 +31,10 @@ static inline long zk_exp_env(const char* name, long dflt) {
 #endif
 // Wave priority of the short kernels (scalar preparation, transforms, reduction tails).  A SIMD arbitrates VALU issue by priority, then AGE
 // (MI355X_MICROARCH.md "Two waves per SIMD"): next to the long-lived waves of an accumulate kernel -- always older -- a young wave only gets the issue
-// slots they leave, which is why these kernels took 3-6x their stand-alone time inside a proof.  -DZKMI_PRIO_HI=n (1..3) raises them above the
-// accumulate kernels (priority 0); 0 compiles the call away.
+// slots they leave -- tools/corun_bench.hip: at equal priority a sort makes NO progress under a compute kernel, at any occupancy.  -DZKMI_PRIO_HI=n (1..3)
+// raises them above the accumulate kernels (priority 0); 0 compiles the call away.  The shipped build uses 3 here and 1 for the transforms (Makefile PRIO):
+// priority alone does not make a short kernel fast next to an accumulate kernel at full occupancy (it also needs free registers: 6-7 x its solo time),
+// but it keeps it from starving, and the memory-bound preparation gets through computeH's phase ahead of the transforms.
 #ifndef ZKMI_PRIO_HI
 #define ZKMI_PRIO_HI 0
 #endif
@@ -40,6 +42,15 @@ static inline long zk_exp_env(const char* name, long dflt) {
 __device__ __forceinline__ void prio_hi() {
 #if ZKMI_PRIO_HI
     __builtin_amdgcn_s_setprio(ZKMI_PRIO_HI);
+#endif
+}
+// the transforms: above the accumulate kernels, below the memory-bound preparation kernels they share computeH's phase with (-DZKMI_PRIO_MID=n)
+#ifndef ZKMI_PRIO_MID
+#define ZKMI_PRIO_MID ZKMI_PRIO_HI
+#endif
+__device__ __forceinline__ void prio_mid() {
+#if ZKMI_PRIO_MID
+    __builtin_amdgcn_s_setprio(ZKMI_PRIO_MID);
 #endif
 }
 #endif

@@ -141,7 +141,7 @@ __device__ __forceinline__ void ntt_group(const PassArgs& A, uint4* lo, uint4* h
 }
 
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs A) {
-    prio_hi();
+    prio_mid();
     extern __shared__ uint4 lds[];
     const unsigned E = 1u << (A.k + A.logL);
     uint4* lo = lds;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void tile_copy_out(const PassArgs& A, const uint4* lo
 
 template <int GMAX, unsigned THREADS>
 __global__ __launch_bounds__(THREADS) void k_ntt_pass29(PassArgs A) {
-    prio_hi();
+    prio_mid();
     extern __shared__ uint4 lds[];
     const unsigned E = 1u << (A.k + A.logL);
     uint4* lo = lds;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(THREADS) void k_ntt_pass29(PassArgs A) {
 // per vector.
 template <int GMAX, unsigned THREADS>
 __global__ __launch_bounds__(THREADS) void k_ntt_pass29_if(PassArgs A) {
-    prio_hi();
+    prio_mid();
     extern __shared__ uint4 lds[];
     const unsigned E = 1u << (A.k + A.logL);
     uint4* lo = lds;
@@ -354,13 +354,13 @@ __global__ __launch_bounds__(THREADS) void k_ntt_pass29_if(PassArgs A) {
 
 // a[i] *= t[i]  (used when a transform has no stage to fold a scaling into: N == 1)
 __global__ void k_scale_table(Fr* a, const Fr* t, size_t n) {
-    prio_hi();
+    prio_mid();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = a[i] * gload_fr(t + i);
 }
 
 __global__ void k_bit_reverse(Fr* a, unsigned logn) {
-    prio_hi();
+    prio_mid();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t n = (size_t)1 << logn;
     if (i >= n) return;
@@ -374,7 +374,7 @@ __global__ void k_bit_reverse(Fr* a, unsigned logn) {
 
 // h = (a*b - c) * den    (gnark computeH pointwise step)
 __global__ void k_h_pointwise(Fr* a, const Fr* b, const Fr* c, Fr den, size_t n) {
-    prio_hi();
+    prio_mid();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr x = gload_fr(a + i) * gload_fr(b + i) - gload_fr(c + i);
@@ -383,14 +383,14 @@ __global__ void k_h_pointwise(Fr* a, const Fr* b, const Fr* c, Fr den, size_t n)
 
 // h = (u - c) * den: the last step of computeH when c stays in coefficient form (see compute_h_inplace)
 __global__ void k_h_final(Fr* u, const Fr* c, Fr den, size_t n) {
-    prio_hi();
+    prio_mid();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u[i] = (gload_fr(u + i) - gload_fr(c + i)) * den;
 }
 
 __global__ void k_fr_mul(Fr* out, const Fr* a, const Fr* b, size_t n) {
-    prio_hi();
+    prio_mid();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gload_fr(a + i) * gload_fr(b + i);
 }
@@ -685,7 +685,7 @@ int fr_mul_dev(Slot* s, hipStream_t st, Fr* out, const Fr* a, const Fr* b, size_
 // w^(((s mod h)*M + rho*C + j) << t); DIT cross stage u pairs s, s + 2^u with w^(((s mod 2^u)*M + rho*C + j) * (G >> (u+1))).
 template <int LOGG, bool DIF>
 __global__ __launch_bounds__(256) void k_ntt_cross(Fr* __restrict__ T, const Fr* __restrict__ tw, unsigned logM, unsigned rank) {
-    prio_hi();
+    prio_mid();
     constexpr unsigned G = 1u << LOGG;
     const size_t C = ((size_t)1 << logM) >> LOGG;
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
