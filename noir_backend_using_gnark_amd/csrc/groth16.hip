@@ -822,6 +822,21 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
         // prepare(h) run underneath the accumulate kernels).  computeH goes FIRST and alone with the bandwidth-bound sort of w:
         // measured, an NTT launched underneath an accumulate kernel is starved (1.3 ms -> 8 ms) because the long-running accumulate
         // workgroups never free enough wave slots, and the Z chain then finishes late.
+        // ZKMI_H_UNDER_G2=1 (experiment switch): prepare(w) ALONE first, then computeH started together with the G2.B accumulate (to be combined with
+        // ZKMI_ACC_WG_G2=1: that kernel at one wave per SIMD leaves half of the registers and the LDS to the transforms' workgroups)
+        static const bool h_under_g2 = ZK_EXP("ZKMI_H_UNDER_G2", 0) == 1;
+        if (h_under_g2) {
+            if (!on_device && nw && hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
+            in.d_w = d_w;
+            in.d_wk = d_w + P.n_public;
+            in.d_h = d_abc[0];
+            if (rc == ZK_OK) rc = msm5_prepare_w(g.s, in, nullptr, &S);
+            if (rc == ZK_OK) rc = upload_abc();
+            if (rc == ZK_OK && S.prep_w.ready && hipStreamWaitEvent(st, S.prep_w.ready, 0) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipStreamWaitEvent failed");
+            if (rc == ZK_OK) rc = run_compute_h();
+            if (rc == ZK_OK) rc = msm5_accumulate_w(g.s, in, nullptr, &S, nullptr);
+            if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
+        } else {
         rc = upload_abc();
         if (rc == ZK_OK) rc = run_compute_h();
         if (!on_device && rc == ZK_OK && nw && hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
@@ -835,6 +850,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
         } else {
             if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);
             if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S);
+        }
         }
     }
     if (ev_h) (void)hipEventDestroy(ev_h);

@@ -58,6 +58,11 @@ struct PassArgs {
     int canonical;       // 29-bit-limb passes: last pass of the transform -> canonical image; else a lazily reduced 256-bit intermediate
     const Fr* tw2;       // fused inverse-then-forward pass (k_ntt_pass29_if): twiddles of the forward half
     const Fr* src;       // 29-bit-limb passes: read the tile from here instead of `data` (first pass of an out-of-place transform) or null
+    const Fr* sub;       // 29-bit-limb passes, last stage: after `post`, element i becomes (x - sub[i]) * post_const  (computeH's closing step) or null
+    Fr* data2;           // 29-bit-limb passes launched with gridDim.y = 2 or 3: the workgroups with blockIdx.y = 1 / 2 run the same pass on these vectors
+    const Fr* src2;      // (src2 -> data2, src3 -> data3).  In k_ntt_pass29_if the third vector only takes the inverse half, closed by post_const (computeH's c)
+    Fr* data3;
+    const Fr* src3;
     uint32_t tw_and;     // EXPERIMENT (ZKMI_NTT_TWMASK): twiddle index mask -- 0xffffffff in production; a small mask makes every twiddle load an L1 hit
                          // (wrong results, right timing): the upper bound of what any twiddle-staging scheme could gain
 };
@@ -208,8 +213,18 @@ __device__ __forceinline__ void lds_store9(uint4* lo, uint4* hi, uint32_t* top, 
     top[t] = v.l[8];
 }
 
-template <int G, bool DIF, unsigned THREADS>
-__device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, unsigned s0,
+// What a pass does at its two ends, resolved by the kernel once (no copies of PassArgs): twiddles, the entry table, the exit table or constant, whether the
+// stored image is canonical.  SUB (compile-time: its extra live values would cost every other pass a wave of occupancy) adds computeH's closing step.
+struct PassEnds {
+    const Fr* tw;
+    const Fr* pre;
+    const Fr* post;
+    bool post_const;  // multiply by A.post_const on exit (when post is null)
+    bool canonical;
+};
+
+template <int G, bool DIF, unsigned THREADS, bool SUB>
+__device__ __forceinline__ void ntt_group29(const PassArgs& A, const PassEnds& P, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, unsigned s0,
                                             bool load_packed, bool apply_pre, bool apply_post, bool store_packed) {
     constexpr unsigned NE = 1u << G;
     const unsigned L = 1u << A.logL;
@@ -222,7 +237,7 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
         for (unsigned e = 0; e < NE; e++) {
             const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
             x[e] = load_packed ? u29_unpack(lds_load(lo, hi, t)) : lds_load9(lo, hi, top, t);
-            if (apply_pre && A.pre) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
+            if (apply_pre && P.pre) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(P.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
         }
 #pragma unroll
         for (int sl = 0; sl < G; sl++) {
@@ -234,7 +249,7 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
                 const unsigned e1 = e0 | (1u << bitl);
                 const size_t g0 = base + ((size_t)(mid0 | (e0 << ql)) << A.bit_lo) + l;
                 const size_t j = g0 & (((size_t)1 << b) - 1);
-                const U29 w = u29_unpack(gload_fr(A.tw + ((j << (A.logn - 1 - b)) & A.tw_and)));  // b == 0: entry 0 = 2^261 mod r, the unit
+                const U29 w = u29_unpack(gload_fr(P.tw + ((j << (A.logn - 1 - b)) & A.tw_and)));  // b == 0: entry 0 = 2^261 mod r, the unit
                 if (DIF) {
                     U29 d;
                     if (sl == 0) d = u29r_sub<16>(x[e0], x[e1]);
@@ -259,56 +274,74 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
         for (unsigned e = 0; e < NE; e++) {
             const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
             if (apply_post) {
-                if (A.post) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.post + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
-                else if (A.has_post_const) x[e] = u29r_mul(x[e], u29r_load5(A.post_const));
+                if (P.post) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(P.post + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
+                else if (P.post_const) x[e] = u29r_mul(x[e], u29r_load5(A.post_const));
+                if (SUB) {  // x < 2 r after the product above; sub[i] canonical: the difference stays below 6 r, a legal multiplicand (tools/u29_ntt_model.py)
+                    const U29 c = u29_unpack(gload_fr(A.sub + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l));
+                    x[e] = u29r_mul(u29r_sub<4>(x[e], c), u29r_load5(A.post_const));
+                }
             }
-            if (store_packed) lds_store(lo, hi, t, u29r_pack(u29r_reduce(x[e]), A.canonical != 0));
+            if (store_packed) lds_store(lo, hi, t, u29r_pack(u29r_reduce(x[e]), P.canonical));
             else lds_store9(lo, hi, top, t, x[e]);
         }
     }
 }
 
 // all k stages of a pass, GMAX at a time.  packed_in / packed_out: the tile sits in LDS as 8 packed words before / after.
-template <int GMAX, unsigned THREADS, bool DIF>
-__device__ __forceinline__ void ntt_stages29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, bool packed_in,
+template <int GMAX, unsigned THREADS, bool DIF, bool SUB = false>
+__device__ __forceinline__ void ntt_stages29(const PassArgs& A, const PassEnds& P, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, bool packed_in,
                                              bool packed_out) {
     for (unsigned s0 = 0; s0 < A.k;) {
         const unsigned G = (A.k - s0 >= (unsigned)GMAX) ? (unsigned)GMAX : (A.k - s0);
         const bool first = (s0 == 0), last = (s0 + G == A.k);
         const bool lp = first && packed_in, sp = last && packed_out;
-        if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), DIF, THREADS>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
-        else if (G == 2) ntt_group29<2, DIF, THREADS>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
-        else ntt_group29<1, DIF, THREADS>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+        if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), DIF, THREADS, SUB>(A, P, lo, hi, top, base, E, s0, lp, first, last, sp);
+        else if (G == 2) ntt_group29<2, DIF, THREADS, SUB>(A, P, lo, hi, top, base, E, s0, lp, first, last, sp);
+        else ntt_group29<1, DIF, THREADS, SUB>(A, P, lo, hi, top, base, E, s0, lp, first, last, sp);
         s0 += G;
         __syncthreads();
     }
 }
 
+// which vector a workgroup works on (gridDim.y = 1 .. 3): resolved once, in scalar registers.  Masks instead of ?: on purpose -- a conditional between two
+// members of the kernel-argument struct is a conditional between their ADDRESSES, which makes the compiler keep a copy of the whole struct in scratch memory
+__device__ __forceinline__ uintptr_t pick3(uintptr_t v0, uintptr_t v1, uintptr_t v2) {
+    const uintptr_t m1 = (uintptr_t)0 - (uintptr_t)(blockIdx.y == 1), m2 = (uintptr_t)0 - (uintptr_t)(blockIdx.y == 2);
+    return (v0 & ~(m1 | m2)) | (v1 & m1) | (v2 & m2);
+}
+__device__ __forceinline__ Fr* pass_data(const PassArgs& A) { return reinterpret_cast<Fr*>(pick3((uintptr_t)A.data, (uintptr_t)A.data2, (uintptr_t)A.data3)); }
+__device__ __forceinline__ const Fr* pass_src(const PassArgs& A, const Fr* data) {
+    const uintptr_t src = pick3((uintptr_t)A.src, (uintptr_t)A.src2, (uintptr_t)A.src3);
+    return src ? reinterpret_cast<const Fr*>(src) : data;
+}
 template <unsigned THREADS>
-__device__ __forceinline__ void tile_copy_in(const PassArgs& A, uint4* lo, uint4* hi, size_t base, unsigned E) {
-    const unsigned L = 1u << A.logL;
-    const uint4* g = reinterpret_cast<const uint4*>(A.src ? A.src : A.data);
+__device__ __forceinline__ void tile_copy_in(const Fr* src, unsigned logL, unsigned bit_lo, uint4* lo, uint4* hi, size_t base, unsigned E) {
+    const unsigned L = 1u << logL;
+    const uint4* g = reinterpret_cast<const uint4*>(src);
     for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
         unsigned e = h >> 1, half = h & 1;
-        unsigned mid = e >> A.logL, l = e & (L - 1);
-        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        unsigned mid = e >> logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << bit_lo) + l;
         (half ? hi : lo)[e] = g[gi * 2 + half];
     }
 }
 template <unsigned THREADS>
-__device__ __forceinline__ void tile_copy_out(const PassArgs& A, const uint4* lo, const uint4* hi, size_t base, unsigned E) {
-    const unsigned L = 1u << A.logL;
-    uint4* g = reinterpret_cast<uint4*>(A.data);
+__device__ __forceinline__ void tile_copy_out(Fr* dst, unsigned logL, unsigned bit_lo, const uint4* lo, const uint4* hi, size_t base, unsigned E) {
+    const unsigned L = 1u << logL;
+    uint4* g = reinterpret_cast<uint4*>(dst);
     for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
         unsigned e = h >> 1, half = h & 1;
-        unsigned mid = e >> A.logL, l = e & (L - 1);
-        size_t gi = base + ((size_t)mid << A.bit_lo) + l;
+        unsigned mid = e >> logL, l = e & (L - 1);
+        size_t gi = base + ((size_t)mid << bit_lo) + l;
         g[gi * 2 + half] = (half ? hi : lo)[e];
     }
 }
 
-template <int GMAX, unsigned THREADS>
-__global__ __launch_bounds__(THREADS) void k_ntt_pass29(PassArgs A) {
+// 512 lanes: two workgroups per CU (4 waves per SIMD, 128 VGPRs); 256 lanes (radix-8 groups, A/B variant): two waves per SIMD
+#define ZK_NTT_BOUNDS(THREADS) __launch_bounds__(THREADS, (THREADS) == 512 ? 4 : 2)
+
+template <int GMAX, unsigned THREADS, bool SUB = false>
+__global__ ZK_NTT_BOUNDS(THREADS) void k_ntt_pass29(PassArgs A) {
     prio_mid();
     extern __shared__ uint4 lds[];
     const unsigned E = 1u << (A.k + A.logL);
@@ -320,11 +353,13 @@ __global__ __launch_bounds__(THREADS) void k_ntt_pass29(PassArgs A) {
     const size_t hi_idx = tile / lo_blks;
     const unsigned lo_blk = (unsigned)(tile % lo_blks);
     const size_t base = (hi_idx << (A.bit_lo + A.k)) + ((size_t)lo_blk << A.logL);
-    tile_copy_in<THREADS>(A, lo, hi, base, E);
+    Fr* const data = pass_data(A);
+    tile_copy_in<THREADS>(pass_src(A, data), A.logL, A.bit_lo, lo, hi, base, E);
     __syncthreads();
-    if (A.dif) ntt_stages29<GMAX, THREADS, true>(A, lo, hi, top, base, E, true, true);
-    else ntt_stages29<GMAX, THREADS, false>(A, lo, hi, top, base, E, true, true);
-    tile_copy_out<THREADS>(A, lo, hi, base, E);
+    const PassEnds P = {A.tw, A.pre, A.post, A.has_post_const != 0, A.canonical != 0};
+    if (A.dif) ntt_stages29<GMAX, THREADS, true, SUB>(A, P, lo, hi, top, base, E, true, true);
+    else ntt_stages29<GMAX, THREADS, false, SUB>(A, P, lo, hi, top, base, E, true, true);
+    tile_copy_out<THREADS>(data, A.logL, A.bit_lo, lo, hi, base, E);
 }
 
 // computeH runs FFTInverse(DIF) immediately followed by FFT(DIT, coset) on the same vector: the inverse transform ENDS with the
@@ -332,7 +367,7 @@ __global__ __launch_bounds__(THREADS) void k_ntt_pass29(PassArgs A) {
 // kernel: load tile, k DIF stages (A.tw), * A.post (1/N * g^bitrev(i)), k DIT stages (A.tw2), store.  One HBM round trip saved
 // per vector.
 template <int GMAX, unsigned THREADS>
-__global__ __launch_bounds__(THREADS) void k_ntt_pass29_if(PassArgs A) {
+__global__ ZK_NTT_BOUNDS(THREADS) void k_ntt_pass29_if(PassArgs A) {
     prio_mid();
     extern __shared__ uint4 lds[];
     const unsigned E = 1u << (A.k + A.logL);
@@ -340,16 +375,19 @@ __global__ __launch_bounds__(THREADS) void k_ntt_pass29_if(PassArgs A) {
     uint4* hi = lds + E;
     uint32_t* top = reinterpret_cast<uint32_t*>(lds + 2 * E);
     const size_t base = (size_t)blockIdx.x << A.k;  // contiguous tiles only (bit_lo = 0, logL = 0)
-    tile_copy_in<THREADS>(A, lo, hi, base, E);
+    Fr* const data = pass_data(A);
+    tile_copy_in<THREADS>(pass_src(A, data), 0, 0, lo, hi, base, E);
     __syncthreads();
-    ntt_stages29<GMAX, THREADS, true>(A, lo, hi, top, base, E, true, false);   // inverse half; its post table is applied, limbs stay unpacked
-    PassArgs F = A;
-    F.tw = A.tw2;
-    F.pre = nullptr;
-    F.post = nullptr;
-    F.has_post_const = 0;
-    ntt_stages29<GMAX, THREADS, false>(F, lo, hi, top, base, E, false, true);  // forward half
-    tile_copy_out<THREADS>(A, lo, hi, base, E);
+    if (blockIdx.y == 2) {  // the third vector: a plain FFTInverse ending (* post_const, canonical image)
+        const PassEnds C = {A.tw, nullptr, nullptr, true, true};
+        ntt_stages29<GMAX, THREADS, true>(A, C, lo, hi, top, base, E, true, true);
+    } else {
+        const PassEnds I = {A.tw, nullptr, A.post, false, false};
+        ntt_stages29<GMAX, THREADS, true>(A, I, lo, hi, top, base, E, true, false);   // inverse half; its post table is applied, limbs stay unpacked
+        const PassEnds F = {A.tw2, nullptr, nullptr, false, A.canonical != 0};
+        ntt_stages29<GMAX, THREADS, false>(A, F, lo, hi, top, base, E, false, true);  // forward half
+    }
+    tile_copy_out<THREADS>(data, 0, 0, lo, hi, base, E);
 }
 
 // a[i] *= t[i]  (used when a transform has no stage to fold a scaling into: N == 1)
@@ -488,15 +526,19 @@ static int launch_pass(Slot* s, hipStream_t st, const PassArgs& A_, bool sat) {
     unsigned E = 1u << (A.k + A.logL);
     size_t tiles = ((size_t)1 << A.logn) / E;
     const char* name = A.logL ? "ntt_pass_strided" : "ntt_pass_contig";
+    const unsigned ny = sat ? 1 : 1 + (A.data2 ? 1 : 0) + (A.data2 && A.data3 ? 1 : 0);
     if (sat) ZK_LAUNCH(s, st, name, k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 32, A);
-    else if (g_ntt_g2) ZK_LAUNCH(s, st, name, (k_ntt_pass29<2, 512>), dim3((unsigned)tiles), dim3(512), (size_t)E * 36, A);
-    else ZK_LAUNCH(s, st, name, (k_ntt_pass29<3, 256>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 36, A);
+    else if (A.sub && g_ntt_g2) ZK_LAUNCH(s, st, name, (k_ntt_pass29<2, 512, true>), dim3((unsigned)tiles, ny), dim3(512), (size_t)E * 36, A);
+    else if (A.sub) ZK_LAUNCH(s, st, name, (k_ntt_pass29<3, 256, true>), dim3((unsigned)tiles, ny), dim3(NTT_THREADS), (size_t)E * 36, A);
+    else if (g_ntt_g2) ZK_LAUNCH(s, st, name, (k_ntt_pass29<2, 512>), dim3((unsigned)tiles, ny), dim3(512), (size_t)E * 36, A);
+    else ZK_LAUNCH(s, st, name, (k_ntt_pass29<3, 256>), dim3((unsigned)tiles, ny), dim3(NTT_THREADS), (size_t)E * 36, A);
     return ZK_OK;
 }
 
 // Runs the log2(N) stages of one transform as a sequence of tile passes.
 static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int inverse, int dif, const Fr* pre, const Fr* post,
-                      const Fr* post_const, const Fr* src = nullptr) {
+                      const Fr* post_const, const Fr* src = nullptr, const Fr* sub = nullptr) {
+    // sub (29-bit-limb passes only, with `post` AND `post_const`): the last stage leaves (x * post[i] - sub[i]) * post_const
     const unsigned logn = dom->logn;
     const bool sat = g_ntt_saturated;
     const Fr* tw = sat ? (inverse ? dom->tw_inv : dom->tw) : (inverse ? dom->tw29_inv : dom->tw29);
@@ -516,11 +558,13 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int 
         // DIF walks the bits from the top, DIT from the bottom
         const PassPlan& p = dif ? passes[npass - 1 - idx] : passes[idx];
         PassArgs A;
+        A.data2 = nullptr; A.src2 = nullptr; A.data3 = nullptr; A.src3 = nullptr;
         A.data = data; A.tw = tw; A.tw2 = nullptr; A.src = (idx == 0 && src && src != data) ? src : nullptr; A.logn = logn; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = dif;
         A.pre = (idx == 0) ? pre : nullptr;
         A.post = (idx + 1 == npass) ? post : nullptr;
         A.has_post_const = (idx + 1 == npass && post_const && !post) ? 1 : 0;
-        if (A.has_post_const) A.post_const = *post_const; else A.post_const = Fr::zero();
+        A.sub = (idx + 1 == npass && !sat) ? sub : nullptr;
+        if (A.has_post_const || A.sub) A.post_const = *post_const; else A.post_const = Fr::zero();
         A.canonical = (idx + 1 == npass) ? 1 : 0;
         ZK_TRY(launch_pass(s, st, A, sat));
     }
@@ -530,10 +574,19 @@ static int run_passes(Slot* s, hipStream_t st, Fr* data, const Domain* dom, int 
 // FFTInverse(DIF) with `mid` applied at its end (1/N and whatever scaling follows), then FFT(DIT): as run_passes twice, but the two
 // contiguous passes in the middle are ONE kernel (k_ntt_pass29_if).
 static const bool g_ntt_fuse_if = (ZK_EXP("ZKMI_NTT_FUSE", 1) != 0);  // A/B switch
-static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* dom, const Fr* mid, const Fr* src = nullptr) {
+static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* dom, const Fr* mid, const Fr* src = nullptr, Fr* data2 = nullptr,
+                               const Fr* src2 = nullptr, Fr* data3 = nullptr, const Fr* src3 = nullptr, const Fr* end3 = nullptr) {
     // src (optional): the input lives there and stays untouched -- the first pass reads it and writes `data`
+    // data2 / src2 (optional): a second vector taken through the same passes by the same launches (gridDim.y = 2)
+    // data3 / src3 / end3 (optional, with data2): a third vector that only takes the INVERSE transform, closed by the constant *end3 (computeH's c), in the
+    // launches of the inverse half (gridDim.y = 3)
     const unsigned logn = dom->logn;
     if (g_ntt_saturated || !g_ntt_fuse_if || logn == 0) {
+        if (data2) {  // the unfused A/B variants take the vectors one after the other
+            ZK_TRY(run_inverse_forward(s, st, data, dom, mid, src));
+            ZK_TRY(run_inverse_forward(s, st, data2, dom, mid, src2));
+            return data3 ? run_passes(s, st, data3, dom, 1, 1, nullptr, nullptr, end3, src3) : ZK_OK;
+        }
         if (src && src != data) ZK_HIP(hipMemcpyAsync(data, src, sizeof(Fr) << logn, hipMemcpyDeviceToDevice, st));
         ZK_TRY(run_passes(s, st, data, dom, 1, 1, nullptr, mid, nullptr));
         return run_passes(s, st, data, dom, 0, 0, nullptr, nullptr, nullptr);
@@ -542,13 +595,22 @@ static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* 
     const size_t npass = passes.size();
     PassArgs A;
     A.data = data; A.logn = logn; A.pre = nullptr; A.post = nullptr; A.has_post_const = 0; A.post_const = Fr::zero(); A.tw2 = nullptr;
+    A.sub = nullptr;
     A.tw_and = g_tw_and;
     A.src = (src && src != data) ? src : nullptr;  // consumed by whichever pass runs first
+    A.data2 = data2;
+    A.src2 = (data2 && src2 && src2 != data2) ? src2 : nullptr;
+    A.data3 = data2 ? data3 : nullptr;
+    A.src3 = (A.data3 && src3 && src3 != data3) ? src3 : nullptr;
+    if (A.data3) A.post_const = *end3;
+    const unsigned ny = 1 + (data2 ? 1 : 0) + (A.data3 ? 1 : 0);
     for (size_t idx = npass - 1; idx >= 1; idx--) {  // strided passes of the inverse transform, top bits first
         const PassPlan& p = passes[idx];
         A.tw = dom->tw29_inv; A.bit_lo = p.bit_lo; A.k = p.k; A.logL = p.logL; A.dif = 1; A.canonical = 0;
         ZK_TRY(launch_pass(s, st, A, false));
         A.src = nullptr;
+        A.src2 = nullptr;
+        A.src3 = nullptr;
     }
     {
         const PassPlan& p = passes[0];
@@ -556,11 +618,14 @@ static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* 
         A.canonical = (npass == 1) ? 1 : 0;
         unsigned E = 1u << p.k;
         size_t tiles = ((size_t)1 << logn) / E;
-        if (g_ntt_g2) ZK_LAUNCH(s, st, "ntt_pass_contig_if", (k_ntt_pass29_if<2, 512>), dim3((unsigned)tiles), dim3(512), (size_t)E * 36, A);
-        else ZK_LAUNCH(s, st, "ntt_pass_contig_if", (k_ntt_pass29_if<3, 256>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)E * 36, A);
+        if (g_ntt_g2) ZK_LAUNCH(s, st, "ntt_pass_contig_if", (k_ntt_pass29_if<2, 512>), dim3((unsigned)tiles, ny), dim3(512), (size_t)E * 36, A);
+        else ZK_LAUNCH(s, st, "ntt_pass_contig_if", (k_ntt_pass29_if<3, 256>), dim3((unsigned)tiles, ny), dim3(NTT_THREADS), (size_t)E * 36, A);
         A.post = nullptr;
         A.tw2 = nullptr;
         A.src = nullptr;
+        A.src2 = nullptr;
+        A.data3 = nullptr;  // c is done
+        A.src3 = nullptr;
     }
     for (size_t idx = 1; idx < npass; idx++) {  // strided passes of the forward transform, low bits first
         const PassPlan& p = passes[idx];
@@ -576,6 +641,8 @@ static int ensure_lds_attr() {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 32));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<3, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<2, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29_if<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29_if<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         g_lds_attr_set = true;
@@ -631,14 +698,26 @@ int compute_h_inplace(Slot* s, hipStream_t st, Fr* a, Fr* b, Fr* c, unsigned log
     static const bool skip_c = (ZK_EXP("ZKMI_H_SKIP_C", 1) != 0);
     if (skip_c && !side && logN > 0) {
         const Fr cinv = to_dev(d->card_inv);
-        for (int i = 0; i < 2; i++) ZK_TRY(run_inverse_forward(s, st, vs[i], d, d->coset_rev_n, src ? src[i] : nullptr));
-        ZK_TRY(run_passes(s, st, c, d, 1, 1, nullptr, nullptr, &cinv, src ? src[2] : nullptr));
-        ZK_LAUNCH(s, st, "fr_mul", k_fr_mul, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)a, (const Fr*)b, N);
-        ZK_TRY(run_passes(s, st, a, d, 1, 1, nullptr, d->coset_inv_n_rev, nullptr));
+        // a, b (and c for the inverse half) go through their passes in the SAME launches (gridDim.y = vector): at 2^20 a pass is ONE round of workgroups moving
+        // in lock-step (load, butterflies, store); with two or three rounds per launch one round's loads and stores run under another's butterflies, and seven
+        // launches disappear.  ZKMI_H_BATCH=0 (A/B switch): one vector per launch.
+        static const bool h_batch = ZK_EXP("ZKMI_H_BATCH", 1) == 1;
+        if (h_batch) {
+            ZK_TRY(run_inverse_forward(s, st, a, d, d->coset_rev_n, src ? src[0] : nullptr, b, src ? src[1] : nullptr, c, src ? src[2] : nullptr, &cinv));
+        } else {
+            for (int i = 0; i < 2; i++) ZK_TRY(run_inverse_forward(s, st, vs[i], d, d->coset_rev_n, src ? src[i] : nullptr));
+            ZK_TRY(run_passes(s, st, c, d, 1, 1, nullptr, nullptr, &cinv, src ? src[2] : nullptr));
+        }
         HFr gN = d->coset;
         for (unsigned i = 0; i < logN; i++) gN = gN.sqr();
-        const HFr den = (gN - HFr::one()).inv();
-        ZK_LAUNCH(s, st, "h_final", k_h_final, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)c, to_dev(den), N);
+        const Fr den = to_dev((gN - HFr::one()).inv());
+        // the product a*b rides on the loads of the closing transform's first stage (`pre` = b) and (x - c) * den on the stores of its last one (`sub` = c)
+        // instead of two element-wise kernels (96 B per element each).  ZKMI_H_FUSE_PW=0 (A/B switch): the two kernels.
+        static const bool fuse_pw = ZK_EXP("ZKMI_H_FUSE_PW", 1) == 1;
+        if (fuse_pw && !g_ntt_saturated) return run_passes(s, st, a, d, 1, 1, b, d->coset_inv_n_rev, &den, nullptr, c);
+        ZK_LAUNCH(s, st, "fr_mul", k_fr_mul, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)a, (const Fr*)b, N);
+        ZK_TRY(run_passes(s, st, a, d, 1, 1, nullptr, d->coset_inv_n_rev, nullptr));
+        ZK_LAUNCH(s, st, "h_final", k_h_final, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, a, (const Fr*)c, den, N);
         return ZK_OK;
     }
     if (side) {

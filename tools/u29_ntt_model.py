@@ -278,6 +278,21 @@ def check_bounds():
     x = b_mul(entry, sc)
     assert x.vmax < int(2.2 * P) * 32 * P // (1 << RBITS) + P + 2
     print("scaled by a (V << 5) table entry: %.2f r" % x.k())
+    # computeH's closing step on the last stage's stores (PassArgs.sub): y = mul(sub<4>(mul(x, post << 5), c), den << 5), c canonical
+    for k in range(1, 12):
+        out = bound_pass(True, k, entry)
+        d = b_sub(b_mul(out, sc), norm_b(P), 4)
+        y = b_mul(d, sc)
+        assert b_reduce(y).vmax < int(2.2 * P)
+    print("closing step (x * post - c) * den on a DIF pass end: difference %.2f r, product %.2f r" % (d.k(), y.k()))
+    rnd = random.Random(11)
+    for _ in range(2000):
+        xv, post, c, den = (rnd.randrange(int(2.2 * P)), rnd.randrange(P), rnd.randrange(P), rnd.randrange(P))
+        x1 = mul_exact(wnorm_exact(limbs(xv)), limbs(post << 5))
+        y1 = mul_exact(sub_exact(x1, limbs(c), 4), limbs(den << 5))
+        rinv = pow(1 << RBITS, -1, P)
+        assert val(y1) % P == ((xv * (post << 5) * rinv - c) * (den << 5) * rinv) % P
+    print("closing step: exact on 2000 samples")
 
 
 def exact_reduce_check(n=20000):
