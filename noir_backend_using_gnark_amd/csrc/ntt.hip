@@ -63,6 +63,7 @@ struct PassArgs {
     const Fr* src2;      // (src2 -> data2, src3 -> data3).  In k_ntt_pass29_if the third vector only takes the inverse half, closed by post_const (computeH's c)
     Fr* data3;
     const Fr* src3;
+    uint32_t unit_skip;  // 1: the stage on index bit 0 skips its product by the unit twiddle (0: A/B switch ZKMI_NTT_UNIT=0)
     uint32_t tw_and;     // EXPERIMENT (ZKMI_NTT_TWMASK): twiddle index mask -- 0xffffffff in production; a small mask makes every twiddle load an L1 hit
                          // (wrong results, right timing): the upper bound of what any twiddle-staging scheme could gain
 };
@@ -249,16 +250,20 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, const PassEnds& P
                 const unsigned e1 = e0 | (1u << bitl);
                 const size_t g0 = base + ((size_t)(mid0 | (e0 << ql)) << A.bit_lo) + l;
                 const size_t j = g0 & (((size_t)1 << b) - 1);
-                const U29 w = u29_unpack(gload_fr(P.tw + ((j << (A.logn - 1 - b)) & A.tw_and)));  // b == 0: entry 0 = 2^261 mod r, the unit
+                // the stage on index bit 0 (the last of a DIF transform, the first of a DIT one) has no twiddles: its product by the unit is replaced by a
+                // partial reduction (DIF) or dropped (DIT) -- one product in 20 at 2^20; same values mod r, bounds in tools/u29_ntt_model.py (`unit`)
+                const bool unit = bitl == 0 && b == 0 && A.unit_skip;  // bitl is a compile-time constant after unrolling, b is uniform over the launch
+                U29 w;
+                if (!unit) w = u29_unpack(gload_fr(P.tw + ((j << (A.logn - 1 - b)) & A.tw_and)));
                 if (DIF) {
                     U29 d;
                     if (sl == 0) d = u29r_sub<16>(x[e0], x[e1]);
                     else if (sl == 1) d = u29r_sub<24>(x[e0], x[e1]);
                     else d = u29r_sub<40>(x[e0], x[e1]);
                     x[e0] = u29_wnorm(u29_add(x[e0], x[e1]));
-                    x[e1] = u29r_mul(d, w);
+                    x[e1] = unit ? u29r_reduce(u29_wnorm(d)) : u29r_mul(d, w);
                 } else {
-                    U29 t = u29r_mul(x[e1], w);
+                    const U29 t = unit ? x[e1] : u29r_mul(x[e1], w);
                     x[e1] = u29_wnorm(u29r_sub<4>(x[e0], t));
                     x[e0] = u29_add(x[e0], t);
                 }
@@ -520,9 +525,11 @@ static std::vector<PassPlan> plan_passes(unsigned logn) {
 }
 
 static const uint32_t g_tw_and = (uint32_t)ZK_EXP("ZKMI_NTT_TWMASK", 0xffffffffL);
+static const uint32_t g_unit_skip = ZK_EXP("ZKMI_NTT_UNIT", 1) != 0;
 static int launch_pass(Slot* s, hipStream_t st, const PassArgs& A_, bool sat) {
     PassArgs A = A_;
     A.tw_and = g_tw_and;
+    A.unit_skip = g_unit_skip;
     unsigned E = 1u << (A.k + A.logL);
     size_t tiles = ((size_t)1 << A.logn) / E;
     const char* name = A.logL ? "ntt_pass_strided" : "ntt_pass_contig";
@@ -597,6 +604,7 @@ static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* 
     A.data = data; A.logn = logn; A.pre = nullptr; A.post = nullptr; A.has_post_const = 0; A.post_const = Fr::zero(); A.tw2 = nullptr;
     A.sub = nullptr;
     A.tw_and = g_tw_and;
+    A.unit_skip = g_unit_skip;
     A.src = (src && src != data) ? src : nullptr;  // consumed by whichever pass runs first
     A.data2 = data2;
     A.src2 = (data2 && src2 && src2 != data2) ? src2 : nullptr;

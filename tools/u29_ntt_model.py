@@ -219,7 +219,7 @@ def dif_group(O, x, tw, G):
             d = O.sub(a, b, DIF_K[s])
             x[e0] = O.wnorm(O.add(a, b))
             w = tw[s][e0]
-            x[e1] = O.mul(d, w)
+            x[e1] = O.mul(d, w) if w is not None else O.reduce(O.wnorm(d))  # unit stage (index bit 0): a partial reduction instead of the product by 1
     x[0] = O.reduce(x[0])
     return x
 
@@ -233,7 +233,7 @@ def dit_group(O, x, tw, G):
                 continue
             e1 = e0 | (1 << bit)
             w = tw[s][e0]
-            t = O.mul(x[e1], w)
+            t = O.mul(x[e1], w) if w is not None else x[e1]  # unit stage (index bit 0): the element itself
             a = x[e0]
             x[e0] = O.add(a, t)
             x[e1] = O.wnorm(O.sub(a, t, DIT_K))
@@ -242,15 +242,23 @@ def dit_group(O, x, tw, G):
     return x
 
 
-def bound_pass(dif, k, entry):
-    """Worst case through a pass of k stages taken 3 at a time; returns the bound of the elements at the end of the pass."""
+GMAX_MODEL = 3
+
+
+def bound_pass(dif, k, entry, unit=False):
+    """Worst case through a pass of k stages taken 3 at a time; returns the bound of the elements at the end of the pass.
+    unit: the pass is the contiguous one (bit_lo = 0) and skips the product of the stage on index bit 0 (DIF: its last stage, DIT: its first)."""
     cur = entry
     s0 = 0
     while s0 < k:
-        G = min(3, k - s0)
+        G = min(GMAX_MODEL, k - s0)
         NE = 1 << G
         worst = None
-        tw = [[TW] * NE for _ in range(G)]  # the unit twiddle of the stage on index bit 0 is multiplied like any other (table entry 0)
+        tw = [[TW] * NE for _ in range(G)]
+        if unit and dif and s0 + G == k:
+            tw[G - 1] = [None] * NE
+        if unit and not dif and s0 == 0:
+            tw[0] = [None] * NE
         x = [B(cur.vmax, cur.lmax) for _ in range(NE)]
         x = (dif_group if dif else dit_group)(Bound, x, tw, G)
         for v in x:
@@ -273,6 +281,12 @@ def check_bounds():
         assert redt.vmax < int(2.2 * P)
         print("pass of %2d stages: DIF end bound %.2f r (top limb %d bits), DIT end bound %.2f r -> after reduce %.3f r"
               % (k, out.k(), out.lmax[NL - 1].bit_length(), outt.k(), redt.k()))
+        for g in (2, 3):  # the same with the unit stage skipped, register groups of 2 (512 lanes) and 3 (256 lanes) stages
+            global GMAX_MODEL
+            GMAX_MODEL = g
+            assert b_reduce(bound_pass(True, k, entry, True)).vmax < int(2.2 * P)
+            assert b_reduce(bound_pass(False, k, entry, True)).vmax < int(2.2 * P)
+        GMAX_MODEL = 3
     # pre / post scalings: multiplication by a table value loaded as V << 5 (< 32 r, normalised)
     sc = norm_b(32 * P)
     x = b_mul(entry, sc)
@@ -315,7 +329,7 @@ def exact_reduce_check(n=20000):
 
 
 # ---------------------------------------------------------------------------------- whole transforms from the group routines
-def transform_exact(vals, log_n, dif, inverse, passes):
+def transform_exact(vals, log_n, dif, inverse, passes, unit=False):
     """vals: integers (canonical images are not needed here: plain residues; the limb routines only see X and W' = w 2^261).
     passes: list of (bit_lo, k) in increasing bit order.  In place, gnark's data movement."""
     n = 1 << log_n
@@ -343,7 +357,7 @@ def transform_exact(vals, log_n, dif, inverse, passes):
                     for e0 in range(1 << G):
                         g0 = idx[e0]
                         j = g0 & ((1 << b) - 1)
-                        row.append(twp(0) if b == 0 else twp(j << (log_n - 1 - b)))
+                        row.append((None if unit else twp(0)) if b == 0 else twp(j << (log_n - 1 - b)))
                     tw.append(row)
                 x = (dif_group if dif else dit_group)(Exact, x, tw, G)
                 for i, v in zip(idx, x):
@@ -365,6 +379,8 @@ def exact_transform_check():
         inv = transform_exact(x, log_n, True, True, passes)
         want = dom.fft_inverse(x, ref.DIF)
         assert [v * dom.card_inv % P for v in inv] == want
+        assert transform_exact(x, log_n, True, False, passes, True) == dom.fft(x, ref.DIF)
+        assert transform_exact(x, log_n, False, False, passes, True) == dom.fft(x, ref.DIT)
         print("transforms 2^%d with passes %s: DIF, DIT, inverse DIF exact" % (log_n, passes))
 
 
