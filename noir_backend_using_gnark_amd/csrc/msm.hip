@@ -468,11 +468,9 @@ __global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accu
     acc_task_pf<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key), stage[threadIdx.x >> 6]);
 }
 #endif
-#ifdef ZKMI_MUL_PAIR
-#define ZK_ACC_BOUNDS __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2))  // the paired products want 136 VGPRs: hold the kernel at four waves per SIMD
-#else
-#define ZK_ACC_BOUNDS __launch_bounds__(256)
-#endif
+// four waves per SIMD (G1) / two (G2) are part of the kernel's design: say so, so that a change that wants a few registers more shows up as spills in
+// -Rpass-analysis=kernel-resource-usage instead of silently dropping a wave (a shorter formula for the second point of a task asked for 134: DESIGN.md 8)
+#define ZK_ACC_BOUNDS __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2))
 template <class F>
 __global__ ZK_ACC_BOUNDS void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
                                                     const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,

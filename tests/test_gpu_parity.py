@@ -275,6 +275,14 @@ def test_compute_h_golden_and_oracle(golden):
         assert (zk.compute_h(a, b, c, log_n) == orc.groth16_compute_h(a, b, c, log_n)).all()
 
 
+@pytest.mark.parametrize("log_n,n", [(1, 2), (2, 3), (11, 2048), (21, (1 << 21) - 3)])
+def test_compute_h_pass_counts_vs_oracle(log_n, n):
+    """computeH where its shared launches change shape: a single contiguous pass (<= 2^11: the closing transform's entry product and
+    exit step meet in ONE kernel), and three passes per transform (2^21); the two-pass sizes are covered above."""
+    a, b, c = orc.rand_fr(11, n), orc.rand_fr(12, n), orc.rand_fr(13, n)
+    assert (zk.compute_h(a, b, c, log_n) == orc.groth16_compute_h(a, b, c, log_n)).all()
+
+
 def test_groth16_golden_proofs(golden):
     """Byte-identical 128-B proofs on the committed instances (each verified by the independent pairing check when
     the fixture was generated), incl. the reference's own toy circuit X*Y=Z (main.go:80-107)."""

@@ -237,6 +237,11 @@ class ExactOps:
         pass
     mul = staticmethod(mul_exact)
     mulN = staticmethod(mulN_exact)
+
+    @staticmethod
+    def reduce(a):
+        return reduce_exact_p(a)
+
     add = staticmethod(add_exact)
     wnorm = staticmethod(wnorm_exact)
 
@@ -255,6 +260,13 @@ class ExactOps:
 
 class BoundOps:
     mul = staticmethod(b_mul)
+
+    @staticmethod
+    def reduce(a):  # u29p_reduce of a weakly normalised value: < 2.01 p, normalised limbs (exactness: reduce_exact_p)
+        assert all(v + (1 << 11) < 1 << 32 for v in a.lmax)
+        v = int(2.01 * Q)
+        return B(v, [MASK] * (NL - 1) + [v >> (W * (NL - 1))])
+
     mulN = staticmethod(b_mulN)
     add = staticmethod(b_add)
 
@@ -290,6 +302,27 @@ def madd_fp(O, X1, Y1, ZZ1, ZZZ1, X2, Y2):
     ZZ3 = O.mul(ZZ1, PP)
     ZZZ3 = O.mul(ZZZ1, PPP)
     return X3, Y3, ZZ3, ZZZ3
+
+
+def madd_fp_second(O, X1, Y1, X2, Y2):
+    """The SECOND point of a task: the accumulator is still affine (ZZ1 = ZZZ1 = "one", X1 / Y1 the contracted first point), so U2 = X2, S2 = Y2,
+    ZZ3 = PP and ZZZ3 = PPP -- four products less.  X2 / Y2 (fresh loads, < 32 p) are partially reduced instead (u29p_reduce, < 2.01 p), which keeps every
+    value inside the envelope of the generic madd; the biases are those of the generic sites except P's (4 p: X1 < 1.2 p here)."""
+    U2 = O.reduce(X2)
+    S2 = O.reduce(Y2)
+    P = O.wnorm(O.sub(U2, X1, 4))
+    R = O.wnorm(O.sub(S2, Y1, "g1.R"))
+    PP = O.mul(P, P)
+    PPP = O.mul(P, PP)
+    Qv = O.mul(X1, PP)
+    t = O.mul(R, R)
+    t = O.wnorm(O.sub(t, PPP, "g1.m"))
+    t = O.sub(t, Qv, "g1.m")
+    t = O.sub(t, Qv, "g1.m")
+    X3 = O.wnorm(t)
+    d = O.wnorm(O.sub(Qv, X3, "g1.QX"))
+    Y3 = O.mulN([(R, d), (O.neg(Y1, "g1.nY"), PPP)])
+    return X3, Y3, PP, PPP
 
 
 def add_fp(O, A, Bp):
@@ -640,9 +673,12 @@ def exact_check(n=300):
     X, Y = mul_exact(to_u29(P0[0]), one), mul_exact(to_u29(P0[1]), one)
     ZZ, ZZZ = list(one), list(one)
     acc = P0
-    for _ in range(n):
+    for it in range(n):
         P2 = on_curve_point()
-        X, Y, ZZ, ZZZ = madd_fp(ExactOps, X, Y, ZZ, ZZZ, to_u29(P2[0]), to_u29(P2[1]))
+        if it == 0:   # the second point of the task: the shorter formula
+            X, Y, ZZ, ZZZ = madd_fp_second(ExactOps, X, Y, to_u29(P2[0]), to_u29(P2[1]))
+        else:
+            X, Y, ZZ, ZZZ = madd_fp(ExactOps, X, Y, ZZ, ZZZ, to_u29(P2[0]), to_u29(P2[1]))
         acc = ec_madd_affine(acc, P2)
         x = from_u29(X) * pow(from_u29(ZZ), -1, Q) % Q
         y = from_u29(Y) * pow(from_u29(ZZZ), -1, Q) % Q
@@ -728,7 +764,18 @@ def main():
     print("p limbs (29-bit):", ", ".join("0x%08x" % v for v in PL))
     print("ninv29 = 0x%08x" % NINV)
     print("G1 (Fp) madd bound propagation:")
-    fixed_point(madd_fp, False)
+    # the second point of a task through the shorter formula: its outputs must lie inside the generic fixed point (they feed generic madds)
+    fx, fy, fzz, fzzz = fixed_point(madd_fp, False)
+    one = B(2 * Q, [MASK] * (NL - 1) + [(2 * Q) >> (W * (NL - 1))])
+    sx, sy, szz, szzz = madd_fp_second(BoundOps, one, one, B.fresh(), B.fresh())
+    # its outputs feed generic madds: propagate from them with the biases already chosen -- no subtraction site may need a larger multiple of p
+    before = dict(SITE_K)
+    gx, gy, gzz, gzzz = madd_fp(BoundOps, sx, sy, szz, szzz, B.fresh(), B.fresh())
+    for _ in range(12):
+        gx, gy, gzz, gzzz = madd_fp(BoundOps, b_max(gx, sx), b_max(gy, sy), b_max(gzz, szz), b_max(gzzz, szzz), B.fresh(), B.fresh())
+    assert SITE_K == before, "the second-point formula needs larger biases: %s vs %s" % (SITE_K, before)
+    print("  second-point formula: X %.2f  Y %.2f  ZZ %.2f  ZZZ %.2f p; generic madds after it: X %.2f  Y %.2f  ZZ %.2f  ZZZ %.2f p, same biases"
+          % (sx.kp(), sy.kp(), szz.kp(), szzz.kp(), gx.kp(), gy.kp(), gzz.kp(), gzzz.kp()))
     print("G2 (Fp2) madd bound propagation:")
     fixed_point(madd_fp2, True)
     print("G2 (Fp2) FUSED madd bound propagation:")
