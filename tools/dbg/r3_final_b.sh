@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, final validation B: rocprofv3 kernel stats + traces (timelines), PMC traffic at 2^20 and 2^24
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-O=$R/gpurun_out/r3fb; mkdir -p $O
+O=$R/gpurun_out/r3hb; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-host-inputs --no-micro > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 python3 $R/tools/summarize_rocprof.py $O/stats "bench.py --steps 50 --no-cpu-baseline --no-host-inputs --no-micro under rocprofv3 (Groth16 2^20 x 55, 2^24 x 6 + its two-slice check, PLONK 2^22 x 4)" > $O/bench_kernel_stats.md 2>&1
