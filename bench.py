@@ -136,7 +136,7 @@ def oracle_proof(inst, log_n):
     return cpu_proof, time.perf_counter() - t0, cores
 
 
-def plonk_block(L, lib, log_n, reps=3):
+def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", "3"))):  # the variable: A/B runs of tools/ab_bench.py that need a quieter figure
     """BASELINE.json configs[3]: "PLONK prove path (KZG-commit MSMs + coset NTTs) at 2^22 gates, 1xMI355X" -- the reference's only live
     prove path (plonk.Prove, backend/plonk/plonk.go:67).  Device-generated KZG SRS (real powers of alpha: kzg.NewSRS), a synthetic
     satisfiable circuit of 2^log_n rows (random wiring, random selectors, qK fixed per gate), plonk.Setup and plonk.Prove on the
@@ -296,6 +296,7 @@ def inner_boundary_block(L, lib, zk, par, inst, proof):
         return ts
 
     def msm5_seq():
+        dom_wake.fft(wake, zk.DIF)  # as in ntt7: the calls are timed back to back, not after a pause
         out, ts = [], []
         for bs, sc in zip(bases, scal):
             t = time.perf_counter()
@@ -306,6 +307,7 @@ def inner_boundary_block(L, lib, zk, par, inst, proof):
     def msm5_conc():
         out = [None] * 5
         th = [threading.Thread(target=lambda k=k: out.__setitem__(k, bases[k].multi_exp(scal[k], config=MONT))) for k in range(5)]
+        dom_wake.fft(wake, zk.DIF)
         t = time.perf_counter()
         for x in th:
             x.start()

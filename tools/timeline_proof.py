@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Kernel timeline of ONE proof out of a rocprofv3 `--kernel-trace --output-format csv` run of bench.py: start offset, duration, hardware queue, kernel.
     timeline_proof.py <dir or kernel_trace.csv[.gz]> groth16|groth16_2p24|plonk [min_us=100]  > profiles/<name>.txt
-A proof is located by its anchor kernel (k_h_final for Groth16 -- grid 2^20 or 2^24 --, k_quotient for PLONK): the period is the distance between two
+A proof is located by its anchor kernel (for Groth16 the last pass of computeH's closing transform, the `true` variant of k_ntt_pass29 -- grid 2^18 or 2^22
+lanes; k_h_final in traces older than that fusion --, k_quotient for PLONK): the period is the distance between two
 consecutive anchors, the proof starts after the longest idle gap in the period before the anchor.  The summary lines give the span, the time at least one
 kernel was running, and per kernel the sum of durations inside the proof."""
 import collections, csv, glob, gzip, io, os, re, sys
@@ -10,7 +11,13 @@ import collections, csv, glob, gzip, io, os, re, sys
 def short(n):
     n = re.sub(r"void |zkmi::|rocprim::ROCPRIM_\d+_NS::|detail::", "", n)
     g = "<G2>" if "Fp2" in n else ("<G1>" if "FpParams" in n else "")
+    if closing(n):
+        g = "(closing)"
     return re.match(r"[A-Za-z0-9_]+", n).group(0) + g
+
+
+def closing(name):
+    return "k_ntt_pass29<" in name and "true>" in name
 
 
 def main():
@@ -26,6 +33,9 @@ def main():
     else:
         grid = "16777216" if what == "groth16_2p24" else "1048576"
         anchors = [r[0] for r in rows if "k_h_final" in r[3] and r[4] == grid]
+        if not anchors:
+            grid = "4194304" if what == "groth16_2p24" else "262144"
+            anchors = [r[0] for r in rows if closing(r[3]) and r[4] == grid]
     if len(anchors) < 3:
         raise SystemExit("fewer than three %s proofs in the trace" % what)
     a0, a1 = anchors[-2], anchors[-1]
