@@ -270,6 +270,100 @@ __global__ void k_task_plan(const uint32_t* start, uint32_t nb, const uint32_t* 
     }
 }
 
+// Hand-off between the workgroups of ONE launch without anybody waiting (the serial step that used to be a launch of its own -- 10-17 us start to start on a
+// dependent chain, whatever it computes -- is run by the workgroup that finishes LAST): every workgroup stores its results, releases them at agent scope and adds
+// 1 to a counter; the one whose add brought it to `expected` acquires and goes on.  Nobody spins, so the launch cannot deadlock however few of its workgroups
+// are resident at a time.  Form per MI355X_MICROARCH.md "inter-workgroup visibility": stores -> barrier (the workgroup's stores are issued) -> release fence ->
+// agent-scope atomic by one lane; the last arriver: acquire fence -> plain loads.  All lanes of the workgroup get the same answer.
+__device__ __forceinline__ bool block_arrive_is_last(uint32_t* counter, uint32_t expected) {
+    __shared__ uint32_t is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        is_last = (atomicAdd(counter, 1u) + 1 == expected) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return false;
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return true;
+}
+
+// k_bucket_stats + k_pick_len in one launch: the last workgroup to arrive picks the task length (ctl[5] counts arrivals)
+__global__ __launch_bounds__(256) void k_bucket_stats_pick(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t factor,
+                                                           uint32_t cap, uint32_t* __restrict__ ctl) {
+    prio_hi();
+    __shared__ uint32_t wmax[4];
+    uint32_t len = 0;
+    uint32_t big = 0;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+        const uint32_t l = start[b + 1] - start[b];
+        len = max(len, l);
+        big += l > GIANT_POINTS ? 1u : 0u;
+    }
+    if (big) atomicAdd(&ctl[3], big);
+    for (int d = 32; d > 0; d >>= 1) len = max(len, (uint32_t)__shfl_down((int)len, d, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        len = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (len) atomicMax(&ctl[1], len);
+    }
+    if (!block_arrive_is_last(&ctl[5], gridDim.x)) return;
+    if (threadIdx.x == 0) {  // = k_pick_len
+        const uint32_t nnz = start[nb], biggest = atomicAdd(&ctl[1], 0u), nbig = atomicAdd(&ctl[3], 0u);
+        const uint32_t q = (nnz + lanes - 1) / lanes;
+        uint32_t lw = factor * q;
+        if (2 * lw < Lmax) lw = (factor / 2 ? factor / 2 : 1) * q;
+        if (nbig > GIANT_MAX) cap = cap > 2048 ? 2048 : cap;
+        const uint32_t lg = (biggest + cap - 1) / cap;
+        const uint32_t L = max(max(lw, lg), Lmin);
+        ctl[2] = min(L, Lmax);
+    }
+}
+
+// k_task_plan + the first two launches of the exclusive scan of its output (radix.hpp: k_xs_sums, k_xs_scan_sums) in one: a workgroup plans one scan tile
+// of buckets, leaves the tile's task count, and the last workgroup to arrive scans the tile counts (ctl[6] counts arrivals).  k_xs_apply follows as before.
+__global__ __launch_bounds__(XS_THREADS) void k_task_plan_scan(const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ ctl, uint32_t* __restrict__ ntasks,
+                                                               uint32_t* __restrict__ multi_list, uint32_t* __restrict__ sums) {
+    prio_hi();
+    const uint32_t L = ctl[2];
+    const uint32_t base = blockIdx.x * XS_TILE + threadIdx.x * XS_IPT;
+    uint32_t v = 0;
+#pragma unroll
+    for (unsigned k = 0; k < XS_IPT; k++) {
+        const uint32_t b = base + k;
+        if (b > nb) continue;
+        uint32_t t = 0;
+        if (b < nb) {
+            const uint32_t cnt = start[b + 1] - start[b];
+            t = (cnt + L - 1) / L;
+            if (t > 1) multi_list[atomicAdd(&ctl[0], 1u)] = b;
+            if (t > GIANT_T) {
+                const uint32_t gi = atomicAdd(&ctl[4], 1u);
+                if (gi < GIANT_MAX) ctl[8 + gi] = b;
+            }
+        }
+        ntasks[b] = t;
+        v += t;
+    }
+    uint32_t total;
+    (void)xs_block_exclusive(v, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+    if (!block_arrive_is_last(&ctl[6], gridDim.x)) return;
+    const uint32_t ntiles = gridDim.x;  // = k_xs_scan_sums
+    uint32_t carry = 0;
+    for (uint32_t lo = 0; lo < ntiles; lo += XS_THREADS) {
+        const uint32_t i = lo + threadIdx.x;
+        const uint32_t x = i < ntiles ? sums[i] : 0;
+        uint32_t tot;
+        const uint32_t ex = xs_block_exclusive(x, &tot);
+        if (i < ntiles) sums[i] = carry + ex;
+        carry += tot;
+    }
+}
+
 // One record per task (thread t < total tasks): where its points start in the sorted array, and a sort key that orders
 // tasks by DECREASING length so that the 64 lanes of a wave run tasks of (nearly) equal length -- bucket loads are
 // Poisson-distributed, and a wave otherwise waits for its longest lane.
@@ -279,10 +373,9 @@ __global__ void k_task_plan(const uint32_t* start, uint32_t nb, const uint32_t* 
 // balances lanes, results never depend on it (every task writes its own partial sum).
 constexpr uint32_t TS_BINS = 2048;
 
-__global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t Lmax,
-                                                   const uint32_t* __restrict__ ctl, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
-                                                   uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
-    prio_hi();
+__device__ __forceinline__ void task_fill_body(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t Lmax,
+                                               const uint32_t* __restrict__ ctl, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
+                                               uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
     const uint32_t L = ctl[2];  // the length the plan cut the buckets with; keys stay relative to Lmax (the accumulate kernel's argument)
     __shared__ uint32_t h[TS_BINS];
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
@@ -314,9 +407,15 @@ __global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ 
         if (h[b]) atomicAdd(&hist[b], h[b]);
 }
 
-// exclusive scan of the <= TS_BINS bin counts, in place (one workgroup)
-__global__ __launch_bounds__(256) void k_task_bins(uint32_t* __restrict__ hist, uint32_t nbins) {
+__global__ __launch_bounds__(256) void k_task_fill(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t Lmax,
+                                                   const uint32_t* __restrict__ ctl, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
+                                                   uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
     prio_hi();
+    task_fill_body(start, task_off, nb, Lmax, ctl, max_tasks, bshift, nbins, task_begin, len_key, hist);
+}
+
+// exclusive scan of the <= TS_BINS bin counts, in place (one workgroup)
+__device__ __forceinline__ void task_bins_body(uint32_t* __restrict__ hist, uint32_t nbins) {
     __shared__ uint32_t part[256];
     constexpr uint32_t PER = TS_BINS / 256;
     uint32_t v[PER], sum = 0;
@@ -341,6 +440,19 @@ __global__ __launch_bounds__(256) void k_task_bins(uint32_t* __restrict__ hist, 
         if (b < nbins) hist[b] = run;
         run += v[k];
     }
+}
+__global__ __launch_bounds__(256) void k_task_bins(uint32_t* __restrict__ hist, uint32_t nbins) {
+    prio_hi();
+    task_bins_body(hist, nbins);
+}
+// k_task_fill + k_task_bins in one launch: the last workgroup to arrive scans the bin counts (ctl[7] counts arrivals)
+__global__ __launch_bounds__(256) void k_task_fill_bins(const uint32_t* __restrict__ start, const uint32_t* __restrict__ task_off, uint32_t nb, uint32_t Lmax,
+                                                        uint32_t* __restrict__ ctl, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
+                                                        uint32_t* __restrict__ task_begin, uint32_t* __restrict__ len_key, uint32_t* __restrict__ hist) {
+    prio_hi();
+    task_fill_body(start, task_off, nb, Lmax, ctl, max_tasks, bshift, nbins, task_begin, len_key, hist);
+    if (!block_arrive_is_last(&ctl[7], gridDim.x)) return;
+    task_bins_body(hist, nbins);
 }
 
 __global__ __launch_bounds__(256) void k_task_scatter(const uint32_t* __restrict__ len_key, uint32_t max_tasks, uint32_t bshift, uint32_t nbins,
@@ -1121,6 +1233,8 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     uint32_t* num_multi = bins;
     uint32_t* hist = bins + 64;
 
+    // the counters of step 4 are cleared here, ahead of the chain of dependent launches they would otherwise lengthen
+    ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
     // ---- 1. digits
     ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
               (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step);
@@ -1141,12 +1255,26 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     const uint32_t* keys = kb.current();
     // ---- 3. bucket bounds
     ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, keys, (uint32_t)total, nb, start);
-    // ---- 4. plan
-    ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
-    if (P.Lmin < L) ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats, dim3(nb / 4096 ? (nb / 4096 > 512 ? 512 : nb / 4096) : 1), dim3(256), 0, (const uint32_t*)start, nb, bins);
+    // ---- 4. plan.  The steps that are one workgroup's work (task length, scan of the tile counts, scan of the bin counts) are run by the LAST workgroup of
+    // the launch before them (block_arrive_is_last): eleven dependent launches of 4-30 us each were 0.26 ms start to end, on the critical path of every MSM
+    // (DESIGN.md 3.4); seven remain.  ZKMI_PREP_MERGE=0 (A/B switch): one launch per step.
+    static const bool merged = ZK_EXP("ZKMI_PREP_MERGE", 1) != 0;
     static const uint32_t l_factor = (uint32_t)ZK_EXP("ZKMI_L_FACTOR", 4);     // experiment switches
     static const uint32_t l_cap = (uint32_t)ZK_EXP("ZKMI_L_GIANT_CAP", 16384);
-    ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, bins);
+    const unsigned stats_grid = nb / 4096 ? (nb / 4096 > 512 ? 512 : nb / 4096) : 1;
+    const unsigned scan_tiles = (unsigned)(((size_t)nb + 1 + XS_TILE - 1) / XS_TILE);
+    if (merged && P.Lmin < L) {
+        ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats_pick, dim3(stats_grid), dim3(256), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor,
+                  l_cap, bins);
+    } else {
+        if (P.Lmin < L) ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats, dim3(stats_grid), dim3(256), 0, (const uint32_t*)start, nb, bins);
+        ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, bins);
+    }
+    if (merged && own_scan) {
+        uint32_t* sums = (uint32_t*)scan_tmp;
+        ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan_scan, dim3(scan_tiles), dim3(XS_THREADS), 0, (const uint32_t*)start, nb, bins, ntasks, multi_list, sums);
+        ZK_LAUNCH(s, st, "msm_task_scan", k_xs_apply, dim3(scan_tiles), dim3(XS_THREADS), 0, (const uint32_t*)ntasks, nb + 1, (const uint32_t*)sums, task_off);
+    } else {
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
 #ifdef ZKMI_EXPERIMENTS
     if (!own_scan) {
@@ -1157,14 +1285,23 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     }
 #endif
     if (own_scan) ZK_TRY(xs_exclusive_scan(s, st, scan_tmp, ntasks, task_off, (size_t)nb + 1));
+    }
     // ---- 4b. per-task records, ordered by decreasing length (counting sort on L - len)
     uint32_t bshift = 0;
     while ((L >> bshift) >= TS_BINS) bshift++;
     const uint32_t nbins = (L >> bshift) + 1;
     const unsigned tgrid = (unsigned)((max_tasks + 255) / 256);
-    ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill, dim3(tgrid), dim3(256), 0, (const uint32_t*)start, (const uint32_t*)task_off, nb, L, (const uint32_t*)bins,
-              (uint32_t)max_tasks, bshift, nbins, task_begin, lkey0, hist);
-    ZK_LAUNCH(s, st, "msm_task_bins", k_task_bins, dim3(1), dim3(256), 0, hist, nbins);
+    // (the same hand-off for fill + bins was measured and is off: one release fence per workgroup is one write-back of the L2 -- 128 / 257 workgroups above do
+    // not notice, the 3,713 of k_task_fill at 2^20 turn a 30 us kernel into 99 us, and the 2^26 MSM loses 3.6 ms.  ZKMI_PREP_MERGE=2 selects it for A/B.)
+    static const bool merged_fill = ZK_EXP("ZKMI_PREP_MERGE", 1) == 2;
+    if (merged_fill) {
+        ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill_bins, dim3(tgrid), dim3(256), 0, (const uint32_t*)start, (const uint32_t*)task_off, nb, L, bins, (uint32_t)max_tasks, bshift,
+                  nbins, task_begin, lkey0, hist);
+    } else {
+        ZK_LAUNCH(s, st, "msm_task_fill", k_task_fill, dim3(tgrid), dim3(256), 0, (const uint32_t*)start, (const uint32_t*)task_off, nb, L, (const uint32_t*)bins,
+                  (uint32_t)max_tasks, bshift, nbins, task_begin, lkey0, hist);
+        ZK_LAUNCH(s, st, "msm_task_bins", k_task_bins, dim3(1), dim3(256), 0, hist, nbins);
+    }
     ZK_LAUNCH(s, st, "msm_task_scatter", k_task_scatter, dim3(tgrid), dim3(256), 0, (const uint32_t*)lkey0, (uint32_t)max_tasks, bshift, nbins, hist,
               lkey1, tid1);
     out->vals = vb.current();
