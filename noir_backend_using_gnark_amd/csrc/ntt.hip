@@ -214,18 +214,15 @@ __device__ __forceinline__ void lds_store9(uint4* lo, uint4* hi, uint32_t* top, 
     top[t] = v.l[8];
 }
 
-// What a pass does at its two ends, resolved by the kernel once (no copies of PassArgs): twiddles, the entry table, the exit table or constant, whether the
-// stored image is canonical.  SUB (compile-time: its extra live values would cost every other pass a wave of occupancy) adds computeH's closing step.
-struct PassEnds {
-    const Fr* tw;
-    const Fr* pre;
-    const Fr* post;
-    bool post_const;  // multiply by A.post_const on exit (when post is null)
-    bool canonical;
-};
-
-template <int G, bool DIF, unsigned THREADS, bool SUB>
-__device__ __forceinline__ void ntt_group29(const PassArgs& A, const PassEnds& P, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, unsigned s0,
+// What a pass does at its two ends is a compile-time MODE, resolved against the kernel arguments where it is used (a struct of pointers built once per kernel
+// keeps them all in scalar registers for the whole kernel, and the hot loop pays for the spills: measured 4 % on a 2^24-point transform):
+//   0  a plain pass: A.tw, entry table A.pre, exit table A.post or the constant A.post_const, canonical image if A.canonical
+//   1  inverse half of k_ntt_pass29_if: A.tw, exit table A.post, limbs stay unpacked
+//   2  forward half of k_ntt_pass29_if: A.tw2, no tables, canonical image if A.canonical
+//   3  k_ntt_pass29_if's third vector, a plain FFTInverse ending: A.tw, * A.post_const, canonical image
+// SUB (compile-time too: its extra live values would cost every other pass a wave of occupancy) adds computeH's closing step.
+template <int G, bool DIF, unsigned THREADS, bool SUB, int MODE, bool UNIT>
+__device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, unsigned s0,
                                             bool load_packed, bool apply_pre, bool apply_post, bool store_packed) {
     constexpr unsigned NE = 1u << G;
     const unsigned L = 1u << A.logL;
@@ -238,7 +235,7 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, const PassEnds& P
         for (unsigned e = 0; e < NE; e++) {
             const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
             x[e] = load_packed ? u29_unpack(lds_load(lo, hi, t)) : lds_load9(lo, hi, top, t);
-            if (apply_pre && P.pre) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(P.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
+            if (MODE == 0 && apply_pre && A.pre) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.pre + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
         }
 #pragma unroll
         for (int sl = 0; sl < G; sl++) {
@@ -251,10 +248,13 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, const PassEnds& P
                 const size_t g0 = base + ((size_t)(mid0 | (e0 << ql)) << A.bit_lo) + l;
                 const size_t j = g0 & (((size_t)1 << b) - 1);
                 // the stage on index bit 0 (the last of a DIF transform, the first of a DIT one) has no twiddles: its product by the unit is replaced by a
-                // partial reduction (DIF) or dropped (DIT) -- one product in 20 at 2^20; same values mod r, bounds in tools/u29_ntt_model.py (`unit`)
-                const bool unit = bitl == 0 && b == 0 && A.unit_skip;  // bitl is a compile-time constant after unrolling, b is uniform over the launch
+                // partial reduction (DIF) or dropped (DIT) -- one product in 20 at 2^20; same values mod r, bounds in tools/u29_ntt_model.py (`unit`).
+                // UNIT is a property of the GROUP (it holds index bit 0), chosen by the caller: a run-time test here would sit in every group's bitl == 0
+                // stage and cut the butterflies' instruction streams apart -- measured: 3 % on a 2^26-point transform, more than the skipped product gives
+                constexpr bool unit_ct = UNIT;
+                const bool unit = unit_ct && bitl == 0;
                 U29 w;
-                if (!unit) w = u29_unpack(gload_fr(P.tw + ((j << (A.logn - 1 - b)) & A.tw_and)));
+                if (!unit) w = u29_unpack(gload_fr((MODE == 2 ? A.tw2 : A.tw) + ((j << (A.logn - 1 - b)) & A.tw_and)));
                 if (DIF) {
                     U29 d;
                     if (sl == 0) d = u29r_sub<16>(x[e0], x[e1]);
@@ -279,30 +279,36 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, const PassEnds& P
         for (unsigned e = 0; e < NE; e++) {
             const unsigned t = ((mid0 | (e << ql)) << A.logL) + l;
             if (apply_post) {
-                if (P.post) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(P.post + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
-                else if (P.post_const) x[e] = u29r_mul(x[e], u29r_load5(A.post_const));
+                if ((MODE == 0 || MODE == 1) && A.post) x[e] = u29r_mul(x[e], u29r_load5(gload_fr(A.post + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l)));
+                else if (MODE == 3 || (MODE == 0 && A.has_post_const)) x[e] = u29r_mul(x[e], u29r_load5(A.post_const));
                 if (SUB) {  // x < 2 r after the product above; sub[i] canonical: the difference stays below 6 r, a legal multiplicand (tools/u29_ntt_model.py)
                     const U29 c = u29_unpack(gload_fr(A.sub + base + ((size_t)(mid0 | (e << ql)) << A.bit_lo) + l));
                     x[e] = u29r_mul(u29r_sub<4>(x[e], c), u29r_load5(A.post_const));
                 }
             }
-            if (store_packed) lds_store(lo, hi, t, u29r_pack(u29r_reduce(x[e]), P.canonical));
+            if (store_packed) lds_store(lo, hi, t, u29r_pack(u29r_reduce(x[e]), MODE == 3 || A.canonical != 0));
             else lds_store9(lo, hi, top, t, x[e]);
         }
     }
 }
 
 // all k stages of a pass, GMAX at a time.  packed_in / packed_out: the tile sits in LDS as 8 packed words before / after.
-template <int GMAX, unsigned THREADS, bool DIF, bool SUB = false>
-__device__ __forceinline__ void ntt_stages29(const PassArgs& A, const PassEnds& P, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, bool packed_in,
-                                             bool packed_out) {
+template <int GMAX, unsigned THREADS, bool DIF, bool SUB, int MODE>
+__device__ __forceinline__ void ntt_stages29(const PassArgs& A, uint4* lo, uint4* hi, uint32_t* top, size_t base, unsigned E, bool packed_in, bool packed_out) {
     for (unsigned s0 = 0; s0 < A.k;) {
         const unsigned G = (A.k - s0 >= (unsigned)GMAX) ? (unsigned)GMAX : (A.k - s0);
         const bool first = (s0 == 0), last = (s0 + G == A.k);
         const bool lp = first && packed_in, sp = last && packed_out;
-        if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), DIF, THREADS, SUB>(A, P, lo, hi, top, base, E, s0, lp, first, last, sp);
-        else if (G == 2) ntt_group29<2, DIF, THREADS, SUB>(A, P, lo, hi, top, base, E, s0, lp, first, last, sp);
-        else ntt_group29<1, DIF, THREADS, SUB>(A, P, lo, hi, top, base, E, s0, lp, first, last, sp);
+        const bool ug = A.unit_skip && A.bit_lo == 0 && (DIF ? last : first);  // the group that holds index bit 0 (uniform)
+        if (ug) {
+            if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), DIF, THREADS, SUB, MODE, true>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+            else if (G == 2) ntt_group29<2, DIF, THREADS, SUB, MODE, true>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+            else ntt_group29<1, DIF, THREADS, SUB, MODE, true>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+        } else {
+            if (GMAX >= 3 && G == 3) ntt_group29<(GMAX >= 3 ? 3 : 1), DIF, THREADS, SUB, MODE, false>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+            else if (G == 2) ntt_group29<2, DIF, THREADS, SUB, MODE, false>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+            else ntt_group29<1, DIF, THREADS, SUB, MODE, false>(A, lo, hi, top, base, E, s0, lp, first, last, sp);
+        }
         s0 += G;
         __syncthreads();
     }
@@ -322,7 +328,13 @@ __device__ __forceinline__ const Fr* pass_src(const PassArgs& A, const Fr* data)
 template <unsigned THREADS>
 __device__ __forceinline__ void tile_copy_in(const Fr* src, unsigned logL, unsigned bit_lo, uint4* lo, uint4* hi, size_t base, unsigned E) {
     const unsigned L = 1u << logL;
-    const uint4* g = reinterpret_cast<const uint4*>(src);
+    // the pointer went through integer masks (pick3): tell the compiler again that it is global memory, or it emits flat_load / flat_store
+#ifdef __HIP_DEVICE_COMPILE__
+    typedef __attribute__((address_space(1))) const uint4 g_uint4;
+    const g_uint4* g = (const g_uint4*)(uintptr_t)src;
+#else
+    const uint4* g = reinterpret_cast<const uint4*>(src);  // host pass: never executed
+#endif
     for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
         unsigned e = h >> 1, half = h & 1;
         unsigned mid = e >> logL, l = e & (L - 1);
@@ -333,7 +345,12 @@ __device__ __forceinline__ void tile_copy_in(const Fr* src, unsigned logL, unsig
 template <unsigned THREADS>
 __device__ __forceinline__ void tile_copy_out(Fr* dst, unsigned logL, unsigned bit_lo, const uint4* lo, const uint4* hi, size_t base, unsigned E) {
     const unsigned L = 1u << logL;
+#ifdef __HIP_DEVICE_COMPILE__
+    typedef __attribute__((address_space(1))) uint4 g_uint4;
+    g_uint4* g = (g_uint4*)(uintptr_t)dst;
+#else
     uint4* g = reinterpret_cast<uint4*>(dst);
+#endif
     for (unsigned h = threadIdx.x; h < 2 * E; h += THREADS) {
         unsigned e = h >> 1, half = h & 1;
         unsigned mid = e >> logL, l = e & (L - 1);
@@ -342,8 +359,10 @@ __device__ __forceinline__ void tile_copy_out(Fr* dst, unsigned logL, unsigned b
     }
 }
 
-// 512 lanes: two workgroups per CU (4 waves per SIMD, 128 VGPRs); 256 lanes (radix-8 groups, A/B variant): two waves per SIMD
-#define ZK_NTT_BOUNDS(THREADS) __launch_bounds__(THREADS, (THREADS) == 512 ? 4 : 2)
+// 512 lanes: two workgroups per CU (4 waves per SIMD, <= 128 VGPRs); 256 lanes (radix-8 groups, A/B variant): two waves per SIMD.  The register counts are
+// what -Rpass-analysis=kernel-resource-usage shows (123 / 119 for the 512-lane kernels); asking for them with __launch_bounds__(512, 4) gives the same
+// counts and a schedule that is 1.5 % slower on a 2^26-point transform (measured), so the bound stays implicit -- check the remark when touching the kernels.
+#define ZK_NTT_BOUNDS(THREADS) __launch_bounds__(THREADS)
 
 template <int GMAX, unsigned THREADS, bool SUB = false>
 __global__ ZK_NTT_BOUNDS(THREADS) void k_ntt_pass29(PassArgs A) {
@@ -361,9 +380,8 @@ __global__ ZK_NTT_BOUNDS(THREADS) void k_ntt_pass29(PassArgs A) {
     Fr* const data = pass_data(A);
     tile_copy_in<THREADS>(pass_src(A, data), A.logL, A.bit_lo, lo, hi, base, E);
     __syncthreads();
-    const PassEnds P = {A.tw, A.pre, A.post, A.has_post_const != 0, A.canonical != 0};
-    if (A.dif) ntt_stages29<GMAX, THREADS, true, SUB>(A, P, lo, hi, top, base, E, true, true);
-    else ntt_stages29<GMAX, THREADS, false, SUB>(A, P, lo, hi, top, base, E, true, true);
+    if (A.dif) ntt_stages29<GMAX, THREADS, true, SUB, 0>(A, lo, hi, top, base, E, true, true);
+    else ntt_stages29<GMAX, THREADS, false, SUB, 0>(A, lo, hi, top, base, E, true, true);
     tile_copy_out<THREADS>(data, A.logL, A.bit_lo, lo, hi, base, E);
 }
 
@@ -384,13 +402,10 @@ __global__ ZK_NTT_BOUNDS(THREADS) void k_ntt_pass29_if(PassArgs A) {
     tile_copy_in<THREADS>(pass_src(A, data), 0, 0, lo, hi, base, E);
     __syncthreads();
     if (blockIdx.y == 2) {  // the third vector: a plain FFTInverse ending (* post_const, canonical image)
-        const PassEnds C = {A.tw, nullptr, nullptr, true, true};
-        ntt_stages29<GMAX, THREADS, true>(A, C, lo, hi, top, base, E, true, true);
+        ntt_stages29<GMAX, THREADS, true, false, 3>(A, lo, hi, top, base, E, true, true);
     } else {
-        const PassEnds I = {A.tw, nullptr, A.post, false, false};
-        ntt_stages29<GMAX, THREADS, true>(A, I, lo, hi, top, base, E, true, false);   // inverse half; its post table is applied, limbs stay unpacked
-        const PassEnds F = {A.tw2, nullptr, nullptr, false, A.canonical != 0};
-        ntt_stages29<GMAX, THREADS, false>(A, F, lo, hi, top, base, E, false, true);  // forward half
+        ntt_stages29<GMAX, THREADS, true, false, 1>(A, lo, hi, top, base, E, true, false);   // inverse half; its post table is applied, limbs stay unpacked
+        ntt_stages29<GMAX, THREADS, false, false, 2>(A, lo, hi, top, base, E, false, true);  // forward half
     }
     tile_copy_out<THREADS>(data, 0, 0, lo, hi, base, E);
 }
