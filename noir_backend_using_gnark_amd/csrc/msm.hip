@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accu
 #endif
 // four waves per SIMD (G1) / two (G2) are part of the kernel's design: say so, so that a change that wants a few registers more shows up as spills in
 // -Rpass-analysis=kernel-resource-usage instead of silently dropping a wave (a shorter formula for the second point of a task asked for 134: DESIGN.md 8)
-#define ZK_ACC_BOUNDS __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2))
+#define ZK_ACC_BOUNDS __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2))  // (measured equal to __launch_bounds__(256) in four alternating pairs: unlike the NTT passes, ntt.hip)
 template <class F>
 __global__ ZK_ACC_BOUNDS void k_accumulate(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
                                                     const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
