@@ -24,8 +24,8 @@ for log_n in (22, 24, 26):
     d.free()
 print(sys.argv[1], out)
 PY
-for rep in 1 2; do
-for v in old plain p_nounit ug; do
+for rep in 1 2 3; do
+for v in head mid; do
 cp noir_backend_using_gnark_amd/variants/libzkmi_exp_$v.so noir_backend_using_gnark_amd/libzkmi_exp.so
 python /tmp/ntt26.py $v 2>&1 | tail -1
 done
