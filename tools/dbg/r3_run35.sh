@@ -1,5 +1,8 @@
 #!/bin/bash
-# which part of the day's restructuring of the pass kernels costs the 2^26 transform 3-6 %: variants of ntt.hip linked into the experiments library, one box
+# which part of the day's restructuring of the pass kernels costs the 2^26 transform 3-6 %: variants of ntt.hip linked into the experiments library, one box.
+# The variants are built by hand beforehand (not kept in the tree): `git show <commit>:.../ntt.hip` or the current file with -D switches -> hipcc -c with the flags of
+# `make EXPERIMENTS=1` -> hipcc -shared with build_exp/*.o and that ntt.o -> noir_backend_using_gnark_amd/variants/libzkmi_exp_<name>.so; the loop below copies each over
+# libzkmi_exp.so in turn.  Results of the runs: DESIGN.md 8 (round 3, the unit-stage item), profiles/r03_j_ntt_kernel_variants_last_run.txt
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/r3z; mkdir -p $O
 cd $R
