@@ -23,6 +23,7 @@
 
 #include "ctx.hpp"
 #include "curve.hpp"
+#include "ff29.hpp"
 #include "host_ff.hpp"
 #include "msm.hpp"
 #include "keyio.hpp"
@@ -343,6 +344,49 @@ __global__ __launch_bounds__(256) void k_quotient(QuotArgs A) {
     Fr one = (z - Fr::one()) * ld(A.l1 + i);
     Fr t = ((one * A.alpha + (b - a)) * A.alpha + gate) * A.xn_inv[j & (rho - 1)];
     A.out[i] = t;
+}
+
+// The same numerator with its 21 products in the 9 x 29-bit representation of ff29.hpp (Fr29: 206 instructions per product instead of ~305; the kernel is bound by
+// them, not by its 8.6 GB).  Values loaded from memory are canonical images V = v 2^256; a product needs ONE operand in the multiplier form V << 5 (= v 2^261):
+// u29r_mul(X, Y << 5) = X Y / 2^261 stays in the 2^256 domain.  So the second and third factor of each permutation product are BUILT in the 2^261 domain --
+// (w << 5) + (gamma << 5) + u29r_mul(x << 5, beta << 5) -- and no in-register shift is ever needed.  Sums are plain limb additions; bounds (units of r; checked with
+// tools/u29_ntt_model.py's bound classes): gate < 5.8, first factors < 3.2, 2^261-domain factors < 71.1 (re-normalised once: two operands with
+// 31-bit limbs would overflow a 64-bit column), products < 2.4, the last sum < 8.1, t < 2.6 -> one partial reduction, canonical image out.
+__global__ __launch_bounds__(256, 4) void k_quotient29(QuotArgs A) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N4 = (size_t)1 << A.logN4;
+    if (i >= N4) return;
+    const unsigned j = brev((unsigned)i, A.logN4);
+    const unsigned rho = 1u << A.log_rho;
+    const unsigned js = (j + rho) & (unsigned)(N4 - 1);  // z(omega * x): omega = W^rho
+    const size_t is = brev(js, A.logN4);
+    const Fr fl = ld(A.el + i), fr = ld(A.er + i), fo = ld(A.eo + i), fz = ld(A.ez + i), fx = ld(A.id + i);
+    const U29 l = u29_unpack(fl), r = u29_unpack(fr), o = u29_unpack(fo), z = u29_unpack(fz);
+    // gate = ql l + qr r + qm (l r) + qo o + qk
+    U29 gate = u29r_mul(l, u29r_load5(ld(A.ql + i)));
+    gate = u29_add(gate, u29r_mul(r, u29r_load5(ld(A.qr + i))));
+    gate = u29_add(gate, u29r_mul(u29r_mul(l, u29r_load5(fr)), u29r_load5(ld(A.qm + i))));
+    gate = u29_add(gate, u29r_mul(o, u29r_load5(ld(A.qo + i))));
+    gate = u29_add(gate, u29_unpack(ld(A.eqk + i)));
+    const U29 g = u29_unpack(A.gamma), g5 = u29r_load5(A.gamma), x5 = u29r_load5(fx);
+    // a = (l + g + beta x) (r + g + beta u x) (o + g + beta u^2 x) z
+    U29 a = u29_add(u29_add(l, g), u29r_mul(u29_unpack(fx), u29r_load5(A.beta)));
+    a = u29r_mul(a, u29_wnorm(u29_add(u29_add(u29r_load5(fr), g5), u29r_mul(x5, u29r_load5(A.beta_u)))));
+    a = u29r_mul(a, u29_wnorm(u29_add(u29_add(u29r_load5(fo), g5), u29r_mul(x5, u29r_load5(A.beta_uu)))));
+    a = u29r_mul(a, u29r_load5(fz));
+    // b = (l + g + beta s1) (r + g + beta s2) (o + g + beta s3) z(omega x)
+    const U29 b5 = u29r_load5(A.beta);
+    U29 b = u29_add(u29_add(l, g), u29r_mul(u29_unpack(ld(A.s1 + i)), b5));
+    b = u29r_mul(b, u29_wnorm(u29_add(u29_add(u29r_load5(fr), g5), u29r_mul(u29r_load5(ld(A.s2 + i)), b5))));
+    b = u29r_mul(b, u29_wnorm(u29_add(u29_add(u29r_load5(fo), g5), u29r_mul(u29r_load5(ld(A.s3 + i)), b5))));
+    b = u29r_mul(b, u29r_load5(ld(A.ez + is)));
+    // t = ((one alpha + (b - a)) alpha + gate) / (x^n - 1),  one = (z - 1) L1
+    const U29 a5 = u29r_load5(A.alpha);
+    const U29 one = u29r_mul(u29r_sub<4>(z, u29_unpack(Fr::one())), u29r_load5(ld(A.l1 + i)));
+    U29 t = u29_add(u29r_mul(one, a5), u29r_sub<4>(b, a));
+    t = u29_add(u29r_mul(t, a5), gate);
+    t = u29r_mul(t, u29r_load5(A.xn_inv[j & (rho - 1)]));
+    A.out[i] = u29r_pack(u29r_reduce(t), true);
 }
 
 // linearised polynomial (prove.go computeLinearizedPolynomial), len = n + 3 coefficients
@@ -1274,7 +1318,9 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             cur = cur * Wn;
         }
         for (unsigned j = (1u << P->log_rho); j < 8; j++) A.xn_inv[j] = Fr::zero();
-        ZK_LAUNCH(s, st, "plonk_quotient", k_quotient, dim3(grid_of(N4)), dim3(256), 0, A);
+        static const bool quot29 = ZK_EXP("ZKMI_PLONK_QUOT29", 1) != 0;  // A/B switch: 0 = the saturated 8 x 32-bit form
+        if (quot29) ZK_LAUNCH(s, st, "plonk_quotient", k_quotient29, dim3(grid_of(N4)), dim3(256), 0, A);
+        else ZK_LAUNCH(s, st, "plonk_quotient", k_quotient, dim3(grid_of(N4)), dim3(256), 0, A);
     }
     Fr* h = P->w_big[4];
     ZK_TRY(ntt_dev(s, st, h, logN4, 1, ZK_DIT, 1));  // LagrangeCoset (bit-reversed) -> canonical (regular)
