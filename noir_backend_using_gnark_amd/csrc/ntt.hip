@@ -251,8 +251,10 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
                 // partial reduction (DIF) or dropped (DIT) -- one product in 20 at 2^20; same values mod r, bounds in tools/u29_ntt_model.py (`unit`).
                 // UNIT is a property of the GROUP (it holds index bit 0), chosen by the caller: a run-time test here would sit in every group's bitl == 0
                 // stage and cut the butterflies' instruction streams apart -- measured: 3 % on a 2^26-point transform, more than the skipped product gives
+                // In that group the stage on bit 1 has unit twiddles too, for the butterflies whose low element has bit 0 clear (e0 even): half of them.
+                // (Stage 2's quarter would meet sums of four elements, whose limbs no bias covers.)
                 constexpr bool unit_ct = UNIT;
-                const bool unit = unit_ct && bitl == 0;
+                const bool unit = unit_ct && (bitl == 0 || (bitl == 1 && (e0 & 1u) == 0));
                 U29 w;
                 if (!unit) w = u29_unpack(gload_fr((MODE == 2 ? A.tw2 : A.tw) + ((j << (A.logn - 1 - b)) & A.tw_and)));
                 if (DIF) {
@@ -264,7 +266,8 @@ __device__ __forceinline__ void ntt_group29(const PassArgs& A, uint4* lo, uint4*
                     x[e1] = unit ? u29r_reduce(u29_wnorm(d)) : u29r_mul(d, w);
                 } else {
                     const U29 t = unit ? x[e1] : u29r_mul(x[e1], w);
-                    x[e1] = u29_wnorm(u29r_sub<4>(x[e0], t));
+                    // a unit twiddle on bit 1 meets an element that is already the sum of two (< 4.4 r, limbs < 2^30): 16 r instead of 4 r
+                    x[e1] = u29_wnorm((unit && bitl == 1) ? u29r_sub<16>(x[e0], t) : u29r_sub<4>(x[e0], t));
                     x[e0] = u29_add(x[e0], t);
                 }
             }

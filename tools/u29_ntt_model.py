@@ -233,10 +233,11 @@ def dit_group(O, x, tw, G):
                 continue
             e1 = e0 | (1 << bit)
             w = tw[s][e0]
-            t = O.mul(x[e1], w) if w is not None else x[e1]  # unit stage (index bit 0): the element itself
+            t = O.mul(x[e1], w) if w is not None else x[e1]  # unit twiddle: the element itself
             a = x[e0]
             x[e0] = O.add(a, t)
-            x[e1] = O.wnorm(O.sub(a, t, DIT_K))
+            # a unit twiddle past the group's first stage meets an element that is already a SUM of two (< 4.4 r): its bias is 16 r
+            x[e1] = O.wnorm(O.sub(a, t, DIT_K if (w is not None or s == 0) else 16))
     for e in range(NE):
         x[e] = O.wnorm(x[e])
     return x
@@ -255,10 +256,13 @@ def bound_pass(dif, k, entry, unit=False):
         NE = 1 << G
         worst = None
         tw = [[TW] * NE for _ in range(G)]
-        if unit and dif and s0 + G == k:
-            tw[G - 1] = [None] * NE
-        if unit and not dif and s0 == 0:
-            tw[0] = [None] * NE
+        # in the group that holds index bit 0 the twiddle of stage `bit` is 1 for the butterflies whose low element has its bits below `bit` clear:
+        # all of stage 0, half of stage 1 (unit = 1: stage 0 only; unit = 2: both; stage 2's quarter would meet sums of four, limbs above every bias)
+        if unit and (s0 + G == k if dif else s0 == 0):
+            for st in range(G):
+                bit = (G - 1 - st) if dif else st
+                if bit == 0 or (unit == 2 and bit == 1):
+                    tw[st] = [None if (e0 & ((1 << bit) - 1)) == 0 else TW for e0 in range(NE)]
         x = [B(cur.vmax, cur.lmax) for _ in range(NE)]
         x = (dif_group if dif else dit_group)(Bound, x, tw, G)
         for v in x:
@@ -284,8 +288,9 @@ def check_bounds():
         for g in (2, 3):  # the same with the unit stage skipped, register groups of 2 (512 lanes) and 3 (256 lanes) stages
             global GMAX_MODEL
             GMAX_MODEL = g
-            assert b_reduce(bound_pass(True, k, entry, True)).vmax < int(2.2 * P)
-            assert b_reduce(bound_pass(False, k, entry, True)).vmax < int(2.2 * P)
+            for u in (1, 2):
+                assert b_reduce(bound_pass(True, k, entry, u)).vmax < int(2.2 * P)
+                assert b_reduce(bound_pass(False, k, entry, u)).vmax < int(2.2 * P)
         GMAX_MODEL = 3
     # pre / post scalings: multiplication by a table value loaded as V << 5 (< 32 r, normalised)
     sc = norm_b(32 * P)
@@ -357,7 +362,8 @@ def transform_exact(vals, log_n, dif, inverse, passes, unit=False):
                     for e0 in range(1 << G):
                         g0 = idx[e0]
                         j = g0 & ((1 << b) - 1)
-                        row.append((None if unit else twp(0)) if b == 0 else twp(j << (log_n - 1 - b)))
+                        e = j << (log_n - 1 - b) if b else 0
+                        row.append(None if (unit and b == 0) or (unit == 2 and e == 0 and b == 1 and gbit == 0) else twp(e))
                     tw.append(row)
                 x = (dif_group if dif else dit_group)(Exact, x, tw, G)
                 for i, v in zip(idx, x):
@@ -379,8 +385,9 @@ def exact_transform_check():
         inv = transform_exact(x, log_n, True, True, passes)
         want = dom.fft_inverse(x, ref.DIF)
         assert [v * dom.card_inv % P for v in inv] == want
-        assert transform_exact(x, log_n, True, False, passes, True) == dom.fft(x, ref.DIF)
-        assert transform_exact(x, log_n, False, False, passes, True) == dom.fft(x, ref.DIT)
+        for u in (1, 2):
+            assert transform_exact(x, log_n, True, False, passes, u) == dom.fft(x, ref.DIF)
+            assert transform_exact(x, log_n, False, False, passes, u) == dom.fft(x, ref.DIT)
         print("transforms 2^%d with passes %s: DIF, DIT, inverse DIF exact" % (log_n, passes))
 
 
