@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, final validation F: the driver's multi-GPU commands as dry runs (ranks share the one GPU over gloo; timings meaningless, proof bytes and cross-checks are the point)
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-O=$R/gpurun_out/r3jf; mkdir -p $O
+O=$R/gpurun_out/r3lf; mkdir -p $O
 cd $R
 export ZKMI_DIST_BACKEND=gloo MASTER_ADDR=127.0.0.1
 for n in 2 4; do
