@@ -357,6 +357,18 @@ int zk_plonk_prove_with_pk(const char *acir_json, size_t acir_len, const char *v
 int zk_acir_to_sparse_r1cs(const char *acir_json, size_t acir_len, size_t n_values, int layout, size_t *n_public, size_t *n_vars,
                            size_t *n_constraints, zk_fr *ql, zk_fr *qr, zk_fr *qo, zk_fr *qm, zk_fr *qk, uint32_t *xa, uint32_t *xb,
                            uint32_t *xc, uint32_t *order);
+/* What the verifier needs of HandleValues (backend/common.go:45-60; PlonkVerifyWithVK, main.go:44-56): out[k] = 0-based position, in the witness-value
+ * vector, of public variable k.  *n_public is set even when cap is too small (ZK_ERR_ARG then). */
+int zk_acir_public_witnesses(const char *acir_json, size_t acir_len, size_t n_values, int layout, uint32_t *out, size_t cap, size_t *n_public);
+/* What the export path keeps resident between calls.  The reference re-reads everything per call (main.go:24-37 -> backend/plonk/plonk.go:53-73: the ACIR
+ * is unmarshalled and lowered, the key hex-decoded and ReadFrom'd); at 2^19 gates that is 0.24 GB of JSON and 0.33 GB of key text in front of a 10 ms
+ * prover.  zk_plonk_prove_with_pk / zk_plonk_preprocess / zk_acir_public_witnesses identify both texts by a 128-bit content key and keep the lowered
+ * circuit (wiring + variable order in HBM) and the decoded key (with its big-coset forms) resident, least recently used first out, within
+ * ZKMI_TABLE_CAP_GB (0 keeps nothing).  A key text is only ever matched together with the circuit text and the SRS it was first seen with. */
+int zk_export_cache_info(size_t *n_circuits, size_t *n_keys, size_t *bytes);
+int zk_export_cache_clear(void);
+/* HBM held by a resident PLONK key */
+int zk_bn254_plonk_pk_bytes(uint64_t handle, size_t *bytes);
 
 /* buildR1CS of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:9-72; payload RawR1CS, src/gnark_backend_wrapper/groth16/
  * acir_to_r1cs.rs:18-60) on a JSON RawR1CS: a resident R1CS plus the full wire vector [ONE, public, secret, product variables] in HBM
@@ -426,7 +438,9 @@ int zk_dev_d2h(void *h_dst, const void *d_src, size_t bytes);
 int zk_dev_sync(void);
 
 /* ---- per-kernel timing (hipEvent pairs on the stream the kernels run on; feeds bench.py's roofline object) ------- */
-int zk_profile_enable(int on);                 /* 1: record an event pair around every kernel launch */
+int zk_profile_enable(int on);
+/* a host-side section of a caller above the C ABI (libgnark_backend.so's SRS handling), accounted beside the library's own; no-op unless profiling is on */
+int zk_profile_host(const char *name, double ms);                 /* 1: record an event pair around every kernel launch */
 int zk_profile_reset(void);
 int zk_profile_count(void);                    /* number of distinct kernel names seen */
 int zk_profile_get(int idx, char *name_out, size_t name_cap, uint64_t *launches, double *total_ms);

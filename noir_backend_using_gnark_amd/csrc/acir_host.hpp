@@ -1,0 +1,826 @@
+// Host-only text front end of the path (no HIP in this file: it also compiles with plain g++ under -fsanitize=address,undefined for the mutation
+// run of tests/cpp/parser_fuzz.cpp).  What the reference's Go shim does to the strings Noir hands over before gnark sees them:
+//     acir.ACIR JSON                                  gnark_backend_ffi/acir/acir.go:17-75, opcode/arithmetic_opcode.go:18-83, term/mul_term.go:21-62,
+//                                                     term/simple_term.go:20-51
+//     BuildSparseR1CS / handleArithmeticOpcode        backend/plonk/sparse_r1cs.go:18-107 (one gate per arithmetic opcode: MulTerms[0] only;
+//                                                     SimpleTerms of length 1 -> qO, 2 -> qL qR, 3 -> qL qR qO; directives / black boxes emit nothing)
+//     HandleValues                                    backend/common.go:45-76
+//     RawR1CS JSON (the intended Groth16 FFI)         src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60, backend/groth16/r1cs.go:9-72
+// The circuits Noir produces are hundreds of MB of JSON (2^19 arithmetic opcodes = 240 MB), so the text is read ONCE by a pull tokenizer that is
+// specialised to the two schemas: no document tree, no std::string per key or coefficient (a 64-character hex literal goes straight to four 64-bit
+// limbs), numbers through a digit loop (strtod only for the spellings that need it).  The grammar accepted is exactly the one of the document-tree
+// reader this replaces (kept as tests/cpp/json_dom_ref.hpp, the differential checker of the mutation run): same whitespace, escapes, literals,
+// number spellings, nesting limit, first-key-wins for duplicate keys, nothing required after the root value.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/zkmi.h"
+#include "host_ff.hpp"
+
+namespace zkmi {
+
+// ------------------------------------------------------------------------------------------------ the tokenizer
+struct JTok {
+    const char* p;
+    const char* end;
+    const char* err = nullptr;
+    std::string buf;  // the decoded form of the rare string that contains an escape
+
+    static constexpr int MAX_DEPTH = 64;
+    bool fail(const char* m) { if (!err) err = m; return false; }
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    // every value starts here: the nesting limit, then the first character of the value
+    bool enter(int depth) {
+        if (depth > MAX_DEPTH) return fail("nesting too deep");
+        ws();
+        if (p >= end) return fail("unexpected end");
+        return true;
+    }
+    // p at the opening quote.  *s / *n: the characters between the quotes -- a view of the text, or of `buf` when the string had escapes
+    bool str(const char** s, size_t* n) {
+        if (p >= end || *p != '"') return fail("expected a string");
+        const char* q = p + 1;
+        while (q < end && *q != '"' && *q != '\\') q++;
+        if (q >= end) return fail("unterminated string");
+        if (*q == '"') { *s = p + 1; *n = (size_t)(q - p - 1); p = q + 1; return true; }
+        buf.assign(p + 1, (size_t)(q - p - 1));
+        p = q;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                p++;
+                if (p >= end) return fail("bad escape");
+                switch (*p) {
+                    case 'n': buf.push_back('\n'); break;
+                    case 't': buf.push_back('\t'); break;
+                    case 'r': buf.push_back('\r'); break;
+                    case 'b': buf.push_back('\b'); break;
+                    case 'f': buf.push_back('\f'); break;
+                    case 'u': {  // only the ASCII range can occur in these schemas
+                        if (end - p < 5) return fail("bad \\u escape");
+                        char h[5] = {p[1], p[2], p[3], p[4], 0};
+                        buf.push_back((char)(strtoul(h, nullptr, 16) & 0x7f));
+                        p += 4;
+                        break;
+                    }
+                    default: buf.push_back(*p);
+                }
+                p++;
+            } else {
+                buf.push_back(*p++);
+            }
+        }
+        if (p >= end) return fail("unterminated string");
+        p++;
+        *s = buf.data();
+        *n = buf.size();
+        return true;
+    }
+    bool skip_str() {
+        if (p >= end || *p != '"') return fail("expected a string");
+        p++;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                p++;
+                if (p >= end) return fail("bad escape");
+                if (*p == 'u') {
+                    if (end - p < 5) return fail("bad \\u escape");
+                    p += 4;
+                }
+            }
+            p++;
+        }
+        if (p >= end) return fail("unterminated string");
+        p++;
+        return true;
+    }
+    // a scalar that is not a string: true / false / null (reported as "not a number") or a number.  p at its first character.
+    bool scalar(bool* is_num, double* num) {
+        *is_num = false;
+        // the length test comes first: the text is a GoString payload, not NUL-terminated
+        if (end - p >= 4 && !memcmp(p, "true", 4)) { p += 4; return true; }
+        if (end - p >= 5 && !memcmp(p, "false", 5)) { p += 5; return true; }
+        if (end - p >= 4 && !memcmp(p, "null", 4)) { p += 4; return true; }
+        {   // the spelling every index of a real circuit has: up to 18 digits and nothing a longer number could continue with
+            const char* q = p;
+            uint64_t v = 0;
+            int nd = 0;
+            while (q < end && *q >= '0' && *q <= '9' && nd < 19) { v = v * 10 + (uint64_t)(*q - '0'); q++; nd++; }
+            if (nd > 0 && nd < 19 && (q == end || !(*q == '.' || *q == 'e' || *q == 'E' || *q == 'x' || *q == 'X' || *q == 'p' || *q == 'P'))) {
+                p = q;
+                *is_num = true;
+                *num = (double)v;
+                return true;
+            }
+        }
+        char tmp[41];
+        const size_t k = (size_t)(end - p) < 40 ? (size_t)(end - p) : 40;
+        memcpy(tmp, p, k);
+        tmp[k] = 0;
+        char* e = nullptr;
+        *num = strtod(tmp, &e);
+        if (e == tmp) return fail("unexpected character");
+        *is_num = true;
+        p += e - tmp;
+        return true;
+    }
+    // any value, validated and dropped
+    bool skip(int depth) {
+        if (!enter(depth)) return false;
+        if (*p == '{') return object(depth, [&](const char*, size_t) { return skip(depth + 1); });
+        if (*p == '[') return array(depth, [&](size_t) { return skip(depth + 1); });
+        if (*p == '"') return skip_str();
+        bool is_num;
+        double d;
+        return scalar(&is_num, &d);
+    }
+    // p at '{' (after enter(depth)).  member(key, key_len) consumes the member's value (a value at depth + 1).
+    template <class F>
+    bool object(int depth, F&& member) {
+        p++;
+        ws();
+        if (p < end && *p == '}') { p++; return true; }
+        for (;;) {
+            ws();
+            const char* k;
+            size_t kn;
+            if (!str(&k, &kn)) return false;
+            std::string kept;
+            if (k == buf.data()) { kept.assign(k, kn); k = kept.data(); }  // the member's value may reuse `buf`
+            ws();
+            if (p >= end || *p != ':') return fail("expected ':'");
+            p++;
+            if (!member(k, kn)) return false;
+            ws();
+            if (p < end && *p == ',') { p++; continue; }
+            if (p < end && *p == '}') { p++; return true; }
+            return fail("expected ',' or '}'");
+        }
+        (void)depth;
+    }
+    // p at '[' (after enter(depth)).  elem(i) consumes element i (a value at depth + 1).
+    template <class F>
+    bool array(int depth, F&& elem) {
+        p++;
+        ws();
+        if (p < end && *p == ']') { p++; return true; }
+        for (size_t i = 0;; i++) {
+            if (!elem(i)) return false;
+            ws();
+            if (p < end && *p == ',') { p++; continue; }
+            if (p < end && *p == ']') { p++; return true; }
+            return fail("expected ',' or ']'");
+        }
+        (void)depth;
+    }
+};
+
+static inline bool key_is(const char* k, size_t n, const char* lit) { return n == strlen(lit) && !memcmp(k, lit, n); }
+static inline int hex_nibble(int c) { return (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; }
+
+// fr.Element.SetString on a hex literal (FieldElement: up to 64 hex characters big-endian, canonical or not: reduced mod r) -> canonical limbs
+static inline bool felt_from_hex(const char* s, size_t n, uint64_t t[4]) {
+    if (n > 64 || n == 0) return false;
+    t[0] = t[1] = t[2] = t[3] = 0;
+    int bad = 0;
+    for (size_t i = 0; i < n; i++) {  // character i from the END is nibble i
+        const int d = hex_nibble((unsigned char)s[n - 1 - i]);
+        bad |= d;
+        t[i >> 4] |= (uint64_t)(d & 15) << (4 * (i & 15));
+    }
+    if (bad < 0) return false;
+    while (HFr::geq_mod(t)) HFr::sub_mod(t);
+    return true;
+}
+// a JSON number as a witness / variable index: an integer in [0, 2^32)
+static inline bool as_index(double num, uint32_t* out) {
+    if (!(num >= 0) || num > 4294967295.0 || num != (double)(uint64_t)num) return false;
+    *out = (uint32_t)num;
+    return true;
+}
+
+// canonical limbs -> Montgomery images, in place.  Circuits are mostly 0 / 1 / -1 coefficients: those skip the product.
+static inline void to_mont_bulk(HFr* v, size_t n) {
+    static const HFr one = HFr::one(), minus_one = HFr::zero() - HFr::one();
+    static const uint64_t RM1[4] = {HFrParams::MOD[0] - 1, HFrParams::MOD[1], HFrParams::MOD[2], HFrParams::MOD[3]};
+    auto run = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            uint64_t* l = v[i].l;
+            if (!(l[1] | l[2] | l[3]) && l[0] <= 1) { if (l[0]) v[i] = one; continue; }
+            if (l[0] == RM1[0] && l[1] == RM1[1] && l[2] == RM1[2] && l[3] == RM1[3]) { v[i] = minus_one; continue; }
+            v[i] = v[i].to_mont();
+        }
+    };
+    unsigned nt = n < ((size_t)1 << 15) ? 1 : std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt <= 1) { run(0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++) th.emplace_back(run, n * k / nt, n * (k + 1) / nt);
+    for (auto& t : th) t.join();
+}
+
+// ------------------------------------------------------------------------------------------------ ACIR -> gates
+struct Gates {
+    size_t n_public = 0, n_vars = 0;
+    bool with_coeffs = true;                 // false: only the wiring (what PlonkProveWithPK needs: the selectors come with the key)
+    std::vector<HFr> ql, qr, qo, qm, qk;     // Montgomery
+    std::vector<uint32_t> xa, xb, xc;
+    std::vector<uint32_t> order;             // variable k holds witness order[k] (1-based witness index - 1): the gather that builds the solution
+    size_t n_gates() const { return xa.size(); }
+};
+
+// HandleValues (common.go:45-76) without its |values| x |public inputs| loops.  Loop 1 there appends one PUBLIC variable per (witness w, public
+// input equal to w) in witness order; loop 2, with public inputs, one SECRET variable per (w, public input NOT equal to w) -- i.e. |P| - c(w)
+// copies of w, c(w) = how often w is listed -- and without public inputs one secret variable per witness; indexMap keeps the last index assigned.
+// All copies appended for one w are equal, so only the counts matter: c(w) by one pass over the public inputs, then two passes over the witnesses.
+// ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS: public witnesses first (witness order), then the others, one variable each.
+static inline int handle_values(const std::vector<uint32_t>& pub, size_t n_values, int layout, Gates* G, std::vector<uint32_t>* index, std::string* err) {
+    std::vector<uint32_t> cnt(n_values + 1, 0);
+    for (uint32_t p : pub)
+        if (p >= 1 && p <= n_values) cnt[p]++;
+    index->assign(n_values + 1, 0);
+    G->order.clear();
+    if (layout == ZK_ACIR_LAYOUT_REFERENCE) {
+        const size_t k = pub.size();
+        size_t n_sec = 0;
+        for (size_t w = 1; w <= n_values; w++) n_sec += k ? k - cnt[w] : 1;
+        if (n_sec + n_values * k >= ((size_t)1 << 31)) {
+            char m[160];
+            snprintf(m, sizeof m, "HandleValues: %zu witnesses x %zu public inputs make too many variables", n_values, k);
+            *err = m;
+            return ZK_ERR_ARG;
+        }
+        size_t n_pub = 0;
+        for (size_t w = 1; w <= n_values; w++) n_pub += cnt[w];
+        G->order.resize(n_pub + n_sec);
+        uint32_t* o = G->order.data();
+        size_t at = 0;
+        for (size_t w = 1; w <= n_values; w++)
+            for (uint32_t c = 0; c < cnt[w]; c++) { o[at] = (uint32_t)(w - 1); (*index)[w] = (uint32_t)at++; }
+        G->n_public = at;
+        for (size_t w = 1; w <= n_values; w++) {
+            const size_t copies = k ? k - cnt[w] : 1;
+            for (size_t c = 0; c < copies; c++) { o[at] = (uint32_t)(w - 1); (*index)[w] = (uint32_t)at++; }
+        }
+    } else {
+        G->order.resize(n_values);
+        uint32_t* o = G->order.data();
+        size_t at = 0;
+        for (size_t w = 1; w <= n_values; w++)
+            if (cnt[w]) { o[at] = (uint32_t)(w - 1); (*index)[w] = (uint32_t)at++; }
+        G->n_public = at;
+        for (size_t w = 1; w <= n_values; w++)
+            if (!cnt[w]) { o[at] = (uint32_t)(w - 1); (*index)[w] = (uint32_t)at++; }
+    }
+    G->n_vars = G->order.size();
+    return ZK_OK;
+}
+
+namespace acir_detail {
+struct Term {       // one [coefficient, witness...] term as the text gave it
+    bool ok = false;
+    uint64_t c[4] = {0, 0, 0, 0};
+    uint32_t w[2] = {0, 0};
+};
+// [hex, index x arity] at a value position.  ok = it is an array of exactly 1 + arity elements of the right kinds.
+static inline bool read_term(JTok& T, int depth, int arity, bool want_coeff, Term* t) {
+    t->ok = false;
+    if (!T.enter(depth)) return false;
+    if (*T.p != '[') return T.skip(depth);
+    bool good = true;
+    size_t count = 0;
+    if (!T.array(depth, [&](size_t j) {
+            count = j + 1;
+            if (j > (size_t)arity) { good = false; return T.skip(depth + 1); }
+            if (!T.enter(depth + 1)) return false;
+            if (j == 0) {
+                if (*T.p != '"') { good = false; return T.skip(depth + 1); }
+                const char* s;
+                size_t n;
+                if (!T.str(&s, &n)) return false;
+                if (want_coeff) good = felt_from_hex(s, n, t->c) && good;
+                else {  // the wiring alone: the literal must still be one SetString accepts
+                    bool hex = n >= 1 && n <= 64;
+                    for (size_t i = 0; hex && i < n; i++) hex = hex_nibble((unsigned char)s[i]) >= 0;
+                    good = hex && good;
+                }
+                return true;
+            }
+            if (*T.p == '{' || *T.p == '[' || *T.p == '"') { good = false; return T.skip(depth + 1); }
+            bool is_num;
+            double d;
+            if (!T.scalar(&is_num, &d)) return false;
+            good = is_num && as_index(d, &t->w[j - 1]) && good;
+            return true;
+        }))
+        return false;
+    t->ok = good && count == (size_t)arity + 1;
+    return true;
+}
+}  // namespace acir_detail
+
+// BuildSparseR1CS (sparse_r1cs.go:18-107) + HandleValues (common.go:45-76).  n_values = number of witness values handed over (witnesses 1..n).
+// Returns ZK_OK or ZK_ERR_ARG with *err set.
+static inline int lower_acir(const char* json, size_t len, size_t n_values, int layout, bool with_coeffs, Gates* G, std::string* err) {
+    using acir_detail::Term;
+    using acir_detail::read_term;
+    if (layout != ZK_ACIR_LAYOUT_REFERENCE && layout != ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS) {
+        *err = "unknown ACIR variable layout " + std::to_string(layout);
+        return ZK_ERR_ARG;
+    }
+    const bool exact = layout == ZK_ACIR_LAYOUT_REFERENCE;
+    *G = Gates();
+    G->with_coeffs = with_coeffs;
+    JTok T{json, json + len};
+    const char* sem = nullptr;  // the first semantic error (the text itself was well formed up to there)
+    auto bad = [&](const char* m) { if (!sem) sem = m; return false; };
+    std::vector<uint32_t> pub;
+    std::vector<uint8_t> has;   // per gate, bit k: xa / xb / xc names a WITNESS still to be mapped to its variable (else: variable 0)
+    bool have_ops = false, have_pub = false;
+
+    // a witness named by a gate: out of range -> variable 0 in the reference's map lookup (sparse_r1cs.go:53-54), an error in the other layout
+    auto place = [&](uint32_t w, uint32_t* x, uint8_t* mask, int bit) -> bool {
+        if (w < 1 || w > n_values) {
+            if (!exact) return false;
+            *x = 0;
+            *mask &= (uint8_t)~(1u << bit);
+            return true;
+        }
+        *x = w;
+        *mask |= (uint8_t)(1u << bit);
+        return true;
+    };
+
+    auto arithmetic = [&](int depth) -> bool {  // p at '{' of the Arithmetic object; members are values at depth + 1
+        Term mul0, lin[3], qc;
+        bool have_mul = false, have_lin = false, have_qc = false, mul_arr = false, lin_arr = false, mul_empty = true;
+        size_t nl = 0;
+        if (!T.object(depth, [&](const char* k, size_t kn) {
+                const int d = depth + 1;
+                if (!have_mul && key_is(k, kn, "mul_terms")) {
+                    have_mul = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '[') return T.skip(d);
+                    mul_arr = true;
+                    return T.array(d, [&](size_t i) {
+                        mul_empty = false;
+                        return i == 0 ? read_term(T, d + 1, 2, with_coeffs, &mul0) : T.skip(d + 1);
+                    });
+                }
+                if (!have_lin && key_is(k, kn, "linear_combinations")) {
+                    have_lin = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '[') return T.skip(d);
+                    lin_arr = true;
+                    return T.array(d, [&](size_t i) {
+                        nl = i + 1;
+                        return i < 3 ? read_term(T, d + 1, 1, with_coeffs, &lin[i]) : T.skip(d + 1);
+                    });
+                }
+                if (!have_qc && key_is(k, kn, "q_c")) {
+                    have_qc = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '"') return T.skip(d);
+                    const char* s;
+                    size_t n;
+                    if (!T.str(&s, &n)) return false;
+                    qc.ok = felt_from_hex(s, n, qc.c);
+                    return true;
+                }
+                return T.skip(d);
+            }))
+            return false;
+        if (!mul_arr || !lin_arr || !have_qc) return bad("ACIR JSON: malformed arithmetic opcode");
+        uint32_t xa = 0, xb = 0, xc = 0;
+        uint8_t mask = 0;
+        const uint64_t* c_m = nullptr;
+        const uint64_t *c_l = nullptr, *c_r = nullptr, *c_o = nullptr;
+        if (!mul_empty) {  // qM * (xa * xb): only the first mul term
+            if (!mul0.ok || !place(mul0.w[0], &xa, &mask, 0) || !place(mul0.w[1], &xb, &mask, 1)) return bad("ACIR JSON: malformed mul term");
+            c_m = mul0.c;
+        }
+        bool ok = true;
+        if (nl == 1) {
+            ok = lin[0].ok && place(lin[0].w[0], &xc, &mask, 2);
+            c_o = lin[0].c;
+        } else if (nl == 2 || nl == 3) {
+            ok = lin[0].ok && place(lin[0].w[0], &xa, &mask, 0) && lin[1].ok && place(lin[1].w[0], &xb, &mask, 1);
+            c_l = lin[0].c;
+            c_r = lin[1].c;
+            if (ok && nl == 3) {
+                ok = lin[2].ok && place(lin[2].w[0], &xc, &mask, 2);
+                c_o = lin[2].c;
+            }
+        }
+        if (!ok || !qc.ok) return bad("ACIR JSON: malformed linear combination / q_c");
+        if (with_coeffs) {
+            static const uint64_t Z[4] = {0, 0, 0, 0};
+            auto put = [](std::vector<HFr>& v, const uint64_t* c) { v.push_back(HFr{{c[0], c[1], c[2], c[3]}}); };
+            put(G->ql, c_l ? c_l : Z); put(G->qr, c_r ? c_r : Z); put(G->qo, c_o ? c_o : Z); put(G->qm, c_m ? c_m : Z); put(G->qk, qc.c);
+        }
+        G->xa.push_back(xa); G->xb.push_back(xb); G->xc.push_back(xc);
+        has.push_back(mask);
+        return true;
+    };
+
+    auto opcode = [&](int depth) -> bool {  // one element of "opcodes"
+        if (!T.enter(depth)) return false;
+        if (*T.p != '{') return T.skip(depth) && bad("ACIR JSON: opcode is not an object");
+        bool have_arith = false, arith_obj = false, other = false;
+        // the Arithmetic member is lowered where it stands; a second one (the first wins) is only validated
+        if (!T.object(depth, [&](const char* k, size_t kn) {
+                const int d = depth + 1;
+                if (!have_arith && key_is(k, kn, "Arithmetic")) {
+                    have_arith = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '{') return T.skip(d);
+                    arith_obj = true;
+                    return arithmetic(d);
+                }
+                if (key_is(k, kn, "Directive") || key_is(k, kn, "BlackBoxFuncCall")) other = true;  // no constraints (sparse_r1cs.go:33-37)
+                return T.skip(d);
+            }))
+            return false;
+        if (!have_arith) return other ? true : bad("unknown opcode type");
+        if (!arith_obj) return bad("ACIR JSON: malformed arithmetic opcode");
+        return true;
+    };
+
+    bool root_obj = false, ops_arr = false;
+    bool fine = T.enter(0);
+    if (fine) {
+        if (*T.p != '{') fine = T.skip(0);
+        else {
+            root_obj = true;
+            fine = T.object(0, [&](const char* k, size_t kn) {
+                if (!have_ops && key_is(k, kn, "opcodes")) {
+                    have_ops = true;
+                    if (!T.enter(1)) return false;
+                    if (*T.p != '[') return T.skip(1);
+                    ops_arr = true;
+                    return T.array(1, [&](size_t) { return opcode(2); });
+                }
+                if (!have_pub && key_is(k, kn, "public_inputs")) {
+                    have_pub = true;
+                    if (!T.enter(1)) return false;
+                    if (*T.p != '[') return T.skip(1);
+                    return T.array(1, [&](size_t) {
+                        if (!T.enter(2)) return false;
+                        if (*T.p == '{' || *T.p == '[' || *T.p == '"') return T.skip(2) && bad("ACIR JSON: bad public input");
+                        bool is_num;
+                        double d;
+                        uint32_t w;
+                        if (!T.scalar(&is_num, &d)) return false;
+                        if (!is_num || !as_index(d, &w)) return bad("ACIR JSON: bad public input");
+                        pub.push_back(w);
+                        return true;
+                    });
+                }
+                return T.skip(1);
+            });
+        }
+    }
+    if (!fine || !root_obj) {
+        *err = std::string("ACIR JSON: ") + (T.err ? T.err : sem ? sem : "not an object");
+        if (sem && !T.err) *err = sem;
+        return ZK_ERR_ARG;
+    }
+    if (!ops_arr) { *err = "ACIR JSON: no opcodes array"; return ZK_ERR_ARG; }
+    std::vector<uint32_t> index;
+    const int rc = handle_values(pub, n_values, layout, G, &index, err);
+    if (rc != ZK_OK) return rc;
+    const size_t nc = G->xa.size();
+    for (size_t i = 0; i < nc; i++) {
+        const uint8_t m = has[i];
+        if (m & 1) G->xa[i] = index[G->xa[i]];
+        if (m & 2) G->xb[i] = index[G->xb[i]];
+        if (m & 4) G->xc[i] = index[G->xc[i]];
+    }
+    if (with_coeffs)
+        for (std::vector<HFr>* v : {&G->ql, &G->qr, &G->qo, &G->qm, &G->qk}) to_mont_bulk(v->data(), v->size());
+    return ZK_OK;
+}
+
+// hex felt vector header: u32 big-endian count as 8 hex characters
+static inline bool count_from_hex(const char* hex, size_t len, size_t* n) {
+    if (len < 8) return false;
+    size_t v = 0;
+    for (int k = 0; k < 8; k++) {
+        const int d = hex_nibble((unsigned char)hex[k]);
+        if (d < 0) return false;
+        v = (v << 4) | (size_t)d;
+    }
+    *n = v;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ RawR1CS -> R1CS rows + wire values
+// buildR1CS of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:9-72, commented out there; payload RawR1CS of
+// src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60: {"gates":[{"mul_terms":[{"coefficient","multiplicand","multiplier"}],"add_terms":
+// [{"coefficient","sum"}],"constant_term"}],"public_inputs","values" (hex felt vector),"num_variables","num_constraints"}): every mul term gets an
+// internal product variable p with (1 * multiplicand) * (1 * multiplier) = 1 * p; every gate ends in
+// (1 * ONE) * (sum coefficient * p + sum coefficient * x + constant * ONE) = 0.  Made well-defined where the sketch is not: wires = [ONE, public
+// witnesses in witness order, the other witnesses, product variables]; values[w - 1] is witness w; the product variable is the plain product (the
+// sketch puts the coefficient on the product constraint's output AND on the term, which cancels it); the constant term IS in the sum (the sketch
+// drops it); a mul term with coefficient 0 emits nothing.
+struct RawR1CSBuilt {
+    std::vector<uint32_t> ptr[3], idx[3];
+    std::vector<HFr> val[3];
+    std::vector<HFr> wires;  // the full wire vector (Montgomery): [ONE, public..., secret..., products...]
+    size_t n_public = 0;     // ONE included
+};
+
+static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, std::string* err) {
+    struct MulT { bool ok; HFr c; uint32_t a, b; };
+    struct AddT { bool ok; HFr c; uint32_t x; };
+    struct Gate { bool shape_ok, k_ok; size_t m0, m1, a0, a1; HFr k; };
+    std::vector<MulT> muls;
+    std::vector<AddT> adds;
+    std::vector<Gate> gates;
+    std::vector<double> pubs;      // numbers as read; kinds checked after (a non-number is NaN)
+    std::string values;
+    bool have_gates = false, gates_arr = false, have_pub = false, pub_arr = false, have_vals = false, vals_str = false;
+    JTok T{json, json + len};
+    const double NOT_NUM = -1;  // as_index rejects it like any other non-index
+
+    // {"coefficient": hex, <name1>: index[, <name2>: index]} ; ok only if every named member is present (first occurrence) with the right kind
+    auto term = [&](int depth, const char* n1, const char* n2, HFr* c, uint32_t* w1, uint32_t* w2, bool* ok) -> bool {
+        *ok = false;
+        if (!T.enter(depth)) return false;
+        if (*T.p != '{') return T.skip(depth);
+        bool hc = false, h1 = false, h2 = false, cs = false, i1 = false, i2 = false;
+        if (!T.object(depth, [&](const char* k, size_t kn) {
+                const int d = depth + 1;
+                if (!hc && key_is(k, kn, "coefficient")) {
+                    hc = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '"') return T.skip(d);
+                    const char* s;
+                    size_t n;
+                    if (!T.str(&s, &n)) return false;
+                    uint64_t t[4];
+                    cs = felt_from_hex(s, n, t);
+                    if (cs) *c = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+                    return true;
+                }
+                const bool m1 = !h1 && key_is(k, kn, n1), m2 = !m1 && n2 && !h2 && key_is(k, kn, n2);
+                if (m1 || m2) {
+                    (m1 ? h1 : h2) = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p == '{' || *T.p == '[' || *T.p == '"') return T.skip(d);
+                    bool is_num;
+                    double v;
+                    if (!T.scalar(&is_num, &v)) return false;
+                    (m1 ? i1 : i2) = is_num && as_index(v, m1 ? w1 : w2);
+                    return true;
+                }
+                return T.skip(d);
+            }))
+            return false;
+        *ok = cs && i1 && (!n2 || i2);
+        return true;
+    };
+    auto gate = [&](int depth) -> bool {
+        Gate g{false, false, muls.size(), muls.size(), adds.size(), adds.size(), HFr::zero()};
+        if (!T.enter(depth)) return false;
+        if (*T.p != '{') { gates.push_back(g); return T.skip(depth); }
+        bool hm = false, ha = false, hk = false, m_arr = false, a_arr = false, k_str = false;
+        if (!T.object(depth, [&](const char* k, size_t kn) {
+                const int d = depth + 1;
+                if (!hm && key_is(k, kn, "mul_terms")) {
+                    hm = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '[') return T.skip(d);
+                    m_arr = true;
+                    g.m0 = muls.size();
+                    const bool r = T.array(d, [&](size_t) {
+                        MulT t{false, HFr::zero(), 0, 0};
+                        if (!term(d + 1, "multiplicand", "multiplier", &t.c, &t.a, &t.b, &t.ok)) return false;
+                        muls.push_back(t);
+                        return true;
+                    });
+                    g.m1 = muls.size();
+                    return r;
+                }
+                if (!ha && key_is(k, kn, "add_terms")) {
+                    ha = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '[') return T.skip(d);
+                    a_arr = true;
+                    g.a0 = adds.size();
+                    const bool r = T.array(d, [&](size_t) {
+                        AddT t{false, HFr::zero(), 0};
+                        if (!term(d + 1, "sum", nullptr, &t.c, &t.x, nullptr, &t.ok)) return false;
+                        adds.push_back(t);
+                        return true;
+                    });
+                    g.a1 = adds.size();
+                    return r;
+                }
+                if (!hk && key_is(k, kn, "constant_term")) {
+                    hk = true;
+                    if (!T.enter(d)) return false;
+                    if (*T.p != '"') return T.skip(d);
+                    k_str = true;
+                    const char* s;
+                    size_t n;
+                    if (!T.str(&s, &n)) return false;
+                    uint64_t t[4];
+                    g.k_ok = felt_from_hex(s, n, t);
+                    if (g.k_ok) g.k = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+                    return true;
+                }
+                return T.skip(d);
+            }))
+            return false;
+        g.shape_ok = m_arr && a_arr && k_str;
+        gates.push_back(g);
+        return true;
+    };
+
+    bool root_obj = false;
+    bool fine = T.enter(0);
+    if (fine) {
+        if (*T.p != '{') fine = T.skip(0);
+        else {
+            root_obj = true;
+            fine = T.object(0, [&](const char* k, size_t kn) {
+                if (!have_gates && key_is(k, kn, "gates")) {
+                    have_gates = true;
+                    if (!T.enter(1)) return false;
+                    if (*T.p != '[') return T.skip(1);
+                    gates_arr = true;
+                    return T.array(1, [&](size_t) { return gate(2); });
+                }
+                if (!have_pub && key_is(k, kn, "public_inputs")) {
+                    have_pub = true;
+                    if (!T.enter(1)) return false;
+                    if (*T.p != '[') return T.skip(1);
+                    pub_arr = true;
+                    return T.array(1, [&](size_t) {
+                        if (!T.enter(2)) return false;
+                        if (*T.p == '{' || *T.p == '[' || *T.p == '"') { pubs.push_back(NOT_NUM); return T.skip(2); }
+                        bool is_num;
+                        double v;
+                        if (!T.scalar(&is_num, &v)) return false;
+                        pubs.push_back(is_num ? v : NOT_NUM);
+                        return true;
+                    });
+                }
+                if (!have_vals && key_is(k, kn, "values")) {
+                    have_vals = true;
+                    if (!T.enter(1)) return false;
+                    if (*T.p != '"') return T.skip(1);
+                    vals_str = true;
+                    const char* s;
+                    size_t n;
+                    if (!T.str(&s, &n)) return false;
+                    values.assign(s, n);
+                    return true;
+                }
+                return T.skip(1);
+            });
+        }
+    }
+    if (!fine || !root_obj) { *err = std::string("RawR1CS JSON: ") + (T.err ? T.err : "not an object"); return ZK_ERR_ARG; }
+    if (!gates_arr || !vals_str) { *err = "RawR1CS JSON: gates / values missing"; return ZK_ERR_ARG; }
+    // witness values: hex felt vector, decoded on the host here (they feed the host-side solver step for the product variables)
+    size_t n = 0;
+    if (values.size() < 8) { *err = "felt vector: " + std::to_string(values.size()) + " characters cannot hold the 4-byte count"; return ZK_ERR_ARG; }
+    if (!count_from_hex(values.data(), values.size(), &n)) { *err = "felt vector: invalid hex character in the count"; return ZK_ERR_ARG; }
+    if (values.size() != 8 + 64 * n) { *err = "felt vector: " + std::to_string(values.size()) + " characters, the count says " + std::to_string(n) + " felts"; return ZK_ERR_LEN; }
+    std::vector<bool> is_pub(n + 1, false);
+    if (pub_arr)
+        for (double v : pubs) {
+            uint32_t w;
+            if (!as_index(v, &w)) { *err = "RawR1CS JSON: bad public input"; return ZK_ERR_ARG; }
+            if (w >= 1 && w <= n) is_pub[w] = true;
+        }
+    std::vector<HFr>& wv = B->wires;
+    wv.assign(1, HFr::one());
+    std::vector<uint32_t> wire(n + 1, 0);
+    size_t npub = 1;
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t w = 1; w <= n; w++)
+            if (is_pub[w] == (pass == 0)) {
+                uint64_t t[4] = {0, 0, 0, 0};
+                int badc = 0;
+                const char* s = values.data() + 8 + 64 * (w - 1);
+                for (int i = 0; i < 64; i++) {  // canonical values only, like fr.Vector.UnmarshalBinary
+                    const int d = hex_nibble((unsigned char)s[63 - i]);
+                    badc |= d;
+                    t[i >> 4] |= (uint64_t)(d & 15) << (4 * (i & 15));
+                }
+                if (badc < 0 || HFr::geq_mod(t)) { *err = "felt vector: invalid hex character or fr.Element encoding"; return ZK_ERR_ARG; }
+                wire[w] = (uint32_t)wv.size();
+                wv.push_back(HFr{{t[0], t[1], t[2], t[3]}}.to_mont());
+                if (pass == 0) npub++;
+            }
+    for (int m = 0; m < 3; m++) { B->ptr[m].assign(1, 0); B->idx[m].clear(); B->val[m].clear(); }
+    auto end_row = [&]() { for (int m = 0; m < 3; m++) B->ptr[m].push_back((uint32_t)B->idx[m].size()); };
+    const HFr one = HFr::one();
+    std::vector<std::pair<uint32_t, HFr>> terms;
+    for (const Gate& g : gates) {
+        if (!g.shape_ok) { *err = "RawR1CS JSON: malformed gate"; return ZK_ERR_ARG; }
+        terms.clear();
+        auto add_term = [&](uint32_t x, const HFr& c) {
+            for (auto& t : terms)
+                if (t.first == x) { t.second = t.second + c; return; }
+            terms.emplace_back(x, c);
+        };
+        {
+            for (size_t i = g.m0; i < g.m1; i++) {
+                const MulT& t = muls[i];
+                if (!t.ok || t.a < 1 || t.a > n || t.b < 1 || t.b > n) { *err = "RawR1CS JSON: malformed mul term"; return ZK_ERR_ARG; }
+                if (t.c.is_zero()) continue;
+                const uint32_t a = wire[t.a], b = wire[t.b], p = (uint32_t)wv.size();
+                wv.push_back(wv[a] * wv[b]);  // the solver's step for this internal variable
+                B->idx[0].push_back(a); B->val[0].push_back(one);
+                B->idx[1].push_back(b); B->val[1].push_back(one);
+                B->idx[2].push_back(p); B->val[2].push_back(one);
+                end_row();
+                add_term(p, t.c);
+            }
+            for (size_t i = g.a0; i < g.a1; i++) {
+                const AddT& t = adds[i];
+                if (!t.ok || t.x < 1 || t.x > n) { *err = "RawR1CS JSON: malformed add term"; return ZK_ERR_ARG; }
+                add_term(wire[t.x], t.c);
+            }
+        }
+        if (!g.k_ok) { *err = "RawR1CS JSON: malformed constant term"; return ZK_ERR_ARG; }
+        if (!g.k.is_zero()) add_term(0, g.k);
+        B->idx[0].push_back(0); B->val[0].push_back(one);
+        for (auto& t : terms) { B->idx[1].push_back(t.first); B->val[1].push_back(t.second); }
+        end_row();
+    }
+    B->n_public = npub;
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ content keys
+// 128-bit content key of a text (the caches of decoded keys and lowered circuits are keyed by it): four independent multiply-rotate lanes per
+// 64 KB segment, segments hashed on up to 16 threads (a proving key is 0.3 GB of hex text: one core reads it in 50 ms, sixteen in 5), the
+// segment digests folded in order.  Not a cryptographic hash: a caller who forges a collision only obtains a proof under the wrong one of his own keys.
+struct ContentKey {
+    uint64_t h[2] = {0, 0};
+    uint64_t len = 0;
+    bool operator<(const ContentKey& o) const { return h[0] != o.h[0] ? h[0] < o.h[0] : h[1] != o.h[1] ? h[1] < o.h[1] : len < o.len; }
+    bool operator==(const ContentKey& o) const { return h[0] == o.h[0] && h[1] == o.h[1] && len == o.len; }
+};
+static inline uint64_t ck_mix(uint64_t a, uint64_t b) {
+    const unsigned __int128 m = (unsigned __int128)(a ^ 0x9e3779b97f4a7c15ULL) * (b ^ 0xd1b54a32d192ed03ULL);
+    return (uint64_t)m ^ (uint64_t)(m >> 64);
+}
+static inline void ck_segment(const char* p, size_t n, uint64_t seed, uint64_t out[2]) {
+    uint64_t s[4] = {seed ^ 0x243f6a8885a308d3ULL, seed ^ 0x13198a2e03707344ULL, seed ^ 0xa4093822299f31d0ULL, seed ^ 0x082efa98ec4e6c89ULL};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        s[0] = ck_mix(s[0], w[0]);
+        s[1] = ck_mix(s[1], w[1]);
+        s[2] = ck_mix(s[2], w[2]);
+        s[3] = ck_mix(s[3], w[3]);
+    }
+    uint64_t w[4] = {0, 0, 0, 0};
+    memcpy(w, p + i, n - i);
+    s[0] = ck_mix(s[0], w[0] ^ n);
+    s[1] = ck_mix(s[1], w[1]);
+    s[2] = ck_mix(s[2], w[2]);
+    s[3] = ck_mix(s[3], w[3] ^ (n << 32));
+    out[0] = ck_mix(s[0], s[2]);
+    out[1] = ck_mix(s[1], s[3]);
+}
+static inline ContentKey content_key(const char* p, size_t n) {
+    const size_t SEG = (size_t)1 << 16;
+    const size_t nseg = (n + SEG - 1) / SEG;
+    std::vector<uint64_t> d(2 * (nseg ? nseg : 1), 0);
+    auto run = [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) ck_segment(p + k * SEG, k + 1 == nseg ? n - k * SEG : SEG, k, &d[2 * k]);
+    };
+    unsigned nt = nseg < 64 ? 1 : std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt <= 1) run(0, nseg);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; k++) th.emplace_back(run, nseg * k / nt, nseg * (k + 1) / nt);
+        for (auto& t : th) t.join();
+    }
+    ContentKey K;
+    K.len = n;
+    uint64_t a = 0x452821e638d01377ULL, b = 0xbe5466cf34e90c6cULL;
+    for (size_t k = 0; k < nseg; k++) {
+        a = ck_mix(a, d[2 * k]) + d[2 * k + 1];
+        b = ck_mix(b, d[2 * k + 1]) ^ a;
+    }
+    K.h[0] = ck_mix(a, n);
+    K.h[1] = ck_mix(b, ~(uint64_t)n);
+    return K;
+}
+
+}  // namespace zkmi

@@ -81,8 +81,15 @@ int ensure_init() {
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
         return ZK_OK;
     }
-    std::lock_guard<std::mutex> lk(c.mu);
-    return init_locked(0);
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.ready) return ZK_OK;
+        rc = init_locked(0);
+    }
+    prof_host("export.hip_init", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());  // runtime start + streams, once per process
+    return rc;
 }
 
 // A caller that already holds slots (an msm5 session pins 5 of the 8) and asks for more than are left would wait forever:
@@ -320,6 +327,11 @@ int zk_dev_sync(void) {
 
 int zk_profile_enable(int on) {
     ctx().profiling = on != 0;
+    return ZK_OK;
+}
+int zk_profile_host(const char* name, double ms) {
+    if (!name) return set_err(ZK_ERR_ARG, "null pointer");
+    prof_host(name, ms);
     return ZK_OK;
 }
 int zk_profile_reset(void) {

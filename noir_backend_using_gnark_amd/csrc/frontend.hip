@@ -20,257 +20,24 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <list>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
+#include "acir_host.hpp"  // the text side (host only, sanitizer- and mutation-tested on the CPU: tests/cpp/parser_fuzz.cpp)
 #include "ctx.hpp"
 #include "ff.hpp"
 #include "host_ff.hpp"
 
 namespace zkmi {
 
-// ------------------------------------------------------------------------------------------------ a small JSON reader
-struct JVal {
-    enum Kind { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
-    double num = 0;
-    bool b = false;
-    std::string str;
-    std::vector<JVal> arr;
-    std::vector<std::pair<std::string, JVal>> obj;
-    const JVal* get(const char* k) const {
-        for (auto& kv : obj)
-            if (kv.first == k) return &kv.second;
-        return nullptr;
-    }
-};
-struct JParser {
-    const char* p;
-    const char* end;
+static int lower(const char* json, size_t len, size_t n_values, int layout, bool with_coeffs, Gates* G) {
     std::string err;
-    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
-    bool fail(const char* m) { if (err.empty()) err = m; return false; }
-    bool str(std::string* out) {
-        if (p >= end || *p != '"') return fail("expected a string");
-        p++;
-        out->clear();
-        while (p < end && *p != '"') {
-            if (*p == '\\') {
-                p++;
-                if (p >= end) return fail("bad escape");
-                switch (*p) {
-                    case 'n': out->push_back('\n'); break;
-                    case 't': out->push_back('\t'); break;
-                    case 'r': out->push_back('\r'); break;
-                    case 'b': out->push_back('\b'); break;
-                    case 'f': out->push_back('\f'); break;
-                    case 'u': {  // only the ASCII range can occur in this schema
-                        if (end - p < 5) return fail("bad \\u escape");
-                        unsigned v = (unsigned)strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
-                        out->push_back((char)(v & 0x7f));
-                        p += 4;
-                        break;
-                    }
-                    default: out->push_back(*p);
-                }
-                p++;
-            } else {
-                out->push_back(*p++);
-            }
-        }
-        if (p >= end) return fail("unterminated string");
-        p++;
-        return true;
-    }
-    bool value(JVal* v, int depth = 0) {
-        if (depth > 64) return fail("nesting too deep");
-        ws();
-        if (p >= end) return fail("unexpected end");
-        if (*p == '{') {
-            v->kind = JVal::OBJ;
-            p++;
-            ws();
-            if (p < end && *p == '}') { p++; return true; }
-            for (;;) {
-                ws();
-                std::string k;
-                if (!str(&k)) return false;
-                ws();
-                if (p >= end || *p != ':') return fail("expected ':'");
-                p++;
-                v->obj.emplace_back(k, JVal());
-                if (!value(&v->obj.back().second, depth + 1)) return false;
-                ws();
-                if (p < end && *p == ',') { p++; continue; }
-                if (p < end && *p == '}') { p++; return true; }
-                return fail("expected ',' or '}'");
-            }
-        }
-        if (*p == '[') {
-            v->kind = JVal::ARR;
-            p++;
-            ws();
-            if (p < end && *p == ']') { p++; return true; }
-            for (;;) {
-                v->arr.emplace_back();
-                if (!value(&v->arr.back(), depth + 1)) return false;
-                ws();
-                if (p < end && *p == ',') { p++; continue; }
-                if (p < end && *p == ']') { p++; return true; }
-                return fail("expected ',' or ']'");
-            }
-        }
-        if (*p == '"') { v->kind = JVal::STR; return str(&v->str); }
-        // the length test comes first: the text is a GoString payload, not NUL-terminated
-        if (end - p >= 4 && !memcmp(p, "true", 4)) { v->kind = JVal::BOOL; v->b = true; p += 4; return true; }
-        if (end - p >= 5 && !memcmp(p, "false", 5)) { v->kind = JVal::BOOL; p += 5; return true; }
-        if (end - p >= 4 && !memcmp(p, "null", 4)) { p += 4; return true; }
-        char* e = nullptr;
-        std::string tmp(p, (size_t)(end - p) < 40 ? end : p + 40);
-        v->num = strtod(tmp.c_str(), &e);
-        if (e == tmp.c_str()) return fail("unexpected character");
-        v->kind = JVal::NUM;
-        p += e - tmp.c_str();
-        return true;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------ ACIR -> gates
-struct Gates {
-    size_t n_public = 0, n_vars = 0;
-    std::vector<HFr> ql, qr, qo, qm, qk;
-    std::vector<uint32_t> xa, xb, xc;
-    std::vector<uint32_t> order;  // variable k holds witness order[k] (1-based witness index - 1): the gather that builds the solution
-};
-
-// fr.Element.SetString on a hex literal of the ACIR (FieldElement: 64 hex characters big-endian, canonical or not: reduced mod r)
-static bool felt_from_hex(const std::string& h, HFr* out) {
-    if (h.size() > 64 || h.empty()) return false;
-    uint8_t be[32] = {0};
-    std::string s(64 - h.size(), '0');
-    s += h;
-    for (int i = 0; i < 32; i++) {
-        auto hv = [](int c) { return (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; };
-        int hi = hv(s[2 * i]), lo = hv(s[2 * i + 1]);
-        if (hi < 0 || lo < 0) return false;
-        be[i] = (uint8_t)((hi << 4) | lo);
-    }
-    uint64_t t[4];
-    for (int i = 0; i < 4; i++) {
-        uint64_t v = 0;
-        for (int b = 0; b < 8; b++) v = (v << 8) | be[8 * (3 - i) + b];
-        t[i] = v;
-    }
-    while (HFr::geq_mod(t)) HFr::sub_mod(t);
-    *out = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
-    return true;
-}
-static bool as_index(const JVal& v, uint32_t* out) {
-    if (v.kind != JVal::NUM || v.num < 0 || v.num > 4294967295.0 || v.num != (double)(uint64_t)v.num) return false;
-    *out = (uint32_t)v.num;
-    return true;
-}
-
-// BuildSparseR1CS (sparse_r1cs.go:18-107) + HandleValues (common.go:45-76).  n_values = number of witness values handed over (witnesses 1..n).
-static int lower_acir(const char* json, size_t len, size_t n_values, int layout, Gates* G) {
-    if (layout != ZK_ACIR_LAYOUT_REFERENCE && layout != ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS) return set_err(ZK_ERR_ARG, "unknown ACIR variable layout %d", layout);
-    JParser P{json, json + len, ""};
-    JVal root;
-    if (!P.value(&root) || root.kind != JVal::OBJ) return set_err(ZK_ERR_ARG, "ACIR JSON: %s", P.err.empty() ? "not an object" : P.err.c_str());
-    const JVal* ops = root.get("opcodes");
-    const JVal* pubs = root.get("public_inputs");
-    if (!ops || ops->kind != JVal::ARR) return set_err(ZK_ERR_ARG, "ACIR JSON: no opcodes array");
-    std::vector<uint32_t> pub;
-    if (pubs && pubs->kind == JVal::ARR)
-        for (auto& e : pubs->arr) {
-            uint32_t w;
-            if (!as_index(e, &w)) return set_err(ZK_ERR_ARG, "ACIR JSON: bad public input");
-            pub.push_back(w);
-        }
-    // index[w] = variable of witness w (1-based); -1 = none
-    std::vector<int64_t> index(n_values + 1, -1);
-    G->order.clear();
-    const bool exact = layout == ZK_ACIR_LAYOUT_REFERENCE;
-    if (exact) {
-        // HandleValues, literally (common.go:45-76).  Loop 1: one public variable per (witness, matching public input), in witness order.  Loop 2: with
-        // public inputs, one SECRET variable per (witness, NON-matching public input) -- i.e. |P| copies of a private witness, |P| - 1 copies of a public
-        // one -- and indexMap keeps the last index assigned, so that with |P| >= 2 every gate names a secret copy; without public inputs one secret
-        // variable per witness.  cs.AddPublicVariable / AddSecretVariable number the variables public first, then secret, in the order of the calls.
-        const size_t k = pub.size();
-        size_t n_sec = 0;
-        for (size_t w = 1; w <= n_values; w++) {
-            size_t same = 0;
-            for (uint32_t p : pub) same += p == w;
-            n_sec += k ? k - same : 1;
-        }
-        if (n_sec + n_values * k >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "HandleValues: %zu witnesses x %zu public inputs make too many variables", n_values, k);
-        for (size_t w = 1; w <= n_values; w++)
-            for (uint32_t p : pub)
-                if (p == w) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
-        G->n_public = G->order.size();
-        for (size_t w = 1; w <= n_values; w++) {
-            if (k) {
-                for (uint32_t p : pub)
-                    if (p != w) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
-            } else {
-                index[w] = (int64_t)G->order.size();
-                G->order.push_back((uint32_t)(w - 1));
-            }
-        }
-    } else {
-        // one variable per witness: public witnesses first (in witness order), then the others
-        std::vector<bool> is_pub(n_values + 1, false);
-        for (uint32_t w : pub)
-            if (w >= 1 && w <= n_values) is_pub[w] = true;
-        for (size_t w = 1; w <= n_values; w++)
-            if (is_pub[w]) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
-        G->n_public = G->order.size();
-        for (size_t w = 1; w <= n_values; w++)
-            if (!is_pub[w]) { index[w] = (int64_t)G->order.size(); G->order.push_back((uint32_t)(w - 1)); }
-    }
-    G->n_vars = G->order.size();
-    auto var_of = [&](const JVal& v, uint32_t* out) -> bool {
-        uint32_t w;
-        if (!as_index(v, &w)) return false;
-        if (w < 1 || w > n_values || index[w] < 0) {
-            if (!exact) return false;
-            *out = 0;  // the reference's map lookup of a witness that has no variable yields the zero value: variable 0 (sparse_r1cs.go:53-54)
-            return true;
-        }
-        *out = (uint32_t)index[w];
-        return true;
-    };
-    for (auto& op : ops->arr) {
-        if (op.kind != JVal::OBJ) return set_err(ZK_ERR_ARG, "ACIR JSON: opcode is not an object");
-        const JVal* a = op.get("Arithmetic");
-        if (!a) {
-            if (op.get("Directive") || op.get("BlackBoxFuncCall")) continue;  // no constraints (sparse_r1cs.go:33-37)
-            return set_err(ZK_ERR_ARG, "unknown opcode type");
-        }
-        const JVal *mul = a->get("mul_terms"), *lin = a->get("linear_combinations"), *qc = a->get("q_c");
-        if (!mul || !lin || !qc || mul->kind != JVal::ARR || lin->kind != JVal::ARR || qc->kind != JVal::STR) return set_err(ZK_ERR_ARG, "ACIR JSON: malformed arithmetic opcode");
-        HFr ql = HFr::zero(), qr = ql, qo = ql, qm = ql, qk;
-        uint32_t xa = 0, xb = 0, xc = 0;
-        if (!mul->arr.empty()) {  // qM * (xa * xb): only the first mul term
-            const JVal& t = mul->arr[0];
-            if (t.kind != JVal::ARR || t.arr.size() != 3 || t.arr[0].kind != JVal::STR || !felt_from_hex(t.arr[0].str, &qm) || !var_of(t.arr[1], &xa) || !var_of(t.arr[2], &xb))
-                return set_err(ZK_ERR_ARG, "ACIR JSON: malformed mul term");
-        }
-        auto term = [&](const JVal& t, HFr* c, uint32_t* x) -> bool {
-            return t.kind == JVal::ARR && t.arr.size() == 2 && t.arr[0].kind == JVal::STR && felt_from_hex(t.arr[0].str, c) && var_of(t.arr[1], x);
-        };
-        const size_t nl = lin->arr.size();
-        bool ok = true;
-        if (nl == 1) ok = term(lin->arr[0], &qo, &xc);
-        else if (nl == 2 || nl == 3) {
-            ok = term(lin->arr[0], &ql, &xa) && term(lin->arr[1], &qr, &xb);
-            if (ok && nl == 3) ok = term(lin->arr[2], &qo, &xc);
-        }
-        if (!ok || !felt_from_hex(qc->str, &qk)) return set_err(ZK_ERR_ARG, "ACIR JSON: malformed linear combination / q_c");
-        G->ql.push_back(ql); G->qr.push_back(qr); G->qo.push_back(qo); G->qm.push_back(qm); G->qk.push_back(qk);
-        G->xa.push_back(xa); G->xb.push_back(xb); G->xc.push_back(xc);
-    }
-    return ZK_OK;
+    const int rc = lower_acir(json, len, n_values, layout, with_coeffs, G, &err);
+    return rc == ZK_OK ? ZK_OK : set_err(rc, "%s", err.c_str());
 }
 
 __global__ void k_gather_fr(const Fr* __restrict__ vals, const uint32_t* __restrict__ order, size_t n, Fr* __restrict__ out) {
@@ -278,15 +45,9 @@ __global__ void k_gather_fr(const Fr* __restrict__ vals, const uint32_t* __restr
     if (i < n) out[i] = vals[order[i]];
 }
 
-static int count_from_hex(const char* hex, size_t len, size_t* n) {
+static int count_of(const char* hex, size_t len, size_t* n) {
     if (len < 8) return set_err(ZK_ERR_ARG, "felt vector: %zu characters cannot hold the 4-byte count", len);
-    size_t v = 0;
-    for (int k = 0; k < 8; k++) {
-        int c = hex[k], d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1;
-        if (d < 0) return set_err(ZK_ERR_ARG, "felt vector: invalid hex character in the count");
-        v = (v << 4) | (size_t)d;
-    }
-    *n = v;
+    if (!count_from_hex(hex, len, n)) return set_err(ZK_ERR_ARG, "felt vector: invalid hex character in the count");
     return ZK_OK;
 }
 
@@ -300,81 +61,341 @@ static int circuit_of(const Gates& G, zk_plonk_circuit* c) {
     return ZK_OK;
 }
 
+// wall-clock sections of the export path, reported beside the kernels when profiling is on (zk_profile_*; bench.py's `export_path` block)
+struct Phase {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* name) {
+        const auto t1 = std::chrono::steady_clock::now();
+        prof_host(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ what stays resident between calls
+// The reference re-reads everything on every call: the ACIR text is unmarshalled and lowered, the proving key is hex-decoded and ReadFrom'd
+// (main.go:24-37 -> backend/plonk/plonk.go:53-73), the SRS file is re-read (plonk.go:16,34,58).  At 2^19 gates that is 0.24 GB of JSON and 0.33 GB of
+// key text in front of a 10 ms prover.  Here both texts are identified by a 128-bit content key (acir_host.hpp: sixteen threads read the 0.57 GB in a few
+// ms) and what was derived from them stays resident:
+//   Lowered   the circuit's wiring (xa, xb, xc), HandleValues' variable order in HBM, and the per-proof buffers of the witness vector
+//   CachedKey the decoded proving key with its nine big-coset forms ("device-resident bases cache keyed by pk hash")
+// both least-recently-used within ZKMI_TABLE_CAP_GB (the bound the window tables of resident keys already obey; 0 = keep nothing between calls).
+// A second call with the same texts costs: two content keys, the witness vector (33 MB of hex, decoded on the device), the prover.
+struct Lowered {
+    ContentKey key;
+    size_t n_values = 0;
+    int layout = 0;
+    size_t n_public = 0, n_vars = 0, n_gates = 0;
+    std::vector<uint32_t> xa, xb, xc, order_public;  // host copies: a key that is not resident yet is read against the wiring; the verifier's public-witness list
+    std::vector<uint32_t> order;                     // kept until it is uploaded
+    std::mutex work;                                 // one proof at a time per circuit (the key serialises them anyway)
+    uint32_t* d_order = nullptr;
+    void *d_vals = nullptr, *d_sol = nullptr;
+    size_t bytes() const { return (xa.size() * 3 + order_public.size() + order.size()) * 4 + (d_order ? n_vars * 36 + n_values * 32 : 0); }
+    ~Lowered() {
+        for (void* q : {(void*)d_order, d_vals, d_sol})
+            if (q) (void)hipFree(q);
+    }
+    int device_buffers() {  // under `work`
+        if (d_order) return ZK_OK;
+        ZK_TRY(ensure_init());
+        ZK_HIP(hipMalloc((void**)&d_order, (n_vars ? n_vars : 1) * 4));
+        ZK_HIP(hipMalloc(&d_vals, (n_values ? n_values : 1) * 32));
+        ZK_HIP(hipMalloc(&d_sol, (n_vars ? n_vars : 1) * 32));
+        if (n_vars) ZK_HIP(hipMemcpy(d_order, order.data(), n_vars * 4, hipMemcpyHostToDevice));
+        std::vector<uint32_t>().swap(order);
+        return ZK_OK;
+    }
+};
+struct CachedKey {
+    ContentKey pk, acir;
+    size_t n_values = 0;
+    int layout = 0;
+    uint64_t srs = 0, handle = 0;
+    size_t bytes = 0;
+    int in_use = 0;
+};
+static std::mutex g_cache_mu;
+static std::list<std::shared_ptr<Lowered>> g_lowered;  // most recently used first
+static std::list<CachedKey> g_keys;
+static size_t cache_cap_bytes() {
+    static const size_t cap_gb = (size_t)zk_env_bounded("ZKMI_TABLE_CAP_GB", 128, 0, 1024);
+    return cap_gb << 30;
+}
+// drops least-recently-used entries until `extra` more bytes fit (entries in use stay); keys first (1 GB each at 2^19 gates), then circuits
+static void cache_trim_locked(size_t extra, std::vector<uint64_t>* to_free) {
+    const size_t cap = cache_cap_bytes();
+    auto total = [&]() {
+        size_t t = extra;
+        for (auto& k : g_keys) t += k.bytes;
+        for (auto& l : g_lowered) t += l->bytes();
+        return t;
+    };
+    for (auto it = g_keys.end(); it != g_keys.begin() && (total() > cap || g_keys.size() >= 8);) {
+        --it;
+        if (it->in_use) continue;
+        to_free->push_back(it->handle);
+        it = g_keys.erase(it);
+    }
+    while (!g_lowered.empty() && (total() > cap || g_lowered.size() >= 8)) {
+        if (g_lowered.back().use_count() > 1) break;  // a call is using it
+        g_lowered.pop_back();
+    }
+}
+static void free_handles(const std::vector<uint64_t>& hs) {
+    for (uint64_t h : hs) (void)zk_bn254_plonk_pk_free(h);
+}
+
+// One fully lowered circuit (coefficients included) waits here between the two calls of a preprocess -- the size query and the call that writes the
+// key -- so that 0.24 GB of JSON is read once, not twice.  Taken by the first request for it, replaced by the next size query.
+struct Stash {
+    ContentKey key;
+    size_t n_values = 0;
+    int layout = 0;
+    std::unique_ptr<Gates> gates;
+};
+static Stash g_stash;
+static void stash_put(const Lowered& L, Gates&& G) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_stash.key = L.key;
+    g_stash.n_values = L.n_values;
+    g_stash.layout = L.layout;
+    g_stash.gates.reset(new Gates(std::move(G)));
+}
+
+// the circuit behind an ACIR text: from the cache, or lowered now.  full != NULL: the caller also wants the gates with their coefficients (Setup).
+static int lowered_get(const char* acir_json, size_t acir_len, size_t n_values, int layout, std::shared_ptr<Lowered>* out, Gates* full) {
+    Phase ph;
+    const ContentKey key = content_key(acir_json, acir_len);
+    ph.lap("export.acir_content_key");
+    bool have_full = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (full && g_stash.gates && g_stash.key == key && g_stash.n_values == n_values && g_stash.layout == layout) {
+            *full = std::move(*g_stash.gates);
+            g_stash.gates.reset();
+            have_full = true;
+        }
+        if (!full || have_full)
+            for (auto it = g_lowered.begin(); it != g_lowered.end(); ++it)
+                if ((*it)->key == key && (*it)->n_values == n_values && (*it)->layout == layout) {
+                    g_lowered.splice(g_lowered.begin(), g_lowered, it);
+                    *out = g_lowered.front();
+                    return ZK_OK;
+                }
+    }
+    Gates local;
+    Gates* G = full ? full : &local;
+    if (!have_full) {
+        ZK_TRY(lower(acir_json, acir_len, n_values, layout, full != nullptr, G));
+        ph.lap(full ? "export.acir_parse_lower_with_coefficients" : "export.acir_parse_lower");
+    }
+    auto L = std::make_shared<Lowered>();
+    L->key = key;
+    L->n_values = n_values;
+    L->layout = layout;
+    L->n_public = G->n_public;
+    L->n_vars = G->n_vars;
+    L->n_gates = G->xa.size();
+    L->order_public.assign(G->order.begin(), G->order.begin() + G->n_public);
+    if (full) { L->xa = G->xa; L->xb = G->xb; L->xc = G->xc; L->order = G->order; }
+    else { L->xa.swap(G->xa); L->xb.swap(G->xb); L->xc.swap(G->xc); L->order.swap(G->order); }
+    std::vector<uint64_t> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_lowered.begin(); it != g_lowered.end(); ++it)
+            if ((*it)->key == key && (*it)->n_values == n_values && (*it)->layout == layout) { g_lowered.erase(it); break; }  // re-lowered with coefficients
+        if (cache_cap_bytes()) {
+            cache_trim_locked(L->bytes() + L->n_vars * 36 + L->n_values * 32, &dead);
+            g_lowered.push_front(L);
+        }
+    }
+    free_handles(dead);
+    *out = L;
+    return ZK_OK;
+}
+
+// the resident key behind a key text: from the cache, or decoded now against the circuit's wiring.  *entry_handle stays valid until key_release.
+static int key_get(const char* pk_hex, size_t pk_len, const Lowered& L, uint64_t srs, uint64_t* handle, bool* cached) {
+    Phase ph;
+    const ContentKey key = content_key(pk_hex, pk_len);
+    ph.lap("export.pk_content_key");
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_keys.begin(); it != g_keys.end(); ++it)
+            if (it->pk == key && it->acir == L.key && it->n_values == L.n_values && it->layout == L.layout && it->srs == srs) {
+                it->in_use++;
+                *handle = it->handle;
+                *cached = true;
+                g_keys.splice(g_keys.begin(), g_keys, it);
+                return ZK_OK;
+            }
+    }
+    *cached = false;
+    uint64_t h = 0;
+    int rc = zk_bn254_plonk_pk_read(pk_hex, pk_len, 1, L.n_vars, L.n_gates, L.xa.data(), L.xb.data(), L.xc.data(), srs, &h);
+    if (rc == ZK_ERR_HIP) {  // out of HBM with idle keys resident: let them go and try once more
+        std::vector<uint64_t> dead;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (auto it = g_keys.begin(); it != g_keys.end();)
+                if (!it->in_use) { dead.push_back(it->handle); it = g_keys.erase(it); } else ++it;
+        }
+        if (!dead.empty()) {
+            free_handles(dead);
+            rc = zk_bn254_plonk_pk_read(pk_hex, pk_len, 1, L.n_vars, L.n_gates, L.xa.data(), L.xb.data(), L.xc.data(), srs, &h);
+        }
+    }
+    ZK_TRY(rc);
+    *handle = h;
+    size_t bytes = 0;
+    (void)zk_bn254_plonk_pk_bytes(h, &bytes);
+    if (!cache_cap_bytes() || bytes > cache_cap_bytes()) return ZK_OK;  // not kept: the caller frees it (*cached stays false)
+    std::vector<uint64_t> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        cache_trim_locked(bytes, &dead);
+        CachedKey e;
+        e.pk = key; e.acir = L.key; e.n_values = L.n_values; e.layout = L.layout; e.srs = srs; e.handle = h; e.bytes = bytes; e.in_use = 1;
+        g_keys.push_front(e);
+        *cached = true;
+    }
+    free_handles(dead);
+    return ZK_OK;
+}
+static void key_release(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto& k : g_keys)
+        if (k.handle == handle) { if (k.in_use > 0) k.in_use--; return; }
+}
+// a key Setup has just produced enters the cache under the content key of the text it was written as: the PlonkProveWithPK that follows finds it
+static void key_adopt(const char* pk_hex, size_t pk_len, const Lowered& L, uint64_t srs, uint64_t h, bool* adopted) {
+    *adopted = false;
+    size_t bytes = 0;
+    if (zk_bn254_plonk_pk_bytes(h, &bytes) != ZK_OK || !cache_cap_bytes() || bytes > cache_cap_bytes()) return;
+    const ContentKey key = content_key(pk_hex, pk_len);
+    std::vector<uint64_t> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto& k : g_keys)
+            if (k.pk == key && k.acir == L.key && k.n_values == L.n_values && k.layout == L.layout && k.srs == srs) return;  // already resident
+        cache_trim_locked(bytes, &dead);
+        CachedKey e;
+        e.pk = key; e.acir = L.key; e.n_values = L.n_values; e.layout = L.layout; e.srs = srs; e.handle = h; e.bytes = bytes; e.in_use = 0;
+        g_keys.push_front(e);
+        *adopted = true;
+    }
+    free_handles(dead);
+}
+
 }  // namespace zkmi
 
 using namespace zkmi;
 
 extern "C" {
 
+// Releases everything the export path keeps resident between calls (lowered circuits, decoded proving keys).  Keys in use by a running proof stay.
+int zk_export_cache_clear(void) {
+    std::vector<uint64_t> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_keys.begin(); it != g_keys.end();)
+            if (!it->in_use) { dead.push_back(it->handle); it = g_keys.erase(it); } else ++it;
+        g_lowered.clear();
+    }
+    free_handles(dead);
+    return ZK_OK;
+}
+// resident entries and their HBM + host bytes (tests, bench.py)
+int zk_export_cache_info(size_t* n_circuits, size_t* n_keys, size_t* bytes) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t t = 0;
+    for (auto& k : g_keys) t += k.bytes;
+    for (auto& l : g_lowered) t += l->bytes();
+    if (n_circuits) *n_circuits = g_lowered.size();
+    if (n_keys) *n_keys = g_keys.size();
+    if (bytes) *bytes = t;
+    return ZK_OK;
+}
+
 // PlonkPreprocess (main.go:58-78): ACIR + the witness-value vector (only its length and the public/secret split matter to Setup) -> hex of
 // ProvingKey.WriteTo and hex of VerifyingKey.WriteTo (= the first 368 bytes of the former).  pk_hex_out may be NULL with pk_cap = 0 to query
-// the sizes.  The key also stays resident: *pk_handle (optional) can be handed to zk_bn254_plonk_prove directly.
+// the sizes.  The key also stays resident: *pk_handle (optional) can be handed to zk_bn254_plonk_prove directly; without it the key enters the
+// export cache under the content key of pk_hex_out, so that the zk_plonk_prove_with_pk which follows in this process neither decodes nor rebuilds it.
 int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, uint64_t srs_handle, char* pk_hex_out,
                         size_t pk_cap, size_t* pk_len, char* vk_hex_out, size_t vk_cap, size_t* vk_len, uint64_t* pk_handle) {
     if (!acir_json || !values_hex || !pk_len || !vk_len) return set_err(ZK_ERR_ARG, "null pointer");
     size_t n_values = 0;
-    ZK_TRY(count_from_hex(values_hex, values_len, &n_values));
+    ZK_TRY(count_of(values_hex, values_len, &n_values));
     if (values_len != 8 + 64 * n_values) return set_err(ZK_ERR_LEN, "felt vector: %zu characters, the count says %zu felts", values_len, n_values);
+    std::shared_ptr<Lowered> L;
     Gates G;
-    ZK_TRY(lower_acir(acir_json, acir_len, n_values, layout, &G));
+    ZK_TRY(lowered_get(acir_json, acir_len, n_values, layout, &L, &G));
     // sizes first (a call with pk_hex_out == NULL only asks for them): domain n = next power of two >= gates + public inputs
     size_t n = 1;
-    while (n < G.xa.size() + G.n_public) n <<= 1;
+    while (n < L->n_gates + L->n_public) n <<= 1;
     *pk_len = 2 * (704 + 9 * (4 + 32 * n) + 24 * n);
     *vk_len = 2 * 368;
-    if (!pk_hex_out) return ZK_OK;
+    if (!pk_hex_out) { stash_put(*L, std::move(G)); return ZK_OK; }  // the lowered circuit waits for the call that writes the key
     if (pk_cap < *pk_len || (vk_hex_out && vk_cap < *vk_len)) return set_err(ZK_ERR_ARG, "outputs hold %zu / %zu characters, %zu / %zu needed", pk_cap, vk_cap, *pk_len, *vk_len);
+    Phase ph;
     zk_plonk_circuit c;
     circuit_of(G, &c);
     uint64_t h = 0;
     ZK_TRY(zk_bn254_plonk_setup(&c, srs_handle, &h, nullptr));
+    ph.lap("export.plonk_setup");
     int rc = zk_bn254_plonk_pk_write(h, 1, pk_hex_out, pk_cap, pk_len);
+    ph.lap("export.pk_write_hex");
     if (rc == ZK_OK && vk_hex_out) memcpy(vk_hex_out, pk_hex_out, *vk_len);  // ProvingKey.WriteTo starts with VerifyingKey.WriteTo
-    if (pk_handle && rc == ZK_OK) *pk_handle = h;
-    else (void)zk_bn254_plonk_pk_free(h);
+    if (pk_handle && rc == ZK_OK) { *pk_handle = h; return ZK_OK; }
+    bool adopted = false;
+    if (rc == ZK_OK) key_adopt(pk_hex_out, *pk_len, *L, srs_handle, h, &adopted);
+    ph.lap("export.pk_adopt");
+    if (!adopted) (void)zk_bn254_plonk_pk_free(h);
     return rc;
 }
 
 // PlonkProveWithPK (main.go:24-37): ACIR + hex witness values + hex proving key -> hex of Proof.WriteTo (2 * 548 characters, no terminator).
 // pk_hex may be NULL when pk_handle names a resident key (zk_plonk_preprocess / zk_bn254_plonk_pk_read) -- the reference deserialises the
-// key on every call.  blinders: 9 scalars or NULL (drawn from /dev/urandom, as upstream draws them with fr.SetRandom).
+// key on every call; here a key text seen before (same circuit, same SRS) is found resident by its content key.
+// blinders: 9 scalars or NULL (drawn from /dev/urandom, as upstream draws them with fr.SetRandom).
 int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, const char* pk_hex, size_t pk_len,
                            uint64_t pk_handle, uint64_t srs_handle, const zk_fr* blinders, char proof_hex_out[2 * ZK_PLONK_PROOF_BYTES]) {
     if (!acir_json || !values_hex || !proof_hex_out || (!pk_hex && !pk_handle)) return set_err(ZK_ERR_ARG, "null pointer");
     size_t n_values = 0;
-    ZK_TRY(count_from_hex(values_hex, values_len, &n_values));
-    Gates G;
-    ZK_TRY(lower_acir(acir_json, acir_len, n_values, layout, &G));
+    ZK_TRY(count_of(values_hex, values_len, &n_values));
+    std::shared_ptr<Lowered> L;
+    ZK_TRY(lowered_get(acir_json, acir_len, n_values, layout, &L, nullptr));
     ZK_TRY(ensure_init());
+    std::lock_guard<std::mutex> work(L->work);
+    Phase ph;
+    ZK_TRY(L->device_buffers());
+    ph.lap("export.circuit_to_device");
     // witness values: DeserializeFelts on the device, then the public-first gather (BuildWitnesses)
-    void *d_vals = nullptr, *d_sol = nullptr, *d_order = nullptr;
-    struct Free { void** p[3]; ~Free() { for (auto q : p) if (*q) (void)hipFree(*q); } } guard{{&d_vals, &d_sol, &d_order}};
-    ZK_HIP(hipMalloc(&d_vals, (n_values ? n_values : 1) * 32));
-    ZK_HIP(hipMalloc(&d_sol, (G.n_vars ? G.n_vars : 1) * 32));
-    ZK_HIP(hipMalloc(&d_order, (G.n_vars ? G.n_vars : 1) * 4));
     size_t n_dec = 0;
-    ZK_TRY(zk_bn254_felts_decode_hex(values_hex, values_len, d_vals, n_values ? n_values : 1, &n_dec));
+    ZK_TRY(zk_bn254_felts_decode_hex(values_hex, values_len, L->d_vals, n_values ? n_values : 1, &n_dec));
+    ph.lap("export.values_decode");
     {
         SlotGuard g;
         ZK_TRY(acquire_slot(&g.s));
         hipStream_t st = g.s->stream;
-        if (G.n_vars) {
-            ZK_HIP(hipMemcpyAsync(d_order, G.order.data(), G.n_vars * 4, hipMemcpyHostToDevice, st));
-            ZK_LAUNCH(g.s, st, "witness_gather", k_gather_fr, dim3((unsigned)((G.n_vars + 255) / 256)), dim3(256), 0, (const Fr*)d_vals, (const uint32_t*)d_order, G.n_vars, (Fr*)d_sol);
-        }
+        if (L->n_vars)
+            ZK_LAUNCH(g.s, st, "witness_gather", k_gather_fr, dim3((unsigned)((L->n_vars + 255) / 256)), dim3(256), 0, (const Fr*)L->d_vals, (const uint32_t*)L->d_order, L->n_vars, (Fr*)L->d_sol);
         ZK_TRY(slot_sync(g.s, st));
     }
+    ph.lap("export.witness_gather");
     uint64_t h = pk_handle;
-    if (pk_hex) ZK_TRY(zk_bn254_plonk_pk_read(pk_hex, pk_len, 1, G.n_vars, G.xa.size(), G.xa.data(), G.xb.data(), G.xc.data(), srs_handle, &h));
+    bool cached = false;
+    if (pk_hex) ZK_TRY(key_get(pk_hex, pk_len, *L, srs_handle, &h, &cached));
+    struct Done {  // whatever happens below: a cached key is unpinned, an uncached one freed
+        uint64_t h; bool from_text, cached;
+        ~Done() { if (from_text) { if (cached) key_release(h); else (void)zk_bn254_plonk_pk_free(h); } }
+    } done{h, pk_hex != nullptr, cached};
+    ph.lap("export.pk_resident");
     {   // the key must be the key of THIS circuit: same public / variable / gate counts (a key of another shape would read the solution out of bounds)
         size_t kp = 0, kv = 0, kc = 0;
-        int rc = zk_bn254_plonk_pk_info(h, nullptr, &kp, &kc, &kv);
-        if (rc == ZK_OK && (kp != G.n_public || kv != G.n_vars || kc != G.xa.size()))
-            rc = set_err(ZK_ERR_ARG, "proving key is for %zu public / %zu variables / %zu gates, the circuit has %zu / %zu / %zu", kp, kv, kc, G.n_public, G.n_vars, G.xa.size());
-        if (rc != ZK_OK) {
-            if (pk_hex) (void)zk_bn254_plonk_pk_free(h);
-            return rc;
-        }
+        ZK_TRY(zk_bn254_plonk_pk_info(h, nullptr, &kp, &kc, &kv));
+        if (kp != L->n_public || kv != L->n_vars || kc != L->n_gates)
+            return set_err(ZK_ERR_ARG, "proving key is for %zu public / %zu variables / %zu gates, the circuit has %zu / %zu / %zu", kp, kv, kc, L->n_public, L->n_vars, L->n_gates);
     }
     zk_fr rnd[9];
     if (!blinders) {
@@ -382,7 +403,6 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
         uint8_t raw[9 * 32];
         if (!f || fread(raw, 1, sizeof raw, f) != sizeof raw) {
             if (f) fclose(f);
-            if (pk_hex) (void)zk_bn254_plonk_pk_free(h);
             return set_err(ZK_ERR_ARG, "no randomness source for the blinding scalars");
         }
         fclose(f);
@@ -397,9 +417,8 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
         blinders = rnd;
     }
     uint8_t proof[ZK_PLONK_PROOF_BYTES];
-    int rc = zk_bn254_plonk_prove(h, d_sol, G.n_vars, 1, blinders, nullptr, proof);
-    if (pk_hex) (void)zk_bn254_plonk_pk_free(h);
-    ZK_TRY(rc);
+    ZK_TRY(zk_bn254_plonk_prove(h, L->d_sol, L->n_vars, 1, blinders, nullptr, proof));
+    ph.lap("export.plonk_prove");
     static const char dig[] = "0123456789abcdef";
     for (size_t i = 0; i < ZK_PLONK_PROOF_BYTES; i++) {
         proof_hex_out[2 * i] = dig[proof[i] >> 4];
@@ -408,130 +427,50 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
     return ZK_OK;
 }
 
+// The public inputs of a circuit as the verifier needs them: out[k] = 0-based index, into the witness-value vector, of public variable k (HandleValues'
+// first loop, common.go:45-60).  *n_public comes back even when cap is too small (ZK_ERR_ARG then).  Uses the resident lowering of the text when there is one.
+int zk_acir_public_witnesses(const char* acir_json, size_t acir_len, size_t n_values, int layout, uint32_t* out, size_t cap, size_t* n_public) {
+    if (!acir_json || !n_public) return set_err(ZK_ERR_ARG, "null pointer");
+    std::shared_ptr<Lowered> L;
+    ZK_TRY(lowered_get(acir_json, acir_len, n_values, layout, &L, nullptr));
+    *n_public = L->n_public;
+    if (L->n_public > cap || (L->n_public && !out)) return set_err(ZK_ERR_ARG, "%zu public inputs, the output holds %zu", L->n_public, cap);
+    if (L->n_public) memcpy(out, L->order_public.data(), L->n_public * 4);
+    return ZK_OK;
+}
+
 // buildR1CS of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:9-72, commented out there; payload RawR1CS of
-// src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60: {"gates":[{"mul_terms":[{"coefficient","multiplicand","multiplier"}],"add_terms":
-// [{"coefficient","sum"}],"constant_term"}],"public_inputs","values" (hex felt vector),"num_variables","num_constraints"}): every mul term gets an
-// internal product variable p with (1 * multiplicand) * (1 * multiplier) = 1 * p; every gate ends in
-// (1 * ONE) * (sum coefficient * p + sum coefficient * x + constant * ONE) = 0.  Made well-defined where the sketch is not: wires = [ONE, public
-// witnesses in witness order, the other witnesses, product variables]; values[w - 1] is witness w; the product variable is the plain product (the
-// sketch puts the coefficient on the product constraint's output AND on the term, which cancels it); the constant term IS in the sum (the sketch
-// drops it); a mul term with coefficient 0 emits nothing.  Out: a resident R1CS (zk_bn254_r1cs_*) and the full wire vector in HBM
-// (*d_witness: n_wires Montgomery elements, to be released with zk_dev_free) -- ready for zk_bn254_groth16_setup / _prove_r1cs(on_device = 1).
+// src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60) -- the text side is acir_host.hpp's raw_r1cs_build.  Out: a resident R1CS (zk_bn254_r1cs_*)
+// and the full wire vector in HBM (*d_witness: n_wires Montgomery elements, to be released with zk_dev_free) -- ready for zk_bn254_groth16_setup /
+// _prove_r1cs(on_device = 1).
 int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_handle, void** d_witness, size_t* n_wires, size_t* n_public) {
     if (!raw_json || !r1cs_handle || !d_witness) return set_err(ZK_ERR_ARG, "null pointer");
-    JParser P{raw_json, raw_json + len, ""};
-    JVal root;
-    if (!P.value(&root) || root.kind != JVal::OBJ) return set_err(ZK_ERR_ARG, "RawR1CS JSON: %s", P.err.empty() ? "not an object" : P.err.c_str());
-    const JVal *gates = root.get("gates"), *pubs = root.get("public_inputs"), *vals = root.get("values");
-    if (!gates || gates->kind != JVal::ARR || !vals || vals->kind != JVal::STR) return set_err(ZK_ERR_ARG, "RawR1CS JSON: gates / values missing");
-    // witness values: hex felt vector, decoded on the host here (they feed the host-side solver step for the product variables)
-    const std::string& vh = vals->str;
-    size_t n = 0;
-    ZK_TRY(count_from_hex(vh.data(), vh.size(), &n));
-    if (vh.size() != 8 + 64 * n) return set_err(ZK_ERR_LEN, "felt vector: %zu characters, the count says %zu felts", vh.size(), n);
-    std::vector<HFr> wv(1, HFr::one());
-    std::vector<bool> is_pub(n + 1, false);
-    if (pubs && pubs->kind == JVal::ARR)
-        for (auto& e : pubs->arr) {
-            uint32_t w;
-            if (!as_index(e, &w)) return set_err(ZK_ERR_ARG, "RawR1CS JSON: bad public input");
-            if (w >= 1 && w <= n) is_pub[w] = true;
-        }
-    std::vector<uint32_t> wire(n + 1, 0);
-    size_t npub = 1;
-    auto felt_at = [&](size_t w, HFr* out) -> bool {  // canonical values only, like fr.Vector.UnmarshalBinary
-        uint64_t t[4];
-        for (int i = 0; i < 4; i++) {
-            uint64_t v = 0;
-            for (int b = 0; b < 16; b++) {
-                int c = vh[8 + 64 * (w - 1) + 16 * (3 - i) + b], d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1;
-                if (d < 0) return false;
-                v = (v << 4) | (uint64_t)d;
-            }
-            t[i] = v;
-        }
-        if (HFr::geq_mod(t)) return false;
-        *out = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
-        return true;
-    };
-    for (int pass = 0; pass < 2; pass++)
-        for (size_t w = 1; w <= n; w++)
-            if (is_pub[w] == (pass == 0)) {
-                HFr v;
-                if (!felt_at(w, &v)) return set_err(ZK_ERR_ARG, "felt vector: invalid hex character or fr.Element encoding");
-                wire[w] = (uint32_t)wv.size();
-                wv.push_back(v);
-                if (pass == 0) npub++;
-            }
-    auto wire_of = [&](const JVal* v, uint32_t* out) -> bool {
-        uint32_t w;
-        if (!v || !as_index(*v, &w) || w < 1 || w > n) return false;
-        *out = wire[w];
-        return true;
-    };
-    std::vector<uint32_t> ptr[3], idx[3];
-    std::vector<HFr> val[3];
-    for (int m = 0; m < 3; m++) ptr[m].push_back(0);
-    auto end_row = [&]() { for (int m = 0; m < 3; m++) ptr[m].push_back((uint32_t)idx[m].size()); };
-    const HFr one = HFr::one();
-    for (auto& g : gates->arr) {
-        const JVal *mt = g.get("mul_terms"), *at = g.get("add_terms"), *kt = g.get("constant_term");
-        if (g.kind != JVal::OBJ || !mt || !at || !kt || mt->kind != JVal::ARR || at->kind != JVal::ARR || kt->kind != JVal::STR) return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed gate");
-        std::vector<std::pair<uint32_t, HFr>> terms;
-        auto add_term = [&](uint32_t x, const HFr& c) {
-            for (auto& t : terms)
-                if (t.first == x) { t.second = t.second + c; return; }
-            terms.emplace_back(x, c);
-        };
-        for (auto& t : mt->arr) {
-            const JVal* cj = t.get("coefficient");
-            HFr c;
-            uint32_t a, b;
-            if (t.kind != JVal::OBJ || !cj || cj->kind != JVal::STR || !felt_from_hex(cj->str, &c) || !wire_of(t.get("multiplicand"), &a) || !wire_of(t.get("multiplier"), &b))
-                return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed mul term");
-            if (c.is_zero()) continue;
-            const uint32_t p = (uint32_t)wv.size();
-            wv.push_back(wv[a] * wv[b]);  // the solver's step for this internal variable
-            idx[0].push_back(a); val[0].push_back(one);
-            idx[1].push_back(b); val[1].push_back(one);
-            idx[2].push_back(p); val[2].push_back(one);
-            end_row();
-            add_term(p, c);
-        }
-        for (auto& t : at->arr) {
-            const JVal* cj = t.get("coefficient");
-            HFr c;
-            uint32_t x;
-            if (t.kind != JVal::OBJ || !cj || cj->kind != JVal::STR || !felt_from_hex(cj->str, &c) || !wire_of(t.get("sum"), &x)) return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed add term");
-            add_term(x, c);
-        }
-        HFr k;
-        if (!felt_from_hex(kt->str, &k)) return set_err(ZK_ERR_ARG, "RawR1CS JSON: malformed constant term");
-        if (!k.is_zero()) add_term(0, k);
-        idx[0].push_back(0); val[0].push_back(one);
-        for (auto& t : terms) { idx[1].push_back(t.first); val[1].push_back(t.second); }
-        end_row();
+    RawR1CSBuilt B;
+    {
+        std::string err;
+        const int rc = raw_r1cs_build(raw_json, len, &B, &err);
+        if (rc != ZK_OK) return set_err(rc, "%s", err.c_str());
     }
     zk_r1cs r;
     memset(&r, 0, sizeof r);
-    r.n_constraints = ptr[0].size() - 1;
-    r.n_wires = wv.size();
-    r.n_public = npub;
-    r.l_ptr = ptr[0].data(); r.l_idx = idx[0].data(); r.l_val = (const zk_fr*)val[0].data();
-    r.r_ptr = ptr[1].data(); r.r_idx = idx[1].data(); r.r_val = (const zk_fr*)val[1].data();
-    r.o_ptr = ptr[2].data(); r.o_idx = idx[2].data(); r.o_val = (const zk_fr*)val[2].data();
+    r.n_constraints = B.ptr[0].size() - 1;
+    r.n_wires = B.wires.size();
+    r.n_public = B.n_public;
+    r.l_ptr = B.ptr[0].data(); r.l_idx = B.idx[0].data(); r.l_val = (const zk_fr*)B.val[0].data();
+    r.r_ptr = B.ptr[1].data(); r.r_idx = B.idx[1].data(); r.r_val = (const zk_fr*)B.val[1].data();
+    r.o_ptr = B.ptr[2].data(); r.o_idx = B.idx[2].data(); r.o_val = (const zk_fr*)B.val[2].data();
     ZK_TRY(zk_bn254_r1cs_load(&r, r1cs_handle));
     void* d = nullptr;
-    int rc = zk_dev_alloc(&d, wv.size() * 32);
-    if (rc == ZK_OK) rc = zk_dev_h2d(d, wv.data(), wv.size() * 32);
+    int rc = zk_dev_alloc(&d, B.wires.size() * 32);
+    if (rc == ZK_OK) rc = zk_dev_h2d(d, B.wires.data(), B.wires.size() * 32);
     if (rc != ZK_OK) {
         if (d) (void)zk_dev_free(d);
         (void)zk_bn254_r1cs_free(*r1cs_handle);
         return rc;
     }
     *d_witness = d;
-    if (n_wires) *n_wires = wv.size();
-    if (n_public) *n_public = npub;
+    if (n_wires) *n_wires = B.wires.size();
+    if (n_public) *n_public = B.n_public;
     return ZK_OK;
 }
 
@@ -633,7 +572,7 @@ int zk_acir_to_sparse_r1cs(const char* acir_json, size_t acir_len, size_t n_valu
                            zk_fr* qr, zk_fr* qo, zk_fr* qm, zk_fr* qk, uint32_t* xa, uint32_t* xb, uint32_t* xc, uint32_t* order) {
     if (!acir_json) return set_err(ZK_ERR_ARG, "null pointer");
     Gates G;
-    ZK_TRY(lower_acir(acir_json, acir_len, n_values, layout, &G));
+    ZK_TRY(lower(acir_json, acir_len, n_values, layout, true, &G));
     if (n_public) *n_public = G.n_public;
     if (n_vars) *n_vars = G.n_vars;
     if (n_constraints) *n_constraints = G.xa.size();

@@ -24,11 +24,14 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "zkmi.h"
+#include "text_host.hpp"
+#include "acir_host.hpp"
 
 extern "C" {
 struct GoString {
@@ -58,36 +61,28 @@ char* c_string(const std::string& s) {  // C.CString
     o[s.size()] = 0;
     return o;
 }
-// encodedValues reach PlonkPreprocess as a JSON string (main.go:66-72: "TODO: Fix this in the Rust backend side") and the other exports bare
-std::string unquote(GoString s) {
-    std::string v(s.p, (size_t)s.n);
-    if (v.size() >= 2 && v.front() == '"' && v.back() == '"') v = v.substr(1, v.size() - 2);
+// the text helpers (unquote, hex_to_bytes, felts_from_hex, be_to_mont) live in text_host.hpp with the other readers of untrusted bytes: host only,
+// sanitizer- and mutation-tested on the CPU (tests/cpp/parser_fuzz.cpp)
+using zkmi::be_to_mont;
+using zkmi::felts_from_hex;
+using zkmi::hex_to_bytes;
+struct View {  // a GoString's payload without its JSON quotes (main.go:66-72), borrowed for the call
+    const char* p;
+    size_t n;
+};
+View unquoted(GoString s) {
+    View v;
+    zkmi::unquote(s.p, (size_t)s.n, &v.p, &v.n);
     return v;
 }
-bool hex_to_bytes(const std::string& h, std::vector<uint8_t>* out) {
-    if (h.size() & 1) return false;
-    out->resize(h.size() / 2);
-    for (size_t i = 0; i < out->size(); i++) {
-        int v = 0;
-        for (int k = 0; k < 2; k++) {
-            const int c = h[2 * i + k], d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1;
-            if (d < 0) return false;
-            v = (v << 4) | d;
-        }
-        (*out)[i] = (uint8_t)v;
+struct Lap {  // wall-clock sections of the shim, reported beside the library's own when profiling is on (bench.py `export_path`)
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* name) {
+        const auto t1 = std::chrono::steady_clock::now();
+        (void)zk_profile_host(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
     }
-    return true;
-}
-// DeserializeFelts on the host for the handful of public inputs a verifier needs: u32 BE count | count x 32 B BE -> canonical big-endian elements
-bool felts_from_hex(const std::string& h, std::vector<std::vector<uint8_t>>* out) {
-    std::vector<uint8_t> b;
-    if (!hex_to_bytes(h, &b) || b.size() < 4) return false;
-    const size_t n = ((size_t)b[0] << 24) | ((size_t)b[1] << 16) | ((size_t)b[2] << 8) | b[3];
-    if (b.size() != 4 + 32 * n) return false;
-    out->clear();
-    for (size_t i = 0; i < n; i++) out->emplace_back(b.begin() + 4 + 32 * i, b.begin() + 36 + 32 * i);
-    return true;
-}
+};
 
 // ---- the SRS of backend/common.go:78-144, once per process
 struct Srs {
@@ -127,6 +122,7 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         const int lock_fd = open((path + ".lock").c_str(), O_CREAT | O_RDWR, 0644);
         if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
         struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); } } } unlock{lock_fd};
+        Lap lap;
         std::string text;
         if (FILE* f = fopen(path.c_str(), "rb")) {
             char buf[1 << 16];
@@ -139,7 +135,9 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         // ends the process and leaves the file (and every key issued against it) alone.
         if (is_hex_text(text)) {
             size_t n = 0;
+            lap.lap("export.srs_file_read");
             must(zk_bn254_kzg_srs_read(text.data(), text.size(), 1, 0, &g_srs.handle, &n, g_srs.g2), "LoadSRS");
+            lap.lap("export.srs_decode_and_tables");
         } else {
             uint64_t a[4];
             FILE* r = fopen("/dev/urandom", "rb");
@@ -157,6 +155,7 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
             must(zk_bn254_kzg_new_srs_dev(d, size, &alpha, g_srs.g2, nullptr), "NewSRS");
             must(zk_bn254_bases_register_dev(d, size, 0, &g_srs.handle), "NewSRS");
             (void)zk_dev_free(d);
+            lap.lap("export.srs_generate_and_tables");
             // SaveSRS: the whole text goes to a temporary file that is renamed over srs.hex, so that no reader ever sees half of it
             const size_t cap = 2 * (132 + 32 * size);
             std::string out(cap, '\0');
@@ -171,6 +170,7 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
                 saved = saved && rename(tmp.c_str(), path.c_str()) == 0;
                 if (!saved) (void)unlink(tmp.c_str());
             }  // like upstream (SaveSRS's error is dropped, common.go:141), a failure to save is not an error: the SRS is usable for this process
+            lap.lap("export.srs_save");
         }
         g_srs.ready = true;
     }
@@ -178,45 +178,11 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
     memcpy(g2, g_srs.g2, sizeof g_srs.g2);
 }
 
-// canonical big-endian 32-byte elements -> Montgomery images (through the library's felt decoder semantics: value < r required)
-bool to_mont(const std::vector<std::vector<uint8_t>>& be, std::vector<zk_fr>* out) {
-    // 2^256 mod r and the modulus, for a schoolbook Montgomery conversion on the host: x * R mod r by 256 doublings
-    static const uint64_t MOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-    auto geq = [](const uint64_t* t) {
-        for (int i = 3; i >= 0; i--)
-            if (t[i] != MOD[i]) return t[i] > MOD[i];
-        return true;
-    };
-    out->resize(be.size());
-    for (size_t k = 0; k < be.size(); k++) {
-        uint64_t t[4];
-        for (int i = 0; i < 4; i++) {
-            uint64_t v = 0;
-            for (int b = 0; b < 8; b++) v = (v << 8) | be[k][8 * (3 - i) + b];
-            t[i] = v;
-        }
-        if (geq(t)) return false;
-        for (int s = 0; s < 256; s++) {  // t <- 2 t mod r
-            const uint64_t top = t[3] >> 63;
-            for (int i = 3; i > 0; i--) t[i] = (t[i] << 1) | (t[i - 1] >> 63);
-            t[0] <<= 1;
-            if (top || geq(t)) {
-                unsigned __int128 bw = 0;
-                for (int i = 0; i < 4; i++) {
-                    unsigned __int128 d = (unsigned __int128)t[i] - MOD[i] - (uint64_t)bw;
-                    t[i] = (uint64_t)d;
-                    bw = (d >> 64) & 1;
-                }
-            }
-        }
-        memcpy(&(*out)[k], t, 32);
-    }
-    return true;
-}
-
-std::string plonk_prove(GoString acir, const std::string& values, const char* pk_hex, size_t pk_len, uint64_t pk_handle, uint64_t srs) {
-    std::string proof(2 * ZK_PLONK_PROOF_BYTES, '\0');
-    must(zk_plonk_prove_with_pk(acir.p, (size_t)acir.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, pk_hex, pk_len, pk_handle, srs, nullptr, &proof[0]), "PlonkProveWithPK");
+char* plonk_prove(GoString acir, View values, const char* pk_hex, size_t pk_len, uint64_t pk_handle, uint64_t srs) {
+    char* proof = (char*)malloc(2 * ZK_PLONK_PROOF_BYTES + 1);  // C.CString
+    if (!proof) fatal("out of memory");
+    must(zk_plonk_prove_with_pk(acir.p, (size_t)acir.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, pk_hex, pk_len, pk_handle, srs, nullptr, proof), "PlonkProveWithPK");
+    proof[2 * ZK_PLONK_PROOF_BYTES] = 0;
     return proof;
 }
 
@@ -228,33 +194,38 @@ char* PlonkProveWithPK(GoString acirJSON, GoString encodedValues, GoString encod
     uint64_t srs;
     zk_g2_affine g2[2];
     try_load_srs(&srs, g2);
-    return c_string(plonk_prove(acirJSON, unquote(encodedValues), encodedProvingKey.p, (size_t)encodedProvingKey.n, 0, srs));
+    return plonk_prove(acirJSON, unquoted(encodedValues), encodedProvingKey.p, (size_t)encodedProvingKey.n, 0, srs);
 }
 
 KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {
     uint64_t srs;
     zk_g2_affine g2[2];
     try_load_srs(&srs, g2);
-    const std::string values = unquote(encodedRandomValues);
+    const View values = unquoted(encodedRandomValues);
     size_t pk_len = 0, vk_len = 0;
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkPreprocess");
-    std::string pk(pk_len, '\0'), vk(vk_len, '\0');
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, &pk[0], pk.size(), &pk_len, &vk[0], vk.size(), &vk_len, nullptr), "PlonkPreprocess");
-    return KeyPair{c_string(pk), c_string(vk)};
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkPreprocess");
+    // the key text (0.33 GB at 2^19 gates) is written once, into the C.CString the caller receives
+    char* pk = (char*)malloc(pk_len + 1);
+    char* vk = (char*)malloc(vk_len + 1);
+    if (!pk || !vk) fatal("out of memory");
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, pk, pk_len, &pk_len, vk, vk_len, &vk_len, nullptr), "PlonkPreprocess");
+    pk[pk_len] = 0;
+    vk[vk_len] = 0;
+    return KeyPair{pk, vk};
 }
 
 char* PlonkProveWithMeta(GoString acirJSON, GoString encodedValues) {
     uint64_t srs, h = 0;
     zk_g2_affine g2[2];
     try_load_srs(&srs, g2);
-    const std::string values = unquote(encodedValues);
+    const View values = unquoted(encodedValues);
     size_t pk_len = 0, vk_len = 0;
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkProveWithMeta");
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkProveWithMeta");
     std::string pk(pk_len, '\0');
-    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.data(), values.size(), ZK_ACIR_LAYOUT_REFERENCE, srs, &pk[0], pk.size(), &pk_len, nullptr, 0, &vk_len, &h), "PlonkProveWithMeta");
-    const std::string proof = plonk_prove(acirJSON, values, nullptr, 0, h, srs);
+    must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, &pk[0], pk.size(), &pk_len, nullptr, 0, &vk_len, &h), "PlonkProveWithMeta");
+    char* proof = plonk_prove(acirJSON, values, nullptr, 0, h, srs);
     (void)zk_bn254_plonk_pk_free(h);
-    return c_string(proof);
+    return proof;
 }
 
 unsigned char PlonkVerifyWithMeta(GoString, GoString, GoString) { return 0; }  // main.go:40-42
@@ -264,19 +235,31 @@ unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoStri
     zk_g2_affine g2[2];
     try_load_srs(&srs, g2);
     std::vector<uint8_t> proof;
-    if (!hex_to_bytes(std::string(encodedProof.p, (size_t)encodedProof.n), &proof) || proof.size() != ZK_PLONK_PROOF_BYTES) { fprintf(stderr, "DeserializeProof: not the hex of a PLONK proof\n"); exit(1); }
+    if (!hex_to_bytes(encodedProof.p, (size_t)encodedProof.n, &proof) || proof.size() != ZK_PLONK_PROOF_BYTES) { fprintf(stderr, "DeserializeProof: not the hex of a PLONK proof\n"); exit(1); }
     // the values arrive indexed by witness (backend.rs:103: get_values_from_witness_tree over all of the circuit's variables); HandleValues keeps the
-    // public ones, in witness order (common.go:45-60) -- the first n_public entries of the lowering's variable order
-    std::vector<std::vector<uint8_t>> values;
-    if (!felts_from_hex(unquote(encodedPublicInputs), &values)) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }
-    size_t n_public = 0, n_vars = 0, n_cons = 0;
-    must(zk_acir_to_sparse_r1cs(acirJSON.p, (size_t)acirJSON.n, values.size(), ZK_ACIR_LAYOUT_REFERENCE, &n_public, &n_vars, &n_cons, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "BuildSparseR1CS");
-    std::vector<uint32_t> order(n_vars ? n_vars : 1);
-    must(zk_acir_to_sparse_r1cs(acirJSON.p, (size_t)acirJSON.n, values.size(), ZK_ACIR_LAYOUT_REFERENCE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, order.data()), "BuildSparseR1CS");
+    // public ones, in witness order (common.go:45-60).  Only those are decoded: the count comes from the vector's header, the positions from the
+    // lowering of the circuit (resident after the first call with this text)
+    const View vals = unquoted(encodedPublicInputs);
+    size_t n_values = 0;
+    if (!zkmi::count_from_hex(vals.p, vals.n, &n_values) || (vals.n - 8) / 64 != n_values || (vals.n - 8) % 64) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }
+    for (size_t i = 8; i < vals.n; i++)  // hex.DecodeString sees the whole text
+        if (zkmi::hexv((unsigned char)vals.p[i]) < 0) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }
+    size_t n_public = 0;
+    std::vector<uint32_t> where(16);
+    int qrc = zk_acir_public_witnesses(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE, where.data(), where.size(), &n_public);
+    if (qrc == ZK_ERR_ARG && n_public > where.size()) {
+        where.resize(n_public);
+        qrc = zk_acir_public_witnesses(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE, where.data(), where.size(), &n_public);
+    }
+    must(qrc, "BuildSparseR1CS");
     std::vector<std::vector<uint8_t>> pub_be;
-    for (size_t k = 0; k < n_public; k++) pub_be.push_back(values[order[k]]);
+    for (size_t k = 0; k < n_public; k++) {
+        std::vector<uint8_t> be;
+        if (!hex_to_bytes(vals.p + 8 + 64 * (size_t)where[k], 64, &be)) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }
+        pub_be.push_back(be);
+    }
     std::vector<zk_fr> pub;
-    if (!to_mont(pub_be, &pub)) { fprintf(stderr, "DeserializeFelts: invalid fr.Element encoding\n"); exit(1); }
+    if (!be_to_mont(pub_be, &pub)) { fprintf(stderr, "DeserializeFelts: invalid fr.Element encoding\n"); exit(1); }
     int ok = 0;
     const int rc = zk_bn254_plonk_verify(proof.data(), encodedVerifyingKey.p, (size_t)encodedVerifyingKey.n, 1, g2, pub.data(), pub.size(), &ok);
     if (rc == ZK_ERR_LEN) return 0;  // plonk.Verify's "invalid witness size" is an error value upstream, i.e. `false` (plonk.go:47-50)
@@ -308,7 +291,7 @@ KeyPair Preprocess(GoString rawR1CS) {
 unsigned char VerifyWithMeta(GoString, GoString) { return 0; }
 unsigned char VerifyWithVK(GoString rawR1CS, GoString encodedProof, GoString encodedVerifyingKey) {
     std::vector<uint8_t> proof;
-    if (!hex_to_bytes(std::string(encodedProof.p, (size_t)encodedProof.n), &proof) || proof.size() != 128) { fprintf(stderr, "DeserializeProof: not the hex of a Groth16 proof\n"); exit(1); }
+    if (!hex_to_bytes(encodedProof.p, (size_t)encodedProof.n, &proof) || proof.size() != 128) { fprintf(stderr, "DeserializeProof: not the hex of a Groth16 proof\n"); exit(1); }
     uint64_t r1cs = 0;
     void* d_w = nullptr;
     size_t n_wires = 0, n_public = 0;

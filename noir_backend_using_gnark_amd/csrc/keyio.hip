@@ -15,6 +15,7 @@
 #include "ctx.hpp"
 #include "ff.hpp"
 #include "keyio.hpp"
+#include "text_host.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
 #include "proofio.hpp"
@@ -420,9 +421,14 @@ extern "C" {
 // zk_bn254_bases_register_cfg); handle / n_g1 / the two G2 points come back.  This is what replaces LoadSRS (backend/common.go:86-105).
 int zk_bn254_kzg_srs_read(const void* data, size_t len, int is_hex, int table_window_bits, uint64_t* handle, size_t* n_g1, zk_g2_affine g2_out[2]) {
     if (!data || !handle) return set_err(ZK_ERR_ARG, "null pointer");
-    const size_t nbytes = is_hex ? len / 2 : len;
-    if ((is_hex && (len & 1)) || nbytes < 132) return set_err(ZK_ERR_LEN, "SRS: %zu bytes cannot hold the two G2 points and the count", nbytes);
-    if (nbytes & 3) return set_err(ZK_ERR_LEN, "SRS: %zu bytes, the count cannot match", nbytes);
+    SrsHeader H;  // the count and the total length are settled on the host, from the caller's bytes alone (text_host.hpp), before anything is sized by them
+    {
+        std::string e;
+        const int rc = kzg_srs_header(data, len, is_hex, &H, &e);
+        if (rc != ZK_OK) return set_err(rc, "%s", e.c_str());
+    }
+    const size_t nbytes = H.nbytes, n = H.n_g1;
+    const uint8_t* head = H.g2;
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     Slot* s = g.s;
@@ -438,11 +444,6 @@ int zk_bn254_kzg_srs_read(const void* data, size_t len, int is_hex, int table_wi
     } else {
         ZK_HIP(hipMemcpyAsync(d_bytes, data, nbytes, hipMemcpyHostToDevice, st));
     }
-    uint8_t head[132];
-    ZK_HIP(hipMemcpyAsync(head, d_bytes, 132, hipMemcpyDeviceToHost, st));
-    ZK_TRY(slot_sync(s, st));
-    const size_t n = ((size_t)head[128] << 24) | ((size_t)head[129] << 16) | ((size_t)head[130] << 8) | head[131];
-    if (nbytes != 132 + 32 * n) return set_err(ZK_ERR_LEN, "SRS: %zu bytes, the count says %zu G1 points (%zu bytes)", nbytes, n, 132 + 32 * n);
     Affine<HFp2> g2[2];
     for (int k = 0; k < 2; k++)
         if (!g2_decompress_host(head + 64 * k, &g2[k])) return set_err(ZK_ERR_ARG, "SRS: invalid G2 point %d", k);
@@ -511,39 +512,6 @@ int zk_bn254_kzg_srs_write(uint64_t handle, const zk_g2_affine g2[2], int as_hex
 //   | G2.B u32 count + 64 B per point | nbWires u64 | NbInfinityA u64 | NbInfinityB u64 | InfinityA, InfinityB: nbWires bytes (0 / 1) each, no prefix
 // A, B, G2.B are stored WITHOUT their points at infinity (that is what the bitmaps are for); the public-wire count is nbWires - len(K).
 namespace {
-struct Blob {  // the caller's buffer: bytes, or their hex text
-    const uint8_t* p;
-    size_t len;
-    bool hex;
-    size_t nbytes() const { return hex ? len / 2 : len; }
-    bool get(size_t off, size_t n, uint8_t* dst) const {
-        if (off > nbytes() || n > nbytes() - off) return false;
-        if (!hex) { memcpy(dst, p + off, n); return true; }
-        for (size_t i = 0; i < n; i++) {
-            int v = 0;
-            for (int k = 0; k < 2; k++) {
-                const int c = p[2 * (off + i) + k], d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1;
-                if (d < 0) return false;
-                v = (v << 4) | d;
-            }
-            dst[i] = (uint8_t)v;
-        }
-        return true;
-    }
-    bool u32(size_t off, size_t* v) const {
-        uint8_t b[4];
-        if (!get(off, 4, b)) return false;
-        *v = ((size_t)b[0] << 24) | ((size_t)b[1] << 16) | ((size_t)b[2] << 8) | b[3];
-        return true;
-    }
-    bool u64(size_t off, uint64_t* v) const {
-        uint8_t b[8];
-        if (!get(off, 8, b)) return false;
-        *v = 0;
-        for (int i = 0; i < 8; i++) *v = (*v << 8) | b[i];
-        return true;
-    }
-};
 void put_be(uint8_t* o, uint64_t v, int n) { for (int i = 0; i < n; i++) o[i] = (uint8_t)(v >> (8 * (n - 1 - i))); }
 void domain_bytes(const Domain* d, uint8_t o[168]) {
     put_be(o, (uint64_t)1 << d->logn, 8);
@@ -571,41 +539,20 @@ struct DevFree {
 int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags, int table_window_bits, uint64_t* handle) {
     if (!data || !handle) return set_err(ZK_ERR_ARG, "null pointer");
     if (flags & ~1) return set_err(ZK_ERR_ARG, "only flag bit 0 (no window tables) applies to a key read from its wire format");
-    if (is_hex && (len & 1)) return set_err(ZK_ERR_LEN, "proving key: odd number of hex characters");
-    const Blob B{(const uint8_t*)data, len, is_hex != 0};
-    const size_t nbytes = B.nbytes();
-    const char* trunc = "proving key: truncated or invalid hex in the header fields";
-    uint64_t card = 0;
-    if (!B.u64(0, &card)) return set_err(ZK_ERR_LEN, "%s", trunc);
-    unsigned logN = 0;
-    while (logN < 28 && ((uint64_t)1 << logN) < card) logN++;
-    if (card == 0 || ((uint64_t)1 << logN) != card) return set_err(ZK_ERR_ARG, "proving key: domain cardinality %llu is not a power of two <= 2^28", (unsigned long long)card);
-    // section offsets
-    size_t off = 168 + 96, cnt[5] = {0, 0, 0, 0, 0}, at[5] = {0, 0, 0, 0, 0};  // A, B, Z, K, G2.B
-    for (int k = 0; k < 4; k++) {
-        if (!B.u32(off, &cnt[k])) return set_err(ZK_ERR_LEN, "%s", trunc);
-        at[k] = off + 4;
-        if (cnt[k] > (nbytes - at[k]) / 32) return set_err(ZK_ERR_LEN, "proving key: %zu bytes cannot hold a slice of %zu G1 points", nbytes, cnt[k]);
-        off = at[k] + 32 * cnt[k];
+    Groth16KeyHeader H;  // the section table, the counts and the two bitmaps: read and cross-checked on the host from the caller's bytes alone (text_host.hpp)
+    {
+        std::string e;
+        const int rc = groth16_pk_header(data, len, is_hex, &H, &e);
+        if (rc != ZK_OK) return set_err(rc, "%s", e.c_str());
     }
-    const size_t at_g2 = off;
-    off += 128;
-    if (!B.u32(off, &cnt[4])) return set_err(ZK_ERR_LEN, "%s", trunc);
-    at[4] = off + 4;
-    if (cnt[4] > (nbytes - at[4]) / 64) return set_err(ZK_ERR_LEN, "proving key: %zu bytes cannot hold a slice of %zu G2 points", nbytes, cnt[4]);
-    off = at[4] + 64 * cnt[4];
-    uint64_t nw = 0, nia = 0, nib = 0;
-    if (!B.u64(off, &nw) || !B.u64(off + 8, &nia) || !B.u64(off + 16, &nib)) return set_err(ZK_ERR_LEN, "%s", trunc);
-    const size_t at_bm = off + 24;
-    if (nw >= ((uint64_t)1 << 31) || nbytes != at_bm + 2 * nw) return set_err(ZK_ERR_LEN, "proving key: %zu bytes, the fields say %llu wires (%zu bytes)", nbytes, (unsigned long long)nw, at_bm + 2 * (size_t)nw);
-    if (nia > nw || nib > nw || cnt[0] != nw - nia || cnt[1] != nw - nib || cnt[4] != nw - nib) return set_err(ZK_ERR_ARG, "proving key: the point counts do not match NbInfinityA / NbInfinityB");
-    if (cnt[2] != card || cnt[3] > nw) return set_err(ZK_ERR_ARG, "proving key: Z holds %zu points for a domain of %llu, K %zu for %llu wires", cnt[2], (unsigned long long)card, cnt[3], (unsigned long long)nw);
-    std::vector<uint8_t> ia(nw ? nw : 1), ib(nw ? nw : 1);
-    if (!B.get(at_bm, nw, ia.data()) || !B.get(at_bm + nw, nw, ib.data())) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
-    for (size_t i = 0; i < nw; i++)
-        if (ia[i] > 1 || ib[i] > 1) return set_err(ZK_ERR_ARG, "proving key: a bool that is neither 0 nor 1");
-    uint8_t dom_in[168], dom_ok[168];
-    if (!B.get(0, 168, dom_in)) return set_err(ZK_ERR_LEN, "%s", trunc);
+    const unsigned logN = H.logN;
+    const size_t* cnt = H.cnt;
+    const size_t* at = H.at;
+    const size_t at_g2 = H.at_g2, at_bm = H.at_bitmaps;
+    const uint64_t nw = H.n_wires, nia = H.nb_inf_a, nib = H.nb_inf_b;
+    const std::vector<uint8_t>&ia = H.inf_a, &ib = H.inf_b;
+    const uint8_t* dom_in = H.domain;
+    uint8_t dom_ok[168];
 
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -29,6 +30,7 @@
 #include "keyio.hpp"
 #include "ntt.hpp"
 #include "proofio.hpp"
+#include "text_host.hpp"
 
 namespace zkmi {
 
@@ -481,6 +483,7 @@ struct PlonkPK {
     Fr *w_big[5] = {}, *w_small = nullptr;
     std::shared_ptr<std::mutex> mu;
     std::vector<void*> allocs;
+    size_t bytes = 0;  // HBM held by the key
 };
 static std::mutex g_ppk_mu;
 static std::map<uint64_t, PlonkPK*> g_ppks;
@@ -492,6 +495,7 @@ static int pk_alloc(PlonkPK* P, Fr** out, size_t elems) {
     void* p = nullptr;
     ZK_HIP(hipMalloc(&p, (elems ? elems : 1) * sizeof(Fr)));
     P->allocs.push_back(p);
+    P->bytes += (elems ? elems : 1) * sizeof(Fr);
     *out = (Fr*)p;
     return ZK_OK;
 }
@@ -747,25 +751,16 @@ static int register_pk(PlonkPK* P, uint64_t* handle) {
     return ZK_OK;
 }
 
-// Key headers come from untrusted bytes (PlonkProveWithPK hands over whatever the caller sends): NbPublicVariables must fit the variables the
-// circuit has -- the prover reads that many elements of the solution -- and neither count may be large enough to wrap the sum below.
+// the count / domain rules live with the other readers of untrusted bytes (text_host.hpp: host only, sanitizer- and mutation-tested)
 static int check_counts(uint64_t n_public, size_t n_vars, size_t n_constraints) {
-    if (n_public > n_vars) return set_err(ZK_ERR_ARG, "proving key: %llu public inputs but %zu variables", (unsigned long long)n_public, n_vars);
-    if (n_public >= ((uint64_t)1 << 28) || n_constraints >= ((size_t)1 << 28)) return set_err(ZK_ERR_ARG, "proving key: %llu public inputs + %zu constraints exceed the Fr two-adicity 2^28", (unsigned long long)n_public, n_constraints);
-    return ZK_OK;
+    std::string e;
+    const int rc = plonk_check_counts(n_public, n_vars, n_constraints, &e);
+    return rc == ZK_OK ? ZK_OK : set_err(rc, "%s", e.c_str());
 }
-
 static int domains_for(size_t size_system, unsigned* logn, unsigned* logN4) {
-    if (size_system < 2) return set_err(ZK_ERR_ARG, "PLONK needs at least 2 rows (constraints + public inputs)");
-    unsigned ln = 0;
-    while (((size_t)1 << ln) < size_system) ln++;
-    size_t big = (size_system < 6 ? 8 : 4) * size_system;
-    unsigned lb = 0;
-    while (((size_t)1 << lb) < big) lb++;
-    if (lb > 28) return set_err(ZK_ERR_ARG, "PLONK big domain 2^%u exceeds the Fr two-adicity 2^28", lb);
-    *logn = ln;
-    *logN4 = lb;
-    return ZK_OK;
+    std::string e;
+    const int rc = plonk_domains_for(size_system, logn, logN4, &e);
+    return rc == ZK_OK ? ZK_OK : set_err(rc, "%s", e.c_str());
 }
 
 }  // namespace zkmi
@@ -936,45 +931,21 @@ int zk_bn254_plonk_pk_load(const zk_plonk_pk* k, uint64_t srs, uint64_t* handle)
 //   Domain[0], Domain[1]  Cardinality u64 | CardinalityInv | Generator | GeneratorInv | FrMultiplicativeGen | FrMultiplicativeGenInv      168 B each
 //   Ql Qr Qm Qo CQk LQk S1Canonical S2Canonical S3Canonical   each u32 BE length | n x 32 B BE
 //   Permutation           3n raw big-endian int64
-static const size_t PK_HEAD = 368 + 2 * 168;
-
-static int hexval(int c) { return (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; }
-// bytes [off, off + cnt) of a payload given as raw bytes or as hex text (host side: headers and length prefixes only)
-static int payload_bytes(const void* data, size_t len, int is_hex, size_t off, size_t cnt, uint8_t* out) {
-    const size_t nbytes = is_hex ? len / 2 : len;
-    if (off + cnt > nbytes) return set_err(ZK_ERR_LEN, "proving key: truncated (%zu bytes, %zu needed)", nbytes, off + cnt);
-    const uint8_t* p = (const uint8_t*)data;
-    for (size_t i = 0; i < cnt; i++) {
-        if (!is_hex) { out[i] = p[off + i]; continue; }
-        int h = hexval(p[2 * (off + i)]), l = hexval(p[2 * (off + i) + 1]);
-        if (h < 0 || l < 0) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
-        out[i] = (uint8_t)((h << 4) | l);
-    }
-    return ZK_OK;
-}
-static uint64_t be64(const uint8_t* p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }
+static const size_t PK_HEAD = PLONK_PK_HEAD;
 
 int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_vars, size_t n_constraints, const uint32_t* xa, const uint32_t* xb,
                            const uint32_t* xc, uint64_t srs, uint64_t* handle) {
     if (!data || !handle || (n_constraints && (!xa || !xb || !xc))) return set_err(ZK_ERR_ARG, "null pointer");
-    if (is_hex && (len & 1)) return set_err(ZK_ERR_LEN, "proving key: odd number of hex characters");
-    const size_t nbytes = is_hex ? len / 2 : len;
-    uint8_t head[PK_HEAD];
-    ZK_TRY(payload_bytes(data, len, is_hex, 0, PK_HEAD, head));
-    const uint64_t size = be64(head), npub = be64(head + 72), card0 = be64(head + 368), card1 = be64(head + 368 + 168);
-    unsigned logn, logN4;
-    ZK_TRY(check_counts(npub, n_vars, n_constraints));
-    ZK_TRY(domains_for(n_constraints + (size_t)npub, &logn, &logN4));
-    if (size != ((uint64_t)1 << logn) || card0 != size || card1 != ((uint64_t)1 << logN4))
-        return set_err(ZK_ERR_ARG, "proving key: domain sizes %llu / %llu / %llu do not match %zu constraints + %llu public inputs", (unsigned long long)size,
-                       (unsigned long long)card0, (unsigned long long)card1, n_constraints, (unsigned long long)npub);
-    const size_t n = (size_t)size;
-    if (nbytes != PK_HEAD + 9 * (4 + 32 * n) + 24 * n) return set_err(ZK_ERR_LEN, "proving key: %zu bytes, %zu expected for a domain of %zu", nbytes, PK_HEAD + 9 * (4 + 32 * n) + 24 * n, n);
-    for (int k = 0; k < 9; k++) {
-        uint8_t pre[4];
-        ZK_TRY(payload_bytes(data, len, is_hex, PK_HEAD + (size_t)k * (4 + 32 * n), 4, pre));
-        if ((((size_t)pre[0] << 24) | ((size_t)pre[1] << 16) | ((size_t)pre[2] << 8) | pre[3]) != n) return set_err(ZK_ERR_LEN, "proving key: vector %d does not hold %zu elements", k, n);
+    PlonkKeyHeader H;  // every size below comes out of this host-side reading of the header and the nine length prefixes (text_host.hpp)
+    {
+        std::string e;
+        const int rc = plonk_pk_header(data, len, is_hex, n_vars, n_constraints, &H, &e);
+        if (rc != ZK_OK) return set_err(rc, "%s", e.c_str());
     }
+    const size_t n = H.n, nbytes = H.nbytes;
+    const uint64_t npub = H.n_public;
+    const unsigned logn = H.logn, logN4 = H.logN4;
+    const auto t_start = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n_constraints; i++)
         if (xa[i] >= n_vars || xb[i] >= n_vars || xc[i] >= n_vars) return set_err(ZK_ERR_ARG, "gate %zu names a wire outside the %zu variables", i, n_vars);
     ZK_TRY(ensure_init());
@@ -993,7 +964,6 @@ int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_va
     ZK_HIP(hipMemsetAsync(d_status, 0, 4, st));
     uint8_t* d_bytes = (uint8_t*)s->alloc(nbytes + 16);
     if (is_hex) {
-        if (nbytes & 3) return set_err(ZK_ERR_LEN, "proving key: length is not a multiple of 4 bytes");
         void* d_text = s->alloc(len + 16);
         ZK_HIP(hipMemcpyAsync(d_text, data, len, hipMemcpyHostToDevice, st));
         ZK_TRY(hex_decode_dev(s, st, d_text, nbytes, d_bytes, d_status));
@@ -1033,8 +1003,11 @@ int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_va
         *wid[i] = (uint32_t*)tmp;
         if (n_constraints) ZK_HIP(hipMemcpyAsync(*wid[i], wsrc[i], n_constraints * 4, hipMemcpyHostToDevice, st));
     }
+    const auto t_decoded = std::chrono::steady_clock::now();
     ZK_TRY(make_sigma(P.get(), s, st, P->perm));
     ZK_TRY(finish_pk(P.get(), s, st));
+    prof_host("export.pk_text_to_device", std::chrono::duration<double, std::milli>(t_decoded - t_start).count());
+    prof_host("export.pk_coset_forms", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_decoded).count());
     return register_pk(P.release(), handle);
 }
 
@@ -1116,6 +1089,15 @@ int zk_bn254_plonk_pk_info(uint64_t handle, size_t* domain_size, size_t* n_publi
     if (n_public) *n_public = P->n_public;
     if (n_constraints) *n_constraints = P->n_constraints;
     if (n_vars) *n_vars = P->n_vars;
+    return ZK_OK;
+}
+
+int zk_bn254_plonk_pk_bytes(uint64_t handle, size_t* bytes) {
+    if (!bytes) return set_err(ZK_ERR_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(g_ppk_mu);
+    auto it = g_ppks.find(handle);
+    if (it == g_ppks.end()) return set_err(ZK_ERR_HANDLE, "unknown PLONK proving key %llu", (unsigned long long)handle);
+    *bytes = it->second->bytes;
     return ZK_OK;
 }
 

@@ -1,0 +1,179 @@
+// TEST INFRASTRUCTURE: deterministic mutation run over the host-side parsers of untrusted text (CPU only; built by tests/cpp/Makefile with
+// -fsanitize=address,undefined).  The reference ends the process cleanly on any parse failure (gnark_backend_ffi/main.go:26-30,46-50,61-72: every
+// error is a log.Fatal) -- here that means: every mutant is either accepted or rejected with a status code, never undefined behaviour, and the
+// streaming front end (csrc/acir_host.hpp) agrees with the document-tree reader it replaced (tests/cpp/json_dom_ref.hpp) on accept / reject, on
+// the status code and on every output word.
+//   parser_fuzz <cases> <seed file>...      seed files: *.acir.json (ACIR), *.raw.json (RawR1CS), *.felts.hex (felt vector), *.bin (key images)
+// Mutations: bit flips, byte overwrites from a dictionary of structural characters, deletions, insertions, truncations, slice duplications,
+// digit-run edits (length fields / indices), escapes spliced into strings.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../noir_backend_using_gnark_amd/csrc/acir_host.hpp"
+#include "../../noir_backend_using_gnark_amd/csrc/text_host.hpp"
+#include "json_dom_ref.hpp"
+
+static uint64_t g_state = 0x9e3779b97f4a7c15ULL;
+static uint64_t rnd() {  // SplitMix64
+    uint64_t z = (g_state += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static size_t below(size_t n) { return n ? (size_t)(rnd() % n) : 0; }
+
+static std::string mutate(const std::string& seed) {
+    static const char* dict[] = {"{", "}", "[", "]", "\"", ",", ":", "\\", "\\u0041", "\\\"", "0", "9", "-", ".", "e", "1e2", "4294967296", "4294967295", "null", "true",
+                                 "false", "Arithmetic", "Directive", "mul_terms", "linear_combinations", "q_c", "opcodes", "public_inputs", " ", "\n", "\f", "nan", "0x10",
+                                 "\"Arithmetic\":", "\"q_c\":\"01\",", "[[\"01\",1,2]]", "gates", "values", "coefficient", "sum", "multiplier", "multiplicand", "g", "ff"};
+    std::string s = seed;
+    const int rounds = 1 + (int)below(4);
+    for (int r = 0; r < rounds; r++) {
+        const size_t n = s.size();
+        switch (below(9)) {
+            case 0: if (n) s[below(n)] ^= (char)(1u << below(8)); break;
+            case 1: if (n) { const char* d = dict[below(sizeof dict / sizeof *dict)]; s.replace(below(n), below(3), d); } break;
+            case 2: if (n) s.erase(below(n), 1 + below(8)); break;
+            case 3: s.insert(below(n + 1), dict[below(sizeof dict / sizeof *dict)]); break;
+            case 4: if (n) s.resize(below(n)); break;
+            case 5: if (n) { const size_t a = below(n), l = 1 + below(n - a < 200 ? n - a : 200); s.insert(below(n + 1), s.substr(a, l)); } break;
+            case 6: {  // edit a run of digits (indices, counts)
+                size_t a = below(n + 1);
+                while (a < n && !(s[a] >= '0' && s[a] <= '9')) a++;
+                if (a < n) { size_t b = a; while (b < n && s[b] >= '0' && s[b] <= '9' && b - a < 12) b++; s.replace(a, b - a, std::to_string(rnd() >> below(64))); }
+                break;
+            }
+            case 7: if (n) { const size_t a = below(n); s.insert(a, std::string(1 + below(70), "[{"[below(2)])); } break;  // nesting
+            case 8: if (n) { const size_t a = below(n), b = below(n); std::swap(s[a], s[b]); } break;
+        }
+    }
+    return s;
+}
+
+static int failures = 0;
+#define CHECK(cond, ...)                                        \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            if (failures++ < 20) { fprintf(stderr, "MISMATCH: " __VA_ARGS__); fprintf(stderr, "\n"); } \
+        }                                                       \
+    } while (0)
+
+static bool same_frs(const std::vector<zkmi::HFr>& a, const std::vector<zkmi::HFr>& b) { return a.size() == b.size() && (a.empty() || !memcmp(a.data(), b.data(), a.size() * 32)); }
+
+static void check_acir(const std::string& text, size_t n_values, int layout, const char* what, size_t id) {
+    zkmi::Gates G, W;
+    std::string err, err2;
+    const int rc = zkmi::lower_acir(text.data(), text.size(), n_values, layout, true, &G, &err);
+    const int rcw = zkmi::lower_acir(text.data(), text.size(), n_values, layout, false, &W, &err2);
+    domref::Gates D;
+    const int rd = domref::lower_acir(text.data(), text.size(), n_values, layout, &D);
+    CHECK(rc == rd, "%s #%zu (n_values %zu, layout %d): streaming rc %d (%s) vs tree rc %d (%s)", what, id, n_values, layout, rc, err.c_str(), rd, domref::g_err.c_str());
+    CHECK(rc == rcw, "%s #%zu: rc with coefficients %d, wiring only %d", what, id, rc, rcw);
+    if (rc != ZK_OK || rd != ZK_OK) return;
+    CHECK(G.n_public == D.n_public && G.n_vars == D.n_vars, "%s #%zu: n_public / n_vars", what, id);
+    CHECK(G.xa == D.xa && G.xb == D.xb && G.xc == D.xc && G.order == D.order, "%s #%zu: wiring / order", what, id);
+    CHECK(same_frs(G.ql, D.ql) && same_frs(G.qr, D.qr) && same_frs(G.qo, D.qo) && same_frs(G.qm, D.qm) && same_frs(G.qk, D.qk), "%s #%zu: coefficients", what, id);
+    CHECK(W.xa == D.xa && W.xb == D.xb && W.xc == D.xc && W.order == D.order && W.n_public == D.n_public, "%s #%zu: wiring-only mode", what, id);
+}
+
+static void check_raw(const std::string& text, const char* what, size_t id) {
+    zkmi::RawR1CSBuilt B;
+    std::string err;
+    const int rc = zkmi::raw_r1cs_build(text.data(), text.size(), &B, &err);
+    domref::RawBuilt D;
+    const int rd = domref::raw_r1cs_build(text.data(), text.size(), &D);
+    CHECK(rc == rd, "%s #%zu: streaming rc %d (%s) vs tree rc %d (%s)", what, id, rc, err.c_str(), rd, domref::g_err.c_str());
+    if (rc != ZK_OK || rd != ZK_OK) return;
+    bool same = B.n_public == D.n_public && same_frs(B.wires, D.wires);
+    for (int m = 0; m < 3; m++) same = same && B.ptr[m] == D.ptr[m] && B.idx[m] == D.idx[m] && same_frs(B.val[m], D.val[m]);
+    CHECK(same, "%s #%zu: R1CS rows / wires differ", what, id);
+}
+
+// the shim's own text helpers (goffi.cpp) and the key / SRS header readers: no second implementation to compare with -- the sanitizers are the check,
+// plus the invariants a caller relies on (an accepted header's sizes are consistent with the length it was given)
+static void check_text(const std::string& text, size_t id) {
+    std::vector<uint8_t> bytes;
+    const bool ok = zkmi::hex_to_bytes(text.data(), text.size(), &bytes);
+    CHECK(!ok || bytes.size() * 2 == text.size(), "hex_to_bytes #%zu: length", id);
+    const char* u;
+    size_t un;
+    zkmi::unquote(text.data(), text.size(), &u, &un);
+    CHECK(un <= text.size(), "unquote #%zu", id);
+    std::vector<std::vector<uint8_t>> felts;
+    if (zkmi::felts_from_hex(u, un, &felts)) {
+        CHECK(un == 8 + 64 * felts.size(), "felts_from_hex #%zu: count", id);
+        std::vector<zk_fr> m;
+        (void)zkmi::be_to_mont(felts, &m);
+    }
+    size_t n = 0;
+    if (zkmi::count_from_hex(text.data(), text.size(), &n)) CHECK(text.size() >= 8, "count_from_hex #%zu", id);
+}
+static void check_key_headers(const std::string& img, size_t id) {
+    for (int is_hex = 0; is_hex < 2; is_hex++) {
+        zkmi::PlonkKeyHeader h;
+        std::string err;
+        for (size_t nc : {(size_t)0, (size_t)3, (size_t)1000}) {
+            const int rc = zkmi::plonk_pk_header(img.data(), img.size(), is_hex, nc + 5, nc, &h, &err);
+            if (rc == ZK_OK) {
+                const size_t nbytes = is_hex ? img.size() / 2 : img.size();
+                CHECK(nbytes == zkmi::PLONK_PK_HEAD + 9 * (4 + 32 * h.n) + 24 * h.n && h.n == ((size_t)1 << h.logn), "plonk header #%zu accepted with inconsistent sizes", id);
+            }
+        }
+        zkmi::SrsHeader sh;
+        if (zkmi::kzg_srs_header(img.data(), img.size(), is_hex, &sh, &err) == ZK_OK) {
+            const size_t nbytes = is_hex ? img.size() / 2 : img.size();
+            CHECK(nbytes == 4 + 32 * sh.n_g1 + 128, "SRS header #%zu accepted with inconsistent sizes", id);
+        }
+        zkmi::Groth16KeyHeader gh;
+        if (zkmi::groth16_pk_header(img.data(), img.size(), is_hex, &gh, &err) == ZK_OK) {
+            const size_t nbytes = is_hex ? img.size() / 2 : img.size();
+            CHECK(gh.total_bytes == nbytes, "Groth16 key header #%zu accepted with inconsistent sizes", id);
+        }
+    }
+}
+
+static bool ends_with(const std::string& s, const char* suf) { const size_t k = strlen(suf); return s.size() >= k && !s.compare(s.size() - k, k, suf); }
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: parser_fuzz <cases> <seed file>...\n"); return 2; }
+    const size_t cases = (size_t)strtoull(argv[1], nullptr, 10);
+    std::vector<std::pair<std::string, std::string>> seeds;
+    for (int i = 2; i < argc; i++) {
+        FILE* f = fopen(argv[i], "rb");
+        if (!f) { fprintf(stderr, "cannot read %s\n", argv[i]); return 2; }
+        std::string s;
+        char buf[1 << 16];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, k);
+        fclose(f);
+        seeds.emplace_back(argv[i], s);
+    }
+    size_t done = 0, accepted = 0;
+    const size_t nvals[] = {0, 1, 5, 6, 7, 300};
+    for (size_t c = 0; c < cases; c++) {
+        const auto& sd = seeds[c % seeds.size()];
+        const std::string m = c < seeds.size() ? sd.second : mutate(sd.second);  // the seeds themselves first
+        if (ends_with(sd.first, ".acir.json")) {
+            const size_t nv = nvals[below(sizeof nvals / sizeof *nvals)];
+            const int layout = (int)below(2);
+            check_acir(m, nv, layout, "ACIR", c);
+            zkmi::Gates G;
+            std::string e;
+            accepted += zkmi::lower_acir(m.data(), m.size(), nv, layout, false, &G, &e) == ZK_OK;
+        } else if (ends_with(sd.first, ".raw.json")) {
+            check_raw(m, "RawR1CS", c);
+        } else if (ends_with(sd.first, ".bin")) {
+            check_key_headers(m, c);
+        } else {
+            check_text(m, c);
+        }
+        done++;
+    }
+    printf("{\"cases\": %zu, \"accepted_acir\": %zu, \"mismatches\": %d}\n", done, accepted, failures);
+    return failures ? 1 : 0;
+}

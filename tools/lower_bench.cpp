@@ -1,0 +1,47 @@
+// Measurement tool (CPU only): the streaming ACIR front end (csrc/acir_host.hpp) against the document-tree reader it replaced (tests/cpp/json_dom_ref.hpp)
+// on one ACIR text.   g++ -O2 -std=c++17 tools/lower_bench.cpp -lpthread -o /tmp/lower_bench ; /tmp/lower_bench <acir.json> <n_values> [skip_tree]
+#include <chrono>
+#include <cstdio>
+#include <string>
+
+#include "../noir_backend_using_gnark_amd/csrc/acir_host.hpp"
+#include "../tests/cpp/json_dom_ref.hpp"
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    std::string text;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    char buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k);
+    fclose(f);
+    const size_t n_values = strtoull(argv[2], nullptr, 10);
+    double t0 = now_ms();
+    const zkmi::ContentKey ck = zkmi::content_key(text.data(), text.size());
+    double t_key = now_ms() - t0;
+    zkmi::Gates W, G;
+    std::string err;
+    t0 = now_ms();
+    int rc = zkmi::lower_acir(text.data(), text.size(), n_values, ZK_ACIR_LAYOUT_REFERENCE, false, &W, &err);
+    double t_wiring = now_ms() - t0;
+    t0 = now_ms();
+    int rc2 = zkmi::lower_acir(text.data(), text.size(), n_values, ZK_ACIR_LAYOUT_REFERENCE, true, &G, &err);
+    double t_full = now_ms() - t0;
+    double t_tree = -1;
+    bool same = true;
+    if (argc < 4) {
+        domref::Gates D;
+        t0 = now_ms();
+        int rd = domref::lower_acir(text.data(), text.size(), n_values, ZK_ACIR_LAYOUT_REFERENCE, &D);
+        t_tree = now_ms() - t0;
+        same = rd == rc2 && D.xa == G.xa && D.xb == G.xb && D.xc == G.xc && D.order == G.order && D.ql.size() == G.ql.size() &&
+               !memcmp(D.ql.data(), G.ql.data(), 32 * G.ql.size()) && !memcmp(D.qk.data(), G.qk.data(), 32 * G.qk.size()) && !memcmp(D.qm.data(), G.qm.data(), 32 * G.qm.size());
+    }
+    printf("{\"text_bytes\": %zu, \"gates\": %zu, \"n_vars\": %zu, \"n_public\": %zu, \"rc\": [%d, %d], \"content_key_ms\": %.2f, \"streaming_wiring_ms\": %.1f, "
+           "\"streaming_with_coefficients_ms\": %.1f, \"document_tree_ms\": %.1f, \"same_output\": %s, \"key\": \"%016llx%016llx\"}\n",
+           text.size(), G.xa.size(), G.n_vars, G.n_public, rc, rc2, t_key, t_wiring, t_full, t_tree, same ? "true" : "false", (unsigned long long)ck.h[0], (unsigned long long)ck.h[1]);
+    return same ? 0 : 1;
+}
