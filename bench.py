@@ -468,6 +468,69 @@ def srs_block(lib, n=1_000_000):
     return {"points": n, "read_ms": round(dt * 1e3, 2), "points_per_s": round(n / dt, 1), "bytes": len(raw), "write_of_read_is_identity": bool(ok)}
 
 
+def export_path_block(log_gates=19, warm_calls=10):
+    """The reference's live call end to end (gnark_backend_ffi/main.go:24-37,58-78; backend/plonk/plonk.go:13-73; backend/common.go:45-76,127-144) through
+    libgnark_backend.so's Go ABI: tools/export_bench.py in three child processes -- circuit text, PlonkPreprocess (fresh process), PlonkProveWithPK cold then
+    warm + PlonkVerifyWithVK (another fresh process) -- plus the text front end against the document-tree reader it replaced (tools/lower_bench.cpp)."""
+    import shutil
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="zkmi_export_")
+    exe = [sys.executable, os.path.join(ROOT, "tools", "export_bench.py")]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("ZKMI_EXPORT_SRS_SIZE", None)
+
+    def run(*a):
+        r = subprocess.run(exe + list(a), capture_output=True, text=True, timeout=900, env=env)
+        if r.returncode != 0:
+            raise RuntimeError("export_bench %s failed: %s" % (a[0], (r.stdout + r.stderr)[-1500:]))
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    try:
+        blk = {"workload": "synthetic ACIR, 2^%d - 8 arithmetic opcodes + 8 public inputs, reference variable layout, 1,000,000-point SRS (backend/common.go:137)" % log_gates,
+               "circuit": run("make", d, str(log_gates))}
+        blk["preprocess_process"] = run("preprocess", d)
+        blk["prove_process"] = run("prove", d, str(warm_calls))
+        pp = blk["prove_process"]
+        blk["warm_PlonkProveWithPK_ms"] = pp["warm_PlonkProveWithPK_ms"]
+        blk["zk_bn254_plonk_prove_ms"] = pp["zk_bn254_plonk_prove_ms"]
+        blk["warm_over_prove"] = pp["warm_over_prove"]
+        blk["ok"] = bool(pp["verifies"] == 1 and pp["warm_proof_verifies"] == 1 and pp["wrong_public_input_rejected"] == 1 and blk["preprocess_process"]["verifies"] == 1)
+        try:  # the text front end alone, on this box's cores: the streaming reader against the document-tree reader of rounds 1-3
+            lb = os.path.join(d, "lower_bench")
+            subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "lower_bench.cpp"), "-lpthread", "-o", lb], timeout=300)
+            r = subprocess.run([lb, os.path.join(d, "acir.json"), str(blk["circuit"]["witnesses"])], capture_output=True, text=True, timeout=600)
+            blk["acir_reader"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # no compiler on the box: the block stands without it
+            blk["acir_reader"] = {"skipped": str(e)[:200]}
+        return blk
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def go_toolchain_probe():
+    """is there a Go toolchain (and gnark's module cache) on this box?  If so tools/go_pin checks the committed fixtures against
+    the real gnark / gnark-crypto (go.mod:5,23) and the counts are reported; otherwise the oracle stays the checker ("parity unpinned")."""
+    import shutil
+    import subprocess
+    go = shutil.which("go")
+    out = {"go": go, "version": None, "module_cache": None, "go_pin": None}
+    if not go:
+        return out
+    try:
+        out["version"] = subprocess.run([go, "version"], capture_output=True, text=True, timeout=30).stdout.strip()
+        cache = subprocess.run([go, "env", "GOMODCACHE"], capture_output=True, text=True, timeout=30).stdout.strip()
+        have = os.path.isdir(os.path.join(cache, "github.com", "consensys")) if cache else False
+        out["module_cache"] = {"path": cache, "has_consensys_modules": have}
+        if have:
+            r = subprocess.run([go, "run", "."], cwd=os.path.join(ROOT, "tools", "go_pin"), capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, GOFLAGS="-mod=mod", GOPROXY="off"))
+            txt = r.stdout + r.stderr
+            out["go_pin"] = {"rc": r.returncode, "pass": txt.count("PASS"), "fail": txt.count("FAIL"), "tail": txt[-400:]}
+    except Exception as e:
+        out["error"] = str(e)[:200]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,6 +549,8 @@ def main():
     ap.add_argument("--plonk-log-n", type=int, default=22)
     ap.add_argument("--no-micro", action="store_true", help="skip the configs[4] block (2^26-point G1 MSM + 2^26 NTT) and the SRS-load block")
     ap.add_argument("--micro-log-n", type=int, default=26, help="log2 of the points of the sharded configs[4] block at N > 1 (total over all ranks)")
+    ap.add_argument("--no-export", action="store_true", help="skip the export-path block (PlonkPreprocess -> PlonkProveWithPK -> PlonkVerifyWithVK through libgnark_backend.so at 2^19 gates)")
+    ap.add_argument("--export-log-gates", type=int, default=19)
     ap.add_argument("--verify-2p24-oracle", action="store_true", help="also check the 2^24 proof bytes against the CPU oracle (~2 min on 128 cores)")
     args = ap.parse_args()
 
@@ -741,10 +806,24 @@ def main():
     if single and log_n == 20 and not args.no_micro:
         if inst is not None:
             inst.free()
+            inst = None
         out["micro_2p26"] = micro_block(L, _lib, zk, 26)
         out["srs_read_1e6"] = srs_block(_lib)
         if not (out["micro_2p26"]["equals_split_recombination"] and out["micro_2p26"]["equals_window_table_path"] and out["srs_read_1e6"]["write_of_read_is_identity"]):
             out["parity_error"] = "micro-benchmark cross-check failed"
+    # ---- the reference's live call end to end through libgnark_backend.so (child processes; the GPU is shared with this one, which is idle meanwhile)
+    if single and log_n == 20 and not args.no_export:
+        if inst is not None:
+            inst.free()
+            inst = None
+        try:
+            out["export_path"] = export_path_block(args.export_log_gates)
+            if not out["export_path"]["ok"]:
+                out["parity_error"] = "export path: a proof made through libgnark_backend.so does not verify"
+        except Exception as e:
+            out["export_path"] = {"error": str(e)[:600]}
+    if rank == 0:
+        out["go_toolchain"] = go_toolchain_probe()
     # ---- configs[4] on several GPUs: the 2^26-point MSM range-sharded and the 2^26-point FFT block-sharded over the ranks
     if (world > 1 or (args.force_sharded and par._force_collectives())) and not args.no_micro:
         inst.free()

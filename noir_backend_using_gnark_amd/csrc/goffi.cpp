@@ -124,10 +124,13 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); } } } unlock{lock_fd};
         Lap lap;
         std::string text;
-        if (FILE* f = fopen(path.c_str(), "rb")) {
-            char buf[1 << 16];
-            size_t k;
-            while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k);
+        if (FILE* f = fopen(path.c_str(), "rb")) {  // 64 MB of text for the reference's 1,000,000 points: sized once, read in one piece
+            struct stat sb;
+            if (fstat(fileno(f), &sb) == 0 && sb.st_size > 0) {
+                text.resize((size_t)sb.st_size);
+                const size_t got = fread(&text[0], 1, text.size(), f);
+                text.resize(got);
+            }
             fclose(f);
         }
         // LoadSRS fails -- and TryLoadSRS generates a new SRS -- exactly when the file cannot be read or is not hex (common.go:92-99, 129-141); it ignores what
@@ -242,8 +245,7 @@ unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoStri
     const View vals = unquoted(encodedPublicInputs);
     size_t n_values = 0;
     if (!zkmi::count_from_hex(vals.p, vals.n, &n_values) || (vals.n - 8) / 64 != n_values || (vals.n - 8) % 64) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }
-    for (size_t i = 8; i < vals.n; i++)  // hex.DecodeString sees the whole text
-        if (zkmi::hexv((unsigned char)vals.p[i]) < 0) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }
+    if (!zkmi::all_hex(vals.p + 8, vals.n - 8)) { fprintf(stderr, "DeserializeFelts: invalid felt vector\n"); exit(1); }  // hex.DecodeString sees the whole text
     size_t n_public = 0;
     std::vector<uint32_t> where(16);
     int qrc = zk_acir_public_witnesses(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE, where.data(), where.size(), &n_public);

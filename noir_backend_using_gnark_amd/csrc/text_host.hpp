@@ -66,6 +66,20 @@ static inline void unquote(const char* p, size_t n, const char** out, size_t* ou
     *out = p;
     *out_n = n;
 }
+// is every character one hex.DecodeString accepts?  (the witness vector of a 2^19-gate circuit is 33 MB of text: a table and no early exit per character)
+static inline bool all_hex(const char* p, size_t n) {
+    static const struct Tab {
+        uint8_t bad[256];
+        Tab() { for (int c = 0; c < 256; c++) bad[c] = hexv(c) < 0; }
+    } T;
+    unsigned acc = 0;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        acc |= T.bad[(uint8_t)p[i]] | T.bad[(uint8_t)p[i + 1]] | T.bad[(uint8_t)p[i + 2]] | T.bad[(uint8_t)p[i + 3]] | T.bad[(uint8_t)p[i + 4]] | T.bad[(uint8_t)p[i + 5]] |
+               T.bad[(uint8_t)p[i + 6]] | T.bad[(uint8_t)p[i + 7]];
+    for (; i < n; i++) acc |= T.bad[(uint8_t)p[i]];
+    return acc == 0;
+}
 static inline bool hex_to_bytes(const char* h, size_t n, std::vector<uint8_t>* out) {
     if (n & 1) return false;
     out->resize(n / 2);

@@ -100,6 +100,7 @@ static void check_text(const std::string& text, size_t id) {
     std::vector<uint8_t> bytes;
     const bool ok = zkmi::hex_to_bytes(text.data(), text.size(), &bytes);
     CHECK(!ok || bytes.size() * 2 == text.size(), "hex_to_bytes #%zu: length", id);
+    CHECK((text.size() & 1) || ok == zkmi::all_hex(text.data(), text.size()), "all_hex #%zu disagrees with hex_to_bytes", id);
     const char* u;
     size_t un;
     zkmi::unquote(text.data(), text.size(), &u, &un);

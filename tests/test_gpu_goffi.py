@@ -167,3 +167,33 @@ def test_errors_end_the_process_like_log_fatal(tmp_path):
     e = json.load(open(os.path.join(HERE, "golden", "plonk_golden.json")))[0]
     out = run_worker(tmp_path, dict(what="fatal", acir=json.dumps(e["acir"]), values=ref.felts_wire([h2i(v) for v in e["values"]]).hex()), "fatal", expect_fail=True)
     assert out.returncode == 1 and "PlonkProveWithPK" in out.stderr
+
+
+def test_export_path_worker_cold_and_warm_calls_at_2p10(tmp_path):
+    """tools/export_bench.py (the worker of bench.py's `export_path` block) at 2^10 - 8 opcodes + 8 public inputs: PlonkPreprocess in one process,
+    PlonkProveWithPK cold + warm and PlonkVerifyWithVK in another, both through Go's ABI.  The key text equals the oracle's Setup under the SRS the first
+    process wrote; the cold and the warm proofs verify; another public input is rejected; one circuit and one key stay resident."""
+    exe = [sys.executable, os.path.join(ROOT, "tools", "export_bench.py")]
+    env = dict(os.environ, PYTHONPATH=ROOT, ZKMI_EXPORT_SRS_SIZE="2048")
+    d = str(tmp_path)
+    run = lambda *a: json.loads(subprocess.run(exe + list(a), capture_output=True, text=True, timeout=900, env=env, check=True).stdout.strip().splitlines()[-1])
+    made = run("make", d, "10")
+    assert made["opcodes"] == 1016 and made["witnesses"] == 1018
+    pre = run("preprocess", d)
+    assert pre["verifies"] == 1 and "acir_parse_lower_with_coefficients" in pre["phases"] and "plonk_setup" in pre["phases"]
+    assert "pk_text_to_device" not in pre["phases_prove_after_preprocess"]      # the key Preprocess made is resident under the text it returned
+    pr = run("prove", d, "3")
+    assert pr["verifies"] == 1 and pr["warm_proof_verifies"] == 1 and pr["wrong_public_input_rejected"] == 1
+    assert pr["resident"]["circuits"] == 1 and pr["resident"]["keys"] == 1
+    for k in ("hip_init", "srs_file_read", "srs_decode_and_tables", "acir_parse_lower", "pk_text_to_device", "pk_coset_forms", "values_decode", "witness_gather", "plonk_prove"):
+        assert k in pr["cold_phases"], k
+    assert "acir_parse_lower" not in pr["warm_phases_per_call"] and "pk_text_to_device" not in pr["warm_phases_per_call"]
+    # the oracle's Setup under the same SRS gives the same key text
+    srs = pl.kzg_srs_from_bytes(bytes.fromhex(open(os.path.join(d, "cfg", "noir-lang", "srs.hex")).read()))
+    acir = json.load(open(os.path.join(d, "acir.json")))
+    vh = open(os.path.join(d, "values.hex")).read()
+    values = [int(vh[8 + 64 * i:72 + 64 * i], 16) for i in range(int(vh[:8], 16))]
+    spr, sol = pl.sparse_r1cs_from_acir(acir, values)
+    assert spr.is_satisfied(sol) and spr.n_public == 8 and spr.n_vars == 8 * len(values)
+    opk, ovk = pl.plonk_setup(spr, srs, fast=True)
+    assert pl.plonk_pk_bytes(opk).hex() == open(os.path.join(d, "pk.hex")).read()

@@ -322,6 +322,66 @@ def test_plonk_preprocess_and_prove_with_pk_on_the_reference_fixtures(plonk_gold
         srs.free()
 
 
+def test_export_cache_keeps_circuit_and_key_resident_and_changes_no_byte(plonk_golden):
+    """The content-keyed caches behind zk_plonk_prove_with_pk (SURVEY §5 "device-resident bases cache keyed by pk hash"; the reference re-reads both texts
+    per call, main.go:24-37 -> backend/plonk/plonk.go:53-73): the first call with a (circuit text, key text) pair decodes and stays resident, every later
+    call finds both by content and gives the SAME bytes (pinned blinders: the golden proof); a key text that differs in one coefficient is another key
+    (the proof is another proof and is NOT the golden one), another spelling of the same circuit (whitespace) is another circuit entry; clearing empties it;
+    zk_acir_public_witnesses answers from the resident lowering."""
+    import json as js
+    from noir_backend_using_gnark_amd import frontend as fe, kzg
+    L = _lib.lib()
+    info = lambda: tuple(int(v.value) for v in _info())
+
+    def _info():
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        _lib.check(L.zk_export_cache_info(C.byref(a), C.byref(b), C.byref(c)))
+        return a, b, c
+    _lib.check(L.zk_export_cache_clear())
+    assert info()[:2] == (0, 0)
+    e = plonk_golden[1]
+    acir = js.dumps(e["acir"])
+    values = [h2i(v) for v in e["values"]]
+    enc = ref.felts_wire(values).hex()
+    srs = kzg.new_srs(e["srs_size"], M([h2i(e["srs_alpha"])])[0])
+    bl = M([h2i(v) for v in e["blinders"]])
+    pk_hex, vk_hex = fe.plonk_preprocess(acir, enc, srs)          # no handle asked for: the fresh key enters the cache under its text
+    assert pk_hex == e["pk_hex"] and info()[:2] == (1, 1)
+    for _ in range(3):
+        assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"]
+    assert info()[:2] == (1, 1) and info()[2] > 0
+    # the digests of Ql and Qr swapped in the key's verifying-key part (two valid points; the transcript binds them): same length, another content key,
+    # another key -> another proof
+    a0, a1, a2 = 2 * (112 + 96), 2 * (112 + 128), 2 * (112 + 160)
+    other = pk_hex[:a0] + pk_hex[a1:a2] + pk_hex[a0:a1] + pk_hex[a2:]
+    assert other != pk_hex and len(other) == len(pk_hex)
+    p_other = fe.plonk_prove_with_pk(acir, enc, other, srs, blinders=bl)
+    assert p_other != e["proof"] and info()[:2] == (1, 2)
+    assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"]      # the first key is still itself
+    assert fe.plonk_prove_with_pk(acir, enc, other, srs, blinders=bl) == p_other
+    # the same circuit spelt without spaces: another text, another entry, the same proof
+    compact = js.dumps(e["acir"], separators=(",", ":"))
+    assert fe.plonk_prove_with_pk(compact, enc, pk_hex, srs, blinders=bl) == e["proof"] and info()[:2] == (2, 3)
+    # the verifier's question, answered from the resident lowering
+    out, npub = np.zeros(8, np.uint32), C.c_size_t(0)
+    a = acir.encode()
+    _lib.check(L.zk_acir_public_witnesses(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(len(values)), C.c_int(0), _lib.vp(out), C.c_size_t(8), C.byref(npub)))
+    assert [int(x) + 1 for x in out[:npub.value]] == sorted(e["acir"]["public_inputs"])
+    assert L.zk_acir_public_witnesses(C.c_char_p(a), C.c_size_t(len(a)), C.c_size_t(len(values)), C.c_int(0), None, C.c_size_t(0), C.byref(npub)) == (_lib.ZK_ERR_ARG if npub.value else _lib.ZK_OK)
+    # a witness that violates the circuit is still refused with the resident key; a key of another circuit is refused, not mis-indexed
+    bad = list(values)
+    bad[4] = (bad[4] + 1) % R
+    with pytest.raises((ValueError, _lib.ZkmiError)):
+        fe.plonk_prove_with_pk(acir, ref.felts_wire(bad).hex(), pk_hex, srs, blinders=bl)
+    with pytest.raises((ValueError, _lib.ZkmiError)):
+        fe.plonk_prove_with_pk(js.dumps(plonk_golden[2]["acir"]), enc, pk_hex, srs, blinders=bl)
+    _lib.check(L.zk_export_cache_clear())
+    assert info() == (0, 0, 0)
+    assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"] and info()[:2] == (1, 1)   # cold again, same bytes
+    _lib.check(L.zk_export_cache_clear())
+    srs.free()
+
+
 def test_plonk_exports_reproduce_handle_values_for_two_and_three_public_inputs():
     """The reference's variable layout with SEVERAL public inputs (backend/common.go:45-76: one secret variable per (witness, non-matching public input),
     gates on the last copy): key, verifying key and proof bytes of zk_plonk_preprocess / zk_plonk_prove_with_pk equal the oracle's literal restatement
