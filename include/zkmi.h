@@ -59,7 +59,8 @@ typedef struct {
                           (gnark v0.8.0 calls FromMont() on the wire values / h and passes the default config)         */
     int window_bits;   /* 0 = auto (cost model for the GPU), else c in [2, 22]; against registered bases with window
                           tables an explicit value selects the plain (table-less) method                              */
-    int reserved;
+    int device_mask;   /* several GPUs in ONE process (zk_init_devices): bit i = device entry i takes part; 0 = the process default
+                          (zk_set_default_devices; every entry once zk_init_devices was called, else the calling thread's entry)  */
 } zk_msm_cfg;
 
 enum { ZK_DIT = 0, ZK_DIF = 1 }; /* fft.Decimation (same iota order as gnark-crypto) */
@@ -67,6 +68,18 @@ enum { ZK_DIT = 0, ZK_DIF = 1 }; /* fft.Decimation (same iota order as gnark-cry
 /* ---- lifecycle ------------------------------------------------------------------------------------------------ */
 int zk_device_count(void);             /* number of visible HIP devices (0 if none / runtime missing)             */
 int zk_init(int device);               /* optional: bind the calling process to `device` (default: 0, lazily)     */
+/* Several GPUs in ONE process (the reference is one process: nargo -> Rust -> cgo; gnark_backend_ffi/main.go:24-37).  zk_init_devices gives the process
+ * its device list: one ENTRY per listed HIP device, in order (devices == NULL or n == 0: every visible device); a device may be listed several times
+ * (each listing is an entry with streams and workspaces of its own: "virtual devices").  From then on the calls that carry a device_mask -- and, through
+ * the process default, those that do not (zk_bn254_ntt on host slices, zk_bn254_bases_register*) -- spread over the entries: MSMs by point range, a
+ * resident Groth16 key by wire range with computeH block-sharded, transforms by blocks; results are the single-GPU bytes.  Resident objects carry their
+ * entry in their handle, so every call on a handle runs on that handle's GPU whatever thread makes it; zk_set_entry picks the entry for the calls of the
+ * calling THREAD that take no handle (zk_dev_alloc, zk_bn254_ntt_dev, ...).  Calling zk_init_devices again may only extend the list. */
+int zk_init_devices(const int *devices, size_t n);
+int zk_device_entries(int *devices_out, size_t cap); /* number of entries; devices_out[i] = HIP device of entry i */
+int zk_set_entry(int entry);
+int zk_set_default_devices(uint32_t mask);
+uint32_t zk_default_devices(void);
 const char *zk_last_error(void);
 const char *zk_version(void);
 
@@ -107,6 +120,9 @@ int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars
  * natural out.  coset != 0 evaluates on / interpolates from the coset g*H, g = 5 (FrMultiplicativeGen).
  * FFTInverse also scales by 1/N exactly like upstream. */
 int zk_bn254_ntt(zk_fr *a, uint32_t log_n, int inverse, int decimation, int coset);
+/* the same over several device entries of this process (bit i of device_mask = entry i; 2, 4 or 8 entries): block k of the array goes to entry k over that
+ * GPU's own PCIe link, the transform runs block-sharded with two all-to-all transposes between the GPUs.  zk_bn254_ntt == device_mask 0 (process default). */
+int zk_bn254_ntt_devices(zk_fr *a, uint32_t log_n, int inverse, int decimation, int coset, uint32_t device_mask);
 int zk_bn254_ntt_dev(void *d_a, uint32_t log_n, int inverse, int decimation, int coset, void *stream);
 int zk_bn254_bit_reverse(zk_fr *a, uint32_t log_n);
 int zk_bn254_bit_reverse_dev(void *d_a, uint32_t log_n, void *stream);
@@ -177,7 +193,9 @@ typedef struct {
     const uint8_t *infinity_a, *infinity_b; /* gnark's InfinityA / InfinityB ([]bool, HOST pointers, n_wires bytes) or NULL */
     size_t nb_infinity_a, nb_infinity_b;    /* gnark's NbInfinityA / NbInfinityB; must equal the number of non-zero bytes */
     int table_window_bits;                  /* 0: planner's choice; else the window width c in [8, 22] of the tables */
-    int reserved;
+    int device_mask;                        /* several GPUs in ONE process: bit i = device entry i holds a range slice of the key (2, 4 or 8 entries);
+                                               0 = the process default.  zk_bn254_groth16_prove on such a key runs computeH block-sharded over the
+                                               entries and the five MSMs per slice; same proof bytes. */
     uint32_t shard_rank, shard_count;       /* flags bit 2: this rank and the number of ranks (window sharding) */
 } zk_groth16_pk;
 int zk_bn254_groth16_pk_load(const zk_groth16_pk *pk, uint64_t *handle);

@@ -22,7 +22,7 @@ class ZkmiError(RuntimeError):
 
 
 class MsmCfg(C.Structure):
-    _fields_ = [("nb_tasks", C.c_int), ("scalars_mont", C.c_int), ("window_bits", C.c_int), ("reserved", C.c_int)]
+    _fields_ = [("nb_tasks", C.c_int), ("scalars_mont", C.c_int), ("window_bits", C.c_int), ("device_mask", C.c_int)]
 
 
 class Groth16PK(C.Structure):
@@ -31,7 +31,7 @@ class Groth16PK(C.Structure):
                 ("g1_a", C.c_void_p), ("g1_b", C.c_void_p), ("g1_k", C.c_void_p), ("g1_z", C.c_void_p),
                 ("g2_beta", C.c_void_p), ("g2_delta", C.c_void_p), ("g2_b", C.c_void_p), ("bases_on_device", C.c_int), ("flags", C.c_int),
                 ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p), ("nb_infinity_a", C.c_size_t), ("nb_infinity_b", C.c_size_t),
-                ("table_window_bits", C.c_int), ("reserved", C.c_int), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32)]
+                ("table_window_bits", C.c_int), ("device_mask", C.c_int), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
 class R1CS(C.Structure):
@@ -78,6 +78,7 @@ SYMBOLS = [
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev", "zk_bn254_kzg_new_srs_dev", "zk_bn254_kzg_srs_read", "zk_bn254_kzg_srs_write",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_profile_host", "zk_selftest_host",
+    "zk_init_devices", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
     "zk_acir_public_witnesses", "zk_export_cache_info", "zk_export_cache_clear", "zk_bn254_plonk_pk_bytes",
 ]
 

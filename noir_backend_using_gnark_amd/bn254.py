@@ -30,9 +30,10 @@ class MultiExpConfig:
     nb_tasks: int = 0          # upstream NbTasks; > 1024 is an error like upstream, otherwise ignored on the GPU
     scalars_mont: bool = False  # upstream's zero value: scalars in regular form (gnark v0.8.0 calls FromMont() before MultiExp); True = Montgomery images
     window_bits: int = 0       # 0 = auto
+    device_mask: int = 0       # several GPUs in one process (zk_init_devices): bit i = device entry i; 0 = the process default
 
     def _c(self) -> MsmCfg:
-        return MsmCfg(self.nb_tasks, 1 if self.scalars_mont else 0, self.window_bits, 0)
+        return MsmCfg(self.nb_tasks, 1 if self.scalars_mont else 0, self.window_bits, self.device_mask)
 
 
 def _as_u64(a, width) -> np.ndarray:

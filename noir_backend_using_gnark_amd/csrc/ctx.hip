@@ -2,11 +2,13 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "multidev.hpp"
 
 #include <string.h>
 
 #include <stdlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -24,35 +26,96 @@ int set_err(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- the device list.  Entries are created once and never move (contexts are referenced from slots in flight); g_n_entries only grows.
+static Ctx* g_entries[MAX_ENTRIES];
+static std::atomic<int> g_n_entries{0};
+static std::mutex g_entries_mu;
+static thread_local int t_entry = 0;
+
+Prof& prof() {
+    static Prof p;
+    return p;
+}
+int n_entries() { return g_n_entries.load(std::memory_order_acquire); }
+int current_entry() { return t_entry; }
 Ctx& ctx() {
-    static Ctx c;
-    return c;
+    const int n = n_entries();
+    if (t_entry < n) return *g_entries[t_entry];
+    static Ctx unbound;  // before any device was named: not ready, device 0 (ensure_init creates entry 0)
+    return unbound;
 }
 
-static int init_locked(int device) {
-    Ctx& c = ctx();
+static int init_entry(Ctx& c) {  // under c.mu
     if (c.ready) return ZK_OK;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0)
-        return set_err(ZK_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount: %s); libzkmi has no CPU fallback",
-                       e == hipSuccess ? "0 devices" : hipGetErrorString(e));
-    if (device < 0 || device >= n) return set_err(ZK_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
-    ZK_HIP(hipSetDevice(device));
+    ZK_HIP(hipSetDevice(c.device));
     hipDeviceProp_t prop;
-    ZK_HIP(hipGetDeviceProperties(&prop, device));
-    c.device = device;
+    ZK_HIP(hipGetDeviceProperties(&prop, c.device));
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    {
-        int lo = 0, hi = 0;  // numerically lower = higher priority
-        ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        for (int i = 0; i < Ctx::NSLOTS; i++) {
-            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
-            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi, hipStreamNonBlocking, hi));
-        }
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    for (int i = 0; i < Ctx::NSLOTS; i++) {
+        c.slots[i].owner = &c;
+        ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
+        ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi, hipStreamNonBlocking, hi));
     }
     c.ready = true;
     return ZK_OK;
+}
+
+int init_devices(const int* devices, int n) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_err(ZK_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount: %s); libzkmi has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    std::vector<int> all;
+    if (n <= 0 || !devices) {
+        for (int d = 0; d < count; d++) all.push_back(d);
+        devices = all.data();
+        n = count;
+    }
+    if (n > MAX_ENTRIES) return set_err(ZK_ERR_ARG, "%d device entries, at most %d", n, MAX_ENTRIES);
+    for (int i = 0; i < n; i++)
+        if (devices[i] < 0 || devices[i] >= count) return set_err(ZK_ERR_ARG, "device %d out of range (0..%d)", devices[i], count - 1);
+    std::lock_guard<std::mutex> lk(g_entries_mu);
+    const int have = n_entries();
+    for (int i = 0; i < have && i < n; i++)
+        if (g_entries[i]->device != devices[i]) return set_err(ZK_ERR_ARG, "entry %d is already bound to device %d", i, g_entries[i]->device);
+    for (int i = have; i < n; i++) {
+        Ctx* c = new Ctx();
+        c->entry = i;
+        c->device = devices[i];
+        g_entries[i] = c;
+        g_n_entries.store(i + 1, std::memory_order_release);
+    }
+    // peers see each other's memory where the hardware allows it (xGMI); a refusal only means copies are staged by the runtime
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            if (devices[i] != devices[j]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                    (void)hipSetDevice(devices[i]);
+                    (void)hipDeviceEnablePeerAccess(devices[j], 0);
+                    (void)hipGetLastError();  // "already enabled" is not an error worth keeping
+                }
+            }
+    (void)hipSetDevice(g_entries[t_entry < n_entries() ? t_entry : 0]->device);
+    return ZK_OK;
+}
+
+CtxScope::CtxScope(int entry) : prev(t_entry) {
+    if (entry < 0 || entry >= n_entries()) {
+        if (entry == 0) { rc = ensure_init(); return; }  // handles made before any explicit list: entry 0
+        rc = set_err(ZK_ERR_HANDLE, "device entry %d does not exist (%d entries)", entry, n_entries());
+        return;
+    }
+    t_entry = entry;
+    rc = ensure_init();
+}
+CtxScope::~CtxScope() {
+    if (t_entry != prev) {
+        t_entry = prev;
+        if (prev < n_entries()) (void)hipSetDevice(g_entries[prev]->device);
+    }
 }
 
 // Experiment: a pair of CU-masked streams per slot.  ZKMI_CU_SPLIT=k gives the scalar preparation (digits, sort, plan: bandwidth-bound, needs wave slots to
@@ -74,22 +137,29 @@ int masked_streams(Slot* s) {
 }
 
 int ensure_init() {
-    Ctx& c = ctx();
-    if (c.ready) {
-        // other host threads (goroutine-backed OS threads) must also target the device
-        hipError_t e = hipSetDevice(c.device);
-        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
-        return ZK_OK;
+    if (n_entries() == 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int dev0 = 0;
+        ZK_TRY(init_devices(&dev0, 1));
+        Ctx& c0 = *g_entries[0];
+        int rc;
+        {
+            std::lock_guard<std::mutex> lk(c0.mu);
+            rc = init_entry(c0);
+        }
+        prof_host("export.hip_init", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());  // runtime start + streams, once per process
+        ZK_TRY(rc);
     }
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc;
-    {
+    if (t_entry >= n_entries()) return set_err(ZK_ERR_ARG, "this thread is on device entry %d, %d entries exist", t_entry, n_entries());
+    Ctx& c = *g_entries[t_entry];
+    if (!c.ready) {
         std::lock_guard<std::mutex> lk(c.mu);
-        if (c.ready) return ZK_OK;
-        rc = init_locked(0);
+        ZK_TRY(init_entry(c));
     }
-    prof_host("export.hip_init", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());  // runtime start + streams, once per process
-    return rc;
+    // other host threads (goroutine-backed OS threads, the per-entry workers of multidev.hip) must also target the entry's device
+    hipError_t e = hipSetDevice(c.device);
+    if (e != hipSuccess) return set_err(ZK_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    return ZK_OK;
 }
 
 // A caller that already holds slots (an msm5 session pins 5 of the 8) and asks for more than are left would wait forever:
@@ -152,7 +222,7 @@ int acquire_slots(int k, Slot** out) {
 }
 
 void release_slot(Slot* s) {
-    std::lock_guard<std::mutex> lk(ctx().mu);
+    std::lock_guard<std::mutex> lk((s->owner ? *s->owner : ctx()).mu);  // whatever entry the releasing thread is on
     s->busy = false;
 }
 
@@ -205,7 +275,7 @@ void prof_begin(Slot* s, hipStream_t st, const char* name) {
 }
 void prof_end(Slot* s, hipStream_t st) { (void)hipEventRecord(s->pending.back().e1, st); }
 void prof_host(const char* name, double ms) {
-    Ctx& c = ctx();
+    Prof& c = prof();
     if (!c.profiling) return;
     std::lock_guard<std::mutex> lk(c.mu);
     auto it = c.prof.find(name);
@@ -221,7 +291,7 @@ void prof_host(const char* name, double ms) {
 // caller's stream returned without synchronising) stay attached to the slot until a later fold.
 static void fold_pending(Slot* s) {
     if (s->pending.empty()) return;
-    Ctx& c = ctx();
+    Prof& c = prof();
     std::lock_guard<std::mutex> lk(c.mu);
     std::vector<Slot::Pending> keep;
     for (auto& p : s->pending) {
@@ -252,9 +322,13 @@ int slot_sync(Slot* s, hipStream_t st) {
 }
 
 void fold_all_slots() {
-    (void)hipDeviceSynchronize();
-    Ctx& c = ctx();
-    for (int i = 0; i < Ctx::NSLOTS; i++) fold_pending(&c.slots[i]);
+    for (int e = 0; e < n_entries(); e++) {
+        Ctx& c = *g_entries[e];
+        if (!c.ready) continue;
+        CtxScope sc(e);
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < Ctx::NSLOTS; i++) fold_pending(&c.slots[i]);
+    }
 }
 
 }  // namespace zkmi
@@ -270,29 +344,28 @@ int zk_device_count(void) {
 }
 
 int zk_init(int device) {
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (c.ready) return c.device == device ? ZK_OK : set_err(ZK_ERR_ARG, "already bound to device %d", c.device);
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return set_err(ZK_ERR_NO_DEVICE, "no HIP device visible; libzkmi has no CPU fallback");
-    if (device < 0 || device >= n) return set_err(ZK_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
-    // inline the body of init_locked with the requested device
-    ZK_HIP(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    ZK_HIP(hipGetDeviceProperties(&prop, device));
-    c.device = device;
-    c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    {
-        int lo = 0, hi = 0;  // numerically lower = higher priority
-        ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        for (int i = 0; i < Ctx::NSLOTS; i++) {
-            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
-            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi, hipStreamNonBlocking, hi));
-        }
-    }
-    c.ready = true;
-    return ZK_OK;
+    if (n_entries() > 0) return g_entries[0]->device == device ? ensure_init() : set_err(ZK_ERR_ARG, "already bound to device %d", g_entries[0]->device);
+    ZK_TRY(init_devices(&device, 1));
+    return ensure_init();
+}
+// The process's device list: one entry per listed HIP device, in order (n == 0 or devices == NULL: every visible device).  A device may be listed more
+// than once -- each listing is an entry of its own with its own streams and workspaces.  Calling it again may only extend the list.
+int zk_init_devices(const int* devices, size_t n) {
+    ZK_TRY(init_devices(devices, (int)n));
+    const int e = n_entries();
+    md_set_default_mask(e >= 32 ? 0xffffffffu : ((1u << e) - 1u));  // calls without a device_mask of their own spread over every entry from here on
+    return ensure_init();
+}
+int zk_device_entries(int* devices_out, size_t cap) {
+    const int n = n_entries();
+    for (int i = 0; i < n && (size_t)i < cap && devices_out; i++) devices_out[i] = g_entries[i]->device;
+    return n;
+}
+// The calling THREAD's entry for the single-device entry points that take no handle (zk_dev_alloc, zk_bn254_ntt_dev, ...); entry 0 by default.
+int zk_set_entry(int entry) {
+    if (entry < 0 || entry >= (n_entries() ? n_entries() : 1)) return set_err(ZK_ERR_ARG, "device entry %d does not exist (%d entries)", entry, n_entries());
+    t_entry = entry;
+    return ensure_init();
 }
 
 const char* zk_last_error(void) { return g_err.c_str(); }
@@ -326,7 +399,7 @@ int zk_dev_sync(void) {
 }
 
 int zk_profile_enable(int on) {
-    ctx().profiling = on != 0;
+    prof().profiling = on != 0;
     return ZK_OK;
 }
 int zk_profile_host(const char* name, double ms) {
@@ -335,18 +408,18 @@ int zk_profile_host(const char* name, double ms) {
     return ZK_OK;
 }
 int zk_profile_reset(void) {
-    Ctx& c = ctx();
+    Prof& c = prof();
     std::lock_guard<std::mutex> lk(c.mu);
     c.prof.clear();
     c.prof_names.clear();
     return ZK_OK;
 }
 int zk_profile_count(void) {
-    if (ctx().ready) fold_all_slots();  // asynchronous calls may have left event pairs in flight
-    return (int)ctx().prof_names.size();
+    fold_all_slots();  // asynchronous calls may have left event pairs in flight
+    return (int)prof().prof_names.size();
 }
 int zk_profile_get(int idx, char* name_out, size_t name_cap, uint64_t* launches, double* total_ms) {
-    Ctx& c = ctx();
+    Prof& c = prof();
     std::lock_guard<std::mutex> lk(c.mu);
     if (idx < 0 || idx >= (int)c.prof_names.size()) return set_err(ZK_ERR_ARG, "profile index out of range");
     const std::string& n = c.prof_names[idx];

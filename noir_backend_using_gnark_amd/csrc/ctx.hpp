@@ -1,5 +1,8 @@
-// Runtime context of libzkmi: device binding, stream slots with bump-allocated HBM workspaces, per-kernel hipEvent
-// timing, thread-local error text.  One process drives one GPU (multi-GPU = one process per GPU, see parallel.py).
+// Runtime context of libzkmi: device ENTRIES (one context per entry of the process's device list: stream slots with bump-allocated HBM workspaces),
+// per-kernel hipEvent timing, thread-local error text.  One process drives any number of GPUs: zk_init_devices(list) creates one entry per listed
+// device -- the same device may be listed several times (virtual devices: that is how the multi-device paths are tested on a one-GPU box) -- every
+// thread works on ITS current entry (entry 0 unless inside a CtxScope / after zk_set_entry), every resident object (bases, keys, sessions) carries
+// the entry it lives on in the top byte of its handle, and csrc/multidev.hip runs the range-sharded phases over the entries from host threads of its own.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -94,6 +97,7 @@ struct Slot {
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     bool busy = false;
+    struct Ctx* owner = nullptr;  // the entry whose device the stream and the arena live on
     struct Pending {
         const char* name;
         hipEvent_t e0, e1;
@@ -109,18 +113,44 @@ struct Slot {
 
 struct Ctx {
     bool ready = false;
-    int device = 0;
+    int entry = 0;    // position in the process's device list
+    int device = 0;   // HIP device ordinal (several entries may name the same device)
     int num_cus = 256;
     std::mutex mu;
     static constexpr int NSLOTS = 8;
     Slot slots[NSLOTS];
+};
+// the profile is one per process (kernels of every entry fold into it)
+struct Prof {
+    std::mutex mu;
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
     std::vector<std::string> prof_names;
 };
+Prof& prof();
+static inline bool profiling_on() { return prof().profiling; }
 
-Ctx& ctx();
-int ensure_init();                  // lazy device init; ZK_ERR_NO_DEVICE if there is no GPU
+static constexpr int MAX_ENTRIES = 64;
+Ctx& ctx();                         // the calling thread's current entry
+int n_entries();                    // entries created so far (0 before the first call that needs a device)
+int current_entry();
+int ensure_init();                  // lazy init of the current entry (entry 0 on device 0 if the process named no devices); ZK_ERR_NO_DEVICE if there is no GPU
+int init_devices(const int* devices, int n);  // the process's device list (n == 0: every visible device); extends an existing list, never rebinds an entry
+// the calling thread works on `entry` for the lifetime of the scope (hipSetDevice included); rc != ZK_OK if there is no such entry
+struct CtxScope {
+    int prev = 0, rc = ZK_OK;
+    explicit CtxScope(int entry);
+    ~CtxScope();
+    CtxScope(const CtxScope&) = delete;
+    CtxScope& operator=(const CtxScope&) = delete;
+};
+// handles of resident objects: the entry they live on in the top byte, a per-kind counter below
+static inline uint64_t hmake(uint64_t counter) { return ((uint64_t)current_entry() << 56) | counter; }
+static inline int hentry(uint64_t handle) { return (handle >> 56) == 0xff ? (int)((handle >> 48) & 0xff) : (int)(handle >> 56); }  // 0xff: a composite of multidev.hip, first entry next
+// first line of every entry point that takes a handle: the call runs on the handle's entry whatever entry the calling thread was on
+#define ZK_ON_ENTRY_OF(handle)                   \
+    zkmi::CtxScope _scope(zkmi::hentry(handle)); \
+    if (_scope.rc != ZK_OK) return _scope.rc
 int acquire_slot(Slot** out);       // blocks (spins) until a slot is free
 int acquire_slots(int k, Slot** out); // k slots at once (all or nothing: no partial holds, hence no deadlock)
 void release_slot(Slot* s);
@@ -144,9 +174,9 @@ void prof_host(const char* name, double ms);  // host-side section of the path (
 
 #define ZK_LAUNCH(slot, st, name, kernel, grid, block, shmem, ...)                  \
     do {                                                                            \
-        if (zkmi::ctx().profiling) zkmi::prof_begin(slot, st, name);                \
+        if (zkmi::profiling_on()) zkmi::prof_begin(slot, st, name);                 \
         hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);            \
-        if (zkmi::ctx().profiling) zkmi::prof_end(slot, st);                        \
+        if (zkmi::profiling_on()) zkmi::prof_end(slot, st);                         \
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -83,7 +83,7 @@ struct Phase {
 struct Lowered {
     ContentKey key;
     size_t n_values = 0;
-    int layout = 0;
+    int layout = 0, entry = 0;  // entry: the device entry whose HBM holds d_order / d_vals / d_sol
     size_t n_public = 0, n_vars = 0, n_gates = 0;
     std::vector<uint32_t> xa, xb, xc, order_public;  // host copies: a key that is not resident yet is read against the wiring; the verifier's public-witness list
     std::vector<uint32_t> order;                     // kept until it is uploaded
@@ -177,7 +177,7 @@ static int lowered_get(const char* acir_json, size_t acir_len, size_t n_values, 
         }
         if (!full || have_full)
             for (auto it = g_lowered.begin(); it != g_lowered.end(); ++it)
-                if ((*it)->key == key && (*it)->n_values == n_values && (*it)->layout == layout) {
+                if ((*it)->key == key && (*it)->n_values == n_values && (*it)->layout == layout && (*it)->entry == current_entry()) {
                     g_lowered.splice(g_lowered.begin(), g_lowered, it);
                     *out = g_lowered.front();
                     return ZK_OK;
@@ -193,6 +193,7 @@ static int lowered_get(const char* acir_json, size_t acir_len, size_t n_values, 
     L->key = key;
     L->n_values = n_values;
     L->layout = layout;
+    L->entry = current_entry();
     L->n_public = G->n_public;
     L->n_vars = G->n_vars;
     L->n_gates = G->xa.size();
@@ -203,7 +204,7 @@ static int lowered_get(const char* acir_json, size_t acir_len, size_t n_values, 
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (auto it = g_lowered.begin(); it != g_lowered.end(); ++it)
-            if ((*it)->key == key && (*it)->n_values == n_values && (*it)->layout == layout) { g_lowered.erase(it); break; }  // re-lowered with coefficients
+            if ((*it)->key == key && (*it)->n_values == n_values && (*it)->layout == layout && (*it)->entry == current_entry()) { g_lowered.erase(it); break; }  // re-lowered with coefficients
         if (cache_cap_bytes()) {
             cache_trim_locked(L->bytes() + L->n_vars * 36 + L->n_values * 32, &dead);
             g_lowered.push_front(L);
@@ -324,6 +325,7 @@ int zk_export_cache_info(size_t* n_circuits, size_t* n_keys, size_t* bytes) {
 int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, uint64_t srs_handle, char* pk_hex_out,
                         size_t pk_cap, size_t* pk_len, char* vk_hex_out, size_t vk_cap, size_t* vk_len, uint64_t* pk_handle) {
     if (!acir_json || !values_hex || !pk_len || !vk_len) return set_err(ZK_ERR_ARG, "null pointer");
+    ZK_ON_ENTRY_OF(srs_handle);
     size_t n_values = 0;
     ZK_TRY(count_of(values_hex, values_len, &n_values));
     if (values_len != 8 + 64 * n_values) return set_err(ZK_ERR_LEN, "felt vector: %zu characters, the count says %zu felts", values_len, n_values);
@@ -361,6 +363,7 @@ int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* valu
 int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, const char* pk_hex, size_t pk_len,
                            uint64_t pk_handle, uint64_t srs_handle, const zk_fr* blinders, char proof_hex_out[2 * ZK_PLONK_PROOF_BYTES]) {
     if (!acir_json || !values_hex || !proof_hex_out || (!pk_hex && !pk_handle)) return set_err(ZK_ERR_ARG, "null pointer");
+    ZK_ON_ENTRY_OF(pk_handle ? pk_handle : srs_handle);
     size_t n_values = 0;
     ZK_TRY(count_of(values_hex, values_len, &n_values));
     std::shared_ptr<Lowered> L;

@@ -23,6 +23,7 @@
 #include "host_ff.hpp"
 #include "keyio.hpp"
 #include "msm.hpp"
+#include "multidev.hpp"
 #include "ntt.hpp"
 #include "proofio.hpp"
 
@@ -114,6 +115,14 @@ static int infinity_map(const uint8_t* inf, size_t n_wires, size_t nb_inf, std::
 
 int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     if (!pk || !handle) return set_err(ZK_ERR_ARG, "null pointer");
+    // several device entries (pk->device_mask / the process default): a composite key of per-entry range slices (multidev.hip); one entry: a key on that entry.
+    // Slices of a key that is already sharded by its caller (flags bits 1, 2: one process per GPU) stay where the caller's thread is.
+    std::vector<int> ents;
+    if (pk->flags & 6) ents.push_back(current_entry());
+    else ZK_TRY(md_entries_for((uint32_t)pk->device_mask, pk->n_wires, (size_t)1 << 18, &ents));
+    if (ents.size() > 1) return md_groth16_pk_load(pk, ents, handle);
+    CtxScope _entry(ents[0]);
+    if (_entry.rc != ZK_OK) return _entry.rc;
     if (pk->log_domain > 28 || pk->n_public > pk->n_wires) return set_err(ZK_ERR_ARG, "bad proving-key geometry");
     if (pk->n_wires >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "n_wires = %zu does not fit 31 bits", pk->n_wires);
     if (!pk->g1_alpha || !pk->g1_beta || !pk->g1_delta || !pk->g2_beta || !pk->g2_delta) return set_err(ZK_ERR_ARG, "null pk element");
@@ -247,13 +256,15 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     }
     if (win_shard && !P.tables) return set_err(ZK_ERR_ARG, "a window-sharded key needs its window tables");
     std::lock_guard<std::mutex> lk(g_pk_mu);
-    *handle = g_next_pk++;
+    *handle = hmake(g_next_pk++);
     g_pks[*handle] = P;
     mem.keep = true;
     return ZK_OK;
 }
 
 int zk_bn254_groth16_pk_free(uint64_t handle) {
+    if (md_is_composite(handle)) return md_groth16_pk_free(handle);
+    ZK_ON_ENTRY_OF(handle);
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pks.find(handle);
     if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
@@ -298,6 +309,8 @@ int groth16_pk_view(uint64_t handle, Groth16View* v) {
 extern "C" {
 
 int zk_bn254_groth16_pk_info(uint64_t handle, size_t* n_wires, size_t* n_public, uint32_t* log_domain, int* has_tables) {
+    if (md_is_composite(handle)) return md_groth16_pk_info(handle, n_wires, n_public, log_domain, has_tables, nullptr);
+    ZK_ON_ENTRY_OF(handle);
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pks.find(handle);
     if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
@@ -648,6 +661,7 @@ static void session_drain(Msm5Session* ss) {
 }
 
 int zk_bn254_groth16_msm5_pk_begin(uint64_t pk_handle, const void* d_w, uint64_t* session) {
+    ZK_ON_ENTRY_OF(pk_handle);
     if (!session) return set_err(ZK_ERR_ARG, "null pointer");
     std::unique_ptr<Msm5Session> ss(new Msm5Session());
     ZK_TRY(lookup_pk(pk_handle, &ss->P));
@@ -669,12 +683,13 @@ int zk_bn254_groth16_msm5_pk_begin(uint64_t pk_handle, const void* d_w, uint64_t
     ss->pk_handle = pk_handle;
     pk_session_ref(pk_handle, +1);
     std::lock_guard<std::mutex> lk(g_sess_mu);
-    *session = g_next_session++;
+    *session = hmake(g_next_session++);
     g_sessions[*session] = ss.release();
     return ZK_OK;
 }
 
 int zk_bn254_groth16_msm5_pk_abort(uint64_t session) {
+    ZK_ON_ENTRY_OF(session);
     std::unique_ptr<Msm5Session> ss;
     {
         std::lock_guard<std::mutex> lk(g_sess_mu);
@@ -689,6 +704,7 @@ int zk_bn254_groth16_msm5_pk_abort(uint64_t session) {
 }
 
 int zk_bn254_groth16_msm5_session_stream(uint64_t session, void** stream_out) {
+    ZK_ON_ENTRY_OF(session);
     if (!stream_out) return set_err(ZK_ERR_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(g_sess_mu);
     auto it = g_sessions.find(session);
@@ -698,6 +714,7 @@ int zk_bn254_groth16_msm5_session_stream(uint64_t session, void** stream_out) {
 }
 
 int zk_bn254_groth16_msm5_pk_end(uint64_t session, const void* d_h, uint64_t out_xyzz[96], void* stream) {
+    ZK_ON_ENTRY_OF(session);
     std::unique_ptr<Msm5Session> ss;
     {
         std::lock_guard<std::mutex> lk(g_sess_mu);
@@ -727,12 +744,15 @@ int zk_bn254_groth16_msm5_pk_end(uint64_t session, const void* d_h, uint64_t out
 }
 
 int zk_bn254_groth16_msm5_pk(uint64_t pk_handle, const void* d_w, const void* d_h, uint64_t out_xyzz[96], void* stream) {
+    ZK_ON_ENTRY_OF(pk_handle);
     uint64_t session = 0;
     ZK_TRY(zk_bn254_groth16_msm5_pk_begin(pk_handle, d_w, &session));
     return zk_bn254_groth16_msm5_pk_end(session, d_h, out_xyzz, stream);
 }
 
 int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size_t n_partials, const zk_fr* r, const zk_fr* s, uint8_t proof_out[128]) {
+    if (md_is_composite(pk_handle)) return md_groth16_finalize(pk_handle, partials, n_partials, r, s, proof_out);
+    ZK_ON_ENTRY_OF(pk_handle);
     if (!partials || !n_partials || !r || !s || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
     Groth16PK P;
     ZK_TRY(lookup_pk(pk_handle, &P));
@@ -742,6 +762,8 @@ int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size
 
 int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, const void* c, size_t n_constraints, const void* w, size_t n_wires,
                            const zk_fr* r_, const zk_fr* s_, int on_device, uint8_t proof_out[128]) {
+    if (md_is_composite(pk_handle)) return md_groth16_prove(pk_handle, a, b, c, n_constraints, w, n_wires, r_, s_, on_device, proof_out);
+    ZK_ON_ENTRY_OF(pk_handle);
     if (!r_ || !s_ || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
     Groth16PK P;
     ZK_TRY(lookup_pk(pk_handle, &P));

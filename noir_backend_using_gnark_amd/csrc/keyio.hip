@@ -462,6 +462,7 @@ int zk_bn254_kzg_srs_read(const void* data, size_t len, int is_hex, int table_wi
 
 // kzg.SRS.WriteTo of a registered G1 base array + the two G2 points: bytes (or hex text) into out; *out_len = bytes written.
 int zk_bn254_kzg_srs_write(uint64_t handle, const zk_g2_affine g2[2], int as_hex, void* out, size_t cap, size_t* out_len) {
+    ZK_ON_ENTRY_OF(handle);
     if (!g2 || !out || !out_len) return set_err(ZK_ERR_ARG, "null pointer");
     const void* d_pts = nullptr;
     size_t n = 0;
@@ -629,6 +630,7 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
 
 // groth16.ProvingKey.WriteTo of a resident key: bytes (or hex text) into out; *out_len = bytes needed / written (out == NULL: size query).
 int zk_bn254_groth16_pk_write(uint64_t handle, int as_hex, void* out, size_t cap, size_t* out_len) {
+    ZK_ON_ENTRY_OF(handle);
     if (!out_len) return set_err(ZK_ERR_ARG, "null pointer");
     Groth16View v;
     ZK_TRY(groth16_pk_view(handle, &v));
@@ -718,6 +720,7 @@ int zk_bn254_groth16_pk_write(uint64_t handle, int as_hex, void* out, size_t cap
 // proving key ([beta]1, [delta]1).  Host only: 292 + 32 * n_k bytes.
 int zk_bn254_groth16_vk_write(uint64_t pk_handle, const zk_g1_affine* vk_g1, size_t n_k, const zk_g2_affine vk_g2[3], int as_hex, void* out, size_t cap,
                               size_t* out_len) {
+    ZK_ON_ENTRY_OF(pk_handle);
     if (!vk_g1 || !vk_g2 || !out_len) return set_err(ZK_ERR_ARG, "null pointer");
     Groth16View v;
     ZK_TRY(groth16_pk_view(pk_handle, &v));

@@ -37,6 +37,7 @@
 #include "ff29.hpp"
 #include "host_ff.hpp"
 #include "msm.hpp"
+#include "multidev.hpp"
 #include "radix.hpp"
 
 namespace zkmi {
@@ -1245,9 +1246,9 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     own_sort = ZK_EXP("ZKMI_SORT", 1) != 0;  // 0: rocPRIM's onesweep (A/B)
     own_scan = ZK_EXP("ZKMI_SCAN", 1) != 0;  // 0: rocPRIM's single-pass scan (A/B)
     if (!own_sort) {
-        if (ctx().profiling) prof_begin(s, st, "msm_radix_sort(rocprim)");
+        if (profiling_on()) prof_begin(s, st, "msm_radix_sort(rocprim)");
         hipError_t e = sort_pairs(sort_tmp, sort_tmp_bytes, kb, vb, total, key_bits, st);
-        if (ctx().profiling) prof_end(s, st);
+        if (profiling_on()) prof_end(s, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
     }
 #endif
@@ -1278,9 +1279,9 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
 #ifdef ZKMI_EXPERIMENTS
     if (!own_scan) {
-        if (ctx().profiling) prof_begin(s, st, "msm_task_scan(rocprim)");
+        if (profiling_on()) prof_begin(s, st, "msm_task_scan(rocprim)");
         hipError_t e = rocprim::exclusive_scan(scan_tmp, scan_tmp_bytes, ntasks, task_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
-        if (ctx().profiling) prof_end(s, st);
+        if (profiling_on()) prof_end(s, st);
         if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
     }
 #endif
@@ -1752,6 +1753,10 @@ int bases_ptr(uint64_t handle, const void** d, size_t* n, int* is_g2) {
 }
 // window table of a registered base array (null when it was registered without one)
 int bases_table(uint64_t handle, const void** d_table, MsmTable* tab, size_t* n) {
+    if (md_is_composite(handle)) {  // spread over several GPUs: no single table; commits go through zk_bn254_msm_bases_dev, one partial per entry
+        if (d_table) *d_table = nullptr;
+        return md_bases_info(handle, n, nullptr);
+    }
     std::lock_guard<std::mutex> lk(g_bases_mu);
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
@@ -1761,6 +1766,7 @@ int bases_table(uint64_t handle, const void** d_table, MsmTable* tab, size_t* n)
     return ZK_OK;
 }
 int bases_info(uint64_t handle, size_t* n, int* is_g2) {
+    if (md_is_composite(handle)) return md_bases_info(handle, n, is_g2);
     std::lock_guard<std::mutex> lk(g_bases_mu);
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
@@ -1831,6 +1837,19 @@ static int msm_dev_impl(const void* d_points, const void* d_scalars, size_t n, c
     return ZK_OK;
 }
 
+// several device entries (cfg->device_mask / the process default): the slices go to the entries by range (multidev.hip); one entry: that entry
+template <int G2>
+static int msm_host_entry(const void* points, size_t n_points, const zk_fr* scalars, size_t n_scalars, const zk_msm_cfg* cfg, void* out) {
+    if (n_points != n_scalars) return set_err(ZK_ERR_LEN, "len(points) != len(scalars)");
+    ZK_TRY(check_cfg(cfg));
+    if (!out || (n_points && (!points || !scalars))) return set_err(ZK_ERR_ARG, "null pointer");
+    std::vector<int> ents;
+    ZK_TRY(md_entries_for(cfg ? (uint32_t)cfg->device_mask : 0u, n_points, (size_t)1 << 17, &ents));
+    if (ents.size() > 1 && n_points >= ents.size()) return md_msm_host(G2, points, scalars, n_points, cfg, out, ents);
+    CtxScope sc(ents[0]);
+    if (sc.rc != ZK_OK) return sc.rc;
+    return msm_host_impl<G2>(points, n_points, scalars, n_scalars, cfg, out);
+}
 extern "C" {
 
 // what the planner picks for n points: the window width c and the number of c-bit digits per scalar (= mixed additions per scalar-mul)
@@ -1843,10 +1862,10 @@ int zk_bn254_msm_plan_info(size_t n, int window_tables, uint32_t* window_bits, u
 }
 
 int zk_bn254_g1_msm(const zk_g1_affine* points, size_t n_points, const zk_fr* scalars, size_t n_scalars, const zk_msm_cfg* cfg, zk_g1_affine* out) {
-    return msm_host_impl<0>(points, n_points, scalars, n_scalars, cfg, out);
+    return msm_host_entry<0>(points, n_points, scalars, n_scalars, cfg, out);
 }
 int zk_bn254_g2_msm(const zk_g2_affine* points, size_t n_points, const zk_fr* scalars, size_t n_scalars, const zk_msm_cfg* cfg, zk_g2_affine* out) {
-    return msm_host_impl<1>(points, n_points, scalars, n_scalars, cfg, out);
+    return msm_host_entry<1>(points, n_points, scalars, n_scalars, cfg, out);
 }
 int zk_bn254_g1_msm_dev(const void* d_points, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, zk_g1_affine* out_host, void* stream) {
     return msm_dev_impl<0>(d_points, d_scalars, n, cfg, out_host, stream, 0);
@@ -1884,7 +1903,26 @@ int zk_bn254_g2_sum_xyzz(const uint64_t* partials, size_t n_partials, zk_g2_affi
 }
 
 // table_c: 0 = planner's choice (tables for >= 4096 bases when they fit), -1 = no tables, else an explicit window width (any n)
+static int bases_register_here(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c);
 static int bases_register(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c) {
+    if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
+    if (table_c != 0 && table_c != -1 && (table_c < 8 || table_c > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_c);
+    ZK_TRY(ensure_init());
+    if (md_default_mask()) {  // the process named several GPUs: bases of a size that pays for it are kept by range on all of them (a composite handle)
+        std::vector<int> ents;
+        ZK_TRY(md_entries_for(0, n, (size_t)1 << 17, &ents));
+        if (ents.size() > 1) return md_bases_register(points, n, is_g2, kind == hipMemcpyDeviceToDevice, table_c, ents, handle);
+    }
+    return bases_register_here(points, n, is_g2, handle, kind, table_c);
+}
+}  // extern "C"
+namespace zkmi {
+int bases_register_on_this_entry(const void* points, size_t n, int is_g2, int on_device, int table_c, uint64_t* handle) {
+    return bases_register_here(points, n, is_g2, handle, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, table_c);
+}
+}  // namespace zkmi
+extern "C" {
+static int bases_register_here(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c) {
     if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
     if (table_c != 0 && table_c != -1 && (table_c < 8 || table_c > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_c);
     ZK_TRY(ensure_init());
@@ -1919,7 +1957,7 @@ static int bases_register(const void* points, size_t n, int is_g2, uint64_t* han
         }
     }
     std::lock_guard<std::mutex> lk(g_bases_mu);
-    *handle = g_next_handle++;
+    *handle = hmake(g_next_handle++);
     g_bases[*handle] = b;
     cleanup.b = nullptr;
     return ZK_OK;
@@ -1932,6 +1970,8 @@ int zk_bn254_bases_register_cfg(const void* points, size_t n, int is_g2, int on_
     return bases_register(points, n, is_g2, handle, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, table_window_bits);
 }
 int zk_bn254_bases_free(uint64_t handle) {
+    if (md_is_composite(handle)) return md_bases_free(handle);
+    ZK_ON_ENTRY_OF(handle);
     std::lock_guard<std::mutex> lk(g_bases_mu);
     auto it = g_bases.find(handle);
     if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
@@ -1941,6 +1981,11 @@ int zk_bn254_bases_free(uint64_t handle) {
     return ZK_OK;
 }
 static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t n, const zk_msm_cfg* cfg, void* out, hipMemcpyKind kind) {
+    if (md_is_composite(handle)) {
+        ZK_TRY(check_cfg(cfg));
+        return md_msm_bases(handle, offset, scalars, n, cfg, out, kind == hipMemcpyDeviceToDevice);
+    }
+    ZK_ON_ENTRY_OF(handle);
     Bases b;
     {
         std::lock_guard<std::mutex> lk(g_bases_mu);

@@ -22,6 +22,7 @@
 #include "ff.hpp"
 #include "host_ff.hpp"
 #include "ntt.hpp"
+#include "multidev.hpp"
 #include "ff29.hpp"
 
 namespace zkmi {
@@ -460,7 +461,7 @@ __global__ void k_fr_mul(Fr* out, const Fr* a, const Fr* b, size_t n) {
 static const uint64_t ROOT_2_28_MONT[4] = {0x636e735580d13d9cULL, 0xa22bf3742445ffd6ULL, 0x56452ac01eb203d8ULL, 0x1860ef942963f9e7ULL};
 
 static std::mutex g_dom_mu;
-static std::map<unsigned, Domain*> g_domains;
+static std::map<unsigned, Domain*> g_domains;  // by (device entry, log n): the tables live in the HBM of the entry that built them
 
 static Fr to_dev(const HFr& h) {
     Fr r;
@@ -484,7 +485,7 @@ static int make_pow_table(Slot* s, hipStream_t st, Fr** out, size_t n, unsigned 
 int get_domain(Slot* s, hipStream_t st, unsigned logn, unsigned need, Domain** out) {
     if (logn > 28) return set_err(ZK_ERR_ARG, "log_n = %u exceeds Fr two-adicity 28", logn);
     std::lock_guard<std::mutex> lk(g_dom_mu);
-    Domain*& d = g_domains[logn];
+    Domain*& d = g_domains[((unsigned)current_entry() << 8) | logn];
     if (!d) {
         d = new Domain();
         d->logn = logn;
@@ -661,9 +662,12 @@ static int run_inverse_forward(Slot* s, hipStream_t st, Fr* data, const Domain* 
     return ZK_OK;
 }
 
-static bool g_lds_attr_set = false;
+static std::mutex g_lds_mu;
+static uint64_t g_lds_attr_set = 0;  // bit e: done for device entry e (the attribute belongs to the device's copy of the function)
 static int ensure_lds_attr() {
-    if (!g_lds_attr_set) {
+    std::lock_guard<std::mutex> lk(g_lds_mu);
+    const uint64_t bit = (uint64_t)1 << current_entry();
+    if (!(g_lds_attr_set & bit)) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 32));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
@@ -671,7 +675,7 @@ static int ensure_lds_attr() {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29<2, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29_if<3, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass29_if<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (1 << TILE_LOG) * 36));
-        g_lds_attr_set = true;
+        g_lds_attr_set |= bit;
     }
     return ZK_OK;
 }
@@ -845,7 +849,7 @@ static std::map<uint64_t, ShardTables> g_shard_tables;
 
 static int get_shard_tables(Slot* s, hipStream_t st, Domain* dD, unsigned logD, unsigned logg, unsigned rank, ShardTables* out) {
     std::lock_guard<std::mutex> lk(g_shard_mu);
-    const uint64_t key = ((uint64_t)logD << 32) | ((uint64_t)logg << 16) | rank;
+    const uint64_t key = ((uint64_t)current_entry() << 48) | ((uint64_t)logD << 32) | ((uint64_t)logg << 16) | rank;
     ShardTables& t = g_shard_tables[key];
     if (!t.coset_rev_n) {
         const size_t M = ((size_t)1 << logD) >> logg;
@@ -982,14 +986,21 @@ int zk_bn254_ntt_dev(void* d_a, uint32_t log_n, int inverse, int decimation, int
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
     ZK_TRY(ntt_dev(g.s, st, (Fr*)d_a, log_n, inverse, decimation, coset));
     // no workspace is used: safe to return without synchronising a caller-provided stream
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 
-int zk_bn254_ntt(zk_fr* a, uint32_t log_n, int inverse, int decimation, int coset) {
+// device_mask: bit i = device entry i takes a block of the array (2, 4 or 8 entries: multidev.hip); 0 = the process default, which only spreads transforms
+// of at least 2^18 points per entry
+int zk_bn254_ntt_devices(zk_fr* a, uint32_t log_n, int inverse, int decimation, int coset, uint32_t device_mask) {
     if (!a) return set_err(ZK_ERR_ARG, "null data pointer");
     if (log_n > 28) return set_err(ZK_ERR_ARG, "log_n = %u exceeds Fr two-adicity 28", log_n);
     if (decimation != ZK_DIT && decimation != ZK_DIF) return set_err(ZK_ERR_ARG, "decimation must be ZK_DIT or ZK_DIF");
+    std::vector<int> ents;
+    ZK_TRY(md_entries_for(device_mask, (size_t)1 << log_n, (size_t)1 << 18, &ents));
+    if (ents.size() > 1 && (device_mask || ents.size() == 2 || ents.size() == 4 || ents.size() == 8)) return md_ntt_host(a, log_n, inverse, decimation, coset, ents);
+    CtxScope sc(ents[0]);
+    if (sc.rc != ZK_OK) return sc.rc;
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     size_t bytes = ((size_t)1 << log_n) * 32;
@@ -1001,6 +1012,7 @@ int zk_bn254_ntt(zk_fr* a, uint32_t log_n, int inverse, int decimation, int cose
     ZK_HIP(hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, st));
     return slot_sync(g.s, st);
 }
+int zk_bn254_ntt(zk_fr* a, uint32_t log_n, int inverse, int decimation, int coset) { return zk_bn254_ntt_devices(a, log_n, inverse, decimation, coset, 0); }
 
 int zk_bn254_bit_reverse_dev(void* d_a, uint32_t log_n, void* stream) {
     if (!d_a || log_n > 28) return set_err(ZK_ERR_ARG, "bad argument");
@@ -1008,7 +1020,7 @@ int zk_bn254_bit_reverse_dev(void* d_a, uint32_t log_n, void* stream) {
     ZK_TRY(acquire_slot(&g.s));
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
     ZK_TRY(bit_reverse_dev(g.s, st, (Fr*)d_a, log_n));
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 
@@ -1099,7 +1111,7 @@ int zk_bn254_fr_mul_dev(void* d_out, const void* d_a, const void* d_b, size_t n,
     ZK_TRY(acquire_slot(&g.s));
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
     ZK_TRY(fr_mul_dev(g.s, st, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n));
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 

@@ -746,7 +746,7 @@ static void build_permutation(size_t n, size_t npub, size_t nc, size_t nvars, co
 
 static int register_pk(PlonkPK* P, uint64_t* handle) {
     std::lock_guard<std::mutex> lk(g_ppk_mu);
-    *handle = g_next_ppk++;
+    *handle = hmake(g_next_ppk++);
     g_ppks[*handle] = P;
     return ZK_OK;
 }
@@ -782,6 +782,7 @@ int zk_bn254_plonk_synth_qk_dev(void* d_qk, const void* d_ql, const void* d_qr, 
 }
 
 int zk_bn254_plonk_setup(const zk_plonk_circuit* c, uint64_t srs, uint64_t* handle, zk_plonk_vk* vk) {
+    ZK_ON_ENTRY_OF(srs);
     if (!c || !handle) return set_err(ZK_ERR_ARG, "null pointer");
     const size_t npub = c->n_public, nc = c->n_constraints;
     if (nc && (!c->ql || !c->qr || !c->qo || !c->qm || !c->qk || !c->xa || !c->xb || !c->xc)) return set_err(ZK_ERR_ARG, "null pointer");
@@ -868,6 +869,7 @@ int zk_bn254_plonk_setup(const zk_plonk_circuit* c, uint64_t srs, uint64_t* hand
 }
 
 int zk_bn254_plonk_pk_load(const zk_plonk_pk* k, uint64_t srs, uint64_t* handle) {
+    ZK_ON_ENTRY_OF(srs);
     if (!k || !handle) return set_err(ZK_ERR_ARG, "null pointer");
     if (!k->ql || !k->qr || !k->qm || !k->qo || !k->cqk || !k->lqk || !k->s1 || !k->s2 || !k->s3 || !k->permutation || !k->vk_s || !k->vk_ql || !k->vk_qr ||
         !k->vk_qm || !k->vk_qo || !k->vk_qk || (k->n_constraints && (!k->xa || !k->xb || !k->xc)))
@@ -935,6 +937,7 @@ static const size_t PK_HEAD = PLONK_PK_HEAD;
 
 int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_vars, size_t n_constraints, const uint32_t* xa, const uint32_t* xb,
                            const uint32_t* xc, uint64_t srs, uint64_t* handle) {
+    ZK_ON_ENTRY_OF(srs);
     if (!data || !handle || (n_constraints && (!xa || !xb || !xc))) return set_err(ZK_ERR_ARG, "null pointer");
     PlonkKeyHeader H;  // every size below comes out of this host-side reading of the header and the nine length prefixes (text_host.hpp)
     {
@@ -1012,6 +1015,7 @@ int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_va
 }
 
 int zk_bn254_plonk_pk_write(uint64_t handle, int as_hex, void* out, size_t cap, size_t* out_len) {
+    ZK_ON_ENTRY_OF(handle);
     if (!out || !out_len) return set_err(ZK_ERR_ARG, "null pointer");
     PlonkPK* P;
     std::shared_ptr<std::mutex> mu;
@@ -1081,6 +1085,7 @@ int zk_bn254_plonk_pk_write(uint64_t handle, int as_hex, void* out, size_t cap, 
 }
 
 int zk_bn254_plonk_pk_info(uint64_t handle, size_t* domain_size, size_t* n_public, size_t* n_constraints, size_t* n_vars) {
+    ZK_ON_ENTRY_OF(handle);
     std::lock_guard<std::mutex> lk(g_ppk_mu);
     auto it = g_ppks.find(handle);
     if (it == g_ppks.end()) return set_err(ZK_ERR_HANDLE, "unknown PLONK proving key %llu", (unsigned long long)handle);
@@ -1093,6 +1098,7 @@ int zk_bn254_plonk_pk_info(uint64_t handle, size_t* domain_size, size_t* n_publi
 }
 
 int zk_bn254_plonk_pk_bytes(uint64_t handle, size_t* bytes) {
+    ZK_ON_ENTRY_OF(handle);
     if (!bytes) return set_err(ZK_ERR_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(g_ppk_mu);
     auto it = g_ppks.find(handle);
@@ -1102,6 +1108,7 @@ int zk_bn254_plonk_pk_bytes(uint64_t handle, size_t* bytes) {
 }
 
 int zk_bn254_plonk_pk_free(uint64_t handle) {
+    ZK_ON_ENTRY_OF(handle);
     PlonkPK* P;
     {
         std::lock_guard<std::mutex> lk(g_ppk_mu);
@@ -1116,6 +1123,7 @@ int zk_bn254_plonk_pk_free(uint64_t handle) {
 }
 
 int zk_bn254_plonk_pk_export(uint64_t handle, int which, zk_fr* out, size_t cnt) {
+    ZK_ON_ENTRY_OF(handle);
     if (!out) return set_err(ZK_ERR_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(g_ppk_mu);
     auto it = g_ppks.find(handle);
@@ -1129,6 +1137,7 @@ int zk_bn254_plonk_pk_export(uint64_t handle, int which, zk_fr* out, size_t cnt)
 
 int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, int on_device, const zk_fr blinders[9], const zk_fr* challenges,
                          uint8_t proof_out[ZK_PLONK_PROOF_BYTES]) {
+    ZK_ON_ENTRY_OF(handle);
     if (!solution || !blinders || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
     PlonkPK* P;
     std::shared_ptr<std::mutex> mu;

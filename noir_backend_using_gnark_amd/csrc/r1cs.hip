@@ -189,12 +189,13 @@ int zk_bn254_r1cs_load(const zk_r1cs* r, uint64_t* handle) {
         }
     }
     std::lock_guard<std::mutex> lk(g_r1cs_mu);
-    *handle = g_next_r1cs++;
+    *handle = hmake(g_next_r1cs++);
     g_r1cs[*handle] = std::shared_ptr<R1csDev>(D.release(), r1cs_destroy);
     return ZK_OK;
 }
 
 int zk_bn254_r1cs_free(uint64_t handle) {
+    ZK_ON_ENTRY_OF(handle);
     std::shared_ptr<R1csDev> D;  // destroyed here, or by the last call still using it
     {
         std::lock_guard<std::mutex> lk(g_r1cs_mu);
@@ -208,6 +209,7 @@ int zk_bn254_r1cs_free(uint64_t handle) {
 
 // a = L w, b = R w, c = O w (n_constraints each), everything in HBM
 int zk_bn254_r1cs_eval_abc_dev(uint64_t handle, const void* d_w, size_t n_wires, void* d_a, void* d_b, void* d_c, void* stream) {
+    ZK_ON_ENTRY_OF(handle);
     std::shared_ptr<R1csDev> Dref;
     ZK_TRY(lookup_r1cs(handle, &Dref));
     R1csDev* D = Dref.get();
@@ -220,7 +222,7 @@ int zk_bn254_r1cs_eval_abc_dev(uint64_t handle, const void* d_w, size_t n_wires,
     for (int m = 0; m < 3; m++) { M.ptr[m] = D->row[m].ptr; M.idx[m] = D->row[m].idx; M.val[m] = D->row[m].val; }
     if (D->n_constraints)
         ZK_LAUNCH(g.s, st, "r1cs_spmv", k_spmv3, dim3(gridn(D->n_constraints), 3), dim3(256), 0, M, (const Fr*)d_w, D->n_constraints, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 
@@ -228,6 +230,7 @@ int zk_bn254_r1cs_eval_abc_dev(uint64_t handle, const void* d_w, size_t n_wires,
 // built in HBM and loaded as a resident key (*pk_handle, usable with zk_bn254_groth16_prove); the verifying key comes back to the host:
 // vk_g1 = [alpha]G1 followed by the n_public points K_i / gamma (gnark's vk.G1.K), vk_g2 = [beta]G2, [gamma]G2, [delta]G2.
 int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags, uint64_t* pk_handle, zk_g1_affine* vk_g1, zk_g2_affine vk_g2[3]) {
+    ZK_ON_ENTRY_OF(r1cs_handle);
     if (!toxic || !pk_handle) return set_err(ZK_ERR_ARG, "null pointer");
     std::shared_ptr<R1csDev> Dref;
     ZK_TRY(lookup_r1cs(r1cs_handle, &Dref));
@@ -340,6 +343,7 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
 // zk_bn254_groth16_prove on resident data.  w: all wire values [ONE, public..., secret..., internal...] (Montgomery); on_device as there.
 int zk_bn254_groth16_prove_r1cs(uint64_t r1cs_handle, uint64_t pk_handle, const void* w, size_t n_wires, const zk_fr* r, const zk_fr* s_, int on_device,
                                 uint8_t proof_out[128]) {
+    ZK_ON_ENTRY_OF(r1cs_handle);
     std::shared_ptr<R1csDev> Dref;
     ZK_TRY(lookup_r1cs(r1cs_handle, &Dref));
     R1csDev* D = Dref.get();

@@ -185,12 +185,14 @@ static int fixed_base_table(const Affine<F>& gen_dev, Affine<F>** d_out) {
     return ZK_OK;
 }
 static std::mutex g_fb_mu;
-static Affine<Fp>* g_fb_g1 = nullptr;
-static Affine<Fp2>* g_fb_g2 = nullptr;
+static Affine<Fp>* g_fb_g1s[MAX_ENTRIES] = {};   // per device entry
+static Affine<Fp2>* g_fb_g2s[MAX_ENTRIES] = {};
 
 // out[i] = [k_i] G1 / G2 for the scalar source S (declared in fixedbase.hpp for the other translation units)
 int fixed_base_mul(Slot* s, hipStream_t st, int is_g2, const ScalarSrc& S, size_t n, void* d_out) {
     if (!n) return ZK_OK;
+    Affine<Fp>*& g_fb_g1 = g_fb_g1s[current_entry()];
+    Affine<Fp2>*& g_fb_g2 = g_fb_g2s[current_entry()];
     {
         std::lock_guard<std::mutex> lk(g_fb_mu);
         if (!is_g2 && !g_fb_g1) ZK_TRY((fixed_base_table<HFp, Fp>(g1_generator(), &g_fb_g1)));
@@ -228,7 +230,7 @@ int zk_bn254_fr_random_dev(void* d_out, size_t n, uint64_t seed, int mont, int w
     ZK_TRY(acquire_slot(&g.s));
     hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
     if (n) ZK_LAUNCH(g.s, st, "fr_random", k_fr_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (Fr*)d_out, n, seed, mont, witness_like);
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 
@@ -241,7 +243,7 @@ int zk_bn254_g1_generate_dev(void* d_out, size_t n, uint64_t seed, void* stream)
     S.kind = 1;
     S.seed = seed;
     ZK_TRY(fixed_base_mul(g.s, st, 0, S, n, d_out));
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 
@@ -254,7 +256,7 @@ int zk_bn254_g2_generate_dev(void* d_out, size_t n, uint64_t seed, void* stream)
     S.kind = 1;
     S.seed = seed;
     ZK_TRY(fixed_base_mul(g.s, st, 1, S, n, d_out));
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 
@@ -287,7 +289,7 @@ int zk_bn254_kzg_new_srs_dev(void* d_g1_out, size_t size, const zk_fr* alpha, zk
         memcpy(&g2_out[0], &gh, 128);
         memcpy(&g2_out[1], &ag, 128);
     }
-    if (!stream || ctx().profiling) ZK_TRY(slot_sync(g.s, st));
+    if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
 

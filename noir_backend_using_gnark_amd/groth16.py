@@ -25,12 +25,15 @@ class ProvingKey:
     window_shard=(rank, count): the WINDOW-sharded key of one rank -- the whole key, but only the table rows (digit windows) w = rank + k * count;
     msm5 against it yields the partial sums over those windows of the full wire / h vectors.
 
+    device_mask: several GPUs in ONE process (zk_init_devices): bit i = device entry i holds a range slice of the key (2, 4 or 8 entries);
+    prove() on such a key runs computeH block-sharded over the entries and the five MSMs per slice -- same bytes.
+
     A rank of a range-sharded proof loads ITS slice as a key of its own (n_wires / n_public / log_domain describe the
     slice; shard_full_z=True on every rank but the last, whose Z slice ends with the unused N-th entry)."""
 
     def __init__(self, log_domain: int, n_wires: int, n_public: int, g1_alpha, g1_beta, g1_delta, g1_a, g1_b, g1_k, g1_z,
                  g2_beta, g2_delta, g2_b, bases_on_device: bool = False, precompute_tables: bool = True, shard_full_z: bool = False,
-                 infinity_a=None, infinity_b=None, table_window_bits: int = 0, window_shard: tuple | None = None):
+                 infinity_a=None, infinity_b=None, table_window_bits: int = 0, window_shard: tuple | None = None, device_mask: int = 0):
         self.log_domain, self.n_wires, self.n_public = log_domain, n_wires, n_public
         self._keep = []
         inf_a = inf_b = 0
@@ -58,7 +61,7 @@ class ProvingKey:
 
         pk = Groth16PK(log_domain, n_wires, n_public, host(g1_alpha), host(g1_beta), host(g1_delta), base(g1_a), base(g1_b),
                        base(g1_k), base(g1_z), host(g2_beta), host(g2_delta), base(g2_b), 1 if bases_on_device else 0,
-                       (0 if precompute_tables else 1) | (2 if shard_full_z else 0) | (4 if window_shard else 0), inf_a, inf_b, nb_a, nb_b, table_window_bits, 0,
+                       (0 if precompute_tables else 1) | (2 if shard_full_z else 0) | (4 if window_shard else 0), inf_a, inf_b, nb_a, nb_b, table_window_bits, device_mask,
                        *(window_shard or (0, 0)))
         if bases_on_device:
             self._keep += [g1_a, g1_b, g1_k, g1_z, g2_b]  # keep DeviceBuffers alive
