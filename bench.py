@@ -315,8 +315,47 @@ def inner_boundary_block(L, lib, zk, par, inst, proof):
             x.join()
         return out, (time.perf_counter() - t) * 1e3
 
-    ntt7(), msm5_seq(), msm5_conc()  # warm: domain tables, workspaces
+    def ntt7_chains():
+        """the same seven transforms as INTEGRATION.md 4 patches computeH to issue them: a, b, c each go through FFTInverse(DIF) then FFT(DIT, coset) on a goroutine of
+        their own (the three chains are independent), then the closing FFTInverse(DIF, coset) -- downloads of one chain overlap the uploads of another (PCIe is full duplex)"""
+        a, b, c = ha.copy(), hb.copy(), hc.copy()
+        dom_wake.fft(wake, zk.DIF)
+
+        def chain(v):
+            dom.fft_inverse(v, zk.DIF)
+            dom.fft(v, zk.DIT, True)
+        th = [threading.Thread(target=chain, args=(v,)) for v in (a, b, c)]
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dom.fft_inverse(a, zk.DIF, True)
+        return (time.perf_counter() - t) * 1e3
+
+    def msm5_prepared():
+        """the five MultiExp calls as INTEGRATION.md 4 patches groth16.Prove to issue them: the wire values are registered once (zk_bn254_scalars_register: one upload,
+        one recoding shared by A, B1, G2.B, a second one for K from the resident copy), h goes through zk_bn254_msm_bases; five concurrent host threads"""
+        out = [None] * 5
+        dom_wake.fft(wake, zk.DIF)
+        t = time.perf_counter()
+        S = zb.PreparedScalars(hw, MONT)
+        jobs = [lambda: bases[0].multi_exp_prepared(S), lambda: bases[1].multi_exp_prepared(S), lambda: bases[2].multi_exp_prepared(S, skip=npub),
+                lambda: bases[3].multi_exp(scal[3], config=MONT), lambda: bases[4].multi_exp_prepared(S)]
+        th = [threading.Thread(target=lambda k=k: out.__setitem__(k, jobs[k]())) for k in (3, 4, 0, 1, 2)]  # Z's upload and G2.B (the longest) first
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        ms = (time.perf_counter() - t) * 1e3
+        S.free()
+        return out, ms
+
+    ntt7(), msm5_seq(), msm5_conc(), ntt7_chains(), msm5_prepared()  # warm: domain tables, workspaces
     reps = 3
+    chains_ms = float(np.mean([ntt7_chains() for _ in range(reps)]))
+    prep = [msm5_prepared() for _ in range(reps)]
+    prep_ms = float(np.mean([t for _, t in prep]))
     ntt_reps = [ntt7() for _ in range(reps)]
     if os.environ.get("ZKMI_BENCH_DEBUG"):
         print("inner boundary, zk_bn254_ntt per call and repetition (ms):", [[round(x, 2) for x in r] for r in ntt_reps], file=sys.stderr)
@@ -338,13 +377,16 @@ def inner_boundary_block(L, lib, zk, par, inst, proof):
                 parts.append(np.concatenate([p, one, zero, one, zero] if k == 4 else [p, one, one]))
         return np.concatenate(parts)
 
-    ok = all(par.groth16_finalize(inst.pk, record(res)[None, :], inst.r, inst.s) == proof for res in (seq[-1][0], conc[-1][0]))
+    ok = all(par.groth16_finalize(inst.pk, record(res)[None, :], inst.r, inst.s) == proof for res in (seq[-1][0], conc[-1][0], prep[-1][0]))
     for bs in bases:
         bs.free()
     return {"what": "the same 2^%d proof's hot operations through the inner C ABI with host slices, call by call (zk_bn254_ntt x7, zk_bn254_msm_bases x5)" % inst.log_n,
             "ntt_calls_ms": [round(float(x), 3) for x in ntt_ms], "ntt_total_ms": round(float(ntt_ms.sum()), 3),
             "msm_calls_ms": dict(zip(("A", "B1", "K", "Z", "B2"), (round(float(x), 3) for x in msm_ms))), "msm_total_sequential_ms": round(float(msm_ms.sum()), 3),
-            "msm_total_five_threads_ms": round(conc_ms, 3), "total_ms": round(float(ntt_ms.sum()) + conc_ms, 3), "reps": reps,
+            "msm_total_five_threads_ms": round(conc_ms, 3), "total_unpatched_call_sites_ms": round(float(ntt_ms.sum()) + conc_ms, 3),
+            "ntt_total_three_chains_ms": round(chains_ms, 3), "msm_total_prepared_scalars_five_threads_ms": round(prep_ms, 3),
+            "total_ms": round(chains_ms + prep_ms, 3), "total_ms_is": "INTEGRATION.md 4's patch: computeH's three chains on three goroutines + scalars registered once for A, B1, K, G2.B",
+            "reps": reps,
             "bytes_over_pcie_per_proof": int(7 * 2 * N * 32 + 5 * N * 32), "bases_register_s_once_per_key": round(reg_s, 3),
             "proof_from_these_results_matches_single_call": bool(ok),
             "note": "PCIe-inclusive (never `value`); excludes gnark's own Go code between the calls (the pointwise step of computeH, the solver, the host tail)"}

@@ -114,6 +114,15 @@ int zk_bn254_bases_register_dev(const void *d_points, size_t n, int is_g2, uint6
  * -1 no tables, else c in [8, 22] (tables at any n: how the tests reach the widths the planner picks at 2^22 .. 2^26 points). */
 int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_device, int table_window_bits, uint64_t *handle);
 int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);
+/* Scalars kept resident and recoded ONCE for every base array they pair with.  groth16.Prove's five MultiExp calls (gnark v0.8.0 groth16 prove.go, reached
+ * from gnark_backend_ffi/main.go:131) pair A, B1, K and G2.B with the SAME wire values: through zk_bn254_msm_bases each call uploads the 32 B x n scalars and
+ * recodes them (digits, radix sort, task plan).  zk_bn254_scalars_register uploads once (cfg->scalars_mont says which form they are in);
+ * zk_bn254_msm_bases_prepared(bases, bases_offset, scalars, skip, cfg, out) = sum_{i >= skip} scalars[i] * bases[bases_offset + i - skip] shares one recoding
+ * among base arrays registered over the same index space (A, B1, G2.B) and makes a second one from the resident copy for K (skip = n_public) -- callable
+ * from concurrent threads, like upstream's goroutines.  Same affine result as zk_bn254_msm_bases on the same data. */
+int zk_bn254_scalars_register(const zk_fr *scalars, size_t n, const zk_msm_cfg *cfg, uint64_t *handle);
+int zk_bn254_scalars_free(uint64_t handle);
+int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t scalars_handle, size_t skip, const zk_msm_cfg *cfg, void *out);
 
 /* ---- NTT: (*fft.Domain).FFT / FFTInverse / fft.BitReverse ------------------------------------------------------
  * In place on a[0 .. 2^log_n).  decimation: ZK_DIF natural in -> bit-reversed out; ZK_DIT bit-reversed in ->

@@ -139,9 +139,34 @@ class ResidentBases:
         check(rc)
         return out
 
+    def multi_exp_prepared(self, scalars: "PreparedScalars", skip: int = 0, offset: int = 0, config: MultiExpConfig | None = None) -> np.ndarray:
+        """sum_{i >= skip} scalars[i] * bases[offset + i - skip] against scalars that were uploaded and are recoded once (zk_bn254_msm_bases_prepared)."""
+        out = np.zeros(16 if self.is_g2 else 8, dtype=np.uint64)
+        cfg = (config or MultiExpConfig())._c()
+        rc = lib().zk_bn254_msm_bases_prepared(self.handle, C.c_size_t(offset), scalars.handle, C.c_size_t(skip), C.byref(cfg), vp(out))
+        if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_NB_TASKS):
+            raise ValueError((lib().zk_last_error() or b"").decode())
+        check(rc)
+        return out
+
     def free(self):
         if self.handle.value:
             lib().zk_bn254_bases_free(self.handle)
+            self.handle = C.c_uint64(0)
+
+
+class PreparedScalars:
+    """A scalar vector uploaded once and recoded once per table geometry (zk_bn254_scalars_register): what groth16.Prove's A, B1, K and G2.B MultiExp calls share."""
+
+    def __init__(self, scalars, config: MultiExpConfig | None = None):
+        scalars = _as_u64(scalars, 4)
+        self.n, self.handle = scalars.shape[0], C.c_uint64(0)
+        cfg = (config or MultiExpConfig())._c()
+        check(lib().zk_bn254_scalars_register(vp(scalars), C.c_size_t(self.n), C.byref(cfg), C.byref(self.handle)))
+
+    def free(self):
+        if self.handle.value:
+            lib().zk_bn254_scalars_free(self.handle)
             self.handle = C.c_uint64(0)
 
 

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <tuple>
 #include <type_traits>
 
@@ -2042,6 +2043,163 @@ static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t
     }
     return ZK_OK;
 }
+// ---- scalars kept resident and recoded ONCE for every base array they pair with -------------------------------------------------------------------
+// groth16.Prove issues five MultiExp calls and four of them -- A, B1, K, G2.B -- pair with the SAME wire values (gnark v0.8.0 groth16 prove.go; reached from
+// gnark_backend_ffi/main.go:131).  Through zk_bn254_msm_bases each of them uploads the 32 B x n scalars and recodes them (digits, radix sort, task plan).
+// A scalars handle uploads once and keeps one recoding per table geometry (window width, row stride, first scalar): A, B1 and G2.B -- registered over the
+// same wires -- share one; K (registered over the n - n_public private wires) gets a second from the resident copy, no second upload.
+struct PreparedScalars {
+    size_t n = 0;
+    int mont = 0;
+    void* d_sc = nullptr;
+    Slot* slot = nullptr;   // its arena holds the recodings; held until zk_bn254_scalars_free
+    std::mutex mu;
+    struct Geo {
+        unsigned c;
+        size_t stride, skip;
+        bool table;
+        MsmPrep prep;
+    };
+    std::vector<Geo> geos;
+};
+static std::mutex g_ps_mu;
+static std::map<uint64_t, std::shared_ptr<PreparedScalars>> g_ps;
+static uint64_t g_next_ps = 1;
+
+int zk_bn254_scalars_register(const zk_fr* scalars, size_t n, const zk_msm_cfg* cfg, uint64_t* handle) {
+    if (!handle || (n && !scalars)) return set_err(ZK_ERR_ARG, "null pointer");
+    ZK_TRY(check_cfg(cfg));
+    ZK_TRY(ensure_init());
+    auto S = std::make_shared<PreparedScalars>();
+    S->n = n;
+    S->mont = (cfg && cfg->scalars_mont) ? 1 : 0;
+    ZK_HIP(hipMalloc(&S->d_sc, n * 32 + 16));
+    int rc = acquire_slot(&S->slot);
+    if (rc == ZK_OK && n && hipMemcpyAsync(S->d_sc, scalars, n * 32, hipMemcpyHostToDevice, S->slot->stream) != hipSuccess) rc = set_err(ZK_ERR_HIP, "upload of the scalars failed");
+    if (rc == ZK_OK && hipStreamSynchronize(S->slot->stream) != hipSuccess) rc = set_err(ZK_ERR_HIP, "upload of the scalars failed");  // the caller's slice is not ours after the call
+    if (rc != ZK_OK) {
+        if (S->slot) release_slot(S->slot);
+        (void)hipFree(S->d_sc);
+        return rc;
+    }
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    *handle = hmake(g_next_ps++);
+    g_ps[*handle] = S;
+    return ZK_OK;
+}
+int zk_bn254_scalars_free(uint64_t handle) {
+    ZK_ON_ENTRY_OF(handle);
+    std::shared_ptr<PreparedScalars> S;
+    {
+        std::lock_guard<std::mutex> lk(g_ps_mu);
+        auto it = g_ps.find(handle);
+        if (it == g_ps.end()) return set_err(ZK_ERR_HANDLE, "unknown scalars handle %llu", (unsigned long long)handle);
+        S = it->second;
+        g_ps.erase(it);
+    }
+    std::lock_guard<std::mutex> lk(S->mu);  // MSMs in flight against it finish first
+    (void)hipStreamSynchronize(S->slot->stream);
+    for (auto& g : S->geos) msm_prep_release(&g.prep);
+    release_slot(S->slot);
+    (void)hipFree(S->d_sc);
+    return ZK_OK;
+}
+// out = sum_{i >= skip} scalars[i] * bases[bases_offset + (i - skip)]   (skip: Groth16's K pairs with the wire values from the first private wire on)
+int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t scalars_handle, size_t skip, const zk_msm_cfg* cfg, void* out) {
+    if (!out) return set_err(ZK_ERR_ARG, "null pointer");
+    if (md_is_composite(bases)) return set_err(ZK_ERR_ARG, "prepared scalars pair with bases on ONE device entry (register them with the process default on a single entry)");
+    ZK_ON_ENTRY_OF(bases);
+    if (hentry(scalars_handle) != hentry(bases)) return set_err(ZK_ERR_ARG, "the scalars live on device entry %d, the bases on entry %d", hentry(scalars_handle), hentry(bases));
+    ZK_TRY(check_cfg(cfg));
+    Bases b;
+    {
+        std::lock_guard<std::mutex> lk(g_bases_mu);
+        auto it = g_bases.find(bases);
+        if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)bases);
+        b = it->second;
+    }
+    std::shared_ptr<PreparedScalars> S;
+    {
+        std::lock_guard<std::mutex> lk(g_ps_mu);
+        auto it = g_ps.find(scalars_handle);
+        if (it == g_ps.end()) return set_err(ZK_ERR_HANDLE, "unknown scalars handle %llu", (unsigned long long)scalars_handle);
+        S = it->second;
+    }
+    if (skip > S->n) return set_err(ZK_ERR_LEN, "len(points) != len(scalars): the first scalar %zu is beyond the %zu registered", skip, S->n);
+    const size_t n = S->n - skip;
+    if (bases_offset + n > b.n) return set_err(ZK_ERR_LEN, "len(points) != len(scalars): offset %zu + n %zu exceeds the %zu registered bases", bases_offset, n, b.n);
+    zk_msm_cfg c1 = cfg ? *cfg : zk_msm_cfg{0, 0, 0, 0};
+    c1.scalars_mont = S->mont;  // the form they were registered in
+    const size_t esz = b.is_g2 ? 128 : 64;
+    if (!n) { memset(out, 0, esz); return ZK_OK; }
+    if (!b.d_table || c1.window_bits) {  // no window table to share a recoding through: the plain method on the resident scalars (still no upload)
+        return msm_bases(bases, bases_offset, (const char*)S->d_sc + skip * 32, n, &c1, out, hipMemcpyDeviceToDevice);
+    }
+    // the recoding for this table geometry: found, or made now from the resident copy (callers that arrive together wait for the first one's)
+    MsmPrep prep;
+    uint32_t skip_below = 0;
+    const char* table = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(S->mu);
+        // a table over the same index space as the scalars (stride == n_scalars, offset 0) shares the recoding of ALL scalars and ignores those below `skip`;
+        // any other pairing recodes scalars [skip, n) against the table's own stride
+        const bool whole = b.tab.stride == S->n && bases_offset + 0 == skip;
+        const size_t g_skip = whole ? 0 : skip;
+        PreparedScalars::Geo* G = nullptr;
+        for (auto& g : S->geos)
+            if (g.c == b.tab.c && g.stride == b.tab.stride && g.skip == g_skip) G = &g;
+        if (!G) {
+            const size_t cnt = S->n - g_skip;
+            size_t np = 0, na1 = 0, na2 = 0;
+            ZK_TRY(msm_prep_need_table(cnt, b.tab, S->slot->stream, &np, &na1, &na2));
+            size_t have = 0;
+            for (auto& g : S->geos) have += g.prep.P.need_prep + 4096;
+            if (S->geos.empty()) ZK_TRY(S->slot->reserve(2 * np + 16384));  // room for a second geometry (K) without moving the first
+            else if (S->slot->arena_off + np + 8192 > S->slot->arena_cap) {
+                // a third geometry, or a larger one: the recodings are rebuilt in a larger arena (nothing may be reading the old ones)
+                ZK_HIP(hipStreamSynchronize(S->slot->stream));
+                ZK_HIP(hipDeviceSynchronize());
+                for (auto& g : S->geos) msm_prep_release(&g.prep);
+                S->geos.clear();
+                S->slot->reset();
+                ZK_TRY(S->slot->reserve(have + 2 * np + 16384));
+            }
+            PreparedScalars::Geo g;
+            g.c = b.tab.c;
+            g.stride = b.tab.stride;
+            g.skip = g_skip;
+            g.table = true;
+            ZK_TRY(msm_prepare_scalars_table(S->slot, S->slot->stream, (const char*)S->d_sc + g_skip * 32, cnt, &c1, b.tab, &g.prep));
+            S->geos.push_back(g);
+            G = &S->geos.back();
+        }
+        prep = G->prep;
+        if (whole) { skip_below = (uint32_t)skip; table = (const char*)b.d_table; }      // index i of the recoding IS the table index
+        else table = (const char*)b.d_table + bases_offset * esz;                         // index i of the recoding is base bases_offset + i
+    }
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    size_t np = 0, na1 = 0, na2 = 0;
+    ZK_TRY(msm_prep_need_table(prep.n, b.tab, st, &np, &na1, &na2));
+    ZK_TRY(g.s->reserve((b.is_g2 ? na2 : na1) + 4096));
+    MsmJob job;
+    int rc;
+    if (b.is_g2) {
+        XYZZ<HFp2> t;
+        rc = msm_g2_accumulate(g.s, st, prep, table, skip_below, &job);
+        if (rc == ZK_OK) rc = msm_g2_finish(job, &t);
+        if (rc == ZK_OK) write_affine(t, (zk_g2_affine*)out);
+    } else {
+        XYZZ<HFp> t;
+        rc = msm_g1_accumulate(g.s, st, prep, table, skip_below, &job);
+        if (rc == ZK_OK) rc = msm_g1_finish(job, &t);
+        if (rc == ZK_OK) write_affine(t, (zk_g1_affine*)out);
+    }
+    if (rc != ZK_OK) (void)hipStreamSynchronize(st);
+    return rc;
+}
+
 int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr* scalars, size_t n, const zk_msm_cfg* cfg, void* out) {
     return msm_bases(handle, offset, scalars, n, cfg, out, hipMemcpyHostToDevice);
 }

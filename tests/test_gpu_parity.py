@@ -959,6 +959,52 @@ def test_groth16_2p20_proof_bytes_vs_oracle():
         assert got == want, "witness-like" if witness else "uniform"
 
 
+def test_prepared_scalars_shared_by_the_multi_exps_of_one_proof():
+    """zk_bn254_scalars_register + zk_bn254_msm_bases_prepared (the inner boundary's form of groth16.Prove's A, B1, K, G2.B MultiExp calls, which pair with the
+    SAME wire values: gnark v0.8.0 groth16 prove.go via main.go:131): one upload, one recoding per table geometry.  Against the oracle's sums and against
+    zk_bn254_msm_bases on the same data: bases registered over the same wires share the recoding (A, B1, G2.B), K -- registered over the private wires only --
+    pairs with the scalars from n_public on (a second recoding from the resident copy), a K registered over ALL wires shares the first one and skips the public
+    ones; bases without window tables; five concurrent threads like upstream's goroutines; length errors are upstream's."""
+    import threading
+    n, npub = 6000, 9
+    w = orc.rand_fr(0x91, n, witness_like=True)
+    pa, pb, pk_ = orc.g1_gen_points(0x92, n), orc.g1_gen_points(0x93, n), orc.g1_gen_points(0x94, n)
+    p2 = orc.g2_gen_points(0x95, n)
+    want = dict(a=orc.g1_msm(pa, w), b=orc.g1_msm(pb, w), k=orc.g1_msm(pk_[npub:], w[npub:]), b2=orc.g2_msm(p2, w))
+    for tb in (8, -1):  # window tables (c = 8 forced: tables at this size) / none
+        A, B, K = zb.ResidentBases(pa, table_window_bits=tb), zb.ResidentBases(pb, table_window_bits=tb), zb.ResidentBases(pk_[npub:], table_window_bits=tb)
+        Kall, B2 = zb.ResidentBases(pk_, table_window_bits=tb), zb.ResidentBases(p2, is_g2=True, table_window_bits=tb)
+        S = zb.PreparedScalars(w, MONT)
+        got = dict(a=A.multi_exp_prepared(S), b=B.multi_exp_prepared(S), k=K.multi_exp_prepared(S, skip=npub), b2=B2.multi_exp_prepared(S))
+        for key in want:
+            assert (got[key] == want[key]).all(), (tb, key)
+        assert (Kall.multi_exp_prepared(S, skip=npub, offset=npub) == want["k"]).all(), tb        # shares the recoding of all wires
+        assert (A.multi_exp_prepared(S) == A.multi_exp(w, MONT)).all()
+        assert (A.multi_exp_prepared(S, skip=100, offset=40) == A.multi_exp(w[100:], MONT, offset=40)).all()
+        res = {}
+        jobs = [("a", A, 0, 0), ("b", B, 0, 0), ("k", K, npub, 0), ("b2", B2, 0, 0), ("k2", Kall, npub, npub)]
+        S2 = zb.PreparedScalars(w, MONT)  # fresh: the five arrive together at an unprepared handle
+        th = [threading.Thread(target=lambda j=j: res.__setitem__(j[0], j[1].multi_exp_prepared(S2, skip=j[2], offset=j[3]))) for j in jobs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert all((res[k2] == want[k2 if k2 != "k2" else "k"]).all() for k2 in res) and len(res) == 5, tb
+        with pytest.raises(ValueError):
+            K.multi_exp_prepared(S)            # n scalars against n - n_public bases: upstream's length error
+        with pytest.raises(ValueError):
+            A.multi_exp_prepared(S, skip=n + 1)
+        for h in (S, S2, A, B, K, Kall, B2):
+            h.free()
+    # regular-form scalars (upstream's zero-value config) are registered in that form
+    w_reg = orc.rand_fr(0x96, 300)
+    A = zb.ResidentBases(pa[:300], table_window_bits=8)
+    S = zb.PreparedScalars(w_reg, zk.MultiExpConfig())
+    assert (A.multi_exp_prepared(S) == A.multi_exp(w_reg, zk.MultiExpConfig())).all()
+    S.free()
+    A.free()
+
+
 def test_groth16_2p24_proof_bytes_vs_oracle():
     """The metric's second size against the ORACLE, not against the library itself (BASELINE.json metric "at 2^20 / 2^24 constraints"): the 128 proof bytes of
     the synthetic 2^24-constraint instance bench.py measures -- resident key with c = 22 window tables (84 GB), the whole single-call schedule -- equal the
