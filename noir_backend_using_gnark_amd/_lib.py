@@ -79,7 +79,7 @@ SYMBOLS = [
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_profile_host", "zk_selftest_host",
     "zk_init_devices", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
-    "zk_acir_public_witnesses", "zk_export_cache_info", "zk_export_cache_clear", "zk_bn254_plonk_pk_bytes",
+    "zk_acir_public_witnesses", "zk_acir_lower_resident", "zk_export_cache_info", "zk_export_cache_clear", "zk_bn254_plonk_pk_bytes",
 ]
 
 _lib = None

@@ -430,6 +430,15 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
     return ZK_OK;
 }
 
+// Lowers a circuit text into the resident cache without touching a device (a caller that has other start-up work in flight -- the shim's SRS load -- runs this
+// beside it): the zk_plonk_prove_with_pk / zk_acir_public_witnesses that follows finds it by content key.  The lowering is keyed by device entry too: this is for
+// the entry the calling thread is on.
+int zk_acir_lower_resident(const char* acir_json, size_t acir_len, size_t n_values, int layout) {
+    if (!acir_json) return set_err(ZK_ERR_ARG, "null pointer");
+    std::shared_ptr<Lowered> L;
+    return lowered_get(acir_json, acir_len, n_values, layout, &L, nullptr);
+}
+
 // The public inputs of a circuit as the verifier needs them: out[k] = 0-based index, into the witness-value vector, of public variable k (HandleValues'
 // first loop, common.go:45-60).  *n_public comes back even when cap is too small (ZK_ERR_ARG then).  Uses the resident lowering of the text when there is one.
 int zk_acir_public_witnesses(const char* acir_json, size_t acir_len, size_t n_values, int layout, uint32_t* out, size_t cap, size_t* n_public) {

@@ -27,6 +27,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "zkmi.h"
@@ -103,13 +104,8 @@ std::string srs_path() {  // os.UserConfigDir() on Linux: $XDG_CONFIG_HOME, else
     }
     return dir + "/noir-lang/srs.hex";
 }
-// Text that hex.DecodeString accepts (LoadSRS: common.go:96-99): only then does the reference keep the file.
-bool is_hex_text(const std::string& t) {
-    if (t.empty() || (t.size() & 1)) return false;
-    for (unsigned char c : t)
-        if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F'))) return false;
-    return true;
-}
+// Text that hex.DecodeString accepts (LoadSRS: common.go:96-99): only then does the reference keep the file.  64 MB for the reference's 1,000,000 points.
+bool is_hex_text(const std::string& t) { return !t.empty() && !(t.size() & 1) && zkmi::all_hex(t.data(), t.size()); }
 void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
     std::lock_guard<std::mutex> lk(g_srs.mu);
     if (!g_srs.ready) {
@@ -193,11 +189,28 @@ char* plonk_prove(GoString acir, View values, const char* pk_hex, size_t pk_len,
 
 extern "C" {
 
+// The first call of a process: the HIP runtime starts, srs.hex is read and decoded and its window tables are built (0.4 s of driver and GPU work) -- on a
+// thread of its own, while this one reads the circuit text (0.2 s of one host core for 2^19 opcodes, no GPU involved): zk_acir_lower_resident leaves the
+// lowered circuit where the prover's lookup by content key finds it.  Later calls find both resident.
+void load_srs_and_lower(GoString acirJSON, View values, uint64_t* srs, zk_g2_affine g2[2]) {
+    bool first;
+    {
+        std::lock_guard<std::mutex> lk(g_srs.mu);
+        first = !g_srs.ready;
+    }
+    if (!first) { try_load_srs(srs, g2); return; }
+    std::thread loader([&] { try_load_srs(srs, g2); });  // failures end the process (log.Fatal), from whichever thread
+    size_t n_values = 0;
+    if (zkmi::count_from_hex(values.p, values.n, &n_values)) (void)zk_acir_lower_resident(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE);  // errors resurface in the call proper
+    loader.join();
+}
+
 char* PlonkProveWithPK(GoString acirJSON, GoString encodedValues, GoString encodedProvingKey) {
     uint64_t srs;
     zk_g2_affine g2[2];
-    try_load_srs(&srs, g2);
-    return plonk_prove(acirJSON, unquoted(encodedValues), encodedProvingKey.p, (size_t)encodedProvingKey.n, 0, srs);
+    const View values = unquoted(encodedValues);
+    load_srs_and_lower(acirJSON, values, &srs, g2);
+    return plonk_prove(acirJSON, values, encodedProvingKey.p, (size_t)encodedProvingKey.n, 0, srs);
 }
 
 KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {

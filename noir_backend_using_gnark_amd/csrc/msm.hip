@@ -1911,7 +1911,7 @@ static int bases_register(const void* points, size_t n, int is_g2, uint64_t* han
     ZK_TRY(ensure_init());
     if (md_default_mask()) {  // the process named several GPUs: bases of a size that pays for it are kept by range on all of them (a composite handle)
         std::vector<int> ents;
-        ZK_TRY(md_entries_for(0, n, (size_t)1 << 17, &ents));
+        ZK_TRY(md_entries_for(0, n, (size_t)1 << 16, &ents));
         if (ents.size() > 1) return md_bases_register(points, n, is_g2, kind == hipMemcpyDeviceToDevice, table_c, ents, handle);
     }
     return bases_register_here(points, n, is_g2, handle, kind, table_c);
@@ -2141,10 +2141,10 @@ int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t sc
     const char* table = nullptr;
     {
         std::lock_guard<std::mutex> lk(S->mu);
-        // a table over the same index space as the scalars (stride == n_scalars, offset 0) shares the recoding of ALL scalars and ignores those below `skip`;
-        // any other pairing recodes scalars [skip, n) against the table's own stride
-        const bool whole = b.tab.stride == S->n && bases_offset + 0 == skip;
-        const size_t g_skip = whole ? 0 : skip;
+        // one recoding per (window width, row stride, first scalar): the recoded values are table indices w * stride + i, i counted from the first scalar, so
+        // every base array registered with that stride shares it -- whatever its bases_offset, which only moves the table pointer.  (The accumulate kernels'
+        // skip_below compares whole table indices: it cannot drop the first scalars of rows w > 0, so a `skip` is a recoding of its own.)
+        const size_t g_skip = skip;
         PreparedScalars::Geo* G = nullptr;
         for (auto& g : S->geos)
             if (g.c == b.tab.c && g.stride == b.tab.stride && g.skip == g_skip) G = &g;
@@ -2174,8 +2174,7 @@ int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t sc
             G = &S->geos.back();
         }
         prep = G->prep;
-        if (whole) { skip_below = (uint32_t)skip; table = (const char*)b.d_table; }      // index i of the recoding IS the table index
-        else table = (const char*)b.d_table + bases_offset * esz;                         // index i of the recoding is base bases_offset + i
+        table = (const char*)b.d_table + bases_offset * esz;  // index i of the recoding is base bases_offset + i
     }
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));

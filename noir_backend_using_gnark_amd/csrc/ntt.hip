@@ -944,7 +944,7 @@ int ntt_shard_step(Slot* s, hipStream_t st, int step, Fr* a, unsigned logD, unsi
     ZK_TRY(get_shard_tables(s, st, dD, logD, logg, rank, &tb));
     if (coset) {
         std::lock_guard<std::mutex> lk(g_shard_mu);
-        ShardTables& t = g_shard_tables[((uint64_t)logD << 32) | ((uint64_t)logg << 16) | rank];
+        ShardTables& t = g_shard_tables[((uint64_t)current_entry() << 48) | ((uint64_t)logD << 32) | ((uint64_t)logg << 16) | rank];  // the key of get_shard_tables
         if (!t.coset_nat) {
             ZK_TRY(make_pow_table(s, st, &t.coset_nat, M, logD, dD->coset, HFr::one(), 0, (size_t)rank * M));
             ZK_TRY(make_pow_table(s, st, &t.coset_rev, M, logD, dD->coset, HFr::one(), 1, (size_t)rank * M));

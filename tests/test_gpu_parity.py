@@ -963,8 +963,8 @@ def test_prepared_scalars_shared_by_the_multi_exps_of_one_proof():
     """zk_bn254_scalars_register + zk_bn254_msm_bases_prepared (the inner boundary's form of groth16.Prove's A, B1, K, G2.B MultiExp calls, which pair with the
     SAME wire values: gnark v0.8.0 groth16 prove.go via main.go:131): one upload, one recoding per table geometry.  Against the oracle's sums and against
     zk_bn254_msm_bases on the same data: bases registered over the same wires share the recoding (A, B1, G2.B), K -- registered over the private wires only --
-    pairs with the scalars from n_public on (a second recoding from the resident copy), a K registered over ALL wires shares the first one and skips the public
-    ones; bases without window tables; five concurrent threads like upstream's goroutines; length errors are upstream's."""
+    pairs with the scalars from n_public on (a second recoding from the resident copy, no second upload), also against a K registered over ALL wires; bases
+    without window tables; five concurrent threads like upstream's goroutines; length errors are upstream's."""
     import threading
     n, npub = 6000, 9
     w = orc.rand_fr(0x91, n, witness_like=True)
@@ -978,7 +978,7 @@ def test_prepared_scalars_shared_by_the_multi_exps_of_one_proof():
         got = dict(a=A.multi_exp_prepared(S), b=B.multi_exp_prepared(S), k=K.multi_exp_prepared(S, skip=npub), b2=B2.multi_exp_prepared(S))
         for key in want:
             assert (got[key] == want[key]).all(), (tb, key)
-        assert (Kall.multi_exp_prepared(S, skip=npub, offset=npub) == want["k"]).all(), tb        # shares the recoding of all wires
+        assert (Kall.multi_exp_prepared(S, skip=npub, offset=npub) == want["k"]).all(), tb
         assert (A.multi_exp_prepared(S) == A.multi_exp(w, MONT)).all()
         assert (A.multi_exp_prepared(S, skip=100, offset=40) == A.multi_exp(w[100:], MONT, offset=40)).all()
         res = {}
