@@ -1362,6 +1362,22 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     hipStream_t sa = j0->chain ? j0->chain : sts[0];
     if (R.ready) ZK_HIP(hipStreamWaitEvent(sa, R.ready, 0));
     if (j0->gate_acc) ZK_HIP(hipStreamWaitEvent(sa, j0->gate_acc, 0));
+    // Independent callers (the MultiExp calls upstream issues from concurrent goroutines) pass through a turnstile per device entry: their accumulate kernels
+    // -- each of which fills the machine -- run one at a time in arrival order, gated stream to stream (no host wait), while preparation and reduction tails of
+    // the others run underneath: the schedule of the fused prover, for callers that do not know of each other.
+    struct Turnstile {
+        std::mutex mu;
+        hipEvent_t ring[16] = {};
+        int next = 0;
+        hipEvent_t last = nullptr;
+    };
+    static Turnstile g_turn[MAX_ENTRIES];
+    Turnstile* T = j0->turnstile ? &g_turn[current_entry()] : nullptr;
+    std::unique_lock<std::mutex> turn_lock;
+    if (T) {
+        turn_lock = std::unique_lock<std::mutex>(T->mu);
+        if (T->last) ZK_HIP(hipStreamWaitEvent(sa, T->last, 0));
+    }
     // ---- 5. accumulate
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
     const unsigned full_grid = (unsigned)((max_tasks + 255) / 256);
@@ -1389,6 +1405,14 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     }
 #endif
     if (!launched) ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
+    if (T) {
+        hipEvent_t& e = T->ring[T->next];
+        if (!e) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(e, sa));  // re-recording is safe: a stream that already waits on the event waits for the recording it saw
+        T->last = e;
+        T->next = (T->next + 1) % 16;
+        turn_lock.unlock();
+    }
     bool want = j0->chain != nullptr || nb > 1;
     for (int b = 0; b < nb; b++) want = want || jobs[b]->want_done;
     if (want) {
@@ -2010,6 +2034,7 @@ static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t
         MsmPrep prep;
         ZK_TRY(msm_prepare_scalars_table(g.s, st, d_sc, n, cfg, b.tab, &prep));
         MsmJob job;
+        job.turnstile = kind == hipMemcpyHostToDevice;  // host-slice callers are upstream's goroutines; device-pointer callers (the PLONK prover) schedule themselves
         int rc;
         if (b.is_g2) {
             XYZZ<HFp2> t;
@@ -2183,6 +2208,7 @@ int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t sc
     ZK_TRY(msm_prep_need_table(prep.n, b.tab, st, &np, &na1, &na2));
     ZK_TRY(g.s->reserve((b.is_g2 ? na2 : na1) + 4096));
     MsmJob job;
+    job.turnstile = true;
     int rc;
     if (b.is_g2) {
         XYZZ<HFp2> t;

@@ -72,6 +72,7 @@ struct MsmJob {
     bool want_done = false;
     hipEvent_t acc_done = nullptr;
     hipStream_t chain = nullptr;  // run the accumulate kernel on this stream (reduction tail stays on the job's stream)
+    bool turnstile = false;       // an independent caller: the accumulate kernel takes its turn behind those of other callers on this device entry
     bool quad_tail = false;       // G1: reduction tail with four lanes per point (3x shorter serial chain, ~1.4x the ALU work): for the
                                   // tail nothing else can hide -- the last MSM of a proof
 };
