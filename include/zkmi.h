@@ -127,7 +127,10 @@ int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t sc
 /* ---- NTT: (*fft.Domain).FFT / FFTInverse / fft.BitReverse ------------------------------------------------------
  * In place on a[0 .. 2^log_n).  decimation: ZK_DIF natural in -> bit-reversed out; ZK_DIT bit-reversed in ->
  * natural out.  coset != 0 evaluates on / interpolates from the coset g*H, g = 5 (FrMultiplicativeGen).
- * FFTInverse also scales by 1/N exactly like upstream. */
+ * FFTInverse also scales by 1/N exactly like upstream.
+ * Precondition (as for every zk_fr in this header): the elements are fr.Element images, i.e. Montgomery values REDUCED below r -- what gnark's arithmetic
+ * always produces.  The butterflies keep lazily reduced 29-bit-limb values whose bounds (tools/u29_ntt_model.py) start from an entry below 2.2 r; an image in
+ * [4r, 2^256) handed to the DIT transform without coset meets a subtraction bias of 4 r in the twiddle-free first stage and gives an undefined result. */
 int zk_bn254_ntt(zk_fr *a, uint32_t log_n, int inverse, int decimation, int coset);
 /* the same over several device entries of this process (bit i of device_mask = entry i; 2, 4 or 8 entries): block k of the array goes to entry k over that
  * GPU's own PCIe link, the transform runs block-sharded with two all-to-all transposes between the GPUs.  zk_bn254_ntt == device_mask 0 (process default). */

@@ -7,10 +7,17 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkmi.so")
-# Measurement tooling only (tools/, bench.py --experiments): ZKMI_USE_EXPERIMENTS_LIB=1 loads libzkmi_exp.so, the build with the A/B switches of
-# DESIGN.md compiled in (`make -C csrc EXPERIMENTS=1`).  The product library itself reads no experiment variable (csrc/ctx.hpp).
-if os.environ.get("ZKMI_USE_EXPERIMENTS_LIB") == "1":
-    LIB_PATH = os.path.join(_HERE, "libzkmi_exp.so")
+
+
+def use_library(path: str) -> None:
+    """Measurement tooling only (tools/ab_bench.py, bench.py --lib): bind this process to another build of the library -- libzkmi_exp.so, the build with the A/B
+    switches of DESIGN.md compiled in (`make -C csrc EXPERIMENTS=1`; never shipped, never beside the package in a deployment).  Must be called before the first
+    use; the package itself never looks at the environment for this (the product library reads no experiment variable: csrc/ctx.hpp)."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded from %s" % LIB_PATH)
+    LIB_PATH = path
+
 
 ZK_OK, ZK_ERR_LEN, ZK_ERR_NB_TASKS, ZK_ERR_NO_DEVICE, ZK_ERR_HIP, ZK_ERR_ARG, ZK_ERR_HANDLE, ZK_ERR_BUSY = 0, -1, -2, -3, -4, -5, -6, -7
 

@@ -29,8 +29,8 @@
 #include <tuple>
 #include <type_traits>
 
-#ifdef ZKMI_EXPERIMENTS
-#include <rocprim/rocprim.hpp>  // A/B only (ZKMI_SORT=0 / ZKMI_SCAN=0): the shipped library contains no library kernel
+#ifdef ZKMI_EXPERIMENTS  // rocPRIM headers (A/B only: ZKMI_SORT=0 / ZKMI_SCAN=0 select the library sort / scan)
+#include "experiments/msm_rocprim_include.inc"
 #endif
 
 #include "ctx.hpp"
@@ -52,19 +52,8 @@ struct PingPong {
     uint32_t* alternate() const { return b[cur ^ 1]; }
     void swap() { cur ^= 1; }
 };
-#ifdef ZKMI_EXPERIMENTS
-// rocPRIM's onesweep radix sort, kept for A/B runs only (ZKMI_SORT=0).  ZKMI_SORT_CFG=1 selects 1024-lane tiles of 8 items instead of the library's
-// tuned default for (u32, u32): alone it is 6-17 % faster (tools/sort_bench.hip: 0.323 against 0.391 ms for the 13.6 M digits of a 2^20 MSM).
-using SortWide = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 8,
-                                                                                rocprim::block_radix_rank_algorithm::match>>;
-static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, PingPong& kb, PingPong& vb, size_t n, unsigned key_bits, hipStream_t st) {
-    static const int cfg = ZK_EXP("ZKMI_SORT_CFG", 0);
-    rocprim::double_buffer<uint32_t> k2(kb.current(), kb.alternate()), v2(vb.current(), vb.alternate());
-    hipError_t e = cfg == 1 ? rocprim::radix_sort_pairs<SortWide>(tmp, tmp_bytes, k2, v2, n, 0, key_bits, st) : rocprim::radix_sort_pairs(tmp, tmp_bytes, k2, v2, n, 0, key_bits, st);
-    if (tmp && k2.current() != kb.current()) { kb.swap(); vb.swap(); }
-    return e;
-}
+#ifdef ZKMI_EXPERIMENTS  // rocPRIM sort / scan configuration of the A/B runs
+#include "experiments/msm_rocprim_config.inc"
 #endif
 
 // The hand-written sort of radix.hpp (no workgroup ever waits for another one), same contract as sort_pairs: sorted pairs end up in kb / vb's current buffers.
@@ -279,6 +268,10 @@ __global__ void k_task_plan(const uint32_t* start, uint32_t nb, const uint32_t* 
 // agent-scope atomic by one lane; the last arriver: acquire fence -> plain loads.  All lanes of the workgroup get the same answer.
 __device__ __forceinline__ bool block_arrive_is_last(uint32_t* counter, uint32_t expected) {
     __shared__ uint32_t is_last;
+    // every lane drains ITS OWN stores and no-return atomics first (waves other than lane 0's may still have them in flight: the barrier alone does not
+    // wait for vector memory operations): only then does lane 0's release + arrival say "this workgroup's writes are visible"
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -516,71 +509,8 @@ __device__ __forceinline__ void acc_task(const Affine<F>* __restrict__ pts, XYZZ
         gstore(partial + t, acc29g2_to_xyzz(acc));
     }
 }
-#ifdef ZKMI_EXPERIMENTS  // measured and not adopted: neutral -- the kernel is issue-bound, not latency-bound
-// The same task with the gathers taken off the critical path.  In acc_task every mixed addition starts with two DEPENDENT global loads -- the sorted
-// index, then the point it names (a 64- / 128-byte gather out of a multi-GB window table: an HBM access every time) -- and the wave sits in s_waitcnt for
-// both: with four waves per SIMD that is just hidden on an idle GPU and no longer once a sort or a transform keeps the memory system busy (the kernel's
-// rate inside a proof: 0.67 of the routine's, 0.83 alone).  Here the point of step j + 1 is in flight WHILE step j is computed: it travels by LDS-DMA
-// (global_load_lds_dwordx4: per-lane source address, wave-uniform LDS base + lane * 16 -- a gather into a lane-linear image, no VGPR destination, so the
-// kernel stays under 128 registers and keeps its four waves per SIMD), the index of step j + 2 with it.  One staging slot per lane: it is read into
-// registers (ds_read_b128) before the next DMA is issued.  LDS: 4 KB (G1) / 8 KB (G2) per wave.
-template <class F>
-__device__ __forceinline__ void acc_task_pf(const Affine<F>* __restrict__ pts, XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ vals,
-                                            uint32_t skip_below, uint32_t t, uint32_t begin, uint32_t end, uint4* stage /* this wave's: Q x 64 x 16 B */) {
-    constexpr int Q = sizeof(Affine<F>) / 16;
-    const uint32_t lane = threadIdx.x & 63;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto issue = [&](uint32_t v) {
-        const uint4* g = reinterpret_cast<const uint4*>(pts + (v >> 1));
-#pragma unroll
-        for (int q = 0; q < Q; q++) __builtin_amdgcn_global_load_lds((const void*)(g + q), (lds_ptr)(stage + q * 64), 16, 0, 0);
-    };
-    typename std::conditional<sizeof(F) == sizeof(Fp), Acc29, Acc29G2>::type acc;
-    acc.inf = true;
-    uint32_t j = begin, v_cur = 0, v_next = 0;
-    if (j < end) v_cur = vals[j];
-    if (j + 1 < end) v_next = vals[j + 1];
-    if (j < end && (v_cur >> 1) >= skip_below) issue(v_cur);
-    while (j < end) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the point of step j has landed in the slot, v_next is here
-        const bool use = (v_cur >> 1) >= skip_below;  // scalars shared with an MSM whose first bases do not exist (pk.G1.K vs w)
-        Affine<F> p;
-        if (use) {
-            uint4* d = reinterpret_cast<uint4*>(&p);
-#pragma unroll
-            for (int q = 0; q < Q; q++) d[q] = stage[q * 64 + lane];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is free again
-        uint32_t v_nn = 0;
-        if (j + 2 < end) v_nn = vals[j + 2];
-        if (j + 1 < end && (v_next >> 1) >= skip_below) issue(v_next);
-        if (use) {
-            if (v_cur & 1) p.y = p.y.neg();
-            xyzz_madd29(acc, p.x, p.y);
-        }
-        v_cur = v_next;
-        v_next = v_nn;
-        j++;
-    }
-    if constexpr (sizeof(F) == sizeof(Fp)) gstore(partial + t, acc29_to_packed(acc));
-    else gstore(partial + t, acc29g2_to_xyzz(acc));
-}
-template <class F>
-__global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accumulate_pf(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
-                                                       const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
-                                                       uint32_t max_tasks) {
-    __shared__ uint4 stage[4][sizeof(Affine<F>) / 16 * 64];
-    const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
-    XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
-    const uint32_t skip_below = batch.skip_below[blockIdx.y];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= max_tasks) return;
-    uint32_t key = len_key_sorted[i];
-    if (key == 0xffffffffu) return;
-    uint32_t t = task_sorted[i];
-    uint32_t begin = task_begin[t];
-    acc_task_pf<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key), stage[threadIdx.x >> 6]);
-}
+#ifdef ZKMI_EXPERIMENTS  // accumulate with LDS-DMA prefetch of the next point (round 3: neutral)
+#include "experiments/msm_accumulate_prefetch.inc"
 #endif
 // four waves per SIMD (G1) / two (G2) are part of the kernel's design: say so, so that a change that wants a few registers more shows up as spills in
 // -Rpass-analysis=kernel-resource-usage instead of silently dropping a wave (a shorter formula for the second point of a task asked for 134: DESIGN.md 8)
@@ -600,48 +530,8 @@ __global__ ZK_ACC_BOUNDS void k_accumulate(AccBatch batch, const uint32_t* __res
     uint32_t begin = task_begin[t];
     acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
 }
-#ifdef ZKMI_EXPERIMENTS  // measured and not adopted: 3-7 % slower at every size
-// The same work from a RESIDENT grid of a fixed number of workgroups per CU: every wave draws chunks of 64 consecutive sorted tasks from a counter
-// (longest first, so the machine drains evenly) until the padding behind the real tasks begins.  The point is not the loop but the OCCUPANCY: the mixed
-// addition keeps 97 % of its rate with two waves per SIMD instead of four (tools/ubench2.hip), and a grid that never holds more than that leaves half of
-// every SIMD's registers and wave slots free for the kernels that have to make progress underneath -- the next MSM's sort (whose look-back tiles spin
-// while they wait for a slot), the transforms, the reduction tails.  The one-lane-per-task kernel above fills every slot the moment one frees up.
-template <class F, bool PF>
-__global__ __launch_bounds__(256, (sizeof(F) == sizeof(Fp) ? 4 : 2)) void k_accumulate_resident(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
-                                                             const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
-                                                             uint32_t max_tasks, uint32_t* __restrict__ next_chunk) {
-    __shared__ uint4 stage[PF ? 4 : 1][PF ? sizeof(Affine<F>) / 16 * 64 : 1];  // PF: the LDS-DMA staging slots of acc_task_pf
-    const Affine<F>* __restrict__ pts = (const Affine<F>*)batch.pts[blockIdx.y];
-    XYZZ<F>* __restrict__ partial = (XYZZ<F>*)batch.partial[blockIdx.y];
-    const uint32_t skip_below = batch.skip_below[blockIdx.y];
-    const uint32_t lane = threadIdx.x & 63;
-    // next_chunk == nullptr: STATIC serpentine assignment instead of the counter -- wave v of V takes chunk v in round 0, chunk 2V - 1 - v in round 1, 2V + v in
-    // round 2, ...: with the tasks sorted by decreasing length every wave's total is nearly the same (a 2^20-point MSM has only ~2 tasks per lane, so WHICH two
-    // matters: longest with shortest)
-    const uint32_t V = gridDim.x * 4, v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (uint32_t round = 0;; round++) {
-        uint32_t base = 0;
-        if (next_chunk) {
-            if (lane == 0) base = atomicAdd(next_chunk + blockIdx.y, 64u);
-            base = __builtin_amdgcn_readfirstlane(base);
-        } else {
-            base = ((round & 1) ? (round + 1) * V - 1 - v : round * V + v) * 64u;
-            if (round * V * 64u >= max_tasks) return;
-            if (len_key_sorted[min(round * V * 64u, max_tasks - 1)] == 0xffffffffu) return;  // the whole round is padding
-            if (base >= max_tasks || len_key_sorted[base] == 0xffffffffu) continue;        // this wave's chunk of a partly filled round
-        }
-        if (base >= max_tasks) return;
-        if (len_key_sorted[base] == 0xffffffffu) return;  // the real tasks fill [0, total): everything from here on is padding
-        const uint32_t i = base + lane;
-        if (i >= max_tasks) continue;
-        const uint32_t key = len_key_sorted[i];
-        if (key == 0xffffffffu) continue;
-        const uint32_t t = task_sorted[i];
-        const uint32_t begin = task_begin[t];
-        if constexpr (PF) acc_task_pf<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key), stage[threadIdx.x >> 6]);
-        else acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
-    }
-}
+#ifdef ZKMI_EXPERIMENTS  // accumulate from a resident grid with a chunk counter (round 3: 3-7 % slower)
+#include "experiments/msm_accumulate_resident.inc"
 #endif
 
 // ---------------------------------------------------------------------------------------- tail arithmetic
@@ -909,160 +799,8 @@ __global__ __launch_bounds__(64) void k_reduce_wave(const XYZZ<F>* __restrict__ 
     }
 }
 
-#ifdef ZKMI_EXPERIMENTS  // measured and not adopted: the fused fold is neutral, the fused tail costs 0.6 ms per 2^20 proof
-// ---------------------------------------------------------------------------------------- fused tail
-// Hand-off between waves of ONE kernel without anybody waiting: every producer wave stores its result, releases it and adds 1 to the counter of the
-// group it belongs to; the wave whose add came LAST -- told by the value the add returned -- acquires and goes on with the group's entries.  Nobody spins,
-// so the pattern cannot deadlock however few of the kernel's waves are resident at a time (a grid barrier could, under the accumulate kernel of the next
-// MSM).  Form per MI355X_MICROARCH.md "inter-workgroup visibility": plain stores -> vmcnt(0) -> agent release -> vmcnt(0) (asm: the compiler may drop the
-// wait behind the write-back) -> agent-scope atomic add; the last arriver: agent acquire -> vmcnt(0) -> plain loads.
-__device__ __forceinline__ bool arrive_is_last(uint32_t* counter, uint32_t expected) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t old = 0;
-    if ((threadIdx.x & 63) == 0) old = atomicAdd(counter, 1u);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old + 1 != expected) return false;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return true;
-}
-
-// one wave level on registers: 64 entries (A_l, S_l), lane = l, entries past `cnt` are infinity;
-//   S' = sum_l S_l ;  A' = sum_l A_l + 2^sh * sum_l l * S_l      -> lane 0 holds (y = A', s = S')
-template <class PT>
-__device__ __forceinline__ void wave_level(PT& s, PT& a, PT& y, uint32_t lane, uint32_t sh) {
-    for (unsigned d = 1; d < 64; d <<= 1) {  // inclusive suffix sums: s_l = sum_{u >= l} S_u
-        PT t = s.shfl_down(d);
-        if (lane + d < 64) s.add(t);
-    }
-    y = s;
-    if (lane == 0) y = PT::inf();
-    for (uint32_t i = 0; i < sh; i++) y.dbl();
-    y.add(a);
-    for (unsigned d = 32; d > 0; d >>= 1) {
-        PT t = y.shfl_xor(d);
-        y.add(t);
-    }
-}
-
-// The whole bucket reduction of one MSM in ONE launch (was: level 1, an optional lane-serial level 2 and one launch per wave level, each gated on the one
-// before): wave v takes 64 * m consecutive buckets -- each lane the running sums over m of them (level 1), the wave level on the 64 lane results in
-// registers -- and stores ONE entry; the last of every 64 waves to finish (arrive_is_last) runs the next wave level on the group's entries, and so on until
-// at most host_n entries per window are left.  Needs 64 | B / m (one wave never straddles two windows).
-// Level entries live at lvlA/lvlS + level offset (levels of different groups are alive at the same time); the final entries go to outA / outS.
-template <class F>
-__global__ __launch_bounds__(64) void k_tail_fused(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ task_off, uint32_t B, uint32_t W, uint32_t m,
-                                                   uint32_t sh0, uint32_t host_n, XYZZ<F>* lvlA, XYZZ<F>* lvlS, XYZZ<F>* __restrict__ outA,
-                                                   XYZZ<F>* __restrict__ outS, uint32_t* counters) {
-    prio_hi();
-    typedef TailPt<F> PT;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t N1 = B / m, waves_per_window = N1 / 64;
-    const uint32_t w = blockIdx.x / waves_per_window;
-    uint32_t idx = blockIdx.x % waves_per_window;  // this wave's entry within its window at the current level
-    PT s, a, y;
-    {   // level 1 on the lane's m buckets (weights 1 .. m inside the chunk): a = sum_l (l+1) X_l, s = sum_l X_l
-        const uint32_t b0 = w * B + (idx * 64 + lane) * m;
-        PT run = PT::inf(), acc = PT::inf();
-        for (int l = (int)m - 1; l >= 0; l--) {
-            const uint32_t b = b0 + (uint32_t)l;
-            const uint32_t t0 = task_off[b];
-            if (task_off[b + 1] > t0) run.add(PT::load(partial + t0));
-            acc.add(run);
-        }
-        s = run;
-        a = acc;
-    }
-    uint32_t sh = sh0, N = waves_per_window;
-    size_t level_off = 0;
-    uint32_t* cnt = counters;
-    for (;;) {
-        wave_level(s, a, y, lane, sh);  // lane 0: (y, s) = the entry of this wave at the level with N entries per window
-        sh += 6;
-        XYZZ<F>*dA = lvlA + level_off, *dS = lvlS + level_off;
-        const bool last_level = N <= host_n;
-        if (last_level) { dA = outA; dS = outS; }
-        if (lane == 0) {
-            y.store(dA + (size_t)w * N + idx);
-            s.store(dS + (size_t)w * N + idx);
-        }
-        if (last_level) return;
-        const uint32_t groups = (N + 63) / 64, g = idx / 64, gsize = min(64u, N - g * 64);
-        if (!arrive_is_last(cnt + w * groups + g, gsize)) return;
-        // this wave carries the group on: entries g * 64 + lane of the level just written
-        s = PT::inf();
-        a = PT::inf();
-        if (lane < gsize) {
-            s = PT::load(dS + (size_t)w * N + g * 64 + lane);
-            a = PT::load(dA + (size_t)w * N + g * 64 + lane);
-        }
-        level_off += (size_t)W * N;
-        cnt += W * groups;
-        N = groups;
-        idx = g;
-    }
-}
-
-// The two fold kernels in one launch: the first GIANT_MAX * 64 waves each fold one segment of a listed giant bucket and the last of a giant's segment waves
-// to finish (arrive_is_last) folds the segment heads; every wave then takes its share of the other split buckets.  No launch that only finds out on the
-// device that there is nothing to do.
-template <class F>
-__global__ __launch_bounds__(256) void k_fold_fused(XYZZ<F>* partial, const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ multi_list,
-                                                    const uint32_t* __restrict__ ctl, uint32_t* giant_cnt) {
-    prio_hi();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-    const uint32_t ng = min(ctl[4], GIANT_MAX);
-    for (uint32_t item = gw; item < ng * 64; item += nwaves) {
-        const uint32_t gi = item / 64, seg = item % 64;
-        const uint32_t b = ctl[8 + gi];
-        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
-        const uint32_t S = giant_seg(t1 - t0);
-        const uint32_t nseg = (t1 - t0 + S - 1) / S;
-        const uint32_t lo = t0 + seg * S, hi = min(lo + S, t1);
-        if (lo >= t1) continue;
-        if (hi - lo >= 2) {
-            TailPt<F> acc = TailPt<F>::inf();
-            for (uint32_t t = lo + lane; t < hi; t += 64) acc.add(TailPt<F>::load(partial + t));
-            const uint32_t cnt = min(hi - lo, 64u);
-            unsigned first = 32;
-            while (first >= cnt && first > 0) first >>= 1;
-            for (unsigned d = first; d > 0; d >>= 1) {
-                TailPt<F> o = acc.shfl_down(d);
-                if (lane < d) acc.add(o);
-            }
-            if (lane == 0) acc.store(partial + lo);
-        }
-        if (!arrive_is_last(giant_cnt + gi, nseg)) continue;
-        TailPt<F> acc = TailPt<F>::inf();
-        if (lane < nseg) acc = TailPt<F>::load(partial + t0 + lane * S);
-        unsigned first = 32;
-        while (first >= nseg && first > 0) first >>= 1;
-        for (unsigned d = first; d > 0; d >>= 1) {
-            TailPt<F> o = acc.shfl_down(d);
-            if (lane < d) acc.add(o);
-        }
-        if (lane == 0) acc.store(partial + t0);
-    }
-    const uint32_t nm = ctl[0];
-    for (uint32_t mi = gw; mi < nm; mi += nwaves) {
-        const uint32_t b = multi_list[mi];
-        const uint32_t t0 = task_off[b], t1 = task_off[b + 1];
-        if (t1 - t0 > GIANT_T && __ballot(lane < ng && ctl[8 + lane] == b) != 0) continue;  // a listed giant: folded above
-        TailPt<F> acc = TailPt<F>::inf();
-        for (uint32_t t = t0 + lane; t < t1; t += 64) acc.add(TailPt<F>::load(partial + t));
-        const uint32_t cnt = min(t1 - t0, 64u);
-        unsigned first = 32;
-        while (first >= cnt && first > 0) first >>= 1;
-        for (unsigned d = first; d > 0; d >>= 1) {
-            TailPt<F> o = acc.shfl_down(d);
-            if (lane < d) acc.add(o);
-        }
-        if (lane == 0) acc.store(partial + t0);
-    }
-}
+#ifdef ZKMI_EXPERIMENTS  // single-launch fold / reduction tail (round 3: neutral / +0.6 ms per 2^20 proof)
+#include "experiments/msm_tail_fused.inc"
 #endif
 
 // ---------------------------------------------------------------------------------------- host side
@@ -1180,17 +918,8 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     while (((uint64_t)1 << P->key_bits) <= P->nb) P->key_bits++;
     P->sort_tmp_bytes = rs_plan(P->total, P->key_bits).tmp_bytes;
     P->scan_tmp_bytes = xs_tmp_bytes((size_t)P->nb + 1);
-#ifdef ZKMI_EXPERIMENTS
-    {   // the library's workspaces, when an A/B run selects it
-        PingPong kb(nullptr, nullptr), vb(nullptr, nullptr);
-        size_t lib_sort = 0, lib_scan = 0;
-        hipError_t e = sort_pairs(nullptr, lib_sort, kb, vb, P->total, P->key_bits, st);
-        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs sizing: %s", hipGetErrorString(e));
-        e = rocprim::exclusive_scan(nullptr, lib_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P->nb + 1, rocprim::plus<uint32_t>(), st);
-        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan sizing: %s", hipGetErrorString(e));
-        P->sort_tmp_bytes = std::max(P->sort_tmp_bytes, lib_sort);
-        P->scan_tmp_bytes = std::max(P->scan_tmp_bytes, lib_scan);
-    }
+#ifdef ZKMI_EXPERIMENTS  // which sort the preparation calls
+#include "experiments/msm_sort_select.inc"
 #endif
     P->lvl_elems = (size_t)P->W * P->N1;  // level-1 outputs; later levels are 64x smaller
     P->tsort_tmp_bytes = TS_BINS * 4;  // bin counters of the task counting sort
@@ -1243,15 +972,8 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     // ---- 2. sort (bucket key -> point index|sign)
     PingPong kb(keys0, keys1), vb(vals0, vals1);
     bool own_sort = true, own_scan = true;
-#ifdef ZKMI_EXPERIMENTS
-    own_sort = ZK_EXP("ZKMI_SORT", 1) != 0;  // 0: rocPRIM's onesweep (A/B)
-    own_scan = ZK_EXP("ZKMI_SCAN", 1) != 0;  // 0: rocPRIM's single-pass scan (A/B)
-    if (!own_sort) {
-        if (profiling_on()) prof_begin(s, st, "msm_radix_sort(rocprim)");
-        hipError_t e = sort_pairs(sort_tmp, sort_tmp_bytes, kb, vb, total, key_bits, st);
-        if (profiling_on()) prof_end(s, st);
-        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
-    }
+#ifdef ZKMI_EXPERIMENTS  // the rocPRIM radix-sort call of the A/B runs
+#include "experiments/msm_sort_rocprim_call.inc"
 #endif
     if (own_sort) ZK_TRY(rs_sort_pairs(s, st, sort_tmp, kb, vb, total, key_bits));
     const uint32_t* keys = kb.current();
@@ -1278,13 +1000,8 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
         ZK_LAUNCH(s, st, "msm_task_scan", k_xs_apply, dim3(scan_tiles), dim3(XS_THREADS), 0, (const uint32_t*)ntasks, nb + 1, (const uint32_t*)sums, task_off);
     } else {
     ZK_LAUNCH(s, st, "msm_task_plan", k_task_plan, dim3((nb + 1 + 255) / 256), dim3(256), 0, (const uint32_t*)start, nb, (const uint32_t*)bins, ntasks, multi_list, num_multi);
-#ifdef ZKMI_EXPERIMENTS
-    if (!own_scan) {
-        if (profiling_on()) prof_begin(s, st, "msm_task_scan(rocprim)");
-        hipError_t e = rocprim::exclusive_scan(scan_tmp, scan_tmp_bytes, ntasks, task_off, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
-        if (profiling_on()) prof_end(s, st);
-        if (e != hipSuccess) return set_err(ZK_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
-    }
+#ifdef ZKMI_EXPERIMENTS  // the rocPRIM scan call of the A/B runs
+#include "experiments/msm_scan_rocprim_call.inc"
 #endif
     if (own_scan) ZK_TRY(xs_exclusive_scan(s, st, scan_tmp, ntasks, task_off, (size_t)nb + 1));
     }
@@ -1382,29 +1099,25 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
     const char* acc_name = sizeof(F) == 32 ? "msm_accumulate_g1" : "msm_accumulate_g2";
     const unsigned full_grid = (unsigned)((max_tasks + 255) / 256);
     bool launched = false;
-#ifdef ZKMI_EXPERIMENTS
-    {   // workgroups per CU of the resident form (0 = one lane per task, as many workgroups as there are tasks); LDS-DMA prefetch of the next point
-        static const unsigned wg_g1 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G1", 0), wg_g2 = (unsigned)ZK_EXP("ZKMI_ACC_WG_G2", 0);
-        const unsigned wg_per_cu = sizeof(F) == 32 ? wg_g1 : wg_g2;
-        if (wg_per_cu && full_grid > wg_per_cu * (unsigned)ctx().num_cus) {
-            static const bool serpentine = ZK_EXP("ZKMI_ACC_SERP", 0) != 0;  // static longest-with-shortest assignment instead of the chunk counter
-            uint32_t* next_chunk = serpentine ? nullptr : (uint32_t*)sl[0]->alloc(16);
-            if (!serpentine && !next_chunk) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
-            if (next_chunk) ZK_HIP(hipMemsetAsync(next_chunk, 0, 16, sa));
-            if (ZK_EXP(sizeof(F) == 32 ? "ZKMI_ACC_PF_G1" : "ZKMI_ACC_PF_G2", 0) != 0)
-                ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F, true>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
-                          R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
-            else
-                ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_resident<F, false>), dim3(wg_per_cu * (unsigned)ctx().num_cus, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin,
-                          R.lkeys, R.tids, L, (uint32_t)max_tasks, next_chunk);
-            launched = true;
-        } else if (ZK_EXP(sizeof(F) == 32 ? "ZKMI_ACC_PF_G1" : "ZKMI_ACC_PF_G2", 0) != 0) {
-            ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate_pf<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
-            launched = true;
+#ifdef ZKMI_EXPERIMENTS  // launch of the prefetch / resident accumulate variants
+#include "experiments/msm_accumulate_variants_launch.inc"
+#endif
+    // occupancy cap (experiment ZKMI_ACC_LDS_KB): an unused dynamic-LDS request of k KB per workgroup lets only floor(160 / k) workgroups -- that many waves per
+    // SIMD -- of this kernel be resident per CU, so that the short kernels of other streams (sort, transforms) find registers and wave slots beside it
+    static const unsigned acc_lds_kb = (unsigned)ZK_EXP("ZKMI_ACC_LDS_KB", 0);
+    static const unsigned acc_lds_min_tasks = (unsigned)ZK_EXP("ZKMI_ACC_LDS_MIN_TASKS", 0);
+    unsigned acc_shmem = (acc_lds_kb && max_tasks >= acc_lds_min_tasks) ? acc_lds_kb * 1024u : 0u;
+    if (acc_shmem > 65536u) {
+        static std::mutex attr_mu;
+        static uint64_t attr_done = 0;
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (!(attr_done & ((uint64_t)1 << current_entry()))) {
+            ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_accumulate<Fp>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_accumulate<Fp2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done |= (uint64_t)1 << current_entry();
         }
     }
-#endif
-    if (!launched) ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
+    if (!launched) ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), acc_shmem, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
     if (T) {
         hipEvent_t& e = T->ring[T->next];
         if (!e) ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1427,49 +1140,8 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
         Slot* s = sl[b];
         hipStream_t st = sts[b];
         bool folded = false;
-#ifdef ZKMI_EXPERIMENTS
-        {
-            static const bool fuse_fold = ZK_EXP("ZKMI_FUSE_FOLD", 0) != 0, fuse_tail = ZK_EXP("ZKMI_FUSE_TAIL", 0) != 0;
-            // counters of the fused kernels' hand-offs (per job: the tails of MSMs that share one preparation run side by side): [0, GIANT_MAX) giants,
-            // [64, 64 + TAIL_COUNTERS) groups of the reduction levels
-            constexpr uint32_t TAIL_COUNTERS = 4096;
-            uint32_t* counters = nullptr;
-            if (fuse_fold || fuse_tail) {
-                counters = (uint32_t*)s->alloc((64 + TAIL_COUNTERS) * 4);
-                if (!counters) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (%zu bytes needed)", P.need_acc);
-                ZK_HIP(hipMemsetAsync(counters, 0, (64 + TAIL_COUNTERS) * 4, st));
-            }
-            if (fuse_fold) {
-                ZK_LAUNCH(s, st, "msm_fold", (k_fold_fused<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, (const uint32_t*)R.num_multi, counters);
-                folded = true;
-            }
-            // bucket reduce, fused: level 1 + every wave level in one launch (no lane-serial second level: m = m1 buckets per lane)
-            // ZKMI_FUSE_TAIL=2: only the latency-structured tails (no lane-serial second level: the exposed ones -- Z's in a Groth16 proof, every commitment's in PLONK)
-            static const bool exposed_only = ZK_EXP("ZKMI_FUSE_TAIL", 0) == 2;
-            bool fused_ok = fuse_tail && !(exposed_only && P.m2 > 1) && !(sizeof(F) == sizeof(Fp) && jobs[b]->quad_tail) && N1 % 64 == 0;
-            if (fused_ok) {
-                const uint32_t host_n1 = (W * 64 <= 64) ? 64 : 1;
-                uint32_t N = N1 / 64, sh = 6, ncnt = 0;
-                for (uint32_t mm = m1; mm > 1; mm >>= 1) sh++;
-                for (uint32_t n = N; n > host_n1; n = (n + 63) / 64) ncnt += W * ((n + 63) / 64);
-                if (ncnt <= TAIL_COUNTERS) {
-                    if (!folded) {
-                        ZK_LAUNCH(s, st, "msm_fold_giant", (k_fold_giant<F>), dim3(GIANT_MAX * 16), dim3(256), 0, partial[b], R.task_off, (const uint32_t*)R.num_multi);
-                        ZK_LAUNCH(s, st, "msm_fold_multi", (k_fold_multi<F>), dim3(1024), dim3(256), 0, partial[b], R.task_off, R.multi_list, R.num_multi);
-                    }
-                    ZK_LAUNCH(s, st, "msm_tail", (k_tail_fused<F>), dim3(W * (N1 / 64)), dim3(64), 0, (const Pt*)partial[b], R.task_off, B, W, m1, sh - 6, host_n1, lvlA[b][0],
-                              lvlS[b][0], lvlA[b][1], lvlS[b][1], counters + 64);
-                    while (N > host_n1) { N = (N + 63) / 64; sh += 6; }
-                    jobs[b]->n_final = N;
-                    jobs[b]->sh_final = sh;
-                    const size_t cnt = (size_t)W * N;
-                    ZK_TRY(s->pinned_reserve(2 * cnt * sizeof(Pt)));
-                    ZK_HIP(hipMemcpyAsync(s->pinned, lvlA[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
-                    if (N > 1) ZK_HIP(hipMemcpyAsync((char*)s->pinned + cnt * sizeof(Pt), lvlS[b][1], cnt * sizeof(Pt), hipMemcpyDeviceToHost, st));
-                    continue;
-                }
-            }
-        }
+#ifdef ZKMI_EXPERIMENTS  // launch of the fused fold / tail
+#include "experiments/msm_tail_fused_launch.inc"
 #endif
         if (!folded) {
             ZK_LAUNCH(s, st, "msm_fold_giant", (k_fold_giant<F>), dim3(GIANT_MAX * 16), dim3(256), 0, partial[b], R.task_off, (const uint32_t*)R.num_multi);  // exits at once without giants
@@ -2034,7 +1706,8 @@ static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t
         MsmPrep prep;
         ZK_TRY(msm_prepare_scalars_table(g.s, st, d_sc, n, cfg, b.tab, &prep));
         MsmJob job;
-        job.turnstile = kind == hipMemcpyHostToDevice;  // host-slice callers are upstream's goroutines; device-pointer callers (the PLONK prover) schedule themselves
+        static const bool dev_turnstile = ZK_EXP("ZKMI_DEV_TURNSTILE", 0) != 0;  // A/B: the PLONK prover's thread-per-commit MSMs through the turnstile too
+        job.turnstile = kind == hipMemcpyHostToDevice || dev_turnstile;  // host-slice callers are upstream's goroutines; device-pointer callers (the PLONK prover) schedule themselves
         int rc;
         if (b.is_g2) {
             XYZZ<HFp2> t;

@@ -12,8 +12,9 @@
 //   * the in-place DIF (natural -> bit-reversed) and DIT (bit-reversed -> natural) orders fall out of doing the
 //     butterflies in place -- there is no transpose and no separate permutation pass
 //   * coset / 1/N scalings are folded into the first stage's loads (pre table) or the last stage's stores (post)
-// Roofline: 64 B per element per transform algorithmic (read + write once).  On CDNA4 the transform is VALU-bound
-// (a 254-bit Montgomery product is ~136 quarter-rate v_mad_u64_u32), not HBM-bound -- see DESIGN.md.
+// Roofline: 64 B per element per transform algorithmic (read + write once).  On CDNA4 the transform is VALU-bound, not HBM-bound: a butterfly is 327
+// VALU instructions, 206 of them the 9 x 29-bit Montgomery product (162 v_mad_u64_u32, which issue at the rate of an add-with-carry -- 4.4-4.8 cycles per
+// wave instruction, NOT quarter rate: DESIGN.md 3.1, tools/ubench.hip) -- see DESIGN.md 3.3.
 #include <vector>
 
 #include <algorithm>

@@ -58,7 +58,7 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
 
 def _force_collectives() -> bool:
     """ZKMI_FORCE_COLLECTIVES=1: a world of ONE rank still goes through every collective (RCCL executes them as local copies) -- the only way to run
-    the RCCL call pattern (dtypes, async work handles, stream ordering against libzkmi's kernels) on a one-GPU box; tests/test_gpu_rccl_world1.py."""
+    the RCCL call pattern (dtypes, async work handles, stream ordering against libzkmi's kernels) on a one-GPU box; tests/test_gpu_parity.py::test_rccl_executes_the_collectives_of_the_sharded_proof_world_of_one."""
     return os.environ.get("ZKMI_FORCE_COLLECTIVES", "0") == "1"
 
 

@@ -29,21 +29,22 @@ def main():
             argv = argv[1:]
     out_path, cfgs = args[0], args[1:]
     only = only or ["2p20", "2p24", "plonk", "micro"]
-    flags = ["--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-host-inputs"]
+    flags = ["--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-host-inputs", "--no-export"]
     for k, f in (("2p24", "--no-2p24"), ("plonk", "--no-plonk"), ("micro", "--no-micro")):
         if k not in only:
             flags.append(f)
     with open(out_path, "a") as fo:
         for cfg in cfgs:
             name, _, kv = cfg.partition(":")
-            env = dict(os.environ, ZKMI_USE_EXPERIMENTS_LIB="1")
+            env = dict(os.environ)
+            lib = ["--lib", "exp"]
             for item in filter(None, kv.split(",")):
                 k, _, v = item.partition("=")
                 if k == "LIB":  # LIB=product: the shipped libzkmi.so (no switches), e.g. against an experiments build made with other compile flags
-                    env["ZKMI_USE_EXPERIMENTS_LIB"] = "0" if v == "product" else "1"
+                    lib = [] if v == "product" else ["--lib", "exp"]
                 else:
                     env[k] = v
-            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags, capture_output=True, text=True, env=env, cwd=ROOT)
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags + lib, capture_output=True, text=True, env=env, cwd=ROOT)
             lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode != 0 or not lines:
                 rec = {"name": name, "env": kv, "error": (p.stderr or p.stdout)[-600:]}

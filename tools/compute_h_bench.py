@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stand-alone computeH (zk_bn254_groth16_compute_h_dev: three resident input vectors -> h) at 2^20 / 2^22 / 2^24: best and median wall time of 30 synchronous
-calls, one JSON line.  With ZKMI_USE_EXPERIMENTS_LIB=1 the experiment switches of ntt.hip (ZKMI_H_BATCH, ZKMI_H_FUSE_PW, ...) apply; the sha of h shows that
+calls, one JSON line.  After _lib.use_library(<csrc/build_exp/libzkmi_exp.so>) the experiment switches of ntt.hip (ZKMI_H_BATCH, ZKMI_H_FUSE_PW, ...) apply; the sha of h shows that
 every variant computes the same bytes.
     python tools/compute_h_bench.py [log_n ...]"""
 import ctypes as C
