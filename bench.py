@@ -585,6 +585,55 @@ def export_path_block(log_gates=19, warm_calls=10):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def single_process_main(args, zk, lib):
+    """bench.py --gpus N --single-process: the multi-GPU path a caller of the C ABI gets WITHOUT becoming one process per GPU (the reference is one process:
+    gnark_backend_ffi/main.go:24-37) -- zk_init_devices + a proving key with device_mask, then the ordinary zk_bn254_groth16_prove."""
+    L = lib.lib()
+    N = args.gpus
+    real = max(1, int(L.zk_device_count()))
+    devs = [i % real for i in range(N)]
+    lib.check(L.zk_init_devices((C.c_int * N)(*devs), C.c_size_t(N)))
+    lib.check(L.zk_set_default_devices(C.c_uint32(0)))
+    log_n = args.log_n if args.log_n is not None else 20
+    witness = 1 if args.scalars == "witness" else 0
+    t0 = time.time()
+    inst = Instance(L, lib, zk, log_n, 0, N_PUBLIC, witness, not args.no_tables)
+    single = zk.prove(inst.pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True)
+    inst.pk.free()
+    pk = zk.ProvingKey(log_n, inst.N, N_PUBLIC, inst.small["alpha"], inst.small["beta"], inst.small["delta"], inst.g1_a, inst.g1_b, inst.g1_k.ptr + N_PUBLIC * 64, inst.g1_z,
+                       inst.small2["beta"], inst.small2["delta"], inst.g2_b, bases_on_device=True, precompute_tables=not args.no_tables, device_mask=(1 << N) - 1)
+    setup_s = time.time() - t0
+    step = lambda: zk.prove(pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True)
+    proof = None
+    for _ in range(args.warmup):
+        proof = step()
+    lib.check(L.zk_dev_sync())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    lib.check(L.zk_dev_sync())
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    metric = "Groth16 prove ms + BN254 G1 MSM scalar-muls/sec at 2^20 / 2^24 constraints"
+    try:
+        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        pass
+    out = {"metric": metric, "value": round(inst.g1_units() / (ms * 1e-3), 1), "unit": "G1 scalar-muls/s (whole prove: 4 G1 MSMs + G2 MSM + 7 NTTs per step)",
+           "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "prove_ms": round(ms, 3), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": "groth16_prove_bn254_synthetic_r1cs_2^%d" % log_n, "constraints": inst.N, "wires": inst.N, "n_public": N_PUBLIC, "scalars": args.scalars,
+                      "parallelism": "ONE process, %d device entries behind zk_bn254_groth16_prove (composite key by wire range, block-sharded computeH, peer-copy "
+                                     "transposes, 768-byte records combined on the host)" % N,
+                      "devices": devs, "real_gpus": real, "virtual_entries": real < N},
+           "proof_equals_single_entry": bool(proof == single), "proof_sha": hashlib.sha256(proof).hexdigest()[:16], "setup_s": round(setup_s, 2),
+           "roofline": None, "cpu_baseline": None,
+           "note": "virtual entries share one GPU: this line shows that the path runs and gives the single-GPU bytes, not how it scales" if real < N else None}
+    if proof != single:
+        out["parity_error"] = "the proof over %d device entries differs from the single-entry proof" % N
+    pk.free()
+    print(json.dumps(out))
+
+
 def go_toolchain_probe():
     """is there a Go toolchain (and gnark's module cache) on this box?  If so tools/go_pin checks the committed fixtures against
     the real gnark / gnark-crypto (go.mod:5,23) and the counts are reported; otherwise the oracle stays the checker ("parity unpinned")."""
@@ -627,6 +676,9 @@ def main():
     ap.add_argument("--plonk-log-n", type=int, default=22)
     ap.add_argument("--no-micro", action="store_true", help="skip the configs[4] block (2^26-point G1 MSM + 2^26 NTT) and the SRS-load block")
     ap.add_argument("--micro-log-n", type=int, default=26, help="log2 of the points of the sharded configs[4] block at N > 1 (total over all ranks)")
+    ap.add_argument("--single-process", action="store_true", help="with --gpus N: ONE process drives N device entries through the same zk_bn254_groth16_prove call (csrc/multidev.hip: "
+                    "composite key by wire range, block-sharded computeH, peer-copy transposes); no torch.distributed.  On a box with fewer GPUs the devices are listed "
+                    "repeatedly (virtual entries: correctness of the path, not a scaling figure).  --log-n is the TOTAL size")
     ap.add_argument("--lib", default=None, help="measurement tooling: 'exp' binds this run to libzkmi_exp.so (the A/B switches of DESIGN.md 8), or a path to another build")
     ap.add_argument("--no-export", action="store_true", help="skip the export-path block (PlonkPreprocess -> PlonkProveWithPK -> PlonkVerifyWithVK through libgnark_backend.so at 2^19 gates)")
     ap.add_argument("--export-log-gates", type=int, default=19)
@@ -639,6 +691,8 @@ def main():
     if args.lib:
         _lib.use_library(os.path.join(ROOT, "noir_backend_using_gnark_amd", "csrc", "build_exp", "libzkmi_exp.so") if args.lib == "exp" else args.lib)
 
+    if args.single_process:
+        return single_process_main(args, zk, _lib)
     rank, world, local = par.init_distributed()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
