@@ -351,10 +351,14 @@ int zk_init(int device) {
 // The process's device list: one entry per listed HIP device, in order (n == 0 or devices == NULL: every visible device).  A device may be listed more
 // than once -- each listing is an entry of its own with its own streams and workspaces.  Calling it again may only extend the list.
 int zk_init_devices(const int* devices, size_t n) {
+    const bool first = n_entries() == 0;
+    const auto t0 = std::chrono::steady_clock::now();
     ZK_TRY(init_devices(devices, (int)n));
     const int e = n_entries();
     md_set_default_mask(e >= 32 ? 0xffffffffu : ((1u << e) - 1u));  // calls without a device_mask of their own spread over every entry from here on
-    return ensure_init();
+    const int rc = ensure_init();
+    if (first) prof_host("export.hip_init", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());  // runtime start + streams, once per process
+    return rc;
 }
 int zk_device_entries(int* devices_out, size_t cap) {
     const int n = n_entries();

@@ -118,6 +118,9 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         const int lock_fd = open((path + ".lock").c_str(), O_CREAT | O_RDWR, 0644);
         if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
         struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); } } } unlock{lock_fd};
+        // every visible GPU becomes a device entry of this process (HIP_VISIBLE_DEVICES restricts them): on a multi-GPU node the SRS below is then kept by range on
+        // all of them and every commitment of the prover is one partial per GPU (csrc/multidev.hip) -- nothing above this library changes; one GPU: one entry, as before
+        must(zk_init_devices(nullptr, 0), "zk_init_devices");
         Lap lap;
         std::string text;
         if (FILE* f = fopen(path.c_str(), "rb")) {  // 64 MB of text for the reference's 1,000,000 points: sized once, read in one piece

@@ -354,6 +354,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotArgs A) {
 // (w << 5) + (gamma << 5) + u29r_mul(x << 5, beta << 5) -- and no in-register shift is ever needed.  Sums are plain limb additions; bounds (units of r; checked with
 // tools/u29_ntt_model.py's bound classes): gate < 5.8, first factors < 3.2, 2^261-domain factors < 71.1 (re-normalised once: two operands with
 // 31-bit limbs would overflow a 64-bit column), products < 2.4, the last sum < 8.1, t < 2.6 -> one partial reduction, canonical image out.
+// The schedule below is restated statement by statement in tools/u29_ntt_model.py (quotient_schedule): bound propagation + exactness against the field formula,
+// run by the CPU suite (tests/test_limb_models.py) -- edit both or the suite fails.
 __global__ __launch_bounds__(256, 4) void k_quotient29(QuotArgs A) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t N4 = (size_t)1 << A.logN4;

@@ -169,11 +169,34 @@ def main():
         if real < 2:
             out["skipped"] = "one GPU on this box"
         else:
-            n = 1 << 16
             pts, sc = orc.g1_gen_points(31, 4096), orc.rand_fr(32, 4096)
             want = orc.g1_msm(pts, sc)
             out["msm_all_real_devices"] = bool((zk.g1_multi_exp(pts, sc, config=zk.MultiExpConfig(scalars_mont=True, device_mask=mask_of(real))) == want).all())
-            del n
+            k = 1 << (real.bit_length() - 1)  # the largest power of two of real GPUs: Groth16 and the transform shard over 2, 4 or 8
+            k = min(k, 8)
+            import bench
+            log_n = 12
+            inst = bench.Instance(L, _lib, zk, log_n, 0, bench.N_PUBLIC, 1, True)
+            single = zk.prove(inst.pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True)
+            pk = zk.ProvingKey(log_n, inst.N, bench.N_PUBLIC, inst.small["alpha"], inst.small["beta"], inst.small["delta"], inst.g1_a, inst.g1_b,
+                               inst.g1_k.ptr + bench.N_PUBLIC * 64, inst.g1_z, inst.small2["beta"], inst.small2["delta"], inst.g2_b, bases_on_device=True, device_mask=mask_of(k))
+            out["groth16_%d_real_devices_device_inputs" % k] = zk.prove(pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True) == single
+            ha, hb, hc, hw = (d.to_numpy(np.uint64, (inst.N, 4)) for d in (inst.d_a, inst.d_b, inst.d_c, inst.d_w))
+            out["groth16_%d_real_devices_host_inputs" % k] = zk.prove(pk, ha, hb, hc, hw, inst.r, inst.s) == single
+            pk.free()
+            x = orc.rand_fr(0x99, 1 << 13)
+            y = x.copy()
+            _lib.check(L.zk_bn254_ntt_devices(_lib.vp(y), C.c_uint32(13), C.c_int(1), C.c_int(1), C.c_int(1), C.c_uint32(mask_of(k))))
+            out["ntt_%d_real_devices" % k] = bool((y == orc.fr_ntt(x, True, 1, True)).all())
+            n = 1 << 18
+            dp, ds = _lib.DeviceBuffer(n * 64), _lib.DeviceBuffer(n * 32)
+            _lib.check(L.zk_bn254_g1_generate_dev(C.c_void_p(dp.ptr), C.c_size_t(n), C.c_uint64(0x51), None))
+            _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(ds.ptr), C.c_size_t(n), C.c_uint64(0x52), C.c_int(1), C.c_int(0), None))
+            one = zb.ResidentBases(dp, n=n)
+            _lib.check(L.zk_set_default_devices(C.c_uint32(mask_of(min(real, 4)))))
+            comp = zb.ResidentBases(dp, n=n)
+            _lib.check(L.zk_set_default_devices(C.c_uint32(0)))
+            out["composite_bases_device_scalars_over_peers"] = bool((comp.multi_exp_dev(ds, n, MONT) == one.multi_exp_dev(ds, n, MONT)).all())
     print(json.dumps(out))
 
 

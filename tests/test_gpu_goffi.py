@@ -188,6 +188,12 @@ def test_export_path_worker_cold_and_warm_calls_at_2p10(tmp_path):
     for k in ("hip_init", "srs_file_read", "srs_decode_and_tables", "acir_parse_lower", "pk_text_to_device", "pk_coset_forms", "values_decode", "witness_gather", "plonk_prove"):
         assert k in pr["cold_phases"], k
     assert "acir_parse_lower" not in pr["warm_phases_per_call"] and "pk_text_to_device" not in pr["warm_phases_per_call"]
+    # ZKMI_TABLE_CAP_GB=0 keeps nothing between calls (the reference's behaviour): every call decodes again, the proofs still verify
+    env0 = dict(env, ZKMI_TABLE_CAP_GB="0")
+    r0 = subprocess.run(exe + ["prove", d, "2"], capture_output=True, text=True, timeout=900, env=env0, check=True)
+    p0 = json.loads(r0.stdout.strip().splitlines()[-1])
+    assert p0["verifies"] == 1 and p0["warm_proof_verifies"] == 1 and p0["resident"]["circuits"] == 0 and p0["resident"]["keys"] == 0
+    assert "pk_text_to_device" in p0["warm_phases_per_call"] and "acir_parse_lower" in p0["warm_phases_per_call"]
     # the oracle's Setup under the same SRS gives the same key text
     srs = pl.kzg_srs_from_bytes(bytes.fromhex(open(os.path.join(d, "cfg", "noir-lang", "srs.hex")).read()))
     acir = json.load(open(os.path.join(d, "acir.json")))

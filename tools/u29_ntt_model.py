@@ -391,6 +391,69 @@ def exact_transform_check():
         print("transforms 2^%d with passes %s: DIF, DIT, inverse DIF exact" % (log_n, passes))
 
 
+# ------------------------------------------------------------------------------------------------ the PLONK quotient kernel
+# csrc/plonk.hip k_quotient29: 21 products per coset point in the same arithmetic.  U = u29_unpack of a canonical image (value v * 2^256, limbs < 2^29);
+# L5 = u29r_load5 (the image shifted left by 5: v * 2^261, < 32 r, top limb < 2^27); mul(X, Y5) = X Y5 / 2^261 keeps the 2^256 domain, mul of two L5 values
+# stays in the 2^261 domain (the second and third factors of a and b).  The schedule below is the kernel's, statement by statement: an edit there that is not
+# made here -- or that breaks a 64-bit column, a 32-bit limb or a bias -- fails the CPU suite (tests/test_limb_models.py runs this file).
+ONE_IMG = (1 << 256) % P
+QUOT_INPUTS = ("l", "r", "o", "z", "zs", "x", "ql", "qr", "qm", "qo", "eqk", "s1", "s2", "s3", "l1", "gamma", "beta", "beta_u", "beta_uu", "alpha", "xn_inv")
+
+
+def quotient_schedule(O, U, L5, v):
+    l, r, o, z = U(v["l"]), U(v["r"]), U(v["o"]), U(v["z"])
+    gate = O.mul(l, L5(v["ql"]))
+    gate = O.add(gate, O.mul(r, L5(v["qr"])))
+    gate = O.add(gate, O.mul(O.mul(l, L5(v["r"])), L5(v["qm"])))
+    gate = O.add(gate, O.mul(o, L5(v["qo"])))
+    gate = O.add(gate, U(v["eqk"]))
+    g, g5, x5 = U(v["gamma"]), L5(v["gamma"]), L5(v["x"])
+    a = O.add(O.add(l, g), O.mul(U(v["x"]), L5(v["beta"])))
+    a = O.mul(a, O.wnorm(O.add(O.add(L5(v["r"]), g5), O.mul(x5, L5(v["beta_u"])))))
+    a = O.mul(a, O.wnorm(O.add(O.add(L5(v["o"]), g5), O.mul(x5, L5(v["beta_uu"])))))
+    a = O.mul(a, L5(v["z"]))
+    b5 = L5(v["beta"])
+    b = O.add(O.add(l, g), O.mul(U(v["s1"]), b5))
+    b = O.mul(b, O.wnorm(O.add(O.add(L5(v["r"]), g5), O.mul(L5(v["s2"]), b5))))
+    b = O.mul(b, O.wnorm(O.add(O.add(L5(v["o"]), g5), O.mul(L5(v["s3"]), b5))))
+    b = O.mul(b, L5(v["zs"]))
+    a5 = L5(v["alpha"])
+    one = O.mul(O.sub(z, U(ONE_IMG), 4), L5(v["l1"]))
+    t = O.add(O.mul(one, a5), O.sub(b, a, 4))
+    t = O.add(O.mul(t, a5), gate)
+    t = O.mul(t, L5(v["xn_inv"]))
+    return O.reduce(t), dict(gate=gate, a=a, b=b, one=one, t=t)
+
+
+def check_quotient_bounds():
+    canon = B(P - 1, [MASK] * (NL - 1) + [(P - 1) >> (W * (NL - 1))])
+    shifted = B(32 * (P - 1), [MASK] * (NL - 1) + [(32 * (P - 1)) >> (W * (NL - 1))])
+    out, mid = quotient_schedule(Bound, lambda _v: canon, lambda _v: shifted, {k: None for k in QUOT_INPUTS})
+    assert out.vmax < (1 << 256) and out.k() < 2.02, "the reduced quotient value must pack into 8 words (two conditional subtractions make it canonical)"
+    print("quotient kernel bounds: gate < %.2f r, a, b < %.2f r, (z - 1) L1 < %.2f r, t < %.2f r -> %.2f r after the reduction"
+          % (mid["gate"].k(), max(mid["a"].k(), mid["b"].k()), mid["one"].k(), mid["t"].k(), out.k()))
+
+
+def exact_quotient_check(n=300):
+    rnd = random.Random(0xC0FFEE)
+    inv256 = pow(1 << 256, -1, P)
+    edge = [0, 1, P - 1, P - 2, ONE_IMG, (P - 1) // 2]
+    for it in range(n):
+        v = {k: (rnd.choice(edge) if rnd.random() < 0.15 else rnd.randrange(P)) for k in QUOT_INPUTS}   # canonical Montgomery IMAGES
+        if it == 0:
+            v = {k: P - 1 for k in QUOT_INPUTS}
+        out, _ = quotient_schedule(Exact, unpack_exact, lambda img: limbs(img << 5), v)
+        got = pack_exact(out, True)
+        f = {k: img * inv256 % P for k, img in v.items()}   # the field elements behind the images
+        gate = (f["ql"] * f["l"] + f["qr"] * f["r"] + f["qm"] * f["l"] * f["r"] + f["qo"] * f["o"] + f["eqk"]) % P
+        a = (f["l"] + f["gamma"] + f["beta"] * f["x"]) * (f["r"] + f["gamma"] + f["beta_u"] * f["x"]) * (f["o"] + f["gamma"] + f["beta_uu"] * f["x"]) * f["z"] % P
+        b = (f["l"] + f["gamma"] + f["beta"] * f["s1"]) * (f["r"] + f["gamma"] + f["beta"] * f["s2"]) * (f["o"] + f["gamma"] + f["beta"] * f["s3"]) * f["zs"] % P
+        one = (f["z"] - 1) * f["l1"] % P
+        t = ((one * f["alpha"] + (b - a)) * f["alpha"] + gate) * f["xn_inv"] % P
+        assert got == t * (1 << 256) % P, "quotient schedule differs from the field formula (case %d)" % it
+    print("quotient kernel schedule == field formula on %d random / edge inputs" % n)
+
+
 def print_constants():
     h = lambda l: "{" + ", ".join("0x%08xu" % v for v in l) + "}"
     print("// ---- Fr29 constants (tools/u29_ntt_model.py)")
@@ -408,4 +471,6 @@ if __name__ == "__main__":
     check_bounds()
     exact_reduce_check()
     exact_transform_check()
+    check_quotient_bounds()
+    exact_quotient_check()
     print("OK")
