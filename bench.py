@@ -87,7 +87,8 @@ class Instance:
                                             C.c_size_t(bn), None))
         self.pk = zk.ProvingKey(log_n, N, n_public, self.small["alpha"], self.small["beta"], self.small["delta"], self.g1_a, self.g1_b,
                                 self.g1_k.ptr + n_public * 64, self.g1_z, self.small2["beta"], self.small2["delta"], self.g2_b,
-                                bases_on_device=True, precompute_tables=tables, shard_full_z=shard_full_z, window_shard=window_shard)
+                                bases_on_device=True, precompute_tables=tables, shard_full_z=shard_full_z, window_shard=window_shard,
+                                table_window_bits=int(os.environ.get("ZKMI_BENCH_KEY_C", "0")))  # the variable: window-width sweeps (tooling)
         lib.check(L.zk_dev_sync())
 
     def g1_units(self):
@@ -150,7 +151,7 @@ def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", 
     d_srs = lib.DeviceBuffer((n + 3) * 64)
     a_m = np.frombuffer((alpha * (1 << 256) % R_FR).to_bytes(32, "little"), dtype=np.uint64).copy()
     lib.check(L.zk_bn254_kzg_new_srs_dev(C.c_void_p(d_srs.ptr), C.c_size_t(n + 3), lib.vp(a_m), None, None))
-    srs = zb.ResidentBases(d_srs, n=n + 3)
+    srs = zb.ResidentBases(d_srs, n=n + 3, table_window_bits=int(os.environ.get("ZKMI_BENCH_SRS_C", "0")))  # the variable: window-width sweeps (tooling)
     rng = np.random.default_rng(5)
     xa, xb, xc = (rng.integers(0, nvars, nc, dtype=np.uint32) for _ in range(3))
     dsol = lib.DeviceBuffer(nvars * 32)

@@ -22,6 +22,7 @@
 //   7. host              Horner over the <= 32 window sums + one inversion (HField, host_ff.hpp), like gnark's final step.
 // Roofline: algorithmic bytes = 96 B (G1) / 160 B (G2) per scalar-mul.  The kernel is VALU-bound on CDNA4: each mixed
 // addition is 10 Fp products of ~136 quarter-rate v_mad_u64_u32 each -- see DESIGN.md for both fractions.
+#include <math.h>
 #include <string.h>
 
 #include <algorithm>
@@ -233,8 +234,11 @@ __global__ __launch_bounds__(256) void k_bucket_stats(const uint32_t* __restrict
         if (len) atomicMax(&ctl[1], len);
     }
 }
+// flat_keeps: when NO bucket is longer than the host's task length nothing serialises a lane, and every bucket stays one task.  (Cutting them anyway -- to have
+// more tasks than lanes at 2^17..2^19 points, where there are fewer buckets than lanes -- made half of the buckets two-task buckets and cost a fold pass as long
+// as the accumulate kernel itself: PLONK at 2^19 gates 21.6 -> 17.1 ms, 2^18 16.7 -> 12.3, 2^17 10.6 -> 9.4; profiles/r04_h_plonk_window_sweep.jsonl.)
 __global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t factor, uint32_t cap,
-                           uint32_t* __restrict__ ctl) {
+                           uint32_t flat_keeps, uint32_t* __restrict__ ctl) {
     prio_hi();
     const uint32_t nnz = start[nb], biggest = ctl[1];
     const uint32_t q = (nnz + lanes - 1) / lanes;
@@ -243,6 +247,7 @@ __global__ void k_pick_len(const uint32_t* __restrict__ start, uint32_t nb, uint
     if (ctl[3] > GIANT_MAX) cap = cap > 2048 ? 2048 : cap;       // more giants than k_fold_giant takes: keep their serial folds short
     uint32_t lg = (biggest + cap - 1) / cap;
     uint32_t L = max(max(lw, lg), Lmin);
+    if (flat_keeps && biggest <= Lmax && nb * 8 >= lanes) L = Lmax;  // (with very few buckets -- 2^16 points -- cutting them is still the better deal: 3.5 vs 3.7 ms)
     ctl[2] = min(L, Lmax);
 }
 __global__ void k_task_plan(const uint32_t* start, uint32_t nb, const uint32_t* __restrict__ ctl, uint32_t* ntasks, uint32_t* multi_list, uint32_t* num_multi) {
@@ -287,7 +292,7 @@ __device__ __forceinline__ bool block_arrive_is_last(uint32_t* counter, uint32_t
 
 // k_bucket_stats + k_pick_len in one launch: the last workgroup to arrive picks the task length (ctl[5] counts arrivals)
 __global__ __launch_bounds__(256) void k_bucket_stats_pick(const uint32_t* __restrict__ start, uint32_t nb, uint32_t Lmax, uint32_t Lmin, uint32_t lanes, uint32_t factor,
-                                                           uint32_t cap, uint32_t* __restrict__ ctl) {
+                                                           uint32_t cap, uint32_t flat_keeps, uint32_t* __restrict__ ctl) {
     prio_hi();
     __shared__ uint32_t wmax[4];
     uint32_t len = 0;
@@ -313,7 +318,8 @@ __global__ __launch_bounds__(256) void k_bucket_stats_pick(const uint32_t* __res
         if (2 * lw < Lmax) lw = (factor / 2 ? factor / 2 : 1) * q;
         if (nbig > GIANT_MAX) cap = cap > 2048 ? 2048 : cap;
         const uint32_t lg = (biggest + cap - 1) / cap;
-        const uint32_t L = max(max(lw, lg), Lmin);
+        uint32_t L = max(max(lw, lg), Lmin);
+        if (flat_keeps && biggest <= Lmax && nb * 8 >= lanes) L = Lmax;  // see k_pick_len
         ctl[2] = min(L, Lmax);
     }
 }
@@ -824,12 +830,19 @@ unsigned msm_pick_window(size_t n) {
 // Sizes every buffer of one MSM call; `need` is what the caller must reserve in the slot's arena BEFORE it carves
 // anything else out of it (the arena cannot grow while allocations are live).
 // window size for resident bases with precomputed tables: all windows share one bucket set, so only 2^(c-1) buckets are reduced
+// Cost model: mixed additions (n W, 10 units each) + bucket reduction (34 units per bucket).  Round 4: the additions run at full rate only when there is a bucket
+// -- one task, one lane -- for every lane the machine holds (256 CUs x 1,024); with fewer buckets the accumulate kernel's rate falls like (buckets / lanes)^(1/4)
+// (measured at 2^19 points: 7.5 / 8.3 / 10.4 / 9.8 G additions/s with 2^16 / 2^17 / 2^18 / 2^19 buckets).  Without that term the model picked c = 17 at 2^19
+// points and c = 16 at 2^16, where 19 and 17 are 23-29 % and 17 % faster (Groth16 2^19: 8.4 -> 6.0 ms; profiles/r04_j_groth16_window_sweep.jsonl).
 unsigned msm_pick_window_table(size_t n) {
     unsigned best = 8;
     double bc = 1e300;
+    const double lanes = 256.0 * 1024.0;
     for (unsigned c = 8; c <= 22; c++) {
         unsigned W = (255 + c - 1) / c;
-        double cost = (double)n * W * 10.0 + (double)((size_t)1 << (c - 1)) * 34.0;
+        const double buckets = (double)((size_t)1 << (c - 1));
+        const double eff = buckets >= lanes ? 1.0 : sqrt(sqrt(buckets / lanes));
+        double cost = (double)n * W * 10.0 / eff + buckets * 34.0;
         if (cost < bc) { bc = cost; best = c; }
     }
     return best;
@@ -985,14 +998,15 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     static const bool merged = ZK_EXP("ZKMI_PREP_MERGE", 1) != 0;
     static const uint32_t l_factor = (uint32_t)ZK_EXP("ZKMI_L_FACTOR", 4);     // experiment switches
     static const uint32_t l_cap = (uint32_t)ZK_EXP("ZKMI_L_GIANT_CAP", 16384);
+    static const uint32_t l_flat = (uint32_t)ZK_EXP("ZKMI_L_FLAT_KEEPS", 1);   // 0 = the rule of rounds 1-3 (A/B)
     const unsigned stats_grid = nb / 4096 ? (nb / 4096 > 512 ? 512 : nb / 4096) : 1;
     const unsigned scan_tiles = (unsigned)(((size_t)nb + 1 + XS_TILE - 1) / XS_TILE);
     if (merged && P.Lmin < L) {
         ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats_pick, dim3(stats_grid), dim3(256), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor,
-                  l_cap, bins);
+                  l_cap, l_flat, bins);
     } else {
         if (P.Lmin < L) ZK_LAUNCH(s, st, "msm_bucket_stats", k_bucket_stats, dim3(stats_grid), dim3(256), 0, (const uint32_t*)start, nb, bins);
-        ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, bins);
+        ZK_LAUNCH(s, st, "msm_pick_len", k_pick_len, dim3(1), dim3(1), 0, (const uint32_t*)start, nb, L, P.Lmin, (uint32_t)(ctx().num_cus * 1024), l_factor, l_cap, l_flat, bins);
     }
     if (merged && own_scan) {
         uint32_t* sums = (uint32_t*)scan_tmp;

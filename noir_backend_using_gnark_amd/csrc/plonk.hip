@@ -1230,13 +1230,17 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         B.b[0] = to_dev(bl[2 * k]); B.b[1] = to_dev(bl[2 * k + 1]); B.b[2] = Fr::zero();
         ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, can3[k], (uint32_t)n, B);
     }
-    // the three commitments, while this stream already evaluates l, r, o on the big coset (no challenge needed for that)
+    // the three commitments, while this stream already evaluates l, r, o on the big coset (no challenge needed for that).
+    // Experiment ZKMI_PLONK_DEFER_LRO=1: those three transforms wait for round 2 (one commitment there instead of three here: round 1's three scalar
+    // preparations then do not share the machine with them)
+    static const bool defer_lro = ZK_EXP("ZKMI_PLONK_DEFER_LRO", 0) != 0;
     const Fr* small5[5] = {bl_, br_, bo_, bz_, qkc};
     const size_t len5[5] = {n + 2, n + 2, n + 2, n + 3, n};
     {
         const Fr* polys[3] = {bl_, br_, bo_};
         const size_t lens[3] = {n + 2, n + 2, n + 2};
         ZK_TRY(commit_group(3, polys, lens, c_lro, [&]() -> int {
+            if (defer_lro) return ZK_OK;
             for (int k = 0; k < 3; k++) ZK_TRY(to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P));
             return ZK_OK;
         }));
@@ -1274,6 +1278,8 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         const Fr* polys[1] = {bz_};
         const size_t lens[1] = {n + 3};
         ZK_TRY(commit_group(1, polys, lens, &c_z, [&]() -> int {
+            if (defer_lro)
+                for (int k = 0; k < 3; k++) ZK_TRY(to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P));
             static const bool qk_ntt = ZK_EXP("ZKMI_PLONK_QK_NTT", 0) == 1;  // A/B switch: the literal sequence
             if (!qk_ntt && npub <= PLONK_PI_DIRECT_MAX && logN4 >= 2) {
                 ZK_TRY(to_big_coset(s, st, P->w_big[3], small5[3], len5[3], P));
