@@ -178,8 +178,10 @@ def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", 
         proof = zp.prove(pk, dsol, bl)
     ms = (time.perf_counter() - t0) / reps * 1e3
     lib.profile(False)
-    prof = lib.profile_read()
+    prof, host_sections = lib.split_profile(lib.profile_read())
     out = {"gates": n, "prove_ms": round(ms, 2), "steps": reps, "warmup": 1, "setup_ms": round(t_setup * 1e3, 1), "data_s": round(t_data, 2),
+           # wall clock of the protocol's rounds (each ends in a digest the next challenge needs): where a proof's time goes when its kernels do not fill it
+           "rounds_ms": {k.split(".", 1)[1]: round(v[1] / reps, 3) for k, v in host_sections.items() if k.startswith("plonk.")},
            "kzg_commits_per_proof": "10 (9 as MSMs; the linearised polynomial's digest by linearity from the verifying key and [Z])", "ntt_per_proof": "4 x inverse(n) + 4 x coset(4n) + 1 x coset inverse(4n) (gnark's fifth pair -- qk with the public inputs -- is one element-wise kernel here)",
            "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
            "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]},

@@ -189,3 +189,9 @@ def profile_read() -> dict:
         check(lib().zk_profile_get(C.c_int(i), name, C.c_size_t(128), C.byref(launches), C.byref(ms)))
         out[name.value.decode()] = (int(launches.value), float(ms.value))
     return out
+
+
+def split_profile(prof: dict):
+    """(kernels, host sections): host-side wall-clock sections carry a dotted prefix ("plonk.round1...", "export.pk_content_key") or the "host_" prefix."""
+    host = {k: v for k, v in prof.items() if "." in k or k.startswith("host_")}
+    return {k: v for k, v in prof.items() if k not in host}, host

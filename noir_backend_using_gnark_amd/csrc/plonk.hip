@@ -1184,6 +1184,13 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     Domain* d0;
     ZK_TRY(get_domain(s, st, logn, DOM_TW, &d0));
 
+    // wall clock of the protocol's rounds (reported beside the kernels when profiling is on): each ends in a digest the next challenge needs
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* name) {
+        const auto t1 = std::chrono::steady_clock::now();
+        prof_host(name, std::chrono::duration<double, std::milli>(t1 - lap_t).count());
+        lap_t = t1;
+    };
     // ---- l, r, o
     ZK_LAUNCH(s, st, "plonk_gather_lro", k_gather_lro, dim3(grid_of(n)), dim3(256), 0, d_sol, (const uint32_t*)P->xa, (const uint32_t*)P->xb, (const uint32_t*)P->xc,
               (uint32_t)npub, (uint32_t)P->n_constraints, (uint32_t)n, l_lag, r_lag, o_lag);
@@ -1246,6 +1253,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         }));
     }
 
+    lap("plonk.round1_lro_committed");
     // ---- gamma, beta (transcript "gamma" binds the verifying key and the public inputs, then the three digests)
     FsTranscript fs{"gamma", "beta", "alpha", "zeta"};
     for (const Affine<HFp>* d : {&P->vk_s[0], &P->vk_s[1], &P->vk_s[2], &P->vk_ql, &P->vk_qr, &P->vk_qm, &P->vk_qo, &P->vk_qk}) fs.bind_g1(0, *d);
@@ -1294,6 +1302,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             return ZK_OK;
         }));
     }
+    lap("plonk.round2_z_committed");
     fs.bind_g1(2, c_z);
     HFr alpha = fs.challenge(2);
     if (challenges) alpha = pin[2];
@@ -1338,6 +1347,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         if (chain.ok) ZK_TRY(slot_sync(s, st));  // h_flag (chain mode does not synchronise this stream)
     }
     if (h_flag) return set_err(ZK_ERR_ARG, "the solution does not satisfy the constraint system (the quotient is not a polynomial)");
+    lap("plonk.round3_quotient_committed");
     for (int k = 0; k < 3; k++) fs.bind_g1(3, c_h[k]);
     HFr zeta = fs.challenge(3);
     if (challenges) zeta = pin[3];
@@ -1431,6 +1441,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     }
     ZK_HIP(hipMemcpyAsync(ev + 6, d_vals + 6, 2 * sizeof(Fr), hipMemcpyDeviceToHost, st));
     ZK_TRY(slot_sync(s, st));
+    lap("plonk.round4_evaluations_and_linearised");
     if (chain.ok && !lin_direct) ZK_TRY(chain.finish(1, &c_lin));
     if (!lin_direct && !lin_msm && c_lin.x == c_lin_by_linearity.x && c_lin.y == c_lin_by_linearity.y)
         const_cast<PlonkPK*>(P)->vk_consistent = true;  // (the key's workspace mutex is held for the whole proof) from the next proof on: by linearity
@@ -1467,6 +1478,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             c_zopen = azo.out;
         }
     }
+    lap("plonk.round5_openings_committed");
     // ---- Proof.WriteTo
     uint8_t* o = proof_out;
     for (const Affine<HFp>* d : {&c_lro[0], &c_lro[1], &c_lro[2], &c_z, &c_h[0], &c_h[1], &c_h[2]}) { g1_compress(*d, o); o += 32; }
