@@ -134,11 +134,19 @@ __device__ __forceinline__ T shfl_xor_t(const T& v, unsigned d) {
 // key is the digit magnitude alone and the value indexes the table entry (w, i).
 // Window-sharded tables (row_step > 1): every window is still recoded (the carry runs through all of them) but only the digits of the
 // rows this rank owns -- w = row_first + k * row_step -- are emitted, as row k of the rank's table.
-__global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c, unsigned W, uint32_t* keys, uint32_t* vals,
-                             uint32_t table_stride, unsigned row_first, unsigned row_step) {
+// Several scalar vectors against ONE table (sets > 1; table mode only: PLONK commits l, r, o -- and h1, h2, h3 -- against the same SRS): blockIdx.y is the
+// vector, its digits go to a bucket set of their own (key = v * B + digit - 1) and to its own rows of the key / value arrays, so that ONE sort, ONE task
+// plan and ONE accumulate launch serve all of them and the reduction yields one sum per vector.
+struct DigitSrc {
+    const Fr* p[3];
+};
+__global__ void k_msm_digits(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, uint32_t* keys, uint32_t* vals,
+                             uint32_t table_stride, unsigned row_first, unsigned row_step, unsigned rows_per_set) {
     prio_hi();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const unsigned vec = blockIdx.y, sets = gridDim.y;
+    const Fr* scalars = src.p[vec];
     Fr s;
     {
         const uint4* q = reinterpret_cast<const uint4*>(scalars + i);
@@ -148,7 +156,7 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
     }
     if (mont) s = s.from_mont();
     const uint32_t B = 1u << (c - 1);
-    const uint32_t sentinel = table_stride ? B : W * B;
+    const uint32_t sentinel = table_stride ? sets * B : W * B;
     uint32_t carry = 0;
     unsigned next_row = row_first, wl = 0;  // table mode: the next window this rank owns and its row in the rank's table
     for (unsigned w = 0; w < W; w++) {
@@ -170,8 +178,8 @@ __global__ void k_msm_digits(const Fr* scalars, uint32_t n, int mont, unsigned c
         size_t o = (size_t)w * n + i;
         if (table_stride) {
             if (w != next_row) continue;
-            o = (size_t)wl * n + i;
-            keys[o] = mag ? (mag - 1) : sentinel;
+            o = ((size_t)vec * rows_per_set + wl) * n + i;
+            keys[o] = mag ? (vec * B + (mag - 1)) : sentinel;
             vals[o] = ((wl * table_stride + i) << 1) | neg;
             next_row += row_step;
             wl++;
@@ -849,42 +857,43 @@ unsigned msm_pick_window_table(size_t n) {
 }
 
 template <class F>
-static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab);
+static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab, unsigned sets);
 
 // plans are pure functions of (n, window choice, table geometry, group): memoised, because the rocPRIM workspace-size
 // queries inside cost ~0.1 ms of host time per proof otherwise
 template <class F>
-static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab = nullptr) {
+static int msm_plan(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab = nullptr, unsigned sets = 1) {
     struct Key {
         size_t n, stride;
-        unsigned c_cfg, c_tab, g2, l1, rows;
-        bool operator<(const Key& o) const { return std::tie(n, stride, c_cfg, c_tab, g2, l1, rows) < std::tie(o.n, o.stride, o.c_cfg, o.c_tab, o.g2, o.l1, o.rows); }
+        unsigned c_cfg, c_tab, g2, l1, rows, sets;
+        bool operator<(const Key& o) const { return std::tie(n, stride, c_cfg, c_tab, g2, l1, rows, sets) < std::tie(o.n, o.stride, o.c_cfg, o.c_tab, o.g2, o.l1, o.rows, o.sets); }
     };
     static std::mutex mu;
     static std::map<Key, MsmPlan> memo;
-    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32), tab ? (tab->l1_m | (tab->l2_m << 8)) : 0u, tab ? (tab->row_first | (tab->row_step << 8)) : 0u};
+    Key k{n, tab ? tab->stride : 0, (cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : 0u, tab ? tab->c : 0u, (unsigned)(sizeof(F) != 32), tab ? (tab->l1_m | (tab->l2_m << 8)) : 0u, tab ? (tab->row_first | (tab->row_step << 8)) : 0u, sets};
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = memo.find(k);
         if (it != memo.end()) { *P = it->second; return ZK_OK; }
     }
-    ZK_TRY(msm_plan_uncached<F>(n, cfg, st, P, tab));
+    ZK_TRY(msm_plan_uncached<F>(n, cfg, st, P, tab, sets));
     std::lock_guard<std::mutex> lk(mu);
     memo[k] = *P;
     return ZK_OK;
 }
 
 template <class F>
-static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab) {
+static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, MsmPlan* P, const MsmTable* tab, unsigned sets) {
     typedef XYZZ<F> Pt;
     memset(P, 0, sizeof *P);
     if (n == 0) return ZK_OK;
+    if (sets < 1 || sets > 3 || (sets > 1 && !tab)) return set_err(ZK_ERR_ARG, "a batch of %u scalar vectors needs a window table and at most three vectors", sets);
     if (n > ((size_t)1 << 27)) return set_err(ZK_ERR_ARG, "n = %zu exceeds the per-call limit 2^27 (shard the MSM)", n);
     unsigned c = tab ? tab->c : ((cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : msm_pick_window(n));
     if (c < 2 || c > 22) return set_err(ZK_ERR_ARG, "window_bits = %u outside [2, 22]", c);
     P->c = c;
     P->Wd = (255 + c - 1) / c;
-    P->W = tab ? 1 : P->Wd;
+    P->W = tab ? sets : P->Wd;  // bucket sets: one per window without a table, one per scalar vector with one
     P->row_first = tab ? tab->row_first : 0;
     P->row_step = tab ? (tab->row_step ? tab->row_step : 1) : 1;
     P->Wrows = tab ? tab->rows() : P->Wd;
@@ -892,7 +901,7 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     P->table_stride = tab ? (uint32_t)tab->stride : 0;
     P->B = 1u << (c - 1);
     P->nb = P->W * P->B;
-    P->total = n * P->Wrows;
+    P->total = n * P->Wrows * (tab ? sets : 1);
     if (P->total >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "n * windows = %zu overflows 31-bit positions", P->total);
     if (tab && (size_t)tab->stride * P->Wrows >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "table too large for 31-bit indices");
     // tasks of at most L points: 2x the mean bucket load of a uniform input, at least 32.  The top window only sees digits up to
@@ -946,7 +955,7 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
 
 // Scalar-side half of an MSM on stream `st`: digits, sort, bucket bounds, task plan.  The result only depends on the
 // scalars, so several MSMs over the same scalar vector (Groth16: A, B1, K and G2.B all pair with the wire values) share it.
-static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
+static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out, const DigitSrc* batch = nullptr) {
     out->P = P;
     out->n = n;
     out->empty = (n == 0) || P.total == 0;  // no points, or a window-sharded table of which this rank owns no row
@@ -980,8 +989,12 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     // the counters of step 4 are cleared here, ahead of the chain of dependent launches they would otherwise lengthen
     ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
     // ---- 1. digits
-    ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, (uint32_t)n,
-              (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step);
+    {
+        DigitSrc src = batch ? *batch : DigitSrc{{d_scalars, nullptr, nullptr}};
+        const unsigned sets = P.table_stride ? P.W : 1;
+        ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256), sets), dim3(256), 0, src, (uint32_t)n,
+                  (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step, P.Wrows);
+    }
     // ---- 2. sort (bucket key -> point index|sign)
     PingPong kb(keys0, keys1), vb(vals0, vals1);
     bool own_sort = true, own_scan = true;
@@ -1222,8 +1235,10 @@ static int msm_launch(Slot* s, hipStream_t st, const MsmPlan& P, const Affine<F>
 }
 
 template <class HF>
-static int msm_finish(const MsmJob& job, XYZZ<HF>* total_out) {
+static int msm_finish(const MsmJob& job, XYZZ<HF>* total_out, XYZZ<HF>* per_set = nullptr) {
     *total_out = XYZZ<HF>::inf();
+    if (per_set)
+        for (unsigned w = 0; w < (job.empty ? 3u : job.W); w++) per_set[w] = XYZZ<HF>::inf();
     if (job.empty) return ZK_OK;
     ZK_TRY(slot_sync(job.s, job.st));
     const unsigned N = job.n_final;
@@ -1256,6 +1271,7 @@ static int msm_finish(const MsmJob& job, XYZZ<HF>* total_out) {
             for (unsigned k = 0; k < job.sh_final; k++) acc.dbl();
             val.add(acc);
         }
+        if (per_set) per_set[w] = val;  // a batch of scalar vectors: the bucket sets are separate sums, not windows of one
         tot.add(val);
     }
     *total_out = tot;
@@ -1302,6 +1318,22 @@ int msm_prep_need_table(size_t n, const MsmTable& tab, hipStream_t st, size_t* n
     if (need_acc_g1) *need_acc_g1 = P1.need_acc;
     if (need_acc_g2) *need_acc_g2 = P2.need_acc;
     return ZK_OK;
+}
+// up to three scalar vectors of n elements each against one table: one recoding, one accumulate launch, one sum per vector (msm_g1_finish_batch)
+int msm_prep_need_table_batch(size_t n, unsigned sets, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1) {
+    MsmPlan P1;
+    ZK_TRY(msm_plan<Fp>(n, nullptr, st, &P1, &tab, sets));
+    if (need_prep) *need_prep = P1.need_prep;
+    if (need_acc_g1) *need_acc_g1 = P1.need_acc;
+    return ZK_OK;
+}
+int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out) {
+    if (sets < 1 || sets > 3) return set_err(ZK_ERR_ARG, "a batch holds one to three scalar vectors");
+    MsmPlan P;
+    ZK_TRY(msm_plan<Fp>(n, cfg, st, &P, &tab, sets));
+    DigitSrc src = {{nullptr, nullptr, nullptr}};
+    for (unsigned v = 0; v < sets; v++) src.p[v] = (const Fr*)d_scalars[v];
+    return msm_prepare(s, st, P, src.p[0], n, cfg, out, &src);
 }
 int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out) {
     MsmPlan P;
@@ -1422,6 +1454,10 @@ int msm_g2_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_p
     return msm_accumulate<Fp2>(s, st, R, (const Affine<Fp2>*)d_pts, skip_below, job);
 }
 int msm_g1_finish(const MsmJob& job, XYZZ<HFp>* out) { return msm_finish<HFp>(job, out); }
+int msm_g1_finish_batch(const MsmJob& job, XYZZ<HFp> out[3]) {
+    XYZZ<HFp> unused;
+    return msm_finish<HFp>(job, &unused, out);
+}
 int msm_g2_finish(const MsmJob& job, XYZZ<HFp2>* out) { return msm_finish<HFp2>(job, out); }
 int msm_g1_xyzz(Slot* s, hipStream_t st, const void* d_pts, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, XYZZ<HFp>* out) {
     MsmJob job;

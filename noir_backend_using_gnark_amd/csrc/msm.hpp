@@ -84,6 +84,10 @@ int msm_prep_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need_
 int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out);
 int msm_prep_need_table(size_t n, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2);
 int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out);
+// a batch of up to three scalar vectors (n elements each) against ONE window table: one recoding, one accumulate launch, one sum per vector
+int msm_prep_need_table_batch(size_t n, unsigned sets, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1);
+int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out);
+int msm_g1_finish_batch(const MsmJob& job, XYZZ<HFp> out[3]);
 void msm_prep_release(MsmPrep* R);
 int msm_g1_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);
 int msm_g2_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);

@@ -533,6 +533,61 @@ struct AsyncCommit {
     }
     ~AsyncCommit() { if (th.joinable()) th.join(); }
 };
+// Three commitments against the same SRS whose polynomials exist at the same moment (l, r, o; h1, h2, h3) as ONE multi-scalar multiplication with three bucket
+// sets (msm.hip: k_msm_digits over three scalar vectors, one sort of the 3 x 13 n digits, one task plan, ONE accumulate launch, one reduction per set): three
+// concurrent preparations of ~17 dependent launches each, starving each other and whatever the main stream runs meanwhile, become one; the three accumulate kernels
+// -- which could not share the machine anyway -- become one launch without seams.  Needs the SRS's window table on ONE device entry; otherwise the thread-per-commit
+// path below is used.  Runs on a host thread of its own like AsyncCommit.
+struct BatchCommit3 {
+    std::thread th;
+    int rc = ZK_OK;
+    std::string err;
+    Affine<HFp> out[3];
+    static int run(const PlonkPK* P, const Fr* const* polys, size_t len, Affine<HFp>* outs) {
+        const void* d_table = nullptr;
+        MsmTable tab;
+        size_t nbases = 0;
+        ZK_TRY(bases_table(P->srs, &d_table, &tab, &nbases));
+        if (!d_table || len > nbases) return set_err(ZK_ERR_ARG, "no window table for a batched commitment");
+        SlotGuard g;
+        ZK_TRY(acquire_slot(&g.s));
+        hipStream_t st = g.s->stream;
+        size_t np = 0, na = 0;
+        ZK_TRY(msm_prep_need_table_batch(len, 3, tab, st, &np, &na));
+        ZK_TRY(g.s->reserve(np + na + 65536));
+        const void* sc[3] = {polys[0], polys[1], polys[2]};
+        MsmPrep prep;
+        ZK_TRY(msm_prepare_scalars_table_batch(g.s, st, sc, 3, len, &kMont, tab, &prep));
+        MsmJob job;
+        XYZZ<HFp> t[3];
+        int rc = msm_g1_accumulate(g.s, st, prep, d_table, 0, &job);
+        if (rc == ZK_OK) rc = msm_g1_finish_batch(job, t);
+        if (rc != ZK_OK) (void)hipStreamSynchronize(st);
+        msm_prep_release(&prep);
+        ZK_TRY(rc);
+        for (int k = 0; k < 3; k++) outs[k] = t[k].to_affine();
+        return ZK_OK;
+    }
+    static bool possible(const PlonkPK* P, const size_t* lens) {
+        const void* d_table = nullptr;
+        size_t nbases = 0;
+        return lens[0] == lens[1] && lens[1] == lens[2] && bases_table(P->srs, &d_table, nullptr, &nbases) == ZK_OK && d_table && lens[0] <= nbases;
+    }
+    void start(const PlonkPK* P, const Fr* const* polys, size_t len) {
+        const Fr* p3[3] = {polys[0], polys[1], polys[2]};
+        th = std::thread([this, P, p3, len] {
+            rc = run(P, p3, len, out);
+            if (rc != ZK_OK) err = zk_last_error();
+        });
+    }
+    int join() {
+        if (th.joinable()) th.join();
+        return rc == ZK_OK ? ZK_OK : set_err(rc, "%s", err.c_str());
+    }
+    ~BatchCommit3() { if (th.joinable()) th.join(); }
+};
+static const bool g_plonk_batch3 = ZK_EXP("ZKMI_PLONK_BATCH3", 1) != 0;  // 0: three commitments on three threads (A/B)
+
 // The commitments of one proof as a CHAIN (the schedule of Groth16's msm5): every MSM prepares its scalars (digits, radix sort, task plan --
 // bandwidth-bound) on a stream of its own as soon as its polynomial exists, while the accumulate kernels (ALU-bound, each wants the whole
 // machine) run ONE AT A TIME in issue order, gated by the previous one's completion event; the reduction tails and the next preparation run
@@ -1216,6 +1271,16 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         if (g_plonk_serial) {
             for (int k = 0; k < cnt; k++) ZK_TRY(commit(P, s, st, polys[k], lens[k], &outs[k]));
             return meanwhile();
+        }
+        if (cnt == 3 && g_plonk_batch3 && BatchCommit3::possible(P, lens)) {
+            BatchCommit3 bc;
+            ZK_TRY(slot_sync(s, st));
+            bc.start(P, polys, lens[0]);
+            int rc = meanwhile();
+            const int r2 = bc.join();
+            if (rc == ZK_OK) rc = r2;
+            for (int k = 0; k < 3; k++) outs[k] = bc.out[k];
+            return rc;
         }
         AsyncCommit ac[3];
         ZK_TRY(slot_sync(s, st));
