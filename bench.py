@@ -185,8 +185,11 @@ def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", 
            "kzg_commits_per_proof": "10 (9 as MSMs; the linearised polynomial's digest by linearity from the verifying key and [Z])", "ntt_per_proof": "4 x inverse(n) + 4 x coset(4n) + 1 x coset inverse(4n) (gnark's fifth pair -- qk with the public inputs -- is one element-wise kernel here)",
            "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
            "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]},
-           # every commitment is one accumulate launch over ~n scalars against the SRS's window table; the transforms' passes work on n (small domain) or 4n points
-           "roofline": block_roofline(prof, reps, n, 0, 4 * n, log_n)}
+           # nine commitments of ~n scalars per proof against the SRS's window table; l, r, o and h1, h2, h3 are ONE accumulate launch each (three bucket sets),
+           # so a launch carries 9n / (launches per proof) scalars on average; the transforms' passes work on n (small domain) or 4n points
+           "roofline": block_roofline(prof, reps, 9.0 * n * reps / max(1, prof.get("msm_accumulate_g1", (reps * 9, 0.0))[0]), 0, 4 * n, log_n)}
+    if out["roofline"]:
+        out["roofline"]["scalar_muls_per_proof"] = 9 * n
     # ---- checker (CPU oracle, after the timed region): decode Proof.WriteTo and run plonk.Verify's equations
     from oracle import bn254_ref as ref, plonk_ref as pl
 

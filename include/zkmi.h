@@ -114,6 +114,12 @@ int zk_bn254_bases_register_dev(const void *d_points, size_t n, int is_g2, uint6
  * -1 no tables, else c in [8, 22] (tables at any n: how the tests reach the widths the planner picks at 2^22 .. 2^26 points). */
 int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_device, int table_window_bits, uint64_t *handle);
 int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);
+/* `count` scalar vectors of n elements each against ONE registered base array: out[k] = MultiExp(bases[offset : offset + n], scalars[k]) -- plonk.Prove's
+ * three simultaneous kzg.Commit calls (l, r, o; h1, h2, h3: gnark v0.8.0 backend/plonk/bn254/prove.go, reached from gnark_backend_ffi/backend/plonk/plonk.go:53-73).
+ * With a G1 window table and count <= 3 they are ONE multi-scalar multiplication with a bucket set per vector (one recoding, one accumulate launch); otherwise the
+ * vectors run one after the other.  out: count affine points of the handle's group; the same points as count calls of zk_bn254_msm_bases. */
+int zk_bn254_msm_bases_batch(uint64_t handle, size_t offset, const zk_fr *const *scalars, uint32_t count, size_t n, const zk_msm_cfg *cfg, void *out);
+int zk_bn254_msm_bases_batch_dev(uint64_t handle, size_t offset, const void *const *d_scalars, uint32_t count, size_t n, const zk_msm_cfg *cfg, void *out);
 /* Scalars kept resident and recoded ONCE for every base array they pair with.  groth16.Prove's five MultiExp calls (gnark v0.8.0 groth16 prove.go, reached
  * from gnark_backend_ffi/main.go:131) pair A, B1, K and G2.B with the SAME wire values: through zk_bn254_msm_bases each call uploads the 32 B x n scalars and
  * recodes them (digits, radix sort, task plan).  zk_bn254_scalars_register uploads once (cfg->scalars_mont says which form they are in);

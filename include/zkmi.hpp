@@ -205,6 +205,16 @@ public:
         zk_msm_cfg c = {0, 1, 0, 0};
         return make_error(zk_bn254_msm_bases(handle_, 0, p.data(), p.size(), &c, digest));
     }
+    // the three simultaneous commitments of plonk.Prove's rounds 1 and 3 in one call (zk_bn254_msm_bases_batch): digests[k] = Commit(*polys[k])
+    Error CommitBatch(const std::vector<const fr::Vector*>& polys, zk_g1_affine* digests) const {
+        std::vector<const zk_fr*> p;
+        for (const fr::Vector* v : polys) {
+            if (v->size() > size_ || v->size() != polys[0]->size()) return Error{ZK_ERR_LEN, "kzg: invalid polynomial size (larger than SRS, or the batch is ragged)"};
+            p.push_back(v->data());
+        }
+        zk_msm_cfg c = {0, 1, 0, 0};
+        return make_error(zk_bn254_msm_bases_batch(handle_, 0, p.data(), (uint32_t)p.size(), polys.empty() ? 0 : polys[0]->size(), &c, digests));
+    }
     uint64_t handle() const { return handle_; }
     uint64_t Size() const { return size_; }
     zk_g2_affine G2[2] = {};

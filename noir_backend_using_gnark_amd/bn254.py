@@ -139,6 +139,29 @@ class ResidentBases:
         check(rc)
         return out
 
+    def multi_exp_batch(self, vectors, n: int | None = None, config: MultiExpConfig | None = None, offset: int = 0) -> np.ndarray:
+        """Several scalar vectors of one length against these bases in one call (zk_bn254_msm_bases_batch[_dev]): numpy (n, 4) arrays, or DeviceBuffers / raw
+        device pointers together with n.  Returns (len(vectors), 8 or 16) affine points -- the same as one multi_exp per vector."""
+        cnt = len(vectors)
+        out = np.zeros((cnt, 16 if self.is_g2 else 8), dtype=np.uint64)
+        cfg = (config or MultiExpConfig())._c()
+        on_dev = cnt > 0 and isinstance(vectors[0], (_lib.DeviceBuffer, int))
+        if on_dev:
+            if n is None:
+                raise ValueError("n is required with device-resident scalars")
+            ptrs = (C.c_void_p * cnt)(*[v.ptr if isinstance(v, _lib.DeviceBuffer) else int(v) for v in vectors])
+            rc = lib().zk_bn254_msm_bases_batch_dev(self.handle, C.c_size_t(offset), ptrs, C.c_uint32(cnt), C.c_size_t(n), C.byref(cfg), vp(out))
+        else:
+            keep = [_as_u64(v, 4) for v in vectors]
+            if any(k.shape[0] != keep[0].shape[0] for k in keep):
+                raise ValueError("the scalar vectors of one batch have one length")
+            ptrs = (C.c_void_p * cnt)(*[k.ctypes.data for k in keep])
+            rc = lib().zk_bn254_msm_bases_batch(self.handle, C.c_size_t(offset), ptrs, C.c_uint32(cnt), C.c_size_t(keep[0].shape[0] if cnt else 0), C.byref(cfg), vp(out))
+        if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_NB_TASKS):
+            raise ValueError((lib().zk_last_error() or b"").decode())
+        check(rc)
+        return out
+
     def multi_exp_prepared(self, scalars: "PreparedScalars", skip: int = 0, offset: int = 0, config: MultiExpConfig | None = None) -> np.ndarray:
         """sum_{i >= skip} scalars[i] * bases[offset + i - skip] against scalars that were uploaded and are recoded once (zk_bn254_msm_bases_prepared)."""
         out = np.zeros(16 if self.is_g2 else 8, dtype=np.uint64)

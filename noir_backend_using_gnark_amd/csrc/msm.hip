@@ -1955,4 +1955,69 @@ int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void* d_scalars
     return msm_bases(handle, offset, d_scalars, n, cfg, out, hipMemcpyDeviceToDevice);
 }
 
+// ---- several scalar vectors against ONE registered base array ------------------------------------------------------------------------------------------
+// plonk.Prove commits l, r, o -- and later h1, h2, h3 -- against the same SRS at the same moment (gnark v0.8.0 backend/plonk/bn254/prove.go, reached from
+// gnark_backend_ffi/backend/plonk/plonk.go:53-73).  With a G1 window table on one device entry the `count` (<= 3) multi-exps are ONE multi-scalar
+// multiplication with one bucket set per vector: one digit pass over the vectors, one sort, one task plan, ONE accumulate launch, one reduction per set.
+// Everything else (G2, no table, a composite handle, an explicit window width, count > 3) runs the vectors one after the other through msm_bases: same points out.
+static int msm_bases_batch(uint64_t handle, size_t offset, const void* const* scalars, unsigned count, size_t n, const zk_msm_cfg* cfg, void* out, hipMemcpyKind kind) {
+    if (!count) return ZK_OK;
+    if (!scalars || !out) return set_err(ZK_ERR_ARG, "null pointer");
+    for (unsigned k = 0; k < count; k++)
+        if (n && !scalars[k]) return set_err(ZK_ERR_ARG, "null scalar vector %u", k);
+    ZK_TRY(check_cfg(cfg));
+    bool batched = count >= 2 && count <= 3 && n && !md_is_composite(handle) && !(cfg && cfg->window_bits);
+    Bases b;
+    if (batched) {
+        std::lock_guard<std::mutex> lk(g_bases_mu);
+        auto it = g_bases.find(handle);
+        if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
+        b = it->second;
+        batched = b.d_table && !b.is_g2;
+    }
+    if (!batched) {
+        int is_g2 = 0;
+        size_t nb = 0;
+        ZK_TRY(bases_info(handle, &nb, &is_g2));
+        const size_t osz = is_g2 ? sizeof(zk_g2_affine) : sizeof(zk_g1_affine);
+        for (unsigned k = 0; k < count; k++) ZK_TRY(msm_bases(handle, offset, scalars[k], n, cfg, (char*)out + k * osz, kind));
+        return ZK_OK;
+    }
+    ZK_ON_ENTRY_OF(handle);
+    if (offset + n > b.n) return set_err(ZK_ERR_LEN, "len(points) != len(scalars): offset %zu + n %zu exceeds the %zu registered bases", offset, n, b.n);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    size_t np = 0, na = 0;
+    ZK_TRY(msm_prep_need_table_batch(n, count, b.tab, st, &np, &na));
+    const bool up = kind != hipMemcpyDeviceToDevice;
+    ZK_TRY(g.s->reserve((up ? count * (n * 32 + 1024) : 0) + np + na + 65536));
+    const void* sc[3] = {nullptr, nullptr, nullptr};
+    for (unsigned k = 0; k < count; k++) {
+        if (up) {
+            void* d = g.s->alloc(n * 32 + 16);
+            ZK_HIP(hipMemcpyAsync(d, scalars[k], n * 32, kind, st));
+            sc[k] = d;
+        } else sc[k] = scalars[k];
+    }
+    MsmPrep prep;
+    ZK_TRY(msm_prepare_scalars_table_batch(g.s, st, sc, count, n, cfg, b.tab, &prep));
+    MsmJob job;
+    job.turnstile = up;  // as in msm_bases: host-slice callers are upstream's goroutines
+    XYZZ<HFp> t[3];
+    int rc = msm_g1_accumulate(g.s, st, prep, (const char*)b.d_table + offset * 64, 0, &job);
+    if (rc == ZK_OK) rc = msm_g1_finish_batch(job, t);
+    if (rc != ZK_OK) (void)hipStreamSynchronize(st);
+    msm_prep_release(&prep);
+    ZK_TRY(rc);
+    for (unsigned k = 0; k < count; k++) write_affine(t[k], (zk_g1_affine*)out + k);
+    return ZK_OK;
+}
+int zk_bn254_msm_bases_batch(uint64_t handle, size_t offset, const zk_fr* const* scalars, uint32_t count, size_t n, const zk_msm_cfg* cfg, void* out) {
+    return msm_bases_batch(handle, offset, (const void* const*)scalars, count, n, cfg, out, hipMemcpyHostToDevice);
+}
+int zk_bn254_msm_bases_batch_dev(uint64_t handle, size_t offset, const void* const* d_scalars, uint32_t count, size_t n, const zk_msm_cfg* cfg, void* out) {
+    return msm_bases_batch(handle, offset, d_scalars, count, n, cfg, out, hipMemcpyDeviceToDevice);
+}
+
 }  // extern "C"

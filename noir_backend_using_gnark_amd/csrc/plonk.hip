@@ -544,29 +544,8 @@ struct BatchCommit3 {
     std::string err;
     Affine<HFp> out[3];
     static int run(const PlonkPK* P, const Fr* const* polys, size_t len, Affine<HFp>* outs) {
-        const void* d_table = nullptr;
-        MsmTable tab;
-        size_t nbases = 0;
-        ZK_TRY(bases_table(P->srs, &d_table, &tab, &nbases));
-        if (!d_table || len > nbases) return set_err(ZK_ERR_ARG, "no window table for a batched commitment");
-        SlotGuard g;
-        ZK_TRY(acquire_slot(&g.s));
-        hipStream_t st = g.s->stream;
-        size_t np = 0, na = 0;
-        ZK_TRY(msm_prep_need_table_batch(len, 3, tab, st, &np, &na));
-        ZK_TRY(g.s->reserve(np + na + 65536));
         const void* sc[3] = {polys[0], polys[1], polys[2]};
-        MsmPrep prep;
-        ZK_TRY(msm_prepare_scalars_table_batch(g.s, st, sc, 3, len, &kMont, tab, &prep));
-        MsmJob job;
-        XYZZ<HFp> t[3];
-        int rc = msm_g1_accumulate(g.s, st, prep, d_table, 0, &job);
-        if (rc == ZK_OK) rc = msm_g1_finish_batch(job, t);
-        if (rc != ZK_OK) (void)hipStreamSynchronize(st);
-        msm_prep_release(&prep);
-        ZK_TRY(rc);
-        for (int k = 0; k < 3; k++) outs[k] = t[k].to_affine();
-        return ZK_OK;
+        return zk_bn254_msm_bases_batch_dev(P->srs, 0, sc, 3, len, &kMont, outs);
     }
     static bool possible(const PlonkPK* P, const size_t* lens) {
         const void* d_table = nullptr;

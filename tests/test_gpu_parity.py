@@ -959,6 +959,61 @@ def test_groth16_2p20_proof_bytes_vs_oracle():
         assert got == want, "witness-like" if witness else "uniform"
 
 
+def test_batched_multi_exp_of_several_scalar_vectors_against_one_base_array():
+    """zk_bn254_msm_bases_batch[_dev]: plonk.Prove's three simultaneous kzg.Commit calls (l, r, o; h1, h2, h3 -- gnark v0.8.0 plonk prove.go via
+    backend/plonk/plonk.go:53-73) as ONE multi-scalar multiplication with a bucket set per vector.  Against the oracle and against one zk_bn254_msm_bases
+    call per vector: window tables at two widths (one / three bucket-key sort passes), 2 and 3 vectors, uniform / witness-like / all-zero / equal vectors,
+    offsets, device-resident scalars, regular-form scalars; the sequential fallbacks (no table, G2, explicit window width, four vectors) and the errors."""
+    n = 6000
+    pts = orc.g1_gen_points(0xB1, n)
+    v = [orc.rand_fr(0xB2, n), orc.rand_fr(0xB3, n, witness_like=True), orc.rand_fr(0xB4, n), np.zeros((n, 4), np.uint64)]
+    want = [orc.g1_msm(pts, x) for x in v[:3]]
+    for tb in (0, 8, 16, -1):
+        rb = zb.ResidentBases(pts, table_window_bits=tb)
+        got = rb.multi_exp_batch(v[:3], config=MONT)
+        assert got.shape == (3, 8)
+        for k in range(3):
+            assert (got[k] == want[k]).all(), (tb, k)
+        got = rb.multi_exp_batch([v[1], v[0]], config=MONT)
+        assert (got[0] == want[1]).all() and (got[1] == want[0]).all(), tb
+        got = rb.multi_exp_batch([v[2], v[3], v[2]], config=MONT)  # an all-zero vector (an empty bucket set) between two equal ones
+        assert (got[0] == want[2]).all() and (got[1] == 0).all() and (got[2] == want[2]).all(), tb
+        got = rb.multi_exp_batch([x[:4500] for x in v[:3]], config=MONT, offset=1500)
+        for k in range(3):
+            assert (got[k] == orc.g1_msm(pts[1500:], v[k][:4500])).all(), (tb, k)
+        got = rb.multi_exp_batch([x[:3] for x in v[:3]], config=MONT, offset=n - 3)  # fewer scalars than lanes of one workgroup
+        for k in range(3):
+            assert (got[k] == rb.multi_exp(v[k][:3], MONT, offset=n - 3)).all(), (tb, k)
+        got = rb.multi_exp_batch(v[:4], config=MONT)  # four vectors: one after the other
+        assert (got[3] == 0).all() and all((got[k] == want[k]).all() for k in range(3))
+        got = rb.multi_exp_batch(v[:3], config=zk.MultiExpConfig(scalars_mont=True, window_bits=11))  # plain method asked for
+        assert all((got[k] == want[k]).all() for k in range(3))
+        assert (rb.multi_exp_batch(v[:1], config=MONT)[0] == want[0]).all()
+        assert rb.multi_exp_batch([], config=MONT).shape == (0, 8)
+        reg = [orc.ints_to_limbs(from_mont_limbs(x)) for x in v[:3]]  # upstream's default config: regular form
+        got = rb.multi_exp_batch(reg)
+        assert all((got[k] == want[k]).all() for k in range(3)), tb
+        dv = [_lib.DeviceBuffer.from_numpy(x) for x in v[:3]]
+        got = rb.multi_exp_batch(dv, n=n, config=MONT)
+        assert all((got[k] == want[k]).all() for k in range(3)), tb
+        got = rb.multi_exp_batch([d.ptr + 100 * 32 for d in dv], n=3000, config=MONT, offset=100)
+        for k in range(3):
+            assert (got[k] == orc.g1_msm(pts[100:3100], v[k][100:3100])).all(), (tb, k)
+        with pytest.raises(ValueError):
+            rb.multi_exp_batch(v[:3], config=MONT, offset=1)  # len(points) != len(scalars)
+        with pytest.raises(ValueError):
+            rb.multi_exp_batch([v[0], v[1][:10]], config=MONT)
+        rb.free()
+    p2 = orc.g2_gen_points(0xB5, 4200)
+    rb2 = zb.ResidentBases(p2, is_g2=True)
+    s2 = [orc.rand_fr(0xB6, 4200), orc.rand_fr(0xB7, 4200)]
+    got = rb2.multi_exp_batch(s2, config=MONT)
+    assert got.shape == (2, 16) and all((got[k] == orc.g2_msm(p2, s2[k])).all() for k in range(2))
+    rb2.free()
+    with pytest.raises(_lib.ZkmiError):
+        rb2.multi_exp_batch(s2, config=MONT)  # freed handle
+
+
 def test_prepared_scalars_shared_by_the_multi_exps_of_one_proof():
     """zk_bn254_scalars_register + zk_bn254_msm_bases_prepared (the inner boundary's form of groth16.Prove's A, B1, K, G2.B MultiExp calls, which pair with the
     SAME wire values: gnark v0.8.0 groth16 prove.go via main.go:131): one upload, one recoding per table geometry.  Against the oracle's sums and against
