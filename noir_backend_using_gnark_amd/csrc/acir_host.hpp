@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -324,27 +325,30 @@ static inline bool read_term(JTok& T, int depth, int arity, bool want_coeff, Ter
 }
 }  // namespace acir_detail
 
-// BuildSparseR1CS (sparse_r1cs.go:18-107) + HandleValues (common.go:45-76).  n_values = number of witness values handed over (witnesses 1..n).
-// Returns ZK_OK or ZK_ERR_ARG with *err set.
-static inline int lower_acir(const char* json, size_t len, size_t n_values, int layout, bool with_coeffs, Gates* G, std::string* err) {
-    using acir_detail::Term;
-    using acir_detail::read_term;
-    if (layout != ZK_ACIR_LAYOUT_REFERENCE && layout != ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS) {
-        *err = "unknown ACIR variable layout " + std::to_string(layout);
-        return ZK_ERR_ARG;
-    }
-    const bool exact = layout == ZK_ACIR_LAYOUT_REFERENCE;
-    *G = Gates();
-    G->with_coeffs = with_coeffs;
-    JTok T{json, json + len};
-    const char* sem = nullptr;  // the first semantic error (the text itself was well formed up to there)
-    auto bad = [&](const char* m) { if (!sem) sem = m; return false; };
-    std::vector<uint32_t> pub;
+namespace acir_detail {
+// the gates one parser has emitted: wiring still in WITNESS numbers (`has` says which of xa / xb / xc name one), coefficients canonical
+struct OpSink {
+    std::vector<uint32_t> xa, xb, xc;
     std::vector<uint8_t> has;   // per gate, bit k: xa / xb / xc names a WITNESS still to be mapped to its variable (else: variable 0)
-    bool have_ops = false, have_pub = false;
-
+    std::vector<HFr> ql, qr, qo, qm, qk;
+    void append(const OpSink& o) {
+        xa.insert(xa.end(), o.xa.begin(), o.xa.end()); xb.insert(xb.end(), o.xb.begin(), o.xb.end()); xc.insert(xc.end(), o.xc.begin(), o.xc.end());
+        has.insert(has.end(), o.has.begin(), o.has.end());
+        ql.insert(ql.end(), o.ql.begin(), o.ql.end()); qr.insert(qr.end(), o.qr.begin(), o.qr.end()); qo.insert(qo.end(), o.qo.begin(), o.qo.end());
+        qm.insert(qm.end(), o.qm.begin(), o.qm.end()); qk.insert(qk.end(), o.qk.begin(), o.qk.end());
+    }
+};
+// One element of "opcodes" -> at most one gate (sparse_r1cs.go:28-107).  A parser of its own (tokenizer position, first semantic error, sink), so that
+// several can work on different stretches of one opcodes array at once.
+struct OpLower {
+    JTok T;
+    const char* sem = nullptr;  // the first semantic error (the text itself was well formed up to there)
+    size_t n_values = 0;
+    bool exact = true, with_coeffs = true;
+    OpSink S;
+    bool bad(const char* m) { if (!sem) sem = m; return false; }
     // a witness named by a gate: out of range -> variable 0 in the reference's map lookup (sparse_r1cs.go:53-54), an error in the other layout
-    auto place = [&](uint32_t w, uint32_t* x, uint8_t* mask, int bit) -> bool {
+    bool place(uint32_t w, uint32_t* x, uint8_t* mask, int bit) const {
         if (w < 1 || w > n_values) {
             if (!exact) return false;
             *x = 0;
@@ -354,9 +358,8 @@ static inline int lower_acir(const char* json, size_t len, size_t n_values, int 
         *x = w;
         *mask |= (uint8_t)(1u << bit);
         return true;
-    };
-
-    auto arithmetic = [&](int depth) -> bool {  // p at '{' of the Arithmetic object; members are values at depth + 1
+    }
+    bool arithmetic(int depth) {  // p at '{' of the Arithmetic object; members are values at depth + 1
         Term mul0, lin[3], qc;
         bool have_mul = false, have_lin = false, have_qc = false, mul_arr = false, lin_arr = false, mul_empty = true;
         size_t nl = 0;
@@ -421,14 +424,13 @@ static inline int lower_acir(const char* json, size_t len, size_t n_values, int 
         if (with_coeffs) {
             static const uint64_t Z[4] = {0, 0, 0, 0};
             auto put = [](std::vector<HFr>& v, const uint64_t* c) { v.push_back(HFr{{c[0], c[1], c[2], c[3]}}); };
-            put(G->ql, c_l ? c_l : Z); put(G->qr, c_r ? c_r : Z); put(G->qo, c_o ? c_o : Z); put(G->qm, c_m ? c_m : Z); put(G->qk, qc.c);
+            put(S.ql, c_l ? c_l : Z); put(S.qr, c_r ? c_r : Z); put(S.qo, c_o ? c_o : Z); put(S.qm, c_m ? c_m : Z); put(S.qk, qc.c);
         }
-        G->xa.push_back(xa); G->xb.push_back(xb); G->xc.push_back(xc);
-        has.push_back(mask);
+        S.xa.push_back(xa); S.xb.push_back(xb); S.xc.push_back(xc);
+        S.has.push_back(mask);
         return true;
-    };
-
-    auto opcode = [&](int depth) -> bool {  // one element of "opcodes"
+    }
+    bool opcode(int depth) {  // one element of "opcodes"
         if (!T.enter(depth)) return false;
         if (*T.p != '{') return T.skip(depth) && bad("ACIR JSON: opcode is not an object");
         bool have_arith = false, arith_obj = false, other = false;
@@ -449,7 +451,141 @@ static inline int lower_acir(const char* json, size_t len, size_t n_values, int 
         if (!have_arith) return other ? true : bad("unknown opcode type");
         if (!arith_obj) return bad("ACIR JSON: malformed arithmetic opcode");
         return true;
-    };
+    }
+};
+
+// ---- the elements of ONE opcodes array on several threads ---------------------------------------------------------------------------------------------
+// The array of a 2^19-gate circuit is 190 MB of text and a fresh process (nargo runs one per proof) reads it while the HIP runtime starts: one core takes
+// ~0.22 s for it, as long as everything else a cold PlonkProveWithPK does.  Split WITHOUT a structural pre-pass: candidate cut points are commas that look like
+// the separator of two elements ('}' before, '{' after -- a guess: the same bytes can occur inside a string or deeper in the tree); parser k starts after
+// candidate k as if it stood between two elements and runs until it stands exactly ON a later candidate, at the array's ']' or at an error.  Parser 0 starts
+// at the real first element, so its state is the sequential reader's; a parser whose start the previous accepted one landed on inherits that property
+// (induction) and the others are thrown away -- a wrong guess costs time, never a different result.  The accepted parsers' gates concatenate in text order;
+// the first error in text order is the one reported, as in the sequential loop (JTok::array), whose accept / reject grammar and messages this repeats.
+struct ParallelCfg {
+    size_t min_bytes = (size_t)2 << 20;  // shorter texts: one thread
+    unsigned threads = 0;                 // 0: hardware threads, at most 16
+};
+static inline ParallelCfg& parallel_cfg() {
+    static ParallelCfg c;
+    return c;
+}
+static inline bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
+static inline const char* find_element_comma(const char* from, const char* lo, const char* end) {
+    const char* lim = end - from > (ptrdiff_t)(1 << 20) ? from + (1 << 20) : end;
+    for (const char* q = from; q < lim; q++) {
+        q = (const char*)memchr(q, ',', (size_t)(lim - q));
+        if (!q) return nullptr;
+        const char* a = q;
+        while (a > lo && is_ws(a[-1])) a--;
+        if (a == lo || a[-1] != '}') continue;
+        const char* b = q + 1;
+        while (b < end && is_ws(*b)) b++;
+        if (b < end && *b == '{') return q;
+    }
+    return nullptr;
+}
+struct ChunkResult {
+    OpSink S;
+    int landed = -1;             // index of the candidate this parser stopped on
+    const char* after = nullptr; // position after the array's ']' if it got there
+    const char* terr = nullptr;  // tokenizer error / semantic error (either: the parse failed there)
+    const char* sem = nullptr;
+    bool failed = false;
+};
+// elements from `begin` (the first character of an element's value position) on; cuts[j] for j > first_cut are the candidates it may land on
+static inline void run_chunk(const char* begin, const char* end, const std::vector<const char*>& cuts, size_t first_cut, const OpLower& proto, ChunkResult* R) {
+    OpLower L;
+    L.n_values = proto.n_values; L.exact = proto.exact; L.with_coeffs = proto.with_coeffs;
+    L.T.p = begin; L.T.end = end;
+    size_t nb = first_cut;
+    {   // room for the gates of this stretch (an arithmetic opcode is >= ~150 characters of text): no reallocation while the parsers run side by side
+        const char* stop = first_cut < cuts.size() ? cuts[first_cut] : end;
+        const size_t est = (size_t)(stop - begin) / 128 + 16;
+        L.S.xa.reserve(est); L.S.xb.reserve(est); L.S.xc.reserve(est); L.S.has.reserve(est);
+        if (L.with_coeffs) { L.S.ql.reserve(est); L.S.qr.reserve(est); L.S.qo.reserve(est); L.S.qm.reserve(est); L.S.qk.reserve(est); }
+    }
+    for (;;) {
+        if (!L.opcode(2)) { R->failed = true; break; }
+        L.T.ws();
+        const char* p = L.T.p;
+        if (p < end && *p == ',') {
+            while (nb < cuts.size() && cuts[nb] < p) nb++;
+            if (nb < cuts.size() && cuts[nb] == p) { R->landed = (int)nb; break; }
+            L.T.p++;
+            continue;
+        }
+        if (p < end && *p == ']') { R->after = p + 1; break; }
+        L.T.fail("expected ',' or ']'");
+        R->failed = true;
+        break;
+    }
+    R->terr = L.T.err;
+    R->sem = L.sem;
+    R->S = std::move(L.S);
+}
+// M.T.p at the first element of a non-empty opcodes array.  Returns like JTok::array's loop: true with M.T.p after the ']', or false with M.T.err / M.sem set.
+static inline bool elements_parallel(OpLower& M, unsigned nt) {
+    const char* begin = M.T.p;
+    const char* end = M.T.end;
+    std::vector<const char*> cuts;  // cuts[0]: a placeholder for the real start; cuts[j]: position of a candidate comma
+    cuts.push_back(begin);
+    const size_t span = (size_t)(end - begin);
+    for (unsigned k = 1; k < nt; k++) {
+        const char* from = begin + span / nt * k;
+        if (from <= cuts.back()) continue;
+        const char* c = find_element_comma(from, begin, end);
+        if (c && c > cuts.back()) cuts.push_back(c);
+    }
+    std::vector<ChunkResult> res(cuts.size());
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < cuts.size(); k++) th.emplace_back(run_chunk, cuts[k] + 1, end, std::cref(cuts), k + 1, std::cref(M), &res[k]);
+    run_chunk(begin, end, cuts, 1, M, &res[0]);
+    for (auto& t : th) t.join();
+    size_t total = M.S.xa.size();
+    for (size_t cur = 0;;) {  // sizes first: one reservation
+        total += res[cur].S.xa.size();
+        if (res[cur].landed < 0) break;
+        cur = (size_t)res[cur].landed;
+    }
+    M.S.xa.reserve(total); M.S.xb.reserve(total); M.S.xc.reserve(total); M.S.has.reserve(total);
+    if (M.with_coeffs) { M.S.ql.reserve(total); M.S.qr.reserve(total); M.S.qo.reserve(total); M.S.qm.reserve(total); M.S.qk.reserve(total); }
+    for (size_t cur = 0;;) {
+        const ChunkResult& R = res[cur];
+        M.S.append(R.S);
+        if (R.failed) {
+            if (R.terr) M.T.fail(R.terr);
+            if (R.sem) M.bad(R.sem);
+            return false;
+        }
+        if (R.after) { M.T.p = R.after; return true; }
+        cur = (size_t)R.landed;
+    }
+}
+}  // namespace acir_detail
+
+// BuildSparseR1CS (sparse_r1cs.go:18-107) + HandleValues (common.go:45-76).  n_values = number of witness values handed over (witnesses 1..n).
+// Returns ZK_OK or ZK_ERR_ARG with *err set.
+static inline int lower_acir(const char* json, size_t len, size_t n_values, int layout, bool with_coeffs, Gates* G, std::string* err) {
+    if (layout != ZK_ACIR_LAYOUT_REFERENCE && layout != ZK_ACIR_LAYOUT_ONE_VAR_PER_WITNESS) {
+        *err = "unknown ACIR variable layout " + std::to_string(layout);
+        return ZK_ERR_ARG;
+    }
+    *G = Gates();
+    G->with_coeffs = with_coeffs;
+    acir_detail::OpLower M;
+    M.n_values = n_values;
+    M.exact = layout == ZK_ACIR_LAYOUT_REFERENCE;
+    M.with_coeffs = with_coeffs;
+    M.T.p = json;
+    M.T.end = json + len;
+    JTok& T = M.T;
+    auto bad = [&](const char* m) { return M.bad(m); };
+    std::vector<uint32_t> pub;
+    bool have_ops = false, have_pub = false;
+    unsigned nt = acir_detail::parallel_cfg().threads ? acir_detail::parallel_cfg().threads : std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (len < acir_detail::parallel_cfg().min_bytes || nt < 2) nt = 1;
 
     bool root_obj = false, ops_arr = false;
     bool fine = T.enter(0);
@@ -463,7 +599,13 @@ static inline int lower_acir(const char* json, size_t len, size_t n_values, int 
                     if (!T.enter(1)) return false;
                     if (*T.p != '[') return T.skip(1);
                     ops_arr = true;
-                    return T.array(1, [&](size_t) { return opcode(2); });
+                    if (nt > 1) {  // JTok::array's prologue, then the elements on several threads
+                        T.p++;
+                        T.ws();
+                        if (T.p < T.end && *T.p == ']') { T.p++; return true; }
+                        return acir_detail::elements_parallel(M, nt);
+                    }
+                    return T.array(1, [&](size_t) { return M.opcode(2); });
                 }
                 if (!have_pub && key_is(k, kn, "public_inputs")) {
                     have_pub = true;
@@ -485,12 +627,16 @@ static inline int lower_acir(const char* json, size_t len, size_t n_values, int 
             });
         }
     }
+    const char* sem = M.sem;
     if (!fine || !root_obj) {
         *err = std::string("ACIR JSON: ") + (T.err ? T.err : sem ? sem : "not an object");
         if (sem && !T.err) *err = sem;
         return ZK_ERR_ARG;
     }
     if (!ops_arr) { *err = "ACIR JSON: no opcodes array"; return ZK_ERR_ARG; }
+    G->xa = std::move(M.S.xa); G->xb = std::move(M.S.xb); G->xc = std::move(M.S.xc);
+    G->ql = std::move(M.S.ql); G->qr = std::move(M.S.qr); G->qo = std::move(M.S.qo); G->qm = std::move(M.S.qm); G->qk = std::move(M.S.qk);
+    const std::vector<uint8_t>& has = M.S.has;
     std::vector<uint32_t> index;
     const int rc = handle_values(pub, n_values, layout, G, &index, err);
     if (rc != ZK_OK) return rc;

@@ -53,11 +53,9 @@ static int init_entry(Ctx& c) {  // under c.mu
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int lo = 0, hi = 0;  // numerically lower = higher priority
     ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    for (int i = 0; i < Ctx::NSLOTS; i++) {
-        c.slots[i].owner = &c;
-        ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
-        ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi, hipStreamNonBlocking, hi));
-    }
+    c.prio_lo = lo;
+    c.prio_hi = hi;
+    for (int i = 0; i < Ctx::NSLOTS; i++) c.slots[i].owner = &c;  // the streams: at a slot's first acquisition / first hi()
     c.ready = true;
     return ZK_OK;
 }
@@ -172,6 +170,31 @@ static bool slot_wait_expired(const std::chrono::steady_clock::time_point& t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > slot_timeout_s();
 }
 
+// the slot's own stream, created on the entry's device at the slot's first acquisition (under the entry's mutex: the slot is not visible to anybody else yet)
+static int slot_stream(Slot* s) {
+    if (s->stream) return ZK_OK;
+    hipError_t e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, s->owner->prio_lo);
+    if (e != hipSuccess) {
+        s->stream = nullptr;
+        s->busy = false;
+        return set_err(ZK_ERR_HIP, "hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+    }
+    return ZK_OK;
+}
+hipStream_t Slot::hi() {
+    std::lock_guard<std::mutex> lk(owner->mu);
+    if (!stream_hi_) {
+        int cur = owner->device;
+        (void)hipGetDevice(&cur);
+        if (cur != owner->device) (void)hipSetDevice(owner->device);
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, owner->prio_hi) != hipSuccess) st = stream;  // no second stream: the chain runs on the slot's own
+        stream_hi_ = st;
+        if (cur != owner->device) (void)hipSetDevice(cur);
+    }
+    return stream_hi_;
+}
+
 int acquire_slot(Slot** out) {
     ZK_TRY(ensure_init());
     Ctx& c = ctx();
@@ -186,7 +209,7 @@ int acquire_slot(Slot** out) {
                     c.slots[i].busy = true;
                     c.slots[i].reset();
                     *out = &c.slots[i];
-                    return ZK_OK;
+                    return slot_stream(&c.slots[i]);
                 }
         }
         std::this_thread::yield();
@@ -214,6 +237,13 @@ int acquire_slots(int k, Slot** out) {
                         c.slots[i].reset();
                         out[got++] = &c.slots[i];
                     }
+                for (int i = 0; i < k; i++) {
+                    const int rc = slot_stream(out[i]);
+                    if (rc != ZK_OK) {
+                        for (int j = 0; j < k; j++) out[j]->busy = false;
+                        return rc;
+                    }
+                }
                 return ZK_OK;
             }
         }

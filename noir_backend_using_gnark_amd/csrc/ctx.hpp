@@ -89,8 +89,12 @@ struct ProfEntry {
 
 // A stream slot: one HIP stream + one growing HBM arena + pinned host staging + pending profile events.
 struct Slot {
-    hipStream_t stream = nullptr;     // normal priority
-    hipStream_t stream_hi = nullptr;  // high priority (critical-path chains of a proof)
+    // Streams are created when first needed, not with the entry: hipStreamCreateWithPriority costs 7-14 ms each on MI355X / ROCm 7.2 (tools/hip_start_bench.hip:
+    // 113-229 ms for the 16 of one entry) and a process that makes ONE proof -- nargo's -- uses three or four of them.
+    hipStream_t stream = nullptr;     // normal priority; exists from the slot's first acquisition on
+    hipStream_t stream_hi_ = nullptr; // high priority (critical-path chains of a proof): through hi()
+    hipStream_t hi();                 // creates it on first use
+    void sync_hi() { if (stream_hi_) (void)hipStreamSynchronize(stream_hi_); }
     hipStream_t stream_prep = nullptr, stream_acc = nullptr;  // experiment (ZKMI_CU_SPLIT=k): CU-masked pair -- k CUs for scalar preparation, the rest for accumulates
     char* arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
@@ -116,6 +120,7 @@ struct Ctx {
     int entry = 0;    // position in the process's device list
     int device = 0;   // HIP device ordinal (several entries may name the same device)
     int num_cus = 256;
+    int prio_lo = 0, prio_hi = 0;  // hipDeviceGetStreamPriorityRange: numerically lower = higher priority
     std::mutex mu;
     static constexpr int NSLOTS = 8;
     Slot slots[NSLOTS];

@@ -367,7 +367,7 @@ struct Msm5State {
 // scalar side of the four MSMs over the wire values (digits, sort, task plan) on slot 4's stream
 static int msm5_prepare_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S) {
     static const bool low = ZK_EXP("ZKMI_PREPW_LOW", 0) == 1;  // experiment: normal priority under computeH
-    hipStream_t st4 = low ? sl[4]->stream : sl[4]->stream_hi;
+    hipStream_t st4 = low ? sl[4]->stream : sl[4]->hi();
     if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
     if (in.tab_w) return msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w);
     return msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w);
@@ -381,7 +381,7 @@ static int msm5_launch_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm
     return msm5_accumulate_w(sl, in, ev_w, S, gate_first_acc);
 }
 static int msm5_accumulate_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Msm5State* S, hipEvent_t gate_first_acc, const BetweenFn* between) {
-    hipStream_t st4 = sl[4]->stream_hi;
+    hipStream_t st4 = sl[4]->hi();
     size_t j = 0;
     const bool share_k = k_shares_w(in, &j);
     // accumulate kernels chained through events, each on its MSM's own stream (measured alternatives: one shared "chain" stream
@@ -623,11 +623,11 @@ int zk_bn254_groth16_msm5_dev(const void* d_a, const void* d_b, const void* d_b2
     if (stream) {  // inputs are produced on the caller's stream: gate all five streams on it
         ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         ZK_HIP(hipEventRecord(ev, (hipStream_t)stream));
-        ZK_HIP(hipStreamWaitEvent(g.s[0]->stream_hi, ev, 0));
+        ZK_HIP(hipStreamWaitEvent(g.s[0]->hi(), ev, 0));
     }
     Msm5State S;
     int rc = msm5_launch_w(g.s, in, ev, &S);
-    if (rc == ZK_OK) rc = msm5_launch_h(g.s, g.s[0]->stream_hi, in, &S);
+    if (rc == ZK_OK) rc = msm5_launch_h(g.s, g.s[0]->hi(), in, &S);
     if (rc == ZK_OK) rc = msm5_finish(&S, out_xyzz);
     else { msm_prep_release(&S.prep_w); msm_prep_release(&S.prep_h); }
     if (ev) (void)hipEventDestroy(ev);
@@ -653,7 +653,7 @@ static void pk_session_ref(uint64_t h, int delta) {
     if (it != g_pks.end()) it->second.sessions += delta;
 }
 static void session_drain(Msm5Session* ss) {
-    for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(ss->g.s[i]->stream); (void)hipStreamSynchronize(ss->g.s[i]->stream_hi); }
+    for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(ss->g.s[i]->stream); ss->g.s[i]->sync_hi(); }
     msm_prep_release(&ss->S.prep_w);
     msm_prep_release(&ss->S.prep_h);
     for (int i = 0; i < 5; i++)
@@ -709,7 +709,7 @@ int zk_bn254_groth16_msm5_session_stream(uint64_t session, void** stream_out) {
     std::lock_guard<std::mutex> lk(g_sess_mu);
     auto it = g_sessions.find(session);
     if (it == g_sessions.end()) return set_err(ZK_ERR_HANDLE, "unknown msm5 session %llu", (unsigned long long)session);
-    *stream_out = (void*)it->second->g.s[0]->stream_hi;  // the stream prove() runs computeH on: prepare(h) and Z follow on it in order
+    *stream_out = (void*)it->second->g.s[0]->hi();  // the stream prove() runs computeH on: prepare(h) and Z follow on it in order
     return ZK_OK;
 }
 
@@ -730,12 +730,12 @@ int zk_bn254_groth16_msm5_pk_end(uint64_t session, const void* d_h, uint64_t out
     hipEvent_t ev = nullptr;
     if (rc == ZK_OK && stream) {  // h is being produced on the caller's stream (computeH)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, (hipStream_t)stream) != hipSuccess ||
-            hipStreamWaitEvent(sl[0]->stream_hi, ev, 0) != hipSuccess)
+            hipStreamWaitEvent(sl[0]->hi(), ev, 0) != hipSuccess)
             rc = set_err(ZK_ERR_HIP, "event setup failed");
     }
     // like prove(): the accumulate chain starts when computeH has left the machine
     if (rc == ZK_OK) rc = msm5_accumulate_w(sl, ss->in, nullptr, &ss->S, ev);
-    if (rc == ZK_OK) rc = msm5_launch_h(sl, sl[0]->stream_hi, ss->in, &ss->S);
+    if (rc == ZK_OK) rc = msm5_launch_h(sl, sl[0]->hi(), ss->in, &ss->S);
     if (rc == ZK_OK) rc = msm5_finish(&ss->S, out_xyzz);
     else session_drain(ss.get());
     if (ev) (void)hipEventDestroy(ev);
@@ -774,7 +774,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     SlotsGuard<5> g;
     ZK_TRY(acquire_slots(5, g.s));
     Slot* s0 = g.s[0];
-    hipStream_t st = s0->stream_hi;
+    hipStream_t st = s0->hi();
     Msm5Inputs in = {P.d_a, P.d_b, P.d_b2, nullptr, nw, P.d_k, nullptr, nk, P.d_z, nullptr, P.nz};
     in.d_wk = (const char*)in.d_w + P.n_public * 32;  // placeholder geometry for the reservation; real pointers below
     if (P.tables) {
@@ -787,7 +787,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     // prepare(h) run underneath the accumulate kernels).  computeH goes FIRST and alone with the bandwidth-bound sort of w:
     // measured, an NTT launched underneath an accumulate kernel is starved (1.3 ms -> 8 ms) because the long-running accumulate
     // workgroups never free enough wave slots, and the Z chain then finishes late.
-    hipStream_t st4 = g.s[4]->stream_hi;
+    hipStream_t st4 = g.s[4]->hi();
     int rc = ZK_OK;
     Fr* d_abc[3] = {nullptr, nullptr, nullptr};
     const void* src[3] = {a, b, c};
@@ -813,7 +813,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     const Fr* in_place_src[3] = {(const Fr*)a, (const Fr*)b, (const Fr*)c};
     // ZKMI_H_STREAMS=1 (experiment switch): the transforms of b and c on the (idle) high-priority streams of slots 1 and 2, next to a's
     static const bool h_streams = ZK_EXP("ZKMI_H_STREAMS", 0) == 1;
-    const hipStream_t side[2] = {g.s[1]->stream_hi, g.s[2]->stream_hi};
+    const hipStream_t side[2] = {g.s[1]->hi(), g.s[2]->hi()};
     hipEvent_t ev_h = nullptr;
     auto run_compute_h = [&]() -> int {
         ZK_TRY(compute_h_inplace(s0, st, d_abc[0], d_abc[1], d_abc[2], P.log_domain, direct ? in_place_src : nullptr, h_streams ? side : nullptr));
@@ -882,7 +882,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     const std::function<void(const XYZZ<HFp>&, const XYZZ<HFp>&)> early = [&](const XYZZ<HFp>& ma, const XYZZ<HFp>& mb) { tail_early(P, &T, ma, mb); };
     if (rc == ZK_OK) rc = msm5_finish(&S, parts, &early);
     else {
-        for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(g.s[i]->stream); (void)hipStreamSynchronize(g.s[i]->stream_hi); }
+        for (int i = 0; i < 5; i++) { (void)hipStreamSynchronize(g.s[i]->stream); g.s[i]->sync_hi(); }
         msm_prep_release(&S.prep_w);
         msm_prep_release(&S.prep_h);
     }

@@ -462,7 +462,7 @@ int md_groth16_prove(uint64_t h, const void* a, const void* b, const void* c, si
         const int dev = ctx().device;
         SlotGuard g;
         ZK_TRY(acquire_slot(&g.s));
-        hipStream_t st = g.s->stream_hi;
+        hipStream_t st = g.s->hi();
         const size_t wlo = K->wlo[k], wcnt = K->wlo[k + 1] - wlo;
         ZK_TRY(g.s->reserve(4 * M * 32 + wcnt * 32 + 8192));
         void* blk[3];

@@ -603,7 +603,7 @@ struct CommitChain {
         ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         ZK_HIP(hipEventRecord(ev, producer));
         static const bool prep_hi = (ZK_EXP("ZKMI_PLONK_PREP_HI", 1) != 0);  // A/B switch
-        hipStream_t sp = prep_hi ? s->stream_hi : s->stream;  // the preparation at high priority: its sort must get wave slots under a running accumulate
+        hipStream_t sp = prep_hi ? s->hi() : s->stream;  // the preparation at high priority: its sort must get wave slots under a running accumulate
         ZK_TRY(masked_streams(s));
         hipStream_t sa = s->stream;
         if (s->stream_prep) { sp = s->stream_prep; sa = s->stream_acc; }  // experiment ZKMI_CU_SPLIT: disjoint CU sets instead of priorities
@@ -639,7 +639,7 @@ struct CommitChain {
     ~CommitChain() {
         for (int k = 0; k < NJ; k++)
             if (live[k]) {
-                (void)hipStreamSynchronize(g.s[k]->stream_hi);
+                g.s[k]->sync_hi();
                 (void)hipStreamSynchronize(g.s[k]->stream);
                 if (g.s[k]->stream_prep) { (void)hipStreamSynchronize(g.s[k]->stream_prep); (void)hipStreamSynchronize(g.s[k]->stream_acc); }
                 release(k);

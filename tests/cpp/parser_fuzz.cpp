@@ -74,6 +74,25 @@ static void check_acir(const std::string& text, size_t n_values, int layout, con
     const int rd = domref::lower_acir(text.data(), text.size(), n_values, layout, &D);
     CHECK(rc == rd, "%s #%zu (n_values %zu, layout %d): streaming rc %d (%s) vs tree rc %d (%s)", what, id, n_values, layout, rc, err.c_str(), rd, domref::g_err.c_str());
     CHECK(rc == rcw, "%s #%zu: rc with coefficients %d, wiring only %d", what, id, rc, rcw);
+    if ((id & 3) == 0) {  // (every fourth case: a thread start costs more than these short parses) the same text with the opcodes array split among 2..5 parsers (acir_detail::elements_parallel; forced on these short texts): status, message and
+        // every output word of the one-thread run
+        zkmi::acir_detail::ParallelCfg& pc = zkmi::acir_detail::parallel_cfg();
+        const zkmi::acir_detail::ParallelCfg keep = pc;
+        pc.min_bytes = 0;
+        pc.threads = 2 + (unsigned)below(4);
+        zkmi::Gates GP, WP;
+        std::string ep, ep2;
+        const int rp = zkmi::lower_acir(text.data(), text.size(), n_values, layout, true, &GP, &ep);
+        const int rpw = zkmi::lower_acir(text.data(), text.size(), n_values, layout, false, &WP, &ep2);
+        pc = keep;
+        CHECK(rp == rc && rpw == rcw && ep == err && ep2 == err2, "%s #%zu: %u parsers rc %d (%s) / %d (%s) vs one parser rc %d (%s) / %d (%s)", what, id, pc.threads, rp, ep.c_str(), rpw,
+              ep2.c_str(), rc, err.c_str(), rcw, err2.c_str());
+        if (rc == ZK_OK && rp == ZK_OK) {
+            CHECK(GP.xa == G.xa && GP.xb == G.xb && GP.xc == G.xc && GP.order == G.order && GP.n_public == G.n_public && GP.n_vars == G.n_vars, "%s #%zu: parallel wiring", what, id);
+            CHECK(same_frs(GP.ql, G.ql) && same_frs(GP.qr, G.qr) && same_frs(GP.qo, G.qo) && same_frs(GP.qm, G.qm) && same_frs(GP.qk, G.qk), "%s #%zu: parallel coefficients", what, id);
+        }
+        if (rcw == ZK_OK && rpw == ZK_OK) CHECK(WP.xa == W.xa && WP.xb == W.xb && WP.xc == W.xc && WP.order == W.order, "%s #%zu: parallel wiring-only mode", what, id);
+    }
     if (rc != ZK_OK || rd != ZK_OK) return;
     CHECK(G.n_public == D.n_public && G.n_vars == D.n_vars, "%s #%zu: n_public / n_vars", what, id);
     CHECK(G.xa == D.xa && G.xb == D.xb && G.xc == D.xc && G.order == D.order, "%s #%zu: wiring / order", what, id);

@@ -30,18 +30,30 @@ int main(int argc, char** argv) {
     t0 = now_ms();
     int rc2 = zkmi::lower_acir(text.data(), text.size(), n_values, ZK_ACIR_LAYOUT_REFERENCE, true, &G, &err);
     double t_full = now_ms() - t0;
+    // the same two runs on ONE thread (the opcodes array is split among the hardware threads by default: acir_detail::elements_parallel)
+    zkmi::acir_detail::parallel_cfg().min_bytes = (size_t)-1;
+    zkmi::Gates W1, G1;
+    t0 = now_ms();
+    const int rc3 = zkmi::lower_acir(text.data(), text.size(), n_values, ZK_ACIR_LAYOUT_REFERENCE, false, &W1, &err);
+    const double t_wiring1 = now_ms() - t0;
+    t0 = now_ms();
+    const int rc4 = zkmi::lower_acir(text.data(), text.size(), n_values, ZK_ACIR_LAYOUT_REFERENCE, true, &G1, &err);
+    const double t_full1 = now_ms() - t0;
     double t_tree = -1;
-    bool same = true;
+    bool same = rc3 == rc && rc4 == rc2 && W1.xa == W.xa && W1.xb == W.xb && W1.xc == W.xc && W1.order == W.order && G1.xa == G.xa && G1.xc == G.xc && G1.ql.size() == G.ql.size() &&
+                !memcmp(G1.ql.data(), G.ql.data(), 32 * G.ql.size()) && !memcmp(G1.qk.data(), G.qk.data(), 32 * G.qk.size()) && !memcmp(G1.qo.data(), G.qo.data(), 32 * G.qo.size());
     if (argc < 4) {
         domref::Gates D;
         t0 = now_ms();
         int rd = domref::lower_acir(text.data(), text.size(), n_values, ZK_ACIR_LAYOUT_REFERENCE, &D);
         t_tree = now_ms() - t0;
-        same = rd == rc2 && D.xa == G.xa && D.xb == G.xb && D.xc == G.xc && D.order == G.order && D.ql.size() == G.ql.size() &&
+        same = same && rd == rc2 && D.xa == G.xa && D.xb == G.xb && D.xc == G.xc && D.order == G.order && D.ql.size() == G.ql.size() &&
                !memcmp(D.ql.data(), G.ql.data(), 32 * G.ql.size()) && !memcmp(D.qk.data(), G.qk.data(), 32 * G.qk.size()) && !memcmp(D.qm.data(), G.qm.data(), 32 * G.qm.size());
     }
     printf("{\"text_bytes\": %zu, \"gates\": %zu, \"n_vars\": %zu, \"n_public\": %zu, \"rc\": [%d, %d], \"content_key_ms\": %.2f, \"streaming_wiring_ms\": %.1f, "
-           "\"streaming_with_coefficients_ms\": %.1f, \"document_tree_ms\": %.1f, \"same_output\": %s, \"key\": \"%016llx%016llx\"}\n",
-           text.size(), G.xa.size(), G.n_vars, G.n_public, rc, rc2, t_key, t_wiring, t_full, t_tree, same ? "true" : "false", (unsigned long long)ck.h[0], (unsigned long long)ck.h[1]);
+           "\"streaming_with_coefficients_ms\": %.1f, \"one_thread_wiring_ms\": %.1f, \"one_thread_with_coefficients_ms\": %.1f, \"host_threads\": %u, \"document_tree_ms\": %.1f, "
+           "\"same_output\": %s, \"key\": \"%016llx%016llx\"}\n",
+           text.size(), G.xa.size(), G.n_vars, G.n_public, rc, rc2, t_key, t_wiring, t_full, t_wiring1, t_full1, std::thread::hardware_concurrency(), t_tree, same ? "true" : "false",
+           (unsigned long long)ck.h[0], (unsigned long long)ck.h[1]);
     return same ? 0 : 1;
 }
