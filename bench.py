@@ -574,11 +574,13 @@ def export_path_block(log_gates=19, warm_calls=10):
                "circuit": run("make", d, str(log_gates))}
         blk["preprocess_process"] = run("preprocess", d)
         blk["prove_process"] = run("prove", d, str(warm_calls))
+        blk["verify_process"] = run("verify", d)  # a process that only verifies: no HIP runtime
         pp = blk["prove_process"]
         blk["warm_PlonkProveWithPK_ms"] = pp["warm_PlonkProveWithPK_ms"]
         blk["zk_bn254_plonk_prove_ms"] = pp["zk_bn254_plonk_prove_ms"]
         blk["warm_over_prove"] = pp["warm_over_prove"]
-        blk["ok"] = bool(pp["verifies"] == 1 and pp["warm_proof_verifies"] == 1 and pp["wrong_public_input_rejected"] == 1 and blk["preprocess_process"]["verifies"] == 1)
+        blk["ok"] = bool(pp["verifies"] == 1 and pp["warm_proof_verifies"] == 1 and pp["wrong_public_input_rejected"] == 1 and blk["preprocess_process"]["verifies"] == 1
+                        and blk["verify_process"]["verifies"] == 1)
         try:  # the text front end alone, on this box's cores: the streaming reader against the document-tree reader of rounds 1-3
             lb = os.path.join(d, "lower_bench")
             subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "lower_bench.cpp"), "-lpthread", "-o", lb], timeout=300)

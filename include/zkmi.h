@@ -76,6 +76,10 @@ int zk_init(int device);               /* optional: bind the calling process to 
  * entry in their handle, so every call on a handle runs on that handle's GPU whatever thread makes it; zk_set_entry picks the entry for the calls of the
  * calling THREAD that take no handle (zk_dev_alloc, zk_bn254_ntt_dev, ...).  Calling zk_init_devices again may only extend the list. */
 int zk_init_devices(const int *devices, size_t n);
+/* The stream slots a first proof will take, created ahead of time: a HIP stream costs 7-14 ms to create on MI355X / ROCm 7.2 and the first one of a process
+ * 40-160 ms (tools/hip_start_bench.hip), so the library creates them when a slot is first used -- or here, for a caller that has host work to do meanwhile (the
+ * export shim reads srs.hex).  n slots of the calling thread's device entry (at most all 8). */
+int zk_warm_streams(int n);
 int zk_device_entries(int *devices_out, size_t cap); /* number of entries; devices_out[i] = HIP device of entry i */
 int zk_set_entry(int entry);
 int zk_set_default_devices(uint32_t mask);
@@ -113,6 +117,10 @@ int zk_bn254_bases_register_dev(const void *d_points, size_t n, int is_g2, uint6
 /* The same with the table geometry chosen by the caller: table_window_bits = 0 auto (tables for >= 4096 bases when they fit),
  * -1 no tables, else c in [8, 22] (tables at any n: how the tests reach the widths the planner picks at 2^22 .. 2^26 points). */
 int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_device, int table_window_bits, uint64_t *handle);
+/* Window tables for a base array registered without them (table_window_bits as above; 0 = the planner's width, nothing below 4096 bases; a handle that has
+ * a table is left alone).  The tables of 1,000,000 G1 points take 23 ms to build and save a 2^19-gate PLONK proof 1.4 ms: a process that makes ONE proof (nargo
+ * prove) is better off without them, one that makes many builds them when the second proof is asked for (csrc/goffi.cpp does exactly that). */
+int zk_bn254_bases_build_table(uint64_t handle, int table_window_bits);
 int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);
 /* `count` scalar vectors of n elements each against ONE registered base array: out[k] = MultiExp(bases[offset : offset + n], scalars[k]) -- plonk.Prove's
  * three simultaneous kzg.Commit calls (l, r, o; h1, h2, h3: gnark v0.8.0 backend/plonk/bn254/prove.go, reached from gnark_backend_ffi/backend/plonk/plonk.go:53-73).
@@ -466,6 +474,9 @@ int zk_bn254_kzg_new_srs_dev(void *d_g1_out, size_t size, const zk_fr *alpha, zk
 int zk_bn254_kzg_srs_read(const void *data, size_t len, int is_hex, int table_window_bits, uint64_t *handle, size_t *n_g1,
                           zk_g2_affine g2_out[2]);
 int zk_bn254_kzg_srs_write(uint64_t handle, const zk_g2_affine g2[2], int as_hex, void *out, size_t cap, size_t *out_len);
+/* The two G2 points of an SRS image, on the HOST: all that plonk.Verify needs of the SRS (backend/plonk/plonk.go:28-51 re-reads the whole file for it).  No
+ * device work: a process that only verifies never starts the HIP runtime.  Header and length are checked as in _read; the G1 points are not looked at. */
+int zk_bn254_kzg_srs_g2(const void *data, size_t len, int is_hex, zk_g2_affine g2_out[2]);
 
 /* ---- device memory plumbing for hosts without a HIP binding (ctypes tests, the cgo shim) ------------------------ */
 int zk_dev_alloc(void **d_ptr, size_t bytes);

@@ -70,7 +70,7 @@ SYMBOLS = [
     "zk_device_count", "zk_init", "zk_last_error", "zk_version",
     "zk_bn254_g1_msm", "zk_bn254_g2_msm", "zk_bn254_g1_msm_dev", "zk_bn254_g2_msm_dev",
     "zk_bn254_g1_msm_partial_dev", "zk_bn254_g2_msm_partial_dev", "zk_bn254_g1_sum_xyzz", "zk_bn254_g2_sum_xyzz",
-    "zk_bn254_msm_plan_info", "zk_bn254_bases_register", "zk_bn254_bases_register_dev", "zk_bn254_bases_register_cfg", "zk_bn254_bases_free", "zk_bn254_msm_bases", "zk_bn254_msm_bases_batch", "zk_bn254_msm_bases_batch_dev", "zk_bn254_msm_bases_dev", "zk_bn254_scalars_register", "zk_bn254_scalars_free", "zk_bn254_msm_bases_prepared",
+    "zk_bn254_msm_plan_info", "zk_bn254_bases_register", "zk_bn254_bases_register_dev", "zk_bn254_bases_register_cfg", "zk_bn254_bases_build_table", "zk_bn254_bases_free", "zk_bn254_msm_bases", "zk_bn254_msm_bases_batch", "zk_bn254_msm_bases_batch_dev", "zk_bn254_msm_bases_dev", "zk_bn254_scalars_register", "zk_bn254_scalars_free", "zk_bn254_msm_bases_prepared",
     "zk_bn254_ntt", "zk_bn254_ntt_dev", "zk_bn254_bit_reverse", "zk_bn254_bit_reverse_dev",
     "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev", "zk_bn254_ntt_shard_dev",
     "zk_bn254_felts_decode_hex", "zk_bn254_felts_decode_hex_dev", "zk_bn254_felts_decode_bytes_dev", "zk_bn254_felts_encode_hex",
@@ -85,7 +85,7 @@ SYMBOLS = [
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev", "zk_bn254_kzg_new_srs_dev", "zk_bn254_kzg_srs_read", "zk_bn254_kzg_srs_write",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_profile_host", "zk_selftest_host",
-    "zk_init_devices", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
+    "zk_init_devices", "zk_warm_streams", "zk_bn254_kzg_srs_g2", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
     "zk_acir_public_witnesses", "zk_acir_lower_resident", "zk_export_cache_info", "zk_export_cache_clear", "zk_bn254_plonk_pk_bytes",
 ]
 

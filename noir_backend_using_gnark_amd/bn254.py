@@ -139,6 +139,10 @@ class ResidentBases:
         check(rc)
         return out
 
+    def build_table(self, table_window_bits: int = 0) -> None:
+        """Window tables for bases registered without them (zk_bn254_bases_build_table); a no-op when they exist."""
+        check(lib().zk_bn254_bases_build_table(self.handle, C.c_int(table_window_bits)))
+
     def multi_exp_batch(self, vectors, n: int | None = None, config: MultiExpConfig | None = None, offset: int = 0) -> np.ndarray:
         """Several scalar vectors of one length against these bases in one call (zk_bn254_msm_bases_batch[_dev]): numpy (n, 4) arrays, or DeviceBuffers / raw
         device pointers together with n.  Returns (len(vectors), 8 or 16) affine points -- the same as one multi_exp per vector."""

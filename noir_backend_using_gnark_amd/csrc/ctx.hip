@@ -251,6 +251,18 @@ int acquire_slots(int k, Slot** out) {
     }
 }
 
+// The streams a first proof will take, created ahead of time (7-14 ms each, the process's first one 40-160 ms: tools/hip_start_bench.hip) -- for a caller that
+// has something else to do meanwhile (the export shim reads srs.hex).  n slots of the calling thread's entry, at most all of them.
+extern "C" int zk_warm_streams(int n) {
+    ZK_TRY(ensure_init());
+    if (n < 1) return ZK_OK;
+    if (n > Ctx::NSLOTS) n = Ctx::NSLOTS;
+    Slot* sl[Ctx::NSLOTS];
+    ZK_TRY(acquire_slots(n, sl));
+    for (int i = 0; i < n; i++) release_slot(sl[i]);
+    return ZK_OK;
+}
+
 void release_slot(Slot* s) {
     std::lock_guard<std::mutex> lk((s->owner ? *s->owner : ctx()).mu);  // whatever entry the releasing thread is on
     s->busy = false;

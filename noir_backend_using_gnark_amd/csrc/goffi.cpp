@@ -88,7 +88,10 @@ struct Lap {  // wall-clock sections of the shim, reported beside the library's 
 // ---- the SRS of backend/common.go:78-144, once per process
 struct Srs {
     std::mutex mu;
-    bool ready = false;
+    bool ready = false;     // the G1 bases are resident (handle) and g2 is set
+    bool g2_only = false;   // g2 is set from the file's header and nothing is on a device (a process that has only verified so far)
+    bool tables = false;    // the bases have their window tables
+    int uses = 0;           // exports served that commit against the SRS (Preprocess, Prove*)
     uint64_t handle = 0;
     zk_g2_affine g2[2];
 };
@@ -106,6 +109,19 @@ std::string srs_path() {  // os.UserConfigDir() on Linux: $XDG_CONFIG_HOME, else
 }
 // Text that hex.DecodeString accepts (LoadSRS: common.go:96-99): only then does the reference keep the file.  64 MB for the reference's 1,000,000 points.
 bool is_hex_text(const std::string& t) { return !t.empty() && !(t.size() & 1) && zkmi::all_hex(t.data(), t.size()); }
+std::string read_srs_text(const std::string& path) {  // 64 MB of text for the reference's 1,000,000 points: sized once, read in one piece
+    std::string text;
+    if (FILE* f = fopen(path.c_str(), "rb")) {
+        struct stat sb;
+        if (fstat(fileno(f), &sb) == 0 && sb.st_size > 0) {
+            text.resize((size_t)sb.st_size);
+            const size_t got = fread(&text[0], 1, text.size(), f);
+            text.resize(got);
+        }
+        fclose(f);
+    }
+    return text;
+}
 void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
     std::lock_guard<std::mutex> lk(g_srs.mu);
     if (!g_srs.ready) {
@@ -118,28 +134,29 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         const int lock_fd = open((path + ".lock").c_str(), O_CREAT | O_RDWR, 0644);
         if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
         struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); } } } unlock{lock_fd};
-        // every visible GPU becomes a device entry of this process (HIP_VISIBLE_DEVICES restricts them): on a multi-GPU node the SRS below is then kept by range on
-        // all of them and every commitment of the prover is one partial per GPU (csrc/multidev.hip) -- nothing above this library changes; one GPU: one entry, as before
-        must(zk_init_devices(nullptr, 0), "zk_init_devices");
+        // The HIP runtime starts on a thread of its own (0.07-0.2 s) and then creates the streams the first proof will take (the process's first one: 40-160 ms,
+        // 10 ms each after) while this thread reads the file.  Every visible GPU becomes a device entry of this process (HIP_VISIBLE_DEVICES restricts them): on a
+        // multi-GPU node the SRS below is then kept by range on all of them and every commitment of the prover is one partial per GPU (csrc/multidev.hip) --
+        // nothing above this library changes; one GPU: one entry, as before.
+        std::thread starter([] {
+            must(zk_init_devices(nullptr, 0), "zk_init_devices");
+            must(zk_warm_streams(3), "zk_warm_streams");
+        });
         Lap lap;
-        std::string text;
-        if (FILE* f = fopen(path.c_str(), "rb")) {  // 64 MB of text for the reference's 1,000,000 points: sized once, read in one piece
-            struct stat sb;
-            if (fstat(fileno(f), &sb) == 0 && sb.st_size > 0) {
-                text.resize((size_t)sb.st_size);
-                const size_t got = fread(&text[0], 1, text.size(), f);
-                text.resize(got);
-            }
-            fclose(f);
-        }
+        const std::string text = read_srs_text(path);
         // LoadSRS fails -- and TryLoadSRS generates a new SRS -- exactly when the file cannot be read or is not hex (common.go:92-99, 129-141); it ignores what
         // ReadFrom makes of the bytes.  Here a file that IS hex is never replaced: a malformed SRS in it, or a device / memory failure while decoding it,
         // ends the process and leaves the file (and every key issued against it) alone.
-        if (is_hex_text(text)) {
+        const bool usable = is_hex_text(text);
+        lap.lap("export.srs_file_read");
+        starter.join();
+        lap.lap("export.hip_start_wait");  // what the runtime and the first streams still took once the file was in memory
+        // No window tables yet: for 1,000,000 points they take 23 ms to build and save a 2^19-gate proof 1.4 ms -- a process that makes one proof (nargo prove)
+        // is better off without; srs_for_repeat_use builds them when a second proving call arrives.
+        if (usable) {
             size_t n = 0;
-            lap.lap("export.srs_file_read");
-            must(zk_bn254_kzg_srs_read(text.data(), text.size(), 1, 0, &g_srs.handle, &n, g_srs.g2), "LoadSRS");
-            lap.lap("export.srs_decode_and_tables");
+            must(zk_bn254_kzg_srs_read(text.data(), text.size(), 1, -1, &g_srs.handle, &n, g_srs.g2), "LoadSRS");
+            lap.lap("export.srs_decode");
         } else {
             uint64_t a[4];
             FILE* r = fopen("/dev/urandom", "rb");
@@ -155,9 +172,9 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
             void* d = nullptr;
             must(zk_dev_alloc(&d, size * 64), "NewSRS");
             must(zk_bn254_kzg_new_srs_dev(d, size, &alpha, g_srs.g2, nullptr), "NewSRS");
-            must(zk_bn254_bases_register_dev(d, size, 0, &g_srs.handle), "NewSRS");
+            must(zk_bn254_bases_register_cfg(d, size, 0, 1, -1, &g_srs.handle), "NewSRS");
             (void)zk_dev_free(d);
-            lap.lap("export.srs_generate_and_tables");
+            lap.lap("export.srs_generate");
             // SaveSRS: the whole text goes to a temporary file that is renamed over srs.hex, so that no reader ever sees half of it
             const size_t cap = 2 * (132 + 32 * size);
             std::string out(cap, '\0');
@@ -178,6 +195,38 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
     }
     *handle = g_srs.handle;
     memcpy(g2, g_srs.g2, sizeof g_srs.g2);
+}
+// Every export that commits against the SRS passes here after try_load_srs: the second one builds the window tables (see there).
+void srs_for_repeat_use() {
+    std::lock_guard<std::mutex> lk(g_srs.mu);
+    if (g_srs.uses++ < 1 || g_srs.tables || !g_srs.ready) return;
+    Lap lap;
+    must(zk_bn254_bases_build_table(g_srs.handle, 0), "SRS window tables");
+    g_srs.tables = true;
+    lap.lap("export.srs_window_tables");
+}
+// plonk.Verify takes two G2 points from the SRS and nothing else (kzg.Verify's pairing check; the reference re-reads the whole file for them,
+// backend/plonk/plonk.go:34).  A process that has not proved anything reads them from the file's header on the host: it never starts the HIP runtime.
+void srs_g2_for_verify(zk_g2_affine g2[2]) {
+    {
+        std::lock_guard<std::mutex> lk(g_srs.mu);
+        if (!g_srs.ready && !g_srs.g2_only) {
+            Lap lap;
+            const std::string text = read_srs_text(srs_path());
+            if (is_hex_text(text)) {
+                lap.lap("export.srs_file_read");
+                must(zk_bn254_kzg_srs_g2(text.data(), text.size(), 1, g_srs.g2), "LoadSRS");
+                g_srs.g2_only = true;
+                lap.lap("export.srs_g2_on_host");
+            }
+        }
+        if (g_srs.ready || g_srs.g2_only) {
+            memcpy(g2, g_srs.g2, sizeof g_srs.g2);
+            return;
+        }
+    }
+    uint64_t h;  // no usable file: the reference generates and saves one, here on the device
+    try_load_srs(&h, g2);
 }
 
 char* plonk_prove(GoString acir, View values, const char* pk_hex, size_t pk_len, uint64_t pk_handle, uint64_t srs) {
@@ -201,8 +250,8 @@ void load_srs_and_lower(GoString acirJSON, View values, uint64_t* srs, zk_g2_aff
         std::lock_guard<std::mutex> lk(g_srs.mu);
         first = !g_srs.ready;
     }
-    if (!first) { try_load_srs(srs, g2); return; }
-    std::thread loader([&] { try_load_srs(srs, g2); });  // failures end the process (log.Fatal), from whichever thread
+    if (!first) { try_load_srs(srs, g2); srs_for_repeat_use(); return; }
+    std::thread loader([&] { try_load_srs(srs, g2); srs_for_repeat_use(); });  // failures end the process (log.Fatal), from whichever thread
     size_t n_values = 0;
     if (zkmi::count_from_hex(values.p, values.n, &n_values)) (void)zk_acir_lower_resident(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE);  // errors resurface in the call proper
     loader.join();
@@ -220,6 +269,7 @@ KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {
     uint64_t srs;
     zk_g2_affine g2[2];
     try_load_srs(&srs, g2);
+    srs_for_repeat_use();
     const View values = unquoted(encodedRandomValues);
     size_t pk_len = 0, vk_len = 0;
     must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkPreprocess");
@@ -237,6 +287,7 @@ char* PlonkProveWithMeta(GoString acirJSON, GoString encodedValues) {
     uint64_t srs, h = 0;
     zk_g2_affine g2[2];
     try_load_srs(&srs, g2);
+    srs_for_repeat_use();
     const View values = unquoted(encodedValues);
     size_t pk_len = 0, vk_len = 0;
     must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkProveWithMeta");
@@ -250,9 +301,8 @@ char* PlonkProveWithMeta(GoString acirJSON, GoString encodedValues) {
 unsigned char PlonkVerifyWithMeta(GoString, GoString, GoString) { return 0; }  // main.go:40-42
 
 unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoString encodedPublicInputs, GoString encodedVerifyingKey) {
-    uint64_t srs;
     zk_g2_affine g2[2];
-    try_load_srs(&srs, g2);
+    srs_g2_for_verify(g2);
     std::vector<uint8_t> proof;
     if (!hex_to_bytes(encodedProof.p, (size_t)encodedProof.n, &proof) || proof.size() != ZK_PLONK_PROOF_BYTES) { fprintf(stderr, "DeserializeProof: not the hex of a PLONK proof\n"); exit(1); }
     // the values arrive indexed by witness (backend.rs:103: get_values_from_witness_tree over all of the circuit's variables); HandleValues keeps the

@@ -460,6 +460,23 @@ int zk_bn254_kzg_srs_read(const void* data, size_t len, int is_hex, int table_wi
     return ZK_OK;
 }
 
+// The two G2 points of an SRS image and nothing else: what plonk.Verify takes from the SRS (kzg.Verify's pairing check).  Host only -- no device is
+// touched, so a process that only verifies (nargo verify) never starts the HIP runtime.  The header and the length are checked as in _read; the G1 points are not looked at.
+int zk_bn254_kzg_srs_g2(const void* data, size_t len, int is_hex, zk_g2_affine g2_out[2]) {
+    if (!data || !g2_out) return set_err(ZK_ERR_ARG, "null pointer");
+    SrsHeader H;
+    {
+        std::string e;
+        const int rc = kzg_srs_header(data, len, is_hex, &H, &e);
+        if (rc != ZK_OK) return set_err(rc, "%s", e.c_str());
+    }
+    Affine<HFp2> g2[2];
+    for (int k = 0; k < 2; k++)
+        if (!g2_decompress_host(H.g2 + 64 * k, &g2[k])) return set_err(ZK_ERR_ARG, "SRS: invalid G2 point %d", k);
+    memcpy(g2_out, g2, 256);
+    return ZK_OK;
+}
+
 // kzg.SRS.WriteTo of a registered G1 base array + the two G2 points: bytes (or hex text) into out; *out_len = bytes written.
 int zk_bn254_kzg_srs_write(uint64_t handle, const zk_g2_affine g2[2], int as_hex, void* out, size_t cap, size_t* out_len) {
     ZK_ON_ENTRY_OF(handle);

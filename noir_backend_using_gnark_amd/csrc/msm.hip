@@ -1668,6 +1668,34 @@ int bases_register_on_this_entry(const void* points, size_t n, int is_g2, int on
     return bases_register_here(points, n, is_g2, handle, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, table_c);
 }
 }  // namespace zkmi
+// the window table of a base array that is in HBM already: b->d_table / b->tab (left empty when the planner's table does not fit and none was asked for by width)
+static int bases_make_table(Bases* b, int table_c) {
+    const size_t n = b->n;
+    const int is_g2 = b->is_g2;
+    MsmTable tab;
+    tab.c = table_c > 0 ? (unsigned)table_c : msm_pick_window_table(n);
+    tab.stride = n;
+    // experiment switches: level sizes of the reduction tail of commits against registered bases (0 = the latency-structured default)
+    tab.l1_m = (unsigned)ZK_EXP("ZKMI_BASES_L1M", 0);
+    tab.l2_m = (unsigned)ZK_EXP("ZKMI_BASES_L2M", 0);
+    const size_t Wd = (255 + tab.c - 1) / tab.c, tbytes = Wd * n * (is_g2 ? 128 : 64);
+    size_t free_b = 0, total_b = 0;
+    ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (tbytes < free_b / 2 && tbytes <= ((size_t)64 << 30)) {
+        SlotGuard g;
+        ZK_TRY(acquire_slot(&g.s));
+        void* d_table = nullptr;
+        ZK_HIP(hipMalloc(&d_table, tbytes));
+        int rc = is_g2 ? msm_build_table_g2(g.s, g.s->stream, b->d, n, n, 0, tab.c, d_table) : msm_build_table_g1(g.s, g.s->stream, b->d, n, n, 0, tab.c, d_table);
+        if (rc == ZK_OK) rc = slot_sync(g.s, g.s->stream);
+        if (rc != ZK_OK) { (void)hipFree(d_table); return rc; }
+        b->tab = tab;
+        b->d_table = d_table;
+    } else if (table_c > 0) {
+        return set_err(ZK_ERR_HIP, "window tables of %zu bytes do not fit (free HBM %zu)", tbytes, free_b);
+    }
+    return ZK_OK;
+}
 extern "C" {
 static int bases_register_here(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c) {
     if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
@@ -1683,26 +1711,7 @@ static int bases_register_here(const void* points, size_t n, int is_g2, uint64_t
         ~Cleanup() { if (b) { (void)hipFree(b->d); if (b->d_table) (void)hipFree(b->d_table); } }
     } cleanup{&b};
     if (bytes) ZK_HIP(hipMemcpy(b.d, points, bytes, kind));
-    if (n && table_c != -1 && (table_c > 0 || n >= 4096)) {
-        b.tab.c = table_c > 0 ? (unsigned)table_c : msm_pick_window_table(n);
-        b.tab.stride = n;
-        // experiment switches: level sizes of the reduction tail of commits against registered bases (0 = the latency-structured default)
-        b.tab.l1_m = (unsigned)ZK_EXP("ZKMI_BASES_L1M", 0);
-        b.tab.l2_m = (unsigned)ZK_EXP("ZKMI_BASES_L2M", 0);
-        const size_t Wd = (255 + b.tab.c - 1) / b.tab.c, tbytes = Wd * n * (is_g2 ? 128 : 64);
-        size_t free_b = 0, total_b = 0;
-        ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (tbytes < free_b / 2 && tbytes <= ((size_t)64 << 30)) {
-            SlotGuard g;
-            ZK_TRY(acquire_slot(&g.s));
-            ZK_HIP(hipMalloc(&b.d_table, tbytes));
-            ZK_TRY(is_g2 ? msm_build_table_g2(g.s, g.s->stream, b.d, n, n, 0, b.tab.c, b.d_table)
-                         : msm_build_table_g1(g.s, g.s->stream, b.d, n, n, 0, b.tab.c, b.d_table));
-            ZK_TRY(slot_sync(g.s, g.s->stream));
-        } else if (table_c > 0) {
-            return set_err(ZK_ERR_HIP, "window tables of %zu bytes do not fit (free HBM %zu)", tbytes, free_b);
-        }
-    }
+    if (n && table_c != -1 && (table_c > 0 || n >= 4096)) ZK_TRY(bases_make_table(&b, table_c));
     std::lock_guard<std::mutex> lk(g_bases_mu);
     *handle = hmake(g_next_handle++);
     g_bases[*handle] = b;
@@ -1725,6 +1734,32 @@ int zk_bn254_bases_free(uint64_t handle) {
     (void)hipFree(it->second.d);
     if (it->second.d_table) (void)hipFree(it->second.d_table);
     g_bases.erase(it);
+    return ZK_OK;
+}
+// Window tables for a base array that was registered without them (table_window_bits as in zk_bn254_bases_register_cfg; 0 = the planner's width, and nothing
+// happens below 4096 bases).  Multi-exps that are running keep the geometry they started with; later ones find the table.  A handle that has one: ZK_OK, untouched.
+int zk_bn254_bases_build_table(uint64_t handle, int table_window_bits) {
+    if (table_window_bits != 0 && (table_window_bits < 8 || table_window_bits > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_window_bits);
+    if (md_is_composite(handle)) return md_bases_build_table(handle, table_window_bits);
+    ZK_ON_ENTRY_OF(handle);
+    Bases b;
+    {
+        std::lock_guard<std::mutex> lk(g_bases_mu);
+        auto it = g_bases.find(handle);
+        if (it == g_bases.end()) return set_err(ZK_ERR_HANDLE, "unknown bases handle %llu", (unsigned long long)handle);
+        b = it->second;
+    }
+    if (b.d_table || !b.n || (table_window_bits == 0 && b.n < 4096)) return ZK_OK;
+    ZK_TRY(bases_make_table(&b, table_window_bits));
+    if (!b.d_table) return ZK_OK;
+    std::lock_guard<std::mutex> lk(g_bases_mu);
+    auto it = g_bases.find(handle);
+    if (it == g_bases.end() || it->second.d_table) {  // freed, or built by another caller meanwhile
+        (void)hipFree(b.d_table);
+        return it == g_bases.end() ? set_err(ZK_ERR_HANDLE, "bases handle %llu was freed while its table was built", (unsigned long long)handle) : ZK_OK;
+    }
+    it->second.d_table = b.d_table;
+    it->second.tab = b.tab;
     return ZK_OK;
 }
 static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t n, const zk_msm_cfg* cfg, void* out, hipMemcpyKind kind) {

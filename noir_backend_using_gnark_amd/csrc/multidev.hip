@@ -215,6 +215,11 @@ static int md_find_bases(uint64_t h, std::shared_ptr<MdBases>* out) {
     *out = it->second;
     return ZK_OK;
 }
+int md_bases_build_table(uint64_t h, int table_bits) {
+    std::shared_ptr<MdBases> B;
+    ZK_TRY(md_find_bases(h, &B));
+    return team_run(B->entries, [&](int k) -> int { return zk_bn254_bases_build_table(B->sub[k], table_bits); });
+}
 int md_bases_info(uint64_t h, size_t* n, int* is_g2) {
     std::shared_ptr<MdBases> B;
     ZK_TRY(md_find_bases(h, &B));

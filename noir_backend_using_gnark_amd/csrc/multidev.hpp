@@ -18,6 +18,7 @@ int md_entries_for(uint32_t requested, size_t units, size_t min_units_per_entry,
 int bases_register_on_this_entry(const void* points, size_t n, int is_g2, int on_device, int table_c, uint64_t* handle);  // msm.hip: no spreading
 int md_msm_host(int g2, const void* points, const zk_fr* scalars, size_t n, const zk_msm_cfg* cfg, void* out, const std::vector<int>& entries);
 int md_bases_register(const void* points, size_t n, int is_g2, int on_device, int table_bits, const std::vector<int>& entries, uint64_t* handle);
+int md_bases_build_table(uint64_t h, int table_bits);
 int md_bases_info(uint64_t h, size_t* n, int* is_g2);
 int md_bases_free(uint64_t h);
 int md_msm_bases(uint64_t h, size_t offset, const void* scalars, size_t n, const zk_msm_cfg* cfg, void* out, int on_device);

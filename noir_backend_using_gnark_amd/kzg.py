@@ -65,3 +65,14 @@ def read_srs(data: bytes | str, is_hex: bool = False, table_window_bits: int = 0
     rb = ResidentBases.__new__(ResidentBases)
     rb.is_g2, rb.handle, rb.n = False, h, int(n.value)
     return SRS(rb, g2)
+
+
+def read_srs_g2(data: bytes | str, is_hex: bool = False) -> np.ndarray:
+    """The two G2 points of an SRS image ([1]2, [alpha]2), decoded on the HOST (zk_bn254_kzg_srs_g2): all that plonk.Verify needs of the SRS; no device is touched."""
+    raw = data.encode("ascii") if isinstance(data, str) else bytes(data)
+    g2 = np.zeros((2, 16), np.uint64)
+    rc = lib().zk_bn254_kzg_srs_g2(C.c_char_p(raw), C.c_size_t(len(raw)), C.c_int(int(is_hex)), vp(g2))
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    return g2

@@ -79,6 +79,15 @@ def main():
             except ValueError:
                 res["overrun_refused_%d" % k] = True
             comp.free()
+            # registered WITHOUT window tables, then zk_bn254_bases_build_table on the composite handle (every entry builds its range's): same commitments
+            late = zb.ResidentBases(dp, n=n, table_window_bits=-1)
+            a = single.multi_exp(sc[:70000], MONT, offset=999)
+            before = bool((late.multi_exp(sc[:70000], MONT, offset=999) == a).all())
+            late.build_table()
+            late.build_table()  # a second call finds them
+            res["tables_built_later_%d" % k] = before and bool((late.multi_exp(sc[:70000], MONT, offset=999) == a).all()) and bool(
+                (late.multi_exp_dev(ds, n, MONT) == single.multi_exp_dev(ds, n, MONT)).all())
+            late.free()
         _lib.check(L.zk_set_default_devices(C.c_uint32(0)))
         out.update(res)
     elif mode == "groth16":

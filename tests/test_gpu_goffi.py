@@ -185,8 +185,13 @@ def test_export_path_worker_cold_and_warm_calls_at_2p10(tmp_path):
     pr = run("prove", d, "3")
     assert pr["verifies"] == 1 and pr["warm_proof_verifies"] == 1 and pr["wrong_public_input_rejected"] == 1
     assert pr["resident"]["circuits"] == 1 and pr["resident"]["keys"] == 1
-    for k in ("hip_init", "srs_file_read", "srs_decode_and_tables", "acir_parse_lower", "pk_text_to_device", "pk_coset_forms", "values_decode", "witness_gather", "plonk_prove"):
+    for k in ("hip_init", "srs_file_read", "hip_start_wait", "srs_decode", "acir_parse_lower", "pk_text_to_device", "pk_coset_forms", "values_decode", "witness_gather", "plonk_prove"):
         assert k in pr["cold_phases"], k
+    # the SRS's window tables wait for the second proving call of a process (a process that makes one proof is better off without them)
+    assert "srs_window_tables" not in pr["cold_phases"] and "srs_window_tables" in pr["second_phases"] and "srs_window_tables" not in pr["warm_phases_per_call"]
+    # a process that only verifies takes the SRS's two G2 points from the file's header on the host: no HIP runtime, no device entry
+    ver = run("verify", d)
+    assert ver["verifies"] == 1 and ver["hip_runtime_started"] is False and ver["device_entries"] == 0 and "srs_g2_on_host" in ver["cold_phases"]
     assert "acir_parse_lower" not in pr["warm_phases_per_call"] and "pk_text_to_device" not in pr["warm_phases_per_call"]
     # ZKMI_TABLE_CAP_GB=0 keeps nothing between calls (the reference's behaviour): every call decodes again, the proofs still verify
     env0 = dict(env, ZKMI_TABLE_CAP_GB="0")

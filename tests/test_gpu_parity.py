@@ -959,6 +959,40 @@ def test_groth16_2p20_proof_bytes_vs_oracle():
         assert got == want, "witness-like" if witness else "uniform"
 
 
+def test_window_tables_built_after_registration():
+    """zk_bn254_bases_build_table: bases registered without window tables (what the export shim does for a process's first proof) get them later; commitments
+    before and after equal the oracle's, G1 and G2, planner's width and a forced one; the batched path (which needs the table) is reached afterwards; a second
+    call, a small array (below 4096: nothing to build) and a bad width behave as documented."""
+    n = 5000
+    pts, sc = orc.g1_gen_points(0xC1, n), orc.rand_fr(0xC2, n, witness_like=True)
+    want = orc.g1_msm(pts, sc)
+    for c in (0, 9):
+        rb = zb.ResidentBases(pts, table_window_bits=-1)
+        assert (rb.multi_exp(sc, MONT) == want).all()
+        rb.build_table(c)
+        assert (rb.multi_exp(sc, MONT) == want).all()
+        assert (rb.multi_exp(sc[:1234], MONT, offset=3000) == orc.g1_msm(pts[3000:4234], sc[:1234])).all()
+        got = rb.multi_exp_batch([sc, sc[::-1].copy()], config=MONT)
+        assert (got[0] == want).all() and (got[1] == orc.g1_msm(pts, sc[::-1].copy())).all()
+        rb.build_table(c)
+        rb.build_table(0)
+        assert (rb.multi_exp(sc, MONT) == want).all()
+        rb.free()
+    p2, s2 = orc.g2_gen_points(0xC3, 4100), orc.rand_fr(0xC4, 4100)
+    rb2 = zb.ResidentBases(p2, is_g2=True, table_window_bits=-1)
+    rb2.build_table()
+    assert (rb2.multi_exp(s2, MONT) == orc.g2_msm(p2, s2)).all()
+    rb2.free()
+    small = zb.ResidentBases(pts[:100], table_window_bits=-1)
+    small.build_table()  # below 4096 bases the planner builds none
+    assert (small.multi_exp(sc[:100], MONT) == orc.g1_msm(pts[:100], sc[:100])).all()
+    with pytest.raises(_lib.ZkmiError):
+        small.build_table(23)
+    small.free()
+    with pytest.raises(_lib.ZkmiError):
+        small.build_table()
+
+
 def test_batched_multi_exp_of_several_scalar_vectors_against_one_base_array():
     """zk_bn254_msm_bases_batch[_dev]: plonk.Prove's three simultaneous kzg.Commit calls (l, r, o; h1, h2, h3 -- gnark v0.8.0 plonk prove.go via
     backend/plonk/plonk.go:53-73) as ONE multi-scalar multiplication with a bucket set per vector.  Against the oracle and against one zk_bn254_msm_bases
