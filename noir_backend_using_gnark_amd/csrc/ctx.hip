@@ -56,6 +56,18 @@ static int init_entry(Ctx& c) {  // under c.mu
     c.prio_lo = lo;
     c.prio_hi = hi;
     for (int i = 0; i < Ctx::NSLOTS; i++) c.slots[i].owner = &c;  // the streams: at a slot's first acquisition / first hi()
+    // The own streams of the first five slots (a Groth16 proof's session) exist before anything else touches the runtime: the runtime gives the first four streams
+    // of a priority a hardware queue each and lets later ones -- the null stream's included -- share them, and WHICH streams share is part of the measured
+    // schedule of the 2^20 proof (created after the first copies and launches instead: 9.7 -> 11.1 ms, profiles/r05_c_stream_creation_order.jsonl).  The other
+    // eleven are created when first used: 3.5-10 ms each (tools/hip_start_bench.hip), and a process that makes one PLONK proof never needs them.
+    {
+        static const int at_init = ZK_EXP("ZKMI_INIT_STREAMS", 4);  // experiment: 0 none; 1 all sixteen, interleaved (rounds 1-3); 2 slots 0-4 both; 3 the eight own; 4 five own
+        const int ns = at_init == 1 || at_init == 3 ? Ctx::NSLOTS : (at_init == 2 || at_init == 4) ? 5 : 0;
+        for (int i = 0; i < ns; i++) {
+            ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
+            if (at_init <= 2) ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi_, hipStreamNonBlocking, hi));
+        }
+    }
     c.ready = true;
     return ZK_OK;
 }
@@ -183,6 +195,9 @@ static int slot_stream(Slot* s) {
 }
 hipStream_t Slot::hi() {
     std::lock_guard<std::mutex> lk(owner->mu);
+    return hi_locked();
+}
+hipStream_t Slot::hi_locked() {  // under owner->mu
     if (!stream_hi_) {
         int cur = owner->device;
         (void)hipGetDevice(&cur);
@@ -244,6 +259,14 @@ int acquire_slots(int k, Slot** out) {
                         return rc;
                     }
                 }
+                // A session of several slots (a Groth16 proof's five) uses their high-priority streams too, and WHICH of them share a hardware queue is part of
+                // the measured schedule: the runtime gives the first four streams of a priority a hardware queue each and lets the later ones share, in order of
+                // creation (tools/hip_start_bench.hip: 10 ms for streams 1-8, 3.5 ms after).  Created here in slot order, as when all sixteen streams were created
+                // with the entry, and not in order of first use (init_4 against init_2 in profiles/r05_c_stream_creation_order.jsonl: 9.80 against 9.65 ms).
+                static const int hi_order = ZK_EXP("ZKMI_HI_ORDER", 1234);  // experiment: creation order of the five as decimal digits (01234 = slot order)
+                if (hi_order != 1234 && k == 5)
+                    for (int i = 0, div = 10000; i < 5; i++, div /= 10) out[(hi_order / div) % 10 % 5]->hi_locked();
+                for (int i = 0; i < k; i++) out[i]->hi_locked();
                 return ZK_OK;
             }
         }
@@ -258,9 +281,11 @@ extern "C" int zk_warm_streams(int n) {
     if (n < 1) return ZK_OK;
     if (n > Ctx::NSLOTS) n = Ctx::NSLOTS;
     Slot* sl[Ctx::NSLOTS];
-    ZK_TRY(acquire_slots(n, sl));
-    for (int i = 0; i < n; i++) release_slot(sl[i]);
-    return ZK_OK;
+    int got = 0, rc = ZK_OK;
+    for (; got < n && rc == ZK_OK; got++) rc = acquire_slot(&sl[got]);  // one by one: the slots' own streams only (acquire_slots is a proof session's)
+    if (rc != ZK_OK) got--;
+    for (int i = 0; i < got; i++) release_slot(sl[i]);
+    return rc;
 }
 
 void release_slot(Slot* s) {

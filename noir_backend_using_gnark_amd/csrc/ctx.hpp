@@ -89,11 +89,12 @@ struct ProfEntry {
 
 // A stream slot: one HIP stream + one growing HBM arena + pinned host staging + pending profile events.
 struct Slot {
-    // Streams are created when first needed, not with the entry: hipStreamCreateWithPriority costs 7-14 ms each on MI355X / ROCm 7.2 (tools/hip_start_bench.hip:
-    // 113-229 ms for the 16 of one entry) and a process that makes ONE proof -- nargo's -- uses three or four of them.
-    hipStream_t stream = nullptr;     // normal priority; exists from the slot's first acquisition on
+    // Most streams are created when first needed, not with the entry: hipStreamCreateWithPriority costs 3.5-14 ms each on MI355X / ROCm 7.2
+    // (tools/hip_start_bench.hip: 113-229 ms for the 16 of one entry) and a process that makes ONE proof -- nargo's -- uses three or four of them.
+    hipStream_t stream = nullptr;     // normal priority; slots 0-4: created with the entry (ctx.hip init_entry says why), the others at their first acquisition
     hipStream_t stream_hi_ = nullptr; // high priority (critical-path chains of a proof): through hi()
     hipStream_t hi();                 // creates it on first use
+    hipStream_t hi_locked();          // the same under the owner's mutex (acquire_slots)
     void sync_hi() { if (stream_hi_) (void)hipStreamSynchronize(stream_hi_); }
     hipStream_t stream_prep = nullptr, stream_acc = nullptr;  // experiment (ZKMI_CU_SPLIT=k): CU-masked pair -- k CUs for scalar preparation, the rest for accumulates
     char* arena = nullptr;
