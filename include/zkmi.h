@@ -410,7 +410,8 @@ int zk_acir_public_witnesses(const char *acir_json, size_t acir_len, size_t n_va
  * circuit (wiring + variable order in HBM) and the decoded key (with its big-coset forms) resident, least recently used first out, within
  * ZKMI_TABLE_CAP_GB (0 keeps nothing).  A key text is only ever matched together with the circuit text and the SRS it was first seen with. */
 int zk_export_cache_info(size_t *n_circuits, size_t *n_keys, size_t *bytes);
-int zk_acir_lower_resident(const char *acir_json, size_t acir_len, size_t n_values, int layout); /* host only: lower now, keep resident (start-up overlap) */
+int zk_acir_lower_resident(const char *acir_json, size_t acir_len, size_t n_values, int layout, int with_coefficients); /* host only: lower now, keep resident
+    (start-up overlap: the export shim runs it beside the SRS load); with_coefficients: the selectors too, kept for the zk_plonk_preprocess that follows */
 int zk_export_cache_clear(void);
 /* HBM held by a resident PLONK key */
 int zk_bn254_plonk_pk_bytes(uint64_t handle, size_t *bytes);

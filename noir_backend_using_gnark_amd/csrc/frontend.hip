@@ -433,10 +433,14 @@ int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* v
 // Lowers a circuit text into the resident cache without touching a device (a caller that has other start-up work in flight -- the shim's SRS load -- runs this
 // beside it): the zk_plonk_prove_with_pk / zk_acir_public_witnesses that follows finds it by content key.  The lowering is keyed by device entry too: this is for
 // the entry the calling thread is on.
-int zk_acir_lower_resident(const char* acir_json, size_t acir_len, size_t n_values, int layout) {
+int zk_acir_lower_resident(const char* acir_json, size_t acir_len, size_t n_values, int layout, int with_coefficients) {
     if (!acir_json) return set_err(ZK_ERR_ARG, "null pointer");
     std::shared_ptr<Lowered> L;
-    return lowered_get(acir_json, acir_len, n_values, layout, &L, nullptr);
+    if (!with_coefficients) return lowered_get(acir_json, acir_len, n_values, layout, &L, nullptr);
+    Gates G;  // the selectors too: they wait in the stash for zk_plonk_preprocess's size query, as that query's own lowering does for the call that writes the key
+    ZK_TRY(lowered_get(acir_json, acir_len, n_values, layout, &L, &G));
+    stash_put(*L, std::move(G));
+    return ZK_OK;
 }
 
 // The public inputs of a circuit as the verifier needs them: out[k] = 0-based index, into the witness-value vector, of public variable k (HandleValues'

@@ -244,7 +244,7 @@ extern "C" {
 // The first call of a process: the HIP runtime starts, srs.hex is read and decoded and its window tables are built (0.4 s of driver and GPU work) -- on a
 // thread of its own, while this one reads the circuit text (0.2 s of one host core for 2^19 opcodes, no GPU involved): zk_acir_lower_resident leaves the
 // lowered circuit where the prover's lookup by content key finds it.  Later calls find both resident.
-void load_srs_and_lower(GoString acirJSON, View values, uint64_t* srs, zk_g2_affine g2[2]) {
+void load_srs_and_lower(GoString acirJSON, View values, uint64_t* srs, zk_g2_affine g2[2], int with_coefficients = 0) {
     bool first;
     {
         std::lock_guard<std::mutex> lk(g_srs.mu);
@@ -253,7 +253,8 @@ void load_srs_and_lower(GoString acirJSON, View values, uint64_t* srs, zk_g2_aff
     if (!first) { try_load_srs(srs, g2); srs_for_repeat_use(); return; }
     std::thread loader([&] { try_load_srs(srs, g2); srs_for_repeat_use(); });  // failures end the process (log.Fatal), from whichever thread
     size_t n_values = 0;
-    if (zkmi::count_from_hex(values.p, values.n, &n_values)) (void)zk_acir_lower_resident(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE);  // errors resurface in the call proper
+    if (zkmi::count_from_hex(values.p, values.n, &n_values))  // errors resurface in the call proper
+        (void)zk_acir_lower_resident(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE, with_coefficients);
     loader.join();
 }
 
@@ -268,9 +269,8 @@ char* PlonkProveWithPK(GoString acirJSON, GoString encodedValues, GoString encod
 KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {
     uint64_t srs;
     zk_g2_affine g2[2];
-    try_load_srs(&srs, g2);
-    srs_for_repeat_use();
     const View values = unquoted(encodedRandomValues);
+    load_srs_and_lower(acirJSON, values, &srs, g2, 1);  // a process's first call: the circuit text is lowered (selectors included) while the runtime starts
     size_t pk_len = 0, vk_len = 0;
     must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkPreprocess");
     // the key text (0.33 GB at 2^19 gates) is written once, into the C.CString the caller receives
@@ -286,9 +286,8 @@ KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {
 char* PlonkProveWithMeta(GoString acirJSON, GoString encodedValues) {
     uint64_t srs, h = 0;
     zk_g2_affine g2[2];
-    try_load_srs(&srs, g2);
-    srs_for_repeat_use();
     const View values = unquoted(encodedValues);
+    load_srs_and_lower(acirJSON, values, &srs, g2, 1);
     size_t pk_len = 0, vk_len = 0;
     must(zk_plonk_preprocess(acirJSON.p, (size_t)acirJSON.n, values.p, values.n, ZK_ACIR_LAYOUT_REFERENCE, srs, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "PlonkProveWithMeta");
     std::string pk(pk_len, '\0');
@@ -302,7 +301,8 @@ unsigned char PlonkVerifyWithMeta(GoString, GoString, GoString) { return 0; }  /
 
 unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoString encodedPublicInputs, GoString encodedVerifyingKey) {
     zk_g2_affine g2[2];
-    srs_g2_for_verify(g2);
+    std::thread srs_reader([&] { srs_g2_for_verify(g2); });  // 64 MB of text (22 ms) beside the circuit's lowering (20 ms at 2^19 opcodes); joined before g2 is used
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_reader{srs_reader};
     std::vector<uint8_t> proof;
     if (!hex_to_bytes(encodedProof.p, (size_t)encodedProof.n, &proof) || proof.size() != ZK_PLONK_PROOF_BYTES) { fprintf(stderr, "DeserializeProof: not the hex of a PLONK proof\n"); exit(1); }
     // the values arrive indexed by witness (backend.rs:103: get_values_from_witness_tree over all of the circuit's variables); HandleValues keeps the
@@ -329,6 +329,7 @@ unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoStri
     std::vector<zk_fr> pub;
     if (!be_to_mont(pub_be, &pub)) { fprintf(stderr, "DeserializeFelts: invalid fr.Element encoding\n"); exit(1); }
     int ok = 0;
+    srs_reader.join();
     const int rc = zk_bn254_plonk_verify(proof.data(), encodedVerifyingKey.p, (size_t)encodedVerifyingKey.n, 1, g2, pub.data(), pub.size(), &ok);
     if (rc == ZK_ERR_LEN) return 0;  // plonk.Verify's "invalid witness size" is an error value upstream, i.e. `false` (plonk.go:47-50)
     must(rc, "PlonkVerifyWithVK");
