@@ -67,6 +67,14 @@ static int init_entry(Ctx& c) {  // under c.mu
             ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
             if (at_init <= 2) ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi_, hipStreamNonBlocking, hi));
         }
+        // experiment: slot b runs on slot a's stream (explicit sharing instead of the runtime's hardware-queue sharing): ZKMI_ALIAS_LO / _HI = 10 * a + b + 100
+        static const int alias_lo = ZK_EXP("ZKMI_ALIAS_LO", 0), alias_hi = ZK_EXP("ZKMI_ALIAS_HI", 0);
+        if (alias_lo >= 100 && ns >= 5) c.slots[(alias_lo - 100) % 10].stream = c.slots[(alias_lo - 100) / 10].stream;
+        if (alias_hi >= 100) {
+            for (int i = 0; i < 5; i++)
+                if (!c.slots[i].stream_hi_) ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi_, hipStreamNonBlocking, hi));
+            c.slots[(alias_hi - 100) % 10].stream_hi_ = c.slots[(alias_hi - 100) / 10].stream_hi_;
+        }
     }
     c.ready = true;
     return ZK_OK;
