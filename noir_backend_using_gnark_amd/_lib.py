@@ -79,7 +79,7 @@ SYMBOLS = [
     "zk_bn254_groth16_verify", "zk_bn254_plonk_verify", "zk_bn254_pairing_check",
     "zk_bn254_r1cs_load", "zk_bn254_r1cs_free", "zk_bn254_r1cs_eval_abc_dev", "zk_bn254_groth16_setup", "zk_bn254_groth16_prove_r1cs",
     "zk_bn254_groth16_msm5_dev", "zk_bn254_groth16_msm5_pk", "zk_bn254_groth16_msm5_pk_begin", "zk_bn254_groth16_msm5_pk_end", "zk_bn254_groth16_msm5_pk_abort", "zk_bn254_groth16_msm5_session_stream", "zk_bn254_groth16_finalize",
-    "zk_bn254_plonk_setup", "zk_bn254_plonk_pk_load", "zk_bn254_plonk_pk_free", "zk_bn254_plonk_pk_export", "zk_bn254_plonk_pk_read", "zk_bn254_plonk_pk_write", "zk_bn254_plonk_prove", "zk_bn254_plonk_synth_qk_dev",
+    "zk_bn254_plonk_setup", "zk_bn254_plonk_pk_load", "zk_bn254_plonk_pk_free", "zk_bn254_plonk_pk_lagrange_srs", "zk_bn254_plonk_pk_export", "zk_bn254_plonk_pk_read", "zk_bn254_plonk_pk_write", "zk_bn254_plonk_prove", "zk_bn254_plonk_synth_qk_dev",
     "zk_plonk_preprocess", "zk_plonk_prove_with_pk", "zk_bn254_plonk_pk_info", "zk_acir_to_sparse_r1cs", "zk_groth16_r1cs_from_raw",
     "zk_groth16_preprocess", "zk_groth16_prove_with_pk", "zk_groth16_prove_with_meta",
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev", "zk_bn254_kzg_new_srs_dev", "zk_bn254_kzg_srs_read", "zk_bn254_kzg_srs_write",

@@ -28,6 +28,8 @@
 #include "host_ff.hpp"
 #include "msm.hpp"
 #include "keyio.hpp"
+#include "lagrange.hpp"
+#include "multidev.hpp"
 #include "ntt.hpp"
 #include "proofio.hpp"
 #include "text_host.hpp"
@@ -435,6 +437,11 @@ __global__ void k_blind(Fr* p, uint32_t n, BlindArgs B) {
     p[i] = ld(p + i) - B.b[i];
     p[n + i] = B.b[i];
 }
+// the blinding scalars behind a vector of n evaluations: p[n + i] = b_i -- the scalars of [tau^n - 1], [tau^(n+1) - tau] in a commitment against the Lagrange-form SRS
+__global__ void k_blind_tail(Fr* p, uint32_t n, BlindArgs B) {
+    int i = threadIdx.x;
+    if (i < B.k) p[n + i] = B.b[i];
+}
 // *flag |= 1 if any of a[0 .. n) is non-zero
 __global__ void k_any_nonzero(const Fr* __restrict__ a, size_t n, int* __restrict__ flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -469,6 +476,7 @@ struct PlonkPK {
     unsigned logn = 0, logN4 = 0, log_rho = 0;
     size_t n = 0, N4 = 0, n_public = 0, n_constraints = 0, n_vars = 0;
     uint64_t srs = 0;
+    uint64_t lag_srs = 0;  // the SRS in Lagrange form over this key's domain + the two points of the blinding (lagrange.hip; zk_bn254_plonk_pk_lagrange_srs), or 0
     HFr gen, u, card_inv;
     // canonical (regular) polynomials of the key, n each, and LQk (Lagrange)
     Fr *ql = nullptr, *qr = nullptr, *qm = nullptr, *qo = nullptr, *cqk = nullptr, *lqk = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
@@ -502,6 +510,7 @@ static int pk_alloc(PlonkPK* P, Fr** out, size_t elems) {
     return ZK_OK;
 }
 static void pk_destroy(PlonkPK* P) {
+    if (P->lag_srs) (void)zk_bn254_bases_free(P->lag_srs);
     for (void* p : P->allocs) (void)hipFree(p);
     delete P;
 }
@@ -543,19 +552,19 @@ struct BatchCommit3 {
     int rc = ZK_OK;
     std::string err;
     Affine<HFp> out[3];
-    static int run(const PlonkPK* P, const Fr* const* polys, size_t len, Affine<HFp>* outs) {
+    static int run(uint64_t bases, const Fr* const* polys, size_t len, Affine<HFp>* outs) {
         const void* sc[3] = {polys[0], polys[1], polys[2]};
-        return zk_bn254_msm_bases_batch_dev(P->srs, 0, sc, 3, len, &kMont, outs);
+        return zk_bn254_msm_bases_batch_dev(bases, 0, sc, 3, len, &kMont, outs);
     }
-    static bool possible(const PlonkPK* P, const size_t* lens) {
+    static bool possible(uint64_t bases, const size_t* lens) {
         const void* d_table = nullptr;
         size_t nbases = 0;
-        return lens[0] == lens[1] && lens[1] == lens[2] && bases_table(P->srs, &d_table, nullptr, &nbases) == ZK_OK && d_table && lens[0] <= nbases;
+        return lens[0] == lens[1] && lens[1] == lens[2] && bases_table(bases, &d_table, nullptr, &nbases) == ZK_OK && d_table && lens[0] <= nbases;
     }
-    void start(const PlonkPK* P, const Fr* const* polys, size_t len) {
+    void start(uint64_t bases, const Fr* const* polys, size_t len) {
         const Fr* p3[3] = {polys[0], polys[1], polys[2]};
-        th = std::thread([this, P, p3, len] {
-            rc = run(P, p3, len, out);
+        th = std::thread([this, bases, p3, len] {
+            rc = run(bases, p3, len, out);
             if (rc != ZK_OK) err = zk_last_error();
         });
     }
@@ -1143,6 +1152,42 @@ int zk_bn254_plonk_pk_bytes(uint64_t handle, size_t* bytes) {
     return ZK_OK;
 }
 
+// The SRS in Lagrange form over this key's domain, built once (lagrange.hip: n/2 log2 n + n point-by-scalar multiplications -- 0.15 s at 2^19 gates, 1.3 s at 2^22):
+// from then on zk_bn254_plonk_prove commits l, r, o from the wire values (same digests, a quarter to a third of the additions for the scalars of a real
+// circuit).  For a prover that keeps its key; needs the SRS on one device entry.  A key that has it: ZK_OK, untouched.
+int zk_bn254_plonk_pk_lagrange_srs(uint64_t handle) {
+    ZK_ON_ENTRY_OF(handle);
+    PlonkPK* P;
+    std::shared_ptr<std::mutex> mu;
+    {
+        std::lock_guard<std::mutex> lk(g_ppk_mu);
+        auto it = g_ppks.find(handle);
+        if (it == g_ppks.end()) return set_err(ZK_ERR_HANDLE, "unknown PLONK proving-key handle %llu", (unsigned long long)handle);
+        P = it->second;
+        mu = P->mu;
+    }
+    std::lock_guard<std::mutex> work(*mu);
+    {
+        std::lock_guard<std::mutex> lk(g_ppk_mu);
+        auto it = g_ppks.find(handle);
+        if (it == g_ppks.end() || it->second != P) return set_err(ZK_ERR_HANDLE, "PLONK proving key %llu was freed", (unsigned long long)handle);
+    }
+    if (P->lag_srs) return ZK_OK;
+    if (md_is_composite(P->srs)) return set_err(ZK_ERR_ARG, "the Lagrange form needs the SRS on one device entry");
+    const void* d_srs = nullptr;
+    size_t srs_n = 0;
+    int is_g2 = 0;
+    ZK_TRY(bases_ptr(P->srs, &d_srs, &srs_n, &is_g2));
+    uint64_t h = 0;
+    ZK_TRY(lagrange_srs_build(d_srs, srs_n, P->logn, &h));
+    P->lag_srs = h;
+    const void* d_table = nullptr;
+    MsmTable tab;
+    size_t nb = 0;
+    if (bases_table(h, &d_table, &tab, &nb) == ZK_OK) P->bytes += (P->n + 2) * 64 * (1 + (d_table ? (size_t)tab.rows() : 0));
+    return ZK_OK;
+}
+
 int zk_bn254_plonk_pk_free(uint64_t handle) {
     ZK_ON_ENTRY_OF(handle);
     PlonkPK* P;
@@ -1251,10 +1296,10 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             for (int k = 0; k < cnt; k++) ZK_TRY(commit(P, s, st, polys[k], lens[k], &outs[k]));
             return meanwhile();
         }
-        if (cnt == 3 && g_plonk_batch3 && BatchCommit3::possible(P, lens)) {
+        if (cnt == 3 && g_plonk_batch3 && BatchCommit3::possible(P->srs, lens)) {
             BatchCommit3 bc;
             ZK_TRY(slot_sync(s, st));
-            bc.start(P, polys, lens[0]);
+            bc.start(P->srs, polys, lens[0]);
             int rc = meanwhile();
             const int r2 = bc.join();
             if (rc == ZK_OK) rc = r2;
@@ -1272,22 +1317,48 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         }
         return rc;
     };
-    for (int k = 0; k < 3; k++) {
-        ZK_HIP(hipMemcpyAsync(can3[k], lag3[k], n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        ZK_HIP(hipMemsetAsync(can3[k] + n, 0, 8 * sizeof(Fr), st));
-        ZK_TRY(to_canonical(s, st, can3[k], logn));
-        BlindArgs B;
-        B.k = 2;
-        B.b[0] = to_dev(bl[2 * k]); B.b[1] = to_dev(bl[2 * k + 1]); B.b[2] = Fr::zero();
-        ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, can3[k], (uint32_t)n, B);
-    }
+    // canonical forms of l, r, o with their blinding (rounds 3-5 need them whichever way the digests are made)
+    auto lro_canonical = [&]() -> int {
+        for (int k = 0; k < 3; k++) {
+            ZK_HIP(hipMemcpyAsync(can3[k], lag3[k], n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+            ZK_HIP(hipMemsetAsync(can3[k] + n, 0, 8 * sizeof(Fr), st));
+            ZK_TRY(to_canonical(s, st, can3[k], logn));
+            BlindArgs B;
+            B.k = 2;
+            B.b[0] = to_dev(bl[2 * k]); B.b[1] = to_dev(bl[2 * k + 1]); B.b[2] = Fr::zero();
+            ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, can3[k], (uint32_t)n, B);
+        }
+        return ZK_OK;
+    };
     // the three commitments, while this stream already evaluates l, r, o on the big coset (no challenge needed for that).
     // Experiment ZKMI_PLONK_DEFER_LRO=1: those three transforms wait for round 2 (one commitment there instead of three here: round 1's three scalar
     // preparations then do not share the machine with them)
     static const bool defer_lro = ZK_EXP("ZKMI_PLONK_DEFER_LRO", 0) != 0;
+    static const bool use_lagrange = ZK_EXP("ZKMI_PLONK_LAGRANGE", 1) != 0;  // 0: coefficients against the monomial SRS even when the key has its Lagrange form (A/B)
     const Fr* small5[5] = {bl_, br_, bo_, bz_, qkc};
     const size_t len5[5] = {n + 2, n + 2, n + 2, n + 3, n};
-    {
+    const size_t lens_lag[3] = {n + 2, n + 2, n + 2};
+    if (P->lag_srs && use_lagrange && !chain.ok && !g_plonk_serial && BatchCommit3::possible(P->lag_srs, lens_lag)) {
+        // From the WIRE VALUES against the SRS's Lagrange form (lagrange.hip): [l] = sum_i l_i [L_i(tau)] + b0 [tau^n - 1] + b1 [tau^(n+1) - tau] -- the same three
+        // points, from scalars that are bits and words instead of uniform coefficients, and without waiting for the inverse transforms (they run meanwhile).
+        for (int k = 0; k < 3; k++) {
+            BlindArgs B;
+            B.k = 2;
+            B.b[0] = to_dev(bl[2 * k]); B.b[1] = to_dev(bl[2 * k + 1]); B.b[2] = Fr::zero();
+            ZK_LAUNCH(s, st, "plonk_blind_tail", k_blind_tail, dim3(1), dim3(64), 0, lag3[k], (uint32_t)n, B);
+        }
+        ZK_TRY(slot_sync(s, st));
+        BatchCommit3 bc;
+        bc.start(P->lag_srs, lag3, n + 2);
+        int rc = lro_canonical();
+        if (rc == ZK_OK && !defer_lro)
+            for (int k = 0; k < 3 && rc == ZK_OK; k++) rc = to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P);
+        const int r2 = bc.join();
+        if (rc == ZK_OK) rc = r2;
+        ZK_TRY(rc);
+        for (int k = 0; k < 3; k++) c_lro[k] = bc.out[k];
+    } else {
+        ZK_TRY(lro_canonical());
         const Fr* polys[3] = {bl_, br_, bo_};
         const size_t lens[3] = {n + 2, n + 2, n + 2};
         ZK_TRY(commit_group(3, polys, lens, c_lro, [&]() -> int {

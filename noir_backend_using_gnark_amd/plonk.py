@@ -50,6 +50,10 @@ class ProvingKey:
         check(lib().zk_bn254_plonk_pk_write(self.handle, C.c_int(int(as_hex)), buf, C.c_size_t(n.value), C.byref(n)))
         return buf.raw[:n.value]
 
+    def lagrange_srs(self) -> None:
+        """Build the SRS's Lagrange form over this key's domain (zk_bn254_plonk_pk_lagrange_srs): later proofs commit l, r, o from the wire values."""
+        check(lib().zk_bn254_plonk_pk_lagrange_srs(self.handle))
+
     def free(self):
         if self.handle.value:
             check(lib().zk_bn254_plonk_pk_free(self.handle))

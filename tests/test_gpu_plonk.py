@@ -127,6 +127,18 @@ def test_plonk_random_circuits_vs_oracle(nc, nvars, npub):
     pk2 = zp.load_proving_key(opk["d0"].logn, npub, spr.n_vars, polys, opk["perm"], [c[5] for c in g], [c[6] for c in g], [c[7] for c in g], pk.vk, rb)
     assert zp.prove(pk2, M(sol), M(bl)) == want   # a loaded key: the linearised digest by MSM, and compared with the value obtained by linearity
     assert zp.prove(pk2, M(sol), M(bl)) == want   # ... which this second proof then uses (the digests proved consistent)
+    # the same proof with l, r, o committed from the WIRE VALUES against the Lagrange form of the base array (zk_bn254_plonk_pk_lagrange_srs: the inverse
+    # transform of the points "in the exponent" + the two points of the blinding): same bytes.  The batched path needs a window table, i.e. a domain >= 4096.
+    pk2.lagrange_srs()
+    pk2.lagrange_srs()  # a second call finds it
+    _lib.profile(True)
+    _lib.profile_reset()
+    assert zp.prove(pk2, M(sol), M(bl)) == want
+    kern, _ = _lib.split_profile(_lib.profile_read())
+    _lib.profile(False)
+    assert ("plonk_blind_tail" in kern) == (n + 2 >= 4096), sorted(kern)
+    other = ref.rand_felts(990 + nc, 9)  # other blinders through the two extra points
+    assert zp.prove(pk2, M(sol), M(other)) == pl.plonk_proof_bytes(pl.plonk_prove(opk, sol, other, fast=True))
     pk2.free()
     pk.free()
     rb.free()

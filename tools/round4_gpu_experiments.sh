@@ -1,12 +1,7 @@
 set -u
-O=gpurun_out/r05g; mkdir -p $O
-run() { timeout 300 python bench.py $1 --steps 60 --no-2p24 --no-plonk --no-micro --no-export --no-cpu-baseline --no-host-inputs > $O/p.json 2> $O/p.err
+O=gpurun_out/r05j; mkdir -p $O
+for ln in 12 14 16 17 18 19 20 21 22; do
+  ZKMI_BENCH_PLONK_REPS=6 timeout 600 python bench.py --steps 5 --no-2p24 --no-micro --no-export --no-cpu-baseline --no-host-inputs --plonk-log-n $ln > $O/p.json 2> $O/p.err
   python -c "
-import json;d=json.loads([l for l in open('$O/p.json') if l.startswith('{')][-1]);print(json.dumps({'cfg':'$2','ms':d['ms_per_step'],'sha':d['proof_sha']}))" | tee -a $O/alias.jsonl; }
-run "--lib exp" base
-for q in 4 16; do export GPU_MAX_HW_QUEUES=$q
-for a in 101 102 103 104 112 113 114 123 124 134; do ZKMI_ALIAS_LO=$a run "--lib exp" hwq${q}_lo_$a; done
-for a in 101 102 104 112 114 124; do ZKMI_ALIAS_HI=$a run "--lib exp" hwq${q}_hi_$a; done
+import json;b=json.load(open('$O/p.json'));k=[x for x in b if x.startswith('plonk_2p')][0];p=b[k];print(json.dumps({'log_n':$ln,'prove_ms':p['prove_ms'],'coeff_ms':p['prove_ms_lro_from_coefficients'],'lagrange_build_ms':p['lagrange_srs_ms_once_per_key'],'same':p['same_bytes_both_ways'],'ok':p['proof_verifies'],'round1':p['rounds_ms']['round1_lro_committed']}))" | tee -a $O/plonk_lagrange.jsonl
 done
-unset GPU_MAX_HW_QUEUES
-run "--lib exp" base_again
