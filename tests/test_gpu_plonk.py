@@ -390,6 +390,16 @@ def test_export_cache_keeps_circuit_and_key_resident_and_changes_no_byte(plonk_g
     _lib.check(L.zk_export_cache_clear())
     assert info() == (0, 0, 0)
     assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"] and info()[:2] == (1, 1)   # cold again, same bytes
+    # a resident key that keeps being used gets the Lagrange form of its SRS when its 16th proof is asked for (the first call above decoded it: the key's
+    # count starts with the second): once, and no byte changes
+    _lib.profile(True)
+    _lib.profile_reset()
+    held = info()[2]
+    for _ in range(18):
+        assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"]
+    _, host = _lib.split_profile(_lib.profile_read())
+    _lib.profile(False)
+    assert host["export.pk_lagrange_srs"][0] == 1 and info()[2] > held
     _lib.check(L.zk_export_cache_clear())
     srs.free()
 
