@@ -18,6 +18,7 @@
 
 #include <functional>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -539,7 +540,13 @@ static inline bool elements_parallel(OpLower& M, unsigned nt) {
     }
     std::vector<ChunkResult> res(cuts.size());
     std::vector<std::thread> th;
-    for (size_t k = 1; k < cuts.size(); k++) th.emplace_back(run_chunk, cuts[k] + 1, end, std::cref(cuts), k + 1, std::cref(M), &res[k]);
+    for (size_t k = 1; k < cuts.size(); k++) {
+        try {
+            th.emplace_back(run_chunk, cuts[k] + 1, end, std::cref(cuts), k + 1, std::cref(M), &res[k]);
+        } catch (const std::system_error&) {  // no more threads to be had: this stretch on the calling thread
+            run_chunk(cuts[k] + 1, end, cuts, k + 1, M, &res[k]);
+        }
+    }
     run_chunk(begin, end, cuts, 1, M, &res[0]);
     for (auto& t : th) t.join();
     size_t total = M.S.xa.size();
