@@ -190,6 +190,71 @@ __global__ void k_msm_digits(DigitSrc src, uint32_t n, int mont, unsigned c, uns
     }
 }
 
+// ---- table mode with the zero digits dropped BEFORE the sort (opt-in: callers whose scalars are wire values -- bits, bytes, words -- where two thirds of the
+// digits are zero and the sort would move their sentinel keys through every pass): count the non-zero digits per scalar, scan, write them contiguously.  The caller
+// learns the total from the scan (one small copy + one synchronisation: only for callers that are synchronous anyway) and sorts that many pairs.  Same buckets,
+// same sums: within a bucket the points arrive in another order, and the group law does not care.
+template <class Emit>
+__device__ __forceinline__ void table_digits_of(const Fr* __restrict__ scalars, uint32_t i, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step,
+                                                Emit&& emit) {
+    Fr s;
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(scalars + i);
+        uint4 a = q[0], b = q[1];
+        s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w;
+        s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
+    }
+    if (mont) s = s.from_mont();
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    unsigned next_row = row_first, wl = 0;
+    for (unsigned w = 0; w < W; w++) {  // the recoding of k_msm_digits, digit for digit
+        unsigned bit = w * c, limb = bit >> 5, off = bit & 31;
+        uint64_t v = 0;
+        if (limb < 8) {
+            v = s.l[limb];
+            if (limb + 1 < 8) v |= (uint64_t)s.l[limb + 1] << 32;
+            v >>= off;
+        }
+        uint32_t d = ((uint32_t)v & ((1u << c) - 1)) + carry;
+        carry = 0;
+        uint32_t neg = 0, mag = d;
+        if (d > B) {
+            mag = (1u << c) - d;
+            neg = 1;
+            carry = 1;
+        }
+        if (w != next_row) continue;
+        emit(wl, mag, neg);
+        next_row += row_step;
+        wl++;
+    }
+}
+__global__ void k_msm_digit_count(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step, uint32_t* __restrict__ cnt) {
+    prio_hi();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned vec = blockIdx.y;
+    uint32_t k = 0;
+    table_digits_of(src.p[vec], i, mont, c, W, row_first, row_step, [&](unsigned, uint32_t mag, uint32_t) { k += mag != 0; });
+    cnt[(size_t)vec * n + i] = k;
+}
+__global__ void k_msm_digits_compact(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step, uint32_t table_stride,
+                                     const uint32_t* __restrict__ off, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    prio_hi();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned vec = blockIdx.y;
+    const uint32_t B = 1u << (c - 1);
+    uint32_t o = off[(size_t)vec * n + i];
+    table_digits_of(src.p[vec], i, mont, c, W, row_first, row_step, [&](unsigned wl, uint32_t mag, uint32_t neg) {
+        if (!mag) return;
+        keys[o] = vec * B + (mag - 1);
+        vals[o] = ((wl * table_stride + i) << 1) | neg;
+        o++;
+    });
+}
+
 // ---------------------------------------------------------------------------------------- 3. bucket boundaries
 // start[b] = first sorted position whose key >= b (lower bound), for b in [0, nb]; key nb is the zero-digit sentinel.
 // One lane per bucket, ~log2(total) dependent L2 hits each: no serial gap-filling loops whatever the key distribution
@@ -955,7 +1020,8 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
 
 // Scalar-side half of an MSM on stream `st`: digits, sort, bucket bounds, task plan.  The result only depends on the
 // scalars, so several MSMs over the same scalar vector (Groth16: A, B1, K and G2.B all pair with the wire values) share it.
-static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out, const DigitSrc* batch = nullptr) {
+static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out, const DigitSrc* batch = nullptr,
+                       bool drop_zero_digits = false) {
     out->P = P;
     out->n = n;
     out->empty = (n == 0) || P.total == 0;  // no points, or a window-sharded table of which this rank owns no row
@@ -963,7 +1029,8 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     if (out->empty) return ZK_OK;
     const unsigned c = P.c, W = P.W, key_bits = P.key_bits;
     const uint32_t nb = P.nb, L = P.L;
-    const size_t total = P.total, max_tasks = P.max_tasks;
+    size_t total = P.total;
+    const size_t max_tasks = P.max_tasks;
     size_t sort_tmp_bytes = P.sort_tmp_bytes, scan_tmp_bytes = P.scan_tmp_bytes;
     uint32_t* keys0 = (uint32_t*)s->alloc(total * 4);
     uint32_t* keys1 = (uint32_t*)s->alloc(total * 4);
@@ -992,8 +1059,31 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     {
         DigitSrc src = batch ? *batch : DigitSrc{{d_scalars, nullptr, nullptr}};
         const unsigned sets = P.table_stride ? P.W : 1;
-        ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, dim3((unsigned)((n + 255) / 256), sets), dim3(256), 0, src, (uint32_t)n,
-                  (cfg && cfg->scalars_mont) ? 1 : 0, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step, P.Wrows);
+        const int mont = (cfg && cfg->scalars_mont) ? 1 : 0;
+        const dim3 grid((unsigned)((n + 255) / 256), sets);
+        if (drop_zero_digits && P.table_stride) {  // count, scan, write only the non-zero digits (see k_msm_digit_count); the caller reserved msm_compact_need more
+            const size_t m = (size_t)sets * n;
+            uint32_t* cnt = (uint32_t*)s->alloc((m + 1) * 4);
+            uint32_t* off = (uint32_t*)s->alloc((m + 1) * 4);
+            void* ctmp = s->alloc(xs_tmp_bytes(m + 1) + 16);
+            if (!cnt || !off || !ctmp) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (zero-digit compaction)");
+            ZK_HIP(hipMemsetAsync(cnt + m, 0, 4, st));
+            ZK_LAUNCH(s, st, "msm_digits", k_msm_digit_count, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, P.row_first, P.row_step, cnt);
+            ZK_TRY(xs_exclusive_scan(s, st, ctmp, cnt, off, m + 1));
+            uint32_t h_total = 0;
+            ZK_HIP(hipMemcpyAsync(&h_total, off + m, 4, hipMemcpyDeviceToHost, st));
+            ZK_TRY(slot_sync(s, st));
+            if (h_total == 0) {  // every scalar is zero
+                out->empty = true;
+                return ZK_OK;
+            }
+            ZK_LAUNCH(s, st, "msm_digits", k_msm_digits_compact, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, P.row_first, P.row_step, P.table_stride,
+                      (const uint32_t*)off, keys0, vals0);
+            total = h_total;
+        } else {
+            ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step,
+                      P.Wrows);
+        }
     }
     // ---- 2. sort (bucket key -> point index|sign)
     PingPong kb(keys0, keys1), vb(vals0, vals1);
@@ -1327,13 +1417,18 @@ int msm_prep_need_table_batch(size_t n, unsigned sets, const MsmTable& tab, hipS
     if (need_acc_g1) *need_acc_g1 = P1.need_acc;
     return ZK_OK;
 }
-int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out) {
+size_t msm_compact_need(size_t n, unsigned sets) {  // what dropping the zero digits adds to the preparation's workspace
+    const size_t m = (size_t)sets * n;
+    return 2 * align_up((m + 1) * 4, 256) + align_up(xs_tmp_bytes(m + 1) + 16, 256) + 1024;
+}
+int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out,
+                                    bool drop_zero_digits) {
     if (sets < 1 || sets > 3) return set_err(ZK_ERR_ARG, "a batch holds one to three scalar vectors");
     MsmPlan P;
     ZK_TRY(msm_plan<Fp>(n, cfg, st, &P, &tab, sets));
     DigitSrc src = {{nullptr, nullptr, nullptr}};
     for (unsigned v = 0; v < sets; v++) src.p[v] = (const Fr*)d_scalars[v];
-    return msm_prepare(s, st, P, src.p[0], n, cfg, out, &src);
+    return msm_prepare(s, st, P, src.p[0], n, cfg, out, &src, drop_zero_digits);
 }
 int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out) {
     MsmPlan P;
@@ -1995,7 +2090,8 @@ int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void* d_scalars
 // gnark_backend_ffi/backend/plonk/plonk.go:53-73).  With a G1 window table on one device entry the `count` (<= 3) multi-exps are ONE multi-scalar
 // multiplication with one bucket set per vector: one digit pass over the vectors, one sort, one task plan, ONE accumulate launch, one reduction per set.
 // Everything else (G2, no table, a composite handle, an explicit window width, count > 3) runs the vectors one after the other through msm_bases: same points out.
-static int msm_bases_batch(uint64_t handle, size_t offset, const void* const* scalars, unsigned count, size_t n, const zk_msm_cfg* cfg, void* out, hipMemcpyKind kind) {
+static int msm_bases_batch(uint64_t handle, size_t offset, const void* const* scalars, unsigned count, size_t n, const zk_msm_cfg* cfg, void* out, hipMemcpyKind kind,
+                           bool sparse = false) {
     if (!count) return ZK_OK;
     if (!scalars || !out) return set_err(ZK_ERR_ARG, "null pointer");
     for (unsigned k = 0; k < count; k++)
@@ -2026,7 +2122,7 @@ static int msm_bases_batch(uint64_t handle, size_t offset, const void* const* sc
     size_t np = 0, na = 0;
     ZK_TRY(msm_prep_need_table_batch(n, count, b.tab, st, &np, &na));
     const bool up = kind != hipMemcpyDeviceToDevice;
-    ZK_TRY(g.s->reserve((up ? count * (n * 32 + 1024) : 0) + np + na + 65536));
+    ZK_TRY(g.s->reserve((up ? count * (n * 32 + 1024) : 0) + np + na + 65536 + (sparse ? msm_compact_need(n, count) : 0)));
     const void* sc[3] = {nullptr, nullptr, nullptr};
     for (unsigned k = 0; k < count; k++) {
         if (up) {
@@ -2036,7 +2132,7 @@ static int msm_bases_batch(uint64_t handle, size_t offset, const void* const* sc
         } else sc[k] = scalars[k];
     }
     MsmPrep prep;
-    ZK_TRY(msm_prepare_scalars_table_batch(g.s, st, sc, count, n, cfg, b.tab, &prep));
+    ZK_TRY(msm_prepare_scalars_table_batch(g.s, st, sc, count, n, cfg, b.tab, &prep, sparse));
     MsmJob job;
     job.turnstile = up;  // as in msm_bases: host-slice callers are upstream's goroutines
     XYZZ<HFp> t[3];
@@ -2048,6 +2144,14 @@ static int msm_bases_batch(uint64_t handle, size_t offset, const void* const* sc
     for (unsigned k = 0; k < count; k++) write_affine(t[k], (zk_g1_affine*)out + k);
     return ZK_OK;
 }
+}  // extern "C"
+namespace zkmi {
+// the same for scalars known to be mostly small (the PLONK prover's wire values): the zero digits are dropped before the sort (k_msm_digit_count)
+int msm_bases_batch_dev_sparse(uint64_t handle, size_t offset, const void* const* d_scalars, unsigned count, size_t n, const zk_msm_cfg* cfg, void* out) {
+    return msm_bases_batch(handle, offset, d_scalars, count, n, cfg, out, hipMemcpyDeviceToDevice, true);
+}
+}  // namespace zkmi
+extern "C" {
 int zk_bn254_msm_bases_batch(uint64_t handle, size_t offset, const zk_fr* const* scalars, uint32_t count, size_t n, const zk_msm_cfg* cfg, void* out) {
     return msm_bases_batch(handle, offset, (const void* const*)scalars, count, n, cfg, out, hipMemcpyHostToDevice);
 }

@@ -86,7 +86,11 @@ int msm_prep_need_table(size_t n, const MsmTable& tab, hipStream_t st, size_t* n
 int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out);
 // a batch of up to three scalar vectors (n elements each) against ONE window table: one recoding, one accumulate launch, one sum per vector
 int msm_prep_need_table_batch(size_t n, unsigned sets, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1);
-int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out);
+int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out,
+                                    bool drop_zero_digits = false);  // true: synchronises the stream once (callers that are synchronous anyway), reserve msm_compact_need more
+size_t msm_compact_need(size_t n, unsigned sets);
+// zk_bn254_msm_bases_batch_dev for scalars known to be mostly small (wire values): zero digits dropped before the sort
+int msm_bases_batch_dev_sparse(uint64_t handle, size_t offset, const void* const* d_scalars, unsigned count, size_t n, const zk_msm_cfg* cfg, void* out);
 int msm_g1_finish_batch(const MsmJob& job, XYZZ<HFp> out[3]);
 void msm_prep_release(MsmPrep* R);
 int msm_g1_accumulate(Slot* s, hipStream_t st, const MsmPrep& R, const void* d_pts, uint32_t skip_below, MsmJob* job);

@@ -552,8 +552,10 @@ struct BatchCommit3 {
     int rc = ZK_OK;
     std::string err;
     Affine<HFp> out[3];
-    static int run(uint64_t bases, const Fr* const* polys, size_t len, Affine<HFp>* outs) {
+    static int run(uint64_t bases, const Fr* const* polys, size_t len, Affine<HFp>* outs, bool wire_values) {
         const void* sc[3] = {polys[0], polys[1], polys[2]};
+        static const bool sparse = ZK_EXP("ZKMI_PLONK_SPARSE_DIGITS", 1) != 0;  // 0: wire values sorted with their zero digits (A/B)
+        if (wire_values && sparse) return msm_bases_batch_dev_sparse(bases, 0, sc, 3, len, &kMont, outs);
         return zk_bn254_msm_bases_batch_dev(bases, 0, sc, 3, len, &kMont, outs);
     }
     static bool possible(uint64_t bases, const size_t* lens) {
@@ -561,10 +563,10 @@ struct BatchCommit3 {
         size_t nbases = 0;
         return lens[0] == lens[1] && lens[1] == lens[2] && bases_table(bases, &d_table, nullptr, &nbases) == ZK_OK && d_table && lens[0] <= nbases;
     }
-    void start(uint64_t bases, const Fr* const* polys, size_t len) {
+    void start(uint64_t bases, const Fr* const* polys, size_t len, bool wire_values = false) {
         const Fr* p3[3] = {polys[0], polys[1], polys[2]};
-        th = std::thread([this, bases, p3, len] {
-            rc = run(bases, p3, len, out);
+        th = std::thread([this, bases, p3, len, wire_values] {
+            rc = run(bases, p3, len, out, wire_values);
             if (rc != ZK_OK) err = zk_last_error();
         });
     }
@@ -1349,7 +1351,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         }
         ZK_TRY(slot_sync(s, st));
         BatchCommit3 bc;
-        bc.start(P->lag_srs, lag3, n + 2);
+        bc.start(P->lag_srs, lag3, n + 2, true);
         int rc = lro_canonical();
         if (rc == ZK_OK && !defer_lro)
             for (int k = 0; k < 3 && rc == ZK_OK; k++) rc = to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P);
