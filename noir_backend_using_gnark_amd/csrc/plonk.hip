@@ -1340,6 +1340,14 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     const Fr* small5[5] = {bl_, br_, bo_, bz_, qkc};
     const size_t len5[5] = {n + 2, n + 2, n + 2, n + 3, n};
     const size_t lens_lag[3] = {n + 2, n + 2, n + 2};
+    static const bool coset_side = ZK_EXP("ZKMI_PLONK_COSET_SIDE", 0) != 0;
+    struct SideEvents {
+        hipEvent_t e[2] = {nullptr, nullptr};
+        hipStream_t side = nullptr;
+        ~SideEvents() { if (side) (void)hipStreamSynchronize(side); for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+    } side_events;
+    hipEvent_t* side_ev = side_events.e;
+    bool side_pending = false;
     if (P->lag_srs && use_lagrange && !chain.ok && !g_plonk_serial && BatchCommit3::possible(P->lag_srs, lens_lag)) {
         // From the WIRE VALUES against the SRS's Lagrange form (lagrange.hip): [l] = sum_i l_i [L_i(tau)] + b0 [tau^n - 1] + b1 [tau^(n+1) - tau] -- the same three
         // points, from scalars that are bits and words instead of uniform coefficients, and without waiting for the inverse transforms (they run meanwhile).
@@ -1353,7 +1361,16 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         BatchCommit3 bc;
         bc.start(P->lag_srs, lag3, n + 2, true);
         int rc = lro_canonical();
-        if (rc == ZK_OK && !defer_lro)
+        if (rc == ZK_OK && coset_side && !defer_lro) {  // experiment: the three 4n transforms on the slot's other stream, joined before the quotient kernel
+            hipStream_t side = s->hi();
+            side_events.side = side;
+            if (hipEventCreateWithFlags(&side_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&side_ev[1], hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(side_ev[0], st) != hipSuccess || hipStreamWaitEvent(side, side_ev[0], 0) != hipSuccess)
+                rc = set_err(ZK_ERR_HIP, "event setup failed");
+            for (int k = 0; k < 3 && rc == ZK_OK; k++) rc = to_big_coset(s, side, P->w_big[k], small5[k], len5[k], P);
+            if (rc == ZK_OK && hipEventRecord(side_ev[1], side) != hipSuccess) rc = set_err(ZK_ERR_HIP, "event record failed");
+            side_pending = rc == ZK_OK;
+        } else if (rc == ZK_OK && !defer_lro)
             for (int k = 0; k < 3 && rc == ZK_OK; k++) rc = to_big_coset(s, st, P->w_big[k], small5[k], len5[k], P);
         const int r2 = bc.join();
         if (rc == ZK_OK) rc = r2;
@@ -1443,6 +1460,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             cur = cur * Wn;
         }
         for (unsigned j = (1u << P->log_rho); j < 8; j++) A.xn_inv[j] = Fr::zero();
+        if (side_pending) ZK_HIP(hipStreamWaitEvent(st, side_ev[1], 0));
         static const bool quot29 = ZK_EXP("ZKMI_PLONK_QUOT29", 1) != 0;  // A/B switch: 0 = the saturated 8 x 32-bit form
         if (quot29) ZK_LAUNCH(s, st, "plonk_quotient", k_quotient29, dim3(grid_of(N4)), dim3(256), 0, A);
         else ZK_LAUNCH(s, st, "plonk_quotient", k_quotient, dim3(grid_of(N4)), dim3(256), 0, A);
