@@ -122,6 +122,11 @@ int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_
  * prove) is better off without them, one that makes many builds them when the second proof is asked for (csrc/goffi.cpp does exactly that). */
 int zk_bn254_bases_build_table(uint64_t handle, int table_window_bits);
 int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);
+/* The Lagrange form of a registered G1 base array over the domain of 2^log_n points, as a base array of its own: out[i] = (1/n) sum_j w^(-ij) in[j] for i < n (the
+ * inverse transform taken in the exponent: n/2 log2 n + n point-by-scalar multiplications on the device), then in[n] - in[0] and in[n+1] - in[1] (for a KZG SRS:
+ * [tau^n - 1], [tau^(n+1) - tau], the points of gnark's blinding).  sum_i e_i out[i] == sum_j c_j in[j] whenever c = FFTInverse(e): a polynomial is committed from its
+ * EVALUATIONS -- wire values, small -- instead of its coefficients.  Needs 2^log_n + 2 points on one device entry; free the result with zk_bn254_bases_free. */
+int zk_bn254_bases_lagrange(uint64_t handle, uint32_t log_n, uint64_t *out_handle);
 /* `count` scalar vectors of n elements each against ONE registered base array: out[k] = MultiExp(bases[offset : offset + n], scalars[k]) -- plonk.Prove's
  * three simultaneous kzg.Commit calls (l, r, o; h1, h2, h3: gnark v0.8.0 backend/plonk/bn254/prove.go, reached from gnark_backend_ffi/backend/plonk/plonk.go:53-73).
  * With a G1 window table and count <= 3 they are ONE multi-scalar multiplication with a bucket set per vector (one recoding, one accumulate launch); otherwise the

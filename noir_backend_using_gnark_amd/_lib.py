@@ -70,7 +70,7 @@ SYMBOLS = [
     "zk_device_count", "zk_init", "zk_last_error", "zk_version",
     "zk_bn254_g1_msm", "zk_bn254_g2_msm", "zk_bn254_g1_msm_dev", "zk_bn254_g2_msm_dev",
     "zk_bn254_g1_msm_partial_dev", "zk_bn254_g2_msm_partial_dev", "zk_bn254_g1_sum_xyzz", "zk_bn254_g2_sum_xyzz",
-    "zk_bn254_msm_plan_info", "zk_bn254_bases_register", "zk_bn254_bases_register_dev", "zk_bn254_bases_register_cfg", "zk_bn254_bases_build_table", "zk_bn254_bases_free", "zk_bn254_msm_bases", "zk_bn254_msm_bases_batch", "zk_bn254_msm_bases_batch_dev", "zk_bn254_msm_bases_dev", "zk_bn254_scalars_register", "zk_bn254_scalars_free", "zk_bn254_msm_bases_prepared",
+    "zk_bn254_msm_plan_info", "zk_bn254_bases_register", "zk_bn254_bases_register_dev", "zk_bn254_bases_register_cfg", "zk_bn254_bases_build_table", "zk_bn254_bases_lagrange", "zk_bn254_bases_free", "zk_bn254_msm_bases", "zk_bn254_msm_bases_batch", "zk_bn254_msm_bases_batch_dev", "zk_bn254_msm_bases_dev", "zk_bn254_scalars_register", "zk_bn254_scalars_free", "zk_bn254_msm_bases_prepared",
     "zk_bn254_ntt", "zk_bn254_ntt_dev", "zk_bn254_bit_reverse", "zk_bn254_bit_reverse_dev",
     "zk_bn254_groth16_compute_h", "zk_bn254_groth16_compute_h_dev", "zk_bn254_groth16_h_shard_dev", "zk_bn254_ntt_shard_dev",
     "zk_bn254_felts_decode_hex", "zk_bn254_felts_decode_hex_dev", "zk_bn254_felts_decode_bytes_dev", "zk_bn254_felts_encode_hex",

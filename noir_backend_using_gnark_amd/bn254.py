@@ -139,6 +139,13 @@ class ResidentBases:
         check(rc)
         return out
 
+    def lagrange(self, log_n: int) -> "ResidentBases":
+        """The Lagrange form of these G1 bases over the domain of 2^log_n points (zk_bn254_bases_lagrange): 2^log_n + 2 bases of their own."""
+        rb = ResidentBases.__new__(ResidentBases)
+        rb.is_g2, rb.handle, rb.n = False, C.c_uint64(0), (1 << log_n) + 2
+        check(lib().zk_bn254_bases_lagrange(self.handle, C.c_uint32(log_n), C.byref(rb.handle)))
+        return rb
+
     def build_table(self, table_window_bits: int = 0) -> None:
         """Window tables for bases registered without them (zk_bn254_bases_build_table); a no-op when they exist."""
         check(lib().zk_bn254_bases_build_table(self.handle, C.c_int(table_window_bits)))

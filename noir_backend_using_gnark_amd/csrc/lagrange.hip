@@ -19,7 +19,9 @@
 #include "curve.hpp"
 #include "ff29.hpp"
 #include "host_ff.hpp"
+#include "keyio.hpp"
 #include "lagrange.hpp"
+#include "multidev.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
 #include "proofio.hpp"
@@ -153,3 +155,19 @@ int lagrange_srs_build(const void* d_srs, size_t srs_n, unsigned logn, uint64_t*
 }
 
 }  // namespace zkmi
+
+// The Lagrange form of a registered G1 base array over the domain of 2^log_n points, as a base array of its own (2^log_n + 2 points: [L_i] for i < n, then
+// P_n - P_0 and P_(n+1) - P_1 -- for an SRS [tau^n - 1], [tau^(n+1) - tau]): sum_i e_i out[i] = sum_j c_j in[j] whenever c = FFTInverse(e).  Any points do (the
+// map is linear); the caller frees the result with zk_bn254_bases_free.
+extern "C" int zk_bn254_bases_lagrange(uint64_t bases, uint32_t log_n, uint64_t* out_handle) {
+    using namespace zkmi;
+    if (!out_handle) return set_err(ZK_ERR_ARG, "null pointer");
+    if (md_is_composite(bases)) return set_err(ZK_ERR_ARG, "the Lagrange form needs the base array on one device entry");
+    ZK_ON_ENTRY_OF(bases);
+    const void* d = nullptr;
+    size_t n = 0;
+    int is_g2 = 0;
+    ZK_TRY(bases_ptr(bases, &d, &n, &is_g2));
+    if (is_g2) return set_err(ZK_ERR_ARG, "the Lagrange form is built for G1 base arrays");
+    return lagrange_srs_build(d, n, log_n, out_handle);
+}

@@ -1175,13 +1175,8 @@ int zk_bn254_plonk_pk_lagrange_srs(uint64_t handle) {
         if (it == g_ppks.end() || it->second != P) return set_err(ZK_ERR_HANDLE, "PLONK proving key %llu was freed", (unsigned long long)handle);
     }
     if (P->lag_srs) return ZK_OK;
-    if (md_is_composite(P->srs)) return set_err(ZK_ERR_ARG, "the Lagrange form needs the SRS on one device entry");
-    const void* d_srs = nullptr;
-    size_t srs_n = 0;
-    int is_g2 = 0;
-    ZK_TRY(bases_ptr(P->srs, &d_srs, &srs_n, &is_g2));
     uint64_t h = 0;
-    ZK_TRY(lagrange_srs_build(d_srs, srs_n, P->logn, &h));
+    ZK_TRY(zk_bn254_bases_lagrange(P->srs, P->logn, &h));
     P->lag_srs = h;
     const void* d_table = nullptr;
     MsmTable tab;

@@ -959,6 +959,44 @@ def test_groth16_2p20_proof_bytes_vs_oracle():
         assert got == want, "witness-like" if witness else "uniform"
 
 
+def test_lagrange_form_of_a_base_array_vs_oracle():
+    """zk_bn254_bases_lagrange (csrc/lagrange.hip: the inverse transform of a base array taken in the exponent + the two points of gnark's blinding): a commitment
+    from EVALUATIONS against the Lagrange form equals the oracle's multi-exp of the blinded COEFFICIENTS (the oracle's FFTInverse) against the points themselves --
+    for any points (the map is linear), domains of 2 .. 2^13 points, witness-like and uniform evaluations, through the plain and the window-table multi-exp, and as
+    one batched call; errors as documented."""
+    b = orc.rand_fr(0xD7, 2)
+    for log_n in (1, 2, 5, 9, 13):
+        n = 1 << log_n
+        pts = orc.g1_gen_points(0xD0 + log_n, n + 3)
+        rb = zb.ResidentBases(pts, table_window_bits=-1)
+        lag = rb.lagrange(log_n)
+        assert lag.n == n + 2
+        vecs, wants = [], []
+        for seed, wl in ((0xE0 + log_n, True), (0xF0 + log_n, False)):
+            e = orc.rand_fr(seed, n, witness_like=wl)
+            c = orc.fr_bit_reverse(orc.fr_ntt(e, True, 1))          # FFTInverse(DIF) + BitReverse: canonical coefficients
+            blinded = np.concatenate([c, np.zeros((2, 4), np.uint64)])
+            blinded[0] = orc.fe_op("sub", 0, blinded[0], b[0])         # + (b0 + b1 X)(X^n - 1)
+            blinded[1] = orc.fe_op("sub", 0, blinded[1], b[1])
+            blinded[n] = orc.fe_op("add", 0, blinded[n], b[0])
+            blinded[n + 1] = orc.fe_op("add", 0, blinded[n + 1], b[1])
+            want = orc.g1_msm(pts[:n + 2], blinded)
+            ext = np.concatenate([e, b])
+            assert (lag.multi_exp(ext, MONT) == want).all(), (log_n, wl)
+            vecs.append(ext); wants.append(want)
+        lag.build_table(8)
+        got = lag.multi_exp_batch(vecs, config=MONT)
+        assert (got[0] == wants[0]).all() and (got[1] == wants[1]).all(), log_n
+        lag.free()
+        with pytest.raises(_lib.ZkmiError):
+            rb.lagrange(log_n + 1)          # needs 2^(log_n + 1) + 2 points
+        rb.free()
+    g2 = zb.ResidentBases(orc.g2_gen_points(0xD9, 6), is_g2=True)
+    with pytest.raises(_lib.ZkmiError):
+        g2.lagrange(2)
+    g2.free()
+
+
 def test_window_tables_built_after_registration():
     """zk_bn254_bases_build_table: bases registered without window tables (what the export shim does for a process's first proof) get them later; commitments
     before and after equal the oracle's, G1 and G2, planner's width and a forced one; the batched path (which needs the table) is reached afterwards; a second
