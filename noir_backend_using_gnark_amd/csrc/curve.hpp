@@ -131,4 +131,31 @@ ZK_HD XYZZ<F> scalar_mul(const Affine<F>& p, const uint32_t k[8]) {
     return r;
 }
 
+// sum_t k_t P_t for a handful of terms (cnt <= 8): interleaved 4-bit windows -- ONE chain of 252 doublings shared by all terms, 15 precomputed multiples per
+// point -- instead of one double-and-add per term.  Host use (digests the PLONK prover derives from digests); k_t canonical little-endian, below 2^256.
+template <class F>
+ZK_HD XYZZ<F> multi_scalar_mul(const Affine<F>* pts, const uint32_t (*k)[8], int cnt) {
+    constexpr int MAXT = 8;
+    XYZZ<F> tab[MAXT][16];
+    if (cnt > MAXT) cnt = MAXT;
+    for (int t = 0; t < cnt; t++) {
+        tab[t][0] = XYZZ<F>::inf();
+        tab[t][1] = pts[t].is_inf() ? XYZZ<F>::inf() : XYZZ<F>::from_affine(pts[t]);
+        for (int j = 2; j < 16; j++) {
+            tab[t][j] = tab[t][j - 1];
+            tab[t][j].madd(pts[t]);  // (an affine (0, 0) -- infinity -- is skipped by madd)
+        }
+    }
+    XYZZ<F> r = XYZZ<F>::inf();
+    for (int w = 63; w >= 0; w--) {
+        if (w != 63)
+            for (int d = 0; d < 4; d++) r.dbl();
+        for (int t = 0; t < cnt; t++) {
+            const uint32_t dg = (k[t][w >> 3] >> (4 * (w & 7))) & 15;
+            if (dg) r.add(tab[t][dg]);
+        }
+    }
+    return r;
+}
+
 }  // namespace zkmi

@@ -522,33 +522,13 @@ static int commit(const PlonkPK* P, Slot* s, hipStream_t st, const Fr* d_p, size
     return zk_bn254_msm_bases_dev(P->srs, 0, d_p, len, &kMont, out);
 }
 
-// sum_i k_i P_i for a handful of points on the HOST (digests the prover derives from digests: the linearised polynomial's, the folded quotient's): interleaved
-// 4-bit windows -- one chain of 252 doublings shared by all terms, 15 precomputed multiples per point -- instead of one double-and-add per term.  The group
-// element, and so the affine result, is the same.
+// sum_i k_i P_i for a handful of points on the HOST (digests the prover derives from digests: the linearised polynomial's, the folded quotient's) by the
+// interleaved-window method of curve.hpp instead of one double-and-add per term.  The group element, and so the affine result, is the same.
 static XYZZ<HFp> host_multi_scalar_mul(const Affine<HFp>* pts, const HFr* ks, int cnt) {
-    constexpr int MAXT = 8;
-    XYZZ<HFp> tab[MAXT][16];
-    uint32_t k[MAXT][8];
-    if (cnt > MAXT) cnt = MAXT;
-    for (int t = 0; t < cnt; t++) {
-        to_canonical_u32(ks[t], k[t]);
-        tab[t][0] = XYZZ<HFp>::inf();
-        tab[t][1] = pts[t].is_inf() ? XYZZ<HFp>::inf() : XYZZ<HFp>::from_affine(pts[t]);
-        for (int j = 2; j < 16; j++) {
-            tab[t][j] = tab[t][j - 1];
-            if (!pts[t].is_inf()) tab[t][j].madd(pts[t]);
-        }
-    }
-    XYZZ<HFp> r = XYZZ<HFp>::inf();
-    for (int w = 63; w >= 0; w--) {
-        if (w != 63)
-            for (int d = 0; d < 4; d++) r.dbl();
-        for (int t = 0; t < cnt; t++) {
-            const uint32_t dg = (k[t][w >> 3] >> (4 * (w & 7))) & 15;
-            if (dg) r.add(tab[t][dg]);
-        }
-    }
-    return r;
+    uint32_t k[8][8];
+    if (cnt > 8) cnt = 8;
+    for (int t = 0; t < cnt; t++) to_canonical_u32(ks[t], k[t]);
+    return multi_scalar_mul(pts, k, cnt);
 }
 
 // A commitment in flight on a host thread of its own (the MSM entry point is synchronous and re-entrant: each call takes a stream slot), so that

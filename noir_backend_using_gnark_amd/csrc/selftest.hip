@@ -86,6 +86,24 @@ extern "C" int zk_selftest_host(void) {
     dd.add(p1);
     d2.dbl();
     bad += !same(dd.to_affine(), d2.to_affine());
+    // interleaved-window multi-scalar multiplication (curve.hpp; the PLONK prover's host-side digests) against the sum of plain double-and-add products: random
+    // scalars, a zero scalar, a point at infinity, the same point twice with opposite scalars' worth (k and r - k would need Fr here: equal points suffice)
+    {
+        Affine<HFp> pts[5] = {p1.to_affine(), p2.to_affine(), p3.to_affine(), Affine<HFp>::inf(), p1.to_affine()};
+        uint32_t ks[5][8];
+        for (int t = 0; t < 5; t++) {
+            HFr r = rnd<HFrParams>(s);
+            for (int i = 0; i < 4; i++) { ks[t][2 * i] = (uint32_t)r.l[i]; ks[t][2 * i + 1] = (uint32_t)(r.l[i] >> 32); }
+        }
+        for (int i = 0; i < 8; i++) ks[1][i] = 0;
+        ks[2][0] = 1;
+        for (int i = 1; i < 8; i++) ks[2][i] = 0;
+        XYZZ<HFp> want = XYZZ<HFp>::inf();
+        for (int t = 0; t < 5; t++) want.add(scalar_mul(pts[t], ks[t]));
+        bad += !same(multi_scalar_mul(pts, ks, 5).to_affine(), want.to_affine());
+        bad += !multi_scalar_mul(pts, ks, 0).is_inf();
+        bad += !same(multi_scalar_mul(pts + 2, ks + 2, 1).to_affine(), pts[2]);
+    }
     // the transcript primitives of the PLONK prover (proofio.hpp): SHA-256 known answers (FIPS 180-4: "abc", the 56-byte message that needs two
     // blocks, one million 'a'), the transcript's chaining, fr.SetBytes' reduction
     {
