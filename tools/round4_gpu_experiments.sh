@@ -1,8 +1,7 @@
 set -u
-O=gpurun_out/r05r; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_plonk.py tests/test_gpu_goffi.py -m gpu -q -x > $O/pytest.txt 2>&1; tail -5 $O/pytest.txt
-for ln in 14 17 19 20 22; do
-  ZKMI_BENCH_PLONK_REPS=6 timeout 600 python bench.py --steps 5 --no-2p24 --no-micro --no-export --no-cpu-baseline --no-host-inputs --plonk-log-n $ln > $O/p.json 2> $O/p.err
+O=gpurun_out/r05s; mkdir -p $O
+for q in 4 2 8; do
+  GPU_MAX_HW_QUEUES=$q ZKMI_BENCH_PLONK_REPS=4 timeout 900 python bench.py --steps 20 --no-micro --no-export --no-cpu-baseline --no-host-inputs > $O/p.json 2> $O/p.err
   python -c "
-import json;b=json.load(open('$O/p.json'));k=[x for x in b if x.startswith('plonk_2p')][0];p=b[k];print(json.dumps({'log_n':$ln,'prove_ms':p['prove_ms'],'coeff_ms':p['prove_ms_lro_from_coefficients'],'same':p['same_bytes_both_ways'],'ok':p['proof_verifies'],'rounds':p['rounds_ms']}))" | tee -a $O/plonk_host_straus.jsonl
+import json;d=json.loads([l for l in open('$O/p.json') if l.startswith('{')][-1]);print(json.dumps({'GPU_MAX_HW_QUEUES':$q,'groth16_2p20_ms':d['ms_per_step'],'groth16_2p24_ms':d['at_2p24']['prove_ms'],'plonk_2p22_ms':d['plonk_2p22']['prove_ms'],'plonk_2p22_coeff_ms':d['plonk_2p22']['prove_ms_lro_from_coefficients']}))" | tee -a $O/hwq_all_sizes.jsonl
 done
