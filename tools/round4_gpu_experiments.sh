@@ -1,7 +1,7 @@
 set -u
-O=gpurun_out/r05s; mkdir -p $O
-for q in 4 2 8; do
-  GPU_MAX_HW_QUEUES=$q ZKMI_BENCH_PLONK_REPS=4 timeout 900 python bench.py --steps 20 --no-micro --no-export --no-cpu-baseline --no-host-inputs > $O/p.json 2> $O/p.err
+O=gpurun_out/r05v; mkdir -p $O
+for ln in 8 10 11; do for c in 0 8 10 12; do
+  ZKMI_BENCH_SRS_C=$c ZKMI_BENCH_PLONK_REPS=10 timeout 300 python bench.py --steps 3 --no-2p24 --no-micro --no-export --no-cpu-baseline --no-host-inputs --plonk-log-n $ln > $O/p.json 2> $O/p.err
   python -c "
-import json;d=json.loads([l for l in open('$O/p.json') if l.startswith('{')][-1]);print(json.dumps({'GPU_MAX_HW_QUEUES':$q,'groth16_2p20_ms':d['ms_per_step'],'groth16_2p24_ms':d['at_2p24']['prove_ms'],'plonk_2p22_ms':d['plonk_2p22']['prove_ms'],'plonk_2p22_coeff_ms':d['plonk_2p22']['prove_ms_lro_from_coefficients']}))" | tee -a $O/hwq_all_sizes.jsonl
-done
+import json;b=json.load(open('$O/p.json'));k=[x for x in b if x.startswith('plonk_2p')][0];p=b[k];print(json.dumps({'log_n':$ln,'srs_table_c':$c,'prove_ms':p['prove_ms'],'coeff_ms':p['prove_ms_lro_from_coefficients'],'ok':p['proof_verifies'],'rounds':p['rounds_ms']}))" | tee -a $O/plonk_tiny_tables.jsonl
+done; done
