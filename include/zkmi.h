@@ -118,7 +118,7 @@ int zk_bn254_bases_register_dev(const void *d_points, size_t n, int is_g2, uint6
  * -1 no tables, else c in [8, 22] (tables at any n: how the tests reach the widths the planner picks at 2^22 .. 2^26 points). */
 int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_device, int table_window_bits, uint64_t *handle);
 /* Window tables for a base array registered without them (table_window_bits as above; 0 = the planner's width, nothing below 4096 bases; a handle that has
- * a table is left alone).  The tables of 1,000,000 G1 points take 23 ms to build and save a 2^19-gate PLONK proof 1.4 ms: a process that makes ONE proof (nargo
+ * a table is left alone).  The tables of 1,000,000 G1 points take 17 ms to build and save a 2^19-gate PLONK proof 1.4 ms: a process that makes ONE proof (nargo
  * prove) is better off without them, one that makes many builds them when the second proof is asked for (csrc/goffi.cpp does exactly that). */
 int zk_bn254_bases_build_table(uint64_t handle, int table_window_bits);
 int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);

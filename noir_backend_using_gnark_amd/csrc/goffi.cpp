@@ -151,7 +151,7 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         lap.lap("export.srs_file_read");
         starter.join();
         lap.lap("export.hip_start_wait");  // what the runtime and the first streams still took once the file was in memory
-        // No window tables yet: for 1,000,000 points they take 23 ms to build and save a 2^19-gate proof 1.4 ms -- a process that makes one proof (nargo prove)
+        // No window tables yet: for 1,000,000 points they take 17 ms to build and save a 2^19-gate proof 1.4 ms -- a process that makes one proof (nargo prove)
         // is better off without; srs_for_repeat_use builds them when a second proving call arrives.
         if (usable) {
             size_t n = 0;
