@@ -1469,6 +1469,19 @@ __global__ __launch_bounds__(256) void k_build_table(const Affine<F>* __restrict
             }
         }
     }
+    if constexpr (std::is_same<F, Fp2>::value) {  // G2: the same with the Fp2 form of the chain
+        Acc29G2 A;
+        acc29g2_from_xyzz(A, XYZZ<Fp2>::from_affine(p));
+        for (unsigned w = 0; w < Wd; w++) {
+            if (w) {
+                for (unsigned b = 0; b < c; b++) acc29g2_dbl(A);
+            }
+            if (w < row_first || (w - row_first) % row_step) continue;
+            const XYZZ<Fp2> r = acc29g2_to_xyzz(A);
+            xs[k] = r.x; ys[k] = r.y; zs[k] = r.zz; ws[k] = r.zzz;
+            k++;
+        }
+    }
     if (k == 0) {
         XYZZ<F> acc = XYZZ<F>::from_affine(p);
         for (unsigned w = 0; w < Wd; w++) {
