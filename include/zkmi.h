@@ -80,6 +80,11 @@ int zk_init_devices(const int *devices, size_t n);
  * 40-160 ms (tools/hip_start_bench.hip), so the library creates them when a slot is first used -- or here, for a caller that has host work to do meanwhile (the
  * export shim reads srs.hex).  n slots of the calling thread's device entry (at most all 8). */
 int zk_warm_streams(int n);
+/* Process-wide start-up choices; call before anything that touches a device.  ZK_INIT_LEAN_STREAMS: a device entry creates only the five streams every caller
+ * needs with itself and every other stream on first use (the default also creates the five high-priority streams of a Groth16 proof session up front: 40 ms more
+ * start-up, 1 % less per 2^20 proof -- WHICH streams share a hardware queue follows creation order).  For a process that makes one proof and exits. */
+#define ZK_INIT_LEAN_STREAMS 1u
+int zk_init_flags(uint32_t flags);
 int zk_device_entries(int *devices_out, size_t cap); /* number of entries; devices_out[i] = HIP device of entry i */
 int zk_set_entry(int entry);
 int zk_set_default_devices(uint32_t mask);

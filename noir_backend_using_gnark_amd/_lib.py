@@ -85,7 +85,7 @@ SYMBOLS = [
     "zk_bn254_fr_random_dev", "zk_bn254_g1_generate_dev", "zk_bn254_g2_generate_dev", "zk_bn254_fr_mul_dev", "zk_bn254_kzg_new_srs_dev", "zk_bn254_kzg_srs_read", "zk_bn254_kzg_srs_write",
     "zk_dev_alloc", "zk_dev_free", "zk_dev_h2d", "zk_dev_d2h", "zk_dev_sync",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_profile_host", "zk_selftest_host",
-    "zk_init_devices", "zk_warm_streams", "zk_bn254_kzg_srs_g2", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
+    "zk_init_devices", "zk_warm_streams", "zk_init_flags", "zk_bn254_kzg_srs_g2", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
     "zk_acir_public_witnesses", "zk_acir_lower_resident", "zk_export_cache_info", "zk_export_cache_clear", "zk_bn254_plonk_pk_bytes",
 ]
 

@@ -31,6 +31,7 @@ static Ctx* g_entries[MAX_ENTRIES];
 static std::atomic<int> g_n_entries{0};
 static std::mutex g_entries_mu;
 static thread_local int t_entry = 0;
+static std::atomic<bool> g_lean_start{false};  // zk_init_flags(ZK_INIT_LEAN_STREAMS)
 
 Prof& prof() {
     static Prof p;
@@ -60,8 +61,12 @@ static int init_entry(Ctx& c) {  // under c.mu
     // of a priority a hardware queue each and lets later ones -- the null stream's included -- share them, and WHICH streams share is part of the measured
     // schedule of the 2^20 proof (created after the first copies and launches instead: 9.7 -> 11.1 ms, profiles/r05_c_stream_creation_order.jsonl).  The other
     // eleven are created when first used: 3.5-10 ms each (tools/hip_start_bench.hip), and a process that makes one PLONK proof never needs them.
+    // Their high-priority streams too, interleaved with them, on the process's first entry -- created later (at the first proof session or at a key's load) the
+    // same proof takes 1 % longer (9.48-9.53 against 9.58-9.64 ms, profiles/r05_z_hi_streams_at_init.jsonl) -- unless the caller asked for a lean start
+    // (zk_init_flags: the export shim, whose one PLONK proof uses three streams and counts every 10 ms of its cold call).
     {
-        static const int at_init = ZK_EXP("ZKMI_INIT_STREAMS", 4);  // experiment: 0 none; 1 all sixteen, interleaved (rounds 1-3); 2 slots 0-4 both; 3 the eight own; 4 five own
+        static const int knob = ZK_EXP("ZKMI_INIT_STREAMS", -1);  // experiment: 0 none; 1 all sixteen, interleaved (rounds 1-3); 2 slots 0-4 both; 3 the eight own; 4 five own
+        const int at_init = knob >= 0 ? knob : (g_lean_start.load() || c.entry != 0) ? 4 : 2;
         const int ns = at_init == 1 || at_init == 3 ? Ctx::NSLOTS : (at_init == 2 || at_init == 4) ? 5 : 0;
         for (int i = 0; i < ns; i++) {
             ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
@@ -284,6 +289,13 @@ int acquire_slots(int k, Slot** out) {
 
 // The streams a first proof will take, created ahead of time (7-14 ms each, the process's first one 40-160 ms: tools/hip_start_bench.hip) -- for a caller that
 // has something else to do meanwhile (the export shim reads srs.hex).  n slots of the calling thread's entry, at most all of them.
+// Process-wide start-up choices, read when a device entry is first used (call it before anything that touches a device).  ZK_INIT_LEAN_STREAMS: create only the
+// streams every caller needs with the entry and the others on first use -- for a process that makes one proof and exits.
+extern "C" int zk_init_flags(uint32_t flags) {
+    if (flags & ~(uint32_t)ZK_INIT_LEAN_STREAMS) return set_err(ZK_ERR_ARG, "unknown start-up flags 0x%x", flags);
+    g_lean_start.store((flags & ZK_INIT_LEAN_STREAMS) != 0);
+    return ZK_OK;
+}
 extern "C" int zk_warm_streams(int n) {
     ZK_TRY(ensure_init());
     if (n < 1) return ZK_OK;

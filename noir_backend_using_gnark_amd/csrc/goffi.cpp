@@ -139,6 +139,7 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         // multi-GPU node the SRS below is then kept by range on all of them and every commitment of the prover is one partial per GPU (csrc/multidev.hip) --
         // nothing above this library changes; one GPU: one entry, as before.
         std::thread starter([] {
+            must(zk_init_flags(ZK_INIT_LEAN_STREAMS), "zk_init_flags");  // a process behind these exports typically makes ONE call: no stream it will not use
             must(zk_init_devices(nullptr, 0), "zk_init_devices");
             must(zk_warm_streams(3), "zk_warm_streams");
         });

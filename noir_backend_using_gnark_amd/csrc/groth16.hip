@@ -125,6 +125,13 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     if (_entry.rc != ZK_OK) return _entry.rc;
     if (pk->log_domain > 28 || pk->n_public > pk->n_wires) return set_err(ZK_ERR_ARG, "bad proving-key geometry");
     if (pk->n_wires >= ((size_t)1 << 31)) return set_err(ZK_ERR_ARG, "n_wires = %zu does not fit 31 bits", pk->n_wires);
+    {   // experiment: the five slots of a proof session (and their high-priority streams) exist from the key's load on, not from the first proof on
+        static const bool warm = ZK_EXP("ZKMI_PK_LOAD_WARMS_SESSION", 0) != 0;
+        if (warm) {
+            SlotsGuard<5> g;
+            ZK_TRY(acquire_slots(5, g.s));
+        }
+    }
     if (!pk->g1_alpha || !pk->g1_beta || !pk->g1_delta || !pk->g2_beta || !pk->g2_delta) return set_err(ZK_ERR_ARG, "null pk element");
     if ((pk->infinity_a == nullptr) != (pk->infinity_b == nullptr)) return set_err(ZK_ERR_ARG, "InfinityA and InfinityB must be given together");
     if (!pk->infinity_a && (pk->nb_infinity_a || pk->nb_infinity_b)) return set_err(ZK_ERR_ARG, "NbInfinityA/B without the bitmaps");
