@@ -1,3 +1,5 @@
+# scratch: the LAST one-off experiment of round 4 as it was sent to a GPU box (rewritten per run; results are copied to profiles/ by hand -- see profiles/INDEX.md).
+# The repeatable measurement batch is tools/round4_gpu.sh.
 set -u
 O=gpurun_out/r06c; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_goffi.py tests/test_gpu_plonk.py -m gpu -q -x -k "goffi or export or cache or handle_values" > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
