@@ -1288,6 +1288,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
     CommitChain chain;
     if (g_plonk_chain && !g_plonk_serial) ZK_TRY(chain.init(P, n + 3));
     // a group of independent commitments + the work the main stream does meanwhile
+    hipStream_t commit_sync = st;  // the stream the polynomials of the next commit_group are produced on
     auto commit_group = [&](int cnt, const Fr* const* polys, const size_t* lens, Affine<HFp>* outs, const std::function<int()>& meanwhile) -> int {
         if (chain.ok) {
             for (int k = 0; k < cnt; k++) ZK_TRY(chain.start(k, st, polys[k], lens[k]));
@@ -1313,7 +1314,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             return rc;
         }
         AsyncCommit ac[3];
-        ZK_TRY(slot_sync(s, st));
+        ZK_TRY(slot_sync(s, commit_sync));
         for (int k = 0; k < cnt; k++) ac[k].start(P, polys[k], lens[k]);
         int rc = meanwhile();
         for (int k = 0; k < cnt; k++) {
@@ -1351,7 +1352,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
         ~SideEvents() { if (side) (void)hipStreamSynchronize(side); for (auto& x : e) if (x) (void)hipEventDestroy(x); }
     } side_events;
     hipEvent_t* side_ev = side_events.e;
-    bool side_pending = false;
+    bool side_pending = false, used_lagrange = false;
     if (P->lag_srs && use_lagrange && !chain.ok && !g_plonk_serial && BatchCommit3::possible(P->lag_srs, lens_lag)) {
         // From the WIRE VALUES against the SRS's Lagrange form (lagrange.hip): [l] = sum_i l_i [L_i(tau)] + b0 [tau^n - 1] + b1 [tau^(n+1) - tau] -- the same three
         // points, from scalars that are bits and words instead of uniform coefficients, and without waiting for the inverse transforms (they run meanwhile).
@@ -1362,6 +1363,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             ZK_LAUNCH(s, st, "plonk_blind_tail", k_blind_tail, dim3(1), dim3(64), 0, lag3[k], (uint32_t)n, B);
         }
         ZK_TRY(slot_sync(s, st));
+        used_lagrange = true;
         BatchCommit3 bc;
         bc.start(P->lag_srs, lag3, n + 2, true);
         int rc = lro_canonical();
@@ -1402,24 +1404,29 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
 
     // ---- z
     const HFr u = P->u, uu = u * u;
-    ZK_LAUNCH(s, st, "plonk_z_terms", k_z_terms, dim3(grid_of(n)), dim3(256), 0, (const Fr*)l_lag, (const Fr*)r_lag, (const Fr*)o_lag, (const Fr*)P->sig, (const Fr*)d0->tw,
+    // experiment (ZKMI_PLONK_Z_SIDE=1, with the Lagrange-form round 1): round 1's coset transforms are still running on the main stream when the challenges arrive;
+    // z's chain (short kernels) on the slot's high-priority stream instead of behind them, and its commitment starts as soon as THAT stream is done
+    static const bool z_side = ZK_EXP("ZKMI_PLONK_Z_SIDE", 0) != 0;
+    hipStream_t zst = (z_side && used_lagrange) ? s->hi() : st;
+    ZK_LAUNCH(s, zst, "plonk_z_terms", k_z_terms, dim3(grid_of(n)), dim3(256), 0, (const Fr*)l_lag, (const Fr*)r_lag, (const Fr*)o_lag, (const Fr*)P->sig, (const Fr*)d0->tw,
               (uint32_t)n, to_dev(beta), to_dev(beta * u), to_dev(beta * uu), to_dev(gamma), num, den);
     {
         size_t lanes = (n + BINV_K - 1) / BINV_K;
-        ZK_LAUNCH(s, st, "plonk_batch_inverse", k_batch_inverse, dim3(grid_of(lanes)), dim3(256), 0, den, n, W + 14 * S);
+        ZK_LAUNCH(s, zst, "plonk_batch_inverse", k_batch_inverse, dim3(grid_of(lanes)), dim3(256), 0, den, n, W + 14 * S);
     }
-    ZK_LAUNCH(s, st, "plonk_pscan_local", k_pscan_local, dim3(SB.nb), dim3(256), 0, (const Fr*)num, (const Fr*)den, n, SB.K, SB.t, SB.b);
-    ZK_LAUNCH(s, st, "plonk_pscan_blocks", k_pscan_blocks, dim3(1), dim3(1024), 0, SB.b, SB.nb);
-    ZK_LAUNCH(s, st, "plonk_pscan_apply", k_pscan_apply, dim3(SB.nb), dim3(256), 0, (const Fr*)num, (const Fr*)den, n, SB.K, (const Fr*)SB.t, (const Fr*)SB.b, bz_);
-    ZK_HIP(hipMemsetAsync(bz_ + n, 0, 8 * sizeof(Fr), st));
-    ZK_TRY(to_canonical(s, st, bz_, logn));
+    ZK_LAUNCH(s, zst, "plonk_pscan_local", k_pscan_local, dim3(SB.nb), dim3(256), 0, (const Fr*)num, (const Fr*)den, n, SB.K, SB.t, SB.b);
+    ZK_LAUNCH(s, zst, "plonk_pscan_blocks", k_pscan_blocks, dim3(1), dim3(1024), 0, SB.b, SB.nb);
+    ZK_LAUNCH(s, zst, "plonk_pscan_apply", k_pscan_apply, dim3(SB.nb), dim3(256), 0, (const Fr*)num, (const Fr*)den, n, SB.K, (const Fr*)SB.t, (const Fr*)SB.b, bz_);
+    ZK_HIP(hipMemsetAsync(bz_ + n, 0, 8 * sizeof(Fr), zst));
+    ZK_TRY(to_canonical(s, zst, bz_, logn));
     {
         BlindArgs B;
         B.k = 3;
         for (int i = 0; i < 3; i++) B.b[i] = to_dev(bl[6 + i]);
-        ZK_LAUNCH(s, st, "plonk_blind", k_blind, dim3(1), dim3(64), 0, bz_, (uint32_t)n, B);
+        ZK_LAUNCH(s, zst, "plonk_blind", k_blind, dim3(1), dim3(64), 0, bz_, (uint32_t)n, B);
     }
     // commitment to z; meanwhile: qk completed with the public inputs (canonical), z and qk on the big coset
+    commit_sync = zst;
     {
         const Fr* polys[1] = {bz_};
         const size_t lens[1] = {n + 3};
@@ -1440,6 +1447,7 @@ int zk_bn254_plonk_prove(uint64_t handle, const void* solution, size_t n_vars, i
             return ZK_OK;
         }));
     }
+    commit_sync = st;
     lap("plonk.round2_z_committed");
     fs.bind_g1(2, c_z);
     HFr alpha = fs.challenge(2);
