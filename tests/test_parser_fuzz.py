@@ -87,12 +87,13 @@ def test_content_key_separates_texts_and_is_stable_across_thread_counts(tmp_path
     one byte more gives another key."""
     exe = str(tmp_path / "lower_bench")
     subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tools", "lower_bench.cpp"), "-lpthread", "-o", exe])
-    acir, w = synth_acir.synth(3000, 2, seed=9)  # > 64 segments of 64 KB: the threaded path
+    acir, w = synth_acir.synth(8000, 2, seed=9)  # > 64 segments of 64 KB: the threaded key; > 2 MB: the opcodes array goes to several parsers (acir_detail::elements_parallel)
+    assert len(acir) > (2 << 20)
     keys = []
     for k, text in enumerate([acir, acir, acir[:70000] + ("1" if acir[70000] != "1" else "2") + acir[70001:], acir + " "]):
         f = tmp_path / ("t%d.json" % k)
         f.write_text(text)
         rep = json.loads(subprocess.run([exe, str(f), str(len(w))], capture_output=True, text=True, check=False).stdout.strip().splitlines()[-1])
-        assert rep["same_output"] is True
+        assert rep["same_output"] is True  # the default (several parsers) == one parser == the document-tree reader, word for word
         keys.append(rep["key"])
     assert keys[0] == keys[1] and len({keys[0], keys[2], keys[3]}) == 3
