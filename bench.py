@@ -579,7 +579,7 @@ def export_path_block(log_gates=19, warm_calls=10):
     d = tempfile.mkdtemp(prefix="zkmi_export_")
     exe = [sys.executable, os.path.join(ROOT, "tools", "export_bench.py")]
     env = dict(os.environ, PYTHONPATH=ROOT)
-    env.pop("ZKMI_EXPORT_SRS_SIZE", None)
+    env.pop("ZKMI_TEST_NEW_SRS_SIZE", None)
 
     def run(*a):
         r = subprocess.run(exe + list(a), capture_output=True, text=True, timeout=900, env=env)

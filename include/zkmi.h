@@ -238,6 +238,12 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk *pk, uint64_t *handle);
 int zk_bn254_groth16_pk_free(uint64_t handle);   /* ZK_ERR_HANDLE while an msm5 session still uses the key */
 /* Geometry of a loaded key (any out pointer may be NULL): lets a caller validate len(w) before handing a bare pointer over. */
 int zk_bn254_groth16_pk_info(uint64_t handle, size_t *n_wires, size_t *n_public, uint32_t *log_domain, int *has_tables);
+/* Window tables for a resident key that was loaded without them (flags bit 0): what a caller does once a key turns out to be used again -- the export path
+ * (zk_groth16_prove_with_pk) reads a key text without tables for its first proof and builds them when the second is asked for.  table_window_bits: 0 = the
+ * planner's choice, else [8, 22].  A key that has its tables already, or whose tables do not fit, is left as it is: *built (optional) = 1 / 0. */
+int zk_bn254_groth16_pk_build_tables(uint64_t handle, int table_window_bits, int *built);
+/* HBM held by a resident Groth16 key (the base arrays it owns + its window tables) */
+int zk_bn254_groth16_pk_bytes(uint64_t handle, size_t *bytes);
 /* Prove with the prover randomness (r, s) as INPUTS (upstream draws them from crypto/rand; pinning them is what
  * makes "bit-exact proof bytes" well defined).  a, b, c: n_constraints evaluations (solver output); w: n_wires wire
  * values; all Montgomery fr.Element.  proof_out = Ar | Bs | Krs in gnark's compressed encoding (32+64+32 bytes),
@@ -429,6 +435,10 @@ int zk_export_cache_info(size_t *n_circuits, size_t *n_keys, size_t *bytes);
 int zk_acir_lower_resident(const char *acir_json, size_t acir_len, size_t n_values, int layout, int with_coefficients); /* host only: lower now, keep resident
     (start-up overlap: the export shim runs it beside the SRS load); with_coefficients: the selectors too, kept for the zk_plonk_preprocess that follows */
 int zk_export_cache_clear(void);
+/* Size (G1 points) of an SRS the export shim creates when srs.hex is missing: 1,000,000 like the reference (backend/common.go:137) unless a TEST set another
+ * (4 .. 2^28) before the shim's first call -- a setter instead of an environment variable, so that nothing in a prover's environment can change its SRS. */
+int zk_export_set_new_srs_size(size_t n);
+size_t zk_export_new_srs_size(void);
 /* HBM held by a resident PLONK key */
 int zk_bn254_plonk_pk_bytes(uint64_t handle, size_t *bytes);
 
@@ -449,6 +459,19 @@ int zk_groth16_preprocess(const char *raw_json, size_t raw_len, const zk_fr *tox
 int zk_groth16_prove_with_pk(const char *raw_json, size_t raw_len, const char *pk_hex, size_t pk_len, uint64_t pk_handle, const zk_fr *rs,
                              char proof_hex_out[256]);
 int zk_groth16_prove_with_meta(const char *raw_json, size_t raw_len, const zk_fr *toxic, const zk_fr *rs, char proof_hex_out[256]);
+/* What these three keep resident between calls (the sketch re-reads everything per call, r1cs.go:107-128: json.Unmarshal of the RawR1CS, buildR1CS,
+ * hex.DecodeString + ProvingKey.ReadFrom): a RawR1CS text carries the circuit AND this proof's values string, so the circuit is identified by the content
+ * keys of the text before and after that string (same offset, same length); the key text by its content key.  Resident: the R1CS in HBM with the witness ->
+ * wire order and the operands of every product variable (the wire vector of a later proof is assembled on the device from the values string alone), the
+ * decoded key -- without window tables for its first proof, with them from its second on.  Same LRU bound as the PLONK entries (zk_export_cache_info counts both).
+ *   zk_groth16_lower_resident  read a RawR1CS text into the cache now; to_device = 0: host only (start-up overlap: the export shim runs it beside the HIP
+ *                              runtime's start), 1: also upload the circuit (beside the key's decoding)
+ *   zk_groth16_key_resident    decode a key text into the cache now (no window tables)
+ *   zk_groth16_public_inputs   buildWitnesses' public part for VerifyWithVK (r1cs.go:176-212): the values of the public wires after ONE, in wire order
+ *                              (Montgomery); host only; *n_public is set even when cap is too small (ZK_ERR_ARG then). */
+int zk_groth16_lower_resident(const char *raw_json, size_t raw_len, int to_device);
+int zk_groth16_key_resident(const char *pk_hex, size_t pk_len);
+int zk_groth16_public_inputs(const char *raw_json, size_t raw_len, zk_fr *out, size_t cap, size_t *n_public);
 
 /* What the MSM planner picks for n points (with / without resident window tables): window width c and the number of c-bit
  * digits per scalar, i.e. mixed additions per scalar multiplication -- used by bench.py to turn launches into work. */

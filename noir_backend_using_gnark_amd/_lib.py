@@ -87,6 +87,8 @@ SYMBOLS = [
     "zk_profile_enable", "zk_profile_reset", "zk_profile_count", "zk_profile_get", "zk_profile_host", "zk_selftest_host",
     "zk_init_devices", "zk_warm_streams", "zk_init_flags", "zk_bn254_kzg_srs_g2", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
     "zk_acir_public_witnesses", "zk_acir_lower_resident", "zk_export_cache_info", "zk_export_cache_clear", "zk_bn254_plonk_pk_bytes",
+    "zk_groth16_lower_resident", "zk_groth16_key_resident", "zk_groth16_public_inputs", "zk_bn254_groth16_pk_build_tables", "zk_bn254_groth16_pk_bytes",
+    "zk_export_set_new_srs_size", "zk_export_new_srs_size",
 ]
 
 _lib = None
@@ -104,7 +106,9 @@ def lib() -> C.CDLL:
         _lib.zk_version.restype = C.c_char_p
         for name in SYMBOLS:
             fn = getattr(_lib, name)
-            if name not in ("zk_last_error", "zk_version"):
+            if name == "zk_export_new_srs_size":
+                fn.restype = C.c_size_t
+            elif name not in ("zk_last_error", "zk_version"):
                 fn.restype = C.c_int
     return _lib
 

@@ -684,25 +684,28 @@ static inline bool count_from_hex(const char* hex, size_t len, size_t* n) {
 struct RawR1CSBuilt {
     std::vector<uint32_t> ptr[3], idx[3];
     std::vector<HFr> val[3];
-    std::vector<HFr> wires;  // the full wire vector (Montgomery): [ONE, public..., secret..., products...]
+    std::vector<HFr> wires;  // (want_wires) the full wire vector (Montgomery): [ONE, public..., secret..., products...]
     size_t n_public = 0;     // ONE included
+    // How the wire vector follows from the values vector -- what a RESIDENT circuit keeps to assemble it on the device for every later proof:
+    size_t n_values = 0;
+    std::vector<uint32_t> order;           // wire 1 + k holds witness order[k] + 1 (k < n_values): the public ones first, each group in witness order
+    std::vector<uint32_t> prod_a, prod_b;  // wire 1 + n_values + j = wire prod_a[j] * wire prod_b[j] (both operands are witness wires, never products)
+    size_t values_at = 0, values_len = 0;  // the values string inside the text: offset of its first character and its length (values_at = 0: it had escapes)
 };
 
-static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, std::string* err) {
-    struct MulT { bool ok; HFr c; uint32_t a, b; };
-    struct AddT { bool ok; HFr c; uint32_t x; };
-    struct Gate { bool shape_ok, k_ok; size_t m0, m1, a0, a1; HFr k; };
+namespace raw_detail {
+struct MulT { bool ok; HFr c; uint32_t a, b; };
+struct AddT { bool ok; HFr c; uint32_t x; };
+struct Gate { bool shape_ok, k_ok; size_t m0, m1, a0, a1; HFr k; };
+// One element of "gates" -> its terms, as the text gave them (kinds and ranges are judged afterwards, in text order).  A parser of its own, so that several
+// can read different stretches of one gates array at once (the scheme of acir_detail::elements_parallel).
+struct GateReader {
+    JTok T{nullptr, nullptr, nullptr, {}};
     std::vector<MulT> muls;
     std::vector<AddT> adds;
     std::vector<Gate> gates;
-    std::vector<double> pubs;      // numbers as read; kinds checked after (a non-number is NaN)
-    std::string values;
-    bool have_gates = false, gates_arr = false, have_pub = false, pub_arr = false, have_vals = false, vals_str = false;
-    JTok T{json, json + len};
-    const double NOT_NUM = -1;  // as_index rejects it like any other non-index
-
     // {"coefficient": hex, <name1>: index[, <name2>: index]} ; ok only if every named member is present (first occurrence) with the right kind
-    auto term = [&](int depth, const char* n1, const char* n2, HFr* c, uint32_t* w1, uint32_t* w2, bool* ok) -> bool {
+    bool term(int depth, const char* n1, const char* n2, HFr* c, uint32_t* w1, uint32_t* w2, bool* ok) {
         *ok = false;
         if (!T.enter(depth)) return false;
         if (*T.p != '{') return T.skip(depth);
@@ -718,7 +721,7 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
                     if (!T.str(&s, &n)) return false;
                     uint64_t t[4];
                     cs = felt_from_hex(s, n, t);
-                    if (cs) *c = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+                    if (cs) *c = HFr{{t[0], t[1], t[2], t[3]}};  // canonical; to_mont_bulk afterwards (0 / 1 / -1 skip the product)
                     return true;
                 }
                 const bool m1 = !h1 && key_is(k, kn, n1), m2 = !m1 && n2 && !h2 && key_is(k, kn, n2);
@@ -737,8 +740,8 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
             return false;
         *ok = cs && i1 && (!n2 || i2);
         return true;
-    };
-    auto gate = [&](int depth) -> bool {
+    }
+    bool element(int depth) {
         Gate g{false, false, muls.size(), muls.size(), adds.size(), adds.size(), HFr::zero()};
         if (!T.enter(depth)) return false;
         if (*T.p != '{') { gates.push_back(g); return T.skip(depth); }
@@ -785,7 +788,7 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
                     if (!T.str(&s, &n)) return false;
                     uint64_t t[4];
                     g.k_ok = felt_from_hex(s, n, t);
-                    if (g.k_ok) g.k = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+                    if (g.k_ok) g.k = HFr{{t[0], t[1], t[2], t[3]}};
                     return true;
                 }
                 return T.skip(d);
@@ -794,7 +797,123 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
         g.shape_ok = m_arr && a_arr && k_str;
         gates.push_back(g);
         return true;
-    };
+    }
+    void absorb(GateReader&& o) {  // the gates of the stretch that follows this one in the text
+        const size_t dm = muls.size(), da = adds.size();
+        muls.insert(muls.end(), o.muls.begin(), o.muls.end());
+        adds.insert(adds.end(), o.adds.begin(), o.adds.end());
+        gates.reserve(gates.size() + o.gates.size());
+        for (Gate g : o.gates) { g.m0 += dm; g.m1 += dm; g.a0 += da; g.a1 += da; gates.push_back(g); }
+    }
+};
+// A candidate cut between two GATES: a comma with '}' before and '{' after (acir_detail::find_element_comma) whose '{' opens an object that starts with one of a
+// gate's own keys -- the same bytes `},{` also separate the terms INSIDE a gate's mul_terms / add_terms arrays (objects that start with "coefficient"), and a
+// reader started there would stop at once at that array's ']', leaving the whole text to the first reader.  Still only a guess (see elements_parallel).
+static inline const char* find_gate_comma(const char* from, const char* lo, const char* end) {
+    const char* lim = end - from > (ptrdiff_t)(1 << 20) ? from + (1 << 20) : end;
+    for (const char* q = from; q < lim;) {
+        q = acir_detail::find_element_comma(q, lo, end);
+        if (!q || q >= lim) return nullptr;
+        const char* b = q + 1;
+        while (b < end && acir_detail::is_ws(*b)) b++;
+        b++;  // the '{'
+        while (b < end && acir_detail::is_ws(*b)) b++;
+        for (const char* key : {"\"mul_terms\"", "\"add_terms\"", "\"constant_term\""}) {
+            const size_t kn = strlen(key);
+            if ((size_t)(end - b) >= kn && !memcmp(b, key, kn)) return q;
+        }
+        q++;
+    }
+    return nullptr;
+}
+struct Chunk {
+    GateReader R;
+    int landed = -1;              // index of the candidate comma this parser stopped on
+    const char* after = nullptr;  // position after the array's ']' if it got there
+    bool failed = false;
+};
+static inline void run_chunk(const char* begin, const char* end, const std::vector<const char*>& cuts, size_t first_cut, Chunk* C) {
+    GateReader& L = C->R;
+    L.T.p = begin; L.T.end = end;
+    size_t nb = first_cut;
+    {
+        const char* stop = first_cut < cuts.size() ? cuts[first_cut] : end;
+        const size_t est = (size_t)(stop - begin) / 256 + 16;  // a gate with one term of each kind is ~300 characters
+        L.gates.reserve(est); L.muls.reserve(est); L.adds.reserve(2 * est);
+    }
+    for (;;) {
+        if (!L.element(2)) { C->failed = true; return; }
+        L.T.ws();
+        const char* p = L.T.p;
+        if (p < end && *p == ',') {
+            while (nb < cuts.size() && cuts[nb] < p) nb++;
+            if (nb < cuts.size() && cuts[nb] == p) { C->landed = (int)nb; return; }
+            L.T.p++;
+            continue;
+        }
+        if (p < end && *p == ']') { C->after = p + 1; return; }
+        L.T.fail("expected ',' or ']'");
+        C->failed = true;
+        return;
+    }
+}
+// M.T.p at the first element of a non-empty gates array; like JTok::array's loop: true with M.T.p after the ']', or false with M.T.err set.  Same scheme and the
+// same argument as acir_detail::elements_parallel: candidate cuts are GUESSED, a parser is accepted only if the accepted one before it stopped exactly on its
+// cut while standing between two elements, so a wrong guess costs time and never changes the result; the first error in text order is the one reported.
+static inline bool elements_parallel(GateReader& M, unsigned nt) {
+    const char* begin = M.T.p;
+    const char* end = M.T.end;
+    std::vector<const char*> cuts;
+    cuts.push_back(begin);
+    const size_t span = (size_t)(end - begin);
+    for (unsigned k = 1; k < nt; k++) {
+        const char* from = begin + span / nt * k;
+        if (from <= cuts.back()) continue;
+        const char* c = find_gate_comma(from, begin, end);
+        if (c && c > cuts.back()) cuts.push_back(c);
+    }
+    std::vector<Chunk> res(cuts.size());
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < cuts.size(); k++) {
+        try {
+            th.emplace_back(run_chunk, cuts[k] + 1, end, std::cref(cuts), k + 1, &res[k]);
+        } catch (const std::system_error&) {
+            run_chunk(cuts[k] + 1, end, cuts, k + 1, &res[k]);
+        }
+    }
+    run_chunk(begin, end, cuts, 1, &res[0]);
+    for (auto& t : th) t.join();
+    for (size_t cur = 0;;) {
+        Chunk& C = res[cur];
+        const char* terr = C.R.T.err;
+        M.absorb(std::move(C.R));
+        if (C.failed) { M.T.fail(terr ? terr : "malformed gate"); return false; }
+        if (C.after) { M.T.p = C.after; return true; }
+        cur = (size_t)C.landed;
+    }
+}
+}  // namespace raw_detail
+
+// want_wires: also decode the values and run the solver's step for the product variables on the host (B->wires); without it only the circuit is built
+// (callers that assemble the wire vector on the device from order / prod_a / prod_b).
+static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, std::string* err, bool want_wires = true) {
+    using namespace raw_detail;
+    GateReader M;
+    std::vector<MulT>& muls = M.muls;
+    std::vector<AddT>& adds = M.adds;
+    std::vector<Gate>& gates = M.gates;
+    std::vector<double> pubs;      // numbers as read; kinds checked after (a non-number is NaN)
+    const char* values = nullptr;  // a view of the text (or of `values_own` when the string had escapes)
+    size_t values_n = 0;
+    std::string values_own;
+    bool have_gates = false, gates_arr = false, have_pub = false, pub_arr = false, have_vals = false, vals_str = false;
+    M.T.p = json;
+    M.T.end = json + len;
+    JTok& T = M.T;
+    const double NOT_NUM = -1;  // as_index rejects it like any other non-index
+    unsigned nt = acir_detail::parallel_cfg().threads ? acir_detail::parallel_cfg().threads : std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (len < acir_detail::parallel_cfg().min_bytes || nt < 2) nt = 1;
 
     bool root_obj = false;
     bool fine = T.enter(0);
@@ -808,7 +927,13 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
                     if (!T.enter(1)) return false;
                     if (*T.p != '[') return T.skip(1);
                     gates_arr = true;
-                    return T.array(1, [&](size_t) { return gate(2); });
+                    if (nt > 1) {  // JTok::array's prologue, then the elements on several threads
+                        T.p++;
+                        T.ws();
+                        if (T.p < T.end && *T.p == ']') { T.p++; return true; }
+                        return elements_parallel(M, nt);
+                    }
+                    return T.array(1, [&](size_t) { return M.element(2); });
                 }
                 if (!have_pub && key_is(k, kn, "public_inputs")) {
                     have_pub = true;
@@ -833,7 +958,8 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
                     const char* s;
                     size_t n;
                     if (!T.str(&s, &n)) return false;
-                    values.assign(s, n);
+                    if (s >= json && s + n <= json + len) { values = s; values_n = n; }  // the usual case: 64 MB at 2^20 witnesses, not copied
+                    else { values_own.assign(s, n); values = values_own.data(); values_n = n; }
                     return true;
                 }
                 return T.skip(1);
@@ -842,11 +968,14 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
     }
     if (!fine || !root_obj) { *err = std::string("RawR1CS JSON: ") + (T.err ? T.err : "not an object"); return ZK_ERR_ARG; }
     if (!gates_arr || !vals_str) { *err = "RawR1CS JSON: gates / values missing"; return ZK_ERR_ARG; }
-    // witness values: hex felt vector, decoded on the host here (they feed the host-side solver step for the product variables)
+    // witness values: hex felt vector
     size_t n = 0;
-    if (values.size() < 8) { *err = "felt vector: " + std::to_string(values.size()) + " characters cannot hold the 4-byte count"; return ZK_ERR_ARG; }
-    if (!count_from_hex(values.data(), values.size(), &n)) { *err = "felt vector: invalid hex character in the count"; return ZK_ERR_ARG; }
-    if (values.size() != 8 + 64 * n) { *err = "felt vector: " + std::to_string(values.size()) + " characters, the count says " + std::to_string(n) + " felts"; return ZK_ERR_LEN; }
+    if (values_n < 8) { *err = "felt vector: " + std::to_string(values_n) + " characters cannot hold the 4-byte count"; return ZK_ERR_ARG; }
+    if (!count_from_hex(values, values_n, &n)) { *err = "felt vector: invalid hex character in the count"; return ZK_ERR_ARG; }
+    if (values_n != 8 + 64 * n) { *err = "felt vector: " + std::to_string(values_n) + " characters, the count says " + std::to_string(n) + " felts"; return ZK_ERR_LEN; }
+    B->n_values = n;
+    B->values_at = values_own.empty() && values >= json ? (size_t)(values - json) : 0;
+    B->values_len = values_n;
     std::vector<bool> is_pub(n + 1, false);
     if (pub_arr)
         for (double v : pubs) {
@@ -855,26 +984,54 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
             if (w >= 1 && w <= n) is_pub[w] = true;
         }
     std::vector<HFr>& wv = B->wires;
-    wv.assign(1, HFr::one());
+    wv.clear();
+    if (want_wires) { wv.reserve(1 + n + muls.size()); wv.push_back(HFr::one()); }
     std::vector<uint32_t> wire(n + 1, 0);
+    B->order.clear();
+    B->order.reserve(n);
     size_t npub = 1;
     for (int pass = 0; pass < 2; pass++)
         for (size_t w = 1; w <= n; w++)
             if (is_pub[w] == (pass == 0)) {
+                wire[w] = (uint32_t)(1 + B->order.size());
+                B->order.push_back((uint32_t)(w - 1));
+                if (pass == 0) npub++;
+                if (!want_wires) continue;
                 uint64_t t[4] = {0, 0, 0, 0};
                 int badc = 0;
-                const char* s = values.data() + 8 + 64 * (w - 1);
+                const char* s = values + 8 + 64 * (w - 1);
                 for (int i = 0; i < 64; i++) {  // canonical values only, like fr.Vector.UnmarshalBinary
                     const int d = hex_nibble((unsigned char)s[63 - i]);
                     badc |= d;
                     t[i >> 4] |= (uint64_t)(d & 15) << (4 * (i & 15));
                 }
                 if (badc < 0 || HFr::geq_mod(t)) { *err = "felt vector: invalid hex character or fr.Element encoding"; return ZK_ERR_ARG; }
-                wire[w] = (uint32_t)wv.size();
                 wv.push_back(HFr{{t[0], t[1], t[2], t[3]}}.to_mont());
-                if (pass == 0) npub++;
             }
+    // the coefficients were read as canonical values: Montgomery images now (threads; 0 / 1 / -1 without a product)
+    {
+        std::vector<HFr> cs;
+        cs.reserve(muls.size() + adds.size() + gates.size());
+        for (auto& t : muls) cs.push_back(t.ok ? t.c : HFr::zero());
+        for (auto& t : adds) cs.push_back(t.ok ? t.c : HFr::zero());
+        for (auto& g : gates) cs.push_back(g.k_ok ? g.k : HFr::zero());
+        to_mont_bulk(cs.data(), cs.size());
+        size_t at = 0;
+        for (auto& t : muls) t.c = cs[at++];
+        for (auto& t : adds) t.c = cs[at++];
+        for (auto& g : gates) g.k = cs[at++];
+    }
     for (int m = 0; m < 3; m++) { B->ptr[m].assign(1, 0); B->idx[m].clear(); B->val[m].clear(); }
+    B->prod_a.clear();
+    B->prod_b.clear();
+    {
+        const size_t rows = muls.size() + gates.size();
+        for (int m = 0; m < 3; m++) B->ptr[m].reserve(rows + 1);
+        B->idx[0].reserve(rows); B->val[0].reserve(rows);
+        B->idx[1].reserve(muls.size() * 2 + adds.size() + gates.size()); B->val[1].reserve(muls.size() * 2 + adds.size() + gates.size());
+        B->idx[2].reserve(muls.size()); B->val[2].reserve(muls.size());
+        B->prod_a.reserve(muls.size()); B->prod_b.reserve(muls.size());
+    }
     auto end_row = [&]() { for (int m = 0; m < 3; m++) B->ptr[m].push_back((uint32_t)B->idx[m].size()); };
     const HFr one = HFr::one();
     std::vector<std::pair<uint32_t, HFr>> terms;
@@ -891,8 +1048,10 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
                 const MulT& t = muls[i];
                 if (!t.ok || t.a < 1 || t.a > n || t.b < 1 || t.b > n) { *err = "RawR1CS JSON: malformed mul term"; return ZK_ERR_ARG; }
                 if (t.c.is_zero()) continue;
-                const uint32_t a = wire[t.a], b = wire[t.b], p = (uint32_t)wv.size();
-                wv.push_back(wv[a] * wv[b]);  // the solver's step for this internal variable
+                const uint32_t a = wire[t.a], b = wire[t.b], p = (uint32_t)(1 + n + B->prod_a.size());
+                B->prod_a.push_back(a);
+                B->prod_b.push_back(b);
+                if (want_wires) wv.push_back(wv[a] * wv[b]);  // the solver's step for this internal variable
                 B->idx[0].push_back(a); B->val[0].push_back(one);
                 B->idx[1].push_back(b); B->val[1].push_back(one);
                 B->idx[2].push_back(p); B->val[2].push_back(one);

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "acir_host.hpp"  // the text side (host only, sanitizer- and mutation-tested on the CPU: tests/cpp/parser_fuzz.cpp)
+#include "text_host.hpp"
 #include "ctx.hpp"
 #include "ff.hpp"
 #include "host_ff.hpp"
@@ -297,30 +298,6 @@ using namespace zkmi;
 
 extern "C" {
 
-// Releases everything the export path keeps resident between calls (lowered circuits, decoded proving keys).  Keys in use by a running proof stay.
-int zk_export_cache_clear(void) {
-    std::vector<uint64_t> dead;
-    {
-        std::lock_guard<std::mutex> lk(g_cache_mu);
-        for (auto it = g_keys.begin(); it != g_keys.end();)
-            if (!it->in_use) { dead.push_back(it->handle); it = g_keys.erase(it); } else ++it;
-        g_lowered.clear();
-    }
-    free_handles(dead);
-    return ZK_OK;
-}
-// resident entries and their HBM + host bytes (tests, bench.py)
-int zk_export_cache_info(size_t* n_circuits, size_t* n_keys, size_t* bytes) {
-    std::lock_guard<std::mutex> lk(g_cache_mu);
-    size_t t = 0;
-    for (auto& k : g_keys) t += k.bytes;
-    for (auto& l : g_lowered) t += l->bytes();
-    if (n_circuits) *n_circuits = g_lowered.size();
-    if (n_keys) *n_keys = g_keys.size();
-    if (bytes) *bytes = t;
-    return ZK_OK;
-}
-
 // PlonkPreprocess (main.go:58-78): ACIR + the witness-value vector (only its length and the public/secret split matter to Setup) -> hex of
 // ProvingKey.WriteTo and hex of VerifyingKey.WriteTo (= the first 368 bytes of the former).  pk_hex_out may be NULL with pk_cap = 0 to query
 // the sizes.  The key also stays resident: *pk_handle (optional) can be handed to zk_bn254_plonk_prove directly; without it the key enters the
@@ -485,6 +462,17 @@ int zk_acir_public_witnesses(const char* acir_json, size_t acir_len, size_t n_va
 // src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60) -- the text side is acir_host.hpp's raw_r1cs_build.  Out: a resident R1CS (zk_bn254_r1cs_*)
 // and the full wire vector in HBM (*d_witness: n_wires Montgomery elements, to be released with zk_dev_free) -- ready for zk_bn254_groth16_setup /
 // _prove_r1cs(on_device = 1).
+static int r1cs_of_built(const RawR1CSBuilt& B, uint64_t* handle) {
+    zk_r1cs r;
+    memset(&r, 0, sizeof r);
+    r.n_constraints = B.ptr[0].size() - 1;
+    r.n_wires = 1 + B.n_values + B.prod_a.size();
+    r.n_public = B.n_public;
+    r.l_ptr = B.ptr[0].data(); r.l_idx = B.idx[0].data(); r.l_val = (const zk_fr*)B.val[0].data();
+    r.r_ptr = B.ptr[1].data(); r.r_idx = B.idx[1].data(); r.r_val = (const zk_fr*)B.val[1].data();
+    r.o_ptr = B.ptr[2].data(); r.o_idx = B.idx[2].data(); r.o_val = (const zk_fr*)B.val[2].data();
+    return zk_bn254_r1cs_load(&r, handle);
+}
 int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_handle, void** d_witness, size_t* n_wires, size_t* n_public) {
     if (!raw_json || !r1cs_handle || !d_witness) return set_err(ZK_ERR_ARG, "null pointer");
     RawR1CSBuilt B;
@@ -493,15 +481,7 @@ int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_ha
         const int rc = raw_r1cs_build(raw_json, len, &B, &err);
         if (rc != ZK_OK) return set_err(rc, "%s", err.c_str());
     }
-    zk_r1cs r;
-    memset(&r, 0, sizeof r);
-    r.n_constraints = B.ptr[0].size() - 1;
-    r.n_wires = B.wires.size();
-    r.n_public = B.n_public;
-    r.l_ptr = B.ptr[0].data(); r.l_idx = B.idx[0].data(); r.l_val = (const zk_fr*)B.val[0].data();
-    r.r_ptr = B.ptr[1].data(); r.r_idx = B.idx[1].data(); r.r_val = (const zk_fr*)B.val[1].data();
-    r.o_ptr = B.ptr[2].data(); r.o_idx = B.idx[2].data(); r.o_val = (const zk_fr*)B.val[2].data();
-    ZK_TRY(zk_bn254_r1cs_load(&r, r1cs_handle));
+    ZK_TRY(r1cs_of_built(B, r1cs_handle));
     void* d = nullptr;
     int rc = zk_dev_alloc(&d, B.wires.size() * 32);
     if (rc == ZK_OK) rc = zk_dev_h2d(d, B.wires.data(), B.wires.size() * 32);
@@ -516,6 +496,9 @@ int zk_groth16_r1cs_from_raw(const char* raw_json, size_t len, uint64_t* r1cs_ha
     return ZK_OK;
 }
 
+}  // extern "C"
+
+namespace zkmi {
 // uniform-enough field elements for prover randomness / toxic waste (upstream: fr.SetRandom's rejection sampling over crypto/rand)
 static int random_frs(HFr* out, int n, bool nonzero) {
     FILE* f = fopen("/dev/urandom", "rb");
@@ -531,82 +514,563 @@ static int random_frs(HFr* out, int n, bool nonzero) {
     fclose(f);
     return ZK_OK;
 }
-
-namespace {
-struct RawInstance {  // a RawR1CS lowered and resident; released on scope exit
-    uint64_t r1cs = 0;
-    void* d_w = nullptr;
-    size_t n_wires = 0, n_public = 0;
-    ~RawInstance() {
-        if (d_w) (void)zk_dev_free(d_w);
-        if (r1cs) (void)zk_bn254_r1cs_free(r1cs);
-    }
-};
-void hex_of(const uint8_t* b, size_t n, char* o) {
+static void hex_of(const uint8_t* b, size_t n, char* o) {
     static const char* dg = "0123456789abcdef";
     for (size_t i = 0; i < n; i++) { o[2 * i] = dg[b[i] >> 4]; o[2 * i + 1] = dg[b[i] & 15]; }
 }
-}  // namespace
+
+// ------------------------------------------------------------------------------------------------ Groth16: what stays resident between calls
+// The intended exports (r1cs.go:74-266) take ONE text per call: the RawR1CS JSON carries the circuit (gates, public inputs: 0.25 GB at 2^20 constraints) AND
+// this proof's witness values (a hex string, 64 MB) -- plus, for ProveWithPK, the key text (0.37 GB).  Read naively that is 0.86 s of host and key work in
+// front of a 10 ms prover (round 4: profiles/rnd5_a_groth16_export_baseline.json).  The same remedy as for PLONK, adapted to the one-text payload:
+//   RawCircuit  a RawR1CS text MINUS its values string: identified by the content keys of the bytes before and after that string.  A later call is the
+//               same circuit iff the values string sits at the same offset with the same length and both outside parts hash the same -- a string of hex
+//               digits (the decoder on the device rejects anything else) cannot change what the tokenizer makes of the rest.  Kept: the R1CS in HBM (CSR),
+//               the witness -> wire order, the operand wires of every product variable, buffers for the values text, the wire vector and a, b, c.
+//               The wire vector of a proof is then assembled on the device: decode the values (wire.hip), gather (public first), one product per mul term.
+//   G16Key      a key text by its content key -> the decoded resident key.  No window tables on a key's first proof (0.15 s at 2^20 against the 5 ms per proof
+//               they save); the second proof with it builds them.
+// both least-recently-used within ZKMI_TABLE_CAP_GB together with the PLONK entries above.
+__global__ void k_raw_wires(const Fr* __restrict__ vals, const uint32_t* __restrict__ order, size_t n_values, Fr one, Fr* __restrict__ w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_values) return;
+    w[i] = i == 0 ? one : vals[order[i - 1]];
+}
+__global__ void k_raw_products(const uint32_t* __restrict__ pa, const uint32_t* __restrict__ pb, size_t n_products, size_t base, Fr* __restrict__ w) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_products) return;
+    w[base + j] = w[pa[j]] * w[pb[j]];  // operands are witness wires (below `base`), never products: no ordering among the lanes
+}
+
+struct RawCircuit {
+    ContentKey head, tail;
+    size_t head_len = 0, tail_len = 0, span_len = 0;  // the text = head | values string (span_len characters) | tail
+    int entry = 0;
+    size_t n_values = 0, n_wires = 0, n_public = 0, n_constraints = 0, n_products = 0;
+    std::vector<uint32_t> public_order;  // witness (0-based) behind public wire 1 + k
+    std::unique_ptr<RawR1CSBuilt> host;  // until the circuit is uploaded
+    std::mutex work;                     // one proof at a time per circuit
+    uint64_t r1cs = 0;
+    uint32_t *d_order = nullptr, *d_pa = nullptr, *d_pb = nullptr;
+    char* d_text = nullptr;  // 8 bytes past a 16-byte boundary: the felts start aligned (wire.hip)
+    void *d_vals = nullptr, *d_w = nullptr, *d_abc = nullptr;
+    size_t dev_bytes() const { return n_values * (4 + 64 + 32) + n_products * 8 + n_wires * 32 + n_constraints * (96 + 3 * 4 + 200); }
+    size_t bytes() const { return public_order.size() * 4 + (host ? dev_bytes() / 2 : 0) + (r1cs ? dev_bytes() : 0); }
+    ~RawCircuit() {
+        for (void* q : {(void*)d_order, (void*)d_pa, (void*)d_pb, (void*)d_text, d_vals, d_w, d_abc})
+            if (q) (void)hipFree(q);
+        if (r1cs) (void)zk_bn254_r1cs_free(r1cs);
+    }
+    int device_buffers() {  // under `work`
+        if (r1cs) return ZK_OK;
+        ZK_TRY(ensure_init());
+        if (!host) return set_err(ZK_ERR_ARG, "resident circuit lost its host form");
+        uint64_t h = 0;
+        ZK_TRY(r1cs_of_built(*host, &h));
+        auto up = [](uint32_t** d, const std::vector<uint32_t>& v) -> int {
+            ZK_HIP(hipMalloc((void**)d, (v.size() ? v.size() : 1) * 4));
+            if (!v.empty()) ZK_HIP(hipMemcpy(*d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+            return ZK_OK;
+        };
+        int rc = up(&d_order, host->order);
+        if (rc == ZK_OK) rc = up(&d_pa, host->prod_a);
+        if (rc == ZK_OK) rc = up(&d_pb, host->prod_b);
+        auto dm = [](void** d, size_t bytes) -> int { ZK_HIP(hipMalloc(d, bytes ? bytes : 16)); return ZK_OK; };
+        if (rc == ZK_OK) rc = dm((void**)&d_text, span_len + 32);
+        if (rc == ZK_OK) rc = dm(&d_vals, n_values * 32);
+        if (rc == ZK_OK) rc = dm(&d_w, n_wires * 32);
+        if (rc == ZK_OK) rc = dm(&d_abc, 3 * n_constraints * 32);
+        if (rc != ZK_OK) { (void)zk_bn254_r1cs_free(h); return rc; }  // the buffers go with the entry
+        r1cs = h;
+        host.reset();
+        return ZK_OK;
+    }
+};
+struct G16Key {
+    ContentKey pk;
+    uint64_t handle = 0;
+    size_t bytes = 0;
+    int in_use = 0;
+    unsigned proofs = 0;
+};
+// (never destroyed: at process exit the R1CS registry of r1cs.hip and the HIP runtime may be gone before a static destructor here would free into them)
+static std::list<std::shared_ptr<RawCircuit>>& g_raw = *new std::list<std::shared_ptr<RawCircuit>>();  // most recently used first; under g_cache_mu
+static std::list<G16Key>& g_g16_keys = *new std::list<G16Key>();
+static constexpr unsigned kG16TablesAtProof = 2;
+
+static size_t g16_cache_bytes_locked() {
+    size_t t = 0;
+    for (auto& k : g_g16_keys) t += k.bytes;
+    for (auto& c : g_raw) t += c->bytes();
+    return t;
+}
+// room for `extra` more bytes among the Groth16 entries (idle ones, least recently used first); PLONK's entries are trimmed by their own rule
+static void g16_trim_locked(size_t extra, std::vector<uint64_t>* dead_keys) {
+    const size_t cap = cache_cap_bytes();
+    for (auto it = g_g16_keys.end(); it != g_g16_keys.begin() && (g16_cache_bytes_locked() + extra > cap || g_g16_keys.size() >= 8);) {
+        --it;
+        if (it->in_use) continue;
+        dead_keys->push_back(it->handle);
+        it = g_g16_keys.erase(it);
+    }
+    while (!g_raw.empty() && (g16_cache_bytes_locked() + extra > cap || g_raw.size() >= 8)) {
+        if (g_raw.back().use_count() > 1) break;
+        g_raw.pop_back();
+    }
+}
+static void g16_free_keys(const std::vector<uint64_t>& hs) {
+    for (uint64_t h : hs) (void)zk_bn254_groth16_pk_free(h);
+}
+
+// the circuit behind a RawR1CS text: from the cache (*values_at = where this text keeps its values string), or read now
+static int raw_circuit_get(const char* raw, size_t len, std::shared_ptr<RawCircuit>* out, size_t* values_at) {
+    Phase ph;
+    // candidates: the resident circuits whose span fits this text -- quotes at both ends, the same count header
+    std::vector<std::shared_ptr<RawCircuit>> cand;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto& c : g_raw)
+            if (c->entry == current_entry() && c->head_len + c->span_len + c->tail_len == len && c->head_len >= 1 && raw[c->head_len - 1] == '"' &&
+                raw[c->head_len + c->span_len] == '"')
+                cand.push_back(c);
+    }
+    for (auto& c : cand) {
+        size_t n = 0;
+        if (!count_from_hex(raw + c->head_len, c->span_len, &n) || n != c->n_values) continue;
+        std::future<ContentKey> tail = std::async(std::launch::async, [&] { return content_key(raw + c->head_len + c->span_len, c->tail_len); });
+        const ContentKey head = content_key(raw, c->head_len);
+        if (!(tail.get() == c->tail) || !(head == c->head)) continue;
+        ph.lap("export.raw_content_key");
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_raw.begin(); it != g_raw.end(); ++it)
+            if (it->get() == c.get()) { g_raw.splice(g_raw.begin(), g_raw, it); break; }
+        *out = c;
+        *values_at = c->head_len;
+        return ZK_OK;
+    }
+    auto C = std::make_shared<RawCircuit>();
+    C->host.reset(new RawR1CSBuilt());
+    {
+        std::string err;
+        const int rc = raw_r1cs_build(raw, len, C->host.get(), &err, false);
+        if (rc != ZK_OK) return set_err(rc, "%s", err.c_str());
+    }
+    ph.lap("export.raw_parse_lower");
+    const RawR1CSBuilt& B = *C->host;
+    C->entry = current_entry();
+    C->n_values = B.n_values;
+    C->n_products = B.prod_a.size();
+    C->n_wires = 1 + B.n_values + B.prod_a.size();
+    C->n_public = B.n_public;
+    C->n_constraints = B.ptr[0].size() - 1;
+    C->public_order.assign(B.order.begin(), B.order.begin() + (B.n_public - 1));
+    *out = C;
+    *values_at = B.values_at;
+    if (!B.values_at || !cache_cap_bytes()) { C->span_len = B.values_len; return ZK_OK; }  // (a values string with escapes has no span in the text: never cached)
+    C->head_len = B.values_at;
+    C->span_len = B.values_len;
+    C->tail_len = len - B.values_at - B.values_len;
+    {
+        std::future<ContentKey> tail = std::async(std::launch::async, [&] { return content_key(raw + C->head_len + C->span_len, C->tail_len); });
+        C->head = content_key(raw, C->head_len);
+        C->tail = tail.get();
+    }
+    ph.lap("export.raw_content_key");
+    std::vector<uint64_t> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g16_trim_locked(C->dev_bytes(), &dead);
+        g_raw.push_front(C);
+    }
+    g16_free_keys(dead);
+    return ZK_OK;
+}
+
+// the wire vector of this proof in C->d_w (under C->work): values text -> device, decoded, gathered public-first, one product per mul term
+static int raw_wires_on_device(RawCircuit& C, const char* values, size_t values_len) {
+    Phase ph;
+    ZK_TRY(C.device_buffers());
+    ph.lap("export.circuit_to_device");
+    if (values_len != C.span_len) return set_err(ZK_ERR_LEN, "felt vector: %zu characters, the circuit was read with %zu", values_len, C.span_len);
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t st = g.s->stream;
+    char* d_text = C.d_text + 8;
+    ZK_HIP(hipMemcpyAsync(d_text, values, values_len, hipMemcpyHostToDevice, st));
+    ph.lap("export.values_upload");
+    ZK_TRY(zk_bn254_felts_decode_hex_dev(d_text, values_len, C.d_vals, C.n_values, C.n_values, 1, st));  // synchronises; ZK_ERR_ARG on a non-hex or non-canonical felt
+    ph.lap("export.values_decode");
+    Fr one;
+    {
+        const HFr h1 = HFr::one();
+        memcpy(&one, &h1, 32);
+    }
+    ZK_LAUNCH(g.s, st, "raw_wires", k_raw_wires, dim3((unsigned)((C.n_values + 256) / 256)), dim3(256), 0, (const Fr*)C.d_vals, (const uint32_t*)C.d_order, C.n_values, one,
+              (Fr*)C.d_w);
+    if (C.n_products)
+        ZK_LAUNCH(g.s, st, "raw_products", k_raw_products, dim3((unsigned)((C.n_products + 255) / 256)), dim3(256), 0, (const uint32_t*)C.d_pa, (const uint32_t*)C.d_pb,
+                  C.n_products, 1 + C.n_values, (Fr*)C.d_w);
+    ZK_TRY(slot_sync(g.s, st));
+    ph.lap("export.witness_assemble");
+    return ZK_OK;
+}
+
+// the resident key behind a key text (or decoded now, without window tables); *cached: it is pinned in the cache until g16_key_release
+static int g16_key_get(const char* pk_hex, size_t pk_len, std::future<ContentKey>* key_in_flight, uint64_t* handle, bool* cached) {
+    Phase ph;
+    const ContentKey key = key_in_flight ? key_in_flight->get() : content_key(pk_hex, pk_len);
+    ph.lap("export.pk_content_key");
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_g16_keys.begin(); it != g_g16_keys.end(); ++it)
+            if (it->pk == key && hentry(it->handle) == current_entry()) {
+                it->in_use++;
+                *handle = it->handle;
+                *cached = true;
+                g_g16_keys.splice(g_g16_keys.begin(), g_g16_keys, it);
+                return ZK_OK;
+            }
+    }
+    *cached = false;
+    uint64_t h = 0;
+    int rc = zk_bn254_groth16_pk_read(pk_hex, pk_len, 1, 1, 0, &h);
+    if (rc == ZK_ERR_HIP) {  // out of HBM with idle keys resident: let them go and try once more
+        std::vector<uint64_t> dead;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (auto it = g_g16_keys.begin(); it != g_g16_keys.end();)
+                if (!it->in_use) { dead.push_back(it->handle); it = g_g16_keys.erase(it); } else ++it;
+        }
+        if (!dead.empty()) {
+            g16_free_keys(dead);
+            rc = zk_bn254_groth16_pk_read(pk_hex, pk_len, 1, 1, 0, &h);
+        }
+    }
+    ZK_TRY(rc);
+    ph.lap("export.pk_read");
+    *handle = h;
+    size_t bytes = 0;
+    (void)zk_bn254_groth16_pk_bytes(h, &bytes);
+    if (!cache_cap_bytes() || bytes > cache_cap_bytes()) return ZK_OK;  // not kept: the caller frees it
+    std::vector<uint64_t> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g16_trim_locked(bytes, &dead);
+        G16Key e;
+        e.pk = key; e.handle = h; e.bytes = bytes; e.in_use = 1;
+        g_g16_keys.push_front(e);
+        *cached = true;
+    }
+    g16_free_keys(dead);
+    return ZK_OK;
+}
+static void g16_key_release(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto& k : g_g16_keys)
+        if (k.handle == handle) { if (k.in_use > 0) k.in_use--; return; }
+}
+// a key Setup has just produced enters the cache under the content key of the text it was written as
+static bool g16_key_adopt(const char* pk_hex, size_t pk_len, uint64_t h) {
+    size_t bytes = 0;
+    if (zk_bn254_groth16_pk_bytes(h, &bytes) != ZK_OK || !cache_cap_bytes() || bytes > cache_cap_bytes()) return false;
+    const ContentKey key = content_key(pk_hex, pk_len);
+    std::vector<uint64_t> dead;
+    bool adopted = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        bool have = false;
+        for (auto& k : g_g16_keys) have = have || (k.pk == key && hentry(k.handle) == current_entry());
+        if (!have) {
+            g16_trim_locked(bytes, &dead);
+            G16Key e;
+            e.pk = key; e.handle = h; e.bytes = bytes; e.in_use = 0;
+            g_g16_keys.push_front(e);
+            adopted = true;
+        }
+    }
+    g16_free_keys(dead);
+    return adopted;
+}
+
+// One key waits here between the two calls of a Preprocess -- the size query and the call that writes it -- so that Setup runs once (and, with drawn toxic
+// waste, so that the sizes reported ARE those of the key that gets written).
+struct G16Stash {
+    std::shared_ptr<RawCircuit> circuit;
+    bool drawn = false;
+    HFr toxic[5];
+    uint64_t handle = 0;
+    std::vector<zk_g1_affine> vk_g1;
+    zk_g2_affine vk_g2[3];
+};
+static G16Stash& g_g16_stash = *new G16Stash();
+
+// prove on a resident circuit with a resident key (under C.work; C.d_w holds this proof's wires)
+static int g16_prove_resident(RawCircuit& C, uint64_t pk, const zk_fr* rs, uint8_t proof[128]) {
+    Phase ph;
+    {   // the key must be the key of THIS circuit's shape
+        size_t kw = 0, kp = 0;
+        uint32_t lg = 0;
+        ZK_TRY(zk_bn254_groth16_pk_info(pk, &kw, &kp, &lg, nullptr));
+        if (kw != C.n_wires || kp != C.n_public || C.n_constraints > ((size_t)1 << lg))
+            return set_err(ZK_ERR_ARG, "proving key is for %zu wires / %zu public / 2^%u constraints, the circuit has %zu / %zu / %zu", kw, kp, lg, C.n_wires, C.n_public, C.n_constraints);
+    }
+    HFr r2[2];
+    if (rs) memcpy(r2, rs, sizeof r2);
+    else ZK_TRY(random_frs(r2, 2, false));
+    Fr* abc = (Fr*)C.d_abc;
+    const size_t nc = C.n_constraints;
+    ZK_TRY(zk_bn254_r1cs_eval_abc_dev(C.r1cs, C.d_w, C.n_wires, abc, abc + nc, abc + 2 * nc, nullptr));
+    ph.lap("export.r1cs_solve_abc");
+    ZK_TRY(zk_bn254_groth16_prove(pk, abc, abc + nc, abc + 2 * nc, nc, C.d_w, C.n_wires, (const zk_fr*)&r2[0], (const zk_fr*)&r2[1], 1, proof));
+    ph.lap("export.groth16_prove");
+    return ZK_OK;
+}
+
+}  // namespace zkmi
+
+extern "C" {
+
+// Reads a RawR1CS text into the resident cache; to_device = 0 touches no device (the export shim runs it beside the HIP runtime's start), 1 also uploads the
+// circuit (the shim's second step, beside the key's decoding).  The zk_groth16_* call that follows finds the circuit by content.
+int zk_groth16_lower_resident(const char* raw_json, size_t raw_len, int to_device) {
+    if (!raw_json) return set_err(ZK_ERR_ARG, "null pointer");
+    std::shared_ptr<RawCircuit> C;
+    size_t at = 0;
+    ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+    if (!to_device) return ZK_OK;
+    ZK_TRY(ensure_init());
+    std::lock_guard<std::mutex> work(C->work);
+    Phase ph;
+    ZK_TRY(C->device_buffers());
+    ph.lap("export.circuit_to_device");
+    return ZK_OK;
+}
+// Decodes a key text into the resident cache (no window tables: see zk_groth16_prove_with_pk); the ProveWithPK that follows finds it by content key.
+int zk_groth16_key_resident(const char* pk_hex, size_t pk_len) {
+    if (!pk_hex) return set_err(ZK_ERR_ARG, "null pointer");
+    ZK_TRY(ensure_init());
+    uint64_t h = 0;
+    bool cached = false;
+    ZK_TRY(g16_key_get(pk_hex, pk_len, nullptr, &h, &cached));
+    if (cached) g16_key_release(h);
+    else (void)zk_bn254_groth16_pk_free(h);
+    return ZK_OK;
+}
+// The public witness of a RawR1CS payload as the verifier needs it (buildWitnesses' public part, r1cs.go:176-212): the values of the public wires after ONE,
+// in wire order.  Host only (a process that only verifies never starts the HIP runtime); uses the resident circuit of the text when there is one.
+// *n_public comes back even when cap is too small (ZK_ERR_ARG then).
+int zk_groth16_public_inputs(const char* raw_json, size_t raw_len, zk_fr* out, size_t cap, size_t* n_public) {
+    if (!raw_json || !n_public) return set_err(ZK_ERR_ARG, "null pointer");
+    std::shared_ptr<RawCircuit> C;
+    size_t at = 0;
+    ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+    const size_t np = C->public_order.size();
+    *n_public = np;
+    if (np > cap || (np && !out)) return set_err(ZK_ERR_ARG, "%zu public inputs, the output holds %zu", np, cap);
+    if (!at) {  // a values string with escapes: the general reader
+        RawR1CSBuilt B;
+        std::string err;
+        const int rc = raw_r1cs_build(raw_json, raw_len, &B, &err);
+        if (rc != ZK_OK) return set_err(rc, "%s", err.c_str());
+        for (size_t k = 0; k < np; k++) memcpy(&out[k], &B.wires[1 + k], 32);
+        return ZK_OK;
+    }
+    // DeserializeFelts sees the whole vector: one bad character anywhere fails the call (hex.DecodeString), and so does a non-canonical felt
+    const char* v = raw_json + at;
+    if (!all_hex(v, C->span_len)) return set_err(ZK_ERR_ARG, "felt vector: invalid hex character");
+    for (size_t k = 0; k < np; k++) {
+        uint64_t t[4] = {0, 0, 0, 0};
+        const char* s = v + 8 + 64 * (size_t)C->public_order[k];
+        for (int i = 0; i < 64; i++) t[i >> 4] |= (uint64_t)(hex_nibble((unsigned char)s[63 - i]) & 15) << (4 * (i & 15));
+        if (HFr::geq_mod(t)) return set_err(ZK_ERR_ARG, "felt vector: invalid fr.Element encoding (value >= r)");
+        HFr m = HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+        memcpy(&out[k], &m, 32);
+    }
+    return ZK_OK;
+}
 
 // Preprocess of the reference's intended Groth16 FFI (backend/groth16/r1cs.go:214-266): RawR1CS JSON -> groth16.Setup -> hex(ProvingKey.WriteTo),
 // hex(VerifyingKey.WriteTo).  toxic: tau, alpha, beta, gamma, delta (Montgomery, non-zero) or NULL (/dev/urandom, as upstream draws them).
-// pk_hex_out == NULL: only the sizes (the key is built to learn NbInfinityA / NbInfinityB).  pk_handle (optional) keeps the key resident.
+// pk_hex_out == NULL: only the sizes (the key is built to learn NbInfinityA / NbInfinityB -- and waits for the call that writes it).  pk_handle (optional)
+// keeps the key resident for the caller; without it the key enters the export cache under the text it was written as.
 int zk_groth16_preprocess(const char* raw_json, size_t raw_len, const zk_fr* toxic, char* pk_hex_out, size_t pk_cap, size_t* pk_len, char* vk_hex_out, size_t vk_cap,
                           size_t* vk_len, uint64_t* pk_handle) {
     if (!raw_json || !pk_len || !vk_len) return set_err(ZK_ERR_ARG, "null pointer");
-    RawInstance I;
-    ZK_TRY(zk_groth16_r1cs_from_raw(raw_json, raw_len, &I.r1cs, &I.d_w, &I.n_wires, &I.n_public));
+    std::shared_ptr<RawCircuit> C;
+    size_t at = 0;
+    ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+    ZK_TRY(ensure_init());
+    std::lock_guard<std::mutex> work(C->work);
+    Phase ph;
+    ZK_TRY(C->device_buffers());
+    ph.lap("export.circuit_to_device");
     HFr tx[5];
     if (toxic) memcpy(tx, toxic, sizeof tx);
-    else ZK_TRY(random_frs(tx, 5, true));
-    std::vector<zk_g1_affine> vk_g1(1 + I.n_public);
-    zk_g2_affine vk_g2[3];
     uint64_t h = 0;
-    ZK_TRY(zk_bn254_groth16_setup(I.r1cs, (const zk_fr*)tx, 0, &h, vk_g1.data(), vk_g2));
+    std::vector<zk_g1_affine> vk_g1;
+    zk_g2_affine vk_g2[3];
+    {   // the key the size query built, if this is the call that follows it (same circuit, same -- or equally drawn -- toxic waste)
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        G16Stash& S = g_g16_stash;
+        if (S.handle && S.circuit.get() == C.get() && (toxic ? (!S.drawn && !memcmp(S.toxic, tx, sizeof tx)) : S.drawn)) {
+            h = S.handle;
+            vk_g1.swap(S.vk_g1);
+            memcpy(vk_g2, S.vk_g2, sizeof vk_g2);
+            S.handle = 0;
+            S.circuit.reset();
+        }
+    }
+    if (!h) {
+        if (!toxic) ZK_TRY(random_frs(tx, 5, true));
+        vk_g1.resize(1 + C->n_public);
+        ZK_TRY(zk_bn254_groth16_setup(C->r1cs, (const zk_fr*)tx, 1, &h, vk_g1.data(), vk_g2));  // no window tables: the prover that keeps the key builds them
+        ph.lap("export.groth16_setup");
+    }
     int rc = zk_bn254_groth16_pk_write(h, 1, pk_hex_out, pk_cap, pk_len);
-    if (rc == ZK_OK) rc = zk_bn254_groth16_vk_write(h, vk_g1.data(), I.n_public, vk_g2, 1, pk_hex_out ? vk_hex_out : nullptr, vk_cap, vk_len);
-    if (rc == ZK_OK && pk_handle && pk_hex_out) *pk_handle = h;
-    else (void)zk_bn254_groth16_pk_free(h);
+    if (rc == ZK_OK) rc = zk_bn254_groth16_vk_write(h, vk_g1.data(), C->n_public, vk_g2, 1, pk_hex_out ? vk_hex_out : nullptr, vk_cap, vk_len);
+    if (pk_hex_out) ph.lap("export.pk_write_hex");
+    if (rc == ZK_OK && !pk_hex_out) {  // the size query: the key waits for the writing call
+        uint64_t old = 0;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            G16Stash& S = g_g16_stash;
+            old = S.handle;
+            S.handle = h;
+            S.circuit = C;
+            S.drawn = toxic == nullptr;
+            memcpy(S.toxic, tx, sizeof tx);
+            S.vk_g1.swap(vk_g1);
+            memcpy(S.vk_g2, vk_g2, sizeof vk_g2);
+        }
+        if (old) (void)zk_bn254_groth16_pk_free(old);
+        return ZK_OK;
+    }
+    if (rc == ZK_OK && pk_handle) { *pk_handle = h; return ZK_OK; }
+    if (rc != ZK_OK || !g16_key_adopt(pk_hex_out, *pk_len, h)) (void)zk_bn254_groth16_pk_free(h);
+    ph.lap("export.pk_adopt");
     return rc;
 }
 
 // ProveWithPK (r1cs.go:107-143): RawR1CS JSON + hex(ProvingKey.WriteTo) -> hex(Proof.WriteTo) (256 characters, no terminator).  pk_hex may be NULL when
 // pk_handle names a resident key (the reference deserialises the key on every call).  rs: the prover's (r, s) or NULL (/dev/urandom).
+// Both texts are found resident by content when they were seen before; a key read from its text gets its window tables when its SECOND proof is asked for.
 int zk_groth16_prove_with_pk(const char* raw_json, size_t raw_len, const char* pk_hex, size_t pk_len, uint64_t pk_handle, const zk_fr* rs, char proof_hex_out[256]) {
     if (!raw_json || !proof_hex_out || (!pk_hex && !pk_handle)) return set_err(ZK_ERR_ARG, "null pointer");
-    RawInstance I;
-    ZK_TRY(zk_groth16_r1cs_from_raw(raw_json, raw_len, &I.r1cs, &I.d_w, &I.n_wires, &I.n_public));
+    CtxScope _scope(pk_handle ? hentry(pk_handle) : current_entry());
+    if (_scope.rc != ZK_OK) return _scope.rc;
+    // the key text's content key beside the circuit's (0.37 GB at 2^20 constraints: 2 ms of sixteen threads); a future of std::async joins in its destructor,
+    // so every early return below leaves the caller's text alone
+    std::future<ContentKey> pk_key;
+    if (pk_hex) pk_key = std::async(std::launch::async, [pk_hex, pk_len] { return content_key(pk_hex, pk_len); });
+    std::shared_ptr<RawCircuit> C;
+    size_t at = 0;
+    ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+    ZK_TRY(ensure_init());
+    std::lock_guard<std::mutex> work(C->work);
+    if (at) {
+        ZK_TRY(raw_wires_on_device(*C, raw_json + at, C->span_len));
+    } else {  // a values string written with escapes has no view in the text: the general reader decodes it and runs the solver's step on the host
+        RawR1CSBuilt B;
+        std::string err;
+        const int rb = raw_r1cs_build(raw_json, raw_len, &B, &err);
+        if (rb != ZK_OK) return set_err(rb, "%s", err.c_str());
+        ZK_TRY(C->device_buffers());
+        ZK_HIP(hipMemcpy(C->d_w, B.wires.data(), B.wires.size() * 32, hipMemcpyHostToDevice));
+    }
     uint64_t h = pk_handle;
-    if (pk_hex) ZK_TRY(zk_bn254_groth16_pk_read(pk_hex, pk_len, 1, 0, 0, &h));
-    HFr r2[2];
-    int rc = ZK_OK;
-    if (rs) memcpy(r2, rs, sizeof r2);
-    else rc = random_frs(r2, 2, false);
+    bool cached = false;
+    if (pk_hex) ZK_TRY(g16_key_get(pk_hex, pk_len, &pk_key, &h, &cached));
+    struct Done {
+        uint64_t h; bool from_text, cached;
+        ~Done() { if (from_text) { if (cached) g16_key_release(h); else (void)zk_bn254_groth16_pk_free(h); } }
+    } done{h, pk_hex != nullptr, cached};
+    if (cached) {
+        bool build = false;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (auto& k : g_g16_keys)
+                if (k.handle == h) { build = ++k.proofs == kG16TablesAtProof; break; }
+        }
+        if (build) {
+            Phase ph;
+            int built = 0;
+            ZK_TRY(zk_bn254_groth16_pk_build_tables(h, 0, &built));
+            size_t bytes = 0;
+            (void)zk_bn254_groth16_pk_bytes(h, &bytes);
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (auto& k : g_g16_keys)
+                if (k.handle == h) k.bytes = bytes;
+            ph.lap("export.pk_window_tables");
+        }
+    }
     uint8_t proof[128];
-    if (rc == ZK_OK) rc = zk_bn254_groth16_prove_r1cs(I.r1cs, h, I.d_w, I.n_wires, (const zk_fr*)&r2[0], (const zk_fr*)&r2[1], 1, proof);
-    if (pk_hex) (void)zk_bn254_groth16_pk_free(h);
-    if (rc == ZK_OK) hex_of(proof, 128, proof_hex_out);
-    return rc;
+    ZK_TRY(g16_prove_resident(*C, h, rs, proof));
+    hex_of(proof, 128, proof_hex_out);
+    return ZK_OK;
 }
 
 // ProveWithMeta (r1cs.go:74-105): Setup and Prove in one call (the proving key never leaves HBM).
 int zk_groth16_prove_with_meta(const char* raw_json, size_t raw_len, const zk_fr* toxic, const zk_fr* rs, char proof_hex_out[256]) {
     if (!raw_json || !proof_hex_out) return set_err(ZK_ERR_ARG, "null pointer");
-    RawInstance I;
-    ZK_TRY(zk_groth16_r1cs_from_raw(raw_json, raw_len, &I.r1cs, &I.d_w, &I.n_wires, &I.n_public));
-    HFr tx[5], r2[2];
+    std::shared_ptr<RawCircuit> C;
+    size_t at = 0;
+    ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+    ZK_TRY(ensure_init());
+    std::lock_guard<std::mutex> work(C->work);
+    if (!at) return set_err(ZK_ERR_ARG, "RawR1CS JSON: the values string must be plain hex (no escapes)");
+    ZK_TRY(raw_wires_on_device(*C, raw_json + at, C->span_len));
+    HFr tx[5];
     if (toxic) memcpy(tx, toxic, sizeof tx);
     else ZK_TRY(random_frs(tx, 5, true));
-    if (rs) memcpy(r2, rs, sizeof r2);
-    else ZK_TRY(random_frs(r2, 2, false));
     uint64_t h = 0;
-    ZK_TRY(zk_bn254_groth16_setup(I.r1cs, (const zk_fr*)tx, 1, &h, nullptr, nullptr));  // one proof: window tables would cost more than they save
+    ZK_TRY(zk_bn254_groth16_setup(C->r1cs, (const zk_fr*)tx, 1, &h, nullptr, nullptr));  // one proof: window tables would cost more than they save
     uint8_t proof[128];
-    int rc = zk_bn254_groth16_prove_r1cs(I.r1cs, h, I.d_w, I.n_wires, (const zk_fr*)&r2[0], (const zk_fr*)&r2[1], 1, proof);
+    const int rc = g16_prove_resident(*C, h, rs, proof);
     (void)zk_bn254_groth16_pk_free(h);
     if (rc == ZK_OK) hex_of(proof, 128, proof_hex_out);
     return rc;
 }
+
+// Releases everything the export path keeps resident between calls (lowered circuits, decoded proving keys; PLONK and Groth16).  Keys in use by a running proof stay.
+int zk_export_cache_clear(void) {
+    std::vector<uint64_t> dead, dead16;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_keys.begin(); it != g_keys.end();)
+            if (!it->in_use) { dead.push_back(it->handle); it = g_keys.erase(it); } else ++it;
+        g_lowered.clear();
+        for (auto it = g_g16_keys.begin(); it != g_g16_keys.end();)
+            if (!it->in_use) { dead16.push_back(it->handle); it = g_g16_keys.erase(it); } else ++it;
+        g_raw.clear();
+        if (g_g16_stash.handle) dead16.push_back(g_g16_stash.handle);
+        g_g16_stash.handle = 0;
+        g_g16_stash.circuit.reset();
+    }
+    free_handles(dead);
+    g16_free_keys(dead16);
+    return ZK_OK;
+}
+// resident entries and their HBM + host bytes (tests, bench.py)
+int zk_export_cache_info(size_t* n_circuits, size_t* n_keys, size_t* bytes) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t t = g16_cache_bytes_locked();
+    for (auto& k : g_keys) t += k.bytes;
+    for (auto& l : g_lowered) t += l->bytes();
+    if (n_circuits) *n_circuits = g_lowered.size() + g_raw.size();
+    if (n_keys) *n_keys = g_keys.size() + g_g16_keys.size();
+    if (bytes) *bytes = t;
+    return ZK_OK;
+}
+
+// The number of G1 points of an SRS the export shim CREATES when <config dir>/noir-lang/srs.hex is missing: the reference's 1,000,000 (backend/common.go:137)
+// unless a test asked for fewer (they take seconds to generate and minutes to read back in the Python oracle).  4 .. 2^28; anything else is ZK_ERR_ARG.
+static size_t g_new_srs_size = 1000000;
+int zk_export_set_new_srs_size(size_t n) {
+    if (n < 4 || n > ((size_t)1 << 28)) return set_err(ZK_ERR_ARG, "SRS size %zu outside [4, 2^28]", n);
+    g_new_srs_size = n;
+    return ZK_OK;
+}
+size_t zk_export_new_srs_size(void) { return g_new_srs_size; }
 
 // The lowering alone, for inspection / tests: gates of an ACIR circuit as the reference's BuildSparseR1CS emits them.  Any out pointer may be
 // NULL; arrays need *n_constraints (first call with NULL arrays to size them) entries; coefficients come back as Montgomery fr.Elements.

@@ -13,7 +13,10 @@
 // Differences kept from libzkmi's own entry points (zk_plonk_*, zk_groth16_*): errors end the process with the message on stderr, as the reference's
 // log.Fatal does; the SRS of backend/common.go:78-144 (hex(kzg.SRS.WriteTo) at <user config dir>/noir-lang/srs.hex, created with a random alpha and
 // 1,000,000 points when missing) is read ONCE per process and kept resident instead of being re-read on every call (plonk.go:16,34,58).
-// ZKMI_SRS_SIZE overrides the size of a newly created SRS (tests; validated: 4 .. 2^28).  Plain C++ on the C ABI: no HIP in this file.
+// Devices: ONE -- the first visible GPU -- unless ZKMI_DEVICES says otherwise ("all", or a comma-separated list of HIP device ordinals; validated; read once, before
+// anything touches a device): several GPUs in one process (csrc/multidev.hip) have only ever run on virtual entries, so they are opt-in.
+// The size of an SRS this process CREATES is libzkmi's zk_export_new_srs_size() (1,000,000 unless a test called the setter): this library exports the reference's
+// ten names and nothing else, and reads no variable that could change a result.  Plain C++ on the C ABI: no HIP here.
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -25,6 +28,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <future>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -85,6 +89,34 @@ struct Lap {  // wall-clock sections of the shim, reported beside the library's 
     }
 };
 
+// ---- which GPUs this process uses.  The reference is one process per nargo command and knows nothing of devices: the default is ONE device entry (HIP device
+// 0 of those visible), whatever the node holds -- starting a HIP context per GPU costs each one-shot call its start-up time over again, and concurrent nargo
+// processes would contend for every GPU.  ZKMI_DEVICES=all | d0,d1,... opts in to the in-process multi-GPU path (the SRS kept by range on the listed devices, every
+// commitment one partial per GPU); anything else ends the process with a message (a typo must not silently mean "one GPU").
+std::vector<int> shim_devices() {
+    const char* v = getenv("ZKMI_DEVICES");
+    std::vector<int> devs;
+    if (!v || !*v) { devs.push_back(0); return devs; }
+    if (!strcmp(v, "all")) return devs;  // empty = every visible device (zk_init_devices(NULL, 0))
+    const int visible = zk_device_count();
+    const char* p = v;
+    while (*p) {
+        char* e = nullptr;
+        const long d = strtol(p, &e, 10);
+        if (e == p || d < 0 || d >= visible || (*e && *e != ',')) { fprintf(stderr, "ZKMI_DEVICES = \"%s\": expected \"all\" or a comma-separated list of device ordinals below %d\n", v, visible); exit(1); }
+        devs.push_back((int)d);
+        p = *e ? e + 1 : e;
+    }
+    if (devs.empty() || devs.size() > 8) { fprintf(stderr, "ZKMI_DEVICES = \"%s\": one to eight devices\n", v); exit(1); }
+    return devs;
+}
+void start_devices(int warm_streams) {
+    must(zk_init_flags(ZK_INIT_LEAN_STREAMS), "zk_init_flags");  // a process behind these exports typically makes ONE call: no stream it will not use
+    const std::vector<int> devs = shim_devices();
+    must(zk_init_devices(devs.empty() ? nullptr : devs.data(), devs.size()), "zk_init_devices");
+    if (warm_streams) must(zk_warm_streams(warm_streams), "zk_warm_streams");
+}
+
 // ---- the SRS of backend/common.go:78-144, once per process
 struct Srs {
     std::mutex mu;
@@ -135,14 +167,8 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
         if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
         struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); } } } unlock{lock_fd};
         // The HIP runtime starts on a thread of its own (0.07-0.2 s) and then creates the streams the first proof will take (the process's first one: 40-160 ms,
-        // 10 ms each after) while this thread reads the file.  Every visible GPU becomes a device entry of this process (HIP_VISIBLE_DEVICES restricts them): on a
-        // multi-GPU node the SRS below is then kept by range on all of them and every commitment of the prover is one partial per GPU (csrc/multidev.hip) --
-        // nothing above this library changes; one GPU: one entry, as before.
-        std::thread starter([] {
-            must(zk_init_flags(ZK_INIT_LEAN_STREAMS), "zk_init_flags");  // a process behind these exports typically makes ONE call: no stream it will not use
-            must(zk_init_devices(nullptr, 0), "zk_init_devices");
-            must(zk_warm_streams(3), "zk_warm_streams");
-        });
+        // 10 ms each after) while this thread reads the file.  One device entry unless ZKMI_DEVICES opts in to more (shim_devices).
+        std::thread starter([] { start_devices(3); });
         Lap lap;
         const std::string text = read_srs_text(path);
         // LoadSRS fails -- and TryLoadSRS generates a new SRS -- exactly when the file cannot be read or is not hex (common.go:92-99, 129-141); it ignores what
@@ -166,10 +192,7 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
             a[3] &= 0x0fffffffffffffffULL;  // < 2^252 < r.  The library takes Montgomery images, and multiplication by 2^-256 permutes the field: 252 random
             zk_fr alpha;                    // bits read AS a Montgomery image are as good a secret as 252 random bits read as a value
             memcpy(&alpha, a, 32);
-            const char* sz = getenv("ZKMI_SRS_SIZE");
-            const long req = sz ? atol(sz) : 0;
-            if (sz && (req < 4 || req > (1L << 28))) { fprintf(stderr, "ZKMI_SRS_SIZE = %s outside [4, 2^28]\n", sz); exit(1); }
-            const size_t size = req ? (size_t)req : 1000000;
+            const size_t size = zk_export_new_srs_size();  // the reference's 1,000,000 points (backend/common.go:137) unless a test asked for fewer
             void* d = nullptr;
             must(zk_dev_alloc(&d, size * 64), "NewSRS");
             must(zk_bn254_kzg_new_srs_dev(d, size, &alpha, g_srs.g2, nullptr), "NewSRS");
@@ -238,10 +261,6 @@ char* plonk_prove(GoString acir, View values, const char* pk_hex, size_t pk_len,
     return proof;
 }
 
-}  // namespace
-
-extern "C" {
-
 // The first call of a process: the HIP runtime starts, srs.hex is read and decoded and its window tables are built (0.4 s of driver and GPU work) -- on a
 // thread of its own, while this one reads the circuit text (0.2 s of one host core for 2^19 opcodes, no GPU involved): zk_acir_lower_resident leaves the
 // lowered circuit where the prover's lookup by content key finds it.  Later calls find both resident.
@@ -258,6 +277,34 @@ void load_srs_and_lower(GoString acirJSON, View values, uint64_t* srs, zk_g2_aff
         (void)zk_acir_lower_resident(acirJSON.p, (size_t)acirJSON.n, n_values, ZK_ACIR_LAYOUT_REFERENCE, with_coefficients);
     loader.join();
 }
+
+// ---- Groth16 (backend/groth16/r1cs.go:74-266): no SRS.  A process's first call starts the HIP runtime on a thread of its own while this one reads the RawR1CS text
+// (0.25 GB at 2^20 constraints, host only); ProveWithPK's starter goes on to decode the key text (0.37 GB; G1 / G2 decompression on the device) beside it.
+std::once_flag g_g16_started;
+void groth16_start(GoString rawR1CS, const GoString* pk) {
+    bool first = false;
+    std::call_once(g_g16_started, [&] { first = true; });
+    if (!first) return;
+    Lap lap;
+    std::promise<void> up;
+    std::future<void> is_up = up.get_future();
+    std::thread starter([pk, &up] {
+        start_devices(5);  // the five stream slots of a Groth16 proof session
+        up.set_value();
+        if (pk) (void)zk_groth16_key_resident(pk->p, (size_t)pk->n);  // (errors resurface in the call proper)
+    });
+    (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 0);
+    lap.lap("export.raw_lower_beside_start");
+    is_up.wait();
+    lap.lap("export.hip_start_wait");
+    (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 1);  // the circuit goes to the device while the starter decodes the key
+    starter.join();
+    lap.lap("export.hip_start_and_key_wait");
+}
+
+}  // namespace
+
+extern "C" {
 
 char* PlonkProveWithPK(GoString acirJSON, GoString encodedValues, GoString encodedProvingKey) {
     uint64_t srs;
@@ -339,39 +386,47 @@ unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoStri
 
 // ---- Groth16 (backend/groth16/r1cs.go:74-266)
 char* ProveWithMeta(GoString rawR1CS) {
+    groth16_start(rawR1CS, nullptr);
     std::string proof(256, '\0');
     must(zk_groth16_prove_with_meta(rawR1CS.p, (size_t)rawR1CS.n, nullptr, nullptr, &proof[0]), "ProveWithMeta");
     return c_string(proof);
 }
 char* ProveWithPK(GoString rawR1CS, GoString encodedProvingKey) {
+    groth16_start(rawR1CS, &encodedProvingKey);
     std::string proof(256, '\0');
     must(zk_groth16_prove_with_pk(rawR1CS.p, (size_t)rawR1CS.n, encodedProvingKey.p, (size_t)encodedProvingKey.n, 0, nullptr, &proof[0]), "ProveWithPK");
     return c_string(proof);
 }
 KeyPair Preprocess(GoString rawR1CS) {
+    groth16_start(rawR1CS, nullptr);
     size_t pk_len = 0, vk_len = 0;
-    must(zk_groth16_preprocess(rawR1CS.p, (size_t)rawR1CS.n, nullptr, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "Preprocess");
-    std::string pk(pk_len, '\0'), vk(vk_len, '\0');
-    must(zk_groth16_preprocess(rawR1CS.p, (size_t)rawR1CS.n, nullptr, &pk[0], pk.size(), &pk_len, &vk[0], vk.size(), &vk_len, nullptr), "Preprocess");
-    pk.resize(pk_len);
-    vk.resize(vk_len);
-    return KeyPair{c_string(pk), c_string(vk)};
+    must(zk_groth16_preprocess(rawR1CS.p, (size_t)rawR1CS.n, nullptr, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "Preprocess");  // Setup runs here; the key waits
+    // the key text (0.37 GB at 2^20 constraints) is written once, into the C.CString the caller receives
+    char* pk = (char*)malloc(pk_len + 1);
+    char* vk = (char*)malloc(vk_len + 1);
+    if (!pk || !vk) fatal("out of memory");
+    must(zk_groth16_preprocess(rawR1CS.p, (size_t)rawR1CS.n, nullptr, pk, pk_len, &pk_len, vk, vk_len, &vk_len, nullptr), "Preprocess");
+    pk[pk_len] = 0;
+    vk[vk_len] = 0;
+    return KeyPair{pk, vk};
 }
 // upstream's sketch runs a fresh Setup and verifies against ITS key (r1cs.go:145-174): no proof made elsewhere can pass -- `false`, like PlonkVerifyWithMeta
 unsigned char VerifyWithMeta(GoString, GoString) { return 0; }
 unsigned char VerifyWithVK(GoString rawR1CS, GoString encodedProof, GoString encodedVerifyingKey) {
     std::vector<uint8_t> proof;
     if (!hex_to_bytes(encodedProof.p, (size_t)encodedProof.n, &proof) || proof.size() != 128) { fprintf(stderr, "DeserializeProof: not the hex of a Groth16 proof\n"); exit(1); }
-    uint64_t r1cs = 0;
-    void* d_w = nullptr;
-    size_t n_wires = 0, n_public = 0;
-    must(zk_groth16_r1cs_from_raw(rawR1CS.p, (size_t)rawR1CS.n, &r1cs, &d_w, &n_wires, &n_public), "buildR1CS");
-    std::vector<zk_fr> pub(n_public ? n_public : 1);
-    must(zk_dev_d2h(pub.data(), d_w, n_public * 32), "buildWitnesses");  // [ONE, public...]: the public witness is everything after ONE
-    (void)zk_dev_free(d_w);
-    (void)zk_bn254_r1cs_free(r1cs);
+    // buildWitnesses' public part: the values of the public wires -- read on the host against the circuit's (resident) lowering; a process that only
+    // verifies never starts the HIP runtime
+    size_t n_public = 0;
+    std::vector<zk_fr> pub(16);
+    int rc = zk_groth16_public_inputs(rawR1CS.p, (size_t)rawR1CS.n, pub.data(), pub.size(), &n_public);
+    if (rc == ZK_ERR_ARG && n_public > pub.size()) {
+        pub.resize(n_public);
+        rc = zk_groth16_public_inputs(rawR1CS.p, (size_t)rawR1CS.n, pub.data(), pub.size(), &n_public);
+    }
+    must(rc, "buildR1CS");
     int ok = 0;
-    const int rc = zk_bn254_groth16_verify(proof.data(), encodedVerifyingKey.p, (size_t)encodedVerifyingKey.n, 1, pub.data() + 1, n_public ? n_public - 1 : 0, &ok);
+    rc = zk_bn254_groth16_verify(proof.data(), encodedVerifyingKey.p, (size_t)encodedVerifyingKey.n, 1, pub.data(), n_public, &ok);
     if (rc == ZK_ERR_LEN) return 0;
     must(rc, "VerifyWithVK");
     return ok ? 1 : 0;

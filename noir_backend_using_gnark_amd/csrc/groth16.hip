@@ -113,6 +113,60 @@ static int infinity_map(const uint8_t* inf, size_t n_wires, size_t nb_inf, std::
     return ZK_OK;
 }
 
+// The window tables of a key whose five base arrays are resident (P->d_*): at load time, or later for a key that was loaded without them (a key read from its
+// wire format for ONE proof is better off without: 0.15 s at 2^20 constraints against the 5 ms per proof they save -- zk_bn254_groth16_pk_build_tables).
+// Allocations go through `mem` (freed again unless the caller keeps them).  Nothing is built -- and that is not an error -- when the tables do not fit half of
+// the free HBM or ZKMI_TABLE_CAP_GB, unless the caller asked for a width or a window shard.
+static int pk_build_tables(Groth16PK* Pp, PkAllocs* mem, int table_window_bits, bool win_shard, uint32_t shard_rank, uint32_t shard_count) {
+    Groth16PK& P = *Pp;
+    const size_t N = (size_t)1 << P.log_domain, nk = P.n_wires - P.n_public;
+    if (P.n_wires == 0 || N <= 1) return ZK_OK;
+    P.tab_w.c = table_window_bits ? (unsigned)table_window_bits : msm_pick_window_table(P.n_wires);
+    P.tab_w.stride = P.n_wires;
+    P.tab_h.c = table_window_bits ? (unsigned)table_window_bits : msm_pick_window_table(P.nz);
+    {   // experiment: a narrower window for Z alone (its reduction tail is the exposed one: half the buckets per bit, 1 / 13 more additions per step)
+        const long ch = ZK_EXP("ZKMI_TABLE_C_H_DELTA", 0);
+        if (!table_window_bits && ch < 0 && (long)P.tab_h.c + ch >= 8) P.tab_h.c = (unsigned)((long)P.tab_h.c + ch);
+    }
+    P.tab_h.stride = N;
+    if (win_shard) {
+        P.tab_w.row_first = P.tab_h.row_first = shard_rank;
+        P.tab_w.row_step = P.tab_h.row_step = shard_count;
+    }
+    P.tab_w.l1_m = 16;  // A, B1, K, G2.B: their reduction tails hide under the next accumulate -- less work beats lower latency
+    P.tab_w.l2_m = (unsigned)ZK_EXP("ZKMI_L2_M", 8);  // measured: 8 -> -0.09 ms, 16 -> +0.15 ms, 32 -> +0.9 ms (the level gets too long to hide)
+    P.tab_h.l1_m = (unsigned)ZK_EXP("ZKMI_L1H_M", 8);   // Z finishes last: its tail is exposed
+    P.tab_h.l2_m = (unsigned)ZK_EXP("ZKMI_L2H_M", 0);
+    const size_t Ww = P.tab_w.rows() ? P.tab_w.rows() : 1, Wh = P.tab_h.rows() ? P.tab_h.rows() : 1;  // rows held here (all of them unless window-sharded)
+    const size_t bytes = Ww * P.n_wires * (3 * 64 + 128) + Wh * N * 64;
+    size_t free_b = 0, total_b = 0;
+    ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    // measured (end of round 1): tables pay at every size that fits -- 2^23: 65.8 vs 76.3 ms per proof, 2^24 (84 GB of tables): 126.8 vs
+    // 148.1 ms -- so the only limits are half of the free HBM and a 128 GB cap (an early measurement that showed the opposite at 2^24
+    // was an artefact of the task-size heuristic fixed since)
+    static const size_t cap_gb = (size_t)zk_env_bounded("ZKMI_TABLE_CAP_GB", 128, 0, 1024);  // 0 = never build tables; the result does not depend on it
+    if (bytes < free_b / 2 && bytes <= (cap_gb << 30)) {
+        SlotGuard g;
+        ZK_TRY(acquire_slot(&g.s));
+        hipStream_t st = g.s->stream;
+        struct { void** t; const void* src; size_t n, stride, off, esz; unsigned c; size_t Wd; int g2; } jobs[5] = {
+            {&P.t_a, P.d_a, P.n_wires, P.n_wires, 0, 64, P.tab_w.c, Ww, 0},  {&P.t_b, P.d_b, P.n_wires, P.n_wires, 0, 64, P.tab_w.c, Ww, 0},
+            {&P.t_k, P.d_k, nk, P.n_wires, P.n_public, 64, P.tab_w.c, Ww, 0}, {&P.t_z, P.d_z, P.nz, N, 0, 64, P.tab_h.c, Wh, 0},
+            {&P.t_b2, P.d_b2, P.n_wires, P.n_wires, 0, 128, P.tab_w.c, Ww, 1}};
+        for (auto& j : jobs) {
+            ZK_TRY(mem->dev_alloc(j.t, j.Wd * j.stride * j.esz));
+            const MsmTable& tb = (&j == &jobs[3]) ? P.tab_h : P.tab_w;
+            ZK_TRY(j.g2 ? msm_build_table_g2(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t, tb.row_first, tb.row_step)
+                        : msm_build_table_g1(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t, tb.row_first, tb.row_step));
+        }
+        ZK_TRY(slot_sync(g.s, st));
+        P.tables = true;
+    } else if (table_window_bits || win_shard) {
+        return set_err(ZK_ERR_HIP, "window tables of %zu bytes (c = %u) do not fit (free HBM %zu)", bytes, P.tab_w.c, free_b);
+    }
+    return ZK_OK;
+}
+
 int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     if (!pk || !handle) return set_err(ZK_ERR_ARG, "null pointer");
     // several device entries (pk->device_mask / the process default): a composite key of per-entry range slices (multidev.hip); one entry: a key on that entry.
@@ -216,51 +270,7 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
         P.owns_abb = true;
     }
     // ---- precomputed window tables (unless disabled or HBM is short)
-    if (!(pk->flags & 1) && pk->n_wires > 0 && N > 1) {
-        P.tab_w.c = pk->table_window_bits ? (unsigned)pk->table_window_bits : msm_pick_window_table(pk->n_wires);
-        P.tab_w.stride = pk->n_wires;
-        P.tab_h.c = pk->table_window_bits ? (unsigned)pk->table_window_bits : msm_pick_window_table(P.nz);
-        {   // experiment: a narrower window for Z alone (its reduction tail is the exposed one: half the buckets per bit, 1 / 13 more additions per step)
-            const long ch = ZK_EXP("ZKMI_TABLE_C_H_DELTA", 0);
-            if (!pk->table_window_bits && ch < 0 && (long)P.tab_h.c + ch >= 8) P.tab_h.c = (unsigned)((long)P.tab_h.c + ch);
-        }
-        P.tab_h.stride = N;
-        if (win_shard) {
-            P.tab_w.row_first = P.tab_h.row_first = pk->shard_rank;
-            P.tab_w.row_step = P.tab_h.row_step = pk->shard_count;
-        }
-        P.tab_w.l1_m = 16;  // A, B1, K, G2.B: their reduction tails hide under the next accumulate -- less work beats lower latency
-        P.tab_w.l2_m = (unsigned)ZK_EXP("ZKMI_L2_M", 8);  // measured: 8 -> -0.09 ms, 16 -> +0.15 ms, 32 -> +0.9 ms (the level gets too long to hide)
-        P.tab_h.l1_m = (unsigned)ZK_EXP("ZKMI_L1H_M", 8);   // Z finishes last: its tail is exposed
-        P.tab_h.l2_m = (unsigned)ZK_EXP("ZKMI_L2H_M", 0);
-        const size_t Ww = P.tab_w.rows() ? P.tab_w.rows() : 1, Wh = P.tab_h.rows() ? P.tab_h.rows() : 1;  // rows held here (all of them unless window-sharded)
-        const size_t bytes = Ww * pk->n_wires * (3 * 64 + 128) + Wh * N * 64;
-        size_t free_b = 0, total_b = 0;
-        ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-        // measured (end of round 1): tables pay at every size that fits -- 2^23: 65.8 vs 76.3 ms per proof, 2^24 (84 GB of tables): 126.8 vs
-        // 148.1 ms -- so the only limits are half of the free HBM and a 128 GB cap (an early measurement that showed the opposite at 2^24
-        // was an artefact of the task-size heuristic fixed since)
-        static const size_t cap_gb = (size_t)zk_env_bounded("ZKMI_TABLE_CAP_GB", 128, 0, 1024);  // 0 = never build tables; the result does not depend on it
-        if (bytes < free_b / 2 && bytes <= (cap_gb << 30)) {
-            SlotGuard g;
-            ZK_TRY(acquire_slot(&g.s));
-            hipStream_t st = g.s->stream;
-            struct { void** t; const void* src; size_t n, stride, off, esz; unsigned c; size_t Wd; int g2; } jobs[5] = {
-                {&P.t_a, P.d_a, pk->n_wires, pk->n_wires, 0, 64, P.tab_w.c, Ww, 0},  {&P.t_b, P.d_b, pk->n_wires, pk->n_wires, 0, 64, P.tab_w.c, Ww, 0},
-                {&P.t_k, P.d_k, nk, pk->n_wires, pk->n_public, 64, P.tab_w.c, Ww, 0}, {&P.t_z, P.d_z, P.nz, N, 0, 64, P.tab_h.c, Wh, 0},
-                {&P.t_b2, P.d_b2, pk->n_wires, pk->n_wires, 0, 128, P.tab_w.c, Ww, 1}};
-            for (auto& j : jobs) {
-                ZK_TRY(mem.dev_alloc(j.t, j.Wd * j.stride * j.esz));
-                const MsmTable& tb = (&j == &jobs[3]) ? P.tab_h : P.tab_w;
-                ZK_TRY(j.g2 ? msm_build_table_g2(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t, tb.row_first, tb.row_step)
-                            : msm_build_table_g1(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t, tb.row_first, tb.row_step));
-            }
-            ZK_TRY(slot_sync(g.s, st));
-            P.tables = true;
-        } else if (pk->table_window_bits || win_shard) {
-            return set_err(ZK_ERR_HIP, "window tables of %zu bytes (c = %u) do not fit (free HBM %zu)", bytes, P.tab_w.c, free_b);
-        }
-    }
+    if (!(pk->flags & 1)) ZK_TRY(pk_build_tables(&P, &mem, pk->table_window_bits, win_shard, pk->shard_rank, pk->shard_count));
     if (win_shard && !P.tables) return set_err(ZK_ERR_ARG, "a window-sharded key needs its window tables");
     std::lock_guard<std::mutex> lk(g_pk_mu);
     *handle = hmake(g_next_pk++);
@@ -286,6 +296,56 @@ int zk_bn254_groth16_pk_free(uint64_t handle) {
     if (P.tables)
         for (void* d : {P.t_a, P.t_b, P.t_k, P.t_z, P.t_b2}) (void)hipFree(d);
     g_pks.erase(it);
+    return ZK_OK;
+}
+
+// Window tables for a resident key that was loaded without them (flags bit 0) -- what a caller does when a key turns out to be used again: the export path
+// reads a key text without tables for its first proof and builds them when the second one is asked for.  table_window_bits: 0 = the planner's choice.
+// A key that has its tables, or whose tables do not fit (half of the free HBM, ZKMI_TABLE_CAP_GB), is left as it is: *built (optional) says which.
+int zk_bn254_groth16_pk_build_tables(uint64_t handle, int table_window_bits, int* built) {
+    if (built) *built = 0;
+    if (md_is_composite(handle)) return set_err(ZK_ERR_ARG, "a key spread over several device entries gets its tables at load time");
+    ZK_ON_ENTRY_OF(handle);
+    if (table_window_bits && (table_window_bits < 8 || table_window_bits > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_window_bits);
+    Groth16PK P;
+    {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        auto it = g_pks.find(handle);
+        if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
+        if (it->second.tables) { if (built) *built = 1; return ZK_OK; }
+        if (it->second.nz != ((size_t)1 << it->second.log_domain) - 1) return set_err(ZK_ERR_ARG, "a range-sharded slice of a key gets its tables at load time");
+        P = it->second;
+    }
+    PkAllocs mem;
+    ZK_TRY(pk_build_tables(&P, &mem, table_window_bits, false, 0, 1));
+    if (!P.tables) return ZK_OK;
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end() || it->second.tables) return ZK_OK;  // freed, or built by another caller meanwhile: `mem` releases this copy
+    Groth16PK& Q = it->second;
+    Q.tab_w = P.tab_w; Q.tab_h = P.tab_h;
+    Q.t_a = P.t_a; Q.t_b = P.t_b; Q.t_k = P.t_k; Q.t_z = P.t_z; Q.t_b2 = P.t_b2;
+    Q.tables = true;
+    mem.keep = true;
+    if (built) *built = 1;
+    return ZK_OK;
+}
+
+// HBM a resident key holds (base arrays it owns + window tables): what a cache of keys accounts for
+int zk_bn254_groth16_pk_bytes(uint64_t handle, size_t* bytes) {
+    if (!bytes) return set_err(ZK_ERR_ARG, "null pointer");
+    if (md_is_composite(handle)) return set_err(ZK_ERR_ARG, "not available for a key spread over several device entries");
+    ZK_ON_ENTRY_OF(handle);
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)handle);
+    const Groth16PK& P = it->second;
+    const size_t N = (size_t)1 << P.log_domain, nw = P.n_wires, nk = nw - P.n_public;
+    size_t b = 0;
+    if (P.owns) b += nw * (64 + 64 + 128) + nk * 64 + N * 64;
+    else if (P.owns_abb) b += nw * (64 + 64 + 128);
+    if (P.tables) b += (size_t)P.tab_w.rows() * nw * (3 * 64 + 128) + (size_t)P.tab_h.rows() * N * 64;
+    *bytes = b;
     return ZK_OK;
 }
 
@@ -376,8 +436,11 @@ static int msm5_prepare_w(Slot* sl[5], const Msm5Inputs& in, hipEvent_t ev_w, Ms
     static const bool low = ZK_EXP("ZKMI_PREPW_LOW", 0) == 1;  // experiment: normal priority under computeH
     hipStream_t st4 = low ? sl[4]->stream : sl[4]->hi();
     if (ev_w) ZK_HIP(hipStreamWaitEvent(st4, ev_w, 0));
-    if (in.tab_w) return msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w);
-    return msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w);
+    // the wire values of a real circuit are mostly 0 / 1 / small (booleans, bytes, range-check limbs): their zero digits never enter the sort (msm.hip
+    // k_msm_digit_count; the pair count stays on the device).  Uniform wires have no zero digit to drop and pay one more pass over 32 MB of scalars beside computeH.
+    static const bool drop = ZK_EXP("ZKMI_W_DROP_ZERO_DIGITS", 1) != 0;
+    if (in.tab_w) return msm_prepare_scalars_table(sl[4], st4, in.d_w, in.nw, &kMontCfg, *in.tab_w, &S->prep_w, drop);
+    return msm_prepare_scalars(sl[4], st4, in.d_w, in.nw, &kMontCfg, &S->prep_w, drop);
 }
 // `between` (optional): called once the G2.B accumulate is enqueued, with its completion event; it may enqueue work that must own the machine
 // next (computeH when the inputs came from the host) and return the event the A accumulate has to wait for instead.
@@ -522,7 +585,7 @@ static int msm5_reserve(Slot* sl[5], const Msm5Inputs& in, size_t extra0) {
     else ZK_TRY(msm_prep_need(in.nw, &kMontCfg, sl[1]->stream, &prep, &acc1, &acc2));
     need[1] = acc1;
     need[2] = acc1;
-    need[4] = prep + acc2;
+    need[4] = prep + acc2 + msm_compact_need(in.nw, 1);
     if (in.tab_w || k_shares_w(in, &j)) need[3] = acc1;
     else ZK_TRY(msm_g1_need(in.nk, &kMontCfg, sl[3]->stream, &need[3]));
     need[0] += extra0;
@@ -831,6 +894,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     Msm5State S;
     static const bool nogate = ZK_EXP("ZKMI_NOGATE", 0) == 1;  // experiment: G2.B accumulate does not wait for computeH
     static const bool preph_first = ZK_EXP("ZKMI_PREPH_FIRST", 0) == 1;  // experiment: prepare(h) alone, before G2.B
+    static const bool preph_early = ZK_EXP("ZKMI_PREPH_EARLY", 0) == 1;  // experiment: prepare(h) ENQUEUED before the w-side accumulates (no extra gating)
     if (host_order) {
         if (hipMemcpyAsync(d_w, w, nw * 32, kind, st4) != hipSuccess) rc = set_err(ZK_ERR_HIP, "hipMemcpyAsync failed");
         in.d_w = d_w;
@@ -875,6 +939,13 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
         if (preph_first) {
             if (rc == ZK_OK) rc = msm5_prepare_h(g.s, st, in, &S);
             if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, S.prep_h.ready ? S.prep_h.ready : ev_h);
+            if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S, true);
+        } else if (preph_early) {
+            // host enqueue order only: prepare(h) is enqueued (on computeH's stream, behind it) BEFORE the ~40 launches of the four w-side accumulates and their
+            // tails -- with witness-like wires those are short and the GPU reaches the end of computeH before the host has enqueued prepare(h) behind them
+            if (rc == ZK_OK) rc = msm5_prepare_w(g.s, in, nullptr, &S);
+            if (rc == ZK_OK) rc = msm5_prepare_h(g.s, st, in, &S);
+            if (rc == ZK_OK) rc = msm5_accumulate_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);
             if (rc == ZK_OK) rc = msm5_launch_h(g.s, st, in, &S, true);
         } else {
             if (rc == ZK_OK) rc = msm5_launch_w(g.s, in, nullptr, &S, nogate ? nullptr : ev_h);

@@ -58,7 +58,8 @@ struct PingPong {
 #endif
 
 // The hand-written sort of radix.hpp (no workgroup ever waits for another one), same contract as sort_pairs: sorted pairs end up in kb / vb's current buffers.
-static int rs_sort_pairs(Slot* s, hipStream_t st, void* tmp, PingPong& kb, PingPong& vb, size_t n, unsigned key_bits) {
+// d_n (may be null): the number of pairs when only the device knows it (at most n).
+static int rs_sort_pairs(Slot* s, hipStream_t st, void* tmp, PingPong& kb, PingPong& vb, size_t n, unsigned key_bits, const uint32_t* d_n = nullptr) {
     const RsPlan R = rs_plan(n, key_bits);
     uint32_t* tile_hist = (uint32_t*)tmp;
     uint32_t* ghist = tile_hist + (size_t)RS_MAX_BINS * R.ntiles;
@@ -68,13 +69,13 @@ static int rs_sort_pairs(Slot* s, hipStream_t st, void* tmp, PingPong& kb, PingP
     for (unsigned p = 0; p < RS_MAX_PASSES; p++) { A.shift[p] = R.shift[p]; A.bits[p] = R.bits[p]; }
     const unsigned nt = (unsigned)R.ntiles;
     ZK_HIP(hipMemsetAsync(ghist, 0, RS_MAX_PASSES * RS_MAX_BINS * 4, st));
-    ZK_LAUNCH(s, st, "msm_sort_hist", k_rs_hist, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (uint32_t)n, A, nt, ghist, tile_hist);
+    ZK_LAUNCH(s, st, "msm_sort_hist", k_rs_hist, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (uint32_t)n, A, nt, ghist, tile_hist, d_n);
     ZK_LAUNCH(s, st, "msm_sort_bases", k_rs_bases, dim3(1), dim3(RS_MAX_BINS), 0, (const uint32_t*)ghist, gbase, R.npass);
     for (unsigned p = 0; p < R.npass; p++) {
-        if (p) ZK_LAUNCH(s, st, "msm_sort_hist", k_rs_tile_hist, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (uint32_t)n, R.shift[p], R.bits[p], nt, tile_hist);
+        if (p) ZK_LAUNCH(s, st, "msm_sort_hist", k_rs_tile_hist, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (uint32_t)n, R.shift[p], R.bits[p], nt, tile_hist, d_n);
         ZK_LAUNCH(s, st, "msm_sort_scan", k_rs_scan_rows, dim3(1u << R.bits[p]), dim3(256), 0, tile_hist, nt);
         ZK_LAUNCH(s, st, "msm_sort_pass", k_rs_scatter, dim3(nt), dim3(RS_THREADS), 0, (const uint32_t*)kb.current(), (const uint32_t*)vb.current(), kb.alternate(), vb.alternate(),
-                  (uint32_t)n, R.shift[p], R.bits[p], nt, (const uint32_t*)tile_hist, (const uint32_t*)(gbase + p * RS_MAX_BINS));
+                  (uint32_t)n, R.shift[p], R.bits[p], nt, (const uint32_t*)tile_hist, (const uint32_t*)(gbase + p * RS_MAX_BINS), d_n);
         kb.swap();
         vb.swap();
     }
@@ -190,13 +191,14 @@ __global__ void k_msm_digits(DigitSrc src, uint32_t n, int mont, unsigned c, uns
     }
 }
 
-// ---- table mode with the zero digits dropped BEFORE the sort (opt-in: callers whose scalars are wire values -- bits, bytes, words -- where two thirds of the
-// digits are zero and the sort would move their sentinel keys through every pass): count the non-zero digits per scalar, scan, write them contiguously.  The caller
-// learns the total from the scan (one small copy + one synchronisation: only for callers that are synchronous anyway) and sorts that many pairs.  Same buckets,
-// same sums: within a bucket the points arrive in another order, and the group law does not care.
+// ---- the zero digits dropped BEFORE the sort (opt-in: callers whose scalars are wire values -- bits, bytes, words -- where two thirds of the digits are zero and
+// the sort would move their sentinel keys through every pass): count the non-zero digits per scalar, scan, write them contiguously.  The TOTAL stays on the
+// device: the scan's last entry is what the sort, the bucket bounds and everything after read as their length (radix.hpp rs_len), so the host never waits for
+// it (round 4 copied it back and synchronised -- fine for PLONK's round 1, not for a Groth16 proof whose five multi-exps are enqueued in one go).
+// Same buckets, same sums: within a bucket the points arrive in another order, and the group law does not care.
 template <class Emit>
-__device__ __forceinline__ void table_digits_of(const Fr* __restrict__ scalars, uint32_t i, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step,
-                                                Emit&& emit) {
+__device__ __forceinline__ void digits_of(const Fr* __restrict__ scalars, uint32_t i, int mont, unsigned c, unsigned W, bool table, unsigned row_first, unsigned row_step,
+                                          Emit&& emit) {
     Fr s;
     {
         const uint4* q = reinterpret_cast<const uint4*>(scalars + i);
@@ -224,19 +226,21 @@ __device__ __forceinline__ void table_digits_of(const Fr* __restrict__ scalars, 
             neg = 1;
             carry = 1;
         }
+        if (!table) { emit(w, mag, neg); continue; }  // one bucket set per window: `w` is the window
         if (w != next_row) continue;
-        emit(wl, mag, neg);
+        emit(wl, mag, neg);                           // one bucket set for all windows: `wl` is the row of the table
         next_row += row_step;
         wl++;
     }
 }
-__global__ void k_msm_digit_count(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step, uint32_t* __restrict__ cnt) {
+__global__ void k_msm_digit_count(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, uint32_t table_stride, unsigned row_first, unsigned row_step,
+                                  uint32_t* __restrict__ cnt) {
     prio_hi();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned vec = blockIdx.y;
     uint32_t k = 0;
-    table_digits_of(src.p[vec], i, mont, c, W, row_first, row_step, [&](unsigned, uint32_t mag, uint32_t) { k += mag != 0; });
+    digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned, uint32_t mag, uint32_t) { k += mag != 0; });
     cnt[(size_t)vec * n + i] = k;
 }
 __global__ void k_msm_digits_compact(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step, uint32_t table_stride,
@@ -247,10 +251,15 @@ __global__ void k_msm_digits_compact(DigitSrc src, uint32_t n, int mont, unsigne
     const unsigned vec = blockIdx.y;
     const uint32_t B = 1u << (c - 1);
     uint32_t o = off[(size_t)vec * n + i];
-    table_digits_of(src.p[vec], i, mont, c, W, row_first, row_step, [&](unsigned wl, uint32_t mag, uint32_t neg) {
+    digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned wl, uint32_t mag, uint32_t neg) {
         if (!mag) return;
-        keys[o] = vec * B + (mag - 1);
-        vals[o] = ((wl * table_stride + i) << 1) | neg;
+        if (table_stride) {
+            keys[o] = vec * B + (mag - 1);
+            vals[o] = ((wl * table_stride + i) << 1) | neg;
+        } else {
+            keys[o] = wl * B + (mag - 1);
+            vals[o] = (i << 1) | neg;
+        }
         o++;
     });
 }
@@ -259,10 +268,11 @@ __global__ void k_msm_digits_compact(DigitSrc src, uint32_t n, int mont, unsigne
 // start[b] = first sorted position whose key >= b (lower bound), for b in [0, nb]; key nb is the zero-digit sentinel.
 // One lane per bucket, ~log2(total) dependent L2 hits each: no serial gap-filling loops whatever the key distribution
 // (the top window leaves ~20k empty buckets in a row for uniform scalars).
-__global__ void k_bucket_bounds(const uint32_t* __restrict__ keys, uint32_t total, uint32_t nb, uint32_t* __restrict__ start) {
+__global__ void k_bucket_bounds(const uint32_t* __restrict__ keys, uint32_t total, uint32_t nb, uint32_t* __restrict__ start, const uint32_t* __restrict__ d_total) {
     prio_hi();
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
+    total = rs_len(total, d_total);
     uint32_t lo = 0, hi = total;  // answer in [lo, hi]
     while (lo < hi) {
         uint32_t mid = lo + ((hi - lo) >> 1);
@@ -1056,30 +1066,24 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
     // the counters of step 4 are cleared here, ahead of the chain of dependent launches they would otherwise lengthen
     ZK_HIP(hipMemsetAsync(bins, 0, 256 + TS_BINS * 4, st));
     // ---- 1. digits
+    const uint32_t* d_total = nullptr;  // non-null: the zero digits were dropped and only the device knows how many pairs there are (at most `total`)
     {
         DigitSrc src = batch ? *batch : DigitSrc{{d_scalars, nullptr, nullptr}};
         const unsigned sets = P.table_stride ? P.W : 1;
         const int mont = (cfg && cfg->scalars_mont) ? 1 : 0;
         const dim3 grid((unsigned)((n + 255) / 256), sets);
-        if (drop_zero_digits && P.table_stride) {  // count, scan, write only the non-zero digits (see k_msm_digit_count); the caller reserved msm_compact_need more
+        if (drop_zero_digits) {  // count, scan, write only the non-zero digits (see k_msm_digit_count); the caller reserved msm_compact_need more
             const size_t m = (size_t)sets * n;
             uint32_t* cnt = (uint32_t*)s->alloc((m + 1) * 4);
             uint32_t* off = (uint32_t*)s->alloc((m + 1) * 4);
             void* ctmp = s->alloc(xs_tmp_bytes(m + 1) + 16);
             if (!cnt || !off || !ctmp) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (zero-digit compaction)");
             ZK_HIP(hipMemsetAsync(cnt + m, 0, 4, st));
-            ZK_LAUNCH(s, st, "msm_digits", k_msm_digit_count, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, P.row_first, P.row_step, cnt);
+            ZK_LAUNCH(s, st, "msm_digits", k_msm_digit_count, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, P.table_stride, P.row_first, P.row_step, cnt);
             ZK_TRY(xs_exclusive_scan(s, st, ctmp, cnt, off, m + 1));
-            uint32_t h_total = 0;
-            ZK_HIP(hipMemcpyAsync(&h_total, off + m, 4, hipMemcpyDeviceToHost, st));
-            ZK_TRY(slot_sync(s, st));
-            if (h_total == 0) {  // every scalar is zero
-                out->empty = true;
-                return ZK_OK;
-            }
             ZK_LAUNCH(s, st, "msm_digits", k_msm_digits_compact, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, P.row_first, P.row_step, P.table_stride,
                       (const uint32_t*)off, keys0, vals0);
-            total = h_total;
+            d_total = off + m;  // the number of pairs, where the kernels below read it
         } else {
             ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step,
                       P.Wrows);
@@ -1091,10 +1095,10 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
 #ifdef ZKMI_EXPERIMENTS  // the rocPRIM radix-sort call of the A/B runs
 #include "experiments/msm_sort_rocprim_call.inc"
 #endif
-    if (own_sort) ZK_TRY(rs_sort_pairs(s, st, sort_tmp, kb, vb, total, key_bits));
+    if (own_sort) ZK_TRY(rs_sort_pairs(s, st, sort_tmp, kb, vb, total, key_bits, d_total));
     const uint32_t* keys = kb.current();
     // ---- 3. bucket bounds
-    ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, keys, (uint32_t)total, nb, start);
+    ZK_LAUNCH(s, st, "msm_bucket_bounds", k_bucket_bounds, dim3((nb + 1 + 255) / 256), dim3(256), 0, keys, (uint32_t)total, nb, start, d_total);
     // ---- 4. plan.  The steps that are one workgroup's work (task length, scan of the tile counts, scan of the bin counts) are run by the LAST workgroup of
     // the launch before them (block_arrive_is_last): eleven dependent launches of 4-30 us each were 0.26 ms start to end, on the critical path of every MSM
     // (DESIGN.md 3.4); seven remain.  ZKMI_PREP_MERGE=0 (A/B switch): one launch per step.
@@ -1430,10 +1434,10 @@ int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* 
     for (unsigned v = 0; v < sets; v++) src.p[v] = (const Fr*)d_scalars[v];
     return msm_prepare(s, st, P, src.p[0], n, cfg, out, &src, drop_zero_digits);
 }
-int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out) {
+int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out, bool drop_zero_digits) {
     MsmPlan P;
     ZK_TRY(msm_plan<Fp>(n, cfg, st, &P, &tab));
-    return msm_prepare(s, st, P, (const Fr*)d_scalars, n, cfg, out);
+    return msm_prepare(s, st, P, (const Fr*)d_scalars, n, cfg, out, nullptr, drop_zero_digits);
 }
 
 // T[k * stride + i] = 2^(c*w_k) * P_i as affine points for the rows w_k = row_first + k * row_step < Wd (all rows: row_first = 0, row_step = 1);
@@ -1560,10 +1564,10 @@ int msm_expand_bases(Slot* s, hipStream_t st, int is_g2, const void* d_compact, 
     return ZK_OK;
 }
 
-int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out) {
+int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out, bool drop_zero_digits) {
     MsmPlan P;
     ZK_TRY(msm_plan<Fp>(n, cfg, st, &P));  // the scalar-side plan does not depend on the group
-    return msm_prepare(s, st, P, (const Fr*)d_scalars, n, cfg, out);
+    return msm_prepare(s, st, P, (const Fr*)d_scalars, n, cfg, out, nullptr, drop_zero_digits);
 }
 void msm_prep_release(MsmPrep* R) {
     if (R->ready) (void)hipEventDestroy(R->ready);

@@ -81,13 +81,15 @@ int msm_g2_launch(Slot* s, hipStream_t st, const void* d_pts, const void* d_scal
 // Split form for MSMs that share one scalar vector: prepare once, accumulate per base array (bases indexed by scalar
 // index; indices below `skip_below` are ignored).
 int msm_prep_need(size_t n, const zk_msm_cfg* cfg, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2);
-int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out);
+// drop_zero_digits (here and below): the zero digits never enter the sort -- for scalars that are wire values (0 / 1 / small: most digits are zero); the number of
+// pairs stays on the device, nothing synchronises; reserve msm_compact_need(n, sets) more in the preparing slot.  Same sums either way.
+int msm_prepare_scalars(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, MsmPrep* out, bool drop_zero_digits = false);
 int msm_prep_need_table(size_t n, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1, size_t* need_acc_g2);
-int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out);
+int msm_prepare_scalars_table(Slot* s, hipStream_t st, const void* d_scalars, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out, bool drop_zero_digits = false);
 // a batch of up to three scalar vectors (n elements each) against ONE window table: one recoding, one accumulate launch, one sum per vector
 int msm_prep_need_table_batch(size_t n, unsigned sets, const MsmTable& tab, hipStream_t st, size_t* need_prep, size_t* need_acc_g1);
 int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out,
-                                    bool drop_zero_digits = false);  // true: synchronises the stream once (callers that are synchronous anyway), reserve msm_compact_need more
+                                    bool drop_zero_digits = false);
 size_t msm_compact_need(size_t n, unsigned sets);
 // zk_bn254_msm_bases_batch_dev for scalars known to be mostly small (wire values): zero digits dropped before the sort
 int msm_bases_batch_dev_sparse(uint64_t handle, size_t offset, const void* const* d_scalars, unsigned count, size_t n, const zk_msm_cfg* cfg, void* out);

@@ -50,7 +50,9 @@ struct Csr {
 struct R1csDev {
     size_t n_constraints = 0, n_wires = 0, n_public = 0;  // n_public includes the ONE wire
     Csr row[3];  // L, R, O by constraint (CSR)
-    Csr col[3];  // the same by wire (CSC): Setup's transposed products
+    Csr col[3];  // the same by wire (CSC): Setup's transposed products -- built on the device when a Setup first asks for them (ensure_csc): a prover never does
+    bool have_csc = false;
+    std::mutex csc_mu;
     std::vector<void*> allocs;
 };
 static std::mutex g_r1cs_mu;
@@ -117,6 +119,44 @@ __global__ void k_z_scalars(PowTab tau_pw, uint32_t N, unsigned logN, Fr scale, 
 }
 static unsigned gridn(size_t n) { return (unsigned)((n + 255) / 256); }
 
+// CSR -> CSC on the device: count the entries of every wire, scan, scatter through per-wire cursors.  Inside a column the entries land in whatever order the
+// lanes arrive -- the transposed product sums them in the field, where the order of additions does not exist.
+__global__ void k_csc_count(const uint32_t* __restrict__ idx, size_t nnz, uint32_t* __restrict__ cnt) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) atomicAdd(&cnt[idx[k]], 1u);
+}
+// cnt[0 .. n) -> exclusive prefix sums in ptr[0 .. n], one workgroup (a Setup step: 2^20 wires in ~0.1 ms; not worth a multi-pass scan)
+__global__ __launch_bounds__(1024) void k_csc_scan(const uint32_t* __restrict__ cnt, size_t n, uint32_t* __restrict__ ptr) {
+    __shared__ uint32_t part[1024];
+    const size_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (size_t i = lo; i < hi; i++) sum += cnt[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (size_t i = lo; i < hi; i++) {
+        ptr[i] = run;
+        run += cnt[i];
+    }
+    if (threadIdx.x == 1023) ptr[n] = part[1023];
+}
+__global__ void k_csc_fill(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx, const Fr* __restrict__ val, size_t rows, uint32_t* __restrict__ cursor,
+                           uint32_t* __restrict__ cidx, Fr* __restrict__ cval) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    for (uint32_t k = ptr[i]; k < ptr[i + 1]; k++) {
+        const uint32_t pos = atomicAdd(&cursor[idx[k]], 1u);
+        cidx[pos] = (uint32_t)i;
+        cval[pos] = ldf(val + k);
+    }
+}
+
 static int lookup_r1cs(uint64_t h, std::shared_ptr<R1csDev>* out) {
     std::lock_guard<std::mutex> lk(g_r1cs_mu);
     auto it = g_r1cs.find(h);
@@ -126,6 +166,32 @@ static int lookup_r1cs(uint64_t h, std::shared_ptr<R1csDev>* out) {
 }
 
 int groth16_pk_adopt(uint64_t handle);  // groth16.hip: the key takes ownership of its device arrays
+
+// the by-wire (CSC) form of the three matrices, built once, on the device, when a Setup asks for it
+static int ensure_csc(R1csDev* D, Slot* s, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(D->csc_mu);
+    if (D->have_csc) return ZK_OK;
+    const size_t nw = D->n_wires, nc = D->n_constraints;
+    uint32_t* cnt = nullptr;
+    ZK_HIP(hipMalloc((void**)&cnt, (nw + 1) * 4));
+    struct FreeCnt { uint32_t* p; ~FreeCnt() { (void)hipFree(p); } } fc{cnt};
+    for (int m = 0; m < 3; m++) {
+        const Csr& R = D->row[m];
+        Csr& Cc = D->col[m];
+        Cc.nnz = R.nnz;
+        ZK_TRY(dalloc(D, &Cc.ptr, nw + 1));
+        ZK_TRY(dalloc(D, &Cc.idx, R.nnz));
+        ZK_TRY(dalloc(D, &Cc.val, R.nnz));
+        ZK_HIP(hipMemsetAsync(cnt, 0, (nw + 1) * 4, st));
+        if (R.nnz) ZK_LAUNCH(s, st, "r1cs_csc", k_csc_count, dim3(gridn(R.nnz)), dim3(256), 0, (const uint32_t*)R.idx, R.nnz, cnt);
+        ZK_LAUNCH(s, st, "r1cs_csc", k_csc_scan, dim3(1), dim3(1024), 0, (const uint32_t*)cnt, nw, Cc.ptr);
+        ZK_HIP(hipMemcpyAsync(cnt, Cc.ptr, nw * 4, hipMemcpyDeviceToDevice, st));  // the cursors start at the column starts
+        if (nc && R.nnz) ZK_LAUNCH(s, st, "r1cs_csc", k_csc_fill, dim3(gridn(nc)), dim3(256), 0, (const uint32_t*)R.ptr, (const uint32_t*)R.idx, (const Fr*)R.val, nc, cnt, Cc.idx, Cc.val);
+    }
+    ZK_TRY(slot_sync(s, st));
+    D->have_csc = true;
+    return ZK_OK;
+}
 
 }  // namespace zkmi
 
@@ -164,28 +230,6 @@ int zk_bn254_r1cs_load(const zk_r1cs* r, uint64_t* handle) {
         if (nnz) {
             ZK_HIP(hipMemcpy(R.idx, idxs[m], nnz * 4, hipMemcpyHostToDevice));
             ZK_HIP(hipMemcpy(R.val, vals[m], nnz * 32, hipMemcpyHostToDevice));
-        }
-        // CSC: counting sort of the entries by wire (stable: constraints stay in order inside a column)
-        std::vector<uint32_t> cptr(r->n_wires + 1, 0), cidx(nnz);
-        std::vector<zk_fr> cval(nnz);
-        for (size_t k = 0; k < nnz; k++) cptr[idxs[m][k] + 1]++;
-        for (size_t w = 0; w < r->n_wires; w++) cptr[w + 1] += cptr[w];
-        std::vector<uint32_t> cur(cptr.begin(), cptr.end() - 1);
-        for (size_t i = 0; i < nc; i++)
-            for (uint32_t k = ptrs[m][i]; k < ptrs[m][i + 1]; k++) {
-                uint32_t pos = cur[idxs[m][k]]++;
-                cidx[pos] = (uint32_t)i;
-                cval[pos] = vals[m][k];
-            }
-        Csr& Cc = D->col[m];
-        Cc.nnz = nnz;
-        ZK_TRY(dalloc(D.get(), &Cc.ptr, r->n_wires + 1));
-        ZK_TRY(dalloc(D.get(), &Cc.idx, nnz));
-        ZK_TRY(dalloc(D.get(), &Cc.val, nnz));
-        ZK_HIP(hipMemcpy(Cc.ptr, cptr.data(), (r->n_wires + 1) * 4, hipMemcpyHostToDevice));
-        if (nnz) {
-            ZK_HIP(hipMemcpy(Cc.idx, cidx.data(), nnz * 4, hipMemcpyHostToDevice));
-            ZK_HIP(hipMemcpy(Cc.val, cval.data(), nnz * 32, hipMemcpyHostToDevice));
         }
     }
     std::lock_guard<std::mutex> lk(g_r1cs_mu);
@@ -260,6 +304,7 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
     Fr* zsc = (Fr*)s->alloc(N * sizeof(Fr));
     if (!lag || !abc || !ksc || !zsc) return set_err(ZK_ERR_HIP, "setup workspace");
     ZK_LAUNCH(s, st, "setup_lagrange", k_lagrange_at, dim3(gridn(N)), dim3(256), 0, (const Fr*)dom->tw, (uint32_t)N, todev(tau), todev(zt * dom->card_inv), lag);
+    ZK_TRY(ensure_csc(D, s, st));
     {   // A_i, B_i, C_i = sum_j M[j][i] lag_j: the transposed products, one lane per wire over the CSC form
         Csr3 M;
         for (int m = 0; m < 3; m++) { M.ptr[m] = D->col[m].ptr; M.idx[m] = D->col[m].idx; M.val[m] = D->col[m].val; }

@@ -54,9 +54,17 @@ struct RsArgs {
 };
 
 // all digit histograms in one pass over the keys; tile_hist is bin-major: [bin * ntiles + tile]
+// d_n (every kernel that takes it; may be null): the number of pairs as the DEVICE knows it -- a preparation that drops the zero digits learns its length from a
+// scan and must not make the host wait for it.  The launch is sized for `n` (the most there can be); tiles past *d_n find nothing to do.
+__device__ __forceinline__ uint32_t rs_len(uint32_t n, const uint32_t* __restrict__ d_n) {
+    if (!d_n) return n;
+    const uint32_t m = *d_n;
+    return m < n ? m : n;
+}
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n, RsArgs A, uint32_t ntiles, uint32_t* __restrict__ ghist,
-                                                        uint32_t* __restrict__ tile_hist0) {
+                                                        uint32_t* __restrict__ tile_hist0, const uint32_t* __restrict__ d_n) {
     prio_hi();
+    n = rs_len(n, d_n);
     __shared__ uint32_t h[RS_MAX_PASSES][RS_MAX_BINS];
     for (unsigned i = threadIdx.x; i < RS_MAX_PASSES * RS_MAX_BINS; i += RS_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
@@ -97,8 +105,9 @@ __global__ __launch_bounds__(RS_MAX_BINS) void k_rs_bases(const uint32_t* __rest
 }
 
 __global__ __launch_bounds__(RS_THREADS) void k_rs_tile_hist(const uint32_t* __restrict__ keys, uint32_t n, unsigned shift, unsigned bits, uint32_t ntiles,
-                                                             uint32_t* __restrict__ tile_hist) {
+                                                             uint32_t* __restrict__ tile_hist, const uint32_t* __restrict__ d_n) {
     prio_hi();
+    n = rs_len(n, d_n);
     __shared__ uint32_t h[RS_MAX_BINS];
     for (unsigned i = threadIdx.x; i < RS_MAX_BINS; i += RS_THREADS) h[i] = 0;
     __syncthreads();
@@ -141,8 +150,10 @@ __global__ __launch_bounds__(256) void k_rs_scan_rows(uint32_t* __restrict__ til
 // the digit's running count (an LDS word per wave and digit, written by one lane of the group) plus the lanes of the group below this one.
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
                                                            uint32_t* __restrict__ vals_out, uint32_t n, unsigned shift, unsigned bits, uint32_t ntiles,
-                                                           const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ gbase) {
+                                                           const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ d_n) {
     prio_hi();
+    n = rs_len(n, d_n);
+    if (blockIdx.x * RS_TILE >= n) return;  // (uniform over the workgroup: before any barrier)
     __shared__ uint32_t cnt[RS_WAVES][RS_MAX_BINS];
     __shared__ uint32_t off[RS_MAX_BINS];   // first staged slot of a digit; then (global destination of the digit's first pair of this tile) - off
     __shared__ uint32_t scan[RS_MAX_BINS];

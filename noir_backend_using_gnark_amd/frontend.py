@@ -131,3 +131,47 @@ def groth16_prove_with_meta(raw_json: str, toxic=None, rs=None) -> str:
         raise ValueError((lib().zk_last_error() or b"").decode())
     check(rc)
     return out.raw.decode()
+
+
+def groth16_lower_resident(raw_json: str, to_device: bool = False) -> None:
+    """Reads a RawR1CS text into the resident cache (host only unless to_device): the zk_groth16_* call that follows finds the circuit by content."""
+    a = _b(raw_json)
+    rc = lib().zk_groth16_lower_resident(C.c_char_p(a), C.c_size_t(len(a)), C.c_int(int(to_device)))
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+
+
+def groth16_key_resident(encoded_pk: str) -> None:
+    """Decodes a key text into the resident cache (no window tables: they come with the key's second proof)."""
+    k = _b(encoded_pk)
+    rc = lib().zk_groth16_key_resident(C.c_char_p(k), C.c_size_t(len(k)))
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+
+
+def groth16_public_inputs(raw_json: str) -> np.ndarray:
+    """buildWitnesses' public part for VerifyWithVK (r1cs.go:176-212): the values of the public wires after ONE, in wire order -> (n, 4) Montgomery limbs."""
+    a = _b(raw_json)
+    n = C.c_size_t(0)
+    out = np.zeros((16, 4), dtype=np.uint64)
+    rc = lib().zk_groth16_public_inputs(C.c_char_p(a), C.c_size_t(len(a)), vp(out), C.c_size_t(16), C.byref(n))
+    if rc == _lib.ZK_ERR_ARG and n.value > 16:
+        out = np.zeros((n.value, 4), dtype=np.uint64)
+        rc = lib().zk_groth16_public_inputs(C.c_char_p(a), C.c_size_t(len(a)), vp(out), C.c_size_t(n.value), C.byref(n))
+    if rc in (_lib.ZK_ERR_LEN, _lib.ZK_ERR_ARG):
+        raise ValueError((lib().zk_last_error() or b"").decode())
+    check(rc)
+    return out[:n.value]
+
+
+def export_cache_info() -> dict:
+    """What the export path keeps resident between calls (PLONK and Groth16 entries together)."""
+    nc, nk, by = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    check(lib().zk_export_cache_info(C.byref(nc), C.byref(nk), C.byref(by)))
+    return {"circuits": nc.value, "keys": nk.value, "bytes": by.value}
+
+
+def export_cache_clear() -> None:
+    check(lib().zk_export_cache_clear())

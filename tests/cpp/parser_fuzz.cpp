@@ -107,10 +107,53 @@ static void check_raw(const std::string& text, const char* what, size_t id) {
     domref::RawBuilt D;
     const int rd = domref::raw_r1cs_build(text.data(), text.size(), &D);
     CHECK(rc == rd, "%s #%zu: streaming rc %d (%s) vs tree rc %d (%s)", what, id, rc, err.c_str(), rd, domref::g_err.c_str());
+    if ((id & 3) == 0) {  // the gates array split among 2..5 readers (raw_detail::elements_parallel, forced on these short texts): status, message, every output word
+        zkmi::RawR1CSBuilt P;
+        std::string ep;
+        zkmi::acir_detail::ParallelCfg& pc = zkmi::acir_detail::parallel_cfg();
+        const zkmi::acir_detail::ParallelCfg keep = pc;
+        pc.min_bytes = 0;
+        pc.threads = 2 + (unsigned)below(4);
+        const int rp = zkmi::raw_r1cs_build(text.data(), text.size(), &P, &ep);
+        pc = keep;
+        CHECK(rp == rc && ep == err, "%s #%zu: parallel gate readers rc %d (%s) vs one reader rc %d (%s)", what, id, rp, ep.c_str(), rc, err.c_str());
+        if (rp == ZK_OK && rc == ZK_OK) {
+            bool same = P.n_public == B.n_public && same_frs(P.wires, B.wires) && P.order == B.order && P.prod_a == B.prod_a && P.prod_b == B.prod_b && P.values_at == B.values_at &&
+                        P.values_len == B.values_len;
+            for (int m = 0; m < 3; m++) same = same && P.ptr[m] == B.ptr[m] && P.idx[m] == B.idx[m] && same_frs(P.val[m], B.val[m]);
+            CHECK(same, "%s #%zu: parallel gate readers: R1CS rows / wires differ", what, id);
+        }
+    }
     if (rc != ZK_OK || rd != ZK_OK) return;
     bool same = B.n_public == D.n_public && same_frs(B.wires, D.wires);
     for (int m = 0; m < 3; m++) same = same && B.ptr[m] == D.ptr[m] && B.idx[m] == D.idx[m] && same_frs(B.val[m], D.val[m]);
     CHECK(same, "%s #%zu: R1CS rows / wires differ", what, id);
+    // what a resident circuit keeps to assemble the wire vector on the device: the same wires from (values, order, products), and the circuit alone (no values
+    // decoded) is the same circuit
+    CHECK(B.wires.size() == 1 + B.n_values + B.prod_a.size() && B.order.size() == B.n_values, "%s #%zu: wire count", what, id);
+    if (B.values_at) {
+        CHECK(B.values_at + B.values_len <= text.size() && B.values_len == 8 + 64 * B.n_values && text[B.values_at - 1] == '"' && text[B.values_at + B.values_len] == '"',
+              "%s #%zu: values span", what, id);
+        std::vector<zkmi::HFr> w(B.wires.size());
+        w[0] = zkmi::HFr::one();
+        bool ok = true;
+        for (size_t k = 0; k < B.n_values && ok; k++) {
+            uint64_t t[4];
+            ok = zkmi::felt_from_hex(text.data() + B.values_at + 8 + 64 * (size_t)B.order[k], 64, t);
+            w[1 + k] = zkmi::HFr{{t[0], t[1], t[2], t[3]}}.to_mont();
+        }
+        for (size_t j = 0; j < B.prod_a.size() && ok; j++) {
+            ok = B.prod_a[j] >= 1 && B.prod_a[j] <= B.n_values && B.prod_b[j] >= 1 && B.prod_b[j] <= B.n_values;
+            if (ok) w[1 + B.n_values + j] = w[B.prod_a[j]] * w[B.prod_b[j]];
+        }
+        CHECK(ok && same_frs(w, B.wires), "%s #%zu: wires reassembled from order / products differ", what, id);
+    }
+    zkmi::RawR1CSBuilt C;
+    std::string ec;
+    const int rcc = zkmi::raw_r1cs_build(text.data(), text.size(), &C, &ec, false);
+    bool same_c = rcc == ZK_OK && C.n_public == B.n_public && C.order == B.order && C.prod_a == B.prod_a && C.prod_b == B.prod_b && C.wires.empty();
+    for (int m = 0; m < 3; m++) same_c = same_c && C.ptr[m] == B.ptr[m] && C.idx[m] == B.idx[m] && same_frs(C.val[m], B.val[m]);
+    CHECK(same_c, "%s #%zu: circuit-only mode differs (rc %d %s)", what, id, rcc, ec.c_str());
 }
 
 // the shim's own text helpers (goffi.cpp) and the key / SRS header readers: no second implementation to compare with -- the sanitizers are the check,

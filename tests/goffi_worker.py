@@ -27,7 +27,10 @@ keep = []
 
 def main():
     job = json.load(open(sys.argv[1]))
+    Z = C.CDLL(os.path.join(ROOT, "noir_backend_using_gnark_amd", "libzkmi.so"))  # the mapping libgnark_backend.so links ($ORIGIN rpath)
     L = C.CDLL(os.path.join(ROOT, "noir_backend_using_gnark_amd", "libgnark_backend.so"))
+    if os.environ.get("ZKMI_TEST_NEW_SRS_SIZE"):  # the tests' own variable: an SRS the oracle can read back in seconds (the product reads no such thing)
+        assert Z.zk_export_set_new_srs_size(C.c_size_t(int(os.environ["ZKMI_TEST_NEW_SRS_SIZE"]))) == 0
     for name in ("PlonkProveWithPK", "PlonkProveWithMeta", "ProveWithMeta", "ProveWithPK"):
         getattr(L, name).restype = C.c_void_p
     for name in ("PlonkPreprocess", "Preprocess"):

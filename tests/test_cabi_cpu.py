@@ -158,7 +158,7 @@ def test_handle_values_layouts_match_the_oracle_for_two_and_three_public_inputs(
 
 def test_shipped_libraries_have_no_experiment_switches():
     """The product libraries are loaded into the prover's process: no environment variable may change a result or crash them.  libzkmi.so reads exactly two
-    validated settings (csrc/ctx.hpp), libgnark_backend.so one (the size of a newly created SRS); every A/B switch of DESIGN.md is compiled out unless the
+    validated settings (csrc/ctx.hpp), libgnark_backend.so one (ZKMI_DEVICES: which GPUs -- validated, cannot change a result); every A/B switch of DESIGN.md is compiled out unless the
     library is built with -DZKMI_EXPERIMENTS (libzkmi_exp.so, measurement tooling) -- checked on the strings the binaries contain."""
     import re
 
@@ -167,13 +167,13 @@ def test_shipped_libraries_have_no_experiment_switches():
 
     pkg = os.path.join(ROOT, "noir_backend_using_gnark_amd")
     assert names(os.path.join(pkg, "libzkmi.so")) == {b"ZKMI_TABLE_CAP_GB", b"ZKMI_SLOT_TIMEOUT_S"}
-    assert names(os.path.join(pkg, "libgnark_backend.so")) == {b"ZKMI_SRS_SIZE"}
+    assert names(os.path.join(pkg, "libgnark_backend.so")) == {b"ZKMI_DEVICES"}
     # and the sources read the environment nowhere else
     for f in os.listdir(os.path.join(pkg, "csrc")):
         if f.endswith((".hip", ".hpp", ".cpp")):
             src = open(os.path.join(pkg, "csrc", f)).read()
             for m in re.finditer(r'getenv\("([A-Z_0-9]+)"\)', src):
-                assert m.group(1) in ("ZKMI_SRS_SIZE", "XDG_CONFIG_HOME", "HOME"), (f, m.group(1))
+                assert m.group(1) in ("ZKMI_DEVICES", "XDG_CONFIG_HOME", "HOME"), (f, m.group(1))
 
 
 def test_host_parsers_survive_mutated_inputs():
@@ -248,9 +248,19 @@ def test_go_abi_shim_exports_the_reference_symbols():
     so = os.path.join(ROOT, "noir_backend_using_gnark_amd", "libgnark_backend.so")
     assert os.path.exists(so), "build it: make -C noir_backend_using_gnark_amd/csrc"
     L = C.CDLL(so)
-    for name in ("PlonkVerifyWithMeta", "PlonkProveWithMeta", "PlonkVerifyWithVK", "PlonkProveWithPK", "PlonkPreprocess",
-                 "VerifyWithMeta", "ProveWithMeta", "VerifyWithVK", "ProveWithPK", "Preprocess"):
+    ten = ("PlonkVerifyWithMeta", "PlonkProveWithMeta", "PlonkVerifyWithVK", "PlonkProveWithPK", "PlonkPreprocess",
+           "VerifyWithMeta", "ProveWithMeta", "VerifyWithVK", "ProveWithPK", "Preprocess")
+    for name in ten:
         assert hasattr(L, name), name
+    # ... and nothing else (csrc/goffi.map): what `nm -D` shows of the Go archive's cgo exports
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert sorted(l.split()[-1] for l in out.splitlines() if l.strip()) == sorted(ten), out
+    # the same object as a static archive, for the reference's unchanged build.rs (`static=gnark_backend`, build.rs:17-21)
+    ar = os.path.join(ROOT, "noir_backend_using_gnark_amd", "libgnark_backend.a")
+    assert os.path.exists(ar), "build it: make -C noir_backend_using_gnark_amd/csrc"
+    out = subprocess.run(["nm", "--defined-only", ar], capture_output=True, text=True, check=True).stdout
+    assert {l.split()[-1] for l in out.splitlines() if " T " in l} >= set(ten)
 
     class GoString(C.Structure):
         _fields_ = [("p", C.c_char_p), ("n", C.c_ssize_t)]

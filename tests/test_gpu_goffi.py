@@ -20,7 +20,7 @@ ROOT = os.path.dirname(HERE)
 def run_worker(tmp_path, job, name, env_extra=None, expect_fail=False):
     f = tmp_path / (name + ".json")
     f.write_text(json.dumps(job))
-    env = dict(os.environ, XDG_CONFIG_HOME=str(tmp_path / "cfg"), ZKMI_SRS_SIZE="64", PYTHONPATH=ROOT)
+    env = dict(os.environ, XDG_CONFIG_HOME=str(tmp_path / "cfg"), ZKMI_TEST_NEW_SRS_SIZE="64", PYTHONPATH=ROOT)  # the worker hands it to zk_export_set_new_srs_size
     env.update(env_extra or {})
     out = subprocess.run([sys.executable, os.path.join(HERE, "goffi_worker.py"), str(f)], capture_output=True, text=True, timeout=600, env=env)
     if expect_fail:
@@ -90,6 +90,43 @@ def test_groth16_exports_end_to_end(tmp_path):
     assert ref.groth16_verify(ovk, (pl.g1_decompress(pb[:32]), pl.g2_decompress(pb[32:96]), pl.g1_decompress(pb[96:])), wv[:r1.n_public])
     opk = pl.groth16_pk_from_bytes(bytes.fromhex(a["pk"]))  # ProvingKey.ReadFrom accepts the image
     assert len(opk["infinity_a"]) == r1.n_wires and len(opk["g1_k"]) == r1.n_wires - r1.n_public
+
+
+def test_groth16_exports_at_2p11_constraints_and_the_export_worker(tmp_path):
+    """The same three exports on tools/synth_raw_r1cs.py's circuit of 2^10 gates = 2^11 constraints (both gate shapes, three public inputs), through
+    tools/export_bench_groth16.py -- the worker of bench.py's `export_path_groth16` block -- one process per mode, as nargo would run them: Preprocess (+ a
+    ProveWithPK that finds the key it just wrote resident), then cold / second / warm ProveWithPK with the values alternating between two assignments of the
+    circuit, VerifyWithVK; then a process that only verifies.  The phases say what was read when: the circuit and the key once, the key's window tables at
+    its second proof, nothing but the values afterwards; a verifying process starts no device.  The oracle's pairing verifier accepts the cold proof."""
+    exe = [sys.executable, os.path.join(ROOT, "tools", "export_bench_groth16.py")]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    d = str(tmp_path)
+    run = lambda *a: json.loads(subprocess.run(exe + list(a), capture_output=True, text=True, timeout=900, env=env, check=True).stdout.strip().splitlines()[-1])
+    made = run("make", d, "11")
+    assert made["constraints"] == 2048 and made["witnesses"] == 1026
+    pre = run("preprocess", d)
+    assert pre["verifies"] == 1 and "raw_parse_lower" in pre["phases"] and "groth16_setup" in pre["phases"] and "pk_write_hex" in pre["phases"]
+    assert "pk_read" not in pre["phases_prove_after_preprocess"] and "raw_parse_lower" not in pre["phases_prove_after_preprocess"]
+    pr = run("prove", d, "4")
+    assert pr["verifies"] == 1 and pr["warm_proof_verifies"] == 1 and pr["wrong_public_input_rejected"] == 1
+    assert pr["resident"]["circuits"] == 1 and pr["resident"]["keys"] == 1
+    for k in ("hip_init", "raw_parse_lower", "pk_read", "values_decode", "witness_assemble", "r1cs_solve_abc", "groth16_prove"):
+        assert k in pr["cold_phases"], k
+    assert "pk_window_tables" not in pr["cold_phases"] and "pk_window_tables" in pr["second_phases"]
+    for k in ("raw_parse_lower", "pk_read", "pk_window_tables", "circuit_to_device"):
+        assert k not in pr["warm_phases_per_call"] or (k == "circuit_to_device" and pr["warm_phases_per_call"][k] < 0.05), k
+    ver = run("verify", d)
+    assert ver["verifies"] == 1 and ver["device_entries"] == 0 and "hip_init" not in ver["cold_phases"]
+    # the oracle: the key image reads back, the pairing check accepts the cold proof under the text's public inputs
+    raw = json.loads((tmp_path / "raw.json").read_text())
+    r1, wv = pl.r1cs_from_raw(raw)
+    vkb = bytes.fromhex((tmp_path / "vk.hex").read_text())
+    nk = int.from_bytes(vkb[288:292], "big")
+    assert nk == r1.n_public == 9
+    ovk = dict(g1_alpha=pl.g1_decompress(vkb[0:32]), g2_beta=pl.g2_decompress(vkb[64:128]), g2_gamma=pl.g2_decompress(vkb[128:192]), g2_delta=pl.g2_decompress(vkb[224:288]),
+               g1_ic=[pl.g1_decompress(vkb[292 + 32 * i:324 + 32 * i]) for i in range(nk)])
+    pb = bytes.fromhex((tmp_path / "proof.hex").read_text())
+    assert ref.groth16_verify(ovk, (pl.g1_decompress(pb[:32]), pl.g2_decompress(pb[32:96]), pl.g1_decompress(pb[96:])), wv[:r1.n_public])
 
 
 def test_only_an_unreadable_or_non_hex_srs_file_is_replaced(tmp_path):
@@ -174,7 +211,7 @@ def test_export_path_worker_cold_and_warm_calls_at_2p10(tmp_path):
     PlonkProveWithPK cold + warm and PlonkVerifyWithVK in another, both through Go's ABI.  The key text equals the oracle's Setup under the SRS the first
     process wrote; the cold and the warm proofs verify; another public input is rejected; one circuit and one key stay resident."""
     exe = [sys.executable, os.path.join(ROOT, "tools", "export_bench.py")]
-    env = dict(os.environ, PYTHONPATH=ROOT, ZKMI_EXPORT_SRS_SIZE="2048")
+    env = dict(os.environ, PYTHONPATH=ROOT, ZKMI_TEST_NEW_SRS_SIZE="2048")
     d = str(tmp_path)
     run = lambda *a: json.loads(subprocess.run(exe + list(a), capture_output=True, text=True, timeout=900, env=env, check=True).stdout.strip().splitlines()[-1])
     made = run("make", d, "10")

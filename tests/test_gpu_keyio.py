@@ -1,13 +1,16 @@
 """GPU parity suite: Groth16 key wire formats on the device and the Groth16 FFI entry points that move them (row f2) --
 zk_bn254_groth16_pk_read / _pk_write / _vk_write, zk_groth16_preprocess / _prove_with_pk / _prove_with_meta -- against the oracle's restatement
 of gnark v0.8.0's ProvingKey.WriteTo / ReadFrom (oracle/plonk_ref.py) and the committed fixtures."""
+import ctypes as C
 import json
 import os
 
 import numpy as np
 import pytest
 
+from noir_backend_using_gnark_amd import _lib
 from noir_backend_using_gnark_amd import groth16 as zk
+from noir_backend_using_gnark_amd._lib import vp
 from oracle import bn254_ref as ref
 from oracle import oracle as orc
 from oracle import plonk_ref as pl
@@ -227,6 +230,65 @@ def test_groth16_ffi_preprocess_prove_with_pk_and_with_meta():
             fe.groth16_prove_with_pk(rj, bad_pk, mont_limbs(list(rs)))
     with pytest.raises(ValueError):
         fe.groth16_preprocess("{}")
+
+
+def test_groth16_export_caches_change_no_byte_at_2p11_constraints():
+    """What zk_groth16_prove_with_pk keeps resident (the circuit of a RawR1CS text minus its values string; the decoded key, window tables from its second
+    proof on) against the path that keeps nothing: 2^10 gates = 2^11 constraints (tools/synth_raw_r1cs.py), pinned (r, s).  The first call (everything read,
+    no tables), the second (tables built), a warm one, one after zk_export_cache_clear and the uncached chain zk_groth16_r1cs_from_raw (wire vector
+    assembled on the HOST) -> zk_bn254_groth16_pk_read -> zk_bn254_groth16_prove_r1cs all give the same 128 bytes; another assignment of the same circuit
+    reuses the resident circuit and gives another proof, which the host verifier accepts under its own public inputs only; the oracle's pairing verifier accepts
+    the first proof under the key image Preprocess wrote; a text that differs OUTSIDE the values string is another circuit."""
+    from noir_backend_using_gnark_amd import frontend as fe
+    from noir_backend_using_gnark_amd import verify as vf
+    from tools import synth_raw_r1cs as sr
+    fe.export_cache_clear()
+    raw, w = sr.synth(1 << 10, 3, seed=0x51)
+    raw2, w2 = sr.synth(1 << 10, 3, seed=0x51, first=(0xabcdef, 0x123456789))
+    assert raw[:raw.index('"values"')] == raw2[:raw2.index('"values"')] and w != w2
+    tox, rs = mont_limbs(list(ref.rand_felts(0xC0, 5))), mont_limbs(list(ref.rand_felts(0xC1, 2)))
+    pk_hex, vk_hex = fe.groth16_preprocess(raw, tox)
+    assert fe.export_cache_info()["circuits"] == 1 and fe.export_cache_info()["keys"] == 1  # the key Setup made is resident under the text it was written as
+    fe.export_cache_clear()
+    assert fe.export_cache_info() == {"circuits": 0, "keys": 0, "bytes": 0}
+    first = fe.groth16_prove_with_pk(raw, pk_hex, rs)
+    info = fe.export_cache_info()
+    assert info["circuits"] == 1 and info["keys"] == 1
+    second = fe.groth16_prove_with_pk(raw, pk_hex, rs)     # builds the key's window tables
+    assert fe.export_cache_info()["bytes"] > info["bytes"]
+    warm = fe.groth16_prove_with_pk(raw, pk_hex, rs)
+    other = fe.groth16_prove_with_pk(raw2, pk_hex, rs)     # same circuit, other values: no second circuit
+    assert fe.export_cache_info()["circuits"] == 1 and fe.export_cache_info()["keys"] == 1
+    again = fe.groth16_prove_with_pk(raw, pk_hex, rs)
+    fe.export_cache_clear()
+    cleared = fe.groth16_prove_with_pk(raw, pk_hex, rs)
+    assert first == second == warm == again == cleared and other != first
+    # the chain that keeps nothing: host-assembled wires, a key read with its tables at once
+    r1, d_w = fe.groth16_r1cs_from_raw(raw)
+    rk = zk.ProvingKey.read_from(pk_hex)
+    out = np.zeros(128, dtype=np.uint8)
+    _lib.check(_lib.lib().zk_bn254_groth16_prove_r1cs(r1.handle, rk.handle, C.c_void_p(d_w.ptr), C.c_size_t(r1.n_wires), vp(rs[0]), vp(rs[1]), C.c_int(1), vp(out)))
+    assert bytes(out).hex() == first
+    rk.free(); r1.free(); d_w.free()
+    # verification: public inputs read from the text against the resident circuit (host only)
+    pub, pub2 = fe.groth16_public_inputs(raw), fe.groth16_public_inputs(raw2)
+    assert pub.shape == (3, 4) and [pl.mont_np_to_ints(pub)[k] for k in range(3)] == w[:3]
+    assert vf.groth16_verify(bytes.fromhex(first), vk_hex, pub) and vf.groth16_verify(bytes.fromhex(other), vk_hex, pub2)
+    assert not vf.groth16_verify(bytes.fromhex(first), vk_hex, pub2)
+    vkb = bytes.fromhex(vk_hex)
+    nk = int.from_bytes(vkb[288:292], "big")
+    ovk = dict(g1_alpha=pl.g1_decompress(vkb[0:32]), g2_beta=pl.g2_decompress(vkb[64:128]), g2_gamma=pl.g2_decompress(vkb[128:192]), g2_delta=pl.g2_decompress(vkb[224:288]),
+               g1_ic=[pl.g1_decompress(vkb[292 + 32 * i:324 + 32 * i]) for i in range(nk)])
+    pb = bytes.fromhex(first)
+    assert ref.groth16_verify(ovk, (pl.g1_decompress(pb[:32]), pl.g2_decompress(pb[32:96]), pl.g1_decompress(pb[96:])), [1] + w[:3])
+    # a text that differs outside the values string (one coefficient digit) is another circuit: read again, and the old key's proof for it does not verify
+    at = raw.index('"constant_term":"') + len('"constant_term":"') + 63
+    raw3 = raw[:at] + ("1" if raw[at] != "1" else "2") + raw[at + 1:]
+    p3 = fe.groth16_prove_with_pk(raw3, pk_hex, rs)
+    assert fe.export_cache_info()["circuits"] == 2 and p3 != first
+    with pytest.raises(ValueError):
+        fe.groth16_prove_with_pk(raw.replace(sr.felts_wire_hex(w)[8:72], "g" * 64), pk_hex, rs)  # a non-hex values string of the right length: the device decoder says so
+    fe.export_cache_clear()
 
 
 def test_groth16_setup_prove_verify_chain_at_2p15_constraints():

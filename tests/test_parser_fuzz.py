@@ -19,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from tools import synth_acir  # noqa: E402
+from tools import synth_raw_r1cs  # noqa: E402
 
 
 def _seeds(tmp_path):
@@ -46,6 +47,7 @@ def _seeds(tmp_path):
         {"mul_terms": [{"coefficient": hx(1), "multiplicand": 1, "multiplier": 2}], "add_terms": [{"coefficient": hx(-1), "sum": 3}], "constant_term": hx(0)},
         {"mul_terms": [{"coefficient": hx(2), "multiplicand": 3, "multiplier": 1}], "add_terms": [{"coefficient": hx(3), "sum": 2}, {"coefficient": hx(-1), "sum": 4}], "constant_term": hx(5)}],
         "public_inputs": [4, 2], "values": ref.felts_wire([w1, w2, w3, w4, 99]).hex(), "num_variables": 6, "num_constraints": 2}))
+    put("synth.raw.json", synth_raw_r1cs.synth(24, 3, seed=9)[0])  # enough gates for the gates array to be split among several readers
     for k, e in enumerate(json.load(open(os.path.join(HERE, "golden", "groth16_wire_golden.json")))[:2]):
         put("g16pk%d.bin" % k, bytes.fromhex(e["pk_hex"]))
     put("srs.bin", pl.kzg_srs_bytes(pl.kzg_new_srs(8, 12345)))

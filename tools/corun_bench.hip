@@ -71,13 +71,13 @@ static void sort_enqueue(const Sort& S, hipStream_t st) {
     const unsigned nt = (unsigned)S.P.ntiles;
     int cur = 0;
     CHECK(hipMemsetAsync(ghist, 0, RS_MAX_PASSES * RS_MAX_BINS * 4, st));
-    hipLaunchKernelGGL(k_rs_hist, dim3(nt), dim3(RS_THREADS), 0, st, (const uint32_t*)S.k[0], (uint32_t)S.n, A, nt, ghist, tile_hist);
+    hipLaunchKernelGGL(k_rs_hist, dim3(nt), dim3(RS_THREADS), 0, st, (const uint32_t*)S.k[0], (uint32_t)S.n, A, nt, ghist, tile_hist, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(RS_MAX_BINS), 0, st, (const uint32_t*)ghist, gbase, S.P.npass);
     for (unsigned p = 0; p < S.P.npass; p++) {
-        if (p) hipLaunchKernelGGL(k_rs_tile_hist, dim3(nt), dim3(RS_THREADS), 0, st, (const uint32_t*)S.k[cur], (uint32_t)S.n, S.P.shift[p], S.P.bits[p], nt, tile_hist);
+        if (p) hipLaunchKernelGGL(k_rs_tile_hist, dim3(nt), dim3(RS_THREADS), 0, st, (const uint32_t*)S.k[cur], (uint32_t)S.n, S.P.shift[p], S.P.bits[p], nt, tile_hist, (const uint32_t*)nullptr);
         hipLaunchKernelGGL(k_rs_scan_rows, dim3(1u << S.P.bits[p]), dim3(256), 0, st, tile_hist, nt);
         hipLaunchKernelGGL(k_rs_scatter, dim3(nt), dim3(RS_THREADS), 0, st, (const uint32_t*)S.k[cur], (const uint32_t*)S.v[cur], S.k[cur ^ 1], S.v[cur ^ 1], (uint32_t)S.n, S.P.shift[p],
-                           S.P.bits[p], nt, (const uint32_t*)tile_hist, (const uint32_t*)(gbase + p * RS_MAX_BINS));
+                           S.P.bits[p], nt, (const uint32_t*)tile_hist, (const uint32_t*)(gbase + p * RS_MAX_BINS), (const uint32_t*)nullptr);
         cur ^= 1;
     }
 }

@@ -17,7 +17,7 @@ job = dict(what="plonk", acir=json.dumps(e["acir"]), values=felts_wire(values).h
 f = os.path.join(tmp, "job.json")
 json.dump(job, open(f, "w"))
 env = dict(os.environ, XDG_CONFIG_HOME=os.path.join(tmp, "cfg"), PYTHONPATH=ROOT)
-env.pop("ZKMI_SRS_SIZE", None)
+env.pop("ZKMI_TEST_NEW_SRS_SIZE", None)
 os.makedirs(os.path.join(tmp, "cfg"))
 out = {}
 for name in ("first_process_generates", "second_process_loads"):

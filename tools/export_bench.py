@@ -39,6 +39,8 @@ def libs():
     G.PlonkPreprocess.restype = KeyPair
     G.PlonkVerifyWithVK.restype = C.c_ubyte
     Z.zk_profile_enable(1)
+    if os.environ.get("ZKMI_TEST_NEW_SRS_SIZE"):  # a test asks for an SRS its oracle can read back in seconds (default: the reference's 1,000,000 points)
+        assert Z.zk_export_set_new_srs_size(C.c_size_t(int(os.environ["ZKMI_TEST_NEW_SRS_SIZE"]))) == 0
     return Z, G
 
 
@@ -64,9 +66,6 @@ def read(path) -> bytes:
 def main():
     mode, d = sys.argv[1], sys.argv[2]
     os.environ["XDG_CONFIG_HOME"] = os.path.join(d, "cfg")  # srs.hex of this run lives and dies with the directory
-    os.environ.pop("ZKMI_SRS_SIZE", None)                   # the reference's 1,000,000 points ...
-    if os.environ.get("ZKMI_EXPORT_SRS_SIZE"):              # ... unless a test asks for an SRS its oracle can read back in seconds
-        os.environ["ZKMI_SRS_SIZE"] = os.environ["ZKMI_EXPORT_SRS_SIZE"]
     os.makedirs(os.path.join(d, "cfg"), exist_ok=True)
     if mode == "make":
         from tools import synth_acir

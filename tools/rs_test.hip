@@ -49,13 +49,13 @@ static double run(size_t n, unsigned key_bits, int kind, bool check) {
         cur = 0;
         CHECK(hipEventRecord(e0, 0));
         CHECK(hipMemsetAsync(ghist, 0, RS_MAX_PASSES * RS_MAX_BINS * 4, 0));
-        hipLaunchKernelGGL(k_rs_hist, dim3(nt), dim3(RS_THREADS), 0, 0, (const uint32_t*)dk[0], (uint32_t)n, A, nt, ghist, tile_hist);
+        hipLaunchKernelGGL(k_rs_hist, dim3(nt), dim3(RS_THREADS), 0, 0, (const uint32_t*)dk[0], (uint32_t)n, A, nt, ghist, tile_hist, (const uint32_t*)nullptr);
         hipLaunchKernelGGL(k_rs_bases, dim3(1), dim3(RS_MAX_BINS), 0, 0, (const uint32_t*)ghist, gbase, P.npass);
         for (unsigned p = 0; p < P.npass; p++) {
-            if (p) hipLaunchKernelGGL(k_rs_tile_hist, dim3(nt), dim3(RS_THREADS), 0, 0, (const uint32_t*)dk[cur], (uint32_t)n, P.shift[p], P.bits[p], nt, tile_hist);
+            if (p) hipLaunchKernelGGL(k_rs_tile_hist, dim3(nt), dim3(RS_THREADS), 0, 0, (const uint32_t*)dk[cur], (uint32_t)n, P.shift[p], P.bits[p], nt, tile_hist, (const uint32_t*)nullptr);
             hipLaunchKernelGGL(k_rs_scan_rows, dim3(1u << P.bits[p]), dim3(256), 0, 0, tile_hist, nt);
             hipLaunchKernelGGL(k_rs_scatter, dim3(nt), dim3(RS_THREADS), 0, 0, (const uint32_t*)dk[cur], (const uint32_t*)dv[cur], dk[cur ^ 1], dv[cur ^ 1], (uint32_t)n, P.shift[p],
-                               P.bits[p], nt, (const uint32_t*)tile_hist, (const uint32_t*)(gbase + p * RS_MAX_BINS));
+                               P.bits[p], nt, (const uint32_t*)tile_hist, (const uint32_t*)(gbase + p * RS_MAX_BINS), (const uint32_t*)nullptr);
             cur ^= 1;
         }
         CHECK(hipEventRecord(e1, 0));
