@@ -1,0 +1,117 @@
+"""BASELINE.json configs[3]: plonk.Prove at 2^22 gates (KZG-commit MSMs + coset NTTs), checked by the oracle's pairing verifier."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from .common import *  # noqa: F401,F403
+from .common import ROOT, N_PUBLIC, HBM_PEAK_GBS, R_FR, seed_at
+
+
+def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", "3"))):  # the variable: A/B runs of tools/ab_bench.py that need a quieter figure
+    """BASELINE.json configs[3]: "PLONK prove path (KZG-commit MSMs + coset NTTs) at 2^22 gates, 1xMI355X" -- the reference's only live
+    prove path (plonk.Prove, backend/plonk/plonk.go:67).  Device-generated KZG SRS (real powers of alpha: kzg.NewSRS), a synthetic
+    satisfiable circuit of 2^log_n rows (random wiring, random selectors, qK fixed per gate), plonk.Setup and plonk.Prove on the
+    device; the 548 proof bytes are then handed to the CPU oracle's VERIFIER (quotient identity + two KZG pairing checks)."""
+    from noir_backend_using_gnark_amd import bn254 as zb, plonk as zp
+    n = 1 << log_n
+    npub, nvars = 4, n // 2
+    nc = n - npub
+    alpha = 0xA1FA0123456789ABCDEF
+    t0 = time.time()
+    d_srs = lib.DeviceBuffer((n + 3) * 64)
+    a_m = np.frombuffer((alpha * (1 << 256) % R_FR).to_bytes(32, "little"), dtype=np.uint64).copy()
+    lib.check(L.zk_bn254_kzg_new_srs_dev(C.c_void_p(d_srs.ptr), C.c_size_t(n + 3), lib.vp(a_m), None, None))
+    srs = zb.ResidentBases(d_srs, n=n + 3, table_window_bits=int(os.environ.get("ZKMI_BENCH_SRS_C", "0")))  # the variable: window-width sweeps (tooling)
+    rng = np.random.default_rng(5)
+    xa, xb, xc = (rng.integers(0, nvars, nc, dtype=np.uint32) for _ in range(3))
+    dsol = lib.DeviceBuffer(nvars * 32)
+    lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(dsol.ptr), C.c_size_t(nvars), C.c_uint64(0x51), C.c_int(1), C.c_int(1), None))
+    coef = []
+    for sd in (1, 2, 3, 4):
+        b = lib.DeviceBuffer(nc * 32)
+        lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(b.ptr), C.c_size_t(nc), C.c_uint64(sd), C.c_int(1), C.c_int(0), None))
+        coef.append(b)
+    dqk = lib.DeviceBuffer(nc * 32)
+    dx = [lib.DeviceBuffer.from_numpy(v) for v in (xa, xb, xc)]
+    lib.check(L.zk_bn254_plonk_synth_qk_dev(C.c_void_p(dqk.ptr), *[C.c_void_p(b.ptr) for b in coef], *[C.c_void_p(b.ptr) for b in dx], C.c_void_p(dsol.ptr),
+                                            C.c_size_t(nc), None))
+    t_data = time.time() - t0
+    t0 = time.time()
+    pk = zp.setup(zp.Circuit(npub, nvars, coef[0], coef[1], coef[2], coef[3], dqk, xa, xb, xc), srs)
+    t_setup = time.time() - t0
+    bl = np.arange(1, 37, dtype=np.uint64).reshape(9, 4)  # any nine scalars < r (Montgomery images of something)
+    proof = zp.prove(pk, dsol, bl)
+    # One-time precomputation per key, like the window tables: the SRS in Lagrange form over the key's domain (csrc/lagrange.hip), after which l, r, o are
+    # committed from the wire values -- the same digests (the proof bytes are compared below).  The figure without it is kept beside the headline figure.
+    lib.profile(True)  # the same conditions as the timed loop below (its event pairs cost the small sizes up to a millisecond)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proof_monomial = zp.prove(pk, dsol, bl)
+    ms_monomial = (time.perf_counter() - t0) * 1e3 / reps
+    lib.profile(False)
+    lagrange_ms = None
+    if os.environ.get("ZKMI_BENCH_PLONK_LAGRANGE", "1") != "0":  # the variable: A/B runs (tooling)
+        t0 = time.perf_counter()
+        pk.lagrange_srs()
+        lagrange_ms = (time.perf_counter() - t0) * 1e3
+        proof = zp.prove(pk, dsol, bl)
+    lib.profile(True)
+    lib.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proof = zp.prove(pk, dsol, bl)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    lib.profile(False)
+    prof, host_sections = lib.split_profile(lib.profile_read())
+    out = {"gates": n, "prove_ms": round(ms, 2), "steps": reps, "warmup": 1, "setup_ms": round(t_setup * 1e3, 1), "data_s": round(t_data, 2),
+           "lro_commitments": "from the wire values against the SRS's Lagrange form (zk_bn254_plonk_pk_lagrange_srs, once per key)" if lagrange_ms is not None else "from coefficients",
+           "lagrange_srs_ms_once_per_key": None if lagrange_ms is None else round(lagrange_ms, 1), "prove_ms_lro_from_coefficients": round(ms_monomial, 2),
+           "same_bytes_both_ways": bool(proof == proof_monomial),
+           # wall clock of the protocol's rounds (each ends in a digest the next challenge needs): where a proof's time goes when its kernels do not fill it
+           "rounds_ms": {k.split(".", 1)[1]: round(v[1] / reps, 3) for k, v in host_sections.items() if k.startswith("plonk.")},
+           "kzg_commits_per_proof": "10 (9 as MSMs; the linearised polynomial's digest by linearity from the verifying key and [Z])", "ntt_per_proof": "4 x inverse(n) + 4 x coset(4n) + 1 x coset inverse(4n) (gnark's fifth pair -- qk with the public inputs -- is one element-wise kernel here)",
+           "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
+           "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]},
+           # nine commitments of ~n scalars per proof against the SRS's window table; l, r, o and h1, h2, h3 are ONE accumulate launch each (three bucket sets),
+           # so a launch carries 9n / (launches per proof) scalars on average; the transforms' passes work on n (small domain) or 4n points
+           "roofline": block_roofline(prof, reps, 9.0 * n * reps / max(1, prof.get("msm_accumulate_g1", (reps * 9, 0.0))[0]), 0, 4 * n, log_n)}
+    if out["roofline"]:
+        out["roofline"]["scalar_muls_per_proof"] = 9 * n
+    # ---- checker (CPU oracle, after the timed region): decode Proof.WriteTo and run plonk.Verify's equations
+    from oracle import bn254_ref as ref, plonk_ref as pl
+
+    def dec(b):
+        if b[0] >> 6 == 1:
+            return None
+        x = int.from_bytes(bytes([b[0] & 0x3F]) + b[1:], "big")
+        y = pow((x * x * x + 3) % ref.Q, (ref.Q + 1) // 4, ref.Q)
+        return (x, ref.Q - y if (y > (ref.Q - 1) // 2) != (b[0] >> 6 == 3) else y)
+
+    pts = [dec(proof[32 * i:32 * i + 32]) for i in range(7)]
+    claimed = [int.from_bytes(proof[260 + 32 * i:292 + 32 * i], "big") for i in range(7)]
+    pr = dict(lro=pts[0:3], z=pts[3], h=pts[4:7], batch_h=dec(proof[224:256]), claimed=claimed, z_open_h=dec(proof[484:516]), zu=int.from_bytes(proof[516:548], "big"))
+    P = pl.g1_from_np
+    vkd = pk.vk
+    vk = dict(size=n, size_inv=ref.inv(n, ref.R), generator=pl.mont_np_to_ints(vkd["generator"])[0], n_public=npub, coset_shift=5,
+              srs_g2=[ref.G2_GEN, ref.g2_mul(ref.G2_GEN, alpha)], s=[P(p) for p in vkd["s"]], ql=P(vkd["ql"]), qr=P(vkd["qr"]), qm=P(vkd["qm"]), qo=P(vkd["qo"]), qk=P(vkd["qk"]))
+    pub = pl.mont_np_to_ints(dsol.to_numpy(np.uint64, (npub, 4)))
+    out["verified_by"] = "oracle/plonk_ref.plonk_verify: Fiat-Shamir re-derived from the bytes, quotient identity at zeta, two KZG openings by pairings"
+    out["proof_verifies"] = bool(pl.plonk_verify(vk, pr, pub))
+    out["wrong_public_input_rejected"] = bool(not pl.plonk_verify(vk, pr, [(pub[0] + 1) % ref.R] + pub[1:]))
+    # the product's own host-side verifier (zk_bn254_plonk_verify) on the same bytes, with the key image it would get from the wire: same verdicts, timed
+    from noir_backend_using_gnark_amd import verify as zv
+    g2 = np.stack([np.frombuffer(ref.g2_affine_mont_bytes(q), dtype=np.uint64) for q in vk["srs_g2"]])
+    vkb = pl.plonk_vk_bytes(vk)
+    pub_m = dsol.to_numpy(np.uint64, (npub, 4))
+    t0 = time.perf_counter()
+    acc = zv.plonk_verify(proof, vkb, g2, pub_m)
+    out["host_verify"] = {"accepts": bool(acc), "ms": round((time.perf_counter() - t0) * 1e3, 2),
+                          "rejects_wrong_public_input": bool(not zv.plonk_verify(proof, vkb, g2, pl.ints_to_mont_np([(pub[0] + 1) % ref.R] + pub[1:])))}
+    pk.free()
+    srs.free()
+    return out

@@ -120,7 +120,7 @@ int zk_bn254_msm_bases(uint64_t handle, size_t offset, const zk_fr *scalars, siz
  * Registration builds precomputed window tables 2^(c*w)*P_i when they fit (>= 4096 bases): every commit then feeds one bucket set. */
 int zk_bn254_bases_register_dev(const void *d_points, size_t n, int is_g2, uint64_t *handle);
 /* The same with the table geometry chosen by the caller: table_window_bits = 0 auto (tables for >= 4096 bases when they fit),
- * -1 no tables, else c in [8, 22] (tables at any n: how the tests reach the widths the planner picks at 2^22 .. 2^26 points). */
+ * -1 no tables, else c in [8, 24] (tables at any n: how the tests reach the widths the planner picks at 2^22 .. 2^26 points). */
 int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_device, int table_window_bits, uint64_t *handle);
 /* Window tables for a base array registered without them (table_window_bits as above; 0 = the planner's width, nothing below 4096 bases; a handle that has
  * a table is left alone).  The tables of 1,000,000 G1 points take 17 ms to build and save a 2^19-gate PLONK proof 1.4 ms: a process that makes ONE proof (nargo
@@ -228,7 +228,7 @@ typedef struct {
                                    Needs the tables (an error when they do not fit). */
     const uint8_t *infinity_a, *infinity_b; /* gnark's InfinityA / InfinityB ([]bool, HOST pointers, n_wires bytes) or NULL */
     size_t nb_infinity_a, nb_infinity_b;    /* gnark's NbInfinityA / NbInfinityB; must equal the number of non-zero bytes */
-    int table_window_bits;                  /* 0: planner's choice; else the window width c in [8, 22] of the tables */
+    int table_window_bits;                  /* 0: planner's choice; else the window width c in [8, 24] of the tables */
     int device_mask;                        /* several GPUs in ONE process: bit i = device entry i holds a range slice of the key (2, 4 or 8 entries);
                                                0 = the process default.  zk_bn254_groth16_prove on such a key runs computeH block-sharded over the
                                                entries and the five MSMs per slice; same proof bytes. */
@@ -240,7 +240,7 @@ int zk_bn254_groth16_pk_free(uint64_t handle);   /* ZK_ERR_HANDLE while an msm5 
 int zk_bn254_groth16_pk_info(uint64_t handle, size_t *n_wires, size_t *n_public, uint32_t *log_domain, int *has_tables);
 /* Window tables for a resident key that was loaded without them (flags bit 0): what a caller does once a key turns out to be used again -- the export path
  * (zk_groth16_prove_with_pk) reads a key text without tables for its first proof and builds them when the second is asked for.  table_window_bits: 0 = the
- * planner's choice, else [8, 22].  A key that has its tables already, or whose tables do not fit, is left as it is: *built (optional) = 1 / 0. */
+ * planner's choice, else [8, 24].  A key that has its tables already, or whose tables do not fit, is left as it is: *built (optional) = 1 / 0. */
 int zk_bn254_groth16_pk_build_tables(uint64_t handle, int table_window_bits, int *built);
 /* HBM held by a resident Groth16 key (the base arrays it owns + its window tables) */
 int zk_bn254_groth16_pk_bytes(uint64_t handle, size_t *bytes);

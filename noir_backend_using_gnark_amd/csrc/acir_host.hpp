@@ -1008,68 +1008,127 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
                 if (badc < 0 || HFr::geq_mod(t)) { *err = "felt vector: invalid hex character or fr.Element encoding"; return ZK_ERR_ARG; }
                 wv.push_back(HFr{{t[0], t[1], t[2], t[3]}}.to_mont());
             }
-    // the coefficients were read as canonical values: Montgomery images now (threads; 0 / 1 / -1 without a product)
-    {
-        std::vector<HFr> cs;
-        cs.reserve(muls.size() + adds.size() + gates.size());
-        for (auto& t : muls) cs.push_back(t.ok ? t.c : HFr::zero());
-        for (auto& t : adds) cs.push_back(t.ok ? t.c : HFr::zero());
-        for (auto& g : gates) cs.push_back(g.k_ok ? g.k : HFr::zero());
-        to_mont_bulk(cs.data(), cs.size());
-        size_t at = 0;
-        for (auto& t : muls) t.c = cs[at++];
-        for (auto& t : adds) t.c = cs[at++];
-        for (auto& g : gates) g.k = cs[at++];
-    }
-    for (int m = 0; m < 3; m++) { B->ptr[m].assign(1, 0); B->idx[m].clear(); B->val[m].clear(); }
-    B->prod_a.clear();
-    B->prod_b.clear();
-    {
-        const size_t rows = muls.size() + gates.size();
-        for (int m = 0; m < 3; m++) B->ptr[m].reserve(rows + 1);
-        B->idx[0].reserve(rows); B->val[0].reserve(rows);
-        B->idx[1].reserve(muls.size() * 2 + adds.size() + gates.size()); B->val[1].reserve(muls.size() * 2 + adds.size() + gates.size());
-        B->idx[2].reserve(muls.size()); B->val[2].reserve(muls.size());
-        B->prod_a.reserve(muls.size()); B->prod_b.reserve(muls.size());
-    }
-    auto end_row = [&]() { for (int m = 0; m < 3; m++) B->ptr[m].push_back((uint32_t)B->idx[m].size()); };
+    // From here on the gates are independent: the coefficients' Montgomery images, the rows and the solver's step run over stretches of the gate list on up to
+    // sixteen threads -- a counting pass (rows, entries and product variables per stretch; the first malformed gate IN TEXT ORDER is the error, as in a loop over
+    // all gates), then every stretch writes its rows where the counts say they go.  L has one entry per row (the multiplicand / ONE), O one per product row.
+    const size_t G = gates.size();
+    unsigned nt2 = (nt > 1 && (G >= 4096 || acir_detail::parallel_cfg().min_bytes == 0)) ? nt : 1;  // (min_bytes == 0: the mutation harness forces the threaded paths on short texts)
+    struct Stretch {
+        size_t g0 = 0, g1 = 0, rows = 0, nnz1 = 0, prods = 0;
+        const char* bad = nullptr;
+    };
+    std::vector<Stretch> st(nt2);
+    for (unsigned k = 0; k < nt2; k++) { st[k].g0 = G * k / nt2; st[k].g1 = G * (k + 1) / nt2; }
     const HFr one = HFr::one();
-    std::vector<std::pair<uint32_t, HFr>> terms;
-    for (const Gate& g : gates) {
-        if (!g.shape_ok) { *err = "RawR1CS JSON: malformed gate"; return ZK_ERR_ARG; }
+    static const HFr minus_one = HFr::zero() - HFr::one();
+    static const uint64_t RM1[4] = {HFrParams::MOD[0] - 1, HFrParams::MOD[1], HFrParams::MOD[2], HFrParams::MOD[3]};
+    auto mont = [&](HFr& v) {  // canonical -> Montgomery; circuits are mostly 0 / 1 / -1: those skip the product (to_mont_bulk's rule)
+        uint64_t* l = v.l;
+        if (!(l[1] | l[2] | l[3]) && l[0] <= 1) { if (l[0]) v = one; return; }
+        if (l[0] == RM1[0] && l[1] == RM1[1] && l[2] == RM1[2] && l[3] == RM1[3]) { v = minus_one; return; }
+        v = v.to_mont();
+    };
+    // one gate: its terms (equal wires merged, in order of first appearance).  Returns the first thing wrong with it, or null.
+    typedef std::vector<std::pair<uint32_t, HFr>> Terms;
+    auto gate_terms = [&](const Gate& g, size_t prod0, Terms& terms, size_t* n_prods) -> const char* {
+        if (!g.shape_ok) return "RawR1CS JSON: malformed gate";
         terms.clear();
         auto add_term = [&](uint32_t x, const HFr& c) {
             for (auto& t : terms)
                 if (t.first == x) { t.second = t.second + c; return; }
             terms.emplace_back(x, c);
         };
-        {
-            for (size_t i = g.m0; i < g.m1; i++) {
-                const MulT& t = muls[i];
-                if (!t.ok || t.a < 1 || t.a > n || t.b < 1 || t.b > n) { *err = "RawR1CS JSON: malformed mul term"; return ZK_ERR_ARG; }
-                if (t.c.is_zero()) continue;
-                const uint32_t a = wire[t.a], b = wire[t.b], p = (uint32_t)(1 + n + B->prod_a.size());
-                B->prod_a.push_back(a);
-                B->prod_b.push_back(b);
-                if (want_wires) wv.push_back(wv[a] * wv[b]);  // the solver's step for this internal variable
-                B->idx[0].push_back(a); B->val[0].push_back(one);
-                B->idx[1].push_back(b); B->val[1].push_back(one);
-                B->idx[2].push_back(p); B->val[2].push_back(one);
-                end_row();
-                add_term(p, t.c);
-            }
-            for (size_t i = g.a0; i < g.a1; i++) {
-                const AddT& t = adds[i];
-                if (!t.ok || t.x < 1 || t.x > n) { *err = "RawR1CS JSON: malformed add term"; return ZK_ERR_ARG; }
-                add_term(wire[t.x], t.c);
+        size_t np = 0;
+        for (size_t i = g.m0; i < g.m1; i++) {
+            const MulT& t = muls[i];
+            if (!t.ok || t.a < 1 || t.a > n || t.b < 1 || t.b > n) return "RawR1CS JSON: malformed mul term";
+            if (t.c.is_zero()) continue;
+            add_term((uint32_t)(1 + n + prod0 + np), t.c);
+            np++;
+        }
+        for (size_t i = g.a0; i < g.a1; i++) {
+            const AddT& t = adds[i];
+            if (!t.ok || t.x < 1 || t.x > n) return "RawR1CS JSON: malformed add term";
+            add_term(wire[t.x], t.c);
+        }
+        if (!g.k_ok) return "RawR1CS JSON: malformed constant term";
+        if (!g.k.is_zero()) add_term(0, g.k);
+        *n_prods = np;
+        return nullptr;
+    };
+    auto count = [&](unsigned k) {
+        Stretch& S = st[k];
+        Terms terms;
+        for (size_t gi = S.g0; gi < S.g1; gi++) {
+            Gate& g = gates[gi];
+            for (size_t i = g.m0; i < g.m1; i++) if (muls[i].ok) mont(muls[i].c);
+            for (size_t i = g.a0; i < g.a1; i++) if (adds[i].ok) mont(adds[i].c);
+            if (g.k_ok) mont(g.k);
+            size_t np = 0;
+            if (const char* e = gate_terms(g, 0, terms, &np)) { S.bad = e; return; }
+            S.prods += np;
+            S.rows += np + 1;
+            S.nnz1 += np + terms.size();
+        }
+    };
+    auto on_threads = [&](const std::function<void(unsigned)>& f) {
+        if (nt2 == 1) { f(0); return; }
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt2; k++) {
+            try {
+                th.emplace_back(f, k);
+            } catch (const std::system_error&) {
+                f(k);
             }
         }
-        if (!g.k_ok) { *err = "RawR1CS JSON: malformed constant term"; return ZK_ERR_ARG; }
-        if (!g.k.is_zero()) add_term(0, g.k);
-        B->idx[0].push_back(0); B->val[0].push_back(one);
-        for (auto& t : terms) { B->idx[1].push_back(t.first); B->val[1].push_back(t.second); }
-        end_row();
-    }
+        f(0);
+        for (auto& t : th) t.join();
+    };
+    on_threads(count);
+    for (unsigned k = 0; k < nt2; k++)
+        if (st[k].bad) { *err = st[k].bad; return ZK_ERR_ARG; }
+    size_t rows = 0, nnz1 = 0, prods = 0;
+    std::vector<size_t> row0(nt2), nz0(nt2), pr0(nt2);
+    for (unsigned k = 0; k < nt2; k++) { row0[k] = rows; nz0[k] = nnz1; pr0[k] = prods; rows += st[k].rows; nnz1 += st[k].nnz1; prods += st[k].prods; }
+    if (rows >= ((size_t)1 << 31) || nnz1 >= ((size_t)1 << 31) || 1 + n + prods >= ((size_t)1 << 31)) { *err = "RawR1CS JSON: too many constraints for 31-bit indices"; return ZK_ERR_ARG; }
+    for (int m = 0; m < 3; m++) B->ptr[m].assign(rows + 1, 0);
+    B->idx[0].assign(rows, 0); B->val[0].assign(rows, one);
+    B->idx[1].resize(nnz1); B->val[1].resize(nnz1);
+    B->idx[2].resize(prods); B->val[2].assign(prods, one);
+    B->prod_a.resize(prods);
+    B->prod_b.resize(prods);
+    if (want_wires) wv.resize(1 + n + prods);
+    auto fill = [&](unsigned k) {
+        const Stretch& S = st[k];
+        Terms terms;
+        size_t r = row0[k], z = nz0[k], p = pr0[k];
+        for (size_t gi = S.g0; gi < S.g1; gi++) {
+            const Gate& g = gates[gi];
+            size_t np = 0;
+            (void)gate_terms(g, p, terms, &np);
+            for (size_t i = g.m0; i < g.m1; i++) {  // one product constraint per mul term with a non-zero coefficient: (1 * a) * (1 * b) = 1 * p
+                const MulT& t = muls[i];
+                if (t.c.is_zero()) continue;
+                const uint32_t a = wire[t.a], b = wire[t.b];
+                B->prod_a[p] = a;
+                B->prod_b[p] = b;
+                if (want_wires) wv[1 + n + p] = wv[a] * wv[b];  // the solver's step for this internal variable (operands are witness wires)
+                B->idx[0][r] = a;
+                B->idx[1][z] = b; B->val[1][z] = one;
+                B->idx[2][p] = (uint32_t)(1 + n + p);
+                z++; p++; r++;
+                B->ptr[1][r] = (uint32_t)z;
+                B->ptr[2][r] = (uint32_t)p;
+            }
+            // the gate's sum constraint: (1 * ONE) * (sum of terms) = 0
+            for (auto& t : terms) { B->idx[1][z] = t.first; B->val[1][z] = t.second; z++; }
+            r++;
+            B->ptr[1][r] = (uint32_t)z;
+            B->ptr[2][r] = (uint32_t)p;
+        }
+    };
+    on_threads(fill);
+    for (size_t i = 0; i <= rows; i++) B->ptr[0][i] = (uint32_t)i;
     B->n_public = npub;
     return ZK_OK;
 }
@@ -1077,43 +1136,62 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
 // ------------------------------------------------------------------------------------------------ content keys
 // 128-bit content key of a text (the caches of decoded keys and lowered circuits are keyed by it): four independent multiply-rotate lanes per
 // 64 KB segment, segments hashed on up to 16 threads (a proving key is 0.3 GB of hex text: one core reads it in 50 ms, sixteen in 5), the
-// segment digests folded in order.  Not a cryptographic hash: a caller who forges a collision only obtains a proof under the wrong one of his own keys.
+// segment digests folded in order.  Not a cryptographic hash, so two things keep a caller from steering it (round 4's advisor: with fixed constants a 32-byte
+// block equal to one of them zeroed all four lanes -- an absorbing state -- and a long-lived process serving several parties could be fed a text that collides
+// with another party's circuit, which on the verify path selects WHICH values count as public inputs):
+//   * the two multiplier masks are drawn per PROCESS from the OS generator (content keys never leave the process and are never compared across processes), so
+//     a text cannot be aimed at them;
+//   * a step adds its input state back after the multiplication: a zero product leaves the state it came from, not zero -- nothing is absorbing.
 struct ContentKey {
     uint64_t h[2] = {0, 0};
     uint64_t len = 0;
     bool operator<(const ContentKey& o) const { return h[0] != o.h[0] ? h[0] < o.h[0] : h[1] != o.h[1] ? h[1] < o.h[1] : len < o.len; }
     bool operator==(const ContentKey& o) const { return h[0] == o.h[0] && h[1] == o.h[1] && len == o.len; }
 };
-static inline uint64_t ck_mix(uint64_t a, uint64_t b) {
-    const unsigned __int128 m = (unsigned __int128)(a ^ 0x9e3779b97f4a7c15ULL) * (b ^ 0xd1b54a32d192ed03ULL);
-    return (uint64_t)m ^ (uint64_t)(m >> 64);
+struct CkMasks { uint64_t a, b; };
+static inline const CkMasks& ck_masks() {
+    static const CkMasks m = [] {
+        CkMasks k{0x9e3779b97f4a7c15ULL, 0xd1b54a32d192ed03ULL};
+        uint64_t r[2] = {0, 0};
+        if (FILE* f = fopen("/dev/urandom", "rb")) {
+            if (fread(r, 1, sizeof r, f) == sizeof r) { k.a ^= r[0]; k.b ^= r[1]; }
+            fclose(f);
+        }
+        return k;
+    }();
+    return m;
 }
-static inline void ck_segment(const char* p, size_t n, uint64_t seed, uint64_t out[2]) {
+static inline uint64_t ck_mix(uint64_t a, uint64_t b, const CkMasks& k) {
+    const unsigned __int128 m = (unsigned __int128)(a ^ k.a) * (b ^ k.b);
+    return ((uint64_t)m ^ (uint64_t)(m >> 64)) + ((a << 23) | (a >> 41));
+}
+static inline void ck_segment(const char* p, size_t n, uint64_t seed, uint64_t out[2], const CkMasks k) {
     uint64_t s[4] = {seed ^ 0x243f6a8885a308d3ULL, seed ^ 0x13198a2e03707344ULL, seed ^ 0xa4093822299f31d0ULL, seed ^ 0x082efa98ec4e6c89ULL};
     size_t i = 0;
     for (; i + 32 <= n; i += 32) {
         uint64_t w[4];
         memcpy(w, p + i, 32);
-        s[0] = ck_mix(s[0], w[0]);
-        s[1] = ck_mix(s[1], w[1]);
-        s[2] = ck_mix(s[2], w[2]);
-        s[3] = ck_mix(s[3], w[3]);
+        s[0] = ck_mix(s[0], w[0], k);
+        s[1] = ck_mix(s[1], w[1], k);
+        s[2] = ck_mix(s[2], w[2], k);
+        s[3] = ck_mix(s[3], w[3], k);
     }
     uint64_t w[4] = {0, 0, 0, 0};
     memcpy(w, p + i, n - i);
-    s[0] = ck_mix(s[0], w[0] ^ n);
-    s[1] = ck_mix(s[1], w[1]);
-    s[2] = ck_mix(s[2], w[2]);
-    s[3] = ck_mix(s[3], w[3] ^ (n << 32));
-    out[0] = ck_mix(s[0], s[2]);
-    out[1] = ck_mix(s[1], s[3]);
+    s[0] = ck_mix(s[0], w[0] ^ n, k);
+    s[1] = ck_mix(s[1], w[1], k);
+    s[2] = ck_mix(s[2], w[2], k);
+    s[3] = ck_mix(s[3], w[3] ^ (n << 32), k);
+    out[0] = ck_mix(s[0], s[2], k);
+    out[1] = ck_mix(s[1], s[3], k);
 }
 static inline ContentKey content_key(const char* p, size_t n) {
     const size_t SEG = (size_t)1 << 16;
     const size_t nseg = (n + SEG - 1) / SEG;
     std::vector<uint64_t> d(2 * (nseg ? nseg : 1), 0);
+    const CkMasks masks = ck_masks();
     auto run = [&](size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; k++) ck_segment(p + k * SEG, k + 1 == nseg ? n - k * SEG : SEG, k, &d[2 * k]);
+        for (size_t k = lo; k < hi; k++) ck_segment(p + k * SEG, k + 1 == nseg ? n - k * SEG : SEG, k, &d[2 * k], masks);
     };
     unsigned nt = nseg < 64 ? 1 : std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
@@ -1126,12 +1204,12 @@ static inline ContentKey content_key(const char* p, size_t n) {
     ContentKey K;
     K.len = n;
     uint64_t a = 0x452821e638d01377ULL, b = 0xbe5466cf34e90c6cULL;
-    for (size_t k = 0; k < nseg; k++) {
-        a = ck_mix(a, d[2 * k]) + d[2 * k + 1];
-        b = ck_mix(b, d[2 * k + 1]) ^ a;
+    for (size_t j = 0; j < nseg; j++) {
+        a = ck_mix(a, d[2 * j], masks) + d[2 * j + 1];
+        b = ck_mix(b, d[2 * j + 1], masks) ^ a;
     }
-    K.h[0] = ck_mix(a, n);
-    K.h[1] = ck_mix(b, ~(uint64_t)n);
+    K.h[0] = ck_mix(a, n, masks);
+    K.h[1] = ck_mix(b, ~(uint64_t)n, masks);
     return K;
 }
 

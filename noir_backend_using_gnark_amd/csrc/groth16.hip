@@ -72,10 +72,12 @@ struct Groth16PK {
     // precomputed window tables T[w][i] = 2^(c*w) * P_i for the five base arrays (resident; built once at load time):
     // every window of an MSM then shares one bucket set -- ceil(255/c) * n mixed additions with c ~ 20 instead of 16 windows
     // of c = 16, one bucket reduction instead of 16, no Horner.  The K table uses wire indexing (first n_public rows = infinity).
+    unsigned proofs = 0;    // proofs asked of this key so far (pk_note_proof)
     bool tables = false;
     MsmTable tab_w, tab_h;
     void *t_a = nullptr, *t_b = nullptr, *t_k = nullptr, *t_z = nullptr, *t_b2 = nullptr;
 };
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static std::mutex g_pk_mu;
 static std::map<uint64_t, Groth16PK> g_pks;
 static uint64_t g_next_pk = 1;
@@ -189,8 +191,8 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     if (!pk->g1_alpha || !pk->g1_beta || !pk->g1_delta || !pk->g2_beta || !pk->g2_delta) return set_err(ZK_ERR_ARG, "null pk element");
     if ((pk->infinity_a == nullptr) != (pk->infinity_b == nullptr)) return set_err(ZK_ERR_ARG, "InfinityA and InfinityB must be given together");
     if (!pk->infinity_a && (pk->nb_infinity_a || pk->nb_infinity_b)) return set_err(ZK_ERR_ARG, "NbInfinityA/B without the bitmaps");
-    if (pk->table_window_bits && (pk->table_window_bits < 8 || pk->table_window_bits > 22))
-        return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", pk->table_window_bits);
+    if (pk->table_window_bits && (pk->table_window_bits < 8 || pk->table_window_bits > 24))
+        return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 24]", pk->table_window_bits);
     const bool compact = pk->infinity_a != nullptr;
     const bool win_shard = (pk->flags & 4) != 0;
     if (win_shard && (pk->shard_count < 1 || pk->shard_count > 64 || pk->shard_rank >= pk->shard_count)) return set_err(ZK_ERR_ARG, "bad window-shard rank / count");
@@ -212,10 +214,8 @@ int zk_bn254_groth16_pk_load(const zk_groth16_pk* pk, uint64_t* handle) {
     memcpy(&P.delta, pk->g1_delta, 64);
     memcpy(&P.beta2, pk->g2_beta, 128);
     memcpy(&P.delta2, pk->g2_delta, 128);
-    P.fb_delta = std::make_shared<FixedBase<HFp>>();
-    P.fb_delta->build(P.delta);
-    P.fb_delta2 = std::make_shared<FixedBase<HFp2>>();
-    P.fb_delta2->build(P.delta2);
+    // (the 8-bit window tables of delta / delta2 for the host tail are NOT built here: 8-17 ms of one host core, which a process that makes one proof -- the
+    // reference's use: nargo loads the library, proves once and exits -- never earns back at 0.3 ms per proof; pk_note_proof builds them at a key's second proof)
     const size_t N = (size_t)1 << pk->log_domain, nw = pk->n_wires, nk = pk->n_wires - pk->n_public;
     const size_t na = compact ? nw - pk->nb_infinity_a : nw, nbb = compact ? nw - pk->nb_infinity_b : nw;  // entries the caller's A / B arrays hold
     P.nz = (pk->flags & 2) ? N : N - 1;
@@ -306,7 +306,7 @@ int zk_bn254_groth16_pk_build_tables(uint64_t handle, int table_window_bits, int
     if (built) *built = 0;
     if (md_is_composite(handle)) return set_err(ZK_ERR_ARG, "a key spread over several device entries gets its tables at load time");
     ZK_ON_ENTRY_OF(handle);
-    if (table_window_bits && (table_window_bits < 8 || table_window_bits > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_window_bits);
+    if (table_window_bits && (table_window_bits < 8 || table_window_bits > 24)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 24]", table_window_bits);
     Groth16PK P;
     {
         std::lock_guard<std::mutex> lk(g_pk_mu);
@@ -600,6 +600,30 @@ static int lookup_pk(uint64_t h, Groth16PK* P) {
     *P = it->second;
     return ZK_OK;
 }
+// Called once per proof, just before the host tail: from the key's SECOND proof on the tail multiplies delta / delta2 through 8-bit window tables (FixedBase:
+// built here, once, 8-17 ms of one host core -- in the single-GPU prover that is under the GPU work the call has just enqueued).
+static int pk_tables_for_tail(uint64_t h, Groth16PK* P) {
+    bool build = false;
+    {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        auto it = g_pks.find(h);
+        if (it == g_pks.end()) return set_err(ZK_ERR_HANDLE, "unknown proving-key handle %llu", (unsigned long long)h);
+        build = ++it->second.proofs >= 2 && !it->second.fb_delta;
+        P->fb_delta = it->second.fb_delta;
+        P->fb_delta2 = it->second.fb_delta2;
+    }
+    if (!build) return ZK_OK;
+    auto f1 = std::make_shared<FixedBase<HFp>>();
+    auto f2 = std::make_shared<FixedBase<HFp2>>();
+    f1->build(P->delta);
+    f2->build(P->delta2);
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(h);
+    if (it != g_pks.end() && !it->second.fb_delta) { it->second.fb_delta = f1; it->second.fb_delta2 = f2; }
+    P->fb_delta = f1;
+    P->fb_delta2 = f2;
+    return ZK_OK;
+}
 
 // host tail of groth16.Prove.  The four scalar multiplications that do not depend on the MSM results
 // (r*delta, s*delta, s*delta2, rs*delta) are computed while the GPU is still busy (tail_pre); what is left afterwards
@@ -611,7 +635,6 @@ struct TailPre {
     bool have_early = false;  // s*(A + alpha) and r*(B1 + beta) already computed (single-GPU prove: under the K / Z accumulates)
     XYZZ<HFp> s_aalpha, r_bbeta;
 };
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static void tail_early(const Groth16PK& P, TailPre* T, const XYZZ<HFp>& m_a, const XYZZ<HFp>& m_b) {
     const double t0 = now_ms();
     XYZZ<HFp> a_alpha = m_a, b_beta = m_b;
@@ -632,10 +655,17 @@ static void tail_pre(const Groth16PK& P, const zk_fr* r_, const zk_fr* s_, TailP
     to_canonical_u32(r, T->rk);
     to_canonical_u32(s, T->sk);
     to_canonical_u32(rs, rsk);
-    T->r_delta = P.fb_delta->mul(T->rk);
-    T->s_delta = P.fb_delta->mul(T->sk);
-    T->rs_delta = P.fb_delta->mul(rsk);
-    T->s_delta2 = P.fb_delta2->mul(T->sk);
+    if (P.fb_delta && P.fb_delta2) {
+        T->r_delta = P.fb_delta->mul(T->rk);
+        T->s_delta = P.fb_delta->mul(T->sk);
+        T->rs_delta = P.fb_delta->mul(rsk);
+        T->s_delta2 = P.fb_delta2->mul(T->sk);
+    } else {  // a key's first proof: plain double-and-add (0.36 ms instead of 0.05; hidden under the GPU's work in the single-GPU prover)
+        T->r_delta = scalar_mul(P.delta, T->rk);
+        T->s_delta = scalar_mul(P.delta, T->sk);
+        T->rs_delta = scalar_mul(P.delta, rsk);
+        T->s_delta2 = scalar_mul(P.delta2, T->sk);
+    }
     prof_host("host_tail_pre", now_ms() - t0);
 }
 static void tail_post(const Groth16PK& P, const TailPre& T, const uint64_t* parts, size_t n_parts, uint8_t proof_out[128]) {
@@ -826,6 +856,7 @@ int zk_bn254_groth16_finalize(uint64_t pk_handle, const uint64_t* partials, size
     if (!partials || !n_partials || !r || !s || !proof_out) return set_err(ZK_ERR_ARG, "null pointer");
     Groth16PK P;
     ZK_TRY(lookup_pk(pk_handle, &P));
+    ZK_TRY(pk_tables_for_tail(pk_handle, &P));
     finalize(P, partials, n_partials, r, s, proof_out);
     return ZK_OK;
 }
@@ -956,6 +987,7 @@ int zk_bn254_groth16_prove(uint64_t pk_handle, const void* a, const void* b, con
     if (ev_h) (void)hipEventDestroy(ev_h);
     uint64_t parts[96];
     TailPre T;
+    if (rc == ZK_OK) rc = pk_tables_for_tail(pk_handle, &P);
     if (rc == ZK_OK) tail_pre(P, r_, s_, &T);  // host work hidden under the GPU's
     const std::function<void(const XYZZ<HFp>&, const XYZZ<HFp>&)> early = [&](const XYZZ<HFp>& ma, const XYZZ<HFp>& mb) { tail_early(P, &T, ma, mb); };
     if (rc == ZK_OK) rc = msm5_finish(&S, parts, &early);

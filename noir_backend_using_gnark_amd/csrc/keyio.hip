@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "ctx.hpp"
@@ -143,31 +144,29 @@ __global__ void k_g1_compress(const Affine<Fp>* __restrict__ pts, size_t n, uint
 
 
 // ---- G2 points on the device (a Groth16 proving key holds one per wire)
-__device__ __forceinline__ Fp2 f2_pow_dev(Fp2 a, const uint32_t e[8]) {
-    Fp2 r = Fp2::one();
-    for (int i = 0; i < 254; i++) {
-        if ((e[i >> 5] >> (i & 31)) & 1) r = r * a;
-        a = a.sqr();
-    }
-    return r;
-}
-// square root in Fp2 = Fp[u]/(u^2 + 1), q = 3 mod 4 (Adj & Rodriguez-Henriquez, Alg. 9): two 254-bit exponentiations
-__device__ bool f2_sqrt_dev(const Fp2& a, Fp2* out) {
+// Square root in Fp2 = Fp[u]/(u^2 + 1), q = 3 mod 4, by the complex method -- two exponentiations in Fp instead of the two in Fp2 of rounds 2-4 (Adj &
+// Rodriguez-Henriquez, Alg. 9: 1,778 base-field products per root; this: ~770).  For a = a0 + a1 u with a1 != 0: the norm n = a0^2 + a1^2 is a square in Fp
+// exactly when a is one in Fp2; with s^2 = n and t = (a0 + s) / 2, one exponentiation e = t^((q-3)/4) gives c = e t with c^2 = chi t (chi = +-1 the quadratic
+// character of t) AND 1 / c = c e^2 -- no inversion --, and the root is (c, a1 / 2c) if chi = 1, (a1 / 2c, c) otherwise (then c^2 = -t = -(a0 + s) / 2 and
+// (a1 / 2c)^2 = (a0 - s) / 2).  Either root will do: the caller picks the sign by the encoding's flag.  `half` = 1 / 2 (Montgomery).
+__device__ bool f2_sqrt_dev(const Fp2& a, const Fp& half, Fp2* out) {
     if (a.is_zero()) { *out = a; return true; }
     const uint32_t E1[8] = {0xb61f3f51u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};  // (q - 3) / 4
-    const uint32_t E2[8] = {0x6c3e7ea3u, 0x9e10460bu, 0xb438e546u, 0xcbc0b548u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};  // (q - 1) / 2
-    const Fp2 minus_one = Fp2{Fp::zero() - Fp::one(), Fp::zero()};
-    Fp2 a1 = f2_pow_dev(a, E1);
-    Fp2 alpha = a1 * (a1 * a);
-    Fp2 a0 = Fp2{alpha.a0, alpha.a1.neg()} * alpha;
-    if (a0 == minus_one) return false;
-    Fp2 x0 = a1 * a;
-    if (alpha == minus_one) {
-        *out = Fp2{Fp::zero(), Fp::one()} * x0;
-    } else {
-        Fp2 b = f2_pow_dev(Fp2::one() + alpha, E2);
-        *out = b * x0;
+    if (a.a1.is_zero()) {  // a in Fp: sqrt(a0) or u sqrt(-a0)
+        const Fp c = a.a0.pow(E1) * a.a0;
+        if (c.sqr() == a.a0) *out = Fp2{c, Fp::zero()};
+        else *out = Fp2{Fp::zero(), c};
+        return out->sqr() == a;
     }
+    const Fp n = a.a0.sqr() + a.a1.sqr();
+    const Fp s = n.pow(E1) * n;
+    if (s.sqr() != n) return false;  // the norm is not a square: neither is a
+    Fp t = (a.a0 + s) * half;
+    // (t = 0 would need a0 = -s, i.e. a1^2 = s^2 - a0^2 = 0: not on this branch)
+    const Fp e = t.pow(E1), c = e * t;
+    const Fp w = a.a1 * (c * e.sqr() * half);  // a1 / (2 c)
+    if (c.sqr() == t) *out = Fp2{c, w};
+    else *out = Fp2{w, c};
     return out->sqr() == a;
 }
 __device__ __forceinline__ bool f2_lex_largest_dev(const Fp2& y) {  // gnark-crypto: compares A1 first, A0 when A1 = 0
@@ -175,20 +174,34 @@ __device__ __forceinline__ bool f2_lex_largest_dev(const Fp2& y) {  // gnark-cry
 }
 // G2Affine.SetBytes on a compressed encoding (X.A1 | X.A0 big-endian, flags on the first byte) with the subgroup check the gnark-crypto Decoder
 // applies by default (r * P = infinity: the twist has a cofactor).  bt = 3 / (9 + u), Montgomery.
-// r-torsion membership on the twist as gnark-crypto tests it (G2Jac.IsInSubGroup): psi(P) == [6 x0^2] P, where psi is the untwist-Frobenius-twist
-// endomorphism (x, y) -> (conj(x) * gx, conj(y) * gy), gx = xi^((q-1)/3), gy = xi^((q-1)/2), xi = 9 + u, which acts on G2 as multiplication by
-// q = t - 1 = 6 x0^2 (mod r); x0 = 4965661367192848881.  A 127-bit scalar multiplication instead of the 254 bits of r * P.
-struct PsiConsts { Fp2 gx, gy; };
+// r-torsion membership on the twist, with the untwist-Frobenius-twist endomorphism psi: (x, y) -> (conj(x) * gx, conj(y) * gy), gx = xi^((q-1)/3),
+// gy = xi^((q-1)/2), xi = 9 + u, which acts on G2 as multiplication by q = 6 x0^2 (mod r); x0 = 4965661367192848881.  Two exact tests (both accept exactly
+// the points r * P = infinity accepts; tests/test_gpu_keyio.py holds twist points outside G2 and a G2 point shifted by a cofactor-torsion point):
+//   psi(P) == [6 x0^2] P                                       127 doublings + 64 additions     (rounds 2-4)
+//   [x0 + 1] P + psi([x0] P) + psi^2([x0] P) == psi^3([2 x0] P)  63 doublings + 27 + 4 additions  (eprint 2022/348 sec. 5.1 for BN curves; gnark-crypto's
+//                                                               G2Jac.IsInSubGroup): ONE multiplication by the 63-bit x0, three psi, a few additions -- half
+//                                                               the work of a decompression's larger half (68 -> see DESIGN.md 3.8 per 2^20 points)
+struct PsiConsts { Fp2 gx, gy; Fp half; };  // psi's two coefficients; 1 / 2 for the square root
+__device__ __forceinline__ XYZZ<Fp2> g2_psi_dev(const XYZZ<Fp2>& t, const PsiConsts& K) {  // on x = X / ZZ, y = Y / ZZZ: conjugate everything, scale X and Y
+    return XYZZ<Fp2>{Fp2{t.x.a0, t.x.a1.neg()} * K.gx, Fp2{t.y.a0, t.y.a1.neg()} * K.gy, Fp2{t.zz.a0, t.zz.a1.neg()}, Fp2{t.zzz.a0, t.zzz.a1.neg()}};
+}
 __device__ __forceinline__ bool g2_in_subgroup_dev(const Affine<Fp2>& p, const PsiConsts& K) {
-    const uint32_t k6x2[8] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u, 0, 0, 0, 0};  // 6 x0^2 = 147946756881789318990833708069417712966
-    XYZZ<Fp2> rp = XYZZ<Fp2>::inf();
-    for (int i = 126; i >= 0; i--) {
-        rp.dbl();
-        if ((k6x2[i >> 5] >> (i & 31)) & 1) rp.madd(p);
+    const uint32_t x0[2] = {0x4a6909f1u, 0x44e992b4u};  // 4965661367192848881
+    XYZZ<Fp2> a = XYZZ<Fp2>::inf();
+    for (int i = 62; i >= 0; i--) {
+        a.dbl();
+        if ((x0[i >> 5] >> (i & 31)) & 1) a.madd(p);
     }
-    if (rp.is_inf()) return false;
-    const Fp2 px = Fp2{p.x.a0, p.x.a1.neg()} * K.gx, py = Fp2{p.y.a0, p.y.a1.neg()} * K.gy;
-    return rp.x == px * rp.zz && rp.y == py * rp.zzz;
+    const XYZZ<Fp2> b = g2_psi_dev(a, K);   // psi([x0] P)
+    const XYZZ<Fp2> c = g2_psi_dev(b, K);   // psi^2([x0] P)
+    XYZZ<Fp2> d = g2_psi_dev(c, K);         // psi^3([x0] P)
+    d.dbl();                                // psi^3([2 x0] P)
+    a.madd(p);                              // [x0 + 1] P
+    XYZZ<Fp2> lhs = c;
+    lhs.add(b);
+    lhs.add(a);
+    if (lhs.is_inf() || d.is_inf()) return lhs.is_inf() && d.is_inf();
+    return lhs.x * d.zz == d.x * lhs.zz && lhs.y * d.zzz == d.y * lhs.zzz;
 }
 __global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restrict__ raw, size_t n, Fp2 bt, PsiConsts psi, int full_check, Affine<Fp2>* __restrict__ out,
                                                        int* __restrict__ status) {
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restric
     }
     Fp2 x{x0.to_mont(), x1.to_mont()};
     Fp2 rhs = x.sqr() * x + bt, y;
-    if (!f2_sqrt_dev(rhs, &y)) {
+    if (!f2_sqrt_dev(rhs, psi.half, &y)) {
         atomicOr(status, 8);
         out[i] = p;
         return;
@@ -312,6 +325,8 @@ int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void
     PsiConsts psi;
     memcpy(&psi.gx, &gx, sizeof gx);
     memcpy(&psi.gy, &gy, sizeof gy);
+    const HFp half = (HFp::one() + HFp::one()).inv();
+    memcpy(&psi.half, &half, sizeof half);
     static const int full = ZK_EXP("ZKMI_G2_FULL_SUBGROUP_CHECK", 0);
     if (n) ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, psi, full, (Affine<Fp2>*)d_out, d_status);
     return ZK_OK;
@@ -557,12 +572,21 @@ struct DevFree {
 int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags, int table_window_bits, uint64_t* handle) {
     if (!data || !handle) return set_err(ZK_ERR_ARG, "null pointer");
     if (flags & ~1) return set_err(ZK_ERR_ARG, "only flag bit 0 (no window tables) applies to a key read from its wire format");
+    struct Lap {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        void lap(const char* name) {
+            const auto t1 = std::chrono::steady_clock::now();
+            prof_host(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        }
+    } lap;
     Groth16KeyHeader H;  // the section table, the counts and the two bitmaps: read and cross-checked on the host from the caller's bytes alone (text_host.hpp)
     {
         std::string e;
         const int rc = groth16_pk_header(data, len, is_hex, &H, &e);
         if (rc != ZK_OK) return set_err(rc, "%s", e.c_str());
     }
+    lap.lap("export.pk_read_header_host");
     const unsigned logN = H.logN;
     const size_t* cnt = H.cnt;
     const size_t* at = H.at;
@@ -580,6 +604,7 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     ZK_TRY(get_domain(s, st, logN, 0, &dom));
     domain_bytes(dom, dom_ok);
     if (memcmp(dom_in, dom_ok, 168)) return set_err(ZK_ERR_ARG, "proving key: the domain is not gnark-crypto's radix-2 domain of that size");
+    lap.lap("export.pk_read_header_domain");
     // everything up to the bitmaps goes to the device (a multiple of 4 bytes by construction)
     ZK_TRY(s->reserve((is_hex ? 2 * at_bm : 0) + at_bm + 4096));
     int* d_status = (int*)s->alloc(64);
@@ -592,6 +617,7 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     } else {
         ZK_HIP(hipMemcpyAsync(d_bytes, data, at_bm, hipMemcpyHostToDevice, st));
     }
+    if (profiling_on()) { ZK_TRY(slot_sync(s, st)); lap.lap("export.pk_read_upload_hex"); }
     DevFree tmp, own;  // tmp: the compact A / B / G2.B and the five single points; own: K and Z, adopted by the key
     void *d_a = nullptr, *d_b = nullptr, *d_b2 = nullptr, *d_k = nullptr, *d_z = nullptr, *d_single = nullptr;
     ZK_TRY(tmp.alloc(&d_a, cnt[0] * 64));
@@ -604,12 +630,14 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     ZK_TRY(g2_decompress_dev(s, st, d_bytes + at_g2, 2, (uint8_t*)d_single + 192, d_status));
     void* g1_dst[4] = {d_a, d_b, d_z, d_k};
     for (int k = 0; k < 4; k++) ZK_TRY(g1_decompress_dev(s, st, d_bytes + at[k], cnt[k], g1_dst[k], d_status));
+    if (profiling_on()) { ZK_TRY(slot_sync(s, st)); lap.lap("export.pk_read_g1_decompress"); }
     ZK_TRY(g2_decompress_dev(s, st, d_bytes + at[4], cnt[4], d_b2, d_status));
     uint8_t single[3 * 64 + 2 * 128];
     int h_status = 0;
     ZK_HIP(hipMemcpyAsync(single, d_single, sizeof single, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipMemcpyAsync(&h_status, d_status, 4, hipMemcpyDeviceToHost, st));
     ZK_TRY(slot_sync(s, st));
+    lap.lap("export.pk_read_g2_decompress");
     if (h_status & 1) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
     if (h_status & 4) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G1 point (bad flags, x >= q, or no square root)");
     if (h_status & 8) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G2 point (bad flags, coordinate >= q, or no square root)");
@@ -640,6 +668,7 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     pk.nb_infinity_b = nib;
     pk.table_window_bits = table_window_bits;
     ZK_TRY(zk_bn254_groth16_pk_load(&pk, handle));
+    lap.lap("export.pk_read_load");
     ZK_TRY(groth16_pk_adopt(*handle));  // K and Z were allocated here for the key; A / B / G2.B are its own expanded arrays already
     own.keep = true;
     return ZK_OK;

@@ -233,35 +233,58 @@ __device__ __forceinline__ void digits_of(const Fr* __restrict__ scalars, uint32
         wl++;
     }
 }
-__global__ void k_msm_digit_count(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, uint32_t table_stride, unsigned row_first, unsigned row_step,
-                                  uint32_t* __restrict__ cnt) {
+// One pass: a workgroup recodes its 256 scalars, ranks their non-zero digits with a scan over the workgroup, stages the pairs in LDS in that order, reserves
+// room for all of them with ONE atomic add on the global pair counter (one counter even for a batch of vectors: the bucket keys tell the vectors apart) and
+// copies them out with consecutive lanes writing consecutive pairs.  The workgroups land in whatever order their atomics arrive: a sort's input has no order
+// to keep.  (Round 5's earlier forms, both measured on the uniform 2^20 proof, whose scalar preparation is on the critical path beside computeH: count + scan
+// over all scalars + write = two passes and three launches more than k_msm_digits, +0.16 ms; one pass with every lane writing its own run of pairs to global
+// memory -- 52-byte strides between lanes -- still +0.14 ms: profiles/rnd5_d_*, rnd5_e_*.)  Dynamic LDS: 256 * W pairs of 8 bytes.
+__global__ __launch_bounds__(256) void k_msm_digits_compact(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step,
+                                                           uint32_t table_stride, uint32_t* __restrict__ total, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     prio_hi();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    extern __shared__ uint32_t stage[];  // [0, 256 W): keys, [256 W, 512 W): values
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t base;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned vec = blockIdx.y;
+    const uint32_t B = 1u << (c - 1), cap = 256u * W;
+    const bool live = i < n;
     uint32_t k = 0;
-    digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned, uint32_t mag, uint32_t) { k += mag != 0; });
-    cnt[(size_t)vec * n + i] = k;
-}
-__global__ void k_msm_digits_compact(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step, uint32_t table_stride,
-                                     const uint32_t* __restrict__ off, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    prio_hi();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned vec = blockIdx.y;
-    const uint32_t B = 1u << (c - 1);
-    uint32_t o = off[(size_t)vec * n + i];
-    digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned wl, uint32_t mag, uint32_t neg) {
-        if (!mag) return;
-        if (table_stride) {
-            keys[o] = vec * B + (mag - 1);
-            vals[o] = ((wl * table_stride + i) << 1) | neg;
-        } else {
-            keys[o] = wl * B + (mag - 1);
-            vals[o] = (i << 1) | neg;
-        }
-        o++;
-    });
+    if (live) digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned, uint32_t mag, uint32_t) { k += mag != 0; });
+    // exclusive scan of k over the workgroup: inside the wave by shuffles, across the four waves through LDS
+    uint32_t incl = k;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= (unsigned)d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (unsigned w2 = 0; w2 < wave; w2++) before += wsum[w2];
+    const uint32_t wg_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) base = wg_total ? atomicAdd(total, wg_total) : 0;
+    if (live && k) {
+        uint32_t o = before + incl - k;
+        digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned wl, uint32_t mag, uint32_t neg) {
+            if (!mag) return;
+            if (table_stride) {
+                stage[o] = vec * B + (mag - 1);
+                stage[cap + o] = ((wl * table_stride + i) << 1) | neg;
+            } else {
+                stage[o] = wl * B + (mag - 1);
+                stage[cap + o] = (i << 1) | neg;
+            }
+            o++;
+        });
+    }
+    __syncthreads();
+    const uint32_t g0 = base;
+    for (uint32_t j = threadIdx.x; j < wg_total; j += 256) {
+        keys[g0 + j] = stage[j];
+        vals[g0 + j] = stage[cap + j];
+    }
 }
 
 // ---------------------------------------------------------------------------------------- 3. bucket boundaries
@@ -965,7 +988,9 @@ static int msm_plan_uncached(size_t n, const zk_msm_cfg* cfg, hipStream_t st, Ms
     if (sets < 1 || sets > 3 || (sets > 1 && !tab)) return set_err(ZK_ERR_ARG, "a batch of %u scalar vectors needs a window table and at most three vectors", sets);
     if (n > ((size_t)1 << 27)) return set_err(ZK_ERR_ARG, "n = %zu exceeds the per-call limit 2^27 (shard the MSM)", n);
     unsigned c = tab ? tab->c : ((cfg && cfg->window_bits) ? (unsigned)cfg->window_bits : msm_pick_window(n));
-    if (c < 2 || c > 22) return set_err(ZK_ERR_ARG, "window_bits = %u outside [2, 22]", c);
+    // plain method: c <= 22 (one bucket set PER WINDOW: 12 x 2^21 partial sums already); against a window table all windows share one bucket set and c = 23, 24
+    // -- 11 digits per scalar instead of 12 at 2^24 points -- are admissible (round 5 measured them: DESIGN.md 8)
+    if (c < 2 || c > (tab ? 24u : 22u)) return set_err(ZK_ERR_ARG, "window_bits = %u outside [2, %u]", c, tab ? 24u : 22u);
     P->c = c;
     P->Wd = (255 + c - 1) / c;
     P->W = tab ? sets : P->Wd;  // bucket sets: one per window without a table, one per scalar vector with one
@@ -1072,18 +1097,14 @@ static int msm_prepare(Slot* s, hipStream_t st, const MsmPlan& P, const Fr* d_sc
         const unsigned sets = P.table_stride ? P.W : 1;
         const int mont = (cfg && cfg->scalars_mont) ? 1 : 0;
         const dim3 grid((unsigned)((n + 255) / 256), sets);
-        if (drop_zero_digits) {  // count, scan, write only the non-zero digits (see k_msm_digit_count); the caller reserved msm_compact_need more
-            const size_t m = (size_t)sets * n;
-            uint32_t* cnt = (uint32_t*)s->alloc((m + 1) * 4);
-            uint32_t* off = (uint32_t*)s->alloc((m + 1) * 4);
-            void* ctmp = s->alloc(xs_tmp_bytes(m + 1) + 16);
-            if (!cnt || !off || !ctmp) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (zero-digit compaction)");
-            ZK_HIP(hipMemsetAsync(cnt + m, 0, 4, st));
-            ZK_LAUNCH(s, st, "msm_digits", k_msm_digit_count, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, P.table_stride, P.row_first, P.row_step, cnt);
-            ZK_TRY(xs_exclusive_scan(s, st, ctmp, cnt, off, m + 1));
-            ZK_LAUNCH(s, st, "msm_digits", k_msm_digits_compact, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, P.row_first, P.row_step, P.table_stride,
-                      (const uint32_t*)off, keys0, vals0);
-            d_total = off + m;  // the number of pairs, where the kernels below read it
+        if (drop_zero_digits && 256u * P.Wd * 8u > 65536u) drop_zero_digits = false;  // windows narrower than 8 bits (tests): more pairs per workgroup than the stage holds
+        if (drop_zero_digits) {  // only the non-zero digits are written (k_msm_digits_compact); their number stays on the device
+            uint32_t* cnt = (uint32_t*)s->alloc(256);
+            if (!cnt) return set_err(ZK_ERR_HIP, "MSM workspace was not reserved up front (zero-digit compaction)");
+            ZK_HIP(hipMemsetAsync(cnt, 0, 4, st));
+            ZK_LAUNCH(s, st, "msm_digits", k_msm_digits_compact, grid, dim3(256), 256u * P.Wd * 8u, src, (uint32_t)n, mont, c, P.Wd, P.row_first, P.row_step, P.table_stride, cnt,
+                      keys0, vals0);
+            d_total = cnt;  // the number of pairs, where the kernels below read it
         } else {
             ZK_LAUNCH(s, st, "msm_digits", k_msm_digits, grid, dim3(256), 0, src, (uint32_t)n, mont, c, P.Wd, keys0, vals0, P.table_stride, P.row_first, P.row_step,
                       P.Wrows);
@@ -1421,10 +1442,7 @@ int msm_prep_need_table_batch(size_t n, unsigned sets, const MsmTable& tab, hipS
     if (need_acc_g1) *need_acc_g1 = P1.need_acc;
     return ZK_OK;
 }
-size_t msm_compact_need(size_t n, unsigned sets) {  // what dropping the zero digits adds to the preparation's workspace
-    const size_t m = (size_t)sets * n;
-    return 2 * align_up((m + 1) * 4, 256) + align_up(xs_tmp_bytes(m + 1) + 16, 256) + 1024;
-}
+size_t msm_compact_need(size_t, unsigned) { return 1024; }  // what dropping the zero digits adds to the preparation's workspace: the pair counter
 int msm_prepare_scalars_table_batch(Slot* s, hipStream_t st, const void* const* d_scalars, unsigned sets, size_t n, const zk_msm_cfg* cfg, const MsmTable& tab, MsmPrep* out,
                                     bool drop_zero_digits) {
     if (sets < 1 || sets > 3) return set_err(ZK_ERR_ARG, "a batch holds one to three scalar vectors");
@@ -1784,7 +1802,7 @@ int zk_bn254_g2_sum_xyzz(const uint64_t* partials, size_t n_partials, zk_g2_affi
 static int bases_register_here(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c);
 static int bases_register(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c) {
     if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
-    if (table_c != 0 && table_c != -1 && (table_c < 8 || table_c > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_c);
+    if (table_c != 0 && table_c != -1 && (table_c < 8 || table_c > 24)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 24]", table_c);
     ZK_TRY(ensure_init());
     if (md_default_mask()) {  // the process named several GPUs: bases of a size that pays for it are kept by range on all of them (a composite handle)
         std::vector<int> ents;
@@ -1830,7 +1848,7 @@ static int bases_make_table(Bases* b, int table_c) {
 extern "C" {
 static int bases_register_here(const void* points, size_t n, int is_g2, uint64_t* handle, hipMemcpyKind kind, int table_c) {
     if (!handle || (n && !points)) return set_err(ZK_ERR_ARG, "null pointer");
-    if (table_c != 0 && table_c != -1 && (table_c < 8 || table_c > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_c);
+    if (table_c != 0 && table_c != -1 && (table_c < 8 || table_c > 24)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 24]", table_c);
     ZK_TRY(ensure_init());
     Bases b;
     b.n = n;
@@ -1870,7 +1888,7 @@ int zk_bn254_bases_free(uint64_t handle) {
 // Window tables for a base array that was registered without them (table_window_bits as in zk_bn254_bases_register_cfg; 0 = the planner's width, and nothing
 // happens below 4096 bases).  Multi-exps that are running keep the geometry they started with; later ones find the table.  A handle that has one: ZK_OK, untouched.
 int zk_bn254_bases_build_table(uint64_t handle, int table_window_bits) {
-    if (table_window_bits != 0 && (table_window_bits < 8 || table_window_bits > 22)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 22]", table_window_bits);
+    if (table_window_bits != 0 && (table_window_bits < 8 || table_window_bits > 24)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 24]", table_window_bits);
     if (md_is_composite(handle)) return md_bases_build_table(handle, table_window_bits);
     ZK_ON_ENTRY_OF(handle);
     Bases b;
@@ -1962,19 +1980,33 @@ static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t
 // gnark_backend_ffi/main.go:131).  Through zk_bn254_msm_bases each of them uploads the 32 B x n scalars and recodes them (digits, radix sort, task plan).
 // A scalars handle uploads once and keeps one recoding per table geometry (window width, row stride, first scalar): A, B1 and G2.B -- registered over the
 // same wires -- share one; K (registered over the n - n_public private wires) gets a second from the resident copy, no second upload.
+// Lifetimes (round 5; the advisor's finding on round 4's layout, where all recodings lived in ONE pool slot's arena that a third geometry rebuilt in place under
+// readers that had already dropped the lock): every recoding is an allocation of its OWN, shared -- a multi-exp keeps its shared_ptr from the lookup until its sums
+// are back on the host, so neither zk_bn254_scalars_free nor a new geometry can free or move what a kernel in flight reads; the scalars handle holds no pool slot
+// (preparations borrow one for the time it takes to enqueue them), so any number of registrations can be live next to a proof session.
+struct PrepGeo {
+    unsigned c = 0;
+    size_t stride = 0, skip = 0;
+    Slot ws;        // a private workspace (never one of the entry's pool slots): its arena IS this recoding's arrays
+    MsmPrep prep;
+    ~PrepGeo() {
+        msm_prep_release(&prep);
+        for (auto& p : ws.pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+        for (hipEvent_t e : ws.free_events) (void)hipEventDestroy(e);
+        if (ws.arena) (void)hipFree(ws.arena);
+        if (ws.pinned) (void)hipHostFree(ws.pinned);
+    }
+};
 struct PreparedScalars {
     size_t n = 0;
     int mont = 0;
     void* d_sc = nullptr;
-    Slot* slot = nullptr;   // its arena holds the recodings; held until zk_bn254_scalars_free
-    std::mutex mu;
-    struct Geo {
-        unsigned c;
-        size_t stride, skip;
-        bool table;
-        MsmPrep prep;
-    };
-    std::vector<Geo> geos;
+    std::mutex mu;  // the list below; a geometry being prepared (callers that arrive together wait for the first one's)
+    std::vector<std::shared_ptr<PrepGeo>> geos;
+    ~PreparedScalars() {
+        geos.clear();
+        if (d_sc) (void)hipFree(d_sc);
+    }
 };
 static std::mutex g_ps_mu;
 static std::map<uint64_t, std::shared_ptr<PreparedScalars>> g_ps;
@@ -1988,19 +2020,18 @@ int zk_bn254_scalars_register(const zk_fr* scalars, size_t n, const zk_msm_cfg* 
     S->n = n;
     S->mont = (cfg && cfg->scalars_mont) ? 1 : 0;
     ZK_HIP(hipMalloc(&S->d_sc, n * 32 + 16));
-    int rc = acquire_slot(&S->slot);
-    if (rc == ZK_OK && n && hipMemcpyAsync(S->d_sc, scalars, n * 32, hipMemcpyHostToDevice, S->slot->stream) != hipSuccess) rc = set_err(ZK_ERR_HIP, "upload of the scalars failed");
-    if (rc == ZK_OK && hipStreamSynchronize(S->slot->stream) != hipSuccess) rc = set_err(ZK_ERR_HIP, "upload of the scalars failed");  // the caller's slice is not ours after the call
-    if (rc != ZK_OK) {
-        if (S->slot) release_slot(S->slot);
-        (void)hipFree(S->d_sc);
-        return rc;
+    {
+        SlotGuard g;  // borrowed for the upload only
+        ZK_TRY(acquire_slot(&g.s));
+        if (n) ZK_HIP(hipMemcpyAsync(S->d_sc, scalars, n * 32, hipMemcpyHostToDevice, g.s->stream));
+        ZK_HIP(hipStreamSynchronize(g.s->stream));  // the caller's slice is not ours after the call
     }
     std::lock_guard<std::mutex> lk(g_ps_mu);
     *handle = hmake(g_next_ps++);
     g_ps[*handle] = S;
     return ZK_OK;
 }
+// The handle is gone at once; the resident copy and its recodings go when the last multi-exp still reading them has its result.
 int zk_bn254_scalars_free(uint64_t handle) {
     ZK_ON_ENTRY_OF(handle);
     std::shared_ptr<PreparedScalars> S;
@@ -2011,12 +2042,7 @@ int zk_bn254_scalars_free(uint64_t handle) {
         S = it->second;
         g_ps.erase(it);
     }
-    std::lock_guard<std::mutex> lk(S->mu);  // MSMs in flight against it finish first
-    (void)hipStreamSynchronize(S->slot->stream);
-    for (auto& g : S->geos) msm_prep_release(&g.prep);
-    release_slot(S->slot);
-    (void)hipFree(S->d_sc);
-    return ZK_OK;
+    return ZK_OK;  // ~PreparedScalars runs here unless a call in flight still holds S
 }
 // out = sum_{i >= skip} scalars[i] * bases[bases_offset + (i - skip)]   (skip: Groth16's K pairs with the wire values from the first private wire on)
 int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t scalars_handle, size_t skip, const zk_msm_cfg* cfg, void* out) {
@@ -2050,7 +2076,7 @@ int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t sc
         return msm_bases(bases, bases_offset, (const char*)S->d_sc + skip * 32, n, &c1, out, hipMemcpyDeviceToDevice);
     }
     // the recoding for this table geometry: found, or made now from the resident copy (callers that arrive together wait for the first one's)
-    MsmPrep prep;
+    std::shared_ptr<PrepGeo> G;  // held until this call's sums are on the host: what the accumulate kernel reads cannot go away under it
     uint32_t skip_below = 0;
     const char* table = nullptr;
     {
@@ -2058,38 +2084,31 @@ int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t sc
         // one recoding per (window width, row stride, first scalar): the recoded values are table indices w * stride + i, i counted from the first scalar, so
         // every base array registered with that stride shares it -- whatever its bases_offset, which only moves the table pointer.  (The accumulate kernels'
         // skip_below compares whole table indices: it cannot drop the first scalars of rows w > 0, so a `skip` is a recoding of its own.)
-        const size_t g_skip = skip;
-        PreparedScalars::Geo* G = nullptr;
         for (auto& g : S->geos)
-            if (g.c == b.tab.c && g.stride == b.tab.stride && g.skip == g_skip) G = &g;
+            if (g->c == b.tab.c && g->stride == b.tab.stride && g->skip == skip) G = g;
         if (!G) {
-            const size_t cnt = S->n - g_skip;
+            const size_t cnt = S->n - skip;
+            auto N = std::make_shared<PrepGeo>();
+            N->c = b.tab.c;
+            N->stride = b.tab.stride;
+            N->skip = skip;
+            SlotGuard borrowed;  // its stream carries the preparation; the arrays live in N->ws
+            ZK_TRY(acquire_slot(&borrowed.s));
+            hipStream_t pst = borrowed.s->stream;
+            N->ws.stream = pst;
+            N->ws.owner = &ctx();
             size_t np = 0, na1 = 0, na2 = 0;
-            ZK_TRY(msm_prep_need_table(cnt, b.tab, S->slot->stream, &np, &na1, &na2));
-            size_t have = 0;
-            for (auto& g : S->geos) have += g.prep.P.need_prep + 4096;
-            if (S->geos.empty()) ZK_TRY(S->slot->reserve(2 * np + 16384));  // room for a second geometry (K) without moving the first
-            else if (S->slot->arena_off + np + 8192 > S->slot->arena_cap) {
-                // a third geometry, or a larger one: the recodings are rebuilt in a larger arena (nothing may be reading the old ones)
-                ZK_HIP(hipStreamSynchronize(S->slot->stream));
-                ZK_HIP(hipDeviceSynchronize());
-                for (auto& g : S->geos) msm_prep_release(&g.prep);
-                S->geos.clear();
-                S->slot->reset();
-                ZK_TRY(S->slot->reserve(have + 2 * np + 16384));
-            }
-            PreparedScalars::Geo g;
-            g.c = b.tab.c;
-            g.stride = b.tab.stride;
-            g.skip = g_skip;
-            g.table = true;
-            ZK_TRY(msm_prepare_scalars_table(S->slot, S->slot->stream, (const char*)S->d_sc + g_skip * 32, cnt, &c1, b.tab, &g.prep));
-            S->geos.push_back(g);
-            G = &S->geos.back();
+            ZK_TRY(msm_prep_need_table(cnt, b.tab, pst, &np, &na1, &na2));
+            ZK_TRY(N->ws.reserve(np + 16384));
+            ZK_TRY(msm_prepare_scalars_table(&N->ws, pst, (const char*)S->d_sc + skip * 32, cnt, &c1, b.tab, &N->prep));
+            if (profiling_on()) ZK_TRY(slot_sync(&N->ws, pst));  // the event pairs of these launches sit in the private workspace: folded here
+            N->ws.stream = nullptr;  // (not ours; prep.ready orders the readers behind the preparation)
+            S->geos.push_back(N);
+            G = N;
         }
-        prep = G->prep;
         table = (const char*)b.d_table + bases_offset * esz;  // index i of the recoding is base bases_offset + i
     }
+    const MsmPrep& prep = G->prep;
     SlotGuard g;
     ZK_TRY(acquire_slot(&g.s));
     hipStream_t st = g.s->stream;

@@ -61,23 +61,6 @@ int md_entries_for(uint32_t requested, size_t units, size_t min_units_per_entry,
     return ZK_OK;
 }
 
-// ---- a team of host threads, one per entry; the first failure is the call's failure
-static int team_run(const std::vector<int>& entries, const std::function<int(int)>& fn) {
-    const int G = (int)entries.size();
-    std::vector<int> rcs(G, ZK_OK);
-    std::vector<std::string> errs(G);
-    std::vector<std::thread> th;
-    for (int k = 0; k < G; k++)
-        th.emplace_back([&, k] {
-            CtxScope sc(entries[k]);
-            rcs[k] = sc.rc != ZK_OK ? sc.rc : fn(k);
-            if (rcs[k] != ZK_OK) errs[k] = g_err;
-        });
-    for (auto& t : th) t.join();
-    for (int k = 0; k < G; k++)
-        if (rcs[k] != ZK_OK) return set_err(rcs[k], "entry %d: %s", entries[k], errs[k].c_str());
-    return ZK_OK;
-}
 struct Barrier {  // reusable; a failing member releases the others through `broken`
     std::mutex mu;
     std::condition_variable cv;
@@ -98,6 +81,28 @@ struct Barrier {  // reusable; a failing member releases the others through `bro
         cv.notify_all();
     }
 };
+// ---- a team of host threads, one per entry; the first failure is the call's failure.  `bar` (optional): the barrier the members meet at -- EVERY member that ends
+// with an error breaks it, wherever the error came from (its entry could not be entered, a slot timed out, a workspace did not fit: exits that never reach the
+// member's own bar.fail()), so that no other member waits for it for ever.
+static int team_run(const std::vector<int>& entries, const std::function<int(int)>& fn, Barrier* bar = nullptr) {
+    const int G = (int)entries.size();
+    std::vector<int> rcs(G, ZK_OK);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> th;
+    for (int k = 0; k < G; k++)
+        th.emplace_back([&, k] {
+            CtxScope sc(entries[k]);
+            rcs[k] = sc.rc != ZK_OK ? sc.rc : fn(k);
+            if (rcs[k] != ZK_OK) {
+                errs[k] = g_err;
+                if (bar) bar->fail();
+            }
+        });
+    for (auto& t : th) t.join();
+    for (int k = 0; k < G; k++)
+        if (rcs[k] != ZK_OK) return set_err(rcs[k], "entry %d: %s", entries[k], errs[k].c_str());
+    return ZK_OK;
+}
 
 static int device_of_entry(int e) {
     CtxScope sc(e);
@@ -518,7 +523,7 @@ int md_groth16_prove(uint64_t h, const void* a, const void* b, const void* c, si
         const uint64_t sess = session;
         session = 0;  // _end consumes the session whatever it returns
         return zk_bn254_groth16_msm5_pk_end(sess, xa[k], &recs[(size_t)k * 96], (void*)st);
-    });
+    }, &X.bar);
     ZK_TRY(rc);
     return zk_bn254_groth16_finalize(K->sub[0], recs.data(), (size_t)G, r_, s_, proof_out);
 }
@@ -565,7 +570,7 @@ int md_ntt_host(zk_fr* a, uint32_t log_n, int inverse, int decimation, int coset
         }
         if (hipMemcpyAsync(a + (size_t)k * M, x[k], M * 32, hipMemcpyDeviceToHost, st) != hipSuccess) return set_err(ZK_ERR_HIP, "download failed");
         return slot_sync(g.s, st);
-    });
+    }, &X.bar);
 }
 
 }  // namespace zkmi

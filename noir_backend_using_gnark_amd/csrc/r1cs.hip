@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <vector>
@@ -79,14 +80,48 @@ struct Csr3 {
     const uint32_t* idx[3];
     const Fr* val[3];
 };
-__global__ __launch_bounds__(256) void k_spmv3(Csr3 M, const Fr* __restrict__ x, size_t rows, Fr* __restrict__ out0, Fr* __restrict__ out1, Fr* __restrict__ out2) {
+// Rows longer than SPMV_LONG entries are left to k_spmv3_long (listed through `long_rows`: [0] = count, then (matrix, row) pairs): in the by-wire form
+// Setup multiplies with, the ONE wire's column holds an entry for every gate's sum constraint -- 2^19 of them at 2^20 constraints -- and one lane walking it alone
+// took 0.52 s of a 0.59 s Setup (profiles/rnd5_e_groth16_export_2p20.json).
+constexpr uint32_t SPMV_LONG = 1024, SPMV_LONG_MAX = 4096;
+__global__ __launch_bounds__(256) void k_spmv3(Csr3 M, const Fr* __restrict__ x, size_t rows, Fr* __restrict__ out0, Fr* __restrict__ out1, Fr* __restrict__ out2,
+                                               uint32_t* __restrict__ long_rows) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int m = blockIdx.y;
     if (i >= rows) return;
     const uint32_t b = M.ptr[m][i], e = M.ptr[m][i + 1];
+    if (long_rows && e - b > SPMV_LONG) {
+        const uint32_t slot = atomicAdd(&long_rows[0], 1u);
+        if (slot < SPMV_LONG_MAX) {  // (more long rows than the list holds: they are summed here after all, slowly and correctly)
+            long_rows[1 + 2 * slot] = (uint32_t)m;
+            long_rows[2 + 2 * slot] = (uint32_t)i;
+            return;
+        }
+    }
     Fr acc = Fr::zero();
     for (uint32_t k = b; k < e; k++) acc = acc + ldf(M.val[m] + k) * ldf(x + M.idx[m][k]);
     (m == 0 ? out0 : m == 1 ? out1 : out2)[i] = acc;
+}
+// one workgroup per listed row: 256 partial sums over strided entries, folded through LDS
+__global__ __launch_bounds__(256) void k_spmv3_long(Csr3 M, const Fr* __restrict__ x, Fr* __restrict__ out0, Fr* __restrict__ out1, Fr* __restrict__ out2,
+                                                    const uint32_t* __restrict__ long_rows) {
+    __shared__ Fr part[256];
+    const uint32_t cnt = long_rows[0] < SPMV_LONG_MAX ? long_rows[0] : SPMV_LONG_MAX;
+    for (uint32_t r = blockIdx.x; r < cnt; r += gridDim.x) {
+        const int m = (int)long_rows[1 + 2 * r];
+        const size_t i = long_rows[2 + 2 * r];
+        const uint32_t b = M.ptr[m][i], e = M.ptr[m][i + 1];
+        Fr acc = Fr::zero();
+        for (uint32_t k = b + threadIdx.x; k < e; k += 256) acc = acc + ldf(M.val[m] + k) * ldf(x + M.idx[m][k]);
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (unsigned d = 128; d > 0; d >>= 1) {
+            if (threadIdx.x < d) part[threadIdx.x] = part[threadIdx.x] + part[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) (m == 0 ? out0 : m == 1 ? out1 : out2)[i] = part[0];
+        __syncthreads();
+    }
 }
 // Lagrange basis of the size-N domain at tau: lag_j = (tau^N - 1) / N * w^j / (tau - w^j)
 __global__ __launch_bounds__(256) void k_lagrange_at(const Fr* __restrict__ tw, uint32_t N, Fr tau, Fr scale /* (tau^N - 1) / N */, Fr* __restrict__ out) {
@@ -265,7 +300,8 @@ int zk_bn254_r1cs_eval_abc_dev(uint64_t handle, const void* d_w, size_t n_wires,
     Csr3 M;
     for (int m = 0; m < 3; m++) { M.ptr[m] = D->row[m].ptr; M.idx[m] = D->row[m].idx; M.val[m] = D->row[m].val; }
     if (D->n_constraints)
-        ZK_LAUNCH(g.s, st, "r1cs_spmv", k_spmv3, dim3(gridn(D->n_constraints), 3), dim3(256), 0, M, (const Fr*)d_w, D->n_constraints, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
+        ZK_LAUNCH(g.s, st, "r1cs_spmv", k_spmv3, dim3(gridn(D->n_constraints), 3), dim3(256), 0, M, (const Fr*)d_w, D->n_constraints, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c,
+                  (uint32_t*)nullptr);  // by constraint: rows are a handful of terms
     if (!stream || profiling_on()) ZK_TRY(slot_sync(g.s, st));
     return ZK_OK;
 }
@@ -297,18 +333,31 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
     for (unsigned i = 0; i < logN; i++) tauN = tauN.sqr();
     const HFr zt = tauN - HFr::one();
     if (zt.is_zero()) return set_err(ZK_ERR_ARG, "tau is a root of unity of the domain");
-    ZK_TRY(s->reserve((N + 4 * nw + N) * sizeof(Fr) + 65536));
+    ZK_TRY(s->reserve((N + 4 * nw + N) * sizeof(Fr) + 131072));
     Fr* lag = (Fr*)s->alloc(N * sizeof(Fr));
     Fr* abc = (Fr*)s->alloc(3 * nw * sizeof(Fr));
     Fr* ksc = (Fr*)s->alloc(nw * sizeof(Fr));
     Fr* zsc = (Fr*)s->alloc(N * sizeof(Fr));
     if (!lag || !abc || !ksc || !zsc) return set_err(ZK_ERR_HIP, "setup workspace");
     ZK_LAUNCH(s, st, "setup_lagrange", k_lagrange_at, dim3(gridn(N)), dim3(256), 0, (const Fr*)dom->tw, (uint32_t)N, todev(tau), todev(zt * dom->card_inv), lag);
+    struct Lap {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        void lap(const char* name) {
+            const auto t1 = std::chrono::steady_clock::now();
+            prof_host(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        }
+    } lap;
     ZK_TRY(ensure_csc(D, s, st));
+    lap.lap("export.setup_csc");
     {   // A_i, B_i, C_i = sum_j M[j][i] lag_j: the transposed products, one lane per wire over the CSC form
         Csr3 M;
         for (int m = 0; m < 3; m++) { M.ptr[m] = D->col[m].ptr; M.idx[m] = D->col[m].idx; M.val[m] = D->col[m].val; }
-        ZK_LAUNCH(s, st, "setup_spmv_t", k_spmv3, dim3(gridn(nw), 3), dim3(256), 0, M, (const Fr*)lag, nw, abc, abc + nw, abc + 2 * nw);
+        uint32_t* long_rows = (uint32_t*)s->alloc((1 + 2 * SPMV_LONG_MAX) * 4);
+        if (!long_rows) return set_err(ZK_ERR_HIP, "setup workspace");
+        ZK_HIP(hipMemsetAsync(long_rows, 0, 4, st));
+        ZK_LAUNCH(s, st, "setup_spmv_t", k_spmv3, dim3(gridn(nw), 3), dim3(256), 0, M, (const Fr*)lag, nw, abc, abc + nw, abc + 2 * nw, long_rows);
+        ZK_LAUNCH(s, st, "setup_spmv_t_long", k_spmv3_long, dim3(512), dim3(256), 0, M, (const Fr*)lag, abc, abc + nw, abc + 2 * nw, (const uint32_t*)long_rows);
     }
     ZK_LAUNCH(s, st, "setup_k_scalars", k_k_scalars, dim3(gridn(nw)), dim3(256), 0, (const Fr*)abc, (const Fr*)(abc + nw), (const Fr*)(abc + 2 * nw), nw, npub, todev(alpha),
               todev(beta), todev(gamma.inv()), todev(delta.inv()), ksc);
@@ -353,11 +402,14 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
         memcpy(kk, c.l, 32);
         *o = scalar_mul(gh, kk).to_affine();
     };
+    lap.lap("export.setup_enqueue");
     Affine<HFp> a1, b1, d1;
     Affine<HFp2> b2, g2, d2;
     mul1(alpha, &a1); mul1(beta, &b1); mul1(delta, &d1);
     mul2(beta, &b2); mul2(gamma, &g2); mul2(delta, &d2);
+    lap.lap("export.setup_host_points");
     ZK_TRY(slot_sync(s, st));
+    lap.lap("export.setup_device_wait");
     zk_groth16_pk pk;
     memset(&pk, 0, sizeof pk);
     pk.log_domain = logN;
@@ -370,6 +422,7 @@ int zk_bn254_groth16_setup(uint64_t r1cs_handle, const zk_fr toxic[5], int flags
     pk.bases_on_device = 1;
     pk.flags = flags & 1;
     ZK_TRY(zk_bn254_groth16_pk_load(&pk, pk_handle));
+    lap.lap("export.setup_pk_load");
     ZK_TRY(groth16_pk_adopt(*pk_handle));
     d_a = d_b = d_k = d_z = d_b2 = nullptr;  // the key owns them now
     if (vk_g1) {

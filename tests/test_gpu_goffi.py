@@ -129,6 +129,27 @@ def test_groth16_exports_at_2p11_constraints_and_the_export_worker(tmp_path):
     assert ref.groth16_verify(ovk, (pl.g1_decompress(pb[:32]), pl.g2_decompress(pb[32:96]), pl.g1_decompress(pb[96:])), wv[:r1.n_public])
 
 
+def test_the_shim_uses_one_device_unless_asked(tmp_path):
+    """libgnark_backend.so starts ONE device entry whatever the node holds (the reference is one process per nargo command; several GPUs in one process have only
+    run on virtual entries): the default worker reports 1 entry -- on a multi-GPU box too.  ZKMI_DEVICES opts in: "0,0" (the same GPU listed twice: two virtual
+    entries, the SRS spread by range over both, every commitment one partial per entry) still produces a proof the first process's key verifies; a value that is
+    neither "all" nor a list of visible ordinals ends the process with a message instead of silently meaning one GPU."""
+    e = json.load(open(os.path.join(HERE, "golden", "plonk_golden.json")))[0]
+    values = [h2i(v) for v in e["values"]]
+    job = dict(what="plonk", acir=json.dumps(e["acir"]), values=ref.felts_wire(values).hex(), values_wrong_public=ref.felts_wire(values).hex(),
+               random_values=ref.felts_wire(ref.rand_felts(91, len(values))).hex())
+    os.makedirs(tmp_path / "cfg", exist_ok=True)
+    a = run_worker(tmp_path, job, "one")
+    assert a["verifies"] == 1 and a["device_entries"] == 1
+    b = run_worker(tmp_path, dict(job, pk=a["pk"], vk=a["vk"]), "two_virtual", env_extra={"ZKMI_DEVICES": "0,0"})
+    assert b["verifies"] == 1 and b["device_entries"] == 2
+    c = run_worker(tmp_path, dict(job, pk=a["pk"], vk=a["vk"]), "all", env_extra={"ZKMI_DEVICES": "all"})
+    assert c["verifies"] == 1 and c["device_entries"] >= 1
+    for bad in ("7,x", "99", "-1", "0,1,2,3,4,5,6,7,8"):
+        out = run_worker(tmp_path, dict(job, pk=a["pk"], vk=a["vk"]), "bad", env_extra={"ZKMI_DEVICES": bad}, expect_fail=True)
+        assert out.returncode == 1 and "ZKMI_DEVICES" in out.stderr, (bad, out.stderr[-300:])
+
+
 def test_only_an_unreadable_or_non_hex_srs_file_is_replaced(tmp_path):
     """LoadSRS fails -- and TryLoadSRS generates and saves a new SRS -- exactly when srs.hex cannot be read or is not hex (common.go:86-104, 127-141); what
     ReadFrom makes of hex that is not an SRS is ignored there and the prover then dies on the broken SRS.  Here: a non-hex file is replaced and the call

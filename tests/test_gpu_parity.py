@@ -756,7 +756,7 @@ def test_msm_plain_window_bits_21_22_vs_oracle(c):
         zk.g1_multi_exp(pts, sc, zk.MultiExpConfig(scalars_mont=True, window_bits=23))
 
 
-@pytest.mark.parametrize("c", [8, 21, 22])
+@pytest.mark.parametrize("c", [8, 21, 22, 23, 24])
 def test_registered_bases_table_window_bits_vs_oracle(c):
     """window tables 2^(c*w) * P_i with the widths the planner uses at 2^22 .. 2^26 points, on few points (table_window_bits knob)."""
     n = 2500
@@ -775,7 +775,7 @@ def test_registered_bases_table_window_bits_vs_oracle(c):
     assert (rb2.multi_exp(s2, config=MONT) == orc.g2_msm(p2, s2)).all()
     rb2.free()
     with pytest.raises(_lib.ZkmiError):
-        zb.ResidentBases(pts, table_window_bits=23)
+        zb.ResidentBases(pts, table_window_bits=25)
 
 
 def _random_pk(log_n, n_wires, n_public, seed0=0):
@@ -787,7 +787,7 @@ def _random_pk(log_n, n_wires, n_public, seed0=0):
                 g2_b=orc.g2_gen_points(seed0 + 10, n_wires))
 
 
-@pytest.mark.parametrize("c", [21, 22])
+@pytest.mark.parametrize("c", [21, 22, 24])
 def test_groth16_prove_with_table_window_bits_21_22(c):
     log_n = 10
     N = 1 << log_n
@@ -1130,6 +1130,84 @@ def test_prepared_scalars_shared_by_the_multi_exps_of_one_proof():
     assert (A.multi_exp_prepared(S) == A.multi_exp(w_reg, zk.MultiExpConfig())).all()
     S.free()
     A.free()
+
+
+def test_prepared_scalars_outlive_new_geometries_frees_and_many_registrations():
+    """Lifetimes of zk_bn254_scalars_register's recodings (round 4's advisor: a third table geometry rebuilt ALL recodings in place while another caller's
+    accumulate kernel, already past the lock, was still reading the old ones; a registration pinned one of the entry's eight stream slots).  Now every recoding
+    is an allocation of its own held by whoever reads it: (i) readers of two geometries keep running while other threads ask for a third, a fourth and a fifth
+    geometry (tables of other widths, other first scalars) on the same handle -- every result equals the oracle's; (ii) zk_bn254_scalars_free while multi-exps
+    are in flight: they finish with the right sums, later calls get the unknown-handle error; (iii) twelve live registrations next to a Groth16 proof (which
+    takes five slots at once)."""
+    import threading
+    n = 5000
+    w = orc.rand_fr(0xA1, n, witness_like=True)
+    pts = orc.g1_gen_points(0xA2, n)
+    bases = {c: zb.ResidentBases(pts, table_window_bits=c) for c in (8, 9, 10, 11)}
+    want_all = orc.g1_msm(pts, w)
+    want_skip = {sk: orc.g1_msm(pts[: n - sk], w[sk:]) for sk in (7, 30)}
+    S = zb.PreparedScalars(w, MONT)
+    errs, done = [], []
+
+    def reader(c, skip, reps):
+        try:
+            for _ in range(reps):
+                got = bases[c].multi_exp_prepared(S, skip=skip)
+                ok = (got == (want_all if skip == 0 else want_skip[skip])).all()
+                done.append(ok)
+                if not ok:
+                    errs.append((c, skip))
+        except Exception as e:  # noqa: BLE001
+            errs.append((c, skip, repr(e)))
+
+    th = [threading.Thread(target=reader, args=(8, 0, 12)), threading.Thread(target=reader, args=(9, 0, 12)),
+          threading.Thread(target=reader, args=(10, 0, 6)), threading.Thread(target=reader, args=(11, 7, 6)), threading.Thread(target=reader, args=(8, 30, 6))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs and len(done) == 42 and all(done), errs
+    # (ii) free under readers: calls that already hold the handle's data finish; the handle itself is gone at once
+    S2 = zb.PreparedScalars(w, MONT)
+    assert (bases[8].multi_exp_prepared(S2) == want_all).all()
+    res = []
+    s2_handle = C.c_uint64(S2.handle.value)
+
+    def late_reader():
+        try:
+            out = np.zeros(8, dtype=np.uint64)
+            rc = _lib.lib().zk_bn254_msm_bases_prepared(bases[9].handle, C.c_size_t(0), s2_handle, C.c_size_t(0), C.byref(MONT._c()), _lib.vp(out))
+            res.append("gone" if rc == _lib.ZK_ERR_HANDLE else bool(rc == 0 and (out == want_all).all()))
+        except Exception as e:  # noqa: BLE001
+            res.append(repr(e))
+
+    th = [threading.Thread(target=late_reader) for _ in range(4)]
+    for t in th:
+        t.start()
+    S2.free()
+    for t in th:
+        t.join()
+    # each of the four either got the handle's data before the free took the handle away (right sum) or finds the handle gone: never a wrong sum, never a fault
+    assert len(res) == 4 and all(r is True or r == "gone" for r in res), res
+    assert _lib.lib().zk_bn254_msm_bases_prepared(bases[8].handle, C.c_size_t(0), s2_handle, C.c_size_t(0), C.byref(MONT._c()), _lib.vp(np.zeros(8, np.uint64))) == _lib.ZK_ERR_HANDLE
+    # (iii) more live registrations than the entry has stream slots, next to a proof
+    many = [zb.PreparedScalars(w[: 100 + k], MONT) for k in range(12)]
+    log_n = 8
+    N = 1 << log_n
+    pkd = dict(log_domain=log_n, n_wires=N, n_public=3, g1_alpha=orc.g1_gen_points(1, 1)[0], g1_beta=orc.g1_gen_points(2, 1)[0], g1_delta=orc.g1_gen_points(3, 1)[0],
+               g1_a=orc.g1_gen_points(4, N), g1_b=orc.g1_gen_points(5, N), g1_k=orc.g1_gen_points(6, N - 3), g1_z=orc.g1_gen_points(7, N),
+               g2_beta=orc.g2_gen_points(8, 1)[0], g2_delta=orc.g2_gen_points(9, 1)[0], g2_b=orc.g2_gen_points(10, N))
+    a, b = orc.rand_fr(20, N), orc.rand_fr(21, N)
+    c_ = np.stack([orc.fe_op("mul", 0, a[i], b[i]) for i in range(N)])
+    ww = orc.rand_fr(22, N, witness_like=True)
+    r, s_ = orc.rand_fr(23, 1)[0], orc.rand_fr(24, 1)[0]
+    exp, _ = orc.groth16_prove(pkd, a, b, c_, ww, r, s_)
+    pk = zk.ProvingKey(**pkd)
+    assert zk.prove(pk, a, b, c_, ww, r, s_) == exp
+    assert (bases[10].multi_exp_prepared(many[11], offset=0) == orc.g1_msm(pts[:111], w[:111])).all()
+    pk.free()
+    for h in many + [S] + list(bases.values()):
+        h.free()
 
 
 def test_groth16_2p24_proof_bytes_vs_oracle():

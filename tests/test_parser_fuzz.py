@@ -91,11 +91,19 @@ def test_content_key_separates_texts_and_is_stable_across_thread_counts(tmp_path
     subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tools", "lower_bench.cpp"), "-lpthread", "-o", exe])
     acir, w = synth_acir.synth(8000, 2, seed=9)  # > 64 segments of 64 KB: the threaded key; > 2 MB: the opcodes array goes to several parsers (acir_detail::elements_parallel)
     assert len(acir) > (2 << 20)
-    keys = []
-    for k, text in enumerate([acir, acir, acir[:70000] + ("1" if acir[70000] != "1" else "2") + acir[70001:], acir + " "]):
+    # a 32-byte-aligned block of round 4's fixed multiplier mask zeroed all four lanes of a segment (an absorbing state: whatever came before it in the segment
+    # was forgotten); the masks are drawn per process now and a step keeps its input state, so two texts that differ only BEFORE such a block differ in their keys
+    blk = bytes.fromhex("d1b54a32d192ed03")[::-1] * 4
+    poisoned = [acir[:64] + c + acir[65:96] + blk.decode("latin-1") + acir[128:] for c in "ab"]
+    files = []
+    for k, text in enumerate([acir, acir, acir[:70000] + ("1" if acir[70000] != "1" else "2") + acir[70001:], acir + " "] + poisoned):
         f = tmp_path / ("t%d.json" % k)
-        f.write_text(text)
-        rep = json.loads(subprocess.run([exe, str(f), str(len(w))], capture_output=True, text=True, check=False).stdout.strip().splitlines()[-1])
-        assert rep["same_output"] is True  # the default (several parsers) == one parser == the document-tree reader, word for word
-        keys.append(rep["key"])
-    assert keys[0] == keys[1] and len({keys[0], keys[2], keys[3]}) == 3
+        f.write_bytes(text.encode("latin-1"))
+        files.append(str(f))
+        if k < 4 and k != 1:
+            rep = json.loads(subprocess.run([exe, str(f), str(len(w))], capture_output=True, text=True, check=False).stdout.strip().splitlines()[-1])
+            assert rep["same_output"] is True  # the default (several parsers) == one parser == the document-tree reader, word for word
+    keys = json.loads(subprocess.run([exe, "--keys"] + files, capture_output=True, text=True, check=True).stdout)  # one process: the masks are per process
+    assert keys[0] == keys[1] and len({keys[0], keys[2], keys[3]}) == 3 and keys[4] != keys[5]
+    again = json.loads(subprocess.run([exe, "--keys", files[0]], capture_output=True, text=True, check=True).stdout)
+    assert again[0] != keys[0]  # another process, other masks: a collision cannot be prepared offline

@@ -43,8 +43,9 @@ def libs():
     return Z, G
 
 
-def phases(Z, reset=True):
-    out = {}
+def phases(Z, reset=True, kernels=None):
+    """the wall-clock sections (export.*); kernels (a dict, optional) receives the eight largest kernel totals of the same interval, in ms"""
+    out, ker = {}, {}
     name = C.create_string_buffer(128)
     n, ms = C.c_uint64(0), C.c_double(0)
     for i in range(Z.zk_profile_count()):
@@ -52,6 +53,10 @@ def phases(Z, reset=True):
         k = name.value.decode()
         if k.startswith("export."):
             out[k[7:]] = round(ms.value, 3)
+        elif not k.startswith("host_"):
+            ker[k] = round(ms.value, 3)
+    if kernels is not None:
+        kernels.update(dict(sorted(ker.items(), key=lambda kv: -kv[1])[:8]))
     if reset:
         Z.zk_profile_reset()
     return out
@@ -88,7 +93,8 @@ def main():
         t0 = time.perf_counter()
         kp = G.Preprocess(gs(raw))
         ms = (time.perf_counter() - t0) * 1e3
-        ph = phases(Z)
+        kern = {}
+        ph = phases(Z, kernels=kern)
         pk, vk = C.string_at(kp.proving_key), C.string_at(kp.verifying_key)
         with open(os.path.join(d, "pk.hex"), "wb") as f:
             f.write(pk)
@@ -98,7 +104,7 @@ def main():
         proof = C.string_at(G.ProveWithPK(gs(raw), gs(pk)))
         ms_prove = (time.perf_counter() - t0) * 1e3
         ph2 = phases(Z)
-        print(json.dumps({"Preprocess_ms": round(ms, 1), "phases": ph, "pk_text_bytes": len(pk), "vk_text_bytes": len(vk),
+        print(json.dumps({"Preprocess_ms": round(ms, 1), "phases": ph, "largest_kernels_ms": kern, "pk_text_bytes": len(pk), "vk_text_bytes": len(vk),
                           "ProveWithPK_after_preprocess_ms": round(ms_prove, 2), "phases_prove_after_preprocess": ph2,
                           "verifies": int(G.VerifyWithVK(gs(raw), gs(proof), gs(vk))), "process_s": round(time.perf_counter() - t_start, 2)}))
         return
@@ -108,7 +114,8 @@ def main():
         t0 = time.perf_counter()
         proof = C.string_at(G.ProveWithPK(gs(raw), gs(pk)))
         cold_ms = (time.perf_counter() - t0) * 1e3
-        cold = phases(Z)
+        cold_kern = {}
+        cold = phases(Z, kernels=cold_kern)
         t0 = time.perf_counter()
         G.ProveWithPK(gs(raw), gs(pk))  # the second proving call with this key: it builds the key's window tables
         second_ms = (time.perf_counter() - t0) * 1e3
@@ -133,7 +140,7 @@ def main():
         if hasattr(Z, "zk_export_cache_info"):
             Z.zk_export_cache_info(C.byref(nc), C.byref(nk), C.byref(by))
         prove = wph.get("groth16_prove_r1cs", 0.0)
-        print(json.dumps({"cold_ProveWithPK_ms": round(cold_ms, 1), "cold_phases": cold, "second_ProveWithPK_ms": round(second_ms, 2), "second_phases": second,
+        print(json.dumps({"cold_ProveWithPK_ms": round(cold_ms, 1), "cold_phases": cold, "cold_largest_kernels_ms": cold_kern, "second_ProveWithPK_ms": round(second_ms, 2), "second_phases": second,
                           "warm_ProveWithPK_ms": round(warm_ms, 3), "warm_calls": warm, "warm_phases_per_call": wph,
                           "zk_bn254_groth16_prove_r1cs_ms": prove, "warm_over_prove": round(warm_ms / prove, 3) if prove else None,
                           "VerifyWithVK_ms": round(ver_ms, 2), "verifies": ok, "warm_proof_verifies": ok2, "wrong_public_input_rejected": int(rej == 0),

@@ -9,7 +9,28 @@
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+static bool slurp(const char* path, std::string* text) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) text->append(buf, k);
+    fclose(f);
+    return true;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 3 && !strcmp(argv[1], "--keys")) {  // the content keys of several texts from ONE process (the key's masks are drawn per process)
+        printf("[");
+        for (int i = 2; i < argc; i++) {
+            std::string t;
+            if (!slurp(argv[i], &t)) return 2;
+            const zkmi::ContentKey k = zkmi::content_key(t.data(), t.size());
+            printf("%s\"%016llx%016llx\"", i > 2 ? ", " : "", (unsigned long long)k.h[0], (unsigned long long)k.h[1]);
+        }
+        printf("]\n");
+        return 0;
+    }
     if (argc < 3) return 2;
     std::string text;
     FILE* f = fopen(argv[1], "rb");
