@@ -80,6 +80,8 @@ int zk_init_devices(const int *devices, size_t n);
  * 40-160 ms (tools/hip_start_bench.hip), so the library creates them when a slot is first used -- or here, for a caller that has host work to do meanwhile (the
  * export shim reads srs.hex).  n slots of the calling thread's device entry (at most all 8). */
 int zk_warm_streams(int n);
+/* The same for the five slots of a Groth16 proof session INCLUDING their high-priority streams (what zk_bn254_groth16_prove takes at once). */
+int zk_warm_session_streams(void);
 /* Process-wide start-up choices; call before anything that touches a device.  ZK_INIT_LEAN_STREAMS: a device entry creates only the five streams every caller
  * needs with itself and every other stream on first use (the default also creates the five high-priority streams of a Groth16 proof session up front: 40 ms more
  * start-up, 1 % less per 2^20 proof -- WHICH streams share a hardware queue follows creation order).  For a process that makes one proof and exits. */

@@ -681,15 +681,27 @@ static inline bool count_from_hex(const char* hex, size_t len, size_t* n) {
 // witnesses in witness order, the other witnesses, product variables]; values[w - 1] is witness w; the product variable is the plain product (the
 // sketch puts the coefficient on the product constraint's output AND on the term, which cancels it); the constant term IS in the sum (the sketch
 // drops it); a mul term with coefficient 0 emits nothing.
+// vectors whose resize() leaves new elements uninitialised (trivial element types only): the rows of a 2^20-constraint circuit are 0.15 GB that several
+// threads fill right after -- zeroing them first, on one thread, was a fifth of the reader's time
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 struct RawR1CSBuilt {
-    std::vector<uint32_t> ptr[3], idx[3];
-    std::vector<HFr> val[3];
-    std::vector<HFr> wires;  // (want_wires) the full wire vector (Montgomery): [ONE, public..., secret..., products...]
+    RawVec<uint32_t> ptr[3], idx[3];
+    RawVec<HFr> val[3];
+    RawVec<HFr> wires;  // (want_wires) the full wire vector (Montgomery): [ONE, public..., secret..., products...]
     size_t n_public = 0;     // ONE included
     // How the wire vector follows from the values vector -- what a RESIDENT circuit keeps to assemble it on the device for every later proof:
     size_t n_values = 0;
-    std::vector<uint32_t> order;           // wire 1 + k holds witness order[k] + 1 (k < n_values): the public ones first, each group in witness order
-    std::vector<uint32_t> prod_a, prod_b;  // wire 1 + n_values + j = wire prod_a[j] * wire prod_b[j] (both operands are witness wires, never products)
+    RawVec<uint32_t> order;           // wire 1 + k holds witness order[k] + 1 (k < n_values): the public ones first, each group in witness order
+    RawVec<uint32_t> prod_a, prod_b;  // wire 1 + n_values + j = wire prod_a[j] * wire prod_b[j] (both operands are witness wires, never products)
     size_t values_at = 0, values_len = 0;  // the values string inside the text: offset of its first character and its length (values_at = 0: it had escapes)
 };
 
@@ -798,13 +810,9 @@ struct GateReader {
         gates.push_back(g);
         return true;
     }
-    void absorb(GateReader&& o) {  // the gates of the stretch that follows this one in the text
-        const size_t dm = muls.size(), da = adds.size();
-        muls.insert(muls.end(), o.muls.begin(), o.muls.end());
-        adds.insert(adds.end(), o.adds.begin(), o.adds.end());
-        gates.reserve(gates.size() + o.gates.size());
-        for (Gate g : o.gates) { g.m0 += dm; g.m1 += dm; g.a0 += da; g.a1 += da; gates.push_back(g); }
-    }
+    // after a read on several threads: the accepted readers of the stretches of the gates array, in text order (their gates index their OWN muls / adds;
+    // nothing is merged: 0.11 GB of terms at 2^20 constraints would be copied by one thread); empty after a read on one thread (this reader holds everything)
+    std::vector<GateReader> parts;
 };
 // A candidate cut between two GATES: a comma with '}' before and '{' after (acir_detail::find_element_comma) whose '{' opens an object that starts with one of a
 // gate's own keys -- the same bytes `},{` also separate the terms INSIDE a gate's mul_terms / add_terms arrays (objects that start with "coefficient"), and a
@@ -886,10 +894,13 @@ static inline bool elements_parallel(GateReader& M, unsigned nt) {
     for (size_t cur = 0;;) {
         Chunk& C = res[cur];
         const char* terr = C.R.T.err;
-        M.absorb(std::move(C.R));
-        if (C.failed) { M.T.fail(terr ? terr : "malformed gate"); return false; }
-        if (C.after) { M.T.p = C.after; return true; }
-        cur = (size_t)C.landed;
+        const bool failed = C.failed;
+        const char* after = C.after;
+        const int landed = C.landed;
+        M.parts.push_back(std::move(C.R));
+        if (failed) { M.T.fail(terr ? terr : "malformed gate"); return false; }
+        if (after) { M.T.p = after; return true; }
+        cur = (size_t)landed;
     }
 }
 }  // namespace raw_detail
@@ -899,9 +910,6 @@ static inline bool elements_parallel(GateReader& M, unsigned nt) {
 static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, std::string* err, bool want_wires = true) {
     using namespace raw_detail;
     GateReader M;
-    std::vector<MulT>& muls = M.muls;
-    std::vector<AddT>& adds = M.adds;
-    std::vector<Gate>& gates = M.gates;
     std::vector<double> pubs;      // numbers as read; kinds checked after (a non-number is NaN)
     const char* values = nullptr;  // a view of the text (or of `values_own` when the string had escapes)
     size_t values_n = 0;
@@ -983,9 +991,9 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
             if (!as_index(v, &w)) { *err = "RawR1CS JSON: bad public input"; return ZK_ERR_ARG; }
             if (w >= 1 && w <= n) is_pub[w] = true;
         }
-    std::vector<HFr>& wv = B->wires;
+    RawVec<HFr>& wv = B->wires;
     wv.clear();
-    if (want_wires) { wv.reserve(1 + n + muls.size()); wv.push_back(HFr::one()); }
+    if (want_wires) { wv.reserve(1 + n); wv.push_back(HFr::one()); }
     std::vector<uint32_t> wire(n + 1, 0);
     B->order.clear();
     B->order.reserve(n);
@@ -1011,14 +1019,36 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
     // From here on the gates are independent: the coefficients' Montgomery images, the rows and the solver's step run over stretches of the gate list on up to
     // sixteen threads -- a counting pass (rows, entries and product variables per stretch; the first malformed gate IN TEXT ORDER is the error, as in a loop over
     // all gates), then every stretch writes its rows where the counts say they go.  L has one entry per row (the multiplicand / ONE), O one per product row.
-    const size_t G = gates.size();
-    unsigned nt2 = (nt > 1 && (G >= 4096 || acir_detail::parallel_cfg().min_bytes == 0)) ? nt : 1;  // (min_bytes == 0: the mutation harness forces the threaded paths on short texts)
+    // The gates stay in the readers that read them (M.parts after a read on several threads): a stretch is a range of ONE reader's gates.
+    std::vector<GateReader*> readers;
+    if (M.parts.empty()) readers.push_back(&M);
+    else for (auto& r : M.parts) readers.push_back(&r);
+    size_t G = 0;
+    for (auto* r : readers) G += r->gates.size();
+    const unsigned nt2 = (nt > 1 && (G >= 4096 || acir_detail::parallel_cfg().min_bytes == 0)) ? nt : 1;  // (min_bytes == 0: the mutation harness forces the threaded paths on short texts)
     struct Stretch {
+        GateReader* R = nullptr;
         size_t g0 = 0, g1 = 0, rows = 0, nnz1 = 0, prods = 0;
         const char* bad = nullptr;
     };
-    std::vector<Stretch> st(nt2);
-    for (unsigned k = 0; k < nt2; k++) { st[k].g0 = G * k / nt2; st[k].g1 = G * (k + 1) / nt2; }
+    std::vector<Stretch> st;
+    {   // about G / nt2 gates per stretch, never across readers
+        const size_t per = G / nt2 + 1;
+        for (auto* r : readers)
+            for (size_t g0 = 0; g0 < r->gates.size(); g0 += per) {
+                Stretch S;
+                S.R = r;
+                S.g0 = g0;
+                S.g1 = g0 + per < r->gates.size() ? g0 + per : r->gates.size();
+                st.push_back(S);
+            }
+        if (st.empty()) {  // no gate at all
+            Stretch S;
+            S.R = readers[0];
+            st.push_back(S);
+        }
+    }
+    const unsigned ns = (unsigned)st.size();
     const HFr one = HFr::one();
     static const HFr minus_one = HFr::zero() - HFr::one();
     static const uint64_t RM1[4] = {HFrParams::MOD[0] - 1, HFrParams::MOD[1], HFrParams::MOD[2], HFrParams::MOD[3]};
@@ -1030,7 +1060,7 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
     };
     // one gate: its terms (equal wires merged, in order of first appearance).  Returns the first thing wrong with it, or null.
     typedef std::vector<std::pair<uint32_t, HFr>> Terms;
-    auto gate_terms = [&](const Gate& g, size_t prod0, Terms& terms, size_t* n_prods) -> const char* {
+    auto gate_terms = [&](const GateReader& Rd, const Gate& g, size_t prod0, Terms& terms, size_t* n_prods) -> const char* {
         if (!g.shape_ok) return "RawR1CS JSON: malformed gate";
         terms.clear();
         auto add_term = [&](uint32_t x, const HFr& c) {
@@ -1040,14 +1070,14 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
         };
         size_t np = 0;
         for (size_t i = g.m0; i < g.m1; i++) {
-            const MulT& t = muls[i];
+            const MulT& t = Rd.muls[i];
             if (!t.ok || t.a < 1 || t.a > n || t.b < 1 || t.b > n) return "RawR1CS JSON: malformed mul term";
             if (t.c.is_zero()) continue;
             add_term((uint32_t)(1 + n + prod0 + np), t.c);
             np++;
         }
         for (size_t i = g.a0; i < g.a1; i++) {
-            const AddT& t = adds[i];
+            const AddT& t = Rd.adds[i];
             if (!t.ok || t.x < 1 || t.x > n) return "RawR1CS JSON: malformed add term";
             add_term(wire[t.x], t.c);
         }
@@ -1058,23 +1088,24 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
     };
     auto count = [&](unsigned k) {
         Stretch& S = st[k];
+        GateReader& Rd = *S.R;
         Terms terms;
         for (size_t gi = S.g0; gi < S.g1; gi++) {
-            Gate& g = gates[gi];
-            for (size_t i = g.m0; i < g.m1; i++) if (muls[i].ok) mont(muls[i].c);
-            for (size_t i = g.a0; i < g.a1; i++) if (adds[i].ok) mont(adds[i].c);
+            Gate& g = Rd.gates[gi];
+            for (size_t i = g.m0; i < g.m1; i++) if (Rd.muls[i].ok) mont(Rd.muls[i].c);
+            for (size_t i = g.a0; i < g.a1; i++) if (Rd.adds[i].ok) mont(Rd.adds[i].c);
             if (g.k_ok) mont(g.k);
             size_t np = 0;
-            if (const char* e = gate_terms(g, 0, terms, &np)) { S.bad = e; return; }
+            if (const char* e = gate_terms(Rd, g, 0, terms, &np)) { S.bad = e; return; }
             S.prods += np;
             S.rows += np + 1;
             S.nnz1 += np + terms.size();
         }
     };
     auto on_threads = [&](const std::function<void(unsigned)>& f) {
-        if (nt2 == 1) { f(0); return; }
+        if (ns == 1) { f(0); return; }
         std::vector<std::thread> th;
-        for (unsigned k = 1; k < nt2; k++) {
+        for (unsigned k = 1; k < ns; k++) {
             try {
                 th.emplace_back(f, k);
             } catch (const std::system_error&) {
@@ -1085,50 +1116,54 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
         for (auto& t : th) t.join();
     };
     on_threads(count);
-    for (unsigned k = 0; k < nt2; k++)
+    for (unsigned k = 0; k < ns; k++)
         if (st[k].bad) { *err = st[k].bad; return ZK_ERR_ARG; }
     size_t rows = 0, nnz1 = 0, prods = 0;
-    std::vector<size_t> row0(nt2), nz0(nt2), pr0(nt2);
-    for (unsigned k = 0; k < nt2; k++) { row0[k] = rows; nz0[k] = nnz1; pr0[k] = prods; rows += st[k].rows; nnz1 += st[k].nnz1; prods += st[k].prods; }
+    std::vector<size_t> row0(ns), nz0(ns), pr0(ns);
+    for (unsigned k = 0; k < ns; k++) { row0[k] = rows; nz0[k] = nnz1; pr0[k] = prods; rows += st[k].rows; nnz1 += st[k].nnz1; prods += st[k].prods; }
     if (rows >= ((size_t)1 << 31) || nnz1 >= ((size_t)1 << 31) || 1 + n + prods >= ((size_t)1 << 31)) { *err = "RawR1CS JSON: too many constraints for 31-bit indices"; return ZK_ERR_ARG; }
-    for (int m = 0; m < 3; m++) B->ptr[m].assign(rows + 1, 0);
-    B->idx[0].assign(rows, 0); B->val[0].assign(rows, one);
+    // (uninitialised: every element below is written by the stretch that owns it -- first touched, too, by the thread that fills it)
+    for (int m = 0; m < 3; m++) { B->ptr[m].resize(rows + 1); B->ptr[m][0] = 0; }
+    B->idx[0].resize(rows); B->val[0].resize(rows);
     B->idx[1].resize(nnz1); B->val[1].resize(nnz1);
-    B->idx[2].resize(prods); B->val[2].assign(prods, one);
+    B->idx[2].resize(prods); B->val[2].resize(prods);
     B->prod_a.resize(prods);
     B->prod_b.resize(prods);
     if (want_wires) wv.resize(1 + n + prods);
     auto fill = [&](unsigned k) {
         const Stretch& S = st[k];
+        const GateReader& Rd = *S.R;
         Terms terms;
         size_t r = row0[k], z = nz0[k], p = pr0[k];
         for (size_t gi = S.g0; gi < S.g1; gi++) {
-            const Gate& g = gates[gi];
+            const Gate& g = Rd.gates[gi];
             size_t np = 0;
-            (void)gate_terms(g, p, terms, &np);
+            (void)gate_terms(Rd, g, p, terms, &np);
             for (size_t i = g.m0; i < g.m1; i++) {  // one product constraint per mul term with a non-zero coefficient: (1 * a) * (1 * b) = 1 * p
-                const MulT& t = muls[i];
+                const MulT& t = Rd.muls[i];
                 if (t.c.is_zero()) continue;
                 const uint32_t a = wire[t.a], b = wire[t.b];
                 B->prod_a[p] = a;
                 B->prod_b[p] = b;
                 if (want_wires) wv[1 + n + p] = wv[a] * wv[b];  // the solver's step for this internal variable (operands are witness wires)
-                B->idx[0][r] = a;
+                B->idx[0][r] = a; B->val[0][r] = one;
                 B->idx[1][z] = b; B->val[1][z] = one;
-                B->idx[2][p] = (uint32_t)(1 + n + p);
+                B->idx[2][p] = (uint32_t)(1 + n + p); B->val[2][p] = one;
                 z++; p++; r++;
+                B->ptr[0][r] = (uint32_t)r;
                 B->ptr[1][r] = (uint32_t)z;
                 B->ptr[2][r] = (uint32_t)p;
             }
             // the gate's sum constraint: (1 * ONE) * (sum of terms) = 0
+            B->idx[0][r] = 0; B->val[0][r] = one;
             for (auto& t : terms) { B->idx[1][z] = t.first; B->val[1][z] = t.second; z++; }
             r++;
+            B->ptr[0][r] = (uint32_t)r;
             B->ptr[1][r] = (uint32_t)z;
             B->ptr[2][r] = (uint32_t)p;
         }
     };
     on_threads(fill);
-    for (size_t i = 0; i <= rows; i++) B->ptr[0][i] = (uint32_t)i;
     B->n_public = npub;
     return ZK_OK;
 }

@@ -308,6 +308,13 @@ extern "C" int zk_warm_streams(int n) {
     return rc;
 }
 
+// The five slots of a Groth16 proof session with their high-priority streams (acquire_slots creates them: 3.5-10 ms each), ahead of the first proof: for a caller
+// that has other start-up work in flight -- the export shim's first ProveWithPK runs this beside the key's decoding.
+extern "C" int zk_warm_session_streams(void) {
+    SlotsGuard<5> g;
+    return acquire_slots(5, g.s);
+}
+
 void release_slot(Slot* s) {
     std::lock_guard<std::mutex> lk((s->owner ? *s->owner : ctx()).mu);  // whatever entry the releasing thread is on
     s->busy = false;

@@ -567,7 +567,7 @@ struct RawCircuit {
         if (!host) return set_err(ZK_ERR_ARG, "resident circuit lost its host form");
         uint64_t h = 0;
         ZK_TRY(r1cs_of_built(*host, &h));
-        auto up = [](uint32_t** d, const std::vector<uint32_t>& v) -> int {
+        auto up = [](uint32_t** d, const RawVec<uint32_t>& v) -> int {
             ZK_HIP(hipMalloc((void**)d, (v.size() ? v.size() : 1) * 4));
             if (!v.empty()) ZK_HIP(hipMemcpy(*d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
             return ZK_OK;

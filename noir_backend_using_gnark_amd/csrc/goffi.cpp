@@ -287,17 +287,23 @@ void groth16_start(GoString rawR1CS, const GoString* pk) {
     if (!first) return;
     Lap lap;
     std::promise<void> up;
-    std::future<void> is_up = up.get_future();
+    std::shared_future<void> is_up = up.get_future().share();
     std::thread starter([pk, &up] {
-        start_devices(5);  // the five stream slots of a Groth16 proof session
+        start_devices(2);  // two of the stream slots now; the proof session's five (with their high-priority streams) on a thread of their own, below
         up.set_value();
         if (pk) (void)zk_groth16_key_resident(pk->p, (size_t)pk->n);  // (errors resurface in the call proper)
+    });
+    std::thread streams([is_up] {  // the proof session's high-priority streams (3.5-10 ms each) as soon as there is a runtime, beside the key's decoding and the text
+        is_up.wait();
+        (void)zk_warm_session_streams();
     });
     (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 0);
     lap.lap("export.raw_lower_beside_start");
     is_up.wait();
     lap.lap("export.hip_start_wait");
     (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 1);  // the circuit goes to the device while the starter decodes the key
+    lap.lap("export.circuit_upload");
+    streams.join();
     starter.join();
     lap.lap("export.hip_start_and_key_wait");
 }

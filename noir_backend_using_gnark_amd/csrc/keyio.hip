@@ -605,19 +605,29 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     domain_bytes(dom, dom_ok);
     if (memcmp(dom_in, dom_ok, 168)) return set_err(ZK_ERR_ARG, "proving key: the domain is not gnark-crypto's radix-2 domain of that size");
     lap.lap("export.pk_read_header_domain");
-    // everything up to the bitmaps goes to the device (a multiple of 4 bytes by construction)
+    // Everything up to the bitmaps goes to the device (every section starts at a multiple of 4 bytes by construction) -- G2.B FIRST: its points are the expensive
+    // ones to decompress (an Fp2 square root and the subgroup test each), so their kernel runs on the slot's second stream while the other 0.24 GB of a
+    // 2^20-constraint key's text are still crossing PCIe on the first (round 5: 41 + 17 + 68 ms one after the other before).
     ZK_TRY(s->reserve((is_hex ? 2 * at_bm : 0) + at_bm + 4096));
     int* d_status = (int*)s->alloc(64);
     uint8_t* d_bytes = (uint8_t*)s->alloc(at_bm + 16);
+    uint8_t* d_text = is_hex ? (uint8_t*)s->alloc(2 * at_bm + 16) : nullptr;
+    hipStream_t sx = s->hi();  // decompression
     ZK_HIP(hipMemsetAsync(d_status, 0, 4, st));
-    if (is_hex) {
-        void* d_text = s->alloc(2 * at_bm + 16);
-        ZK_HIP(hipMemcpyAsync(d_text, data, 2 * at_bm, hipMemcpyHostToDevice, st));
-        ZK_TRY(hex_decode_dev(s, st, d_text, at_bm, d_bytes, d_status));
-    } else {
-        ZK_HIP(hipMemcpyAsync(d_bytes, data, at_bm, hipMemcpyHostToDevice, st));
-    }
-    if (profiling_on()) { ZK_TRY(slot_sync(s, st)); lap.lap("export.pk_read_upload_hex"); }
+    auto upload = [&](size_t from, size_t to) -> int {  // bytes [from, to) of the key image -> d_bytes, on `st`
+        if (to <= from) return ZK_OK;
+        if (is_hex) {
+            ZK_HIP(hipMemcpyAsync(d_text + 2 * from, (const char*)data + 2 * from, 2 * (to - from), hipMemcpyHostToDevice, st));
+            ZK_TRY(hex_decode_dev(s, st, d_text + 2 * from, to - from, d_bytes + from, d_status));
+        } else {
+            ZK_HIP(hipMemcpyAsync(d_bytes + from, (const char*)data + from, to - from, hipMemcpyHostToDevice, st));
+        }
+        return ZK_OK;
+    };
+    hipEvent_t ev_g2 = nullptr, ev_rest = nullptr;
+    struct Ev { hipEvent_t* e[2]; ~Ev() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } ev_guard{{&ev_g2, &ev_rest}};
+    ZK_HIP(hipEventCreateWithFlags(&ev_g2, hipEventDisableTiming));
+    ZK_HIP(hipEventCreateWithFlags(&ev_rest, hipEventDisableTiming));
     DevFree tmp, own;  // tmp: the compact A / B / G2.B and the five single points; own: K and Z, adopted by the key
     void *d_a = nullptr, *d_b = nullptr, *d_b2 = nullptr, *d_k = nullptr, *d_z = nullptr, *d_single = nullptr;
     ZK_TRY(tmp.alloc(&d_a, cnt[0] * 64));
@@ -626,18 +636,28 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     ZK_TRY(tmp.alloc(&d_single, 3 * 64 + 2 * 128));
     ZK_TRY(own.alloc(&d_z, cnt[2] * 64));
     ZK_TRY(own.alloc(&d_k, cnt[3] * 64));
-    ZK_TRY(g1_decompress_dev(s, st, d_bytes + 168, 3, d_single, d_status));
-    ZK_TRY(g2_decompress_dev(s, st, d_bytes + at_g2, 2, (uint8_t*)d_single + 192, d_status));
+    const size_t g2_end = at[4] + cnt[4] * 64;
+    ZK_TRY(upload(at[4], g2_end));
+    ZK_HIP(hipEventRecord(ev_g2, st));
+    ZK_HIP(hipStreamWaitEvent(sx, ev_g2, 0));
+    ZK_TRY(g2_decompress_dev(s, sx, d_bytes + at[4], cnt[4], d_b2, d_status));
+    lap.lap("export.pk_read_upload_g2_part");
+    ZK_TRY(upload(0, at[4]));
+    ZK_TRY(upload(g2_end, at_bm));
+    ZK_HIP(hipEventRecord(ev_rest, st));
+    ZK_HIP(hipStreamWaitEvent(sx, ev_rest, 0));
+    lap.lap("export.pk_read_upload_rest");
+    ZK_TRY(g1_decompress_dev(s, sx, d_bytes + 168, 3, d_single, d_status));
+    ZK_TRY(g2_decompress_dev(s, sx, d_bytes + at_g2, 2, (uint8_t*)d_single + 192, d_status));
     void* g1_dst[4] = {d_a, d_b, d_z, d_k};
-    for (int k = 0; k < 4; k++) ZK_TRY(g1_decompress_dev(s, st, d_bytes + at[k], cnt[k], g1_dst[k], d_status));
-    if (profiling_on()) { ZK_TRY(slot_sync(s, st)); lap.lap("export.pk_read_g1_decompress"); }
-    ZK_TRY(g2_decompress_dev(s, st, d_bytes + at[4], cnt[4], d_b2, d_status));
+    for (int k = 0; k < 4; k++) ZK_TRY(g1_decompress_dev(s, sx, d_bytes + at[k], cnt[k], g1_dst[k], d_status));
+    st = sx;  // the results are read back behind the decompression
     uint8_t single[3 * 64 + 2 * 128];
     int h_status = 0;
     ZK_HIP(hipMemcpyAsync(single, d_single, sizeof single, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipMemcpyAsync(&h_status, d_status, 4, hipMemcpyDeviceToHost, st));
     ZK_TRY(slot_sync(s, st));
-    lap.lap("export.pk_read_g2_decompress");
+    lap.lap("export.pk_read_decompress_wait");
     if (h_status & 1) return set_err(ZK_ERR_ARG, "proving key: invalid hex character");
     if (h_status & 4) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G1 point (bad flags, x >= q, or no square root)");
     if (h_status & 8) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G2 point (bad flags, coordinate >= q, or no square root)");

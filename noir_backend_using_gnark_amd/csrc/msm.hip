@@ -196,17 +196,16 @@ __global__ void k_msm_digits(DigitSrc src, uint32_t n, int mont, unsigned c, uns
 // device: the scan's last entry is what the sort, the bucket bounds and everything after read as their length (radix.hpp rs_len), so the host never waits for
 // it (round 4 copied it back and synchronised -- fine for PLONK's round 1, not for a Groth16 proof whose five multi-exps are enqueued in one go).
 // Same buckets, same sums: within a bucket the points arrive in another order, and the group law does not care.
-template <class Emit>
-__device__ __forceinline__ void digits_of(const Fr* __restrict__ scalars, uint32_t i, int mont, unsigned c, unsigned W, bool table, unsigned row_first, unsigned row_step,
-                                          Emit&& emit) {
+__device__ __forceinline__ Fr canonical_scalar(const Fr* __restrict__ scalars, uint32_t i, int mont) {
     Fr s;
-    {
-        const uint4* q = reinterpret_cast<const uint4*>(scalars + i);
-        uint4 a = q[0], b = q[1];
-        s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w;
-        s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
-    }
-    if (mont) s = s.from_mont();
+    const uint4* q = reinterpret_cast<const uint4*>(scalars + i);
+    uint4 a = q[0], b = q[1];
+    s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w;
+    s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
+    return mont ? s.from_mont() : s;
+}
+template <class Emit>
+__device__ __forceinline__ void digits_of(const Fr& s, unsigned c, unsigned W, bool table, unsigned row_first, unsigned row_step, Emit&& emit) {
     const uint32_t B = 1u << (c - 1);
     uint32_t carry = 0;
     unsigned next_row = row_first, wl = 0;
@@ -238,7 +237,9 @@ __device__ __forceinline__ void digits_of(const Fr* __restrict__ scalars, uint32
 // copies them out with consecutive lanes writing consecutive pairs.  The workgroups land in whatever order their atomics arrive: a sort's input has no order
 // to keep.  (Round 5's earlier forms, both measured on the uniform 2^20 proof, whose scalar preparation is on the critical path beside computeH: count + scan
 // over all scalars + write = two passes and three launches more than k_msm_digits, +0.16 ms; one pass with every lane writing its own run of pairs to global
-// memory -- 52-byte strides between lanes -- still +0.14 ms: profiles/rnd5_d_*, rnd5_e_*.)  Dynamic LDS: 256 * W pairs of 8 bytes.
+// memory -- 52-byte strides between lanes -- still +0.14 ms; staged through LDS but with the scalar read and converted twice +0.1 ms; this form -- read and
+// converted once, recoded twice, staged -- costs a uniform vector nothing (9.67-9.73 against 9.75 ms on one box) and a witness-like one 0.3-0.4 ms less:
+// profiles/rnd5_d_*, rnd5_e_*, rnd5_f_*, rnd5_g_*.)  Dynamic LDS: 256 * W pairs of 8 bytes.
 __global__ __launch_bounds__(256) void k_msm_digits_compact(DigitSrc src, uint32_t n, int mont, unsigned c, unsigned W, unsigned row_first, unsigned row_step,
                                                            uint32_t table_stride, uint32_t* __restrict__ total, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     prio_hi();
@@ -250,7 +251,11 @@ __global__ __launch_bounds__(256) void k_msm_digits_compact(DigitSrc src, uint32
     const uint32_t B = 1u << (c - 1), cap = 256u * W;
     const bool live = i < n;
     uint32_t k = 0;
-    if (live) digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned, uint32_t mag, uint32_t) { k += mag != 0; });
+    Fr sc = Fr::zero();
+    if (live) {
+        sc = canonical_scalar(src.p[vec], i, mont);  // read and converted once; recoded twice (count, then write)
+        digits_of(sc, c, W, table_stride != 0, row_first, row_step, [&](unsigned, uint32_t mag, uint32_t) { k += mag != 0; });
+    }
     // exclusive scan of k over the workgroup: inside the wave by shuffles, across the four waves through LDS
     uint32_t incl = k;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void k_msm_digits_compact(DigitSrc src, uint32
     if (threadIdx.x == 0) base = wg_total ? atomicAdd(total, wg_total) : 0;
     if (live && k) {
         uint32_t o = before + incl - k;
-        digits_of(src.p[vec], i, mont, c, W, table_stride != 0, row_first, row_step, [&](unsigned wl, uint32_t mag, uint32_t neg) {
+        digits_of(sc, c, W, table_stride != 0, row_first, row_step, [&](unsigned wl, uint32_t mag, uint32_t neg) {
             if (!mag) return;
             if (table_stride) {
                 stage[o] = vec * B + (mag - 1);
@@ -2100,7 +2105,7 @@ int zk_bn254_msm_bases_prepared(uint64_t bases, size_t bases_offset, uint64_t sc
             size_t np = 0, na1 = 0, na2 = 0;
             ZK_TRY(msm_prep_need_table(cnt, b.tab, pst, &np, &na1, &na2));
             ZK_TRY(N->ws.reserve(np + 16384));
-            ZK_TRY(msm_prepare_scalars_table(&N->ws, pst, (const char*)S->d_sc + skip * 32, cnt, &c1, b.tab, &N->prep));
+            ZK_TRY(msm_prepare_scalars_table(&N->ws, pst, (const char*)S->d_sc + skip * 32, cnt, &c1, b.tab, &N->prep, true));  // registered scalars are wire values: zero digits dropped
             if (profiling_on()) ZK_TRY(slot_sync(&N->ws, pst));  // the event pairs of these launches sit in the private workspace: folded here
             N->ws.stream = nullptr;  // (not ours; prep.ready orders the readers behind the preparation)
             S->geos.push_back(N);

@@ -63,7 +63,8 @@ static int failures = 0;
         }                                                       \
     } while (0)
 
-static bool same_frs(const std::vector<zkmi::HFr>& a, const std::vector<zkmi::HFr>& b) { return a.size() == b.size() && (a.empty() || !memcmp(a.data(), b.data(), a.size() * 32)); }
+template <class VA, class VB>
+static bool same_frs(const VA& a, const VB& b) { return a.size() == b.size() && (a.empty() || !memcmp(a.data(), b.data(), a.size() * 32)); }
 
 static void check_acir(const std::string& text, size_t n_values, int layout, const char* what, size_t id) {
     zkmi::Gates G, W;
@@ -100,6 +101,8 @@ static void check_acir(const std::string& text, size_t n_values, int layout, con
     CHECK(W.xa == D.xa && W.xb == D.xb && W.xc == D.xc && W.order == D.order && W.n_public == D.n_public, "%s #%zu: wiring-only mode", what, id);
 }
 
+template <class A, class B>
+static bool same_words(const A& a, const B& b) { return a.size() == b.size() && std::equal(a.begin(), a.end(), b.begin()); }
 static void check_raw(const std::string& text, const char* what, size_t id) {
     zkmi::RawR1CSBuilt B;
     std::string err;
@@ -126,7 +129,7 @@ static void check_raw(const std::string& text, const char* what, size_t id) {
     }
     if (rc != ZK_OK || rd != ZK_OK) return;
     bool same = B.n_public == D.n_public && same_frs(B.wires, D.wires);
-    for (int m = 0; m < 3; m++) same = same && B.ptr[m] == D.ptr[m] && B.idx[m] == D.idx[m] && same_frs(B.val[m], D.val[m]);
+    for (int m = 0; m < 3; m++) same = same && same_words(B.ptr[m], D.ptr[m]) && same_words(B.idx[m], D.idx[m]) && same_frs(B.val[m], D.val[m]);
     CHECK(same, "%s #%zu: R1CS rows / wires differ", what, id);
     // what a resident circuit keeps to assemble the wire vector on the device: the same wires from (values, order, products), and the circuit alone (no values
     // decoded) is the same circuit
