@@ -80,7 +80,9 @@ int zk_init_devices(const int *devices, size_t n);
  * 40-160 ms (tools/hip_start_bench.hip), so the library creates them when a slot is first used -- or here, for a caller that has host work to do meanwhile (the
  * export shim reads srs.hex).  n slots of the calling thread's device entry (at most all 8). */
 int zk_warm_streams(int n);
-/* The same for the five slots of a Groth16 proof session INCLUDING their high-priority streams (what zk_bn254_groth16_prove takes at once). */
+/* The same for the five slots of a Groth16 proof session INCLUDING their high-priority streams (what zk_bn254_groth16_prove takes at once).  After
+ * zk_init_flags(ZK_INIT_LEAN_STREAMS) this is also what ALLOWS those streams: until it is called a lean process runs every chain on the slots' own streams (its
+ * first proof creates no stream; the export path calls it when a key's second proof is asked for). */
 int zk_warm_session_streams(void);
 /* Process-wide start-up choices; call before anything that touches a device.  ZK_INIT_LEAN_STREAMS: a device entry creates only the five streams every caller
  * needs with itself and every other stream on first use (the default also creates the five high-priority streams of a Groth16 proof session up front: 40 ms more

@@ -32,6 +32,10 @@ static std::atomic<int> g_n_entries{0};
 static std::mutex g_entries_mu;
 static thread_local int t_entry = 0;
 static std::atomic<bool> g_lean_start{false};  // zk_init_flags(ZK_INIT_LEAN_STREAMS)
+// After a lean start the high-priority streams are not created AT ALL until somebody asks for them (zk_warm_session_streams): hi() hands out the slot's own
+// stream -- the fallback that has always existed for a failed hipStreamCreateWithPriority -- so a process's first proof pays no stream creation (five streams
+// at 3.5-10 ms each, serialised with every other runtime call of the start-up: the cold ProveWithPK of profiles/rnd5_h_*) for a schedule refinement worth 1-3 %.
+static std::atomic<bool> g_hi_streams_wanted{true};
 
 Prof& prof() {
     static Prof p;
@@ -211,6 +215,7 @@ hipStream_t Slot::hi() {
     return hi_locked();
 }
 hipStream_t Slot::hi_locked() {  // under owner->mu
+    if (!stream_hi_ && !g_hi_streams_wanted.load()) return stream;
     if (!stream_hi_) {
         int cur = owner->device;
         (void)hipGetDevice(&cur);
@@ -294,6 +299,7 @@ int acquire_slots(int k, Slot** out) {
 extern "C" int zk_init_flags(uint32_t flags) {
     if (flags & ~(uint32_t)ZK_INIT_LEAN_STREAMS) return set_err(ZK_ERR_ARG, "unknown start-up flags 0x%x", flags);
     g_lean_start.store((flags & ZK_INIT_LEAN_STREAMS) != 0);
+    g_hi_streams_wanted.store((flags & ZK_INIT_LEAN_STREAMS) == 0);
     return ZK_OK;
 }
 extern "C" int zk_warm_streams(int n) {
@@ -311,6 +317,7 @@ extern "C" int zk_warm_streams(int n) {
 // The five slots of a Groth16 proof session with their high-priority streams (acquire_slots creates them: 3.5-10 ms each), ahead of the first proof: for a caller
 // that has other start-up work in flight -- the export shim's first ProveWithPK runs this beside the key's decoding.
 extern "C" int zk_warm_session_streams(void) {
+    g_hi_streams_wanted.store(true);  // (after a lean start: from now on hi() creates them)
     SlotsGuard<5> g;
     return acquire_slots(5, g.s);
 }

@@ -993,6 +993,8 @@ int zk_groth16_prove_with_pk(const char* raw_json, size_t raw_len, const char* p
         }
         if (build) {
             Phase ph;
+            (void)zk_warm_session_streams();  // a key that proves again: the schedule's high-priority streams too (a lean process has none until now)
+            ph.lap("export.session_streams");
             int built = 0;
             ZK_TRY(zk_bn254_groth16_pk_build_tables(h, 0, &built));
             size_t bytes = 0;

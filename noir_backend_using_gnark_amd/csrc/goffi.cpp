@@ -228,6 +228,8 @@ void srs_for_repeat_use() {
     must(zk_bn254_bases_build_table(g_srs.handle, 0), "SRS window tables");
     g_srs.tables = true;
     lap.lap("export.srs_window_tables");
+    (void)zk_warm_session_streams();  // a process that proves again also gets the high-priority streams a lean start withheld (csrc/ctx.hip)
+    lap.lap("export.session_streams");
 }
 // plonk.Verify takes two G2 points from the SRS and nothing else (kzg.Verify's pairing check; the reference re-reads the whole file for them,
 // backend/plonk/plonk.go:34).  A process that has not proved anything reads them from the file's header on the host: it never starts the HIP runtime.
@@ -289,13 +291,9 @@ void groth16_start(GoString rawR1CS, const GoString* pk) {
     std::promise<void> up;
     std::shared_future<void> is_up = up.get_future().share();
     std::thread starter([pk, &up] {
-        start_devices(2);  // two of the stream slots now; the proof session's five (with their high-priority streams) on a thread of their own, below
+        start_devices(5);  // the five stream slots of a Groth16 proof session (no high-priority streams after a lean start: csrc/ctx.hip)
         up.set_value();
         if (pk) (void)zk_groth16_key_resident(pk->p, (size_t)pk->n);  // (errors resurface in the call proper)
-    });
-    std::thread streams([is_up] {  // the proof session's high-priority streams (3.5-10 ms each) as soon as there is a runtime, beside the key's decoding and the text
-        is_up.wait();
-        (void)zk_warm_session_streams();
     });
     (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 0);
     lap.lap("export.raw_lower_beside_start");
@@ -303,7 +301,6 @@ void groth16_start(GoString rawR1CS, const GoString* pk) {
     lap.lap("export.hip_start_wait");
     (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 1);  // the circuit goes to the device while the starter decodes the key
     lap.lap("export.circuit_upload");
-    streams.join();
     starter.join();
     lap.lap("export.hip_start_and_key_wait");
 }

@@ -497,26 +497,37 @@ int md_groth16_prove(uint64_t h, const void* a, const void* b, const void* c, si
         if (int r = zk_bn254_groth16_msm5_pk_begin(K->sub[k], d_w, &session)) return fail(r);
         struct Abort { uint64_t* s; ~Abort() { if (*s) (void)zk_bn254_groth16_msm5_pk_abort(*s); } } abort_guard{&session};
         if (!X.bar.wait()) return set_err(ZK_ERR_HIP, "another entry failed");  // every block and exchange target exists from here on
-        // ---- computeH, six-transform schedule (include/zkmi.h, zk_bn254_groth16_h_shard_dev)
-        void** cur[3] = {&xa[k], &xb[k], &xc[k]};
+        // ---- computeH, six-transform schedule (include/zkmi.h, zk_bn254_groth16_h_shard_dev).  The nine transposes travel on the slot's SECOND stream, one
+        // array ahead of the arithmetic: while the phase kernels of array i run on `st`, array i + 1 is already crossing the links on `sc` (round 4 ran both on
+        // one stream and drained it at every transpose: exchange and arithmetic strictly alternated).  ready[i] = the last kernel that wrote array i.
         std::vector<void*>* arrs[3] = {&xa, &xb, &xc};
+        hipStream_t sc = g.s->stream;
+        hipEvent_t ready[3] = {nullptr, nullptr, nullptr};
+        struct Ev { hipEvent_t* e; ~Ev() { for (int i = 0; i < 3; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ready};
+        for (int i = 0; i < 3; i++) {
+            if (hipEventCreateWithFlags(&ready[i], hipEventDisableTiming) != hipSuccess || hipEventRecord(ready[i], st) != hipSuccess) return fail(set_err(ZK_ERR_HIP, "event setup failed"));
+        }
+        auto mark = [&](int i) -> int { return hipEventRecord(ready[i], st) == hipSuccess ? ZK_OK : set_err(ZK_ERR_HIP, "hipEventRecord failed"); };
         auto phase = [&](int ph, void* pa, void* pb, void* pc) { return zk_bn254_groth16_h_shard_dev(ph, pa, pb, pc, K->log_domain, lg, (uint32_t)k, (void*)st); };
-        // one transpose of array i: into the spare block, which then IS the array (the old block becomes the spare).  All members swap alike.
+        // one transpose of array i: into the spare block, which then IS the array (the old block becomes the spare).  All members swap alike.  The sends wait for
+        // the array's last kernel, the host waits for the sends (the arithmetic of the other arrays goes on meanwhile), and after the barrier every member's new
+        // block is complete: kernels enqueued on `st` from here on may read it.
         auto transpose = [&](int i) -> int {
-            ZK_TRY(X.run(k, arrs[i]->data(), xt.data(), chunk, st));
+            if (hipStreamWaitEvent(sc, ready[i], 0) != hipSuccess) return fail(set_err(ZK_ERR_HIP, "hipStreamWaitEvent failed"));
+            ZK_TRY(X.run(k, arrs[i]->data(), xt.data(), chunk, sc));
             std::swap((*arrs[i])[k], xt[k]);
             if (!X.bar.wait()) return set_err(ZK_ERR_HIP, "another entry failed");  // every member has swapped before anyone sends again
             return ZK_OK;
         };
-        (void)cur;
-        for (int i = 0; i < 3; i++) if (int r = transpose(i)) return r;
-        for (int i = 0; i < 3; i++) if (int r = phase(0, (*arrs[i])[k], nullptr, nullptr)) return fail(r);
-        for (int i = 0; i < 3; i++) if (int r = transpose(i)) return r;
-        for (int i = 0; i < 2; i++) if (int r = phase(1, (*arrs[i])[k], nullptr, nullptr)) return fail(r);
-        if (int r = phase(6, xc[k], nullptr, nullptr)) return fail(r);
-        for (int i = 0; i < 2; i++) if (int r = transpose(i)) return r;
-        for (int i = 0; i < 2; i++) if (int r = phase(4, (*arrs[i])[k], nullptr, nullptr)) return fail(r);
+        auto one = [&](int ph, int i) -> int {  // a phase on array i alone
+            if (int r = phase(ph, (*arrs[i])[k], nullptr, nullptr)) return fail(r);
+            return mark(i) == ZK_OK ? ZK_OK : fail(ZK_ERR_HIP);
+        };
+        for (int i = 0; i < 3; i++) { if (int r = transpose(i)) return r; if (int r = one(0, i)) return r; }
+        for (int i = 0; i < 3; i++) { if (int r = transpose(i)) return r; if (int r = one(i < 2 ? 1 : 6, i)) return r; }
+        for (int i = 0; i < 2; i++) { if (int r = transpose(i)) return r; if (int r = one(4, i)) return r; }
         if (int r = phase(7, xa[k], xb[k], nullptr)) return fail(r);
+        if (mark(0) != ZK_OK) return fail(ZK_ERR_HIP);
         if (int r = transpose(0)) return r;
         if (int r = phase(8, xa[k], nullptr, xc[k])) return fail(r);
         // ---- the five MSMs of this slice against this block of h (still in flight on st: the session orders itself behind it)
