@@ -324,6 +324,18 @@ def main():
             blk["cpu_oracle"] = {"prove_ms": round(cpu_s * 1e3, 1), "cores": cores, "proof_bytes_match_gpu": bool(cpu_proof == p24)}
             if cpu_proof != p24:
                 out["parity_error"] = "2^24: GPU proof bytes differ from the CPU oracle's"
+        if args.scalars == "uniform":  # the same key with a witness-like wire vector (50 % in {0, 1}, 25 % below 2^32, 25 % uniform): its zero digits never enter the sort
+            d_w24 = _lib.DeviceBuffer(big.N * 32)
+            _lib.check(L.zk_bn254_fr_random_dev(C.c_void_p(d_w24.ptr), C.c_size_t(big.N), C.c_uint64(seed_at(0xC, 5, 0)), C.c_int(1), C.c_int(1), None))
+            run_w24 = lambda: zk.prove(big.pk, big.d_a, big.d_b, big.d_c, d_w24, big.r, big.s, n_constraints=big.N, on_device=True)
+            pw24 = run_w24()
+            _lib.check(L.zk_dev_sync())
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pw24b = run_w24()
+            w_ms24 = (time.perf_counter() - t0) / reps * 1e3
+            blk["prove_ms_witness_like_scalars"] = {"value": round(w_ms24, 2), "reps": reps, "deterministic": bool(pw24 == pw24b)}
+            d_w24.free()
         out["at_2p24"] = blk
         big.free()
         inst = None

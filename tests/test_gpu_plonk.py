@@ -137,7 +137,7 @@ def test_plonk_random_circuits_vs_oracle(nc, nvars, npub):
     kern, _ = _lib.split_profile(_lib.profile_read())
     _lib.profile(False)
     assert ("plonk_blind_tail" in kern) == (n + 2 >= 4096), sorted(kern)
-    if nc == 1000:  # other blinders through the two extra points (one size, a small one: the oracle's prover is the slow part of this test)
+    if nc == 4093:  # other blinders through the two extra points (one size: the oracle's prover is the slow part of this test)
         other = ref.rand_felts(990 + nc, 9)
         assert zp.prove(pk2, M(sol), M(other)) == pl.plonk_proof_bytes(pl.plonk_prove(opk, sol, other, fast=True))
     pk2.free()
