@@ -1025,7 +1025,7 @@ def test_window_tables_built_after_registration():
     small.build_table()  # below 4096 bases the planner builds none
     assert (small.multi_exp(sc[:100], MONT) == orc.g1_msm(pts[:100], sc[:100])).all()
     with pytest.raises(_lib.ZkmiError):
-        small.build_table(23)
+        small.build_table(25)
     small.free()
     with pytest.raises(_lib.ZkmiError):
         small.build_table()
