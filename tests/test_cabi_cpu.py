@@ -1,5 +1,6 @@
 """CPU suite: the C-ABI library loads without a GPU, exports every symbol include/zkmi.h declares, fails loudly (no CPU
 fallback) and its host-side arithmetic (Horner / affine conversion / partial-sum combine) agrees with the oracle."""
+import json
 import os
 import re
 
@@ -269,3 +270,38 @@ def test_go_abi_shim_exports_the_reference_symbols():
     assert L.PlonkVerifyWithMeta(g, g, g) == 0
     L.VerifyWithMeta.restype = C.c_ubyte
     assert L.VerifyWithMeta(g, g) == 0
+
+
+def test_groth16_resident_circuit_and_public_inputs_on_the_host():
+    """The host side of the Groth16 export path needs no device (a process that only verifies never starts the HIP runtime): zk_groth16_lower_resident reads a
+    RawR1CS text into the cache, zk_groth16_public_inputs returns buildWitnesses' public part (r1cs.go:176-212) -- the values of the public wires after ONE, in
+    wire order -- for that text AND for a second assignment of the same circuit without reading the gates again (one resident circuit, found by the content keys
+    of the text either side of its values string); a text that differs outside the values string is another circuit; a non-hex or non-canonical values string, a
+    truncated text and a public input out of range are refused with upstream's kinds of error."""
+    from noir_backend_using_gnark_amd import frontend as fe
+    from tools import synth_raw_r1cs as sr
+    L = _lib.lib()
+    assert L.zk_export_cache_clear() == 0
+    raw, w = sr.synth(300, 3, seed=0x77)
+    raw2, w2 = sr.synth(300, 3, seed=0x77, first=(5, 6))
+    fe.groth16_lower_resident(raw)
+    assert fe.export_cache_info()["circuits"] == 1
+    want = lambda ws: [v % ref.R for v in ws[:3]]
+    from oracle import plonk_ref as pl
+    assert pl.mont_np_to_ints(fe.groth16_public_inputs(raw)) == want(w)
+    assert pl.mont_np_to_ints(fe.groth16_public_inputs(raw2)) == want(w2)
+    assert fe.export_cache_info()["circuits"] == 1
+    # the oracle's buildR1CS agrees on which wires are public and in which order
+    r1, wv = pl.r1cs_from_raw(json.loads(raw))
+    assert r1.n_public == 4 and list(wv[1:4]) == want(w)
+    other = raw.replace('"public_inputs":[1,2,3]', '"public_inputs":[3,1]')
+    assert other != raw and pl.mont_np_to_ints(fe.groth16_public_inputs(other)) == [w[0], w[2]]   # wire order = witness order, whatever the list's order
+    assert fe.export_cache_info()["circuits"] == 2
+    at = raw.index('"values":"') + len('"values":"')
+    for bad in (raw[:at + 8] + "zz" + raw[at + 10:],                      # not hex
+                raw[:at + 8] + "f" * 64 + raw[at + 72:],                  # >= r: not a canonical fr.Element
+                raw[:at + 7] + raw[at + 8:],                              # one character short: the count no longer matches
+                raw[:-40]):                                               # truncated JSON
+        with pytest.raises(ValueError):
+            fe.groth16_public_inputs(bad)
+    assert L.zk_export_cache_clear() == 0 and fe.export_cache_info() == {"circuits": 0, "keys": 0, "bytes": 0}
