@@ -946,17 +946,18 @@ def test_ntt_2p26_identity_and_sharded_equivalence():
 
 
 def test_groth16_2p20_proof_bytes_vs_oracle():
-    """BASELINE configs[1] itself inside the suite (bench.py re-checks it after its timed region): the 128 proof bytes of the synthetic 2^20-constraint
-    instance -- resident key with window tables, the whole single-call schedule -- equal the bytes the CPU oracle (oracle/bn254_oracle.c, OpenMP) computes
-    for the same key, a, b, c, w, r, s; for uniform and for witness-like wire values (giant buckets, adaptive task lengths)."""
+    """BASELINE configs[1]'s size inside the suite with the wire vector real circuits have: the 128 proof bytes of the synthetic 2^20-constraint instance --
+    resident key with window tables, the whole single-call schedule, WITNESS-LIKE wire values (giant buckets, adaptive task lengths, zero digits dropped before the
+    sort with the pair count left on the device) -- equal the bytes the CPU oracle (oracle/bn254_oracle.c, OpenMP) computes for the same key, a, b, c, w, r, s.
+    (The uniform instance of this size is compared with the oracle by every bench.py run after its timed region, and at 2^24 by the test below.)"""
     import bench
     L = _lib.lib()
-    for witness in (0, 1):
-        inst = bench.Instance(L, _lib, zk, 20, 0, bench.N_PUBLIC, witness, True)
-        got = zk.prove(inst.pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True)
-        want, _, _ = bench.oracle_proof(inst, 20)
-        inst.free()
-        assert got == want, "witness-like" if witness else "uniform"
+    inst = bench.Instance(L, _lib, zk, 20, 0, bench.N_PUBLIC, 1, True)
+    got = zk.prove(inst.pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True)
+    again = zk.prove(inst.pk, inst.d_a, inst.d_b, inst.d_c, inst.d_w, inst.r, inst.s, n_constraints=inst.N, on_device=True)
+    want, _, _ = bench.oracle_proof(inst, 20)
+    inst.free()
+    assert got == want and again == want
 
 
 def test_lagrange_form_of_a_base_array_vs_oracle():
