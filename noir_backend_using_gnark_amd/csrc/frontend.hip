@@ -623,7 +623,10 @@ static void g16_free_keys(const std::vector<uint64_t>& hs) {
 }
 
 // the circuit behind a RawR1CS text: from the cache (*values_at = where this text keeps its values string), or read now
-static int raw_circuit_get(const char* raw, size_t len, std::shared_ptr<RawCircuit>* out, size_t* values_at) {
+// `pending` (optional): with exactly one resident circuit that fits this text structurally, return it AT ONCE and let the content keys be compared on other
+// threads -- *pending then says whether it really is this text's circuit; the caller may meanwhile do anything that only touches the candidate's scratch buffers
+// (upload, decode and assemble the values: 1 of the 3 ms the keys take at 2^20 constraints) and must look at *pending before it uses the circuit itself.
+static int raw_circuit_get(const char* raw, size_t len, std::shared_ptr<RawCircuit>* out, size_t* values_at, std::future<bool>* pending = nullptr) {
     Phase ph;
     // candidates: the resident circuits whose span fits this text -- quotes at both ends, the same count header
     std::vector<std::shared_ptr<RawCircuit>> cand;
@@ -633,6 +636,28 @@ static int raw_circuit_get(const char* raw, size_t len, std::shared_ptr<RawCircu
             if (c->entry == current_entry() && c->head_len + c->span_len + c->tail_len == len && c->head_len >= 1 && raw[c->head_len - 1] == '"' &&
                 raw[c->head_len + c->span_len] == '"')
                 cand.push_back(c);
+    }
+    if (pending && cand.size() == 1) {
+        std::shared_ptr<RawCircuit> c = cand[0];
+        size_t n = 0;
+        if (count_from_hex(raw + c->head_len, c->span_len, &n) && n == c->n_values) {
+            *pending = std::async(std::launch::async, [raw, c] {
+                const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                std::future<ContentKey> tail = std::async(std::launch::async, [raw, c] { return content_key(raw + c->head_len + c->span_len, c->tail_len); });
+                const ContentKey head = content_key(raw, c->head_len);
+                const bool same = tail.get() == c->tail && head == c->head;
+                prof_host("export.raw_content_key", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+                return same;
+            });
+            {
+                std::lock_guard<std::mutex> lk(g_cache_mu);
+                for (auto it = g_raw.begin(); it != g_raw.end(); ++it)
+                    if (it->get() == c.get()) { g_raw.splice(g_raw.begin(), g_raw, it); break; }
+            }
+            *out = c;
+            *values_at = c->head_len;
+            return ZK_OK;
+        }
     }
     for (auto& c : cand) {
         size_t n = 0;
@@ -964,12 +989,26 @@ int zk_groth16_prove_with_pk(const char* raw_json, size_t raw_len, const char* p
     if (pk_hex) pk_key = std::async(std::launch::async, [pk_hex, pk_len] { return content_key(pk_hex, pk_len); });
     std::shared_ptr<RawCircuit> C;
     size_t at = 0;
-    ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+    std::future<bool> same_circuit;  // (joins in its destructor: an early return leaves the caller's text alone)
+    ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at, &same_circuit));
     ZK_TRY(ensure_init());
-    std::lock_guard<std::mutex> work(C->work);
-    if (at) {
+    std::unique_lock<std::mutex> work(C->work);
+    if (same_circuit.valid()) {
+        // a resident circuit fits this text and its content keys are being compared: this proof's values go to the device meanwhile (they only touch scratch buffers)
+        const int rw = raw_wires_on_device(*C, raw_json + at, C->span_len);
+        if (!same_circuit.get()) {  // another circuit after all: read the text
+            work.unlock();
+            C.reset();
+            ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+            work = std::unique_lock<std::mutex>(C->work);
+            if (at) ZK_TRY(raw_wires_on_device(*C, raw_json + at, C->span_len));
+        } else {
+            ZK_TRY(rw);
+        }
+    } else if (at) {
         ZK_TRY(raw_wires_on_device(*C, raw_json + at, C->span_len));
-    } else {  // a values string written with escapes has no view in the text: the general reader decodes it and runs the solver's step on the host
+    }
+    if (!at) {  // a values string written with escapes has no view in the text: the general reader decodes it and runs the solver's step on the host
         RawR1CSBuilt B;
         std::string err;
         const int rb = raw_r1cs_build(raw_json, raw_len, &B, &err);

@@ -117,6 +117,11 @@ def test_groth16_exports_at_2p11_constraints_and_the_export_worker(tmp_path):
         assert k not in pr["warm_phases_per_call"] or (k == "circuit_to_device" and pr["warm_phases_per_call"][k] < 0.05), k
     ver = run("verify", d)
     assert ver["verifies"] == 1 and ver["device_entries"] == 0 and "hip_init" not in ver["cold_phases"]
+    # ZKMI_TABLE_CAP_GB=0 keeps nothing between calls (the sketch's behaviour: everything read again per call): the proofs still verify
+    r0 = subprocess.run(exe + ["prove", d, "2"], capture_output=True, text=True, timeout=900, env=dict(env, ZKMI_TABLE_CAP_GB="0"), check=True)
+    p0 = json.loads(r0.stdout.strip().splitlines()[-1])
+    assert p0["verifies"] == 1 and p0["warm_proof_verifies"] == 1 and p0["wrong_public_input_rejected"] == 1 and p0["resident"]["circuits"] == 0 and p0["resident"]["keys"] == 0
+    assert "raw_parse_lower" in p0["warm_phases_per_call"] and "pk_read" in p0["warm_phases_per_call"]
     # the oracle: the key image reads back, the pairing check accepts the cold proof under the text's public inputs
     raw = json.loads((tmp_path / "raw.json").read_text())
     r1, wv = pl.r1cs_from_raw(raw)
