@@ -1229,8 +1229,7 @@ static inline ContentKey content_key(const char* p, size_t n) {
         for (size_t k = lo; k < hi; k++) ck_segment(p + k * SEG, k + 1 == nseg ? n - k * SEG : SEG, k, &d[2 * k], masks);
     };
     unsigned nt = nseg < 64 ? 1 : std::thread::hardware_concurrency();
-    const unsigned cap = n > ((size_t)96 << 20) ? 32 : 16;  // (texts of 0.1 GB and more -- a 2^20-constraint RawR1CS, its key -- are worth a thread per 8 MB: the content keys are 3 of the 15 ms of a warm ProveWithPK)
-    if (nt > cap) nt = cap;
+    if (nt > 16) nt = 16;  // (32 threads for the 0.26 + 0.37 GB of a 2^20-constraint call were measured: no faster -- the host's memory feeds them, not its cores)
     if (nt <= 1) run(0, nseg);
     else {
         std::vector<std::thread> th;
