@@ -238,7 +238,8 @@ def test_groth16_export_caches_change_no_byte_at_2p11_constraints():
     no tables), the second (tables built), a warm one, one after zk_export_cache_clear and the uncached chain zk_groth16_r1cs_from_raw (wire vector
     assembled on the HOST) -> zk_bn254_groth16_pk_read -> zk_bn254_groth16_prove_r1cs all give the same 128 bytes; another assignment of the same circuit
     reuses the resident circuit and gives another proof, which the host verifier accepts under its own public inputs only; the oracle's pairing verifier accepts
-    the first proof under the key image Preprocess wrote; a text that differs OUTSIDE the values string is another circuit."""
+    the first proof under the key image Preprocess wrote; a text that differs OUTSIDE the values string is another circuit; another key of the same length is
+    another key (the warm path's speculative proof with the resident one is dropped)."""
     from noir_backend_using_gnark_amd import frontend as fe
     from noir_backend_using_gnark_amd import verify as vf
     from tools import synth_raw_r1cs as sr
@@ -286,6 +287,13 @@ def test_groth16_export_caches_change_no_byte_at_2p11_constraints():
     raw3 = raw[:at] + ("1" if raw[at] != "1" else "2") + raw[at + 1:]
     p3 = fe.groth16_prove_with_pk(raw3, pk_hex, rs)
     assert fe.export_cache_info()["circuits"] == 2 and p3 != first
+    # another key of the SAME length for the first circuit while the first key is warm (tables built by the call above): the warm path proves with the resident
+    # key of that length while the texts are still being compared, and must drop that proof -- what comes back is the second key's
+    pk2_hex, vk2_hex = fe.groth16_preprocess(raw, mont_limbs(list(ref.rand_felts(0xC2, 5))))
+    assert len(pk2_hex) == len(pk_hex) and pk2_hex != pk_hex
+    q = bytes.fromhex(fe.groth16_prove_with_pk(raw, pk2_hex, rs))
+    assert vf.groth16_verify(q, vk2_hex, pub) and not vf.groth16_verify(q, vk_hex, pub)
+    assert fe.groth16_prove_with_pk(raw, pk_hex, rs) == first
     with pytest.raises(ValueError):
         fe.groth16_prove_with_pk(raw.replace(sr.felts_wire_hex(w)[8:72], "g" * 64), pk_hex, rs)  # a non-hex values string of the right length: the device decoder says so
     fe.export_cache_clear()
