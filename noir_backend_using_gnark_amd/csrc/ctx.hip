@@ -422,6 +422,71 @@ int slot_sync(Slot* s, hipStream_t st) {
     return ZK_OK;
 }
 
+// Pageable host memory -> HBM for the big one-off uploads of a process's first call (a key text of 0.37 GB, a constraint system of 0.2 GB).  hipMemcpy pins the
+// caller's pages on first touch: 14.5 GB/s for a text that was just read, a third of that when two threads upload at once (tools/h2d_bench.hip,
+// profiles/rnd5_p_h2d_bench.jsonl: the cold ProveWithPK at 2^20 spent 90-108 ms on 0.53 GB).  Here four threads copy 8 MB pieces into a ring of pinned buffers
+// and enqueue them on `st` themselves -- 24-25 GB/s, no pinning of the caller's pages -- one upload at a time per device entry.  Returns when `src` has been read
+// and every piece is enqueued: like hipMemcpyAsync from pageable memory, the data is in place in stream order.  Copies below 1 MB take the runtime's own path.
+int h2d_big(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    constexpr size_t PIECE = (size_t)8 << 20;
+    constexpr int T = 4;
+    static const size_t tmp_min = getenv("ZKMI_TMP_H2D_MIN_MB") ? (size_t)atol(getenv("ZKMI_TMP_H2D_MIN_MB")) << 20 : ((size_t)1 << 20);  // TEMPORARY (batch U)
+    if (bytes < tmp_min) {
+        if (bytes) ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return ZK_OK;
+    }
+    struct Ring {
+        std::mutex mu;
+        char* buf[T] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev[T] = {nullptr, nullptr, nullptr, nullptr};
+        bool in_flight[T] = {false, false, false, false};
+    };
+    static Ring* rings = new Ring[MAX_ENTRIES];  // (never destroyed: the runtime may be gone before a static destructor would free into it)
+    const int entry = current_entry();
+    Ring& R = rings[entry];
+    const auto t_in = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lk(R.mu);
+    const auto t_lock = std::chrono::steady_clock::now();
+    for (int t = 0; t < T; t++)
+        if (!R.buf[t]) {
+            ZK_HIP(hipHostMalloc((void**)&R.buf[t], PIECE, hipHostMallocPortable));
+            ZK_HIP(hipEventCreateWithFlags(&R.ev[t], hipEventDisableTiming));
+        }
+    const auto t_ring = std::chrono::steady_clock::now();
+    const size_t npieces = (bytes + PIECE - 1) / PIECE;
+    hipError_t err[T] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
+    int scope_rc[T] = {ZK_OK, ZK_OK, ZK_OK, ZK_OK};
+    auto work = [&](int t) {
+        CtxScope sc(entry);
+        if (sc.rc != ZK_OK) { scope_rc[t] = sc.rc; return; }
+        for (size_t p = (size_t)t; p < npieces; p += T) {
+            if (R.in_flight[t] && (err[t] = hipEventSynchronize(R.ev[t])) != hipSuccess) return;  // this buffer's previous piece has left
+            const size_t from = p * PIECE, len = from + PIECE <= bytes ? PIECE : bytes - from;
+            memcpy(R.buf[t], (const char*)src + from, len);
+            if ((err[t] = hipMemcpyAsync((char*)dst + from, R.buf[t], len, hipMemcpyHostToDevice, st)) != hipSuccess) return;
+            if ((err[t] = hipEventRecord(R.ev[t], st)) != hipSuccess) return;
+            R.in_flight[t] = true;
+        }
+    };
+    std::thread team[T - 1];
+    const int nt = npieces < (size_t)T ? (int)npieces : T;  // (a few MB: one piece, this thread alone)
+    for (int t = 1; t < nt; t++) team[t - 1] = std::thread(work, t);
+    work(0);
+    for (int t = 1; t < nt; t++) team[t - 1].join();
+    {
+        const auto t_out = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        prof_host("export.h2d_ring_wait", ms(t_in, t_lock));
+        prof_host("export.h2d_ring_make", ms(t_lock, t_ring));
+        prof_host("export.h2d_ring_copy", ms(t_ring, t_out));
+    }
+    for (int t = 0; t < T; t++) {
+        if (scope_rc[t] != ZK_OK) return scope_rc[t];
+        if (err[t] != hipSuccess) return set_err(ZK_ERR_HIP, "staged upload: %s", hipGetErrorString(err[t]));
+    }
+    return ZK_OK;
+}
+
 void fold_all_slots() {
     for (int e = 0; e < n_entries(); e++) {
         Ctx& c = *g_entries[e];

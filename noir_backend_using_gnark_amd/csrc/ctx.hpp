@@ -162,6 +162,7 @@ int acquire_slots(int k, Slot** out); // k slots at once (all or nothing: no par
 void release_slot(Slot* s);
 int masked_streams(Slot* s);         // creates stream_prep / stream_acc on first use; ZK_OK with both left null when ZKMI_CU_SPLIT is unset
 int slot_sync(Slot* s, hipStream_t st);  // synchronize + fold pending profile events
+int h2d_big(void* dst, const void* src, size_t bytes, hipStream_t st);  // pageable host memory -> HBM through a ring of pinned buffers (ctx.hip); src is free on return
 
 struct SlotGuard {
     Slot* s = nullptr;

@@ -637,20 +637,25 @@ struct RawCircuit {
         ZK_TRY(ensure_init());
         if (!host) return set_err(ZK_ERR_ARG, "resident circuit lost its host form");
         uint64_t h = 0;
+        Phase ph;
         ZK_TRY(r1cs_of_built(*host, &h));
+        ph.lap("export.circuit_r1cs_load");
         auto up = [](uint32_t** d, const RawVec<uint32_t>& v) -> int {
             ZK_HIP(hipMalloc((void**)d, (v.size() ? v.size() : 1) * 4));
-            if (!v.empty()) ZK_HIP(hipMemcpy(*d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+            if (!v.empty()) ZK_TRY(h2d_big(*d, v.data(), v.size() * 4, nullptr));
             return ZK_OK;
         };
         int rc = up(&d_order, host->order);
         if (rc == ZK_OK) rc = up(&d_pa, host->prod_a);
         if (rc == ZK_OK) rc = up(&d_pb, host->prod_b);
+        if (rc == ZK_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = set_err(ZK_ERR_HIP, "circuit upload failed");
+        ph.lap("export.circuit_order_uploads");
         auto dm = [](void** d, size_t bytes) -> int { ZK_HIP(hipMalloc(d, bytes ? bytes : 16)); return ZK_OK; };
         if (rc == ZK_OK) rc = dm((void**)&d_text, span_len + 32);
         if (rc == ZK_OK) rc = dm(&d_vals, n_values * 32);
         if (rc == ZK_OK) rc = dm(&d_w, n_wires * 32);
         if (rc == ZK_OK) rc = dm(&d_abc, 3 * n_constraints * 32);
+        ph.lap("export.circuit_scratch_allocs");
         if (rc != ZK_OK) {  // nothing half-made stays behind: a later call starts over
             (void)zk_bn254_r1cs_free(h);
             for (void* q : {(void*)d_order, (void*)d_pa, (void*)d_pb, (void*)d_text, d_vals, d_w, d_abc})
@@ -661,7 +666,8 @@ struct RawCircuit {
             return rc;
         }
         r1cs = h;
-        host.reset();
+        // the host form (0.3 GB at 2^20 constraints) is given back to the system on a thread of its own: 25 ms this call need not wait for
+        std::thread([form = host.release()] { delete form; }).detach();
         return ZK_OK;
     }
 };

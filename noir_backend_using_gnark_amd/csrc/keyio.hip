@@ -15,6 +15,7 @@
 
 #include "ctx.hpp"
 #include "ff.hpp"
+#include "ff29.hpp"
 #include "keyio.hpp"
 #include "text_host.hpp"
 #include "msm.hpp"
@@ -86,6 +87,38 @@ __global__ void k_fr_to_be(const Fr* __restrict__ in, size_t n, uint32_t* __rest
     store_be32(raw + 8 * i, in[i].from_mont());
 }
 
+// ---- square roots: a^((q - 3) / 4) on the 29-bit multiplier (ff29.hpp)
+// Both decompressions end in this exponentiation (q = 3 mod 4: sqrt(a) = a^((q+1)/4) = a^((q-3)/4) * a; the Fp2 root takes two).  The saturated
+// Field::pow spends 252 squarings + 127 products of ~305 instructions; here the constant exponent is walked in sliding windows of three bits -- 250 squarings
+// of ~170 instructions and 55 products of 206 with a, a^3, a^5, a^7 -- 2.1 x fewer instructions.  One byte per window: squarings << 2 | (odd power >> 1),
+// most significant window first (the first one only selects the starting power); every value in the chain is a direct product output (< 1.03 p).
+__device__ __forceinline__ U29 u29_pow_qm3_4(const U29& a) {
+    static const uint8_t W[56] = {9,  29, 12, 16, 23, 23, 22, 9,  20, 17, 21, 8,  42, 17, 19, 30, 24, 26, 14, 14, 14, 33, 38, 13, 30, 9,  13, 22,
+                                  15, 38, 14, 18, 12, 26, 14, 31, 27, 22, 8,  21, 8,  23, 4,  20, 24, 21, 34, 14, 14, 4,  31, 9,  23, 15, 18, 16};
+    const U29 a2 = u29_sqr(a), a3 = u29_mul(a2, a), a5 = u29_mul(a3, a2), a7 = u29_mul(a5, a2);
+    U29 acc = a3;  // W[0] & 3 == 1
+#pragma unroll 1
+    for (int k = 1; k < 56; k++) {
+        const unsigned w = W[k];
+#pragma unroll 1
+        for (unsigned j = 0; j < (w >> 2); j++) acc = u29_sqr(acc);
+        switch (w & 3u) {
+            case 0: acc = u29_mul(acc, a); break;
+            case 1: acc = u29_mul(acc, a3); break;
+            case 2: acc = u29_mul(acc, a5); break;
+            default: acc = u29_mul(acc, a7); break;
+        }
+    }
+    return acc;
+}
+// canonical Montgomery image -> a^((q-3)/4) * a^mul_a as a canonical Montgomery image (mul_a: once more by a, the square-root candidate)
+__device__ __forceinline__ Fp fp_pow_qm3_4(const Fp& a, bool times_a) {
+    const U29 x = u29_mul(u29_load(a), u29_one());  // contracted: < 1.2 p
+    U29 e = u29_pow_qm3_4(x);
+    if (times_a) e = u29_mul(e, x);
+    return u29_store(e);
+}
+
 // ---- G1 points
 __device__ __forceinline__ bool fp_lex_largest_dev(const Fp& canonical) {  // value > (q - 1) / 2
     for (int i = 7; i >= 0; i--) {
@@ -115,9 +148,7 @@ __global__ __launch_bounds__(256) void k_g1_decompress(const uint32_t* __restric
     Fp xm = x.to_mont();
     Fp three = Fp::one() + Fp::one() + Fp::one();
     Fp rhs = xm.sqr() * xm + three;
-    // (q + 1) / 4
-    const uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
-    Fp y = rhs.pow(e);
+    Fp y = fp_pow_qm3_4(rhs, true);  // rhs^((q + 1) / 4)
     if (y.sqr() != rhs) {  // not on the curve
         atomicOr(status, 4);
         out[i] = p;
@@ -151,19 +182,19 @@ __global__ void k_g1_compress(const Affine<Fp>* __restrict__ pts, size_t n, uint
 // (a1 / 2c)^2 = (a0 - s) / 2).  Either root will do: the caller picks the sign by the encoding's flag.  `half` = 1 / 2 (Montgomery).
 __device__ bool f2_sqrt_dev(const Fp2& a, const Fp& half, Fp2* out) {
     if (a.is_zero()) { *out = a; return true; }
-    const uint32_t E1[8] = {0xb61f3f51u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};  // (q - 3) / 4
+    // every exponentiation below is by (q - 3) / 4: fp_pow_qm3_4
     if (a.a1.is_zero()) {  // a in Fp: sqrt(a0) or u sqrt(-a0)
-        const Fp c = a.a0.pow(E1) * a.a0;
+        const Fp c = fp_pow_qm3_4(a.a0, true);
         if (c.sqr() == a.a0) *out = Fp2{c, Fp::zero()};
         else *out = Fp2{Fp::zero(), c};
         return out->sqr() == a;
     }
     const Fp n = a.a0.sqr() + a.a1.sqr();
-    const Fp s = n.pow(E1) * n;
+    const Fp s = fp_pow_qm3_4(n, true);
     if (s.sqr() != n) return false;  // the norm is not a square: neither is a
     Fp t = (a.a0 + s) * half;
     // (t = 0 would need a0 = -s, i.e. a1^2 = s^2 - a0^2 = 0: not on this branch)
-    const Fp e = t.pow(E1), c = e * t;
+    const Fp e = fp_pow_qm3_4(t, false), c = e * t;
     const Fp w = a.a1 * (c * e.sqr() * half);  // a1 / (2 c)
     if (c.sqr() == t) *out = Fp2{c, w};
     else *out = Fp2{w, c};
@@ -203,7 +234,57 @@ __device__ __forceinline__ bool g2_in_subgroup_dev(const Affine<Fp2>& p, const P
     if (lhs.is_inf() || d.is_inf()) return lhs.is_inf() && d.is_inf();
     return lhs.x * d.zz == d.x * lhs.zz && lhs.y * d.zzz == d.y * lhs.zzz;
 }
-__global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restrict__ raw, size_t n, Fp2 bt, PsiConsts psi, int full_check, Affine<Fp2>* __restrict__ out,
+// The same test on the 29-bit multiplier (ff29.hpp: acc29g2_dbl / acc29g2_add, whose class invariant -- every coordinate component < 32 p, weakly normalised, in
+// and out -- tools/u29_model.py proves): 63 doublings and 27 + 3 full additions with one reduction per output component instead of three saturated products per
+// Fp2 product.  psi keeps the invariant: X and Y times a contracted constant come out below 1.5 p; the conjugated ZZ / ZZZ components are contracted.
+__device__ __forceinline__ Acc29G2 g2_psi_dev29(const Acc29G2& t, const U29x2& gx, const U29x2& gy) {
+    if (t.inf) return t;
+    const U29 one = u29_one();
+    Acc29G2 r;
+    r.inf = false;
+    // conj(v) * g = (v0 g0 + v1 g1) + (v0 g1 - v1 g0) u
+    r.x = U29x2{u29_mul2(t.x.c0, gx.c0, t.x.c1, gx.c1), u29_mul2(t.x.c0, gx.c1, u29_neg<32>(t.x.c1), gx.c0)};
+    r.y = U29x2{u29_mul2(t.y.c0, gy.c0, t.y.c1, gy.c1), u29_mul2(t.y.c0, gy.c1, u29_neg<32>(t.y.c1), gy.c0)};
+    r.zz = U29x2{t.zz.c0, u29_mul(u29_neg<32>(t.zz.c1), one)};
+    r.zzz = U29x2{t.zzz.c0, u29_mul(u29_neg<32>(t.zzz.c1), one)};
+    return r;
+}
+__device__ __forceinline__ bool f2_eq29(const U29x2& a, const U29x2& b) {  // exact: through the canonical images
+    const Fp2 x = f2_store29(a), y = f2_store29(b);
+    return x == y;
+}
+// *pp is read again wherever P is added (28 times: 128 bytes from L2) instead of being held in 72 registers next to the accumulator and an addition's temporaries
+__device__ __forceinline__ void g2_add_affine29(Acc29G2& a, const Affine<Fp2>* __restrict__ pp) {
+    const Fp2 one2{Fp::one(), Fp::zero()};
+    Acc29G2 P1;
+    const Affine<Fp2> q = *pp;
+    acc29g2_load(P1, XYZZ<Fp2>{q.x, q.y, one2, one2});
+    acc29g2_add(a, P1);
+}
+__device__ bool g2_in_subgroup_dev29(const Affine<Fp2>* __restrict__ pp, const PsiConsts& K) {
+    const uint32_t x0[2] = {0x4a6909f1u, 0x44e992b4u};  // 4965661367192848881
+    Acc29G2 a;
+    a.inf = true;
+    a.x = a.y = a.zz = a.zzz = f2_load29(K.gx);  // (defined values; never read while inf)
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        acc29g2_dbl(a);
+        if ((x0[i >> 5] >> (i & 31)) & 1) g2_add_affine29(a, pp);
+    }
+    const U29x2 gx = f2_contract29(f2_load29(K.gx)), gy = f2_contract29(f2_load29(K.gy));
+    const Acc29G2 b = g2_psi_dev29(a, gx, gy);  // psi([x0] P)
+    g2_add_affine29(a, pp);                      // [x0 + 1] P
+    Acc29G2 lhs = a;
+    acc29g2_add(lhs, b);
+    const Acc29G2 c = g2_psi_dev29(b, gx, gy);  // psi^2([x0] P)
+    acc29g2_add(lhs, c);
+    Acc29G2 d = g2_psi_dev29(c, gx, gy);        // psi^3([x0] P)
+    acc29g2_dbl(d);                              // psi^3([2 x0] P)
+    if (lhs.inf || d.inf) return lhs.inf && d.inf;
+    // (a coordinate sum that came out as the point at infinity went through the canonical path of acc29g2_add / _dbl, which sets .inf)
+    return f2_eq29(f2_mulFK29<40>(lhs.x, d.zz), f2_mulFK29<40>(d.x, lhs.zz)) && f2_eq29(f2_mulFK29<40>(lhs.y, d.zzz), f2_mulFK29<40>(d.y, lhs.zzz));
+}
+__global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restrict__ raw, size_t n, Fp2 bt, PsiConsts psi, Affine<Fp2>* __restrict__ out,
                                                        int* __restrict__ status) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -231,19 +312,27 @@ __global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restric
     if (f2_lex_largest_dev(y) != (flag == 3)) y = y.neg();
     p.x = x;
     p.y = y;
+    out[i] = p;
+}
+// second half of G2Affine.SetBytes, a kernel of its own (the square root and the subgroup test in one kernel need 512 registers: one wave per SIMD; apart, each
+// runs with two or more): a point outside the r-torsion subgroup becomes the point at infinity and sets status bit 16
+template <bool FULL>
+__global__ __launch_bounds__(128) void k_g2_subgroup(Affine<Fp2>* __restrict__ pts, size_t n, PsiConsts psi, int* __restrict__ status) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (pts[i].is_inf()) return;
     bool member;
-    if (full_check) {  // ZKMI_G2_FULL_SUBGROUP_CHECK=1: the definition, r * P == infinity (A/B switch, twice the work)
+    if (FULL) {  // ZKMI_G2_FULL_SUBGROUP_CHECK=1: the definition, r * P == infinity (A/B switch, four times the work)
         const uint32_t rk[8] = {FrParams::MOD[0], FrParams::MOD[1], FrParams::MOD[2], FrParams::MOD[3], FrParams::MOD[4], FrParams::MOD[5], FrParams::MOD[6], FrParams::MOD[7]};
+        const Affine<Fp2> p = pts[i];
         member = scalar_mul(p, rk).is_inf();
     } else {
-        member = g2_in_subgroup_dev(p, psi);
+        member = g2_in_subgroup_dev29(pts + i, psi);
     }
     if (!member) {
         atomicOr(status, 16);
-        out[i] = Affine<Fp2>::inf();
-        return;
+        pts[i] = Affine<Fp2>::inf();
     }
-    out[i] = p;
 }
 // idx == nullptr: point i; else point idx[i] (a key is stored wire-indexed and written without its points at infinity)
 __global__ void k_g2_compress(const Affine<Fp2>* __restrict__ pts, const uint32_t* __restrict__ idx, size_t n, uint32_t* __restrict__ raw) {
@@ -328,7 +417,11 @@ int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void
     const HFp half = (HFp::one() + HFp::one()).inv();
     memcpy(&psi.half, &half, sizeof half);
     static const int full = ZK_EXP("ZKMI_G2_FULL_SUBGROUP_CHECK", 0);
-    if (n) ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, psi, full, (Affine<Fp2>*)d_out, d_status);
+    if (n) {
+        ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, psi, (Affine<Fp2>*)d_out, d_status);
+        if (full) ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<true>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
+        else ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<false>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
+    }
     return ZK_OK;
 }
 int g2_compress_dev(Slot* s, hipStream_t st, const void* d_pts, const uint32_t* d_idx, size_t n, void* d_raw) {
@@ -454,10 +547,10 @@ int zk_bn254_kzg_srs_read(const void* data, size_t len, int is_hex, int table_wi
     uint8_t* d_bytes = (uint8_t*)s->alloc(nbytes + 16);
     if (is_hex) {
         void* d_text = s->alloc(len + 16);
-        ZK_HIP(hipMemcpyAsync(d_text, data, len, hipMemcpyHostToDevice, st));
+        ZK_TRY(h2d_big(d_text, data, len, st));
         ZK_TRY(hex_decode_dev(s, st, d_text, nbytes, d_bytes, d_status));
     } else {
-        ZK_HIP(hipMemcpyAsync(d_bytes, data, nbytes, hipMemcpyHostToDevice, st));
+        ZK_TRY(h2d_big(d_bytes, data, nbytes, st));
     }
     Affine<HFp2> g2[2];
     for (int k = 0; k < 2; k++)
@@ -596,9 +689,11 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     const uint8_t* dom_in = H.domain;
     uint8_t dom_ok[168];
 
-    SlotGuard g;
-    ZK_TRY(acquire_slot(&g.s));
-    Slot* s = g.s;
+    // two slots: the first one's stream carries the uploads (and its arena the text), the second one's the decompression -- two ORDINARY streams, because a lean
+    // process (the export shim's) has no high-priority stream yet and hi() would hand back the slot's own: upload and decompression would take turns
+    SlotsGuard<2> g;
+    ZK_TRY(acquire_slots(2, g.s));
+    Slot* s = g.s[0];
     hipStream_t st = s->stream;
     Domain* dom;
     ZK_TRY(get_domain(s, st, logN, 0, &dom));
@@ -608,19 +703,21 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     // Everything up to the bitmaps goes to the device (every section starts at a multiple of 4 bytes by construction) -- G2.B FIRST: its points are the expensive
     // ones to decompress (an Fp2 square root and the subgroup test each), so their kernel runs on the slot's second stream while the other 0.24 GB of a
     // 2^20-constraint key's text are still crossing PCIe on the first (round 5: 41 + 17 + 68 ms one after the other before).
+    lap.lap("export.pk_read_slot");
     ZK_TRY(s->reserve((is_hex ? 2 * at_bm : 0) + at_bm + 4096));
+    lap.lap("export.pk_read_reserve");
     int* d_status = (int*)s->alloc(64);
     uint8_t* d_bytes = (uint8_t*)s->alloc(at_bm + 16);
     uint8_t* d_text = is_hex ? (uint8_t*)s->alloc(2 * at_bm + 16) : nullptr;
-    hipStream_t sx = s->hi();  // decompression
+    hipStream_t sx = g.s[1]->stream;  // decompression
     ZK_HIP(hipMemsetAsync(d_status, 0, 4, st));
     auto upload = [&](size_t from, size_t to) -> int {  // bytes [from, to) of the key image -> d_bytes, on `st`
         if (to <= from) return ZK_OK;
         if (is_hex) {
-            ZK_HIP(hipMemcpyAsync(d_text + 2 * from, (const char*)data + 2 * from, 2 * (to - from), hipMemcpyHostToDevice, st));
+            ZK_TRY(h2d_big(d_text + 2 * from, (const char*)data + 2 * from, 2 * (to - from), st));
             ZK_TRY(hex_decode_dev(s, st, d_text + 2 * from, to - from, d_bytes + from, d_status));
         } else {
-            ZK_HIP(hipMemcpyAsync(d_bytes + from, (const char*)data + from, to - from, hipMemcpyHostToDevice, st));
+            ZK_TRY(h2d_big(d_bytes + from, (const char*)data + from, to - from, st));
         }
         return ZK_OK;
     };
@@ -637,10 +734,19 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     ZK_TRY(own.alloc(&d_z, cnt[2] * 64));
     ZK_TRY(own.alloc(&d_k, cnt[3] * 64));
     const size_t g2_end = at[4] + cnt[4] * 64;
-    ZK_TRY(upload(at[4], g2_end));
-    ZK_HIP(hipEventRecord(ev_g2, st));
-    ZK_HIP(hipStreamWaitEvent(sx, ev_g2, 0));
-    ZK_TRY(g2_decompress_dev(s, sx, d_bytes + at[4], cnt[4], d_b2, d_status));
+    lap.lap("export.pk_read_allocs");
+    {   // in quarters: the first points are being decompressed while the last ones are still on their way (an event may be re-recorded once the wait on its
+        // previous recording has been enqueued)
+        const size_t parts = cnt[4] >= ((size_t)1 << 16) ? 4 : 1, per = (cnt[4] + parts - 1) / parts;
+        for (size_t q = 0; q < parts; q++) {
+            const size_t p0 = q * per, p1 = p0 + per < cnt[4] ? p0 + per : cnt[4];
+            if (p1 <= p0) break;
+            ZK_TRY(upload(at[4] + p0 * 64, at[4] + p1 * 64));
+            ZK_HIP(hipEventRecord(ev_g2, st));
+            ZK_HIP(hipStreamWaitEvent(sx, ev_g2, 0));
+            ZK_TRY(g2_decompress_dev(s, sx, d_bytes + at[4] + p0 * 64, p1 - p0, (uint8_t*)d_b2 + p0 * 128, d_status));
+        }
+    }
     lap.lap("export.pk_read_upload_g2_part");
     ZK_TRY(upload(0, at[4]));
     ZK_TRY(upload(g2_end, at_bm));
@@ -663,8 +769,10 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     if (h_status & 8) return set_err(ZK_ERR_ARG, "proving key: invalid compressed G2 point (bad flags, coordinate >= q, or no square root)");
     if (h_status & 16) return set_err(ZK_ERR_ARG, "proving key: a G2 point outside the r-torsion subgroup");
     s->reset();
-    release_slot(g.s);  // pk_load takes slots of its own
-    g.s = nullptr;
+    for (int i = 0; i < 2; i++) {  // pk_load takes slots of its own
+        release_slot(g.s[i]);
+        g.s[i] = nullptr;
+    }
     zk_groth16_pk pk;
     memset(&pk, 0, sizeof pk);
     pk.log_domain = logN;

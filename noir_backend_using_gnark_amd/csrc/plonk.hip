@@ -1024,10 +1024,10 @@ int zk_bn254_plonk_pk_read(const void* data, size_t len, int is_hex, size_t n_va
     uint8_t* d_bytes = (uint8_t*)s->alloc(nbytes + 16);
     if (is_hex) {
         void* d_text = s->alloc(len + 16);
-        ZK_HIP(hipMemcpyAsync(d_text, data, len, hipMemcpyHostToDevice, st));
+        ZK_TRY(h2d_big(d_text, data, len, st));
         ZK_TRY(hex_decode_dev(s, st, d_text, nbytes, d_bytes, d_status));
     } else {
-        ZK_HIP(hipMemcpyAsync(d_bytes, data, nbytes, hipMemcpyHostToDevice, st));
+        ZK_TRY(h2d_big(d_bytes, data, nbytes, st));
     }
     Fr** dst[9] = {&P->ql, &P->qr, &P->qm, &P->qo, &P->cqk, &P->lqk, &P->s1, &P->s2, &P->s3};
     for (int k = 0; k < 9; k++) {

@@ -156,9 +156,17 @@ static unsigned gridn(size_t n) { return (unsigned)((n + 255) / 256); }
 
 // CSR -> CSC on the device: count the entries of every wire, scan, scatter through per-wire cursors.  Inside a column the entries land in whatever order the
 // lanes arrive -- the transposed product sums them in the field, where the order of additions does not exist.
+// Column 0 is the ONE wire: every constraint with a constant names it (half a million times in R at 2^20 constraints of the export path's systems), and that
+// many atomics on one address take 25 ms by themselves.  The lanes of a wave that hold it are counted with one ballot and served by one atomic.
 __global__ void k_csc_count(const uint32_t* __restrict__ idx, size_t nnz, uint32_t* __restrict__ cnt) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nnz) atomicAdd(&cnt[idx[k]], 1u);
+    const uint32_t col = k < nnz ? idx[k] : 0xffffffffu;
+    const unsigned long long one = __ballot(col == 0u);
+    if (col == 0u) {
+        if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)one) - 1)) atomicAdd(&cnt[0], (uint32_t)__popcll(one));
+    } else if (k < nnz) {
+        atomicAdd(&cnt[col], 1u);
+    }
 }
 // cnt[0 .. n) -> exclusive prefix sums in ptr[0 .. n], one workgroup (a Setup step: 2^20 wires in ~0.1 ms; not worth a multi-pass scan)
 __global__ __launch_bounds__(1024) void k_csc_scan(const uint32_t* __restrict__ cnt, size_t n, uint32_t* __restrict__ ptr) {
@@ -184,11 +192,28 @@ __global__ __launch_bounds__(1024) void k_csc_scan(const uint32_t* __restrict__ 
 __global__ void k_csc_fill(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx, const Fr* __restrict__ val, size_t rows, uint32_t* __restrict__ cursor,
                            uint32_t* __restrict__ cidx, Fr* __restrict__ cval) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    for (uint32_t k = ptr[i]; k < ptr[i + 1]; k++) {
-        const uint32_t pos = atomicAdd(&cursor[idx[k]], 1u);
-        cidx[pos] = (uint32_t)i;
-        cval[pos] = ldf(val + k);
+    const unsigned lane = threadIdx.x & 63u;
+    uint32_t k = i < rows ? ptr[i] : 0u;
+    const uint32_t end = i < rows ? ptr[i + 1] : 0u;
+    while (__ballot(k < end)) {  // (the whole wave stays in step: the ONE wire's entries of one step share one atomic, as in k_csc_count)
+        const bool act = k < end;
+        const uint32_t col = act ? idx[k] : 0xffffffffu;
+        const bool hot = col == 0u;
+        const unsigned long long one = __ballot(hot);
+        uint32_t pos = 0;
+        if (one) {
+            const int leader = __ffsll((long long)one) - 1;
+            uint32_t base = 0;
+            if (lane == (unsigned)leader) base = atomicAdd(&cursor[0], (uint32_t)__popcll(one));
+            base = __shfl(base, leader, 64);
+            pos = base + (uint32_t)__popcll(one & ((1ull << lane) - 1ull));
+        }
+        if (act && !hot) pos = atomicAdd(&cursor[col], 1u);
+        if (act) {
+            cidx[pos] = (uint32_t)i;
+            cval[pos] = ldf(val + k);
+            k++;
+        }
     }
 }
 
@@ -251,9 +276,13 @@ int zk_bn254_r1cs_load(const zk_r1cs* r, uint64_t* handle) {
         for (size_t k = 0; k < nnz; k++)
             if (idxs[m][k] >= r->n_wires) return set_err(ZK_ERR_ARG, "matrix %d names wire %u of %zu", m, idxs[m][k], r->n_wires);
     }
+    const auto t_a = std::chrono::steady_clock::now();
     ZK_TRY(ensure_init());
     std::unique_ptr<R1csDev, void (*)(R1csDev*)> D(new R1csDev(), r1cs_destroy);
     D->n_constraints = r->n_constraints; D->n_wires = r->n_wires; D->n_public = r->n_public;
+    SlotGuard g;  // a stream of its own for the uploads (the null stream would wait for every other stream's work)
+    ZK_TRY(acquire_slot(&g.s));
+    hipStream_t up = g.s->stream;
     for (int m = 0; m < 3; m++) {
         const size_t nc = r->n_constraints, nnz = ptrs[m][nc];
         Csr& R = D->row[m];
@@ -261,12 +290,14 @@ int zk_bn254_r1cs_load(const zk_r1cs* r, uint64_t* handle) {
         ZK_TRY(dalloc(D.get(), &R.ptr, nc + 1));
         ZK_TRY(dalloc(D.get(), &R.idx, nnz));
         ZK_TRY(dalloc(D.get(), &R.val, nnz));
-        ZK_HIP(hipMemcpy(R.ptr, ptrs[m], (nc + 1) * 4, hipMemcpyHostToDevice));
+        ZK_TRY(h2d_big(R.ptr, ptrs[m], (nc + 1) * 4, up));  // (big arrays go through the pinned ring of ctx.hip: 0.2 GB at 2^20 constraints)
         if (nnz) {
-            ZK_HIP(hipMemcpy(R.idx, idxs[m], nnz * 4, hipMemcpyHostToDevice));
-            ZK_HIP(hipMemcpy(R.val, vals[m], nnz * 32, hipMemcpyHostToDevice));
+            ZK_TRY(h2d_big(R.idx, idxs[m], nnz * 4, up));
+            ZK_TRY(h2d_big(R.val, vals[m], nnz * 32, up));
         }
     }
+    ZK_TRY(slot_sync(g.s, up));
+    prof_host("export.r1cs_load_upload", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
     std::lock_guard<std::mutex> lk(g_r1cs_mu);
     *handle = hmake(g_next_r1cs++);
     g_r1cs[*handle] = std::shared_ptr<R1csDev>(D.release(), r1cs_destroy);

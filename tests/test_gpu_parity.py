@@ -1425,6 +1425,38 @@ def test_r1cs_sparse_mat_vec_at_2p12_constraints():
     dev.free()
 
 
+def test_r1cs_load_of_a_large_system_goes_through_the_pinned_ring():
+    """zk_bn254_r1cs_load moves arrays of 16 MB and more through four threads and a ring of pinned buffers (ctx.hip h2d_big: a cold ProveWithPK uploads
+    0.2 GB of constraint system beside 0.37 GB of key text).  2^19 + 5 constraints with two entries per row of L (33.5 MB of coefficients: five pieces, the
+    last one ragged), one per row of R, none in O; coefficients drawn from sixteen field elements so that big integers can check every row."""
+    g = ref.SplitMix64(0xA7)
+    nc, nw = (1 << 19) + 5, 1 << 16
+    T = [g.felt() for _ in range(16)]
+    Tm = mont_limbs(T)
+    w = [1] + [g.felt() for _ in range(nw - 1)]
+    rng = np.random.default_rng(0xA7)
+    li = rng.integers(0, nw, size=2 * nc, dtype=np.uint32)
+    lt = rng.integers(0, 16, size=2 * nc)
+    ri = rng.integers(0, nw, size=nc, dtype=np.uint32)
+    rt = rng.integers(0, 16, size=nc)
+    lptr = (2 * np.arange(nc + 1)).astype(np.uint32)
+    rptr = np.arange(nc + 1, dtype=np.uint32)
+    optr = np.zeros(nc + 1, dtype=np.uint32)
+    lval, rval = np.ascontiguousarray(Tm[lt]), np.ascontiguousarray(Tm[rt])
+    none_i, none_v = np.zeros(1, np.uint32), np.zeros((1, 4), np.uint64)
+    raw = _lib.R1CS(nc, nw, 1, lptr.ctypes.data, li.ctypes.data, lval.ctypes.data, rptr.ctypes.data, ri.ctypes.data, rval.ctypes.data,
+                    optr.ctypes.data, none_i.ctypes.data, none_v.ctypes.data)
+    h = C.c_uint64(0)
+    _lib.check(_lib.lib().zk_bn254_r1cs_load(C.byref(raw), C.byref(h)))
+    dev = zk.R1CS.from_handle(h.value, 1, nw, nc)
+    a, b, c = dev.eval_abc(mont_limbs(w))
+    assert not c.any()
+    want_a = [(T[lt[2 * i]] * w[li[2 * i]] + T[lt[2 * i + 1]] * w[li[2 * i + 1]]) % ref.R for i in range(nc)]
+    want_b = [T[rt[i]] * w[ri[i]] % ref.R for i in range(nc)]
+    assert from_mont_limbs(a) == want_a and from_mont_limbs(b) == want_b
+    dev.free()
+
+
 def test_groth16_from_raw_r1cs_json():
     """The reference's intended Groth16 payload (RawR1CS JSON, src/gnark_backend_wrapper/groth16/acir_to_r1cs.rs:18-60) through buildR1CS
     (backend/groth16/r1cs.go:9-72, restated in frontend.hip and in oracle/plonk_ref.r1cs_from_raw), Setup and Prove on the device: the proof bytes
