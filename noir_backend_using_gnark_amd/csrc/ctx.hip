@@ -430,8 +430,7 @@ int slot_sync(Slot* s, hipStream_t st) {
 int h2d_big(void* dst, const void* src, size_t bytes, hipStream_t st) {
     constexpr size_t PIECE = (size_t)8 << 20;
     constexpr int T = 4;
-    static const size_t tmp_min = getenv("ZKMI_TMP_H2D_MIN_MB") ? (size_t)atol(getenv("ZKMI_TMP_H2D_MIN_MB")) << 20 : ((size_t)1 << 20);  // TEMPORARY (batch U)
-    if (bytes < tmp_min) {
+    if (bytes < ((size_t)1 << 20)) {
         if (bytes) ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
         return ZK_OK;
     }

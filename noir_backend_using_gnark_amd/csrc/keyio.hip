@@ -213,30 +213,10 @@ __device__ __forceinline__ bool f2_lex_largest_dev(const Fp2& y) {  // gnark-cry
 //                                                               G2Jac.IsInSubGroup): ONE multiplication by the 63-bit x0, three psi, a few additions -- half
 //                                                               the work of a decompression's larger half (68 -> see DESIGN.md 3.8 per 2^20 points)
 struct PsiConsts { Fp2 gx, gy; Fp half; };  // psi's two coefficients; 1 / 2 for the square root
-__device__ __forceinline__ XYZZ<Fp2> g2_psi_dev(const XYZZ<Fp2>& t, const PsiConsts& K) {  // on x = X / ZZ, y = Y / ZZZ: conjugate everything, scale X and Y
-    return XYZZ<Fp2>{Fp2{t.x.a0, t.x.a1.neg()} * K.gx, Fp2{t.y.a0, t.y.a1.neg()} * K.gy, Fp2{t.zz.a0, t.zz.a1.neg()}, Fp2{t.zzz.a0, t.zzz.a1.neg()}};
-}
-__device__ __forceinline__ bool g2_in_subgroup_dev(const Affine<Fp2>& p, const PsiConsts& K) {
-    const uint32_t x0[2] = {0x4a6909f1u, 0x44e992b4u};  // 4965661367192848881
-    XYZZ<Fp2> a = XYZZ<Fp2>::inf();
-    for (int i = 62; i >= 0; i--) {
-        a.dbl();
-        if ((x0[i >> 5] >> (i & 31)) & 1) a.madd(p);
-    }
-    const XYZZ<Fp2> b = g2_psi_dev(a, K);   // psi([x0] P)
-    const XYZZ<Fp2> c = g2_psi_dev(b, K);   // psi^2([x0] P)
-    XYZZ<Fp2> d = g2_psi_dev(c, K);         // psi^3([x0] P)
-    d.dbl();                                // psi^3([2 x0] P)
-    a.madd(p);                              // [x0 + 1] P
-    XYZZ<Fp2> lhs = c;
-    lhs.add(b);
-    lhs.add(a);
-    if (lhs.is_inf() || d.is_inf()) return lhs.is_inf() && d.is_inf();
-    return lhs.x * d.zz == d.x * lhs.zz && lhs.y * d.zzz == d.y * lhs.zzz;
-}
-// The same test on the 29-bit multiplier (ff29.hpp: acc29g2_dbl / acc29g2_add, whose class invariant -- every coordinate component < 32 p, weakly normalised, in
-// and out -- tools/u29_model.py proves): 63 doublings and 27 + 3 full additions with one reduction per output component instead of three saturated products per
-// Fp2 product.  psi keeps the invariant: X and Y times a contracted constant come out below 1.5 p; the conjugated ZZ / ZZZ components are contracted.
+// The second test runs on the 29-bit multiplier (ff29.hpp: acc29g2_dbl / acc29g2_add, whose class invariant -- every coordinate component < 32 p, weakly
+// normalised, in and out -- tools/u29_model.py proves): 63 doublings and 27 + 3 full additions with one reduction per output component instead of three saturated
+// products per Fp2 product (29.5-30.5 ms per 2^20 points against 33.4-34.2 for the saturated form in the same kernel: profiles/rnd5_v_g2_subgroup_variants.txt).
+// psi keeps the invariant: X and Y times a contracted constant come out below 1.5 p; the conjugated ZZ / ZZZ components are contracted.
 __device__ __forceinline__ Acc29G2 g2_psi_dev29(const Acc29G2& t, const U29x2& gx, const U29x2& gy) {
     if (t.inf) return t;
     const U29 one = u29_one();
@@ -419,8 +399,9 @@ int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void
     static const int full = ZK_EXP("ZKMI_G2_FULL_SUBGROUP_CHECK", 0);
     if (n) {
         ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, psi, (Affine<Fp2>*)d_out, d_status);
-        if (full) ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<true>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
-        else ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<false>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
+        const dim3 grid((unsigned)((n + 127) / 128));
+        if (full) ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<true>), grid, dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
+        else ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<false>), grid, dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
     }
     return ZK_OK;
 }
