@@ -289,6 +289,23 @@ def main():
         if cpu_proof != proof:
             out["parity_error"] = "GPU proof bytes differ from the CPU oracle's"
 
+    # ---- the reference's live call end to end through libgnark_backend.so (child processes; the GPU is shared with this one, which is idle meanwhile).
+    # Before the blocks that hold tens of GB of host arrays (2^24, PLONK 2^22, 2^26): behind them the children's host-bandwidth-bound phases -- content keys,
+    # the values' upload -- measured 1.7-3.8 x slower (profiles/rnd5_w_bench_default_line.json: warm PlonkProveWithPK 19.3 ms against 15.5-16.6 alone / in a short line)
+    if single and log_n == 20 and not args.no_export:
+        try:
+            out["export_path"] = export_path_block(args.export_log_gates)
+            if not out["export_path"]["ok"]:
+                out["parity_error"] = "export path: a proof made through libgnark_backend.so does not verify"
+        except Exception as e:
+            out["export_path"] = {"error": str(e)[:600]}
+        # ---- the metric's own proof system behind the reference's ABI at the metric's size: Preprocess -> ProveWithPK -> VerifyWithVK on a RawR1CS of 2^20 constraints
+        try:
+            out["export_path_groth16"] = export_path_groth16_block(args.export_g16_log_constraints)
+            if not out["export_path_groth16"]["ok"]:
+                out["parity_error"] = "Groth16 export path: a proof made through libgnark_backend.so does not verify"
+        except Exception as e:
+            out["export_path_groth16"] = {"error": str(e)[:600]}
     # ---- second measured block: the metric's other size, 2^24 constraints on this GPU (BASELINE metric "at 2^20 / 2^24 constraints")
     if single and log_n == 20 and not args.no_2p24 and not args.no_tables:
         inst.free()
@@ -356,24 +373,6 @@ def main():
         out["srs_read_1e6"] = srs_block(_lib)
         if not (out["micro_2p26"]["equals_split_recombination"] and out["micro_2p26"]["equals_window_table_path"] and out["srs_read_1e6"]["write_of_read_is_identity"]):
             out["parity_error"] = "micro-benchmark cross-check failed"
-    # ---- the reference's live call end to end through libgnark_backend.so (child processes; the GPU is shared with this one, which is idle meanwhile)
-    if single and log_n == 20 and not args.no_export:
-        if inst is not None:
-            inst.free()
-            inst = None
-        try:
-            out["export_path"] = export_path_block(args.export_log_gates)
-            if not out["export_path"]["ok"]:
-                out["parity_error"] = "export path: a proof made through libgnark_backend.so does not verify"
-        except Exception as e:
-            out["export_path"] = {"error": str(e)[:600]}
-        # ---- the metric's own proof system behind the reference's ABI at the metric's size: Preprocess -> ProveWithPK -> VerifyWithVK on a RawR1CS of 2^20 constraints
-        try:
-            out["export_path_groth16"] = export_path_groth16_block(args.export_g16_log_constraints)
-            if not out["export_path_groth16"]["ok"]:
-                out["parity_error"] = "Groth16 export path: a proof made through libgnark_backend.so does not verify"
-        except Exception as e:
-            out["export_path_groth16"] = {"error": str(e)[:600]}
     if rank == 0:
         out["go_toolchain"] = go_toolchain_probe()
     # ---- configs[4] on several GPUs: the 2^26-point MSM range-sharded and the 2^26-point FFT block-sharded over the ranks

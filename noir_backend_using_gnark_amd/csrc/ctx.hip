@@ -72,6 +72,9 @@ static int init_entry(Ctx& c) {  // under c.mu
         static const int knob = ZK_EXP("ZKMI_INIT_STREAMS", -1);  // experiment: 0 none; 1 all sixteen, interleaved (rounds 1-3); 2 slots 0-4 both; 3 the eight own; 4 five own
         const int at_init = knob >= 0 ? knob : (g_lean_start.load() || c.entry != 0) ? 4 : 2;
         const int ns = at_init == 1 || at_init == 3 ? Ctx::NSLOTS : (at_init == 2 || at_init == 4) ? 5 : 0;
+        // (Round 5 measured a lean start with two or three own streams, slots 2-4 borrowing them until the second proof: the runtime's start 24 / 15 ms shorter,
+        // the key reader and the circuit's upload 10-20 ms longer on the shared streams, and every WARM proof 0.9 ms slower for streams created late --
+        // profiles/rnd5_x_lean_stream_count.txt.  Five it stays.)
         for (int i = 0; i < ns; i++) {
             ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream, hipStreamNonBlocking, lo));
             if (at_init <= 2) ZK_HIP(hipStreamCreateWithPriority(&c.slots[i].stream_hi_, hipStreamNonBlocking, hi));
