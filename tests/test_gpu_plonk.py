@@ -388,6 +388,19 @@ def test_export_cache_keeps_circuit_and_key_resident_and_changes_no_byte(plonk_g
         fe.plonk_prove_with_pk(acir, ref.felts_wire(bad).hex(), pk_hex, srs, blinders=bl)
     with pytest.raises((ValueError, _lib.ZkmiError)):
         fe.plonk_prove_with_pk(js.dumps(plonk_golden[2]["acir"]), enc, pk_hex, srs, blinders=bl)
+    # another circuit whose text has the SAME length (one digit of one coefficient changed) while circuit and key are warm: the warm path has proved with the
+    # resident pair by the time the content keys say "another circuit" -- that proof must be dropped: what comes back is the new circuit's answer (these values
+    # do not satisfy it, or its key is not this key: refused), never the golden proof
+    assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"]
+    digits = [i for i, ch in enumerate(acir) if ch in "0123456789abcdef" and acir[max(0, i - 40):i].count('"') % 2 == 1 and i > acir.index("q_c")]
+    at = digits[-1]
+    acir_same_len = acir[:at] + ("1" if acir[at] != "1" else "2") + acir[at + 1:]
+    assert len(acir_same_len) == len(acir) and acir_same_len != acir and js.loads(acir_same_len) != e["acir"]
+    try:
+        assert fe.plonk_prove_with_pk(acir_same_len, enc, pk_hex, srs, blinders=bl) != e["proof"]
+    except (ValueError, _lib.ZkmiError):
+        pass
+    assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"]
     _lib.check(L.zk_export_cache_clear())
     assert info() == (0, 0, 0)
     assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"] and info()[:2] == (1, 1)   # cold again, same bytes
