@@ -241,16 +241,27 @@ __device__ __forceinline__ void g2_add_affine29(Acc29G2& a, const Affine<Fp2>* _
     acc29g2_load(P1, XYZZ<Fp2>{q.x, q.y, one2, one2});
     acc29g2_add(a, P1);
 }
-__device__ bool g2_in_subgroup_dev29(const Affine<Fp2>* __restrict__ pp, const PsiConsts& K) {
+// [x0] P, the long half of the test (63 doublings, 27 additions): a kernel of its own under a two-waves-per-SIMD register bound (256 registers and 132 bytes of
+// scratch per lane; with the tail in the same kernel: 256 + 140 registers, one wave per SIMD)
+__global__ __launch_bounds__(128, 2) void k_g2_x0_mul(const Affine<Fp2>* __restrict__ pts, size_t n, XYZZ<Fp2>* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (pts[i].is_inf()) return;
     const uint32_t x0[2] = {0x4a6909f1u, 0x44e992b4u};  // 4965661367192848881
     Acc29G2 a;
     a.inf = true;
-    a.x = a.y = a.zz = a.zzz = f2_load29(K.gx);  // (defined values; never read while inf)
+    a.x = a.y = a.zz = a.zzz = f2_load29(pts[i].x);  // (defined values; never read while inf)
 #pragma unroll 1
-    for (int i = 62; i >= 0; i--) {
+    for (int k = 62; k >= 0; k--) {
         acc29g2_dbl(a);
-        if ((x0[i >> 5] >> (i & 31)) & 1) g2_add_affine29(a, pp);
+        if ((x0[k >> 5] >> (k & 31)) & 1) g2_add_affine29(a, pts + i);
     }
+    out[i] = acc29g2_to_xyzz(a);
+}
+// the rest: [x0 + 1] P + psi([x0] P) + psi^2([x0] P) == psi^3([2 x0] P)
+__device__ bool g2_subgroup_tail29(const Affine<Fp2>* __restrict__ pp, const XYZZ<Fp2>& x0p, const PsiConsts& K) {
+    Acc29G2 a;
+    acc29g2_load(a, x0p);
     const U29x2 gx = f2_contract29(f2_load29(K.gx)), gy = f2_contract29(f2_load29(K.gy));
     const Acc29G2 b = g2_psi_dev29(a, gx, gy);  // psi([x0] P)
     g2_add_affine29(a, pp);                      // [x0 + 1] P
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(128) void k_g2_decompress(const uint32_t* __restric
 // second half of G2Affine.SetBytes, a kernel of its own (the square root and the subgroup test in one kernel need 512 registers: one wave per SIMD; apart, each
 // runs with two or more): a point outside the r-torsion subgroup becomes the point at infinity and sets status bit 16
 template <bool FULL>
-__global__ __launch_bounds__(128) void k_g2_subgroup(Affine<Fp2>* __restrict__ pts, size_t n, PsiConsts psi, int* __restrict__ status) {
+__global__ __launch_bounds__(128) void k_g2_subgroup(Affine<Fp2>* __restrict__ pts, size_t n, const XYZZ<Fp2>* __restrict__ x0p, PsiConsts psi, int* __restrict__ status) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (pts[i].is_inf()) return;
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(128) void k_g2_subgroup(Affine<Fp2>* __restrict__ p
         const Affine<Fp2> p = pts[i];
         member = scalar_mul(p, rk).is_inf();
     } else {
-        member = g2_in_subgroup_dev29(pts + i, psi);
+        member = g2_subgroup_tail29(pts + i, x0p[i], psi);
     }
     if (!member) {
         atomicOr(status, 16);
@@ -400,8 +411,14 @@ int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void
     if (n) {
         ZK_LAUNCH(s, st, "g2_decompress", k_g2_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (const uint32_t*)d_raw, n, btd, psi, (Affine<Fp2>*)d_out, d_status);
         const dim3 grid((unsigned)((n + 127) / 128));
-        if (full) ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<true>), grid, dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
-        else ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<false>), grid, dim3(128), 0, (Affine<Fp2>*)d_out, n, psi, d_status);
+        if (full) {
+            ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<true>), grid, dim3(128), 0, (Affine<Fp2>*)d_out, n, (const XYZZ<Fp2>*)nullptr, psi, d_status);
+        } else {
+            XYZZ<Fp2>* x0p = (XYZZ<Fp2>*)s->alloc(n * sizeof(XYZZ<Fp2>));  // [x0] P of every point, between the two kernels of the test (the caller reserved it: G2_DECOMPRESS_SCRATCH)
+            if (!x0p) return set_err(ZK_ERR_ARG, "G2 decompression: the slot's workspace has no room for %zu scratch points", n);
+            ZK_LAUNCH(s, st, "g2_x0_mul", k_g2_x0_mul, grid, dim3(128), 0, (const Affine<Fp2>*)d_out, n, x0p);
+            ZK_LAUNCH(s, st, "g2_subgroup", (k_g2_subgroup<false>), grid, dim3(128), 0, (Affine<Fp2>*)d_out, n, (const XYZZ<Fp2>*)x0p, psi, d_status);
+        }
     }
     return ZK_OK;
 }
@@ -685,7 +702,7 @@ int zk_bn254_groth16_pk_read(const void* data, size_t len, int is_hex, int flags
     // ones to decompress (an Fp2 square root and the subgroup test each), so their kernel runs on the slot's second stream while the other 0.24 GB of a
     // 2^20-constraint key's text are still crossing PCIe on the first (round 5: 41 + 17 + 68 ms one after the other before).
     lap.lap("export.pk_read_slot");
-    ZK_TRY(s->reserve((is_hex ? 2 * at_bm : 0) + at_bm + 4096));
+    ZK_TRY(s->reserve((is_hex ? 2 * at_bm : 0) + at_bm + (cnt[4] + 2) * G2_DECOMPRESS_SCRATCH + 8 * 4096));
     lap.lap("export.pk_read_reserve");
     int* d_status = (int*)s->alloc(64);
     uint8_t* d_bytes = (uint8_t*)s->alloc(at_bm + 16);

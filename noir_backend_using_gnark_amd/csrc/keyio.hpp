@@ -17,6 +17,8 @@ int g1_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void
 int g1_compress_dev(Slot* s, hipStream_t st, const void* d_pts, size_t n, void* d_raw);
 // n x 64-byte compressed G2 points <-> affine Montgomery images; *d_status |= 8 on an invalid encoding, |= 16 on a point outside the r-torsion.
 // d_idx (compress only, may be NULL): gather -- point i of the output is d_pts[d_idx[i]]
+// (takes n * G2_DECOMPRESS_SCRATCH bytes from the slot's arena, 256-byte aligned per call: the caller's reserve() includes them)
+static constexpr size_t G2_DECOMPRESS_SCRATCH = 256;
 int g2_decompress_dev(Slot* s, hipStream_t st, const void* d_raw, size_t n, void* d_out, int* d_status);
 int g2_compress_dev(Slot* s, hipStream_t st, const void* d_pts, const uint32_t* d_idx, size_t n, void* d_raw);
 int g1_compress_idx_dev(Slot* s, hipStream_t st, const void* d_pts, const uint32_t* d_idx, size_t n, void* d_raw);
