@@ -388,17 +388,16 @@ def test_export_cache_keeps_circuit_and_key_resident_and_changes_no_byte(plonk_g
         fe.plonk_prove_with_pk(acir, ref.felts_wire(bad).hex(), pk_hex, srs, blinders=bl)
     with pytest.raises((ValueError, _lib.ZkmiError)):
         fe.plonk_prove_with_pk(js.dumps(plonk_golden[2]["acir"]), enc, pk_hex, srs, blinders=bl)
-    # another circuit whose text has the SAME length (one digit of one coefficient changed) while circuit and key are warm: the warm path has proved with the
-    # resident pair by the time the content keys say "another circuit" -- that proof must be dropped: what comes back is the new circuit's answer (these values
-    # do not satisfy it, or its key is not this key: refused), never the golden proof
+    # another circuit whose text has the SAME length while circuit and key are warm -- the last gate reads witness 1 (= 2) instead of witness 5 (= 0); a changed
+    # COEFFICIENT would not do: the prover takes the selectors from the key, and the proof would rightly be the same.  The warm path has proved with the resident
+    # pair by the time the content keys say "another circuit": that proof must be dropped.  What comes back is the new wiring's answer -- under this key's
+    # selectors the last gate now says 2 = 0: refused -- never the golden proof.
     assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"]
-    at = acir.rindex('"q_c": "') + len('"q_c": "') + 63  # the last digit of the last gate's constant
-    acir_same_len = acir[:at] + ("1" if acir[at] != "1" else "2") + acir[at + 1:]
-    assert len(acir_same_len) == len(acir) and acir_same_len != acir and js.loads(acir_same_len) != e["acir"]
-    try:
-        assert fe.plonk_prove_with_pk(acir_same_len, enc, pk_hex, srs, blinders=bl) != e["proof"]
-    except (ValueError, _lib.ZkmiError):
-        pass
+    at = acir.rindex(", 5]]") + 2
+    acir_same_len = acir[:at] + "1" + acir[at + 1:]
+    assert len(acir_same_len) == len(acir) and js.loads(acir_same_len)["opcodes"][-1]["Arithmetic"]["linear_combinations"][0][1] == 1 and values[0] != values[4]
+    with pytest.raises((ValueError, _lib.ZkmiError)):
+        fe.plonk_prove_with_pk(acir_same_len, enc, pk_hex, srs, blinders=bl)
     assert fe.plonk_prove_with_pk(acir, enc, pk_hex, srs, blinders=bl) == e["proof"]
     _lib.check(L.zk_export_cache_clear())
     assert info() == (0, 0, 0)
