@@ -1426,9 +1426,10 @@ def test_r1cs_sparse_mat_vec_at_2p12_constraints():
 
 
 def test_r1cs_load_of_a_large_system_goes_through_the_pinned_ring():
-    """zk_bn254_r1cs_load moves arrays of 16 MB and more through four threads and a ring of pinned buffers (ctx.hip h2d_big: a cold ProveWithPK uploads
-    0.2 GB of constraint system beside 0.37 GB of key text).  2^19 + 5 constraints with two entries per row of L (33.5 MB of coefficients: five pieces, the
-    last one ragged), one per row of R, none in O; coefficients drawn from sixteen field elements so that big integers can check every row."""
+    """zk_bn254_r1cs_load moves arrays of 1 MB and more through a ring of four pinned 8 MB buffers, filled by up to four threads (ctx.hip h2d_big: a cold
+    ProveWithPK uploads 0.2 GB of constraint system beside 0.37 GB of key text).  2^19 + 5 constraints with two entries per row of L (33.5 MB of coefficients:
+    five pieces, the last one ragged; 4 MB of indices: one piece, one thread), one per row of R, none in O; coefficients drawn from sixteen field elements so that
+    big integers can check every row."""
     g = ref.SplitMix64(0xA7)
     nc, nw = (1 << 19) + 5, 1 << 16
     T = [g.felt() for _ in range(16)]
