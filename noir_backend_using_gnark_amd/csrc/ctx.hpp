@@ -123,7 +123,10 @@ struct Ctx {
     int num_cus = 256;
     int prio_lo = 0, prio_hi = 0;  // hipDeviceGetStreamPriorityRange: numerically lower = higher priority
     std::mutex mu;
-    static constexpr int NSLOTS = 8;
+#ifndef ZKMI_NSLOTS
+#define ZKMI_NSLOTS 8  // (measurement builds may ask for more: make EXPERIMENTS=1 EXTRA=-DZKMI_NSLOTS=12 -- two proof sessions at once, tools/throughput_bench.py)
+#endif
+    static constexpr int NSLOTS = ZKMI_NSLOTS;
     Slot slots[NSLOTS];
 };
 // the profile is one per process (kernels of every entry fold into it)
