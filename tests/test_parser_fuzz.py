@@ -63,7 +63,7 @@ def test_sanitizer_mutation_run_of_the_host_parsers(tmp_path):
     rep = json.loads(out.stdout.strip().splitlines()[-1])
     assert rep["cases"] == 100000 and rep["mismatches"] == 0 and rep["accepted_acir"] > 500, rep  # a mutation run that accepts nothing tests nothing
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
-    assert time.time() - t0 < 60
+    assert time.time() - t0 < 150  # 18 s on an idle 8-core container; the bound only says the run stays cheap (a loaded container once took > 60)
 
 
 def test_streaming_lowering_of_a_synthetic_circuit_matches_the_oracle():
