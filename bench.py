@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 from bench_blocks.common import (GOLDEN, HBM_PEAK_GBS, MASK, N_PUBLIC, R_FR, HAND_WRITTEN_HOT, Instance, block_roofline, dominant_by_time, oracle_proof,  # noqa: E402,F401
                                  seed_at)
 from bench_blocks.export_path import export_path_block, export_path_groth16_block  # noqa: E402
+from bench_blocks.launch import needs_self_launch, self_launch  # noqa: E402
 from bench_blocks.inner_boundary import inner_boundary_block, two_slice_recombination  # noqa: E402
 from bench_blocks.micro import micro_block, micro_sharded_block, srs_block  # noqa: E402
 from bench_blocks.plonk import plonk_block  # noqa: E402
@@ -67,7 +68,13 @@ def main():
     ap.add_argument("--export-log-gates", type=int, default=19)
     ap.add_argument("--export-g16-log-constraints", type=int, default=20, help="size of the Groth16 export-path block (Preprocess / ProveWithPK / VerifyWithVK through libgnark_backend.so)")
     ap.add_argument("--verify-2p24-oracle", action="store_true", help="also check the 2^24 proof bytes against the CPU oracle (~2 min on 128 cores)")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher around: print the torch.distributed.run command this script would start and exit")
     args = ap.parse_args()
+
+    # `python3 bench.py --gpus N` typed as is: become the launcher (a child torch.distributed.run with N ranks) BEFORE anything touches the GPU -- no torch.cuda
+    # call, no libzkmi load above this line.  Under an existing launcher (RANK / WORLD_SIZE set) this is skipped and we are one of the ranks.
+    if needs_self_launch(args):
+        sys.exit(self_launch(args, os.path.abspath(__file__), sys.argv[1:]))
 
     import torch
     import noir_backend_using_gnark_amd as zk
@@ -167,6 +174,17 @@ def main():
         allp = par.all_gather_limbs(np.frombuffer(proof, dtype=np.uint64))
         assert (allp == allp[0]).all(), "ranks disagree on the proof bytes"
 
+    n_ranks_seen, rank_devices = 1, [local]
+    if par.dist().is_available() and par.dist().is_initialized():
+        on = "cuda" if par.dist().get_backend() == "nccl" else "cpu"
+        ones = torch.ones(1, dtype=torch.int64, device=on)
+        par.dist().all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+        devs = torch.zeros(world, dtype=torch.int64, device=on)
+        devs[rank] = local
+        par.dist().all_reduce(devs)
+        rank_devices = [int(x) for x in devs.tolist()]
+
     g1_units = N_g + N_g + (N_g - N_PUBLIC) + (N_g - 1)
     ms_per_step = elapsed / args.steps * 1e3
     value = g1_units * args.steps / elapsed
@@ -242,6 +260,8 @@ def main():
     }
     if par.dist().is_available() and par.dist().is_initialized():
         out["config"]["collectives"] = par.dist().get_backend()  # "nccl" = RCCL carried the exchanges of this run
+        out["n_ranks_seen"] = n_ranks_seen  # ranks that answered an all-reduce of ones over that backend, and the devices they ran on
+        out["config"]["rank_devices"] = rank_devices
 
     single = rank == 0 and not sharded
     # ---- the same proof through the entry point a cgo caller has: host slices in, 128 bytes out (PCIe-inclusive; never `value`)

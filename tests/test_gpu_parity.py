@@ -616,16 +616,20 @@ def test_two_process_sharded_proof_equals_single_process():
     ms = out["micro_2p14_sharded"]
     assert ms["ranks"] == 2 and ms["msm_same_on_every_rank"] and ms["msm_equals_odd_split_recombination"] and ms["ntt_inverse_of_forward_is_identity"]
     assert "parity_error" not in out
-    # the window-sharded decomposition (whole key on every rank, table rows split, h all-gathered) gives the same bytes
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--log-n", "12", "--shard", "windows"] + common,
-                           capture_output=True, text=True, timeout=900, env=env)
+    assert out["n_ranks_seen"] == 2 and out["config"]["collectives"] == "gloo"
+    # the window-sharded decomposition (whole key on every rank, table rows split, h all-gathered) gives the same bytes -- and this run is typed the way the
+    # driver types its one-GPU command, `python3 bench.py --gpus 2 ...` with NO launcher and no backend variable: bench.py starts its two ranks itself
+    # (bench_blocks/launch.py: a child torch.distributed.run; gloo because this box shows fewer devices than ranks)
+    env_bare = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ZKMI_DIST_BACKEND")}
+    multi = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--log-n", "12", "--shard", "windows"] + common,
+                           capture_output=True, text=True, timeout=900, env=env_bare)
     assert multi.returncode == 0, multi.stdout[-2000:] + multi.stderr[-2000:]
-    out = json.loads([l for l in multi.stdout.strip().splitlines() if l.startswith("{")][-1])
+    lines = [l for l in multi.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines  # ONE JSON line, relayed from the child's rank 0
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["proof_sha"] == sha1 and "window-sharded" in out["config"]["parallelism"]
+    assert out["n_ranks_seen"] == 2 and out["config"]["collectives"] == "gloo" and out["config"]["launch"]["ranks_share_gpus"] is True
+    assert "torch.distributed.run" in out["config"]["launch"]["command"]
 
 
 def test_rccl_executes_the_collectives_of_the_sharded_proof_world_of_one():
