@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from bench_blocks.common import (GOLDEN, HBM_PEAK_GBS, MASK, N_PUBLIC, R_FR, HAND_WRITTEN_HOT, Instance, block_roofline, dominant_by_time, oracle_proof,  # noqa: E402,F401
+from bench_blocks.common import (GOLDEN, HBM_PEAK_GBS, MASK, N_PUBLIC, R_FR, HAND_WRITTEN_HOT, Instance, block_roofline, dominant_by_time, oracle_proof, traffic_ratio, valu_fraction,  # noqa: E402,F401
                                  seed_at)
 from bench_blocks.export_path import export_path_block, export_path_groth16_block  # noqa: E402
 from bench_blocks.launch import needs_self_launch, self_launch  # noqa: E402
@@ -212,23 +212,15 @@ def main():
             traffic = json.load(open(tpath)).get(name, {}).get("by_log_n", {}).get(str(log_n), {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    # the honest ceiling of this kernel is the VALU, not HBM: mixed additions per second against the measured peak of the
-    # mixed-addition routine alone (tools/ubench.hip: k_madd29 17.4 G/s, G1; a G2 mixed addition costs ~2.1 G1 ones)
-    valu = None
-    if name.startswith("msm_accumulate"):
-        wb, dg = C.c_uint32(0), C.c_uint32(0)
-        _lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(N_g if win else N_loc), C.c_int(1 if pk.info()["tables"] else 0), C.byref(wb), C.byref(dg)))
-        digits = int(dg.value)
-        madds = units_per_launch * digits
-        peak = 17.4e9 if name.endswith("g1") else 17.4e9 / 2.1
-        valu = {"mixed_adds_per_launch": int(madds), "achieved_madd_per_s": round(madds / (per_launch_ms * 1e-3), 1), "peak_madd_per_s": peak,
-                "frac": round(madds / (per_launch_ms * 1e-3) / peak, 4), "window_bits": int(wb.value), "peak_source": "tools/ubench.hip k_madd29, 4 waves/SIMD: 17.44 G madd/s (9,017 cycles per wave)"}
+    # the honest ceiling of this kernel is the VALU, not HBM (bench_blocks/common.py valu_fraction)
+    valu = valu_fraction(L, _lib, name, units_per_launch, per_launch_ms, N_g if win else N_loc, bool(pk.info()["tables"]))
     roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(per_launch_ms, 4), "launches": launches, "measured_in": "a second pass of %d proofs with event pairs on (%.3f ms per proof; the timed region runs without them)"
                 % (args.steps, elapsed_profiled / args.steps * 1e3), "valu": valu, "dominant_by_time": dominant_by_time(prof, args.steps),
                 "note": "VALU-bound kernel (254-bit modular multiplies on 32-bit integer ALUs); see DESIGN.md for the ALU-issue fraction",
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+    traffic_ratio(roofline, units_per_launch, bytes_per_unit)
 
     # the metric's name is BASELINE.json's, verbatim; the size this run used is in config.workload / config.constraints
     baseline_metric = "Groth16 prove ms + BN254 G1 MSM scalar-muls/sec at 2^20 / 2^24 constraints"
@@ -304,7 +296,8 @@ def main():
         cpu_proof, cpu_s, cores = oracle_proof(inst, log_n)
         out["cpu_baseline"] = {"value": round(g1_units / cpu_s, 1), "unit": out["unit"], "cores": cores, "kind": "port",
                                "sample": "1 full proof of the same instance (2^%d constraints, same seeds) by oracle/bn254_oracle.c "
-                                         "(OpenMP, window-parallel Pippenger + radix-2 FFT; a restatement, not the gnark binary)" % log_n,
+                                         "(OpenMP, window-parallel Pippenger + radix-2 FFT; plain C on unsigned __int128, no assembly -- a restatement, "
+                                         "NOT a gnark figure: gnark's assembly field arithmetic would be several times quicker, so GPU / this is not a speed-up over gnark)" % log_n,
                                "prove_ms": round(cpu_s * 1e3, 1), "proof_bytes_match_gpu": bool(cpu_proof == proof)}
         if cpu_proof != proof:
             out["parity_error"] = "GPU proof bytes differ from the CPU oracle's"
@@ -353,7 +346,7 @@ def main():
                "verified_by": "two-slice recombination through the table-less msm5 path + finalize (independent window width / Horner / task sizes)",
                "proof_bytes_match_recombination": bool(two_slice_recombination(big, par, _lib, L) == p24)}
         n24 = prof24.get("msm_accumulate_g1", (1, 0))[0]
-        blk["roofline"] = block_roofline(prof24, reps, big.g1_units() / max(1.0, n24 / float(reps)), big.N, big.N, 24)
+        blk["roofline"] = block_roofline(prof24, reps, big.g1_units() / max(1.0, n24 / float(reps)), big.N, big.N, 24, L=L, lib=_lib, n_plan=big.N)
         if not blk["proof_bytes_match_recombination"]:
             out["parity_error"] = "2^24: single-call proof differs from the two-slice recombination"
         if args.verify_2p24_oracle:

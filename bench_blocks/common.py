@@ -113,7 +113,31 @@ def dominant_by_time(prof, steps):
     return {"kernel": name, "ms_per_step": round(tot / steps, 4), "launches_per_step": round(launches / steps, 2), "hand_written": "rocprim" not in name}
 
 
-def block_roofline(prof, steps, g1_units_per_launch, g2_units_per_launch, ntt_elems_per_launch, log_key, tables=True):
+def valu_fraction(L, lib, name, units_per_launch, per_launch_ms, n_plan, tables):
+    """The honest ceiling of an accumulate kernel is the VALU, not HBM: mixed additions per second against the measured peak of the mixed-addition routine
+    alone (tools/ubench.hip: k_madd29 17.4 G/s, G1; a G2 mixed addition costs ~2.1 G1 ones).  None for any other kernel."""
+    if not name.startswith("msm_accumulate") or L is None:
+        return None
+    wb, dg = C.c_uint32(0), C.c_uint32(0)
+    lib.check(L.zk_bn254_msm_plan_info(C.c_size_t(int(n_plan)), C.c_int(1 if tables else 0), C.byref(wb), C.byref(dg)))
+    madds = units_per_launch * int(dg.value)
+    peak = 17.4e9 if name.endswith("g1") else 17.4e9 / 2.1
+    return {"mixed_adds_per_launch": int(madds), "achieved_madd_per_s": round(madds / (per_launch_ms * 1e-3), 1), "peak_madd_per_s": peak,
+            "frac": round(madds / (per_launch_ms * 1e-3) / peak, 4), "window_bits": int(wb.value),
+            "peak_source": "tools/ubench.hip k_madd29, 4 waves/SIMD: 17.44 G madd/s (9,017 cycles per wave)"}
+
+
+def traffic_ratio(roofline, units_per_launch, bytes_per_unit):
+    """Adds the algorithmic bytes of one launch and counter traffic / algorithmic bytes (the window tables gather ~13 precomputed 64-byte rows per scalar
+    where the algorithm reads the point once: the ratio is the price of that trade, stated where the roofline is)."""
+    alg = float(units_per_launch) * bytes_per_unit
+    roofline["algorithmic_bytes_per_launch"] = int(alg)
+    roofline["traffic_over_algorithmic"] = None if not roofline.get("traffic") or alg <= 0 else round(roofline["traffic"] / alg, 2)
+    roofline["valu_frac"] = (roofline.get("valu") or {}).get("frac")
+    return roofline
+
+
+def block_roofline(prof, steps, g1_units_per_launch, g2_units_per_launch, ntt_elems_per_launch, log_key, tables=True, L=None, lib=None, n_plan=None):
     """`roofline` for one measured block (same definition as the headline's): dominant hand-written hot kernel by total time, achieved = algorithmic bytes
     per launch / average launch duration (event pairs inside libzkmi on the stream of the launch), traffic from profiles/pmc_traffic.json at that size."""
     hot = {k: v for k, v in prof.items() if k in HAND_WRITTEN_HOT[:4]}
@@ -130,7 +154,9 @@ def block_roofline(prof, steps, g1_units_per_launch, g2_units_per_launch, ntt_el
             traffic = json.load(open(tpath)).get(name, {}).get("by_log_n", {}).get(str(log_key), {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+    roof = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "avg_launch_ms": round(per, 4), "launches": launches, "units_per_launch": int(units), "algorithmic_bytes_per_unit": bpu,
+            "valu": valu_fraction(L, lib, name, units, per, n_plan, tables) if n_plan else None,
             "dominant_by_time": dominant_by_time(prof, steps),
             "kernel_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]}}
+    return traffic_ratio(roof, units, bpu)

@@ -79,7 +79,7 @@ def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", 
            "kernel_ms_per_proof": {k: round(v[1] / reps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]},
            # nine commitments of ~n scalars per proof against the SRS's window table; l, r, o and h1, h2, h3 are ONE accumulate launch each (three bucket sets),
            # so a launch carries 9n / (launches per proof) scalars on average; the transforms' passes work on n (small domain) or 4n points
-           "roofline": block_roofline(prof, reps, 9.0 * n * reps / max(1, prof.get("msm_accumulate_g1", (reps * 9, 0.0))[0]), 0, 4 * n, "plonk_%d" % log_n)}  # (traffic: the PMC pass of PLONK alone, tools/pmc_plonk.py)
+           "roofline": block_roofline(prof, reps, 9.0 * n * reps / max(1, prof.get("msm_accumulate_g1", (reps * 9, 0.0))[0]), 0, 4 * n, "plonk_%d" % log_n, L=L, lib=lib, n_plan=n)}  # (traffic: the PMC pass of PLONK alone, tools/pmc_plonk.py)
     if out["roofline"]:
         out["roofline"]["scalar_muls_per_proof"] = 9 * n
     # ---- checker (CPU oracle, after the timed region): decode Proof.WriteTo and run plonk.Verify's equations

@@ -218,7 +218,11 @@ hipStream_t Slot::hi() {
     return hi_locked();
 }
 hipStream_t Slot::hi_locked() {  // under owner->mu
-    if (!stream_hi_ && !g_hi_streams_wanted.load()) return stream;
+    // The answer is STICKY for one acquisition of the slot: zk_warm_session_streams() may flip g_hi_streams_wanted (another thread, a key's second proof in a
+    // lean process) while a proof in flight holds this slot -- if that proof's earlier hi() calls got the slot's own stream, its later ones must too, or work it
+    // ordered by stream (an upload followed by prepare(w)) would be split over two unordered streams.  begin_acquisition() clears the latch.
+    if (hi_latched_) return hi_latched_;
+    if (!stream_hi_ && !g_hi_streams_wanted.load()) return hi_latched_ = stream;
     if (!stream_hi_) {
         int cur = owner->device;
         (void)hipGetDevice(&cur);
@@ -228,7 +232,7 @@ hipStream_t Slot::hi_locked() {  // under owner->mu
         stream_hi_ = st;
         if (cur != owner->device) (void)hipSetDevice(cur);
     }
-    return stream_hi_;
+    return hi_latched_ = stream_hi_;
 }
 
 int acquire_slot(Slot** out) {
@@ -243,7 +247,7 @@ int acquire_slot(Slot** out) {
             for (int i = 0; i < Ctx::NSLOTS; i++)
                 if (!c.slots[i].busy) {
                     c.slots[i].busy = true;
-                    c.slots[i].reset();
+                    c.slots[i].begin_acquisition();
                     *out = &c.slots[i];
                     return slot_stream(&c.slots[i]);
                 }
@@ -270,7 +274,7 @@ int acquire_slots(int k, Slot** out) {
                 for (int i = 0; i < Ctx::NSLOTS && got < k; i++)
                     if (!c.slots[i].busy) {
                         c.slots[i].busy = true;
-                        c.slots[i].reset();
+                        c.slots[i].begin_acquisition();
                         out[got++] = &c.slots[i];
                     }
                 for (int i = 0; i < k; i++) {

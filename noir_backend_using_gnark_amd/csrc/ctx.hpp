@@ -93,6 +93,7 @@ struct Slot {
     // (tools/hip_start_bench.hip: 113-229 ms for the 16 of one entry) and a process that makes ONE proof -- nargo's -- uses three or four of them.
     hipStream_t stream = nullptr;     // normal priority; slots 0-4: created with the entry (ctx.hip init_entry says why), the others at their first acquisition
     hipStream_t stream_hi_ = nullptr; // high priority (critical-path chains of a proof): through hi()
+    hipStream_t hi_latched_ = nullptr; // what hi() answered first during THIS acquisition of the slot: it keeps answering that until the slot is released
     hipStream_t hi();                 // creates it on first use
     hipStream_t hi_locked();          // the same under the owner's mutex (acquire_slots)
     void sync_hi() { if (stream_hi_) (void)hipStreamSynchronize(stream_hi_); }
@@ -113,6 +114,7 @@ struct Slot {
     int reserve(size_t bytes);              // make sure the arena holds `bytes` (call before any alloc of a request)
     void* alloc(size_t bytes);              // bump allocate (256-B aligned); nullptr if reserve() was too small
     void reset() { arena_off = 0; }
+    void begin_acquisition() { arena_off = 0; hi_latched_ = nullptr; }  // acquire_slot / acquire_slots, under the owner's mutex
     int pinned_reserve(size_t bytes);
 };
 
