@@ -373,19 +373,23 @@ def main():
     if single and log_n == 20 and not args.no_plonk:
         if inst is not None:
             inst.free()
-        out["plonk_2p%d" % args.plonk_log_n] = plonk_block(L, _lib, args.plonk_log_n)
+        out["plonk_2p%d" % args.plonk_log_n] = plonk_block(L, _lib, args.plonk_log_n, cpu_oracle=not args.no_cpu_baseline)
         if not out["plonk_2p%d" % args.plonk_log_n]["proof_verifies"]:
             out["parity_error"] = "PLONK: the proof does not verify"
+        if not (out["plonk_2p%d" % args.plonk_log_n].get("cpu_baseline") or {"proof_bytes_match_gpu": True})["proof_bytes_match_gpu"]:
+            out["parity_error"] = "PLONK: GPU proof bytes differ from the C oracle's"
         inst = None
     # ---- configs[4] (standalone 2^26 MSM / NTT) and the SRS load of the reference's size
     if single and log_n == 20 and not args.no_micro:
         if inst is not None:
             inst.free()
             inst = None
-        out["micro_2p26"] = micro_block(L, _lib, zk, 26)
+        out["micro_2p26"] = micro_block(L, _lib, zk, 26, cpu_legs=not args.no_cpu_baseline)
         out["srs_read_1e6"] = srs_block(_lib)
         if not (out["micro_2p26"]["equals_split_recombination"] and out["micro_2p26"]["equals_window_table_path"] and out["srs_read_1e6"]["write_of_read_is_identity"]):
             out["parity_error"] = "micro-benchmark cross-check failed"
+        if not (out["micro_2p26"].get("cpu_baseline_msm", {}).get("point_matches_gpu", True) and out["micro_2p26"].get("cpu_baseline_ntt", {}).get("image_matches_gpu", True)):
+            out["parity_error"] = "2^26 micro-benchmark: the GPU's result differs from the CPU oracle's"
     if rank == 0:
         out["go_toolchain"] = go_toolchain_probe()
     # ---- configs[4] on several GPUs: the 2^26-point MSM range-sharded and the 2^26-point FFT block-sharded over the ranks

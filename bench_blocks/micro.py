@@ -12,7 +12,7 @@ from .common import *  # noqa: F401,F403
 from .common import ROOT, N_PUBLIC, HBM_PEAK_GBS, R_FR, seed_at
 
 
-def micro_block(L, lib, zk, log_n):
+def micro_block(L, lib, zk, log_n, cpu_legs=True):
     """BASELINE.json configs[4] on one GPU: standalone G1 MSM and Fr NTT of 2^log_n, inputs resident in HBM.  Each figure is tied to a check that is not
     the same code path run twice: the MSM equals the recombination of two partial MSMs split at an odd position AND the window-table path over the same
     points registered as resident bases; the transform inverts.  (tools/micro_bench.py is the stand-alone version.)"""
@@ -39,9 +39,32 @@ def micro_block(L, lib, zk, log_n):
     out = {"points": n, "g1_msm_ms": round(dt * 1e3, 2), "g1_scalar_muls_per_s": round(n / dt, 1), "g1_msm_hbm_frac": round(96 * n / dt / 8e12, 5),
            "g1_msm_window_tables_ms": round(dt_tab * 1e3, 2), "equals_split_recombination": bool((zb.g1_sum_partials(parts) == r).all() and (r == r0).all()),
            "equals_window_table_path": bool((rt == r).all())}
+    sc_h = None
+    if cpu_legs:
+        # ---- CPU legs (after the MSM's timed loops): the oracle's MultiExp on the SAME 2^log_n points and scalars, downloaded (6 GB at 2^26) -- its point is
+        # compared with the GPU's, its time is the reported baseline (plain C, no assembly: not a gnark figure)
+        from oracle import oracle as orc
+        pts_h, sc_h = pts.to_numpy(np.uint64, (n, 8)), sc.to_numpy(np.uint64, (n, 4))
+        t0 = time.perf_counter()
+        want = orc.g1_msm(pts_h, sc_h)
+        cpu_msm_s = time.perf_counter() - t0
+        del pts_h
+        out["cpu_baseline_msm"] = {"value": round(n / cpu_msm_s, 1), "unit": "G1 scalar-muls/s", "ms": round(cpu_msm_s * 1e3, 1), "cores": orc.max_threads(), "kind": "port",
+                                   "sample": "the same 2^%d-point MSM once by oracle/bn254_oracle.c orc_g1_msm (OpenMP bucket method, c = 16 signed digits; plain C, no assembly -- "
+                                             "not a gnark figure)" % log_n, "point_matches_gpu": bool((want == r).all())}
     dom = zk.Domain(n)
     head = sc.to_numpy(np.uint64, (4096, 4))
     dom.fft(sc, zk.DIF)
+    if cpu_legs:
+        gpu_sha = hashlib.sha256(sc.to_numpy(np.uint64, (n, 4)).tobytes()).hexdigest()
+        t0 = time.perf_counter()
+        orc.fr_ntt(sc_h, False, orc.DIF, inplace=True)
+        cpu_ntt_s = time.perf_counter() - t0
+        out["cpu_baseline_ntt"] = {"value": round(n / cpu_ntt_s, 1), "unit": "elements/s", "ms": round(cpu_ntt_s * 1e3, 1), "cores": orc.max_threads(), "kind": "port",
+                                   "sample": "the same 2^%d-point FFT(DIF) once by oracle/bn254_oracle.c orc_fr_ntt (OpenMP radix-2, twiddle table built inside the call; "
+                                             "plain C, no assembly -- not a gnark figure)" % log_n,
+                                   "image_matches_gpu": bool(hashlib.sha256(sc_h.tobytes()).hexdigest() == gpu_sha)}
+        del sc_h
     dom.fft_inverse(sc, zk.DIT)
     out["ntt_inverse_of_forward_is_identity"] = bool((sc.to_numpy(np.uint64, (4096, 4)) == head).all())
     t0 = time.perf_counter()

@@ -12,7 +12,7 @@ from .common import *  # noqa: F401,F403
 from .common import ROOT, N_PUBLIC, HBM_PEAK_GBS, R_FR, seed_at
 
 
-def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", "3"))):  # the variable: A/B runs of tools/ab_bench.py that need a quieter figure
+def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", "3")), cpu_oracle=True):  # the variable: A/B runs of tools/ab_bench.py that need a quieter figure
     """BASELINE.json configs[3]: "PLONK prove path (KZG-commit MSMs + coset NTTs) at 2^22 gates, 1xMI355X" -- the reference's only live
     prove path (plonk.Prove, backend/plonk/plonk.go:67).  Device-generated KZG SRS (real powers of alpha: kzg.NewSRS), a synthetic
     satisfiable circuit of 2^log_n rows (random wiring, random selectors, qK fixed per gate), plonk.Setup and plonk.Prove on the
@@ -112,6 +112,26 @@ def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", 
     acc = zv.plonk_verify(proof, vkb, g2, pub_m)
     out["host_verify"] = {"accepts": bool(acc), "ms": round((time.perf_counter() - t0) * 1e3, 2),
                           "rejects_wrong_public_input": bool(not zv.plonk_verify(proof, vkb, g2, pl.ints_to_mont_np([(pub[0] + 1) % ref.R] + pub[1:])))}
+    # ---- CPU leg (after everything timed): oracle/plonk_oracle_impl.h -- plonk.Setup and plonk.Prove restated in C / OpenMP -- on the SAME circuit, SRS, solution
+    # and blinders, downloaded from the device.  Its 548 bytes are compared with the GPU's (parity at the block's full size) and its time is the reported baseline.
+    if cpu_oracle:
+        from oracle import oracle as orc
+        host = lambda b, rows, w=4: b.to_numpy(np.uint64, (rows, w))
+        t0 = time.perf_counter()
+        ck = orc.PlonkKeyC(npub, nvars, host(coef[0], nc), host(coef[1], nc), host(coef[3], nc), host(coef[2], nc), host(dqk, nc), xa, xb, xc, host(d_srs, n + 3, 8))
+        cpu_setup_s = time.perf_counter() - t0
+        gpu_vk = np.stack([np.asarray(p, dtype=np.uint64).reshape(8) for p in list(vkd["s"]) + [vkd[k] for k in ("ql", "qr", "qm", "qo", "qk")]])
+        vk_same = bool((ck.vk_digests() == gpu_vk).all())  # [S1] [S2] [S3] [Ql] [Qr] [Qm] [Qo] [Qk]
+        t0 = time.perf_counter()
+        cpu_proof = ck.prove(host(dsol, nvars), bl)
+        cpu_s = time.perf_counter() - t0
+        ck.free()
+        out["cpu_baseline"] = {"value": round(9 * n / cpu_s, 1), "unit": "KZG-commit scalar-muls/s (whole plonk.Prove: 9 commitment MSMs + the transforms per proof)",
+                               "cores": orc.max_threads(), "kind": "port", "prove_ms": round(cpu_s * 1e3, 1), "setup_ms": round(cpu_setup_s * 1e3, 1),
+                               "sample": "1 full plonk.Prove of the same instance (2^%d gates: same circuit, SRS, solution and blinders, downloaded from the device) by "
+                                         "oracle/plonk_oracle_impl.h (OpenMP; plain C on unsigned __int128, no assembly -- a restatement, NOT a gnark figure)" % log_n,
+                               "proof_bytes_match_gpu": bool(cpu_proof == proof), "verifying_key_digests_match_gpu": vk_same}
+        out["gpu_value"] = round(9 * n / (ms * 1e-3), 1)
     pk.free()
     srs.free()
     return out

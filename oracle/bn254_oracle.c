@@ -415,6 +415,19 @@ typedef struct {
 } domain_t;
 
 static void fr_mul(fe *r, const fe *a, const fe *b) { fld_mul(&FR, r, a, b); }
+static void fr_pow_u64(fe *r, const fe *a, uint64_t e) { fe ee = {{e, 0, 0, 0}}; fld_pow(&FR, r, a, &ee); }
+/* out[i] = first * base^i, i < n -- chunked: one exponentiation per chunk, then a running product (the same values as the sequential product; only the
+ * association differs, and field multiplication is exact) */
+static void fr_powers(fe *out, size_t n, const fe *base, const fe *first, int nthreads) {
+    const size_t chunk = 1 << 14, nch = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) if (n >= 4096)
+    for (size_t c = 0; c < nch; c++) {
+        size_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        fe p; fr_pow_u64(&p, base, (uint64_t)lo);
+        if (first) fr_mul(&p, &p, first);
+        for (size_t i = lo; i < hi; i++) { out[i] = p; fr_mul(&p, &p, base); }
+    }
+}
 
 static void domain_init(domain_t *d, unsigned logn) {
     orc_init();
@@ -425,8 +438,8 @@ static void domain_init(domain_t *d, unsigned logn) {
     fe nn; fld_set_u64(&FR, &nn, (uint64_t)d->n); fld_inv(&FR, &d->card_inv, &nn);
     size_t h = d->n > 1 ? d->n / 2 : 1;
     d->tw = (fe *)malloc(sizeof(fe) * h); d->tw_inv = (fe *)malloc(sizeof(fe) * h);
-    d->tw[0] = FR.one; d->tw_inv[0] = FR.one;
-    for (size_t i = 1; i < h; i++) { fr_mul(&d->tw[i], &d->tw[i - 1], &d->gen); fr_mul(&d->tw_inv[i], &d->tw_inv[i - 1], &d->gen_inv); }
+    fr_powers(d->tw, h, &d->gen, NULL, orc_max_threads());
+    fr_powers(d->tw_inv, h, &d->gen_inv, NULL, orc_max_threads());
 }
 static void domain_free(domain_t *d) { free(d->tw); free(d->tw_inv); }
 
@@ -437,6 +450,7 @@ static size_t bitrev_sz(size_t i, unsigned logn) {
 }
 void orc_fr_bit_reverse(uint64_t *a_, unsigned logn) {
     fe *a = (fe *)a_; size_t n = (size_t)1 << logn;
+#pragma omp parallel for schedule(static) if (n >= 65536)
     for (size_t i = 0; i < n; i++) { size_t j = bitrev_sz(i, logn); if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; } }
 }
 
@@ -473,8 +487,7 @@ static void dit_inplace(fe *a, const fe *tw, unsigned logn, int nthreads) {
 static void scale_powers(fe *a, unsigned logn, const fe *base, int reversed, const fe *extra, int nthreads) {
     size_t n = (size_t)1 << logn;
     fe *pw = (fe *)malloc(sizeof(fe) * n);
-    pw[0] = extra ? *extra : FR.one;
-    for (size_t i = 1; i < n; i++) fr_mul(&pw[i], &pw[i - 1], base);
+    fr_powers(pw, n, base, extra, nthreads);
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) if (n >= 4096)
     for (size_t i = 0; i < n; i++) { size_t e = reversed ? bitrev_sz(i, logn) : i; fr_mul(&a[i], &a[i], &pw[e]); }
     free(pw);
@@ -565,3 +578,6 @@ int orc_groth16_prove(const orc_groth16_pk *pk, const uint64_t *a, const uint64_
     free(h);
     return 0;
 }
+
+/* ------------------------------------------------------------------ PLONK (plonk.Setup / plonk.Prove restated; see the file) */
+#include "plonk_oracle_impl.h"

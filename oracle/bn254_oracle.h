@@ -82,6 +82,29 @@ int orc_groth16_prove(const orc_groth16_pk *pk, const uint64_t *a, const uint64_
                       size_t n_constraints, const uint64_t *w, const uint64_t r[4], const uint64_t s[4],
                       int nthreads, uint8_t proof_out[128], uint64_t *points_out);
 
+/* ---- PLONK (oracle/plonk_oracle_impl.h): plonk.Setup and plonk.Prove of gnark v0.8.0 restated, the C twin of oracle/plonk_ref.py.
+ * The constraint system is the reference's own: one gate qL*xa + qR*xb + qO*xc + qM*xa*xb + qC = 0 per arithmetic opcode
+ * (/root/reference/gnark_backend_ffi/backend/plonk/sparse_r1cs.go:44-107); variables = public first, then secret. */
+typedef struct {
+    size_t n_public, n_constraints, n_vars;
+    const uint64_t *ql, *qr, *qm, *qo, *qk;   /* n_constraints Montgomery Fr each */
+    const uint32_t *xa, *xb, *xc;             /* n_constraints variable indices each */
+    const uint64_t *srs_g1;                   /* kzg.SRS.G1: srs_len >= domain size + 3 affine points; must outlive the key */
+    size_t srs_len;
+} orc_plonk_circuit;
+typedef struct orc_plonk_pk orc_plonk_pk;
+orc_plonk_pk *orc_plonk_setup(const orc_plonk_circuit *c, int nthreads);   /* NULL on bad arguments */
+void orc_plonk_pk_free(orc_plonk_pk *pk);
+void orc_plonk_pk_sizes(const orc_plonk_pk *pk, size_t *n, size_t *n4);
+/* which 0..8: canonical ql, qr, qm, qo, cqk, Lagrange lqk, canonical s1, s2, s3 (n elements each); 9: the verifying key's digests
+ * [S1] [S2] [S3] [Ql] [Qr] [Qm] [Qo] [Qk] (8 affine points); 10: the permutation (3n uint32) */
+void orc_plonk_pk_get(const orc_plonk_pk *pk, int which, void *out);
+/* solution: all variables (Montgomery), blinders: 9 Montgomery scalars (l: 2, r: 2, o: 2, z: 3); proof_out = Proof.WriteTo's 548 bytes;
+ * challenges_out (optional): gamma, beta, alpha, zeta, kzg gamma.  0 ok, -2 the constraint system is not satisfied, -1 bad arguments. */
+int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution, const uint64_t *blinders, int nthreads, uint8_t proof_out[548],
+                    uint64_t *challenges_out);
+void orc_sha256(const uint8_t *data, size_t n, uint8_t out[32]);
+
 int orc_max_threads(void);
 #ifdef __cplusplus
 }

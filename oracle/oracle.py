@@ -14,7 +14,7 @@ DIT, DIF = 0, 1
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("bn254_oracle.c", "bn254_oracle.h", "curve_tmpl.h")]
+    src = [os.path.join(_HERE, f) for f in ("bn254_oracle.c", "bn254_oracle.h", "curve_tmpl.h", "plonk_oracle_impl.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "build/libbn254_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
@@ -185,8 +185,8 @@ def g2_compress(a) -> bytes:
     out = (C.c_uint8 * 64)(); lib().orc_g2_compress(_p(_u64(a)), out); return bytes(out)
 
 
-def fr_ntt(a, inverse: bool, decimation: int, coset: bool = False, nthreads: int = 0) -> np.ndarray:
-    a = _u64(a).copy()
+def fr_ntt(a, inverse: bool, decimation: int, coset: bool = False, nthreads: int = 0, inplace: bool = False) -> np.ndarray:
+    a = _u64(a) if inplace else _u64(a).copy()
     n = a.size // 4
     logn = n.bit_length() - 1
     assert 1 << logn == n
@@ -229,3 +229,82 @@ def groth16_prove(pk: dict, a, b, c, w, r, s, nthreads: int = 0):
                                  C.c_int(nthreads or max_threads()), proof, _p(pts))
     assert rc == 0
     return bytes(proof), pts
+
+
+# ------------------------------------------------------------------------------------------------ PLONK (oracle/plonk_oracle_impl.h)
+class _PlonkCircuit(C.Structure):
+    _fields_ = [("n_public", C.c_size_t), ("n_constraints", C.c_size_t), ("n_vars", C.c_size_t)] + \
+               [(k, C.POINTER(C.c_uint64)) for k in ("ql", "qr", "qm", "qo", "qk")] + \
+               [(k, C.POINTER(C.c_uint32)) for k in ("xa", "xb", "xc")] + \
+               [("srs_g1", C.POINTER(C.c_uint64)), ("srs_len", C.c_size_t)]
+
+
+class PlonkKeyC:
+    """plonk.Setup's key held by the C oracle (orc_plonk_setup): canonical selector / permutation polynomials + the verifying key's digests."""
+    NAMES = ("ql", "qr", "qm", "qo", "cqk", "lqk", "s1", "s2", "s3")
+
+    def __init__(self, n_public, n_vars, ql, qr, qm, qo, qk, xa, xb, xc, srs_g1, nthreads: int = 0):
+        """ql .. qk: (n_constraints, 4) Montgomery Fr; xa, xb, xc: uint32 variable indices; srs_g1: (>= n + 3, 8) affine points."""
+        L = lib()
+        L.orc_plonk_setup.restype = C.c_void_p
+        L.orc_plonk_prove.restype = C.c_int
+        co = [_u64(v).reshape(-1, 4) for v in (ql, qr, qm, qo, qk)]
+        xs = [np.ascontiguousarray(v, dtype=np.uint32) for v in (xa, xb, xc)]
+        self._srs = _u64(srs_g1).reshape(-1, 8)  # borrowed by the C side: kept alive here
+        nc = xs[0].size
+        assert all(c.shape[0] == nc for c in co) and all(x.size == nc for x in xs)
+        u32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+        circ = _PlonkCircuit(n_public, nc, n_vars, *[_p(c) for c in co], *[u32p(x) for x in xs], _p(self._srs), self._srs.shape[0])
+        self.nthreads = nthreads or max_threads()
+        self.h = L.orc_plonk_setup(C.byref(circ), C.c_int(self.nthreads))
+        if not self.h:
+            raise ValueError("orc_plonk_setup refused the circuit (empty system, a variable index out of range, or an SRS shorter than n + 3)")
+        n, n4 = C.c_size_t(0), C.c_size_t(0)
+        L.orc_plonk_pk_sizes(C.c_void_p(self.h), C.byref(n), C.byref(n4))
+        self.n, self.n4, self.n_public = n.value, n4.value, n_public
+
+    def poly(self, name: str) -> np.ndarray:
+        out = np.zeros((self.n, 4), dtype=np.uint64)
+        lib().orc_plonk_pk_get(C.c_void_p(self.h), C.c_int(self.NAMES.index(name)), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def vk_digests(self) -> np.ndarray:
+        """[S1] [S2] [S3] [Ql] [Qr] [Qm] [Qo] [Qk] as (8, 8) affine Montgomery limbs."""
+        out = np.zeros((8, 8), dtype=np.uint64)
+        lib().orc_plonk_pk_get(C.c_void_p(self.h), C.c_int(9), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def perm(self) -> np.ndarray:
+        out = np.zeros(3 * self.n, dtype=np.uint32)
+        lib().orc_plonk_pk_get(C.c_void_p(self.h), C.c_int(10), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def prove(self, solution, blinders, want_challenges: bool = False):
+        """solution: (n_vars, 4) Montgomery; blinders: (9, 4) Montgomery.  -> the 548 bytes of Proof.WriteTo (and the five challenges as ints)."""
+        sol, bl = _u64(solution).reshape(-1, 4), _u64(blinders).reshape(9, 4)
+        proof = (C.c_uint8 * 548)()
+        ch = np.zeros((5, 4), dtype=np.uint64)
+        rc = lib().orc_plonk_prove(C.c_void_p(self.h), _p(sol), _p(bl), C.c_int(self.nthreads), proof, _p(ch))
+        if rc == -2:
+            raise AssertionError("the constraint system is not satisfied (the quotient is not a polynomial)")
+        assert rc == 0, rc
+        if want_challenges:
+            return bytes(proof), dict(zip(("gamma", "beta", "alpha", "zeta", "kzg_gamma"), from_mont_vec(ch)))
+        return bytes(proof)
+
+    def free(self):
+        if self.h:
+            lib().orc_plonk_pk_free(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sha256(data: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().orc_sha256((C.c_uint8 * len(data)).from_buffer_copy(data) if data else None, C.c_size_t(len(data)), out)
+    return bytes(out)

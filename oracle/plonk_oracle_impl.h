@@ -78,21 +78,9 @@ static void fr_from_digest(fe *out, const uint8_t d[32]) {
 /* ------------------------------------------------------------------ small Fr helpers */
 static inline void fr_add(fe *r, const fe *a, const fe *b) { fld_add(&FR, r, a, b); }
 static inline void fr_sub(fe *r, const fe *a, const fe *b) { fld_sub(&FR, r, a, b); }
-static void fr_pow_u64(fe *r, const fe *a, uint64_t e) { fe ee = {{e, 0, 0, 0}}; fld_pow(&FR, r, a, &ee); }
 static fe *fr_zeros(size_t n) { return (fe *)calloc(n ? n : 1, sizeof(fe)); }
 static int thr(int nthreads) { return nthreads > 0 ? nthreads : 1; }
 
-/* out[i] = first * base^i, i < n (chunked: one exponentiation per chunk, then a running product) */
-static void fr_powers(fe *out, size_t n, const fe *base, const fe *first, int nthreads) {
-    const size_t chunk = 1 << 14, nch = (n + chunk - 1) / chunk;
-#pragma omp parallel for schedule(static) num_threads(thr(nthreads)) if (n >= 4096)
-    for (size_t c = 0; c < nch; c++) {
-        size_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
-        fe p; fr_pow_u64(&p, base, (uint64_t)lo);
-        if (first) fr_mul(&p, &p, first);
-        for (size_t i = lo; i < hi; i++) { out[i] = p; fr_mul(&p, &p, base); }
-    }
-}
 /* p(x), Horner per chunk and a combination of the chunks (the value of a polynomial does not depend on the association) */
 static void poly_eval_c(fe *out, const fe *p, size_t len, const fe *x, int nthreads) {
     const size_t chunk = 1 << 14, nch = (len + chunk - 1) / chunk;
@@ -109,6 +97,24 @@ static void poly_eval_c(fe *out, const fe *p, size_t len, const fe *x, int nthre
     for (size_t c = nch; c-- > 0;) { fr_mul(&acc, &acc, &xc); fr_add(&acc, &acc, &part[c]); }
     free(part);
     *out = acc;
+}
+/* v[i] <- v[0] * ... * v[i]: per-chunk running products, a scan over the chunks' totals, one more multiplication per element */
+static void prefix_products(fe *v, size_t n, int nthreads) {
+    const size_t chunk = 1 << 14, nch = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static) num_threads(thr(nthreads)) if (n >= 4096)
+    for (size_t c = 0; c < nch; c++) {
+        const size_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        for (size_t i = lo + 1; i < hi; i++) fr_mul(&v[i], &v[i], &v[i - 1]);
+    }
+    fe *carry = (fe *)malloc(sizeof(fe) * nch);
+    carry[0] = FR.one;
+    for (size_t c = 1; c < nch; c++) fr_mul(&carry[c], &carry[c - 1], &v[c * chunk - 1]);
+#pragma omp parallel for schedule(static) num_threads(thr(nthreads)) if (n >= 4096)
+    for (size_t c = 1; c < nch; c++) {
+        const size_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        for (size_t i = lo; i < hi; i++) fr_mul(&v[i], &v[i], &carry[c]);
+    }
+    free(carry);
 }
 /* kzg.dividePolyByXminusA: (f - f(a)) / (X - a) by synthetic division, in place; the quotient is f[1 .. len) afterwards */
 static void divide_by_x_minus_a_c(fe *f, size_t len, const fe *fa, const fe *a) {
@@ -291,7 +297,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
     fe *num = (fe *)malloc(sizeof(fe) * n), *den = (fe *)malloc(sizeof(fe) * n);
     num[0] = FR.one; den[0] = FR.one;
 #pragma omp parallel for schedule(static) num_threads(T) if (n >= 4096)
-    for (size_t i = 0; i + 1 < n; i++) {
+    for (size_t i = 0; i < n - 1; i++) {
         fe a = FR.one, bb = FR.one, t;
         for (int j = 0; j < 3; j++) {
             fr_mul(&t, &beta, &id[i + (size_t)j * n]); fr_add(&t, &t, &lag[j][i]); fr_add(&t, &t, &gamma); fr_mul(&a, &a, &t);
@@ -299,15 +305,19 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
         }
         num[i + 1] = a; den[i + 1] = bb;
     }
-    for (size_t i = 1; i < n; i++) { fr_mul(&num[i], &num[i], &num[i - 1]); fr_mul(&den[i], &den[i], &den[i - 1]); }
+    prefix_products(num, n, nthreads); prefix_products(den, n, nthreads);
     fe *bz = fr_zeros(n + 3);
-    {   /* z = num / den: one inversion (Montgomery's trick) */
-        fe *pre = (fe *)malloc(sizeof(fe) * n);
-        fe acc = FR.one;
-        for (size_t i = 0; i < n; i++) { pre[i] = acc; fr_mul(&acc, &acc, &den[i]); }
-        fe inv; fld_inv(&FR, &inv, &acc);
-        for (size_t i = n; i-- > 0;) { fe di; fr_mul(&di, &inv, &pre[i]); fr_mul(&inv, &inv, &den[i]); fr_mul(&bz[i], &num[i], &di); }
-        free(pre);
+    {   /* z = num / den: one inversion per chunk (Montgomery's trick) */
+        const size_t chunk = 1 << 12, nch = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static) num_threads(T) if (n >= 4096)
+        for (size_t c = 0; c < nch; c++) {
+            const size_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            fe pre[1 << 12];
+            fe acc = FR.one;
+            for (size_t i = lo; i < hi; i++) { pre[i - lo] = acc; fr_mul(&acc, &acc, &den[i]); }
+            fe inv; fld_inv(&FR, &inv, &acc);
+            for (size_t i = hi; i-- > lo;) { fe di; fr_mul(&di, &inv, &pre[i - lo]); fr_mul(&inv, &inv, &den[i]); fr_mul(&bz[i], &num[i], &di); }
+        }
     }
     free(num); free(den); free(id);
     for (int k = 0; k < 3; k++) free(lag[k]);

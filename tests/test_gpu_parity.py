@@ -926,8 +926,9 @@ def test_g1_msm_2p26_properties():
     rb.free()
 
 
-def test_ntt_2p26_identity_and_sharded_equivalence():
-    """BASELINE configs[4] size, the transform: at 2^26 points (three passes, 2 GiB in HBM) FFTInverse(DIT) . FFT(DIF) is the identity on the device, and
+def test_ntt_2p26_vs_oracle_identity_and_sharded_equivalence():
+    """BASELINE configs[4] size, the transform: at 2^26 points (three passes, 2 GiB in HBM) FFT(DIF) and FFTInverse(DIF, coset) equal the CPU oracle's images
+    (by SHA-256), FFTInverse(DIT) . FFT(DIF) is the identity on the device, and
     the 8-rank block-sharded schedule (zk_bn254_ntt_shard_dev: cross stages on transposed data, size-2^23 block transforms, two all-to-all transposes,
     radix-8 columns), played by this one GPU for all ranks, gives the single-GPU FFT(DIF) bit for bit."""
     from tests import sharded_h_ref as sh
@@ -941,6 +942,10 @@ def test_ntt_2p26_identity_and_sharded_equivalence():
     want = sha_image(d.to_numpy(np.uint64, (n, 4)))
     dom.fft_inverse(d, zk.DIT)
     assert (d.to_numpy(np.uint64, (n, 4)) == x0).all()
+    # ... and against the ORACLE at this size, once: FFT(DIF) and the mode computeH ends with, FFTInverse(DIF, coset) (orc.fr_ntt on the host cores, 2 GiB each)
+    assert sha_image(orc.fr_ntt(x0, False, orc.DIF)) == want
+    dom.fft_inverse(d, zk.DIF, coset=True)
+    assert sha_image(d.to_numpy(np.uint64, (n, 4))) == sha_image(orc.fr_ntt(x0, True, orc.DIF, coset=True))
     d.free()
     M = n // G
     blocks = [x0[r * M:(r + 1) * M].copy() for r in range(G)]

@@ -113,18 +113,30 @@ def test_plonk_random_circuits_vs_oracle(nc, nvars, npub):
     pts = orc.g1_gen_points(500 + nc, n + 3)
     rb = zb.ResidentBases(pts)
     pk = zp.setup(_circuit(spr), rb)
-    opk, ovk = pl.plonk_setup(spr, dict(g1=pts, g2=None), fast=True)
-    assert _vk_hex(pk.vk) == dict(s=[ref.g1_affine_mont_bytes(p).hex() for p in ovk["s"]], **{k: ref.g1_affine_mont_bytes(ovk[k]).hex() for k in ("ql", "qr", "qm", "qo", "qk")})
+    g = spr.constraints
+    if nc >= 1000:
+        # the C / OpenMP oracle (oracle/plonk_oracle_impl.h; equal to the pure-Python restatement on the fixtures and a random circuit: tests/test_plonk_oracle.py)
+        ck = orc.PlonkKeyC(npub, spr.n_vars, *[M([c[k] for c in g]) for k in (0, 1, 3, 2, 4)], *[[c[k] for c in g] for k in (5, 6, 7)], pts)
+        polys = {k: ck.poly(k) for k in ck.NAMES}
+        perm, log_n0 = ck.perm(), ck.n.bit_length() - 1
+        dig = [d.tobytes().hex() for d in ck.vk_digests()]
+        want_vk = dict(s=dig[0:3], ql=dig[3], qr=dig[4], qm=dig[5], qo=dig[6], qk=dig[7])
+        oracle_proof = lambda b: ck.prove(M(sol), M(b))
+    else:
+        opk, ovk = pl.plonk_setup(spr, dict(g1=pts, g2=None), fast=True)
+        polys = {k: M(opk[k]) for k in ("ql", "qr", "qm", "qo", "cqk", "lqk", "s1", "s2", "s3")}
+        perm, log_n0 = opk["perm"], opk["d0"].logn
+        want_vk = dict(s=[ref.g1_affine_mont_bytes(p).hex() for p in ovk["s"]], **{k: ref.g1_affine_mont_bytes(ovk[k]).hex() for k in ("ql", "qr", "qm", "qo", "qk")})
+        oracle_proof = lambda b: pl.plonk_proof_bytes(pl.plonk_prove(opk, sol, b, fast=True))
+    assert _vk_hex(pk.vk) == want_vk
     # the key's canonical polynomials are gnark's (Ql, Qr, Qm, Qo, CQk, S1, S2, S3, LQk)
     for which, name in ((0, "ql"), (2, "qm"), (4, "cqk"), (5, "s1"), (7, "s3"), (8, "lqk")):
-        assert (pk.export(which, n) == M(opk[name])).all(), name
+        assert (pk.export(which, n) == polys[name]).all(), name
     bl = ref.rand_felts(77 + nc, 9)
-    want = pl.plonk_proof_bytes(pl.plonk_prove(opk, sol, bl, fast=True))
+    want = oracle_proof(bl)
     assert zp.prove(pk, M(sol), M(bl)) == want
     # the same key through gnark's own ProvingKey fields (what a shim holds after plonk.Setup / ReadFrom)
-    polys = {k: M(opk[k]) for k in ("ql", "qr", "qm", "qo", "cqk", "lqk", "s1", "s2", "s3")}
-    g = spr.constraints
-    pk2 = zp.load_proving_key(opk["d0"].logn, npub, spr.n_vars, polys, opk["perm"], [c[5] for c in g], [c[6] for c in g], [c[7] for c in g], pk.vk, rb)
+    pk2 = zp.load_proving_key(log_n0, npub, spr.n_vars, polys, perm, [c[5] for c in g], [c[6] for c in g], [c[7] for c in g], pk.vk, rb)
     assert zp.prove(pk2, M(sol), M(bl)) == want   # a loaded key: the linearised digest by MSM, and compared with the value obtained by linearity
     assert zp.prove(pk2, M(sol), M(bl)) == want   # ... which this second proof then uses (the digests proved consistent)
     # the same proof with l, r, o committed from the WIRE VALUES against the Lagrange form of the base array (zk_bn254_plonk_pk_lagrange_srs: the inverse
@@ -137,9 +149,9 @@ def test_plonk_random_circuits_vs_oracle(nc, nvars, npub):
     kern, _ = _lib.split_profile(_lib.profile_read())
     _lib.profile(False)
     assert ("plonk_blind_tail" in kern) == (n + 2 >= 4096), sorted(kern)
-    if nc == 4093:  # other blinders through the two extra points (one size: the oracle's prover is the slow part of this test)
+    if nc == 4093:  # other blinders through the two extra points
         other = ref.rand_felts(990 + nc, 9)
-        assert zp.prove(pk2, M(sol), M(other)) == pl.plonk_proof_bytes(pl.plonk_prove(opk, sol, other, fast=True))
+        assert zp.prove(pk2, M(sol), M(other)) == oracle_proof(other)
     pk2.free()
     pk.free()
     rb.free()
@@ -451,21 +463,24 @@ def test_plonk_exports_reproduce_handle_values_for_two_and_three_public_inputs()
             s_.free()
 
 
-def test_plonk_2p20_gates_accepted_by_both_verifiers():
-    """Size-independent property at 2^20 gates (the block bench.py runs at 2^22, configs[3]): a proof of a synthetic circuit made on the device is accepted
-    by the oracle's pairing verifier AND by the product's host-side verifier reading the wire images; both reject another public input."""
-    import ctypes as C
+def test_plonk_2p20_gates_bytes_equal_the_c_oracle_and_both_verifiers_accept():
+    """2^20 gates (the block bench.py runs at 2^22, configs[3]): the 548 proof bytes of a synthetic circuit proved on the device equal the C / OpenMP oracle's
+    (oracle/plonk_oracle_impl.h: its own plonk.Setup and plonk.Prove on the downloaded circuit, SRS, solution and blinders), the verifying keys agree, and the
+    proof is accepted by the oracle's pairing verifier AND by the product's host-side verifier reading the wire images; both reject another public input."""
     import bench
     L = _lib.lib()
     d = bench.plonk_block(L, _lib, 20, reps=1)
     assert d["gates"] == 1 << 20 and d["proof_verifies"] and d["wrong_public_input_rejected"]
     assert d["host_verify"]["accepts"] and d["host_verify"]["rejects_wrong_public_input"]
+    assert d["cpu_baseline"]["proof_bytes_match_gpu"] and d["cpu_baseline"]["verifying_key_digests_match_gpu"] and d["same_bytes_both_ways"]
 
 
-def test_plonk_2p22_gates_accepted_by_both_verifiers():
+def test_plonk_2p22_gates_bytes_equal_the_c_oracle_and_both_verifiers_accept():
     """BASELINE configs[3] itself (2^22 gates; 4n = 2^24-point coset transforms, nine 2^22-point commitments against the SRS's window tables): the
-    proof bench.py times is accepted by the oracle's pairing verifier and by the product's host-side verifier; both reject another public input."""
+    proof bench.py times equals the C oracle's bytes, and is accepted by the oracle's pairing verifier and by the product's host-side verifier; both
+    reject another public input."""
     import bench
     d = bench.plonk_block(_lib.lib(), _lib, 22, reps=1)
     assert d["gates"] == 1 << 22 and d["proof_verifies"] and d["wrong_public_input_rejected"]
     assert d["host_verify"]["accepts"] and d["host_verify"]["rejects_wrong_public_input"]
+    assert d["cpu_baseline"]["proof_bytes_match_gpu"] and d["cpu_baseline"]["verifying_key_digests_match_gpu"] and d["same_bytes_both_ways"]

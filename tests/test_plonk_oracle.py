@@ -116,3 +116,75 @@ def test_fast_backend_equals_pure_python():
     pp = pl.plonk_prove(pk_p, sol, bl, fast=False)
     assert pl.plonk_proof_bytes(pf) == pl.plonk_proof_bytes(pp)
     assert pl.plonk_verify(vk_f, pf, sol[:npub])
+
+
+# ------------------------------------------------------------------------------------------------ the C / OpenMP twin (oracle/plonk_oracle_impl.h)
+def _c_key(spr, srs_np, nthreads=0):
+    from oracle import oracle as orc
+    co = [pl.ints_to_mont_np([g[k] for g in spr.constraints]) if spr.constraints else pl._np().zeros((0, 4), dtype="uint64") for k in (0, 1, 3, 2, 4)]  # ql, qr, qm, qo, qk
+    xs = [[g[k] for g in spr.constraints] for k in (5, 6, 7)]
+    return orc.PlonkKeyC(spr.n_public, spr.n_vars, *co, *xs, srs_np, nthreads=nthreads)
+
+
+def test_c_sha256_is_sha256():
+    import hashlib
+    from oracle import oracle as orc
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000):
+        data = bytes((7 * i + n) & 0xFF for i in range(n))
+        assert orc.sha256(data) == hashlib.sha256(data).digest(), n
+
+
+def test_c_plonk_oracle_reproduces_the_fixtures(plonk_golden):
+    """orc_plonk_setup / orc_plonk_prove on the reference's three demo circuits: the key's polynomials, the verifying key's digests, the permutation,
+    the five Fiat-Shamir challenges and the 548 proof bytes equal the pure-Python restatement's and the committed fixtures."""
+    np = pl._np()
+    for e in plonk_golden:
+        spr, sol, srs = _instance(e)
+        srs_np = np.stack([pl.g1_to_np(p) for p in srs["g1"]])
+        pk, vk = pl.plonk_setup(spr, srs)
+        ck = _c_key(spr, srs_np)
+        assert ck.n == pk["n"] and ck.n4 == pk["d1"].n
+        for name in ck.NAMES:
+            assert pl.mont_np_to_ints(ck.poly(name)) == list(pk[name]), (e["name"], name)
+        assert list(ck.perm()) == list(pk["perm"])
+        dig = ck.vk_digests()
+        want = [vk["s"][0], vk["s"][1], vk["s"][2], vk["ql"], vk["qr"], vk["qm"], vk["qo"], vk["qk"]]
+        assert [pl.g1_from_np(d) for d in dig] == want
+        proof, ch = ck.prove(pl.ints_to_mont_np(sol), pl.ints_to_mont_np([h2i(v) for v in e["blinders"]]), want_challenges=True)
+        assert proof.hex() == e["proof"], e["name"]
+        assert {k: "%064x" % ch[k] for k in e["challenges"]} == e["challenges"]
+        ck.free()
+
+
+def test_c_plonk_oracle_equals_python_on_a_random_circuit_and_refuses_a_bad_witness():
+    """2^9 rows, random wiring with repeated variables (long permutation cycles), several public inputs, an SRS of exactly n + 3 points; one thread and many
+    give the same bytes; a witness that violates a gate is refused like the Python prover refuses it."""
+    import random
+    np = pl._np()
+    rng = random.Random(0xC0FFEE)
+    npub, nvars, nc = 3, 200, 505
+    sol = [rng.randrange(R) for _ in range(nvars)]
+    gates = []
+    for _ in range(nc):
+        xa, xb, xc = (rng.randrange(nvars) for _ in range(3))
+        ql, qr, qo, qm = (rng.randrange(R) for _ in range(4))
+        qc = (-(ql * sol[xa] + qr * sol[xb] + qo * sol[xc] + qm * sol[xa] * sol[xb])) % R
+        gates.append((ql, qr, qo, qm, qc, xa, xb, xc))
+    spr = pl.SparseR1CS(npub, nvars - npub, gates)
+    assert spr.is_satisfied(sol)
+    srs = pl.kzg_new_srs(512 + 3, 0x1234567, fast=True)
+    bl = [rng.randrange(R) for _ in range(9)]
+    pk, vk = pl.plonk_setup(spr, srs, fast=True)
+    want = pl.plonk_proof_bytes(pl.plonk_prove(pk, sol, bl, fast=True))
+    assert pl.plonk_verify(vk, pl.plonk_prove(pk, sol, bl, fast=True), sol[:npub])
+    srs_np = np.ascontiguousarray(srs["g1"])
+    for nthreads in (1, 0):
+        ck = _c_key(spr, srs_np, nthreads)
+        assert ck.prove(pl.ints_to_mont_np(sol), pl.ints_to_mont_np(bl)) == want
+        bad = list(sol)
+        bad[gates[7][5]] = (bad[gates[7][5]] + 1) % R
+        with pytest.raises(AssertionError, match="not satisfied"):
+            ck.prove(pl.ints_to_mont_np(bad), pl.ints_to_mont_np(bl))
+        ck.free()
+    with pytest.raises(ValueError):
+        _c_key(spr, srs_np[:512 + 2])  # an SRS one point short
