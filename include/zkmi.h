@@ -84,6 +84,12 @@ int zk_warm_streams(int n);
  * zk_init_flags(ZK_INIT_LEAN_STREAMS) this is also what ALLOWS those streams: until it is called a lean process runs every chain on the slots' own streams (its
  * first proof creates no stream; the export path calls it when a key's second proof is asked for). */
 int zk_warm_session_streams(void);
+/* The same from the library's background thread, one slot at a time (each slot is held only while its stream is created): proofs that arrive meanwhile find
+ * their five slots and keep running on the slots' own streams until all five high-priority streams exist.  Returns at once. */
+int zk_warm_session_streams_background(void);
+/* 1 when no background job (window tables of a key or SRS that proves again, zk_warm_session_streams_background) is queued or running; waits up to timeout_ms
+ * for that (< 0: as long as it takes), 0 on timeout.  For callers that want the tables in place before they measure or compare; the provers never wait. */
+int zk_background_wait(int timeout_ms);
 /* Process-wide start-up choices; call before anything that touches a device.  ZK_INIT_LEAN_STREAMS: a device entry creates only the five streams every caller
  * needs with itself and every other stream on first use (the default also creates the five high-priority streams of a Groth16 proof session up front: 40 ms more
  * start-up, 1 % less per 2^20 proof -- WHICH streams share a hardware queue follows creation order).  For a process that makes one proof and exits. */
@@ -130,6 +136,9 @@ int zk_bn254_bases_register_cfg(const void *points, size_t n, int is_g2, int on_
  * a table is left alone).  The tables of 1,000,000 G1 points take 17 ms to build and save a 2^19-gate PLONK proof 1.4 ms: a process that makes ONE proof (nargo
  * prove) is better off without them, one that makes many builds them when the second proof is asked for (csrc/goffi.cpp does exactly that). */
 int zk_bn254_bases_build_table(uint64_t handle, int table_window_bits);
+/* The same on the library's background thread: returns at once; multi-exps against the handle run without the table until it is published.  (What the
+ * export shim does when a process's SECOND proving call arrives: that call no longer waits for the build.) */
+int zk_bn254_bases_build_table_background(uint64_t handle, int table_window_bits);
 int zk_bn254_msm_bases_dev(uint64_t handle, size_t offset, const void *d_scalars, size_t n, const zk_msm_cfg *cfg, void *out);
 /* The Lagrange form of a registered G1 base array over the domain of 2^log_n points, as a base array of its own: out[i] = (1/n) sum_j w^(-ij) in[j] for i < n (the
  * inverse transform taken in the exponent: n/2 log2 n + n point-by-scalar multiplications on the device), then in[n] - in[0] and in[n+1] - in[1] (for a KZG SRS:

@@ -10,6 +10,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <thread>
 
 namespace zkmi {
@@ -327,6 +330,122 @@ extern "C" int zk_warm_session_streams(void) {
     g_hi_streams_wanted.store(true);  // (after a lean start: from now on hi() creates them)
     SlotsGuard<5> g;
     return acquire_slots(5, g.s);
+}
+
+// ------------------------------------------------------------------------------------------------ background work
+// One worker thread per process for work that pays off only if the process goes on proving and must not sit on a call's critical path: the window tables of a
+// key (or SRS) that proves again -- 113 ms at 2^20 constraints -- and the high-priority streams a lean start withheld -- 39 ms.  The call that notices the
+// second proof queues the job and proves WITHOUT the tables; whoever comes after the build finds them (both builds publish their result under the registry's
+// mutex, and running multi-exps keep the geometry they started with).  A process that exits meanwhile cancels: exit() runs bg_stop_at_exit (registered AFTER the
+// HIP runtime's own handlers, so it runs before them), the job in flight stops at its next check, the thread is joined.
+namespace {
+struct Background {
+    std::mutex mu;
+    std::condition_variable cv, idle_cv;
+    std::deque<std::function<void()>> q;
+    std::thread th;
+    bool started = false, stop = false;
+    int running = 0;
+};
+Background& bg() {
+    static Background* b = new Background();  // (never destroyed: the worker may outlive static destruction order otherwise)
+    return *b;
+}
+std::atomic<bool> g_bg_cancel{false};
+void bg_loop() {
+    Background& b = bg();
+    std::unique_lock<std::mutex> lk(b.mu);
+    for (;;) {
+        b.cv.wait(lk, [&] { return b.stop || !b.q.empty(); });
+        if (b.stop) return;
+        std::function<void()> job = std::move(b.q.front());
+        b.q.pop_front();
+        b.running++;
+        lk.unlock();
+        job();
+        lk.lock();
+        b.running--;
+        if (b.q.empty() && !b.running) b.idle_cv.notify_all();
+    }
+}
+void bg_stop_at_exit() {
+    Background& b = bg();
+    g_bg_cancel.store(true);
+    {
+        std::lock_guard<std::mutex> lk(b.mu);
+        b.stop = true;
+        b.q.clear();
+    }
+    b.cv.notify_all();
+    if (b.th.joinable()) b.th.join();
+}
+}  // namespace
+bool bg_cancelled() { return g_bg_cancel.load(std::memory_order_relaxed); }
+void bg_submit(std::function<void()> job) {
+    Background& b = bg();
+    {
+        std::lock_guard<std::mutex> lk(b.mu);
+        if (b.stop) return;
+        if (!b.started) {
+            b.started = true;
+            b.th = std::thread(bg_loop);
+            (void)atexit(bg_stop_at_exit);
+        }
+        b.q.push_back(std::move(job));
+    }
+    b.cv.notify_one();
+}
+// 1 when no background job is queued or running (waits up to timeout_ms for that; < 0 = as long as it takes), else 0.  For callers that want the tables before
+// they measure or compare (tests, bench.py) -- the product never waits.
+extern "C" int zk_background_wait(int timeout_ms) {
+    Background& b = bg();
+    std::unique_lock<std::mutex> lk(b.mu);
+    auto idle = [&] { return b.q.empty() && !b.running; };
+    if (timeout_ms < 0) { b.idle_cv.wait(lk, idle); return 1; }
+    return b.idle_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), idle) ? 1 : 0;
+}
+
+// The high-priority streams of the five slots a proof session takes first, created ONE SLOT AT A TIME from the background: each slot is held only while its
+// stream is created (3.5-10 ms) and the creation itself runs outside the entry's mutex, so a proof that arrives meanwhile still finds the five slots it needs
+// (zk_warm_session_streams takes all five at once for 39 ms).  hi() keeps answering a slot's own stream until all five exist.
+static int warm_hi_streams_one_by_one() {
+    ZK_TRY(ensure_init());
+    Ctx& c = ctx();
+    for (int i = 0; i < 5 && i < Ctx::NSLOTS; i++) {
+        Slot* s = &c.slots[i];
+        for (;;) {
+            if (bg_cancelled()) return ZK_ERR_BUSY;
+            {
+                std::lock_guard<std::mutex> lk(c.mu);
+                if (!s->busy) {
+                    s->busy = true;
+                    s->begin_acquisition();
+                    break;
+                }
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        int rc = slot_stream(s);  // (clears busy itself when it fails)
+        if (rc != ZK_OK) return rc;
+        hipStream_t st = nullptr;
+        if (!s->stream_hi_ && hipStreamCreateWithPriority(&st, hipStreamNonBlocking, c.prio_hi) != hipSuccess) st = nullptr;
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (st) s->stream_hi_ = st;
+        s->busy = false;
+    }
+    g_hi_streams_wanted.store(true);
+    return ZK_OK;
+}
+extern "C" int zk_warm_session_streams_background(void) {
+    ZK_TRY(ensure_init());
+    const int entry = current_entry();
+    bg_submit([entry] {
+        CtxScope sc(entry);
+        const auto t0 = std::chrono::steady_clock::now();
+        if (sc.rc == ZK_OK) (void)warm_hi_streams_one_by_one();
+        prof_host("export.session_streams", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    });
+    return ZK_OK;
 }
 
 void release_slot(Slot* s) {

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -162,6 +163,10 @@ static inline int hentry(uint64_t handle) { return (handle >> 56) == 0xff ? (int
 #define ZK_ON_ENTRY_OF(handle)                   \
     zkmi::CtxScope _scope(zkmi::hentry(handle)); \
     if (_scope.rc != ZK_OK) return _scope.rc
+// background work (ctx.hip): one worker thread per process for what must not sit on a call's critical path -- window tables of keys that prove again, the
+// streams a lean start withheld.  Jobs run in submission order; bg_cancelled() turns true when the process is exiting (long jobs poll it between launches).
+void bg_submit(std::function<void()> job);
+bool bg_cancelled();
 int acquire_slot(Slot** out);       // blocks (spins) until a slot is free
 int acquire_slots(int k, Slot** out); // k slots at once (all or nothing: no partial holds, hence no deadlock)
 void release_slot(Slot* s);

@@ -874,6 +874,43 @@ static int g16_key_get(const char* pk_hex, size_t pk_len, const ContentKey* know
     g16_free_keys(dead);
     return ZK_OK;
 }
+static void g16_key_release(uint64_t handle);
+// the window tables (and the session's high-priority streams) of a resident key, built off the calling thread; see zk_groth16_prove_with_pk
+static void g16_tables_in_background(uint64_t h) {
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        bool found = false;
+        for (auto& k : g_g16_keys)
+            if (k.handle == h) { k.in_use++; found = true; break; }
+        if (!found) return;
+    }
+    static const bool sync_build = ZK_EXP("ZKMI_EXPORT_TABLES_SYNC", 0) != 0;  // experiment: the round-5 behaviour (build inside the second call)
+    auto job = [h] {
+        Phase ph;
+        CtxScope sc(hentry(h));
+        if (sc.rc == ZK_OK && !bg_cancelled()) {
+            int built = 0;
+            if (zk_bn254_groth16_pk_build_tables(h, 0, &built) == ZK_OK) {
+                size_t bytes = 0;
+                (void)zk_bn254_groth16_pk_bytes(h, &bytes);
+                std::lock_guard<std::mutex> lk(g_cache_mu);
+                for (auto& k : g_g16_keys)
+                    if (k.handle == h) k.bytes = bytes;
+            }
+            ph.lap("export.pk_window_tables");
+        }
+        g16_key_release(h);
+    };
+    if (sync_build) {
+        Phase ph;
+        (void)zk_warm_session_streams();
+        ph.lap("export.session_streams");
+        job();
+        return;
+    }
+    (void)zk_warm_session_streams_background();
+    bg_submit(job);
+}
 static void g16_key_release(uint64_t handle) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     for (auto& k : g_g16_keys)
@@ -942,12 +979,24 @@ extern "C" {
 
 // Reads a RawR1CS text into the resident cache; to_device = 0 touches no device (the export shim runs it beside the HIP runtime's start), 1 also uploads the
 // circuit (the shim's second step, beside the key's decoding).  The zk_groth16_* call that follows finds the circuit by content.
+// The values span of a RawR1CS text is identified by its position and its count header when the circuit is found resident, and raw_r1cs_build(want_wires = false)
+// does not decode it either: the entry points that never hand the span to the device decoder (Preprocess, the lowering alone) check here that every character is
+// one hex.DecodeString accepts -- as the reference's DeserializeFelts does on every call -- so that a span with a '"' and further JSON members in it cannot
+// pass for the resident circuit.  Eight threads over 64 MB at 2^20 constraints: a few milliseconds.
+static int raw_span_is_hex(const char* span, size_t n) {
+    const unsigned T = n >= ((size_t)1 << 20) ? 8 : 1;
+    std::vector<std::future<bool>> part;
+    for (unsigned t = 1; t < T; t++) part.push_back(std::async(std::launch::async, [=] { return all_hex(span + n * t / T, n * (t + 1) / T - n * t / T); }));
+    bool ok = all_hex(span, n / T);
+    for (auto& f : part) ok = f.get() && ok;
+    return ok ? ZK_OK : set_err(ZK_ERR_ARG, "felt vector: invalid hex character");
+}
 int zk_groth16_lower_resident(const char* raw_json, size_t raw_len, int to_device) {
     if (!raw_json) return set_err(ZK_ERR_ARG, "null pointer");
     std::shared_ptr<RawCircuit> C;
     size_t at = 0;
     ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
-    if (!to_device) return ZK_OK;
+    if (!to_device) return at ? raw_span_is_hex(raw_json + at, C->span_len) : ZK_OK;
     ZK_TRY(ensure_init());
     std::lock_guard<std::mutex> work(C->work);
     Phase ph;
@@ -1009,6 +1058,7 @@ int zk_groth16_preprocess(const char* raw_json, size_t raw_len, const zk_fr* tox
     std::shared_ptr<RawCircuit> C;
     size_t at = 0;
     ZK_TRY(raw_circuit_get(raw_json, raw_len, &C, &at));
+    if (at) ZK_TRY(raw_span_is_hex(raw_json + at, C->span_len));  // Setup does not read the values, the reference's DeserializeFelts still refuses a bad string
     ZK_TRY(ensure_init());
     std::lock_guard<std::mutex> work(C->work);
     Phase ph;
@@ -1156,19 +1206,11 @@ int zk_groth16_prove_with_pk(const char* raw_json, size_t raw_len, const char* p
             for (auto& k : g_g16_keys)
                 if (k.handle == h) { build = ++k.proofs == kG16TablesAtProof; break; }
         }
-        if (build) {
-            Phase ph;
-            (void)zk_warm_session_streams();  // a key that proves again: the schedule's high-priority streams too (a lean process has none until now)
-            ph.lap("export.session_streams");
-            int built = 0;
-            ZK_TRY(zk_bn254_groth16_pk_build_tables(h, 0, &built));
-            size_t bytes = 0;
-            (void)zk_bn254_groth16_pk_bytes(h, &bytes);
-            std::lock_guard<std::mutex> lk(g_cache_mu);
-            for (auto& k : g_g16_keys)
-                if (k.handle == h) k.bytes = bytes;
-            ph.lap("export.pk_window_tables");
-        }
+        // A key that proves again is worth its window tables (113 ms to build at 2^20 constraints, 5 ms saved per proof) and the schedule's high-priority streams
+        // (39 ms; a lean process has none until now) -- but not on THIS call's critical path: both go to the library's background thread (ctx.hip) and this proof
+        // runs without them, as the key's first one did.  The tables are published under the key registry's mutex when they are complete; proofs that start
+        // after that find them.  The cache entry stays pinned (in_use) while the build reads the key's base arrays.
+        if (build) g16_tables_in_background(h);
     }
     uint8_t proof[128];
     ZK_TRY(g16_prove_resident(*C, h, rs, proof));
@@ -1200,6 +1242,7 @@ int zk_groth16_prove_with_meta(const char* raw_json, size_t raw_len, const zk_fr
 
 // Releases everything the export path keeps resident between calls (lowered circuits, decoded proving keys; PLONK and Groth16).  Keys in use by a running proof stay.
 int zk_export_cache_clear(void) {
+    (void)zk_background_wait(-1);  // a background table build pins its key: let it finish so that the key can go
     std::vector<uint64_t> dead, dead16;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);

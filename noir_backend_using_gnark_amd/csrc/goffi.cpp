@@ -224,12 +224,11 @@ void try_load_srs(uint64_t* handle, zk_g2_affine g2[2]) {
 void srs_for_repeat_use() {
     std::lock_guard<std::mutex> lk(g_srs.mu);
     if (g_srs.uses++ < 1 || g_srs.tables || !g_srs.ready) return;
-    Lap lap;
-    must(zk_bn254_bases_build_table(g_srs.handle, 0), "SRS window tables");
+    // Both on the library's background thread (csrc/ctx.hip): THIS call commits against the SRS without the table, as the first one did; calls that start after the
+    // table is published use it.  (Round 5 built it here: 17 ms for 1,000,000 points + 39 ms of stream creation on the second call's critical path.)
+    must(zk_bn254_bases_build_table_background(g_srs.handle, 0), "SRS window tables");
     g_srs.tables = true;
-    lap.lap("export.srs_window_tables");
-    (void)zk_warm_session_streams();  // a process that proves again also gets the high-priority streams a lean start withheld (csrc/ctx.hip)
-    lap.lap("export.session_streams");
+    (void)zk_warm_session_streams_background();  // a process that proves again also gets the high-priority streams a lean start withheld
 }
 // plonk.Verify takes two G2 points from the SRS and nothing else (kzg.Verify's pairing check; the reference re-reads the whole file for them,
 // backend/plonk/plonk.go:34).  A process that has not proved anything reads them from the file's header on the host: it never starts the HIP runtime.
@@ -284,25 +283,27 @@ void load_srs_and_lower(GoString acirJSON, View values, uint64_t* srs, zk_g2_aff
 // (0.25 GB at 2^20 constraints, host only); ProveWithPK's starter goes on to decode the key text (0.37 GB; G1 / G2 decompression on the device) beside it.
 std::once_flag g_g16_started;
 void groth16_start(GoString rawR1CS, const GoString* pk) {
-    bool first = false;
-    std::call_once(g_g16_started, [&] { first = true; });
-    if (!first) return;
-    Lap lap;
-    std::promise<void> up;
-    std::shared_future<void> is_up = up.get_future().share();
-    std::thread starter([pk, &up] {
-        start_devices(5);  // the five stream slots of a Groth16 proof session (no high-priority streams after a lean start: csrc/ctx.hip)
-        up.set_value();
-        if (pk) (void)zk_groth16_key_resident(pk->p, (size_t)pk->n);  // (errors resurface in the call proper)
+    // The WHOLE start-up runs inside call_once: a second thread that calls an export while the first is still in start_devices waits here until the flags
+    // and the device list are in place (it used to return at once and could initialise libzkmi the default, non-lean way on device 0 before zk_init_devices ran --
+    // with ZKMI_DEVICES="2,3" the starter then failed with "entry 0 is already bound").
+    std::call_once(g_g16_started, [&] {
+        Lap lap;
+        std::promise<void> up;
+        std::shared_future<void> is_up = up.get_future().share();
+        std::thread starter([pk, &up] {
+            start_devices(5);  // the five stream slots of a Groth16 proof session (no high-priority streams after a lean start: csrc/ctx.hip)
+            up.set_value();
+            if (pk) (void)zk_groth16_key_resident(pk->p, (size_t)pk->n);  // (errors resurface in the call proper)
+        });
+        (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 0);
+        lap.lap("export.raw_lower_beside_start");
+        is_up.wait();
+        lap.lap("export.hip_start_wait");
+        (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 1);  // the circuit goes to the device while the starter decodes the key
+        lap.lap("export.circuit_upload");
+        starter.join();
+        lap.lap("export.hip_start_and_key_wait");
     });
-    (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 0);
-    lap.lap("export.raw_lower_beside_start");
-    is_up.wait();
-    lap.lap("export.hip_start_wait");
-    (void)zk_groth16_lower_resident(rawR1CS.p, (size_t)rawR1CS.n, 1);  // the circuit goes to the device while the starter decodes the key
-    lap.lap("export.circuit_upload");
-    starter.join();
-    lap.lap("export.hip_start_and_key_wait");
 }
 
 }  // namespace

@@ -156,6 +156,10 @@ static int pk_build_tables(Groth16PK* Pp, PkAllocs* mem, int table_window_bits, 
             {&P.t_k, P.d_k, nk, P.n_wires, P.n_public, 64, P.tab_w.c, Ww, 0}, {&P.t_z, P.d_z, P.nz, N, 0, 64, P.tab_h.c, Wh, 0},
             {&P.t_b2, P.d_b2, P.n_wires, P.n_wires, 0, 128, P.tab_w.c, Ww, 1}};
         for (auto& j : jobs) {
+            if (bg_cancelled()) {  // the process is exiting under a background build: what was queued is drained, nothing is published
+                (void)slot_sync(g.s, st);
+                return set_err(ZK_ERR_BUSY, "window tables: the process is exiting");
+            }
             ZK_TRY(mem->dev_alloc(j.t, j.Wd * j.stride * j.esz));
             const MsmTable& tb = (&j == &jobs[3]) ? P.tab_h : P.tab_w;
             ZK_TRY(j.g2 ? msm_build_table_g2(g.s, st, j.src, j.n, j.stride, j.off, j.c, *j.t, tb.row_first, tb.row_step)

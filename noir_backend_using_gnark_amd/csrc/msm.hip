@@ -34,6 +34,7 @@
 #include "experiments/msm_rocprim_include.inc"
 #endif
 
+#include <chrono>
 #include "ctx.hpp"
 #include "curve.hpp"
 #include "ff29.hpp"
@@ -646,6 +647,32 @@ __global__ ZK_ACC_BOUNDS void k_accumulate(AccBatch batch, const uint32_t* __res
     uint32_t t = task_sorted[i];
     uint32_t begin = task_begin[t];
     acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
+}
+// G2 with ZZ / ZZZ of the accumulator in LDS (ff29.hpp xyzz_madd29_lds): 36 KB per workgroup -> four workgroups per CU by LDS, three by registers (<= 170)
+__global__ __launch_bounds__(256, 3) void k_accumulate_g2_lds(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
+                                                             const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
+                                                             uint32_t max_tasks) {
+    __shared__ uint32_t zlds[36 * 256];
+    const Affine<Fp2>* __restrict__ pts = (const Affine<Fp2>*)batch.pts[blockIdx.y];
+    XYZZ<Fp2>* __restrict__ partial = (XYZZ<Fp2>*)batch.partial[blockIdx.y];
+    const uint32_t skip_below = batch.skip_below[blockIdx.y];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_tasks) return;
+    uint32_t key = len_key_sorted[i];
+    if (key == 0xffffffffu) return;
+    const uint32_t t = task_sorted[i];
+    const uint32_t begin = task_begin[t], end = begin + (L - key);
+    uint32_t* lane = zlds + threadIdx.x;
+    Acc29G2L acc;
+    acc.inf = true;
+    for (uint32_t j = begin; j < end; j++) {
+        uint32_t v = vals[j];
+        if ((v >> 1) < skip_below) continue;
+        Affine<Fp2> p = gload(pts + (v >> 1));
+        if (v & 1) p.y = p.y.neg();
+        xyzz_madd29_lds(acc, lane, p.x, p.y);
+    }
+    gstore(partial + t, acc29g2l_to_xyzz(acc, lane));
 }
 #ifdef ZKMI_EXPERIMENTS  // accumulate from a resident grid with a chunk counter (round 3: 3-7 % slower)
 #include "experiments/msm_accumulate_resident.inc"
@@ -1262,6 +1289,13 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
             ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_accumulate<Fp>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_accumulate<Fp2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_done |= (uint64_t)1 << current_entry();
+        }
+    }
+    if constexpr (sizeof(F) == sizeof(Fp2)) {
+        static const bool g2_lds = ZK_EXP("ZKMI_G2_LDS", 0) != 0;  // experiment (round 6): ZZ / ZZZ of the G2 accumulator in LDS, three waves per SIMD
+        if (g2_lds && !launched) {
+            ZK_LAUNCH(sl[0], sa, acc_name, k_accumulate_g2_lds, dim3(full_grid, (unsigned)nb), dim3(256), 0, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
+            launched = true;
         }
     }
     if (!launched) ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), acc_shmem, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
@@ -1914,6 +1948,17 @@ int zk_bn254_bases_build_table(uint64_t handle, int table_window_bits) {
     }
     it->second.d_table = b.d_table;
     it->second.tab = b.tab;
+    return ZK_OK;
+}
+int zk_bn254_bases_build_table_background(uint64_t handle, int table_window_bits) {
+    if (table_window_bits != 0 && (table_window_bits < 8 || table_window_bits > 24)) return set_err(ZK_ERR_ARG, "table_window_bits = %d outside [8, 24]", table_window_bits);
+    ZK_TRY(ensure_init());
+    bg_submit([handle, table_window_bits] {
+        if (bg_cancelled()) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        (void)zk_bn254_bases_build_table(handle, table_window_bits);  // (a handle freed meanwhile: ZK_ERR_HANDLE, dropped)
+        prof_host("export.srs_window_tables", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    });
     return ZK_OK;
 }
 static int msm_bases(uint64_t handle, size_t offset, const void* scalars, size_t n, const zk_msm_cfg* cfg, void* out, hipMemcpyKind kind) {

@@ -304,4 +304,14 @@ def test_groth16_resident_circuit_and_public_inputs_on_the_host():
                 raw[:-40]):                                               # truncated JSON
         with pytest.raises(ValueError):
             fe.groth16_public_inputs(bad)
+    # the lowering alone (what Preprocess starts with) refuses a values span that is not hex too -- found resident (position + count header) or read anew; a span
+    # that closes the string early and appends JSON members of its own must not pass for the resident circuit
+    smuggle = '","num_variables":9,"x":"'
+    for bad in (raw[:at + 8] + "zz" + raw[at + 10:], raw[:at + 100] + smuggle + raw[at + 100 + len(smuggle):]):
+        assert len(bad) == len(raw)
+        with pytest.raises((ValueError, _lib.ZkmiError)):
+            fe.groth16_lower_resident(bad)
+    assert L.zk_export_cache_clear() == 0
+    with pytest.raises((ValueError, _lib.ZkmiError)):
+        fe.groth16_lower_resident(raw[:at + 8] + "zz" + raw[at + 10:])   # nothing resident: the general reader's path
     assert L.zk_export_cache_clear() == 0 and fe.export_cache_info() == {"circuits": 0, "keys": 0, "bytes": 0}

@@ -112,7 +112,11 @@ def test_groth16_exports_at_2p11_constraints_and_the_export_worker(tmp_path):
     assert pr["resident"]["circuits"] == 1 and pr["resident"]["keys"] == 1
     for k in ("hip_init", "raw_parse_lower", "pk_read", "values_decode", "witness_assemble", "r1cs_solve_abc", "groth16_prove"):
         assert k in pr["cold_phases"], k
-    assert "pk_window_tables" not in pr["cold_phases"] and "pk_window_tables" in pr["second_phases"]
+    # the key's window tables are built when its SECOND proof is asked for -- on the library's background thread, not inside that call: the second call proves
+    # without them (and its proof verifies), the worker then waits for the build (zk_background_wait) and the warm calls find the tables
+    assert "pk_window_tables" not in pr["cold_phases"] and "pk_window_tables" not in pr["second_phases"] and "session_streams" not in pr["second_phases"]
+    assert pr["background_idle"] == 1 and "pk_window_tables" in pr["background_phases"] and "session_streams" in pr["background_phases"]
+    assert pr["second_proof_verifies"] == 1
     for k in ("raw_parse_lower", "pk_read", "pk_window_tables", "circuit_to_device"):
         assert k not in pr["warm_phases_per_call"] or (k == "circuit_to_device" and pr["warm_phases_per_call"][k] < 0.05), k
     ver = run("verify", d)
@@ -251,7 +255,9 @@ def test_export_path_worker_cold_and_warm_calls_at_2p10(tmp_path):
     for k in ("hip_init", "srs_file_read", "hip_start_wait", "srs_decode", "acir_parse_lower", "pk_text_to_device", "pk_coset_forms", "values_decode", "witness_gather", "plonk_prove"):
         assert k in pr["cold_phases"], k
     # the SRS's window tables wait for the second proving call of a process (a process that makes one proof is better off without them)
-    assert "srs_window_tables" not in pr["cold_phases"] and "srs_window_tables" in pr["second_phases"] and "srs_window_tables" not in pr["warm_phases_per_call"]
+    # ... and then on the library's background thread: the second call commits without them, the worker waits for the build before its warm calls
+    assert "srs_window_tables" not in pr["cold_phases"] and "srs_window_tables" not in pr["second_phases"] and "srs_window_tables" not in pr["warm_phases_per_call"]
+    assert pr["background_idle"] == 1 and "srs_window_tables" in pr["background_phases"] and pr["second_proof_verifies"] == 1
     # a process that only verifies takes the SRS's two G2 points from the file's header on the host: no HIP runtime, no device entry
     ver = run("verify", d)
     assert ver["verifies"] == 1 and ver["hip_runtime_started"] is False and ver["device_entries"] == 0 and "srs_g2_on_host" in ver["cold_phases"]
@@ -271,3 +277,54 @@ def test_export_path_worker_cold_and_warm_calls_at_2p10(tmp_path):
     assert spr.is_satisfied(sol) and spr.n_public == 8 and spr.n_vars == 8 * len(values)
     opk, ovk = pl.plonk_setup(spr, srs, fast=True)
     assert pl.plonk_pk_bytes(opk).hex() == open(os.path.join(d, "pk.hex")).read()
+
+
+def test_proofs_during_the_background_table_build_in_a_lean_process(tmp_path):
+    """A lean process (the export shim's start-up: no high-priority streams), two keys of one circuit, pinned (r, s): every (values, key) pair has ONE right proof.
+    Thread A makes key X's FIRST proof while thread B asks for key Y's SECOND one -- which queues Y's window tables and the session's high-priority streams on
+    the background thread.  Whatever the interleaving (hi() flipping under a proof in flight: ADVICE r5; a proof racing the build of its own key's tables; a proof
+    arriving while one slot is held for its stream), each proof equals the one made sequentially in a fresh state, before and after the tables exist."""
+    code = r"""
+import ctypes as C, json, sys, threading
+sys.path.insert(0, %r)
+from noir_backend_using_gnark_amd import _lib
+L = _lib.lib()
+assert L.zk_init_flags(C.c_uint32(1)) == 0          # ZK_INIT_LEAN_STREAMS, before anything touches a device
+from noir_backend_using_gnark_amd import frontend as fe
+from oracle import bn254_ref as ref
+from tests.helpers import mont_limbs
+from tools import synth_raw_r1cs as sr
+raw, w = sr.synth(1 << 13, 3, seed=0x91)
+raw2, w2 = sr.synth(1 << 13, 3, seed=0x91, first=(0x3333, 0x4444))
+rs = mont_limbs(list(ref.rand_felts(0xE1, 2)))
+keys = [fe.groth16_preprocess(raw, mont_limbs(list(ref.rand_felts(0xE2 + k, 5)))) for k in range(2)]
+texts = [raw, raw2]
+want = {}
+for t in range(2):
+    for k in range(2):
+        fe.export_cache_clear()                       # every reference proof is a key's FIRST proof: no tables, no high-priority streams
+        want[(t, k)] = fe.groth16_prove_with_pk(texts[t], keys[k][0], rs)
+bad = []
+for rnd in range(3):
+    fe.export_cache_clear()
+    assert fe.groth16_prove_with_pk(texts[0], keys[1][0], rs) == want[(0, 1)]   # Y's first proof
+    def a():
+        for t in (0, 1, 0):
+            if fe.groth16_prove_with_pk(texts[t], keys[0][0], rs) != want[(t, 0)]: bad.append(("A", rnd, t))
+    def b():
+        for t in (1, 0, 1, 0):
+            if fe.groth16_prove_with_pk(texts[t], keys[1][0], rs) != want[(t, 1)]: bad.append(("B", rnd, t))
+    ths = [threading.Thread(target=a), threading.Thread(target=b)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    assert L.zk_background_wait(C.c_int(-1)) == 1
+    for (t, k), p in want.items():                    # with the tables and the streams in place: the same bytes
+        if fe.groth16_prove_with_pk(texts[t], keys[k][0], rs) != p: bad.append(("after", rnd, t, k))
+info = fe.export_cache_info()
+fe.export_cache_clear()
+print(json.dumps({"bad": bad, "resident_keys": info["keys"]}))
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["bad"] == [] and d["resident_keys"] == 2

@@ -37,14 +37,16 @@ def main():
         for cfg in cfgs:
             name, _, kv = cfg.partition(":")
             env = dict(os.environ)
-            lib = ["--lib", "exp"]
+            lib, extra = ["--lib", "exp"], []
             for item in filter(None, kv.split(",")):
                 k, _, v = item.partition("=")
-                if k == "LIB":  # LIB=product: the shipped libzkmi.so (no switches), e.g. against an experiments build made with other compile flags
+                if k == "SCALARS":  # SCALARS=witness: the main instance's wire vector is witness-like (bench.py --scalars)
+                    extra = ["--scalars", v]
+                elif k == "LIB":  # LIB=product: the shipped libzkmi.so (no switches), e.g. against an experiments build made with other compile flags
                     lib = [] if v == "product" else ["--lib", "exp"]
                 else:
                     env[k] = v
-            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags + lib, capture_output=True, text=True, env=env, cwd=ROOT)
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags + lib + extra, capture_output=True, text=True, env=env, cwd=ROOT)
             lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode != 0 or not lines:
                 rec = {"name": name, "env": kv, "error": (p.stderr or p.stdout)[-600:]}
