@@ -294,7 +294,9 @@ def main():
     # ---- CPU baseline: the oracle proves the SAME instance on this box's host cores (rank 0, N=1 only)
     if single and not args.no_cpu_baseline:
         cpu_proof, cpu_s, cores = oracle_proof(inst, log_n)
-        out["cpu_baseline"] = {"value": round(g1_units / cpu_s, 1), "unit": out["unit"], "cores": cores, "kind": "port",
+        from oracle import oracle as _orc  # (the checker, after the timed region)
+        out["cpu_baseline"] = {"value": round(g1_units / cpu_s, 1), "unit": out["unit"], "cores": cores, "host_cpus_shown": _orc.host_cpus(), "kind": "port",
+                               "cores_note": "threads the oracle started = min(OpenMP default, cgroup CPU quota): the CPUs this process may use, not the logical CPUs the box shows",
                                "sample": "1 full proof of the same instance (2^%d constraints, same seeds) by oracle/bn254_oracle.c "
                                          "(OpenMP, window-parallel Pippenger + radix-2 FFT; plain C on unsigned __int128, no assembly -- a restatement, "
                                          "NOT a gnark figure: gnark's assembly field arithmetic would be several times quicker, so GPU / this is not a speed-up over gnark)" % log_n,

@@ -49,7 +49,7 @@ def micro_block(L, lib, zk, log_n, cpu_legs=True):
         want = orc.g1_msm(pts_h, sc_h)
         cpu_msm_s = time.perf_counter() - t0
         del pts_h
-        out["cpu_baseline_msm"] = {"value": round(n / cpu_msm_s, 1), "unit": "G1 scalar-muls/s", "ms": round(cpu_msm_s * 1e3, 1), "cores": orc.max_threads(), "kind": "port",
+        out["cpu_baseline_msm"] = {"value": round(n / cpu_msm_s, 1), "unit": "G1 scalar-muls/s", "ms": round(cpu_msm_s * 1e3, 1), "cores": orc.max_threads(), "host_cpus_shown": orc.host_cpus(), "kind": "port",
                                    "sample": "the same 2^%d-point MSM once by oracle/bn254_oracle.c orc_g1_msm (OpenMP bucket method, c = 16 signed digits; plain C, no assembly -- "
                                              "not a gnark figure)" % log_n, "point_matches_gpu": bool((want == r).all())}
     dom = zk.Domain(n)
@@ -60,7 +60,7 @@ def micro_block(L, lib, zk, log_n, cpu_legs=True):
         t0 = time.perf_counter()
         orc.fr_ntt(sc_h, False, orc.DIF, inplace=True)
         cpu_ntt_s = time.perf_counter() - t0
-        out["cpu_baseline_ntt"] = {"value": round(n / cpu_ntt_s, 1), "unit": "elements/s", "ms": round(cpu_ntt_s * 1e3, 1), "cores": orc.max_threads(), "kind": "port",
+        out["cpu_baseline_ntt"] = {"value": round(n / cpu_ntt_s, 1), "unit": "elements/s", "ms": round(cpu_ntt_s * 1e3, 1), "cores": orc.max_threads(), "host_cpus_shown": orc.host_cpus(), "kind": "port",
                                    "sample": "the same 2^%d-point FFT(DIF) once by oracle/bn254_oracle.c orc_fr_ntt (OpenMP radix-2, twiddle table built inside the call; "
                                              "plain C, no assembly -- not a gnark figure)" % log_n,
                                    "image_matches_gpu": bool(hashlib.sha256(sc_h.tobytes()).hexdigest() == gpu_sha)}

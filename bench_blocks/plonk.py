@@ -127,7 +127,7 @@ def plonk_block(L, lib, log_n, reps=int(os.environ.get("ZKMI_BENCH_PLONK_REPS", 
         cpu_s = time.perf_counter() - t0
         ck.free()
         out["cpu_baseline"] = {"value": round(9 * n / cpu_s, 1), "unit": "KZG-commit scalar-muls/s (whole plonk.Prove: 9 commitment MSMs + the transforms per proof)",
-                               "cores": orc.max_threads(), "kind": "port", "prove_ms": round(cpu_s * 1e3, 1), "setup_ms": round(cpu_setup_s * 1e3, 1),
+                               "cores": orc.max_threads(), "host_cpus_shown": orc.host_cpus(), "kind": "port", "prove_ms": round(cpu_s * 1e3, 1), "setup_ms": round(cpu_setup_s * 1e3, 1),
                                "sample": "1 full plonk.Prove of the same instance (2^%d gates: same circuit, SRS, solution and blinders, downloaded from the device) by "
                                          "oracle/plonk_oracle_impl.h (OpenMP; plain C on unsigned __int128, no assembly -- a restatement, NOT a gnark figure)" % log_n,
                                "proof_bytes_match_gpu": bool(cpu_proof == proof), "verifying_key_digests_match_gpu": vk_same}

@@ -10,6 +10,7 @@
  * reference's own tests.
  */
 #include "bn254_oracle.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -206,8 +207,10 @@ static void set_dec_limbs(fe *r, uint64_t l0, uint64_t l1, uint64_t l2, uint64_t
     fld_to_mont(&FP, r, &t);
 }
 
+static int effective_threads(void);
 static void orc_init(void) {
     if (g_init_done) return;
+    (void)effective_threads();
 #pragma omp critical(orc_init_lock)
     {
         if (!g_init_done) {
@@ -229,9 +232,45 @@ static void orc_init(void) {
     }
 }
 
-int orc_max_threads(void) {
+/* The threads worth starting: the CPUs this process may actually USE -- min(OpenMP's default, the cgroup's CPU quota).  The GPU boxes show 256 logical CPUs
+ * under a quota of 16 (cpu.max "1600000 100000"): 128 OpenMP threads time-sliced onto 16 CPUs spend their life in barriers (a 2^12-gate PLONK proof took 42 s
+ * there against 0.4 s on 8 unthrottled cores).  Read once; OMP_NUM_THREADS still wins when it asks for fewer. */
+static int cgroup_cpu_limit(void) {
+    long quota = -1, period = 100000;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");                 /* cgroup v2: "<quota|max> <period>" */
+    if (f) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %ld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) {  /* cgroup v1 */
+        if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+        fclose(f);
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))) { if (fscanf(f, "%ld", &period) != 1) period = 100000; fclose(f); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    long n = (quota + period - 1) / period;
+    return n < 1 ? 1 : (int)n;
+}
+static int g_threads = 0;
+static int effective_threads(void) {
+    if (g_threads) return g_threads;
+    int n = 1;
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    n = omp_get_max_threads();
+#endif
+    const int lim = cgroup_cpu_limit();
+    if (lim > 0 && lim < n) n = lim;
+    g_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+    omp_set_num_threads(g_threads);  /* the parallel regions without a num_threads clause */
+#endif
+    return g_threads;
+}
+int orc_max_threads(void) { return effective_threads(); }
+/* logical CPUs the box shows (what a naive count would have used); for the bench line's record beside `cores` */
+int orc_host_cpus(void) {
+#ifdef _OPENMP
+    return omp_get_num_procs();
 #else
     return 1;
 #endif
@@ -454,31 +493,95 @@ void orc_fr_bit_reverse(uint64_t *a_, unsigned logn) {
     for (size_t i = 0; i < n; i++) { size_t j = bitrev_sz(i, logn); if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; } }
 }
 
-/* difFFT: natural in -> bit-reversed out; butterfly (x, y) -> (x + y, (x - y) * w)   (gnark-crypto fft.go difFFT) */
+/* difFFT: natural in -> bit-reversed out; butterfly (x, y) -> (x + y, (x - y) * w)   (gnark-crypto fft.go difFFT)
+ * ditFFT: bit-reversed in -> natural out; butterfly (x, y) -> (x + y*w, x - y*w)     (gnark-crypto fft.go ditFFT)
+ * Every butterfly is the textbook one with the textbook twiddle; what is organised for the machine is only the ORDER in which they run (field arithmetic is
+ * exact, so the order cannot change a word): below 2^17 points one parallel loop per stage; above, the stages whose span exceeds a 1 MB block run five at a time
+ * on tiles of 32 rows x 64 consecutive elements held in a thread's cache, and the stages inside a block run block by block -- 2 + ceil((log n - 15) / 5) passes
+ * over memory instead of log n (at 2^26 on 128 cores the one-pass-per-stage form was memory-bound at 4.3 s per transform). */
+#define NTT_LB 15u   /* stages with span <= 2^NTT_LB elements (1 MB) run inside contiguous blocks */
+#define NTT_G 5u     /* stages per tiled group */
+#define NTT_C 64u    /* consecutive elements per tile row (2 KB) */
+static inline void bfly_dif(fe *x, fe *y, const fe *w) { fe t, u; fld_add(&FR, &u, x, y); fld_sub(&FR, &t, x, y); fr_mul(y, &t, w); *x = u; }
+static inline void bfly_dit(fe *x, fe *y, const fe *w) { fe t, u; fr_mul(&t, y, w); fld_add(&FR, &u, x, &t); fld_sub(&FR, y, x, &t); *x = u; }
+/* one tiled group: `g` stages over rows `mrow` apart; dif: first in-buffer stage pairs rows g-1 bits apart and halves, dit: starts at 1 and doubles.
+ * tw_shift0: twiddle index of in-buffer stage u = j << (dif ? tw_shift0 + u : tw_shift0 - u), j = k * mrow + column */
+static void ntt_group(fe *a, const fe *tw, size_t n, size_t mrow, unsigned g, unsigned tw_shift0, int dif, int nthreads) {
+    const size_t rows = (size_t)1 << g, big = rows * mrow, ntile_row = mrow / NTT_C, ntiles = (n / big) * ntile_row;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (size_t tile = 0; tile < ntiles; tile++) {
+        fe buf[(1u << NTT_G) * NTT_C];
+        const size_t c0 = (tile % ntile_row) * NTT_C;
+        fe *base = a + (tile / ntile_row) * big + c0;
+        for (size_t r = 0; r < rows; r++) memcpy(buf + r * NTT_C, base + r * mrow, NTT_C * sizeof(fe));
+        for (unsigned u = 0; u < g; u++) {
+            const size_t h = dif ? (size_t)1 << (g - 1 - u) : (size_t)1 << u;
+            const unsigned sh = dif ? tw_shift0 + u : tw_shift0 - u;
+            for (size_t q = 0; q < rows; q += 2 * h)
+                for (size_t k = 0; k < h; k++) {
+                    fe *x = buf + (q + k) * NTT_C, *y = x + h * NTT_C;
+                    const size_t j0 = k * mrow + c0;
+                    if (dif) for (size_t c = 0; c < NTT_C; c++) bfly_dif(&x[c], &y[c], &tw[(j0 + c) << sh]);
+                    else for (size_t c = 0; c < NTT_C; c++) bfly_dit(&x[c], &y[c], &tw[(j0 + c) << sh]);
+                }
+        }
+        for (size_t r = 0; r < rows; r++) memcpy(base + r * mrow, buf + r * NTT_C, NTT_C * sizeof(fe));
+    }
+}
 static void dif_inplace(fe *a, const fe *tw, unsigned logn, int nthreads) {
-    size_t n = (size_t)1 << logn;
+    const size_t n = (size_t)1 << logn;
+    unsigned s = 0;  /* next stage; its half-span is n >> (s + 1), its twiddle index j << s */
+    if (logn > NTT_LB + 1) {
+        while (logn - s > NTT_LB) {
+            unsigned g = logn - s - NTT_LB; if (g > NTT_G) g = NTT_G;
+            ntt_group(a, tw, n, n >> (s + g), g, s, 1, nthreads);
+            s += g;
+        }
+        const size_t blk = n >> s;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+        for (size_t b = 0; b < n / blk; b++) {
+            fe *p = a + b * blk;
+            for (unsigned t = s; t < logn; t++) {
+                const size_t m = n >> (t + 1);
+                for (size_t q = 0; q < blk; q += 2 * m)
+                    for (size_t j = 0; j < m; j++) bfly_dif(&p[q + j], &p[q + j + m], &tw[j << t]);
+            }
+        }
+        return;
+    }
     for (size_t m = n / 2, stride = 1; m >= 1; m >>= 1, stride <<= 1) {
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) if (n >= 4096)
         for (size_t idx = 0; idx < n / 2; idx++) {
-            size_t blk = idx / m, j = idx % m, i0 = blk * 2 * m + j, i1 = i0 + m;
-            fe x = a[i0], y = a[i1], t;
-            fld_add(&FR, &a[i0], &x, &y);
-            fld_sub(&FR, &t, &x, &y);
-            fr_mul(&a[i1], &t, &tw[j * stride]);
+            size_t blk = idx / m, j = idx % m, i0 = blk * 2 * m + j;
+            bfly_dif(&a[i0], &a[i0 + m], &tw[j * stride]);
         }
     }
 }
-/* ditFFT: bit-reversed in -> natural out; butterfly (x, y) -> (x + y*w, x - y*w)   (gnark-crypto fft.go ditFFT) */
 static void dit_inplace(fe *a, const fe *tw, unsigned logn, int nthreads) {
-    size_t n = (size_t)1 << logn;
+    const size_t n = (size_t)1 << logn;
+    if (logn > NTT_LB + 1) {
+        const size_t blk = (size_t)1 << NTT_LB;  /* stages t = 0 .. NTT_LB - 1 (half-span 1 << t, twiddle index j << (logn - 1 - t)) inside contiguous blocks */
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+        for (size_t b = 0; b < n / blk; b++) {
+            fe *p = a + b * blk;
+            for (unsigned t = 0; t < NTT_LB; t++) {
+                const size_t m = (size_t)1 << t;
+                for (size_t q = 0; q < blk; q += 2 * m)
+                    for (size_t j = 0; j < m; j++) bfly_dit(&p[q + j], &p[q + j + m], &tw[j << (logn - 1 - t)]);
+            }
+        }
+        for (unsigned t = NTT_LB; t < logn;) {
+            unsigned g = logn - t; if (g > NTT_G) g = NTT_G;
+            ntt_group(a, tw, n, (size_t)1 << t, g, logn - 1 - t, 0, nthreads);
+            t += g;
+        }
+        return;
+    }
     for (size_t m = 1, stride = n / 2; m < n; m <<= 1, stride >>= 1) {
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) if (n >= 4096)
         for (size_t idx = 0; idx < n / 2; idx++) {
-            size_t blk = idx / m, j = idx % m, i0 = blk * 2 * m + j, i1 = i0 + m;
-            fe x = a[i0], t;
-            fr_mul(&t, &a[i1], &tw[j * stride]);
-            fld_add(&FR, &a[i0], &x, &t);
-            fld_sub(&FR, &a[i1], &x, &t);
+            size_t blk = idx / m, j = idx % m, i0 = blk * 2 * m + j;
+            bfly_dit(&a[i0], &a[i0 + m], &tw[j * stride]);
         }
     }
 }

@@ -105,7 +105,8 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution, const uint
                     uint64_t *challenges_out);
 void orc_sha256(const uint8_t *data, size_t n, uint8_t out[32]);
 
-int orc_max_threads(void);
+int orc_max_threads(void);   /* threads worth starting: min(OpenMP default, the cgroup CPU quota) */
+int orc_host_cpus(void);     /* logical CPUs the box shows */
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,13 @@ def _u64(a) -> np.ndarray:
 
 
 def max_threads() -> int:
+    """Threads the oracle starts: min(OpenMP's default, the cgroup CPU quota) -- the CPUs this process can actually use."""
     return int(lib().orc_max_threads())
+
+
+def host_cpus() -> int:
+    """Logical CPUs the box shows (the GPU boxes: 256 under a quota of 16)."""
+    return int(lib().orc_host_cpus())
 
 
 def int_to_limbs(x: int) -> np.ndarray:

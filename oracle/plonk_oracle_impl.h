@@ -8,6 +8,16 @@
  * Same inputs (the 9 blinding scalars are an input), same Fiat-Shamir transcript, same Proof.WriteTo layout; pinned against plonk_ref.py on the
  * committed fixtures (tests/test_plonk_oracle.py).  PARITY UNPINNED against upstream, like everything else under oracle/. */
 #include <stdio.h>
+#include <time.h>
+/* ORC_PLONK_TRACE=1: wall-clock of the prover's phases on stderr (where a CPU proof spends its time; tooling only) */
+static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void orc_trace(const char *what, double *t0) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("ORC_PLONK_TRACE"); on = e && *e == '1'; }
+    double t1 = orc_now();
+    if (on) fprintf(stderr, "[orc_plonk] %-28s %8.3f s\n", what, t1 - *t0);
+    *t0 = t1;
+}
 
 /* ------------------------------------------------------------------ SHA-256 (FIPS 180-4), for fiatshamir.NewTranscript(sha256.New(), ...) */
 typedef struct { uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill; } sha256_t;
@@ -264,6 +274,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
     const fe *sol = (const fe *)solution_, *bl_ = (const fe *)blinders_;
     const int T = thr(nthreads);
     fe u, uu; fld_set_u64(&FR, &u, 5); fr_mul(&uu, &u, &u);
+    double tr = orc_now();
 
     /* l, r, o: Lagrange (evaluateLROSmallDomain: placeholders first, padding = solution[0]) -> canonical, blinded with degree-1 masks, committed */
     fe *lag[3], *b[3];  /* lag: unblinded Lagrange l, r, o (the ratio below uses them); b: blinded canonical, n + 2 entries */
@@ -283,6 +294,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
         blind_c(b[k], n, bl_ + 2 * k, 2);
         kzg_commit(&lro[k], pk->srs, b[k], n + 2, nthreads);
     }
+    orc_trace("lro: canonical + 3 commits", &tr);
     /* gamma <- bindPublicData (S1..S3, Ql, Qr, Qm, Qo, Qk digests, the public inputs) then [L], [R], [O]; beta <- nothing but gamma */
     fs_t fs; uint8_t dg[32], db[32], da[32], dz[32]; fe gamma, beta, alpha, zeta;
     fs_begin(&fs, "gamma", NULL);
@@ -324,6 +336,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
     to_canonical(&pk->d0, bz, nthreads);
     blind_c(bz, n, bl_ + 6, 3);
     g1_aff z_digest; kzg_commit(&z_digest, pk->srs, bz, n + 3, nthreads);
+    orc_trace("z: ratio + canonical + commit", &tr);
     fs_begin(&fs, "alpha", db); fs_point(&fs, &z_digest); fs_end(&fs, da, &alpha);
 
     /* qk completed with the public inputs (Lagrange), canonical */
@@ -343,6 +356,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
     for (size_t i = 0; i < n; i++) l1[i] = pk->d0.card_inv;
     fe *e_l1 = coset_eval_c(pk, l1, n, nthreads);
     free(l1);
+    orc_trace("13 coset evaluations", &tr);
     fe *xs = (fe *)malloc(sizeof(fe) * N4);
     fr_powers(xs, N4, &pk->d1.gen, &u, nthreads);
     fe *xn_inv = (fe *)malloc(sizeof(fe) * rho);  /* x^n takes rho values on the coset */
@@ -370,6 +384,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
         fr_mul(&t, &one, &alpha); fr_sub(&f, &bb, &a); fr_add(&t, &t, &f); fr_mul(&t, &t, &alpha); fr_add(&t, &t, &ic);
         fr_mul(&t_[i], &t, &xn_inv[i % rho]);
     }
+    orc_trace("quotient loop", &tr);
     fe *evs[] = {e_l, e_r, e_o, e_z, e_qk, e_ql, e_qr, e_qm, e_qo, e_s1, e_s2, e_s3, e_l1, xs, xn_inv};
     for (size_t k = 0; k < sizeof evs / sizeof *evs; k++) free(evs[k]);
     orc_fr_bit_reverse((uint64_t *)t_, pk->log_n4);
@@ -378,9 +393,11 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
     int bad = 0;
     for (size_t i = 3 * (n + 2); i < N4; i++) bad |= !fe_is_zero(&h[i]);
     if (bad) { free(h); for (int k = 0; k < 3; k++) free(b[k]); free(bz); return -2; }
+    orc_trace("coset interpolation of t", &tr);
     fe *h1 = h, *h2 = h + (n + 2), *h3 = h + 2 * (n + 2);
     g1_aff hd[3];
     kzg_commit(&hd[0], pk->srs, h1, n + 2, nthreads); kzg_commit(&hd[1], pk->srs, h2, n + 2, nthreads); kzg_commit(&hd[2], pk->srs, h3, n + 2, nthreads);
+    orc_trace("3 commits of h", &tr);
     fs_begin(&fs, "zeta", da);
     for (int k = 0; k < 3; k++) fs_point(&fs, &hd[k]);
     fs_end(&fs, dz, &zeta);
@@ -398,6 +415,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
         kzg_commit(&z_open_h, pk->srs, q + 1, n + 2, nthreads);
         free(q);
     }
+    orc_trace("openings at zeta + [z/(X-wz)]", &tr);
     /* linearised polynomial (prove.go computeLinearizedPolynomial) */
     fe s1z, s2z, c_s3, c_z, lag1, rl, t, f;
     poly_eval_c(&s1z, pk->poly[PS1], n, &zeta, nthreads); poly_eval_c(&s2z, pk->poly[PS2], n, &zeta, nthreads);
@@ -431,6 +449,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
     }
     g1_aff lin_digest; kzg_commit(&lin_digest, pk->srs, lin, n + 3, nthreads);
 
+    orc_trace("linearised polynomial + commit", &tr);
     /* folded quotient h1 + zeta^(n+2) h2 + zeta^(2(n+2)) h3 and its digest */
     fe zp; fr_pow_u64(&zp, &zeta, (uint64_t)(n + 2));
     fe *folded_h = (fe *)malloc(sizeof(fe) * (n + 2));
@@ -473,6 +492,7 @@ int orc_plonk_prove(const orc_plonk_pk *pk, const uint64_t *solution_, const uin
     free(folded); free(folded_h); free(lin); free(bz);
     for (int k = 0; k < 3; k++) free(b[k]);
 
+    orc_trace("batch opening + commit", &tr);
     /* Proof.WriteTo (marshal.go): LRO[0..2], Z, H[0..2] compressed (7 x 32 B); BatchedProof = H (32 B) | u32 BE count | claimed values (7 x 32 B BE);
      * ZShiftedOpening = H (32 B) | claimed value (32 B).  548 bytes. */
     uint8_t *o = proof_out;
