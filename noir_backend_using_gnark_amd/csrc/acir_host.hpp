@@ -15,7 +15,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
+#include <chrono>
 #include <functional>
 #include <string>
 #include <system_error>
@@ -1169,64 +1171,139 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
 }
 
 // ------------------------------------------------------------------------------------------------ content keys
-// 128-bit content key of a text (the caches of decoded keys and lowered circuits are keyed by it): four independent multiply-rotate lanes per
-// 64 KB segment, segments hashed on up to 16 threads (a proving key is 0.3 GB of hex text: one core reads it in 50 ms, sixteen in 5), the
-// segment digests folded in order.  Not a cryptographic hash, so two things keep a caller from steering it (round 4's advisor: with fixed constants a 32-byte
-// block equal to one of them zeroed all four lanes -- an absorbing state -- and a long-lived process serving several parties could be fed a text that collides
-// with another party's circuit, which on the verify path selects WHICH values count as public inputs):
-//   * the two multiplier masks are drawn per PROCESS from the OS generator (content keys never leave the process and are never compared across processes), so
-//     a text cannot be aimed at them;
-//   * a step adds its input state back after the multiplication: a zero product leaves the state it came from, not zero -- nothing is absorbing.
+// 128-bit content key of a text (the caches of decoded keys and lowered circuits are keyed by it; on the verify path it decides which circuit -- hence which
+// values count as public inputs -- a text stands for).  Round 6: the home-made multiply-rotate mixer is gone; the key is a tree of SipHash-2-4 with 128-bit
+// output (Aumasson & Bernstein, "SipHash: a fast short-input PRF", 2012 -- the reference implementation's outlen = 16 variant, checked below against the
+// paper's test vector), keyed PER PROCESS from the OS generator (content keys never leave the process and are never compared across processes):
+//     leaf    = SipHash-2-4-128_K (16 KB of text)                       four leaves of a 64 KB segment run interleaved in one loop (the rounds of one
+//                                                                        state are a serial chain; four independent states fill the core)
+//     record  = the segment's four leaf digests (a short last segment: one leaf over what is left, the other three zero)
+//     key     = SipHash-2-4-128_K' (record_0 | record_1 | ... | n)      K' = K with k1 complemented: leaves and root are different functions
+// Guarantee: two different texts get the same key only through a collision of SipHash-2-4-128 under a key the caller does not know -- the PRF / MAC property the
+// function was designed and analysed for (forgery probability ~2^-128 per attempt), not a property of an ad-hoc mixer.  Segments are hashed on up to 16
+// threads (a proving key is 0.37 GB of hex text): the host's memory feeds them, not its cores.
 struct ContentKey {
     uint64_t h[2] = {0, 0};
     uint64_t len = 0;
     bool operator<(const ContentKey& o) const { return h[0] != o.h[0] ? h[0] < o.h[0] : h[1] != o.h[1] ? h[1] < o.h[1] : len < o.len; }
     bool operator==(const ContentKey& o) const { return h[0] == o.h[0] && h[1] == o.h[1] && len == o.len; }
 };
-struct CkMasks { uint64_t a, b; };
-static inline const CkMasks& ck_masks() {
-    static const CkMasks m = [] {
-        CkMasks k{0x9e3779b97f4a7c15ULL, 0xd1b54a32d192ed03ULL};
-        uint64_t r[2] = {0, 0};
+struct SipKey { uint64_t k0, k1; };
+static inline uint64_t sip_rotl(uint64_t x, int b) { return (x << b) | (x >> (64 - b)); }
+#define ZK_SIPROUND(v0, v1, v2, v3)                                                                                    \
+    do {                                                                                                               \
+        v0 += v1; v1 = sip_rotl(v1, 13); v1 ^= v0; v0 = sip_rotl(v0, 32);                                              \
+        v2 += v3; v3 = sip_rotl(v3, 16); v3 ^= v2;                                                                     \
+        v0 += v3; v3 = sip_rotl(v3, 21); v3 ^= v0;                                                                     \
+        v2 += v1; v1 = sip_rotl(v1, 17); v1 ^= v2; v2 = sip_rotl(v2, 32);                                              \
+    } while (0)
+static inline uint64_t sip_le64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }  // (little-endian hosts only: x86-64)
+// SipHash-2-4; out128 != nullptr: the 128-bit variant (out128[0], out128[1]); returns the 64-bit variant's value otherwise
+static inline uint64_t siphash24(const uint8_t* in, size_t inlen, SipKey k, uint64_t* out128) {
+    uint64_t v0 = 0x736f6d6570736575ULL ^ k.k0, v1 = 0x646f72616e646f6dULL ^ k.k1, v2 = 0x6c7967656e657261ULL ^ k.k0, v3 = 0x7465646279746573ULL ^ k.k1;
+    if (out128) v1 ^= 0xee;
+    const uint8_t* end = in + (inlen & ~(size_t)7);
+    for (; in != end; in += 8) {
+        const uint64_t m = sip_le64(in);
+        v3 ^= m;
+        ZK_SIPROUND(v0, v1, v2, v3);
+        ZK_SIPROUND(v0, v1, v2, v3);
+        v0 ^= m;
+    }
+    uint64_t b = (uint64_t)inlen << 56;
+    for (size_t i = 0; i < (inlen & 7); i++) b |= (uint64_t)in[i] << (8 * i);
+    v3 ^= b;
+    ZK_SIPROUND(v0, v1, v2, v3);
+    ZK_SIPROUND(v0, v1, v2, v3);
+    v0 ^= b;
+    v2 ^= out128 ? 0xee : 0xff;
+    for (int i = 0; i < 4; i++) ZK_SIPROUND(v0, v1, v2, v3);
+    const uint64_t r0 = v0 ^ v1 ^ v2 ^ v3;
+    if (!out128) return r0;
+    out128[0] = r0;
+    v1 ^= 0xdd;
+    for (int i = 0; i < 4; i++) ZK_SIPROUND(v0, v1, v2, v3);
+    out128[1] = v0 ^ v1 ^ v2 ^ v3;
+    return r0;
+}
+// four SipHash-2-4-128 of four inputs of the SAME length n (a multiple of 8), interleaved: out[j] = siphash24(p[j], n, k) -- the same function, four at a time
+static inline void siphash24_128_x4(const uint8_t* const p[4], size_t n, SipKey k, uint64_t out[4][2]) {
+    uint64_t v0[4], v1[4], v2[4], v3[4];
+    for (int j = 0; j < 4; j++) {
+        v0[j] = 0x736f6d6570736575ULL ^ k.k0; v1[j] = 0x646f72616e646f6dULL ^ k.k1 ^ 0xee; v2[j] = 0x6c7967656e657261ULL ^ k.k0; v3[j] = 0x7465646279746573ULL ^ k.k1;
+    }
+    for (size_t i = 0; i < n; i += 8) {
+        uint64_t m[4];
+        for (int j = 0; j < 4; j++) { m[j] = sip_le64(p[j] + i); v3[j] ^= m[j]; }
+        for (int j = 0; j < 4; j++) ZK_SIPROUND(v0[j], v1[j], v2[j], v3[j]);
+        for (int j = 0; j < 4; j++) ZK_SIPROUND(v0[j], v1[j], v2[j], v3[j]);
+        for (int j = 0; j < 4; j++) v0[j] ^= m[j];
+    }
+    const uint64_t b = (uint64_t)n << 56;
+    for (int j = 0; j < 4; j++) {
+        v3[j] ^= b;
+        ZK_SIPROUND(v0[j], v1[j], v2[j], v3[j]);
+        ZK_SIPROUND(v0[j], v1[j], v2[j], v3[j]);
+        v0[j] ^= b;
+        v2[j] ^= 0xee;
+        for (int i = 0; i < 4; i++) ZK_SIPROUND(v0[j], v1[j], v2[j], v3[j]);
+        out[j][0] = v0[j] ^ v1[j] ^ v2[j] ^ v3[j];
+        v1[j] ^= 0xdd;
+        for (int i = 0; i < 4; i++) ZK_SIPROUND(v0[j], v1[j], v2[j], v3[j]);
+        out[j][1] = v0[j] ^ v1[j] ^ v2[j] ^ v3[j];
+    }
+}
+// the paper's test vector (appendix A: key 00 .. 0f, message 00 .. 0e -> a129ca6149be45e5) and the interleaved form against the plain one; zk_selftest_host calls it
+static inline bool siphash_selftest() {
+    uint8_t key[16], msg[64 * 8];
+    for (int i = 0; i < 16; i++) key[i] = (uint8_t)i;
+    for (size_t i = 0; i < sizeof msg; i++) msg[i] = (uint8_t)i;
+    SipKey k{sip_le64(key), sip_le64(key + 8)};
+    if (siphash24(msg, 15, k, nullptr) != 0xa129ca6149be45e5ULL) return false;
+    const uint8_t* p[4] = {msg, msg + 128, msg + 256, msg + 384};
+    uint64_t x4[4][2], one[2];
+    siphash24_128_x4(p, 128, k, x4);
+    for (int j = 0; j < 4; j++) {
+        siphash24(p[j], 128, k, one);
+        if (one[0] != x4[j][0] || one[1] != x4[j][1]) return false;
+    }
+    siphash24(msg, 15, k, one);  // 128-bit variant differs from the 64-bit one and its halves from each other
+    return one[0] != 0xa129ca6149be45e5ULL && one[0] != one[1];
+}
+static inline const SipKey& ck_key() {
+    static const SipKey key = [] {
+        SipKey k{0, 0};
+        bool ok = false;
         if (FILE* f = fopen("/dev/urandom", "rb")) {
-            if (fread(r, 1, sizeof r, f) == sizeof r) { k.a ^= r[0]; k.b ^= r[1]; }
+            ok = fread(&k, 1, sizeof k, f) == sizeof k;
             fclose(f);
+        }
+        if (!ok) {  // no OS generator: what varies per process (address-space layout, clock, pid) -- weaker, and said so; the keys stay private to the process
+            k.k0 = (uint64_t)(uintptr_t)&k ^ ((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+            k.k1 = (uint64_t)(uintptr_t)&siphash_selftest ^ 0x9e3779b97f4a7c15ULL * (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
         }
         return k;
     }();
-    return m;
+    return key;
 }
-static inline uint64_t ck_mix(uint64_t a, uint64_t b, const CkMasks& k) {
-    const unsigned __int128 m = (unsigned __int128)(a ^ k.a) * (b ^ k.b);
-    return ((uint64_t)m ^ (uint64_t)(m >> 64)) + ((a << 23) | (a >> 41));
-}
-static inline void ck_segment(const char* p, size_t n, uint64_t seed, uint64_t out[2], const CkMasks k) {
-    uint64_t s[4] = {seed ^ 0x243f6a8885a308d3ULL, seed ^ 0x13198a2e03707344ULL, seed ^ 0xa4093822299f31d0ULL, seed ^ 0x082efa98ec4e6c89ULL};
-    size_t i = 0;
-    for (; i + 32 <= n; i += 32) {
-        uint64_t w[4];
-        memcpy(w, p + i, 32);
-        s[0] = ck_mix(s[0], w[0], k);
-        s[1] = ck_mix(s[1], w[1], k);
-        s[2] = ck_mix(s[2], w[2], k);
-        s[3] = ck_mix(s[3], w[3], k);
-    }
-    uint64_t w[4] = {0, 0, 0, 0};
-    memcpy(w, p + i, n - i);
-    s[0] = ck_mix(s[0], w[0] ^ n, k);
-    s[1] = ck_mix(s[1], w[1], k);
-    s[2] = ck_mix(s[2], w[2], k);
-    s[3] = ck_mix(s[3], w[3] ^ (n << 32), k);
-    out[0] = ck_mix(s[0], s[2], k);
-    out[1] = ck_mix(s[1], s[3], k);
-}
-static inline ContentKey content_key(const char* p, size_t n) {
-    const size_t SEG = (size_t)1 << 16;
+static inline ContentKey content_key(const char* p_, size_t n) {
+    const uint8_t* p = (const uint8_t*)p_;
+    const size_t SEG = (size_t)1 << 16, LEAF = SEG / 4;
     const size_t nseg = (n + SEG - 1) / SEG;
-    std::vector<uint64_t> d(2 * (nseg ? nseg : 1), 0);
-    const CkMasks masks = ck_masks();
+    std::vector<uint64_t> rec(8 * (nseg ? nseg : 1), 0);  // per segment: four leaf digests
+    const SipKey key = ck_key();
     auto run = [&](size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; k++) ck_segment(p + k * SEG, k + 1 == nseg ? n - k * SEG : SEG, k, &d[2 * k], masks);
+        for (size_t s = lo; s < hi; s++) {
+            const uint8_t* q = p + s * SEG;
+            const size_t len = s + 1 == nseg ? n - s * SEG : SEG;
+            uint64_t(*out)[2] = reinterpret_cast<uint64_t(*)[2]>(&rec[8 * s]);
+            if (len == SEG) {
+                const uint8_t* lanes[4] = {q, q + LEAF, q + 2 * LEAF, q + 3 * LEAF};
+                siphash24_128_x4(lanes, LEAF, key, out);
+            } else {
+                siphash24(q, len, key, out[0]);  // (the length is part of SipHash's last block and of the root's input: a short leaf cannot pass for a full one)
+            }
+        }
     };
     unsigned nt = nseg < 64 ? 1 : std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;  // (32 threads for the 0.26 + 0.37 GB of a 2^20-constraint call were measured: no faster -- the host's memory feeds them, not its cores)
@@ -1236,15 +1313,10 @@ static inline ContentKey content_key(const char* p, size_t n) {
         for (unsigned k = 0; k < nt; k++) th.emplace_back(run, nseg * k / nt, nseg * (k + 1) / nt);
         for (auto& t : th) t.join();
     }
+    rec.push_back((uint64_t)n);
     ContentKey K;
     K.len = n;
-    uint64_t a = 0x452821e638d01377ULL, b = 0xbe5466cf34e90c6cULL;
-    for (size_t j = 0; j < nseg; j++) {
-        a = ck_mix(a, d[2 * j], masks) + d[2 * j + 1];
-        b = ck_mix(b, d[2 * j + 1], masks) ^ a;
-    }
-    K.h[0] = ck_mix(a, n, masks);
-    K.h[1] = ck_mix(b, ~(uint64_t)n, masks);
+    siphash24(reinterpret_cast<const uint8_t*>(rec.data()), rec.size() * 8, SipKey{key.k0, ~key.k1}, K.h);
     return K;
 }
 

@@ -352,6 +352,25 @@ Background& bg() {
     return *b;
 }
 std::atomic<bool> g_bg_cancel{false};
+// A background job starts when no call holds a stream slot -- the call that queued it is usually still proving, and both the stream creation (runtime locks) and
+// the table kernels (the machine) would cost it: measured at 2^20, the second ProveWithPK took 31.9 ms beside them against 21 alone -- or after 100 ms whatever
+// is running (a process that proves back to back still gets its tables).
+void bg_yield_to_calls_in_flight() {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        if (g_bg_cancel.load()) return;
+        bool busy = false;
+        const int n = n_entries();
+        for (int e = 0; e < n && !busy; e++) {
+            Ctx* c = g_entries[e];
+            if (!c || !c->ready) continue;
+            std::lock_guard<std::mutex> lk(c->mu);
+            for (int i = 0; i < Ctx::NSLOTS; i++) busy = busy || c->slots[i].busy;
+        }
+        if (!busy || std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) return;
+        std::this_thread::sleep_for(std::chrono::microseconds(300));
+    }
+}
 void bg_loop() {
     Background& b = bg();
     std::unique_lock<std::mutex> lk(b.mu);
@@ -362,6 +381,7 @@ void bg_loop() {
         b.q.pop_front();
         b.running++;
         lk.unlock();
+        bg_yield_to_calls_in_flight();
         job();
         lk.lock();
         b.running--;
@@ -581,9 +601,10 @@ int h2d_big(void* dst, const void* src, size_t bytes, hipStream_t st) {
     const size_t npieces = (bytes + PIECE - 1) / PIECE;
     hipError_t err[T] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
     int scope_rc[T] = {ZK_OK, ZK_OK, ZK_OK, ZK_OK};
+    std::string scope_msg[T];
     auto work = [&](int t) {
         CtxScope sc(entry);
-        if (sc.rc != ZK_OK) { scope_rc[t] = sc.rc; return; }
+        if (sc.rc != ZK_OK) { scope_rc[t] = sc.rc; scope_msg[t] = g_err; return; }  // (g_err is thread-local: the text travels with the code)
         for (size_t p = (size_t)t; p < npieces; p += T) {
             if (R.in_flight[t] && (err[t] = hipEventSynchronize(R.ev[t])) != hipSuccess) return;  // this buffer's previous piece has left
             const size_t from = p * PIECE, len = from + PIECE <= bytes ? PIECE : bytes - from;
@@ -606,7 +627,7 @@ int h2d_big(void* dst, const void* src, size_t bytes, hipStream_t st) {
         prof_host("export.h2d_ring_copy", ms(t_ring, t_out));
     }
     for (int t = 0; t < T; t++) {
-        if (scope_rc[t] != ZK_OK) return scope_rc[t];
+        if (scope_rc[t] != ZK_OK) return set_err(scope_rc[t], "staged upload: %s", scope_msg[t].c_str());  // the worker's message, on the CALLER's thread
         if (err[t] != hipSuccess) return set_err(ZK_ERR_HIP, "staged upload: %s", hipGetErrorString(err[t]));
     }
     return ZK_OK;

@@ -685,95 +685,6 @@ __device__ __forceinline__ void xyzz_madd29(Acc29G2& A, const Fp2& px, const Fp2
     A.y = Y3;
 }
 
-// ---- the same mixed addition with ZZ and ZZZ of the accumulator held in LDS (36 words per lane, word-major: lds[w * 256 + lane] -- consecutive lanes read
-// consecutive banks): the two coordinates are operands of ONE product each (U2 = x2 ZZ, S2 = y2 ZZZ) and of their own update, so they need registers only
-// around those four products instead of through the whole routine.  Purpose: k_accumulate<G2> under 170 VGPRs = three waves per SIMD instead of two.
-// Same operation order, bias multiples and products as xyzz_madd29(Acc29G2&) above: the results are the same words.
-struct Acc29G2L {
-    U29x2 x, y;  // zz, zzz: in LDS
-    bool inf;
-};
-__device__ __forceinline__ U29 u29_lds_load(const uint32_t* lane, int slot) {
-    U29 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = lane[(slot * 9 + i) * 256];
-    return r;
-}
-__device__ __forceinline__ void u29_lds_store(uint32_t* lane, int slot, const U29& v) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) lane[(slot * 9 + i) * 256] = v.l[i];
-}
-__device__ __forceinline__ U29x2 f2_lds_load(const uint32_t* lane, int pair) { return U29x2{u29_lds_load(lane, 2 * pair), u29_lds_load(lane, 2 * pair + 1)}; }
-__device__ __forceinline__ void f2_lds_store(uint32_t* lane, int pair, const U29x2& v) { u29_lds_store(lane, 2 * pair, v.c0); u29_lds_store(lane, 2 * pair + 1, v.c1); }
-__device__ __forceinline__ XYZZ<Fp2> acc29g2l_to_xyzz(const Acc29G2L& A, const uint32_t* lane) {
-    if (A.inf) return XYZZ<Fp2>::inf();
-    return XYZZ<Fp2>{f2_store29(A.x), f2_store29(A.y), f2_store29(f2_lds_load(lane, 0)), f2_store29(f2_lds_load(lane, 1))};
-}
-__device__ __noinline__ void xyzz_madd29_lds_cold(Acc29G2L& A, uint32_t* lane, const Fp2& px, const Fp2& py) {
-    XYZZ<Fp2> c = acc29g2l_to_xyzz(A, lane);
-    c.madd(px, py);
-    Acc29G2 B;
-    acc29g2_from_xyzz(B, c);
-    A.x = B.x; A.y = B.y; A.inf = B.inf;
-    f2_lds_store(lane, 0, B.zz);
-    f2_lds_store(lane, 1, B.zzz);
-}
-__device__ __forceinline__ void xyzz_madd29_lds(Acc29G2L& A, uint32_t* lane, const Fp2& px, const Fp2& py) {
-    if (px.is_zero() && py.is_zero()) return;
-    if (A.inf) {
-        A.x = f2_contract29(f2_load29(px));
-        A.y = f2_contract29(f2_load29(py));
-        U29 z;
-#pragma unroll
-        for (int i = 0; i < 9; i++) z.l[i] = 0;
-        const U29x2 one{u29_one(), z};
-        f2_lds_store(lane, 0, one);
-        f2_lds_store(lane, 1, one);
-        A.inf = false;
-        return;
-    }
-    U29x2 P, R;
-    {
-        const U29x2 x2 = f2_load29(px);
-        P = f2_sub29<4>(f2_mulF29(x2, f2_lds_load(lane, 0), u29_neg<40>(x2.c1)), A.x);
-    }
-    {
-        const U29x2 y2 = f2_load29(py);
-        R = f2_sub29<4>(f2_mulF29(y2, f2_lds_load(lane, 1), u29_neg<40>(y2.c1)), A.y);
-    }
-    U29x2 PP;
-    PP.c0 = u29_mul(u29_add(P.c0, P.c1), u29_wnorm(u29_sub<8>(P.c0, P.c1)));
-    PP.c1 = u29_mul(u29_add(P.c0, P.c0), P.c1);
-    if (u29_mulout3_is_zero(PP.c1)) {  // (see xyzz_madd29: the canonical saturated path whenever the filter fires; out of line -- its registers are not the loop's)
-        xyzz_madd29_lds_cold(A, lane, px, py);
-        return;
-    }
-    {   // ZZ' = ZZ PP first: PP's last use but one, and ZZ leaves the registers again
-        const U29x2 zz = f2_lds_load(lane, 0);
-        f2_lds_store(lane, 0, f2_mulF29(zz, PP, u29_neg<8>(zz.c1)));
-    }
-    const U29x2 PPP = f2_mulF29(P, PP, u29_neg<8>(P.c1));
-    {
-        const U29x2 zzz = f2_lds_load(lane, 1);
-        f2_lds_store(lane, 1, f2_mulF29(zzz, PPP, u29_neg<8>(zzz.c1)));
-    }
-    const U29x2 Q = f2_mulF29(A.x, PP, u29_neg<8>(A.x.c1));
-    U29x2 X3;
-    {
-        const U29 W0 = u29_wnorm(u29_add(P.c0, u29_add(A.x.c0, A.x.c0))), W1 = u29_wnorm(u29_add(P.c1, u29_add(A.x.c1, A.x.c1)));
-        const U29 nW0 = u29_neg<12>(W0), nW1 = u29_neg<12>(W1);
-        X3.c0 = u29_mul3(u29_add(R.c0, R.c1), u29_wnorm(u29_sub<8>(R.c0, R.c1)), nW0, PP.c0, W1, PP.c1);
-        X3.c1 = u29_mul3(u29_add(R.c0, R.c0), R.c1, nW0, PP.c1, nW1, PP.c0);
-    }
-    const U29x2 d = f2_sub29<4>(Q, X3);
-    const U29 nR1 = u29_neg<8>(R.c1), nY0 = u29_neg<8>(A.y.c0), nY1 = u29_neg<8>(A.y.c1);
-    U29x2 Y3;
-    Y3.c0 = u29_mul4(R.c0, d.c0, nR1, d.c1, nY0, PPP.c0, A.y.c1, PPP.c1);
-    Y3.c1 = u29_mul4(R.c0, d.c1, R.c1, d.c0, nY0, PPP.c1, nY1, PPP.c0);
-    A.x = X3;
-    A.y = Y3;
-}
-
 // ---- XYZZ + XYZZ and doubling for the bucket-reduction tail (G2), fused multi-product form: every output coordinate is a direct
 // product output.  Class invariant proven by tools/u29_model.py (check_add_dbl_class_g2, exact_check_add_dbl_g2): with both
 // components of every input coordinate < 32 p and weakly normalised, every output component is again < 32 p (add: <= 20.4 p,

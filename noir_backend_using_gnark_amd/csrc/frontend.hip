@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "acir_host.hpp"  // the text side (host only, sanitizer- and mutation-tested on the CPU: tests/cpp/parser_fuzz.cpp)
+#include <atomic>
 #include "text_host.hpp"
 #include "ctx.hpp"
 #include "ff.hpp"
@@ -64,6 +65,7 @@ static int circuit_of(const Gates& G, zk_plonk_circuit* c) {
 }
 
 // wall-clock sections of the export path, reported beside the kernels when profiling is on (zk_profile_*; bench.py's `export_path` block)
+int felts_decode_hex_on_slot(Slot* s, hipStream_t st, const void* d_text, size_t text_len, void* d_out, size_t cap, size_t n, int to_mont, int* d_status);  // wire.hip
 struct Phase {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char* name) {
@@ -126,10 +128,12 @@ static size_t cache_cap_bytes() {
     return cap_gb << 30;
 }
 // drops least-recently-used entries until `extra` more bytes fit (entries in use stay); keys first (1 GB each at 2^19 gates), then circuits
+static size_t g16_cache_bytes_locked();  // the Groth16 entries (further down): both caches count against the ONE bound
+static size_t plonk_cache_bytes_locked();
 static void cache_trim_locked(size_t extra, std::vector<uint64_t>* to_free) {
     const size_t cap = cache_cap_bytes();
     auto total = [&]() {
-        size_t t = extra;
+        size_t t = extra + g16_cache_bytes_locked();
         for (auto& k : g_keys) t += k.bytes;
         for (auto& l : g_lowered) t += l->bytes();
         return t;
@@ -626,7 +630,10 @@ struct RawCircuit {
     char* d_text = nullptr;  // 8 bytes past a 16-byte boundary: the felts start aligned (wire.hip)
     void *d_vals = nullptr, *d_w = nullptr, *d_abc = nullptr;
     size_t dev_bytes() const { return n_values * (4 + 64 + 32) + n_products * 8 + n_wires * 32 + n_constraints * (96 + 3 * 4 + 200); }
-    size_t bytes() const { return public_order.size() * 4 + (host ? dev_bytes() / 2 : 0) + (r1cs ? dev_bytes() : 0); }
+    // what the accounting reads (any thread, under g_cache_mu) while device_buffers() (under `work` only) swaps the host form for the device form: two flags,
+    // the device's set BEFORE the host's is cleared, instead of the unique_ptr and the handle themselves
+    std::atomic<bool> has_host{true}, has_dev{false};
+    size_t bytes() const { return public_order.size() * 4 + (has_host.load() ? dev_bytes() / 2 : 0) + (has_dev.load() ? dev_bytes() : 0); }
     ~RawCircuit() {
         for (void* q : {(void*)d_order, (void*)d_pa, (void*)d_pb, (void*)d_text, d_vals, d_w, d_abc})
             if (q) (void)hipFree(q);
@@ -666,6 +673,8 @@ struct RawCircuit {
             return rc;
         }
         r1cs = h;
+        has_dev.store(true);
+        has_host.store(false);
         // the host form (0.3 GB at 2^20 constraints) is given back to the system on a thread of its own: 25 ms this call need not wait for
         std::thread([form = host.release()] { delete form; }).detach();
         return ZK_OK;
@@ -689,9 +698,17 @@ static size_t g16_cache_bytes_locked() {
     for (auto& c : g_raw) t += c->bytes();
     return t;
 }
-// room for `extra` more bytes among the Groth16 entries (idle ones, least recently used first); PLONK's entries are trimmed by their own rule
+static size_t plonk_cache_bytes_locked() {
+    size_t t = 0;
+    for (auto& k : g_keys) t += k.bytes;
+    for (auto& l : g_lowered) t += l->bytes();
+    return t;
+}
+// room for `extra` more bytes among the Groth16 entries (idle ones, least recently used first).  PLONK's entries are trimmed by their own rule, but their bytes
+// count here as these count there: the two caches together stay within the one documented bound (ZKMI_TABLE_CAP_GB)
 static void g16_trim_locked(size_t extra, std::vector<uint64_t>* dead_keys) {
     const size_t cap = cache_cap_bytes();
+    extra += plonk_cache_bytes_locked();
     for (auto it = g_g16_keys.end(); it != g_g16_keys.begin() && (g16_cache_bytes_locked() + extra > cap || g_g16_keys.size() >= 8);) {
         --it;
         if (it->in_use) continue;
@@ -808,7 +825,8 @@ static int raw_wires_on_device(RawCircuit& C, const char* values, size_t values_
     char* d_text = C.d_text + 8;
     ZK_HIP(hipMemcpyAsync(d_text, values, values_len, hipMemcpyHostToDevice, st));
     ph.lap("export.values_upload");
-    ZK_TRY(zk_bn254_felts_decode_hex_dev(d_text, values_len, C.d_vals, C.n_values, C.n_values, 1, st));  // synchronises; ZK_ERR_ARG on a non-hex or non-canonical felt
+    // on the slot this call holds (no second one); the status word: the 4 bytes in front of the text's padding.  Synchronises; ZK_ERR_ARG on a non-hex or non-canonical felt
+    ZK_TRY(felts_decode_hex_on_slot(g.s, st, d_text, values_len, C.d_vals, C.n_values, C.n_values, 1, (int*)C.d_text));
     ph.lap("export.values_decode");
     Fr one;
     {

@@ -648,32 +648,9 @@ __global__ ZK_ACC_BOUNDS void k_accumulate(AccBatch batch, const uint32_t* __res
     uint32_t begin = task_begin[t];
     acc_task<F>(pts, partial, vals, skip_below, t, begin, begin + (L - key));
 }
-// G2 with ZZ / ZZZ of the accumulator in LDS (ff29.hpp xyzz_madd29_lds): 36 KB per workgroup -> four workgroups per CU by LDS, three by registers (<= 170)
-__global__ __launch_bounds__(256, 3) void k_accumulate_g2_lds(AccBatch batch, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ task_begin,
-                                                             const uint32_t* __restrict__ len_key_sorted, const uint32_t* __restrict__ task_sorted, uint32_t L,
-                                                             uint32_t max_tasks) {
-    __shared__ uint32_t zlds[36 * 256];
-    const Affine<Fp2>* __restrict__ pts = (const Affine<Fp2>*)batch.pts[blockIdx.y];
-    XYZZ<Fp2>* __restrict__ partial = (XYZZ<Fp2>*)batch.partial[blockIdx.y];
-    const uint32_t skip_below = batch.skip_below[blockIdx.y];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= max_tasks) return;
-    uint32_t key = len_key_sorted[i];
-    if (key == 0xffffffffu) return;
-    const uint32_t t = task_sorted[i];
-    const uint32_t begin = task_begin[t], end = begin + (L - key);
-    uint32_t* lane = zlds + threadIdx.x;
-    Acc29G2L acc;
-    acc.inf = true;
-    for (uint32_t j = begin; j < end; j++) {
-        uint32_t v = vals[j];
-        if ((v >> 1) < skip_below) continue;
-        Affine<Fp2> p = gload(pts + (v >> 1));
-        if (v & 1) p.y = p.y.neg();
-        xyzz_madd29_lds(acc, lane, p.x, p.y);
-    }
-    gstore(partial + t, acc29g2l_to_xyzz(acc, lane));
-}
+#ifdef ZKMI_EXPERIMENTS  // G2 accumulate with ZZ / ZZZ in LDS, three waves per SIMD (round 6: 6 % slower at 2^20, 5 % at 2^24, 3 % witness-like -- DESIGN.md 8)
+#include "experiments/msm_accumulate_g2_lds.inc"
+#endif
 #ifdef ZKMI_EXPERIMENTS  // accumulate from a resident grid with a chunk counter (round 3: 3-7 % slower)
 #include "experiments/msm_accumulate_resident.inc"
 #endif
@@ -1291,6 +1268,7 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
             attr_done |= (uint64_t)1 << current_entry();
         }
     }
+#ifdef ZKMI_EXPERIMENTS
     if constexpr (sizeof(F) == sizeof(Fp2)) {
         static const bool g2_lds = ZK_EXP("ZKMI_G2_LDS", 0) != 0;  // experiment (round 6): ZZ / ZZZ of the G2 accumulator in LDS, three waves per SIMD
         if (g2_lds && !launched) {
@@ -1298,6 +1276,7 @@ static int msm_accumulate_batch(int nb, Slot* const* sl, const hipStream_t* sts,
             launched = true;
         }
     }
+#endif
     if (!launched) ZK_LAUNCH(sl[0], sa, acc_name, (k_accumulate<F>), dim3(full_grid, (unsigned)nb), dim3(256), acc_shmem, batch, R.vals, R.task_begin, R.lkeys, R.tids, L, (uint32_t)max_tasks);
     if (T) {
         hipEvent_t& e = T->ring[T->next];

@@ -113,25 +113,37 @@ extern "C" {
 // d_text: device copy of the WHOLE hex string (count header included), 16-byte aligned + 8 (i.e. the felts start 16-byte aligned) is
 // not required: the kernel reads from d_text + 8, so d_text must be 8 bytes past a 16-byte boundary -- zk_bn254_felts_decode_hex
 // stages the text that way.
+}  // extern "C"
+namespace zkmi { int felts_decode_hex_on_slot(Slot* s, hipStream_t st, const void* d_text, size_t text_len, void* d_out, size_t cap, size_t n, int to_mont, int* d_status); }
+extern "C" {
 int zk_bn254_felts_decode_hex_dev(const void* d_text, size_t text_len, void* d_out, size_t cap, size_t n, int to_mont, void* stream) {
     if (!d_text || (n && !d_out)) return set_err(ZK_ERR_ARG, "null pointer");
+    if (!n && text_len == 8) return ZK_OK;
+    SlotGuard g;
+    ZK_TRY(acquire_slot(&g.s));
+    ZK_TRY(g.s->reserve(256));
+    return felts_decode_hex_on_slot(g.s, stream ? (hipStream_t)stream : g.s->stream, d_text, text_len, d_out, cap, n, to_mont, (int*)g.s->alloc(64));
+}
+}  // extern "C"
+namespace zkmi {
+// The same for a caller that already HOLDS a stream slot (the export path's wire assembly): no second slot is taken -- eight concurrent callers that each held
+// one slot and waited for another would wait for ever -- and nothing of the slot's arena is touched: the status word is the caller's (4 bytes in HBM).
+int felts_decode_hex_on_slot(Slot* s, hipStream_t st, const void* d_text, size_t text_len, void* d_out, size_t cap, size_t n, int to_mont, int* d_status) {
+    if (!d_text || (n && !d_out) || !d_status) return set_err(ZK_ERR_ARG, "null pointer");
     if (text_len != 8 + 64 * n) return set_err(ZK_ERR_LEN, "felt vector: %zu characters, the count says %zu felts (%zu characters)", text_len, n, 8 + 64 * n);
     if (n > cap) return set_err(ZK_ERR_ARG, "felt vector of %zu felts does not fit %zu", n, cap);
     if ((((uintptr_t)d_text) + 8) & 15) return set_err(ZK_ERR_ARG, "hex text must start 8 bytes before a 16-byte boundary");
     if (!n) return ZK_OK;
-    SlotGuard g;
-    ZK_TRY(acquire_slot(&g.s));
-    hipStream_t st = stream ? (hipStream_t)stream : g.s->stream;
-    ZK_TRY(g.s->reserve(256));
-    int* d_status = (int*)g.s->alloc(64);
     ZK_HIP(hipMemsetAsync(d_status, 0, 4, st));
-    ZK_LAUNCH(g.s, st, "felts_decode_hex", k_felts_decode_hex, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    ZK_LAUNCH(s, st, "felts_decode_hex", k_felts_decode_hex, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
               reinterpret_cast<const uint4*>((const char*)d_text + 8), n, to_mont, (Fr*)d_out, d_status);
     int h_status = 0;
     ZK_HIP(hipMemcpyAsync(&h_status, d_status, 4, hipMemcpyDeviceToHost, st));
-    ZK_TRY(slot_sync(g.s, st));
+    ZK_TRY(slot_sync(s, st));
     return status_to_rc(h_status);
 }
+}  // namespace zkmi
+extern "C" {
 
 // DeserializeFelts: hex string on the host -> Montgomery fr.Element vector in HBM (d_out, capacity cap); *n_out = count.
 int zk_bn254_felts_decode_hex(const char* hex, size_t hex_len, void* d_out, size_t cap, size_t* n_out) {
