@@ -90,6 +90,11 @@ int zk_warm_session_streams_background(void);
 /* 1 when no background job (window tables of a key or SRS that proves again, zk_warm_session_streams_background) is queued or running; waits up to timeout_ms
  * for that (< 0: as long as it takes), 0 on timeout.  For callers that want the tables in place before they measure or compare; the provers never wait. */
 int zk_background_wait(int timeout_ms);
+/* Background jobs start when no call is in flight: zk_background_hold(+1) / (-1) brackets a call of several phases (the export shim does it around every
+ * export; the library's export entry points do it themselves); a job waits for the count to reach zero and the stream slots to be free, at most
+ * zk_background_set_yield_ms (default 250, 0 = start at once; [0, 60000]).  Neither changes a result. */
+void zk_background_hold(int delta);
+int zk_background_set_yield_ms(int ms);
 /* Process-wide start-up choices; call before anything that touches a device.  ZK_INIT_LEAN_STREAMS: a device entry creates only the five streams every caller
  * needs with itself and every other stream on first use (the default also creates the five high-priority streams of a Groth16 proof session up front: 40 ms more
  * start-up, 1 % less per 2^20 proof -- WHICH streams share a hardware queue follows creation order).  For a process that makes one proof and exits. */

@@ -88,7 +88,7 @@ SYMBOLS = [
     "zk_init_devices", "zk_warm_streams", "zk_init_flags", "zk_bn254_kzg_srs_g2", "zk_device_entries", "zk_set_entry", "zk_set_default_devices", "zk_default_devices", "zk_bn254_ntt_devices",
     "zk_acir_public_witnesses", "zk_acir_lower_resident", "zk_export_cache_info", "zk_export_cache_clear", "zk_bn254_plonk_pk_bytes",
     "zk_groth16_lower_resident", "zk_groth16_key_resident", "zk_groth16_public_inputs", "zk_bn254_groth16_pk_build_tables", "zk_bn254_groth16_pk_bytes",
-    "zk_export_set_new_srs_size", "zk_export_new_srs_size", "zk_warm_session_streams", "zk_warm_session_streams_background", "zk_background_wait", "zk_bn254_bases_build_table_background",
+    "zk_export_set_new_srs_size", "zk_export_new_srs_size", "zk_warm_session_streams", "zk_warm_session_streams_background", "zk_background_wait", "zk_background_hold", "zk_background_set_yield_ms", "zk_bn254_bases_build_table_background",
 ]
 
 _lib = None

@@ -1175,9 +1175,9 @@ static inline int raw_r1cs_build(const char* json, size_t len, RawR1CSBuilt* B, 
 // values count as public inputs -- a text stands for).  Round 6: the home-made multiply-rotate mixer is gone; the key is a tree of SipHash-2-4 with 128-bit
 // output (Aumasson & Bernstein, "SipHash: a fast short-input PRF", 2012 -- the reference implementation's outlen = 16 variant, checked below against the
 // paper's test vector), keyed PER PROCESS from the OS generator (content keys never leave the process and are never compared across processes):
-//     leaf    = SipHash-2-4-128_K (16 KB of text)                       four leaves of a 64 KB segment run interleaved in one loop (the rounds of one
-//                                                                        state are a serial chain; four independent states fill the core)
-//     record  = the segment's four leaf digests (a short last segment: one leaf over what is left, the other three zero)
+//     leaf    = SipHash-2-4-128_K (8 KB of text)                        the eight leaves of a 64 KB segment run interleaved in one loop (the rounds of one
+//                                                                        state are a serial chain; eight independent states -- AVX2 lanes -- fill the core)
+//     record  = the segment's eight leaf digests (a short last segment: one leaf over what is left, the other seven zero)
 //     key     = SipHash-2-4-128_K' (record_0 | record_1 | ... | n)      K' = K with k1 complemented: leaves and root are different functions
 // Guarantee: two different texts get the same key only through a collision of SipHash-2-4-128 under a key the caller does not know -- the PRF / MAC property the
 // function was designed and analysed for (forgery probability ~2^-128 per attempt), not a property of an ad-hoc mixer.  Segments are hashed on up to 16
@@ -1253,22 +1253,85 @@ static inline void siphash24_128_x4(const uint8_t* const p[4], size_t n, SipKey 
         out[j][1] = v0[j] ^ v1[j] ^ v2[j] ^ v3[j];
     }
 }
-// the paper's test vector (appendix A: key 00 .. 0f, message 00 .. 0e -> a129ca6149be45e5) and the interleaved form against the plain one; zk_selftest_host calls it
+// The same eight at a time with AVX2 (four 64-bit lanes per register, two register sets interleaved): what the hashing threads run on x86-64 hosts that have
+// it (every EPYC the GPU boxes use); one scalar state costs ~3 cycles per byte, this ~0.4, and sixteen threads are then fed by memory, not by arithmetic.
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define ZK_SIP_AVX2 1
+__attribute__((target("avx2"))) static inline __m256i sip_rotl_v(__m256i x, int b) { return _mm256_or_si256(_mm256_slli_epi64(x, b), _mm256_srli_epi64(x, 64 - b)); }
+#define ZK_SIPROUND_V(v0, v1, v2, v3)                                                                                                         \
+    do {                                                                                                                                      \
+        v0 = _mm256_add_epi64(v0, v1); v1 = sip_rotl_v(v1, 13); v1 = _mm256_xor_si256(v1, v0); v0 = _mm256_shuffle_epi32(v0, 0xb1);           \
+        v2 = _mm256_add_epi64(v2, v3); v3 = sip_rotl_v(v3, 16); v3 = _mm256_xor_si256(v3, v2);                                                \
+        v0 = _mm256_add_epi64(v0, v3); v3 = sip_rotl_v(v3, 21); v3 = _mm256_xor_si256(v3, v0);                                                \
+        v2 = _mm256_add_epi64(v2, v1); v1 = sip_rotl_v(v1, 17); v1 = _mm256_xor_si256(v1, v2); v2 = _mm256_shuffle_epi32(v2, 0xb1);           \
+    } while (0)
+__attribute__((target("avx2"))) static inline void siphash24_128_x8_avx2(const uint8_t* const p[8], size_t n, SipKey k, uint64_t out[8][2]) {
+    const __m256i k0 = _mm256_set1_epi64x((long long)k.k0), k1 = _mm256_set1_epi64x((long long)k.k1);
+    __m256i a0 = _mm256_xor_si256(_mm256_set1_epi64x(0x736f6d6570736575LL), k0), a1 = _mm256_xor_si256(_mm256_set1_epi64x(0x646f72616e646f6dLL ^ 0xee), k1);
+    __m256i a2 = _mm256_xor_si256(_mm256_set1_epi64x(0x6c7967656e657261LL), k0), a3 = _mm256_xor_si256(_mm256_set1_epi64x(0x7465646279746573LL), k1);
+    __m256i b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+    for (size_t i = 0; i < n; i += 8) {
+        const __m256i ma = _mm256_set_epi64x((long long)sip_le64(p[3] + i), (long long)sip_le64(p[2] + i), (long long)sip_le64(p[1] + i), (long long)sip_le64(p[0] + i));
+        const __m256i mb = _mm256_set_epi64x((long long)sip_le64(p[7] + i), (long long)sip_le64(p[6] + i), (long long)sip_le64(p[5] + i), (long long)sip_le64(p[4] + i));
+        a3 = _mm256_xor_si256(a3, ma); b3 = _mm256_xor_si256(b3, mb);
+        ZK_SIPROUND_V(a0, a1, a2, a3); ZK_SIPROUND_V(b0, b1, b2, b3);
+        ZK_SIPROUND_V(a0, a1, a2, a3); ZK_SIPROUND_V(b0, b1, b2, b3);
+        a0 = _mm256_xor_si256(a0, ma); b0 = _mm256_xor_si256(b0, mb);
+    }
+    const __m256i bl = _mm256_set1_epi64x((long long)((uint64_t)n << 56)), ee = _mm256_set1_epi64x(0xee), dd = _mm256_set1_epi64x(0xdd);
+    __m256i* st[2][4] = {{&a0, &a1, &a2, &a3}, {&b0, &b1, &b2, &b3}};
+    for (int h = 0; h < 2; h++) {
+        __m256i v0 = *st[h][0], v1 = *st[h][1], v2 = *st[h][2], v3 = *st[h][3];
+        v3 = _mm256_xor_si256(v3, bl);
+        ZK_SIPROUND_V(v0, v1, v2, v3); ZK_SIPROUND_V(v0, v1, v2, v3);
+        v0 = _mm256_xor_si256(v0, bl);
+        v2 = _mm256_xor_si256(v2, ee);
+        for (int i = 0; i < 4; i++) ZK_SIPROUND_V(v0, v1, v2, v3);
+        alignas(32) uint64_t r0[4], r1[4];
+        _mm256_store_si256((__m256i*)r0, _mm256_xor_si256(_mm256_xor_si256(v0, v1), _mm256_xor_si256(v2, v3)));
+        v1 = _mm256_xor_si256(v1, dd);
+        for (int i = 0; i < 4; i++) ZK_SIPROUND_V(v0, v1, v2, v3);
+        _mm256_store_si256((__m256i*)r1, _mm256_xor_si256(_mm256_xor_si256(v0, v1), _mm256_xor_si256(v2, v3)));
+        for (int j = 0; j < 4; j++) { out[4 * h + j][0] = r0[j]; out[4 * h + j][1] = r1[j]; }
+    }
+}
+#endif
+static inline bool& sip_scalar_only() { static bool v = false; return v; }  // tooling (tools/content_key_bench.cpp): time the scalar form on a CPU that has AVX2
+// eight SipHash-2-4-128 of eight inputs of the same length (a multiple of 8): the vector form where the CPU has it, the scalar interleave otherwise -- the same values
+static inline void siphash24_128_x8(const uint8_t* const p[8], size_t n, SipKey k, uint64_t out[8][2]) {
+#ifdef ZK_SIP_AVX2
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && !sip_scalar_only()) { siphash24_128_x8_avx2(p, n, k, out); return; }
+#endif
+    siphash24_128_x4(p, n, k, out);
+    siphash24_128_x4(p + 4, n, k, out + 4);
+}
+// the paper's test vector (appendix A: key 00 .. 0f, message 00 .. 0e -> a129ca6149be45e5), the reference implementation's first two 128-bit vectors, and both
+// interleaved forms against the plain one; zk_selftest_host calls it
 static inline bool siphash_selftest() {
-    uint8_t key[16], msg[64 * 8];
+    uint8_t key[16], msg[8 * 136];
     for (int i = 0; i < 16; i++) key[i] = (uint8_t)i;
-    for (size_t i = 0; i < sizeof msg; i++) msg[i] = (uint8_t)i;
+    for (size_t i = 0; i < sizeof msg; i++) msg[i] = (uint8_t)(i * 7 + (i >> 8));
+    for (int i = 0; i < 15; i++) msg[i] = (uint8_t)i;
     SipKey k{sip_le64(key), sip_le64(key + 8)};
     if (siphash24(msg, 15, k, nullptr) != 0xa129ca6149be45e5ULL) return false;
-    const uint8_t* p[4] = {msg, msg + 128, msg + 256, msg + 384};
-    uint64_t x4[4][2], one[2];
-    siphash24_128_x4(p, 128, k, x4);
-    for (int j = 0; j < 4; j++) {
-        siphash24(p[j], 128, k, one);
-        if (one[0] != x4[j][0] || one[1] != x4[j][1]) return false;
+    uint64_t one[2];
+    siphash24(msg, 0, k, one);
+    if (one[0] != 0xe6a825ba047f81a3ULL || one[1] != 0x930255c71472f66dULL) return false;  // a3817f04ba25a8e6 6df67214c7550293 (vectors_sip128[0])
+    siphash24(msg, 1, k, one);
+    if (one[0] != 0x44af996bd8c187daULL || one[1] != 0x45fc229b11597634ULL) return false;  // da87c1d86b99af44 347659119b22fc45 (vectors_sip128[1])
+    const uint8_t* p[8];
+    for (int j = 0; j < 8; j++) p[j] = msg + 136 * j;
+    uint64_t x8[8][2], x4[8][2];
+    siphash24_128_x8(p, 136, k, x8);
+    siphash24_128_x4(p, 136, k, x4);
+    siphash24_128_x4(p + 4, 136, k, x4 + 4);
+    for (int j = 0; j < 8; j++) {
+        siphash24(p[j], 136, k, one);
+        if (one[0] != x8[j][0] || one[1] != x8[j][1] || one[0] != x4[j][0] || one[1] != x4[j][1]) return false;
     }
-    siphash24(msg, 15, k, one);  // 128-bit variant differs from the 64-bit one and its halves from each other
-    return one[0] != 0xa129ca6149be45e5ULL && one[0] != one[1];
+    return true;
 }
 static inline const SipKey& ck_key() {
     static const SipKey key = [] {
@@ -1288,18 +1351,19 @@ static inline const SipKey& ck_key() {
 }
 static inline ContentKey content_key(const char* p_, size_t n) {
     const uint8_t* p = (const uint8_t*)p_;
-    const size_t SEG = (size_t)1 << 16, LEAF = SEG / 4;
+    const size_t SEG = (size_t)1 << 16, LEAF = SEG / 8;
     const size_t nseg = (n + SEG - 1) / SEG;
-    std::vector<uint64_t> rec(8 * (nseg ? nseg : 1), 0);  // per segment: four leaf digests
+    std::vector<uint64_t> rec(16 * (nseg ? nseg : 1), 0);  // per segment: eight leaf digests
     const SipKey key = ck_key();
     auto run = [&](size_t lo, size_t hi) {
         for (size_t s = lo; s < hi; s++) {
             const uint8_t* q = p + s * SEG;
             const size_t len = s + 1 == nseg ? n - s * SEG : SEG;
-            uint64_t(*out)[2] = reinterpret_cast<uint64_t(*)[2]>(&rec[8 * s]);
+            uint64_t(*out)[2] = reinterpret_cast<uint64_t(*)[2]>(&rec[16 * s]);
             if (len == SEG) {
-                const uint8_t* lanes[4] = {q, q + LEAF, q + 2 * LEAF, q + 3 * LEAF};
-                siphash24_128_x4(lanes, LEAF, key, out);
+                const uint8_t* lanes[8];
+                for (int j = 0; j < 8; j++) lanes[j] = q + j * LEAF;
+                siphash24_128_x8(lanes, LEAF, key, out);
             } else {
                 siphash24(q, len, key, out[0]);  // (the length is part of SipHash's last block and of the root's input: a short leaf cannot pass for a full one)
             }

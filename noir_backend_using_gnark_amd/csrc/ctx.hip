@@ -352,14 +352,18 @@ Background& bg() {
     return *b;
 }
 std::atomic<bool> g_bg_cancel{false};
-// A background job starts when no call holds a stream slot -- the call that queued it is usually still proving, and both the stream creation (runtime locks) and
-// the table kernels (the machine) would cost it: measured at 2^20, the second ProveWithPK took 31.9 ms beside them against 21 alone -- or after 100 ms whatever
-// is running (a process that proves back to back still gets its tables).
+// A background job starts when no call is in flight -- no export holds the library (zk_background_hold) and no stream slot is taken -- or after g_bg_yield_ms
+// whatever is running (a process that proves back to back still gets its tables).  The call that queued the job is usually still proving, and both the stream
+// creation (runtime locks, host CPUs: the GPU boxes give a process 16) and the table kernels (the machine) would cost it: at 2^20 the second ProveWithPK took
+// 31.9 ms beside them against 21 alone.
+std::atomic<int> g_bg_holds{0};
+std::atomic<int> g_bg_yield_ms{250};
 void bg_yield_to_calls_in_flight() {
     const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
+    const auto cap = std::chrono::milliseconds(g_bg_yield_ms.load());
+    for (int quiet = 0;;) {
         if (g_bg_cancel.load()) return;
-        bool busy = false;
+        bool busy = g_bg_holds.load() > 0;
         const int n = n_entries();
         for (int e = 0; e < n && !busy; e++) {
             Ctx* c = g_entries[e];
@@ -367,7 +371,8 @@ void bg_yield_to_calls_in_flight() {
             std::lock_guard<std::mutex> lk(c->mu);
             for (int i = 0; i < Ctx::NSLOTS; i++) busy = busy || c->slots[i].busy;
         }
-        if (!busy || std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) return;
+        quiet = busy ? 0 : quiet + 1;
+        if (quiet >= 4 || std::chrono::steady_clock::now() - t0 > cap) return;  // four looks in a row (1 ms): the gap between two phases of one call does not count
         std::this_thread::sleep_for(std::chrono::microseconds(300));
     }
 }
@@ -414,6 +419,15 @@ void bg_submit(std::function<void()> job) {
         b.q.push_back(std::move(job));
     }
     b.cv.notify_one();
+}
+// A caller that is about to make (or is inside) a call of several phases says so: +1 on entry, -1 on exit.  Background jobs wait for the count to reach zero
+// (at most zk_background_set_yield_ms, default 250 ms).  The export shim brackets every export with it; the library's own export entry points do too.
+extern "C" void zk_background_hold(int delta) { g_bg_holds.fetch_add(delta); }
+// How long a background job waits for calls in flight before it starts anyway (0: at once).  A tuning knob for long-lived servers; it changes no result.
+extern "C" int zk_background_set_yield_ms(int ms) {
+    if (ms < 0 || ms > 60000) return set_err(ZK_ERR_ARG, "yield of %d ms outside [0, 60000]", ms);
+    g_bg_yield_ms.store(ms);
+    return ZK_OK;
 }
 // 1 when no background job is queued or running (waits up to timeout_ms for that; < 0 = as long as it takes), else 0.  For callers that want the tables before
 // they measure or compare (tests, bench.py) -- the product never waits.

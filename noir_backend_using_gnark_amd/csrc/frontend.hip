@@ -66,6 +66,12 @@ static int circuit_of(const Gates& G, zk_plonk_circuit* c) {
 
 // wall-clock sections of the export path, reported beside the kernels when profiling is on (zk_profile_*; bench.py's `export_path` block)
 int felts_decode_hex_on_slot(Slot* s, hipStream_t st, const void* d_text, size_t text_len, void* d_out, size_t cap, size_t n, int to_mont, int* d_status);  // wire.hip
+struct InFlight {  // background jobs wait for calls in flight (ctx.hip)
+    InFlight() { zk_background_hold(1); }
+    ~InFlight() { zk_background_hold(-1); }
+    InFlight(const InFlight&) = delete;
+    InFlight& operator=(const InFlight&) = delete;
+};
 struct Phase {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char* name) {
@@ -344,6 +350,7 @@ extern "C" {
 // export cache under the content key of pk_hex_out, so that the zk_plonk_prove_with_pk which follows in this process neither decodes nor rebuilds it.
 int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, uint64_t srs_handle, char* pk_hex_out,
                         size_t pk_cap, size_t* pk_len, char* vk_hex_out, size_t vk_cap, size_t* vk_len, uint64_t* pk_handle) {
+    InFlight _in_flight;
     if (!acir_json || !values_hex || !pk_len || !vk_len) return set_err(ZK_ERR_ARG, "null pointer");
     ZK_ON_ENTRY_OF(srs_handle);
     size_t n_values = 0;
@@ -382,6 +389,7 @@ int zk_plonk_preprocess(const char* acir_json, size_t acir_len, const char* valu
 // blinders: 9 scalars or NULL (drawn from /dev/urandom, as upstream draws them with fr.SetRandom).
 int zk_plonk_prove_with_pk(const char* acir_json, size_t acir_len, const char* values_hex, size_t values_len, int layout, const char* pk_hex, size_t pk_len,
                            uint64_t pk_handle, uint64_t srs_handle, const zk_fr* blinders, char proof_hex_out[2 * ZK_PLONK_PROOF_BYTES]) {
+    InFlight _in_flight;
     if (!acir_json || !values_hex || !proof_hex_out || (!pk_hex && !pk_handle)) return set_err(ZK_ERR_ARG, "null pointer");
     ZK_ON_ENTRY_OF(pk_handle ? pk_handle : srs_handle);
     size_t n_values = 0;
@@ -1072,6 +1080,7 @@ int zk_groth16_public_inputs(const char* raw_json, size_t raw_len, zk_fr* out, s
 // keeps the key resident for the caller; without it the key enters the export cache under the text it was written as.
 int zk_groth16_preprocess(const char* raw_json, size_t raw_len, const zk_fr* toxic, char* pk_hex_out, size_t pk_cap, size_t* pk_len, char* vk_hex_out, size_t vk_cap,
                           size_t* vk_len, uint64_t* pk_handle) {
+    InFlight _in_flight;
     if (!raw_json || !pk_len || !vk_len) return set_err(ZK_ERR_ARG, "null pointer");
     std::shared_ptr<RawCircuit> C;
     size_t at = 0;
@@ -1133,6 +1142,7 @@ int zk_groth16_preprocess(const char* raw_json, size_t raw_len, const zk_fr* tox
 // pk_handle names a resident key (the reference deserialises the key on every call).  rs: the prover's (r, s) or NULL (/dev/urandom).
 // Both texts are found resident by content when they were seen before; a key read from its text gets its window tables when its SECOND proof is asked for.
 int zk_groth16_prove_with_pk(const char* raw_json, size_t raw_len, const char* pk_hex, size_t pk_len, uint64_t pk_handle, const zk_fr* rs, char proof_hex_out[256]) {
+    InFlight _in_flight;
     if (!raw_json || !proof_hex_out || (!pk_hex && !pk_handle)) return set_err(ZK_ERR_ARG, "null pointer");
     CtxScope _scope(pk_handle ? hentry(pk_handle) : current_entry());
     if (_scope.rc != ZK_OK) return _scope.rc;
@@ -1238,6 +1248,7 @@ int zk_groth16_prove_with_pk(const char* raw_json, size_t raw_len, const char* p
 
 // ProveWithMeta (r1cs.go:74-105): Setup and Prove in one call (the proving key never leaves HBM).
 int zk_groth16_prove_with_meta(const char* raw_json, size_t raw_len, const zk_fr* toxic, const zk_fr* rs, char proof_hex_out[256]) {
+    InFlight _in_flight;
     if (!raw_json || !proof_hex_out) return set_err(ZK_ERR_ARG, "null pointer");
     std::shared_ptr<RawCircuit> C;
     size_t at = 0;

@@ -110,6 +110,11 @@ std::vector<int> shim_devices() {
     if (devs.empty() || devs.size() > 8) { fprintf(stderr, "ZKMI_DEVICES = \"%s\": one to eight devices\n", v); exit(1); }
     return devs;
 }
+// every proving export is one "call in flight" for the library's background thread (window tables, streams): jobs queued by a call start after it (csrc/ctx.hip)
+struct InFlight {
+    InFlight() { zk_background_hold(1); }
+    ~InFlight() { zk_background_hold(-1); }
+};
 void start_devices(int warm_streams) {
     must(zk_init_flags(ZK_INIT_LEAN_STREAMS), "zk_init_flags");  // a process behind these exports typically makes ONE call: no stream it will not use
     const std::vector<int> devs = shim_devices();
@@ -311,6 +316,7 @@ void groth16_start(GoString rawR1CS, const GoString* pk) {
 extern "C" {
 
 char* PlonkProveWithPK(GoString acirJSON, GoString encodedValues, GoString encodedProvingKey) {
+    InFlight in_flight;
     uint64_t srs;
     zk_g2_affine g2[2];
     const View values = unquoted(encodedValues);
@@ -319,6 +325,7 @@ char* PlonkProveWithPK(GoString acirJSON, GoString encodedValues, GoString encod
 }
 
 KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {
+    InFlight in_flight;
     uint64_t srs;
     zk_g2_affine g2[2];
     const View values = unquoted(encodedRandomValues);
@@ -336,6 +343,7 @@ KeyPair PlonkPreprocess(GoString acirJSON, GoString encodedRandomValues) {
 }
 
 char* PlonkProveWithMeta(GoString acirJSON, GoString encodedValues) {
+    InFlight in_flight;
     uint64_t srs, h = 0;
     zk_g2_affine g2[2];
     const View values = unquoted(encodedValues);
@@ -390,18 +398,21 @@ unsigned char PlonkVerifyWithVK(GoString acirJSON, GoString encodedProof, GoStri
 
 // ---- Groth16 (backend/groth16/r1cs.go:74-266)
 char* ProveWithMeta(GoString rawR1CS) {
+    InFlight in_flight;
     groth16_start(rawR1CS, nullptr);
     std::string proof(256, '\0');
     must(zk_groth16_prove_with_meta(rawR1CS.p, (size_t)rawR1CS.n, nullptr, nullptr, &proof[0]), "ProveWithMeta");
     return c_string(proof);
 }
 char* ProveWithPK(GoString rawR1CS, GoString encodedProvingKey) {
+    InFlight in_flight;
     groth16_start(rawR1CS, &encodedProvingKey);
     std::string proof(256, '\0');
     must(zk_groth16_prove_with_pk(rawR1CS.p, (size_t)rawR1CS.n, encodedProvingKey.p, (size_t)encodedProvingKey.n, 0, nullptr, &proof[0]), "ProveWithPK");
     return c_string(proof);
 }
 KeyPair Preprocess(GoString rawR1CS) {
+    InFlight in_flight;
     groth16_start(rawR1CS, nullptr);
     size_t pk_len = 0, vk_len = 0;
     must(zk_groth16_preprocess(rawR1CS.p, (size_t)rawR1CS.n, nullptr, nullptr, 0, &pk_len, nullptr, 0, &vk_len, nullptr), "Preprocess");  // Setup runs here; the key waits

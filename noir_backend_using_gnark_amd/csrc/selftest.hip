@@ -3,6 +3,7 @@
 // implements) and the XYZZ formulas of curve.hpp are checked against the independent 64-bit-limb HField code.
 #include <string.h>
 
+#include "acir_host.hpp"
 #include "ctx.hpp"
 #include "curve.hpp"
 #include "host_ff.hpp"
@@ -40,6 +41,7 @@ using namespace zkmi;
 
 extern "C" int zk_selftest_host(void) {
     int bad = 0;
+    bad += !siphash_selftest();  // the content key's PRF against the paper's and the reference implementation's vectors (acir_host.hpp)
     uint64_t s = 0x5e1f7e57;
     for (int it = 0; it < 200; it++) {
         HFp a = rnd<HFpParams>(s), b = rnd<HFpParams>(s);

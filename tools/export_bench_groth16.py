@@ -110,6 +110,8 @@ def main():
         return
     if mode == "prove":
         warm = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+        if os.environ.get("ZKMI_TOOL_BG_YIELD_MS"):  # this tool's own variable (A/B runs): how long background jobs wait for calls in flight (zk_background_set_yield_ms)
+            assert Z.zk_background_set_yield_ms(C.c_int(int(os.environ["ZKMI_TOOL_BG_YIELD_MS"]))) == 0
         pk, vk = read(os.path.join(d, "pk.hex")), read(os.path.join(d, "vk.hex"))
         t0 = time.perf_counter()
         proof = C.string_at(G.ProveWithPK(gs(raw), gs(pk)))
