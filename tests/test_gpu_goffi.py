@@ -331,3 +331,29 @@ print(json.dumps({"bad": bad, "resident_keys": info["keys"]}))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["bad"] == [] and d["resident_keys"] == 2
+
+
+def test_a_process_may_exit_while_its_background_jobs_run(tmp_path):
+    """The second proof of a key queues its window tables and the session's streams on the background thread; a process that exits right after that call (nothing
+    waits for the build) ends with status 0 and without hanging: exit() cancels the queue, the job in flight stops at its next check, the thread is joined before
+    the HIP runtime's own exit handlers run.  Once with the default yield (the job is probably still waiting for the call) and once with none (it is running)."""
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from noir_backend_using_gnark_amd import _lib, frontend as fe
+from oracle import bn254_ref as ref
+from tests.helpers import mont_limbs
+from tools import synth_raw_r1cs as sr
+L = _lib.lib()
+assert L.zk_background_set_yield_ms(C.c_int(int(sys.argv[1]))) == 0
+raw, w = sr.synth(1 << 14, 3, seed=0x92)
+rs = mont_limbs(list(ref.rand_felts(0xE1, 2)))
+pk_hex, vk_hex = fe.groth16_preprocess(raw, mont_limbs(list(ref.rand_felts(0xE2, 5))))
+a = fe.groth16_prove_with_pk(raw, pk_hex, rs)
+b = fe.groth16_prove_with_pk(raw, pk_hex, rs)   # the key's second proof: tables and streams are queued
+assert a == b
+print("done", L.zk_background_wait(C.c_int(0)))
+""" % ROOT
+    for yield_ms in ("250", "0"):
+        out = subprocess.run([sys.executable, "-c", code, yield_ms], capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=ROOT))
+        assert out.returncode == 0 and "done" in out.stdout, (yield_ms, out.stdout[-1000:], out.stderr[-3000:])
