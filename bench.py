@@ -7,7 +7,7 @@ in HBM.  The same JSON line also carries, measured in the same run:
   * `prove_ms_host_inputs`  the proof through the entry point a cgo caller has (host slices: a, b, c, w cross PCIe inside the call),
   * `at_2p24`               the metric's other size (2^24 constraints on this one GPU: key with 84 GB of window tables), whose proof
                             bytes are checked against the recombination of two half-size slices run through the table-less path
-                            (another window width, Horner, other task sizes) -- `--verify-2p24-oracle` adds the CPU oracle's bytes.
+                            (another window width, Horner, other task sizes) AND against the CPU oracle's bytes (`at_2p24.cpu_baseline`; --no-verify-2p24-oracle skips it).
 --gpus N > 1 (one process per GPU, torchrun): ONE proof over N * 2^21 constraints, range-sharded -- N = 8 is BASELINE.json
 configs[2] (2^24 constraints).  Every rank owns one block of a, b, c, w, h and of the proving key (with its window tables); computeH
 is block-sharded (the top log2 N butterfly stages of each transform run on all-to-all-transposed data: 10 RCCL all_to_all_single
@@ -67,7 +67,8 @@ def main():
     ap.add_argument("--no-export", action="store_true", help="skip the export-path block (PlonkPreprocess -> PlonkProveWithPK -> PlonkVerifyWithVK through libgnark_backend.so at 2^19 gates)")
     ap.add_argument("--export-log-gates", type=int, default=19)
     ap.add_argument("--export-g16-log-constraints", type=int, default=20, help="size of the Groth16 export-path block (Preprocess / ProveWithPK / VerifyWithVK through libgnark_backend.so)")
-    ap.add_argument("--verify-2p24-oracle", action="store_true", help="also check the 2^24 proof bytes against the CPU oracle (~2 min on 128 cores)")
+    ap.add_argument("--verify-2p24-oracle", action="store_true", help="(default since round 6; kept for old command lines) check the 2^24 proof bytes against the CPU oracle")
+    ap.add_argument("--no-verify-2p24-oracle", action="store_true", help="skip the CPU oracle's proof of the 2^24 instance (~40 s on the 16 CPUs a GPU box gives; --no-cpu-baseline skips it too)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher around: print the torch.distributed.run command this script would start and exit")
     args = ap.parse_args()
 
@@ -351,9 +352,11 @@ def main():
         blk["roofline"] = block_roofline(prof24, reps, big.g1_units() / max(1.0, n24 / float(reps)), big.N, big.N, 24, L=L, lib=_lib, n_plan=big.N)
         if not blk["proof_bytes_match_recombination"]:
             out["parity_error"] = "2^24: single-call proof differs from the two-slice recombination"
-        if args.verify_2p24_oracle:
+        if not (args.no_verify_2p24_oracle or args.no_cpu_baseline):
             cpu_proof, cpu_s, cores = oracle_proof(big, 24)
-            blk["cpu_oracle"] = {"prove_ms": round(cpu_s * 1e3, 1), "cores": cores, "proof_bytes_match_gpu": bool(cpu_proof == p24)}
+            blk["cpu_baseline"] = {"value": round(big.g1_units() / cpu_s, 1), "unit": out["unit"], "cores": cores, "kind": "port", "prove_ms": round(cpu_s * 1e3, 1),
+                                   "sample": "1 full proof of the same 2^24 instance by oracle/bn254_oracle.c (OpenMP; plain C, no assembly -- NOT a gnark figure)",
+                                   "proof_bytes_match_gpu": bool(cpu_proof == p24)}
             if cpu_proof != p24:
                 out["parity_error"] = "2^24: GPU proof bytes differ from the CPU oracle's"
         if args.scalars == "uniform":  # the same key with a witness-like wire vector (50 % in {0, 1}, 25 % below 2^32, 25 % uniform): its zero digits never enter the sort
