@@ -315,3 +315,28 @@ def test_groth16_resident_circuit_and_public_inputs_on_the_host():
     with pytest.raises((ValueError, _lib.ZkmiError)):
         fe.groth16_lower_resident(raw[:at + 8] + "zz" + raw[at + 10:])   # nothing resident: the general reader's path
     assert L.zk_export_cache_clear() == 0 and fe.export_cache_info() == {"circuits": 0, "keys": 0, "bytes": 0}
+
+
+def test_background_facility_entry_points_need_no_device():
+    """zk_background_wait / _hold / _set_yield_ms (csrc/ctx.hip) are plain host calls: with nothing queued the library is idle at once, the yield knob is range-checked,
+    a hold is a counter -- none of them starts the HIP runtime (a process that only verifies may call them)."""
+    import ctypes as C
+    L = _lib.lib()
+    assert L.zk_background_wait(C.c_int(0)) == 1 and L.zk_background_wait(C.c_int(-1)) == 1
+    assert L.zk_background_set_yield_ms(C.c_int(-1)) != 0 and L.zk_background_set_yield_ms(C.c_int(60001)) != 0
+    assert L.zk_background_set_yield_ms(C.c_int(0)) == 0 and L.zk_background_set_yield_ms(C.c_int(250)) == 0
+    L.zk_background_hold.restype = None
+    L.zk_background_hold(C.c_int(1))
+    L.zk_background_hold(C.c_int(-1))
+    assert L.zk_device_entries(None, C.c_size_t(0)) == 0   # still no device entry
+
+
+def test_oracle_starts_no_more_threads_than_the_process_may_use():
+    from oracle import oracle as orc
+    assert 1 <= orc.max_threads() <= orc.host_cpus()
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+    except OSError:
+        return
+    if q != "max":
+        assert orc.max_threads() <= -(-int(q) // int(p))
