@@ -205,8 +205,38 @@ static void check_key_headers(const std::string& img, size_t id) {
 
 static bool ends_with(const std::string& s, const char* suf) { const size_t k = strlen(suf); return s.size() >= k && !s.compare(s.size() - k, k, suf); }
 
+// The content key (acir_host.hpp: a keyed SipHash-2-4-128 tree) under the sanitizers: the function's published vectors, and the properties the caches rely on -- equal
+// texts give equal keys; a one-byte change anywhere (first / last byte, either side of every leaf and segment boundary, the short last segment) gives another key;
+// so does a text that differs only by trailing zero bytes, or by its length alone; a text cut at a boundary is not a prefix collision of the longer one.
+static void content_key_checks() {
+    if (!zkmi::siphash_selftest()) { fprintf(stderr, "SipHash self-test failed\n"); exit(1); }
+    const size_t SEG = (size_t)1 << 16, LEAF = SEG / 8;
+    for (size_t n : {(size_t)0, (size_t)1, (size_t)7, (size_t)8, LEAF - 1, LEAF, LEAF + 1, SEG - 1, SEG, SEG + 1, 3 * SEG + 5 * LEAF + 3, 70 * SEG + 17}) {  // (>= 64 segments: the threaded path)
+        std::string t(n, '\0');
+        for (size_t i = 0; i < n; i++) t[i] = (char)('a' + (i * 2654435761u >> 13) % 23);
+        const zkmi::ContentKey k0 = zkmi::content_key(t.data(), n);
+        if (!(k0 == zkmi::content_key(std::string(t).data(), n))) { fprintf(stderr, "content key: equal texts, different keys (n = %zu)\n", n); exit(1); }
+        std::vector<size_t> at = {0, n ? n - 1 : 0};
+        for (size_t b = LEAF; b < n; b += LEAF) { at.push_back(b - 1); at.push_back(b); }
+        if (at.size() > 400) at.resize(400);
+        for (size_t i : at) {
+            if (i >= n) continue;
+            std::string u = t;
+            u[i] ^= 1;
+            if (k0 == zkmi::content_key(u.data(), n)) { fprintf(stderr, "content key: byte %zu of %zu does not matter\n", i, n); exit(1); }
+        }
+        std::string z = t + std::string(1, '\0');
+        if (k0 == zkmi::content_key(z.data(), n + 1)) { fprintf(stderr, "content key: a trailing zero byte does not matter (n = %zu)\n", n); exit(1); }
+        if (n > 1) {
+            zkmi::ContentKey kp = zkmi::content_key(t.data(), n - 1);
+            if (kp.h[0] == k0.h[0] && kp.h[1] == k0.h[1]) { fprintf(stderr, "content key: a prefix shares the digest (n = %zu)\n", n); exit(1); }
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: parser_fuzz <cases> <seed file>...\n"); return 2; }
+    content_key_checks();
     const size_t cases = (size_t)strtoull(argv[1], nullptr, 10);
     std::vector<std::pair<std::string, std::string>> seeds;
     for (int i = 2; i < argc; i++) {
