@@ -188,3 +188,44 @@ def test_c_plonk_oracle_equals_python_on_a_random_circuit_and_refuses_a_bad_witn
         ck.free()
     with pytest.raises(ValueError):
         _c_key(spr, srs_np[:512 + 2])  # an SRS one point short
+
+
+def test_c_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """oracle/build/libbn254_oracle_asan.so (-fsanitize=address,undefined; the GPU side has no sanitizer on this pool, the checker does): PLONK Setup + Prove on circuits
+    around the domain edges (sizeSystem < 6 -> 8x domain; one public input; no public input; 1,500 gates) and the transform on both sides of the size from which the cache-tiled
+    schedule runs (2^17), forward . inverse = identity in four modes -- no report."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "build/libbn254_oracle_asan.so"], stdout=subprocess.DEVNULL)
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    code = r"""
+import sys, random
+sys.path.insert(0, %r)
+from oracle import oracle as orc
+orc._SO = %r
+orc.build = lambda force=False: orc._SO
+from oracle import plonk_ref as pl, bn254_ref as ref
+R = ref.R
+rng = random.Random(7)
+for (npub, nvars, nc) in ((0, 5, 3), (1, 4, 5), (3, 60, 61), (2, 700, 1500)):
+    sol = [rng.randrange(R) for _ in range(nvars)]
+    gates = []
+    for _ in range(nc):
+        xa, xb, xc = (rng.randrange(nvars) for _ in range(3))
+        ql, qr, qo, qm = (rng.randrange(R) for _ in range(4))
+        gates.append((ql, qr, qo, qm, (-(ql * sol[xa] + qr * sol[xb] + qo * sol[xc] + qm * sol[xa] * sol[xb])) %% R, xa, xb, xc))
+    n = 1
+    while n < nc + npub: n <<= 1
+    ck = orc.PlonkKeyC(npub, nvars, *[pl.ints_to_mont_np([g[k] for g in gates]) for k in (0, 1, 3, 2, 4)], *[[g[k] for g in gates] for k in (5, 6, 7)], orc.g1_gen_points(5, n + 3))
+    assert len(ck.prove(pl.ints_to_mont_np(sol), pl.ints_to_mont_np([rng.randrange(R) for _ in range(9)]))) == 548
+    ck.free()
+for logn in (3, 12, 16, 17, 18):
+    x = orc.rand_fr(logn, 1 << logn)
+    assert (orc.fr_ntt(orc.fr_ntt(x, False, orc.DIF), True, orc.DIT) == x).all()
+    assert (orc.fr_ntt(orc.fr_ntt(x, False, orc.DIT, True), True, orc.DIF, True) == x).all()
+print("sanitized run ok")
+""" % (root, os.path.join(root, "oracle", "build", "libbn254_oracle_asan.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0 and "sanitized run ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
