@@ -340,3 +340,16 @@ def test_oracle_starts_no_more_threads_than_the_process_may_use():
         return
     if q != "max":
         assert orc.max_threads() <= -(-int(q) // int(p))
+
+
+def test_outer_boundary_header_compiles_as_c_and_the_ten_exports_link(tmp_path):
+    """include/gnark_backend.h -- the header cgo would generate for the reference's archive (main.go:24-78, backend/groth16/r1cs.go:74-266), by hand -- compiles as C,
+    has cgo's structure layout, and a C program linked against libgnark_backend.so resolves the ten names with those prototypes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "noir_backend_using_gnark_amd")
+    exe = str(tmp_path / "goexports_check")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "goexports_check.c"),
+                           "-L" + pkg, "-lgnark_backend", "-lzkmi", "-Wl,-rpath," + pkg, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ten exports resolved" in out.stdout, (out.returncode, out.stdout, out.stderr[-1000:])
